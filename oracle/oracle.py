@@ -1,0 +1,339 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes loader for oracle/liboracle.so (CPU restatement of the
+reference's hot path).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+Arrays are numpy uint64 with a trailing dimension of limbs (Fr/Fp: 4, G1 affine: 8, G2 affine: 16)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("capi.cpp", "algos.hpp", "bn254.hpp", "poseidon.hpp")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.orc_synth_create.restype = ctypes.c_void_p
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+R_MOD = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+P_MOD = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+
+
+def ints_to_limbs(vals):
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        for j in range(4):
+            out[i, j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def limbs_to_ints(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+    return [sum(int(a[i, j]) << (64 * j) for j in range(4)) for i in range(a.shape[0])]
+
+
+def fr_from_ints(vals):
+    c = ints_to_limbs([v % R_MOD for v in vals])
+    out = np.empty_like(c)
+    lib().orc_fr_from_canon(_p(c), _p(out), ctypes.c_size_t(len(vals)))
+    return out
+
+
+def fr_to_ints(a):
+    a = _u64(a).reshape(-1, 4)
+    out = np.empty_like(a)
+    lib().orc_fr_to_canon(_p(a), _p(out), ctypes.c_size_t(a.shape[0]))
+    return limbs_to_ints(out)
+
+
+def fp_from_ints(vals):
+    c = ints_to_limbs([v % P_MOD for v in vals])
+    out = np.empty_like(c)
+    lib().orc_fp_from_canon(_p(c), _p(out), ctypes.c_size_t(len(vals)))
+    return out
+
+
+def fp_to_ints(a):
+    a = _u64(a).reshape(-1, 4)
+    out = np.empty_like(a)
+    lib().orc_fp_to_canon(_p(a), _p(out), ctypes.c_size_t(a.shape[0]))
+    return limbs_to_ints(out)
+
+
+def fr_random(seed, n):
+    out = np.empty((n, 4), dtype=np.uint64)
+    lib().orc_fr_random(ctypes.c_uint64(seed), _p(out), ctypes.c_size_t(n))
+    return out
+
+
+def _binop(name, a, b):
+    a = _u64(a); b = _u64(b)
+    out = np.empty_like(a)
+    getattr(lib(), name)(_p(a), _p(b), _p(out), ctypes.c_size_t(a.reshape(-1, 4).shape[0]))
+    return out
+
+
+def fp_mul(a, b): return _binop("orc_fp_mul", a, b)
+def fp_add(a, b): return _binop("orc_fp_add", a, b)
+def fp_sub(a, b): return _binop("orc_fp_sub", a, b)
+def fr_mul(a, b): return _binop("orc_fr_mul", a, b)
+def fr_add(a, b): return _binop("orc_fr_add", a, b)
+def fr_sub(a, b): return _binop("orc_fr_sub", a, b)
+
+
+def fr_inv(a):
+    a = _u64(a); out = np.empty_like(a)
+    lib().orc_fr_inv(_p(a), _p(out), ctypes.c_size_t(a.reshape(-1, 4).shape[0]))
+    return out
+
+
+def fp_inv(a):
+    a = _u64(a); out = np.empty_like(a)
+    lib().orc_fp_inv(_p(a), _p(out), ctypes.c_size_t(a.reshape(-1, 4).shape[0]))
+    return out
+
+
+def fr_dot(a, b):
+    a = _u64(a); b = _u64(b)
+    out = np.empty((4,), dtype=np.uint64)
+    lib().orc_fr_dot(_p(a), _p(b), ctypes.c_size_t(a.shape[0]), _p(out))
+    return out
+
+
+def g1_from_scalars(sc):
+    sc = _u64(sc); n = sc.shape[0]
+    out = np.empty((n, 8), dtype=np.uint64)
+    lib().orc_g1_from_scalars(_p(sc), ctypes.c_size_t(n), _p(out))
+    return out
+
+
+def g2_from_scalars(sc):
+    sc = _u64(sc); n = sc.shape[0]
+    out = np.empty((n, 16), dtype=np.uint64)
+    lib().orc_g2_from_scalars(_p(sc), ctypes.c_size_t(n), _p(out))
+    return out
+
+
+def g1_on_curve(p):
+    p = _u64(p); return bool(lib().orc_g1_on_curve(_p(p), ctypes.c_size_t(p.reshape(-1, 8).shape[0])))
+
+
+def g2_on_curve(p):
+    p = _u64(p); return bool(lib().orc_g2_on_curve(_p(p), ctypes.c_size_t(p.reshape(-1, 16).shape[0])))
+
+
+def g1_jac_to_affine(j):
+    j = _u64(j).reshape(-1, 12); out = np.empty((j.shape[0], 8), dtype=np.uint64)
+    lib().orc_g1_jac_to_affine(_p(j), _p(out), ctypes.c_size_t(j.shape[0]))
+    return out
+
+
+def g2_jac_to_affine(j):
+    j = _u64(j).reshape(-1, 24); out = np.empty((j.shape[0], 16), dtype=np.uint64)
+    lib().orc_g2_jac_to_affine(_p(j), _p(out), ctypes.c_size_t(j.shape[0]))
+    return out
+
+
+def g1_xyzz_to_affine(x):
+    x = _u64(x).reshape(-1, 16); out = np.empty((x.shape[0], 8), dtype=np.uint64)
+    lib().orc_g1_xyzz_to_affine(_p(x), _p(out), ctypes.c_size_t(x.shape[0]))
+    return out
+
+
+def g1_add(a, b):
+    a = _u64(a).reshape(-1, 8); b = _u64(b).reshape(-1, 8); out = np.empty_like(a)
+    lib().orc_g1_add_affine(_p(a), _p(b), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def g2_add(a, b):
+    a = _u64(a).reshape(-1, 16); b = _u64(b).reshape(-1, 16); out = np.empty_like(a)
+    lib().orc_g2_add_affine(_p(a), _p(b), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def g1_scalar_mul(p, k):
+    p = _u64(p).reshape(-1, 8); k = _u64(k).reshape(-1, 4); out = np.empty_like(p)
+    lib().orc_g1_scalar_mul(_p(p), _p(k), _p(out), ctypes.c_size_t(p.shape[0]))
+    return out
+
+
+def g1_msm(pts, sc, window=0):
+    pts = _u64(pts); sc = _u64(sc); out = np.empty((8,), dtype=np.uint64)
+    lib().orc_g1_msm(_p(pts), _p(sc), ctypes.c_size_t(sc.shape[0]), ctypes.c_int(window), _p(out))
+    return out
+
+
+def g2_msm(pts, sc, window=0):
+    pts = _u64(pts); sc = _u64(sc); out = np.empty((16,), dtype=np.uint64)
+    lib().orc_g2_msm(_p(pts), _p(sc), ctypes.c_size_t(sc.shape[0]), ctypes.c_int(window), _p(out))
+    return out
+
+
+DIT, DIF = 0, 1
+
+
+def fft(a, log2n, inverse=False, decimation=DIF, on_coset=False):
+    a = _u64(a).copy()
+    lib().orc_fft(_p(a), ctypes.c_int(log2n), ctypes.c_int(int(inverse)), ctypes.c_int(decimation),
+                  ctypes.c_int(int(on_coset)))
+    return a
+
+
+def bit_reverse(a, log2n):
+    a = _u64(a).copy()
+    lib().orc_bit_reverse(_p(a), ctypes.c_int(log2n))
+    return a
+
+
+def dft_naive(a, log2n, on_coset=False):
+    a = _u64(a); out = np.empty_like(a)
+    lib().orc_dft_naive(_p(a), ctypes.c_int(log2n), ctypes.c_int(int(on_coset)), _p(out))
+    return out
+
+
+def compute_h(a, b, c, log2d):
+    a = _u64(a); b = _u64(b); c = _u64(c)
+    out = np.empty((1 << log2d, 4), dtype=np.uint64)
+    lib().orc_compute_h(_p(a), _p(b), _p(c), ctypes.c_size_t(a.shape[0]), ctypes.c_int(log2d), _p(out))
+    return out
+
+
+def poseidon_set_convention(out_idx, carry_idx):
+    lib().orc_poseidon_set_convention(ctypes.c_int(out_idx), ctypes.c_int(carry_idx))
+
+
+def poseidon_params(t):
+    rp = lib().orc_poseidon_rp(ctypes.c_int(t))
+    rc = np.empty(((8 + rp) * t, 4), dtype=np.uint64)
+    mds = np.empty((t * t, 4), dtype=np.uint64)
+    lib().orc_poseidon_params(ctypes.c_int(t), _p(rc), _p(mds))
+    return rp, rc, mds
+
+
+def poseidon_permute(state):
+    s = _u64(state).copy()
+    lib().orc_poseidon_permute(_p(s), ctypes.c_int(s.shape[0]))
+    return s
+
+
+def poseidon_hash(inp):
+    inp = _u64(inp); out = np.empty((4,), dtype=np.uint64)
+    lib().orc_poseidon_hash(_p(inp), ctypes.c_size_t(inp.shape[0]), _p(out))
+    return out
+
+
+def poseidon_hash2_batch(pairs):
+    pairs = _u64(pairs).reshape(-1, 4)
+    n = pairs.shape[0] // 2
+    out = np.empty((n, 4), dtype=np.uint64)
+    lib().orc_poseidon_hash2_batch(_p(pairs), ctypes.c_size_t(n), _p(out))
+    return out
+
+
+ACCOUNT_DTYPE = np.dtype([("id_be", np.uint8, 32), ("equity", np.uint64, 2), ("debt", np.uint64, 2),
+                          ("collateral", np.uint64, 2), ("n_assets", np.uint32), ("asset_off", np.uint32)])
+ASSET_DTYPE = np.dtype([("equity", np.uint64), ("debt", np.uint64), ("loan", np.uint64), ("margin", np.uint64),
+                        ("portfolio_margin", np.uint64), ("index", np.uint32), ("pad", np.uint32)])
+assert ACCOUNT_DTYPE.itemsize == 88 and ASSET_DTYPE.itemsize == 48
+
+
+def account_leaves(accounts, assets, tier):
+    accounts = np.ascontiguousarray(accounts, dtype=ACCOUNT_DTYPE)
+    assets = np.ascontiguousarray(assets, dtype=ASSET_DTYPE)
+    out = np.empty((accounts.shape[0], 4), dtype=np.uint64)
+    lib().orc_account_leaves(_p(accounts), _p(assets), ctypes.c_size_t(accounts.shape[0]), ctypes.c_int(tier), _p(out))
+    return out
+
+
+def merkle_build(leaves, depth, nil_leaf, want_levels=False):
+    leaves = _u64(leaves).reshape(-1, 4); n = leaves.shape[0]
+    nil_leaf = _u64(nil_leaf)
+    tot = sum((n + (1 << l) - 1) >> l for l in range(1, depth + 1))
+    levels = np.empty((tot, 4), dtype=np.uint64) if want_levels else None
+    nil = np.empty((depth + 1, 4), dtype=np.uint64)
+    root = np.empty((4,), dtype=np.uint64)
+    lib().orc_merkle_build(_p(leaves), ctypes.c_size_t(n), ctypes.c_int(depth), _p(nil_leaf),
+                           _p(levels) if want_levels else None, _p(nil), _p(root))
+    return root, nil, levels
+
+
+def fr_to_be(a):
+    a = _u64(a).reshape(-1, 4); out = np.empty((a.shape[0], 32), dtype=np.uint8)
+    lib().orc_fr_to_be(_p(a), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def fr_from_be(b):
+    b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 32); out = np.empty((b.shape[0], 4), dtype=np.uint64)
+    lib().orc_fr_from_be(_p(b), _p(out), ctypes.c_size_t(b.shape[0]))
+    return out
+
+
+class Synth:
+    """trapdoor-known synthetic Groth16 instance + key (oracle/algos.hpp synth_*)"""
+
+    def __init__(self, n_inputs, n_cons, n_public=2, seed=1, z_bitrev=True):
+        L = lib()
+        self.h = ctypes.c_void_p(L.orc_synth_create(ctypes.c_size_t(n_inputs), ctypes.c_size_t(n_cons),
+                                                    ctypes.c_size_t(n_public), ctypes.c_uint64(seed),
+                                                    ctypes.c_int(int(z_bitrev))))
+        dims = np.zeros(5, dtype=np.uint64)
+        L.orc_synth_dims(self.h, _p(dims))
+        self.log2d, self.n_wires, self.n_public, self.n_cons, self.n_z = (int(x) for x in dims)
+        self.z_bitrev = z_bitrev
+        nw = self.n_wires
+        self.A = np.empty((nw, 8), np.uint64); self.B1 = np.empty((nw, 8), np.uint64)
+        self.B2 = np.empty((nw, 16), np.uint64); self.K = np.empty((nw, 8), np.uint64)
+        self.Z = np.empty((self.n_z, 8), np.uint64)
+        self.abd1 = np.empty((3, 8), np.uint64); self.bd2 = np.empty((2, 16), np.uint64)
+        self.w = np.empty((nw, 4), np.uint64)
+        self.a = np.empty((self.n_cons, 4), np.uint64); self.b = np.empty_like(self.a); self.c = np.empty_like(self.a)
+        L.orc_synth_export(self.h, _p(self.A), _p(self.B1), _p(self.B2), _p(self.K), _p(self.Z), _p(self.abd1),
+                           _p(self.bd2), _p(self.w), _p(self.a), _p(self.b), _p(self.c))
+
+    def prove_tail(self, r, s):
+        out = np.empty(256, dtype=np.uint8)
+        lib().orc_synth_prove_tail(self.h, _p(_u64(r)), _p(_u64(s)), _p(out))
+        return out
+
+    def check(self, r, s, proof256):
+        proof256 = np.ascontiguousarray(proof256, dtype=np.uint8)
+        return bool(lib().orc_synth_check(self.h, _p(_u64(r)), _p(_u64(s)), _p(proof256)))
+
+    def __del__(self):
+        try:
+            lib().orc_synth_destroy(self.h)
+        except Exception:
+            pass
+
+
+def proof_raw(proof256):
+    proof256 = np.ascontiguousarray(proof256, dtype=np.uint8)
+    out = np.empty(256, dtype=np.uint8)
+    lib().orc_proof_raw(_p(proof256), _p(out))
+    return out
+
+
+def selftest():
+    return lib().orc_selftest()
