@@ -1,0 +1,166 @@
+/* zkpor.h — C ABI of the MI355X (gfx950) backend for the reference's Groth16 / Poseidon hot path.
+ *
+ * Drop-in boundary.  Every entry point replaces work the reference does inside ONE call:
+ *   groth16.Prove(r1cs, pk, witness)            src/prover/prover/prover.go:269   -> zkpor_prove_tail (+ zkpor_commit)
+ *   pk.UnsafeReadFrom / LoadSnarkParamsOnce     src/prover/prover/prover.go:285-367 -> zkpor_pk_* (one-time HBM upload)
+ *   proof.WriteRawTo                            src/prover/prover/prover.go:201   -> zkpor_proof_write_raw
+ *   AccountInfoToHash / buildAccountTree        src/utils/utils.go:744-750, src/witness/main.go:130-199 -> zkpor_poseidon_leaves
+ *   FixedDepthMerkleTree.Build / Root           src/utils/merkletree/merkletree.go:192-279 -> zkpor_merkle_build
+ *   poseidon.Poseidon / hash.Hash Write+Sum     src/utils/account_tree.go:19,27 (hasher factory) -> zkpor_poseidon_hash
+ * The cgo binding a maintainer adds on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all functions return 0 on success, <0 on error (ZKPOR_E_*); they never throw, never call back into the
+ *     host runtime and never retain a host pointer after returning (cgo pointer-passing rule).
+ *   - field elements are gnark-crypto's in-memory form: 4 x uint64 little-endian limbs, MONTGOMERY form
+ *     (fr.Element / fp.Element).  G1 affine = X,Y (64 B); G2 affine = X.A0,X.A1,Y.A0,Y.A1 (128 B);
+ *     G1 Jacobian = X,Y,Z (96 B); G2 Jacobian 192 B.  Affine infinity = all-zero.
+ *   - a zkpor_ctx is bound to one GPU and one HIP stream and is single-caller; different contexts are
+ *     independent (one per GPU, one process or thread each).
+ *   - *_dev variants take DEVICE pointers (inputs already resident in HBM) and are asynchronous on the
+ *     context's stream unless they return a result to the host.
+ *   - there is NO CPU fallback: without a usable gfx950 device every call fails with ZKPOR_E_NODEVICE.
+ */
+#ifndef ZKPOR_H
+#define ZKPOR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKPOR_OK 0
+#define ZKPOR_E_NODEVICE (-1)
+#define ZKPOR_E_HIP (-2)      /* a HIP runtime call failed; zkpor_last_error has the text */
+#define ZKPOR_E_ARG (-3)      /* invalid argument */
+#define ZKPOR_E_OOM (-4)      /* device allocation failed (never aborts the process) */
+#define ZKPOR_E_STATE (-5)    /* key not fully loaded for the requested operation */
+
+typedef struct zkpor_ctx zkpor_ctx;
+typedef struct zkpor_pk zkpor_pk;
+
+/* point arrays of the Groth16 proving key (gnark groth16_bn254.ProvingKey: G1.A, G1.B, G1.K, G1.Z, G2.B and the
+ * Pedersen CommitmentKeys Basis / BasisExpSigma) */
+enum { ZKPOR_G1_A = 0, ZKPOR_G1_B = 1, ZKPOR_G1_K = 2, ZKPOR_G1_Z = 3, ZKPOR_G1_COMMIT_BASIS = 4,
+       ZKPOR_G1_COMMIT_BASIS_SIGMA = 5, ZKPOR_G1_NUM = 6 };
+enum { ZKPOR_G2_B = 0, ZKPOR_G2_NUM = 1 };
+/* order of pk.G1.Z relative to the coefficient index of h: gnark >= 0.9 stores it bit-reversed at setup */
+enum { ZKPOR_Z_ORDER_BITREV = 0, ZKPOR_Z_ORDER_NATURAL = 1 };
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+/* stream: a hipStream_t (as void*) the context launches on, or NULL to create its own. */
+int32_t zkpor_init(int device, void* stream, zkpor_ctx** out);
+void zkpor_destroy(zkpor_ctx* ctx);
+const char* zkpor_last_error(zkpor_ctx* ctx);
+int32_t zkpor_sync(zkpor_ctx* ctx);
+/* tuning knobs: "msm_window" (bits, 0 = auto), "msm_chunk" (entries per accumulation thread),
+ * "poseidon_out_idx", "poseidon_carry_idx" (hash-wrapper convention) */
+int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);
+/* per-phase GPU time in ms accumulated since the last reset (HIP events on the context's stream).
+ * names: "msm_decompose","msm_sort","msm_accumulate","msm_reduce","ntt","pointwise","poseidon_leaf",
+ * "poseidon_tree","gather"; returns <0 for an unknown name.  calls = launches counted. */
+double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls);
+void zkpor_phase_reset(zkpor_ctx* ctx);
+
+/* ---- proving key (replaces pk.UnsafeReadFrom's in-RAM key with an HBM-resident one) ------------------- */
+int32_t zkpor_pk_create(zkpor_ctx* ctx, zkpor_pk** out);
+void zkpor_pk_destroy(zkpor_pk* pk);
+/* pts: n affine points exactly as gnark holds them (compacted: wires whose point is infinity are absent for
+ * A and B; public/committed wires are absent for K).  Copied to HBM before returning. */
+int32_t zkpor_pk_set_g1(zkpor_pk* pk, int which, const void* pts, size_t n);
+int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n);
+/* alpha,beta,delta: G1 affine (64 B each); beta2,delta2: G2 affine (128 B each).
+ * inf_a/inf_b: n_wires bytes, non-zero where pk.InfinityA/B[i] is true (may be NULL = none).
+ * committed_idx: the n_committed wire indices removed from K besides the public wires (may be NULL).
+ * After this call the key arrays are re-laid out WIRE-INDEXED in HBM (infinity where gnark compacted), so one
+ * sorted digit stream of the witness serves the A, B1, B2 and K multi-exponentiations. */
+int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, const void* delta,
+                            const void* beta2, const void* delta2, int log2_domain, const uint8_t* inf_a,
+                            const uint8_t* inf_b, size_t n_wires, size_t n_public,
+                            const uint32_t* committed_idx, size_t n_committed, int z_order);
+/* TEST/BENCH utility (no reference counterpart): fill every array of the key with valid curve points generated
+ * on the device (random walks from seeded multiples of the generators).  Sizes follow SURVEY.md §8(d) C2 when
+ * n_wires = 2^log2_domain.  The key is NOT a sound Groth16 key; it exercises the prover's data path at scale. */
+int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, size_t n_committed,
+                       uint64_t seed);
+/* device pointer + length of a loaded (wire-indexed) array, for tests */
+int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n);
+int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n);
+
+/* ---- multi-scalar multiplication (gnark-crypto G1Jac.MultiExp / G2Jac.MultiExp) ------------------------ */
+/* generic: sum_i scalars[i]*points[i] over caller-provided arrays */
+int32_t zkpor_msm_g1(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[96]);
+int32_t zkpor_msm_g2(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[192]);
+int32_t zkpor_msm_g1_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[96]);
+int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[192]);
+
+/* ---- H polynomial (gnark computeH) ---------------------------------------------------------------------- */
+/* a,b,c: n_constraints evaluations each (zero-padded to the domain internally); h_out: 2^log2_domain elements
+ * in the order the key's Z expects (bit-reversed for ZKPOR_Z_ORDER_BITREV). */
+int32_t zkpor_compute_h(zkpor_ctx* ctx, int log2_domain, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                        size_t n_constraints, uint64_t* h_out);
+/* in-place on device: d_a, d_b, d_c hold 2^log2_domain elements (already zero-padded); h is left in d_a. */
+int32_t zkpor_compute_h_dev(zkpor_ctx* ctx, int log2_domain, void* d_a, void* d_b, void* d_c);
+/* single transforms (gnark-crypto fft.Domain.FFT / FFTInverse): decimation 0 = DIT, 1 = DIF */
+int32_t zkpor_fft(zkpor_ctx* ctx, uint64_t* a, int log2n, int inverse, int decimation, int on_coset);
+
+/* ---- Groth16 prove tail: everything in groth16.Prove after the R1CS solver ------------------------------ */
+/* w: n_wires wire values (full assignment, ONE wire first); a,b,c: n_constraints evaluations; r,s: blinding
+ * scalars (Montgomery Fr).  proof_out: Ar (G1 affine 64 B) | Bs (G2 affine 128 B) | Krs (G1 affine 64 B) as
+ * Montgomery limbs.  Computes h, the A/B1/B2/K/Z multi-exponentiations and the r/s blinding on the device. */
+int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                         const uint64_t* c, size_t n_constraints, const uint64_t r[4], const uint64_t s[4],
+                         uint8_t proof_out[256]);
+/* device-resident inputs; d_a/d_b/d_c must hold 2^log2_domain elements (zero padded) and are overwritten */
+int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c,
+                             const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]);
+/* Pedersen commitment over the committed wires (gnark-crypto pedersen.ProvingKey.Commit / ProveKnowledge):
+ * values: n_committed Fr; out: commitment | knowledge proof, G1 affine 64 B each */
+int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64],
+                     uint8_t out_pok[64]);
+/* gnark raw proof bytes (proof.WriteRawTo): big-endian Ar.X|Ar.Y|Bs.X.A1|Bs.X.A0|Bs.Y.A1|Bs.Y.A0|Krs.X|Krs.Y|
+ * u32 n_commitments | commitments... | pok  (388 B for one commitment; 324 B... for none) */
+int32_t zkpor_proof_write_raw(const uint8_t proof[256], const uint8_t* commitments, uint32_t n_commitments,
+                              const uint8_t pok[64], uint8_t* out, size_t out_cap, size_t* out_len);
+
+/* ---- Poseidon account tree ------------------------------------------------------------------------------ */
+/* one account, packed (mirrors utils.AccountInfo, src/utils/types.go:34-41) */
+typedef struct {
+    uint8_t id_be[32];        /* AccountId, 32 bytes big-endian (reduced mod r like PoseidonBytes does) */
+    uint64_t equity[2];       /* TotalEquity, TotalDebt, TotalCollateral: < 2^128, little-endian words */
+    uint64_t debt[2];
+    uint64_t collateral[2];
+    uint32_t n_assets;        /* number of entries in the asset array */
+    uint32_t asset_off;       /* index of the first one */
+} zkpor_account_t;            /* 88 bytes */
+typedef struct {              /* utils.AccountAsset, src/utils/types.go:25-32; assets sorted by index */
+    uint64_t equity, debt, loan, margin, portfolio_margin;
+    uint32_t index, pad;
+} zkpor_asset_t;              /* 48 bytes */
+/* leaf hashes (utils.AccountInfoToHash) for n accounts padded to `tier` assets; out: n x 32 B big-endian */
+int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, const zkpor_asset_t* assets,
+                              size_t n_assets_total, size_t n, int tier, uint8_t* out32);
+/* fixed-depth tree over n leaves (32 B big-endian each) at positions 0..n-1; every other leaf is nil_leaf.
+ * levels_out (may be NULL): levels 1..depth concatenated, level l holding ceil(n/2^l) nodes, 32 B BE each. */
+int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n, int depth,
+                           const uint8_t nil_leaf[32], uint8_t* levels_out, uint8_t root_out[32]);
+/* device-resident leaves in Montgomery form (n x 32 B), root returned in Montgomery form: the bench path */
+int32_t zkpor_merkle_build_dev(zkpor_ctx* ctx, const void* d_leaves_mont, size_t n, int depth,
+                               const uint64_t nil_leaf_mont[4], uint64_t root_mont[4]);
+/* poseidon.Poseidon(inputs...) for `count` independent inputs of `len` elements each (Montgomery Fr in/out) */
+int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, size_t count, uint64_t* out);
+
+/* ---- device memory helpers for host languages without a HIP binding ------------------------------------ */
+int32_t zkpor_dev_alloc(zkpor_ctx* ctx, size_t bytes, void** out);
+int32_t zkpor_dev_free(zkpor_ctx* ctx, void* p);
+int32_t zkpor_dev_upload(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes);
+int32_t zkpor_dev_download(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* fill n Montgomery Fr elements with seeded pseudo-random values on the device. kind 0 = uniform,
+ * kind 1 = the witness-like mixture of SURVEY.md §8(d) (25% {0,1}, 20% <2^16, 5% <2^64, 50% uniform) */
+int32_t zkpor_dev_fill_fr(zkpor_ctx* ctx, void* d_out, size_t n, uint64_t seed, int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+"""-m gpu: bit-exact parity of the HIP MSM (through the C ABI) against the CPU oracle.
+Edge cases follow SURVEY.md §7 step 3: zeros, ones, r-1, repeated points, P/-P collisions, infinity points."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _g1_eq(jac, aff_expected):
+    return np.array_equal(O.g1_jac_to_affine(jac)[0], aff_expected)
+
+
+def _g2_eq(jac, aff_expected):
+    return np.array_equal(O.g2_jac_to_affine(jac)[0], aff_expected)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 257, 1000, 4096])
+def test_g1_msm_random(zk, n):
+    sc = O.fr_random(100 + n, n)
+    pts = O.g1_from_scalars(O.fr_random(200 + n, n))
+    assert _g1_eq(zk.msm_g1(pts, sc), O.g1_msm(pts, sc))
+
+
+@pytest.mark.parametrize("window", [2, 3, 5, 8, 11, 13, 16])
+@pytest.mark.parametrize("chunk", [4, 32])
+def test_g1_msm_windows_chunks(zk, window, chunk):
+    n = 777
+    sc = O.fr_random(5, n)
+    pts = O.g1_from_scalars(O.fr_random(6, n))
+    zk.set_param("msm_window", window)
+    zk.set_param("msm_chunk", chunk)
+    try:
+        assert _g1_eq(zk.msm_g1(pts, sc), O.g1_msm(pts, sc))
+    finally:
+        zk.set_param("msm_window", 0)
+        zk.set_param("msm_chunk", 32)
+
+
+def test_g1_msm_edge_scalars(zk):
+    n = 600
+    pts = O.g1_from_scalars(O.fr_random(7, n))
+    vals = [0, 1, O.R_MOD - 1, 2, O.R_MOD - 2, 1 << 16, (1 << 16) - 1, 1 << 253, 0xFFFF, 3]
+    sc = O.fr_from_ints([vals[i % len(vals)] for i in range(n)])
+    assert _g1_eq(zk.msm_g1(pts, sc), O.g1_msm(pts, sc))
+    # all zero -> infinity; all one -> plain sum (one giant bucket: exercises the partial-sum recursion)
+    z = O.fr_from_ints([0] * n)
+    assert not O.g1_jac_to_affine(zk.msm_g1(pts, z)).any()
+    ones = O.fr_from_ints([1] * n)
+    assert _g1_eq(zk.msm_g1(pts, ones), O.g1_msm(pts, ones))
+
+
+def test_g1_msm_skew_heavy_bucket(zk):
+    # 5000 equal scalars: a single bucket per window spanning >100 chunks -> several recursion levels
+    n = 5000
+    pts = O.g1_from_scalars(O.fr_random(8, n))
+    sc = np.repeat(O.fr_random(9, 1), n, axis=0)
+    zk.set_param("msm_chunk", 8)
+    try:
+        assert _g1_eq(zk.msm_g1(pts, sc), O.g1_msm(pts, sc))
+    finally:
+        zk.set_param("msm_chunk", 32)
+
+
+def test_g1_msm_repeated_negated_infinity_points(zk):
+    n = 512
+    base = O.g1_from_scalars(O.fr_random(10, 8))
+    pts = np.empty((n, 8), dtype=np.uint64)
+    for i in range(n):
+        pts[i] = base[i % 8]
+    # negate every third point (y -> -y), make every fifth the point at infinity (0,0)
+    neg_y = O.fp_sub(O.fp_from_ints([0] * n), pts[:, 4:8])
+    for i in range(0, n, 3):
+        pts[i, 4:8] = neg_y[i]
+    for i in range(0, n, 5):
+        pts[i] = 0
+    sc = O.fr_from_ints([(i % 4) + 1 for i in range(n)])  # few distinct scalars: P+P and P+(-P) inside buckets
+    assert _g1_eq(zk.msm_g1(pts, sc), O.g1_msm(pts, sc))
+    sc = O.fr_random(11, n)
+    assert _g1_eq(zk.msm_g1(pts, sc), O.g1_msm(pts, sc))
+
+
+def test_g1_msm_trapdoor_linearity_2_16(zk):
+    # size-independent property: points s_i*G => MSM == (sum s_i w_i) * G
+    n = 1 << 16
+    s = O.fr_random(12, n)
+    pts = O.g1_from_scalars(s)
+    w = O.fr_random(13, n)
+    expect = O.g1_from_scalars(O.fr_dot(s, w).reshape(1, 4))[0]
+    assert _g1_eq(zk.msm_g1(pts, w), expect)
+
+
+def test_g1_msm_empty(zk):
+    out = zk.msm_g1(np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64))
+    assert not O.g1_jac_to_affine(out).any()
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 300, 2048])
+def test_g2_msm_random(zk, n):
+    sc = O.fr_random(300 + n, n)
+    pts = O.g2_from_scalars(O.fr_random(400 + n, n))
+    assert _g2_eq(zk.msm_g2(pts, sc), O.g2_msm(pts, sc))
+
+
+def test_g2_msm_edge(zk):
+    n = 256
+    base = O.g2_from_scalars(O.fr_random(14, 4))
+    pts = np.empty((n, 16), dtype=np.uint64)
+    for i in range(n):
+        pts[i] = base[i % 4]
+    for i in range(0, n, 7):
+        pts[i] = 0
+    sc = O.fr_from_ints([(i % 3) for i in range(n)])
+    assert _g2_eq(zk.msm_g2(pts, sc), O.g2_msm(pts, sc))
+    s = O.fr_random(15, n)
+    pts = O.g2_from_scalars(s)
+    w = O.fr_random(16, n)
+    expect = O.g2_from_scalars(O.fr_dot(s, w).reshape(1, 4))[0]
+    assert _g2_eq(zk.msm_g2(pts, w), expect)

@@ -1,0 +1,207 @@
+// C ABI (include/zkpor.h): context, device memory helpers, tuning, phase timers, generic MSM entry points.
+#include "common.cuh"
+#include "msm.cuh"
+
+using namespace zk;
+
+namespace zk {
+int32_t ensure_pinned(zkpor_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_cap) return ZKPOR_OK;
+    if (ctx->pinned) { ZK_HIP(ctx, hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
+    ZK_HIP(ctx, hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+    ctx->pinned_cap = bytes;
+    return ZKPOR_OK;
+}
+}  // namespace zk
+
+// ---- seeded Fr fill (bench/test inputs generated in HBM) ----
+__device__ __forceinline__ u64 splitmix(u64& s) {
+    u64 z = (s += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+__global__ void k_fill_fr(Fr* out, size_t n, u64 seed, int kind) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 s = seed ^ (i * 0xd1342543de82ef95ULL + 0x2545f4914f6cdd1dULL);
+    u64 sel = splitmix(s) % 100;
+    Fr x = Fr::zero();
+    int bits = 254;
+    if (kind == 1) {
+        if (sel < 25) bits = 1;
+        else if (sel < 45) bits = 16;
+        else if (sel < 50) bits = 64;
+    }
+    u64 r0 = splitmix(s), r1 = splitmix(s), r2 = splitmix(s), r3 = splitmix(s);
+    if (bits == 1) { r0 &= 1; r1 = r2 = r3 = 0; }
+    else if (bits == 16) { r0 &= 0xffff; r1 = r2 = r3 = 0; }
+    else if (bits == 64) { r1 = r2 = r3 = 0; }
+    else { r3 &= 0x0fffffffffffffffULL; }  // < 2^252 < r: canonical
+    x.v[0] = (u32)r0; x.v[1] = (u32)(r0 >> 32); x.v[2] = (u32)r1; x.v[3] = (u32)(r1 >> 32);
+    x.v[4] = (u32)r2; x.v[5] = (u32)(r2 >> 32); x.v[6] = (u32)r3; x.v[7] = (u32)(r3 >> 32);
+    out[i] = Fr::to_mont(x);
+}
+
+template <class F>
+static int32_t msm_host(zkpor_ctx* ctx, const void* pts, const uint64_t* scalars, size_t n, XYZZ<F>* r) {
+    if (n == 0) { *r = XYZZ<F>::inf(); return ZKPOR_OK; }
+    void *dp = nullptr, *dsc = nullptr;
+    ZK_HIP(ctx, hipMalloc(&dp, n * sizeof(Affine<F>)));
+    hipError_t e = hipMalloc(&dsc, n * 32);
+    if (e != hipSuccess) { (void)hipFree(dp); ctx->err = "hipMalloc scalars"; return ZKPOR_E_OOM; }
+    int32_t rc = ZKPOR_OK;
+    if (hipMemcpyAsync(dp, pts, n * sizeof(Affine<F>), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(dsc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        ctx->err = "H2D copy failed"; rc = ZKPOR_E_HIP;
+    }
+    if (rc == ZKPOR_OK) rc = msm_dev<F>(ctx, (const Affine<F>*)dp, (const Fr*)dsc, n, r);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dp); (void)hipFree(dsc);
+    return rc;
+}
+
+extern "C" {
+
+int32_t zkpor_init(int device, void* stream, zkpor_ctx** out) {
+    if (!out) return ZKPOR_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZKPOR_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ZKPOR_E_NODEVICE;
+    // kernels are compiled for gfx950 only: refuse anything else rather than fail at first launch
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ZKPOR_E_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return ZKPOR_E_NODEVICE;
+    zkpor_ctx* ctx = new (std::nothrow) zkpor_ctx();
+    if (!ctx) return ZKPOR_E_OOM;
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ZKPOR_E_HIP; }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return ZKPOR_OK;
+}
+
+void zkpor_destroy(zkpor_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->phases)
+        for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->pos_tables) (void)hipFree(ctx->pos_tables);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* zkpor_last_error(zkpor_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t zkpor_sync(zkpor_ctx* ctx) {
+    if (!ctx) return ZKPOR_E_ARG;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return ZKPOR_E_ARG;
+    std::string n(name);
+    if (n == "msm_window") ctx->msm_window = (int)value;
+    else if (n == "msm_chunk") ctx->msm_chunk = (int)value;
+    else if (n == "poseidon_out_idx") ctx->pos_out = (int)value;
+    else if (n == "poseidon_carry_idx") ctx->pos_carry = (int)value;
+    else { ctx->err = "unknown parameter " + n; return ZKPOR_E_ARG; }
+    return ZKPOR_OK;
+}
+
+double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls) {
+    if (!ctx || !name) return -1.0;
+    auto it = ctx->phases.find(name);
+    if (it == ctx->phases.end()) { if (calls) *calls = 0; return 0.0; }
+    phase_resolve(ctx, it->second);
+    if (calls) *calls = it->second.calls;
+    return it->second.ms;
+}
+void zkpor_phase_reset(zkpor_ctx* ctx) {
+    if (!ctx) return;
+    for (auto& kv : ctx->phases) { phase_resolve(ctx, kv.second); kv.second.ms = 0; kv.second.calls = 0; }
+}
+
+int32_t zkpor_dev_alloc(zkpor_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return ZKPOR_E_ARG;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    ZK_HIP(ctx, hipMalloc(out, bytes ? bytes : 1));
+    return ZKPOR_OK;
+}
+int32_t zkpor_dev_free(zkpor_ctx* ctx, void* p) {
+    if (!ctx) return ZKPOR_E_ARG;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, hipFree(p));
+    return ZKPOR_OK;
+}
+int32_t zkpor_dev_upload(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return ZKPOR_E_ARG;
+    ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer is not retained
+    return ZKPOR_OK;
+}
+int32_t zkpor_dev_download(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return ZKPOR_E_ARG;
+    ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+}
+int32_t zkpor_dev_fill_fr(zkpor_ctx* ctx, void* d_out, size_t n, uint64_t seed, int kind) {
+    if (!ctx || (!d_out && n)) return ZKPOR_E_ARG;
+    if (n == 0) return ZKPOR_OK;
+    hipLaunchKernelGGL(k_fill_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_out, n, seed, kind);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+
+// ---- generic MSM ----
+static void store_jac_g1(const G1XYZZ& r, uint8_t* out) {
+    G1Jac j = xyzz_to_jacobian<Fp>(r);
+    memcpy(out, &j, 96);
+}
+static void store_jac_g2(const G2XYZZ& r, uint8_t* out) {
+    G2Jac j = xyzz_to_jacobian<Fp2>(r);
+    memcpy(out, &j, 192);
+}
+
+int32_t zkpor_msm_g1_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[96]) {
+    if (!ctx || !out_jac || (n && (!d_points || !d_scalars))) return ZKPOR_E_ARG;
+    G1XYZZ r;
+    ZK_TRY(msm_dev<Fp>(ctx, (const G1Affine*)d_points, (const Fr*)d_scalars, n, &r));
+    store_jac_g1(r, out_jac);
+    return ZKPOR_OK;
+}
+int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[192]) {
+    if (!ctx || !out_jac || (n && (!d_points || !d_scalars))) return ZKPOR_E_ARG;
+    G2XYZZ r;
+    ZK_TRY(msm_dev<Fp2>(ctx, (const G2Affine*)d_points, (const Fr*)d_scalars, n, &r));
+    store_jac_g2(r, out_jac);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_msm_g1(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[96]) {
+    if (!ctx || !out_jac || (n && (!points_affine || !scalars))) return ZKPOR_E_ARG;
+    G1XYZZ r;
+    ZK_TRY(msm_host<Fp>(ctx, points_affine, scalars, n, &r));
+    store_jac_g1(r, out_jac);
+    return ZKPOR_OK;
+}
+int32_t zkpor_msm_g2(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[192]) {
+    if (!ctx || !out_jac || (n && (!points_affine || !scalars))) return ZKPOR_E_ARG;
+    G2XYZZ r;
+    ZK_TRY(msm_host<Fp2>(ctx, points_affine, scalars, n, &r));
+    store_jac_g2(r, out_jac);
+    return ZKPOR_OK;
+}
+
+}  // extern "C"

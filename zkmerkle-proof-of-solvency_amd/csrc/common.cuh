@@ -1,0 +1,128 @@
+// Context, workspace arena, error plumbing and phase timers shared by the gfx950 kernels' host drivers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <stdio.h>
+#include <string.h>
+#include <cstring>
+#include "../../include/zkpor.h"
+#include "fe.cuh"
+#include "ec.cuh"
+
+struct PhaseTimer {
+    double ms = 0;
+    uint64_t calls = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct zkpor_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // bump-allocated workspace, regrown on demand
+    char* ws = nullptr;
+    size_t ws_cap = 0, ws_off = 0;
+    // tuning
+    int msm_window = 0;  // 0 = auto
+    int msm_chunk = 32;
+    int pos_out = 1, pos_carry = 0;
+    // Poseidon parameter tables on device (built lazily)
+    void* pos_tables = nullptr;
+    // timers
+    std::map<std::string, PhaseTimer> phases;
+    std::vector<hipEvent_t> event_pool;
+    // small pinned host staging buffer
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+};
+
+#define ZK_HIP(ctx, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess) {                                                                      \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                          \
+            return e__ == hipErrorOutOfMemory ? ZKPOR_E_OOM : ZKPOR_E_HIP;                            \
+        }                                                                                             \
+    } while (0)
+#define ZK_TRY(expr)                  \
+    do {                              \
+        int32_t rc__ = (expr);        \
+        if (rc__ != ZKPOR_OK) return rc__; \
+    } while (0)
+#define ZK_KERNEL_CHECK(ctx) ZK_HIP(ctx, hipGetLastError())
+
+namespace zk {
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// make sure the workspace can hold `bytes`; invalidates previous ws_alloc results
+inline int32_t ws_reserve(zkpor_ctx* ctx, size_t bytes) {
+    bytes = align_up(bytes, 1 << 20);
+    ctx->ws_off = 0;
+    if (bytes <= ctx->ws_cap) return ZKPOR_OK;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) { ZK_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_cap = 0; }
+    ZK_HIP(ctx, hipMalloc((void**)&ctx->ws, bytes));
+    ctx->ws_cap = bytes;
+    return ZKPOR_OK;
+}
+template <class T>
+inline T* ws_alloc(zkpor_ctx* ctx, size_t count) {
+    size_t bytes = align_up(count * sizeof(T), 256);
+    if (ctx->ws_off + bytes > ctx->ws_cap) return nullptr;
+    T* p = (T*)(ctx->ws + ctx->ws_off);
+    ctx->ws_off += bytes;
+    return p;
+}
+struct WsPlan {  // accumulate sizes first, then reserve once
+    size_t total = 0;
+    template <class T>
+    void add(size_t count) { total += align_up(count * sizeof(T), 256); }
+};
+
+inline hipEvent_t ev_get(zkpor_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct PhaseScope {  // RAII: GPU time of everything enqueued on the stream while alive
+    zkpor_ctx* ctx;
+    PhaseTimer* t;
+    hipEvent_t a, b;
+    PhaseScope(zkpor_ctx* c, const char* name) : ctx(c), t(&c->phases[name]) {
+        a = ev_get(c); b = ev_get(c);
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~PhaseScope() {
+        (void)hipEventRecord(b, ctx->stream);
+        t->pending.push_back({a, b});
+        t->calls++;
+    }
+};
+inline void phase_resolve(zkpor_ctx* ctx, PhaseTimer& t) {
+    for (auto& pr : t.pending) {
+        (void)hipEventSynchronize(pr.second);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+        t.ms += ms;
+        ctx->event_pool.push_back(pr.first);
+        ctx->event_pool.push_back(pr.second);
+    }
+    t.pending.clear();
+}
+
+// sort.hip (rocPRIM radix sort of (key,value) u32 pairs, keys in [0, 2^end_bit))
+int32_t sort_pairs_temp_bytes(zkpor_ctx* ctx, size_t n, int end_bit, size_t* bytes);
+// sorts (k0,v0); the sorted data ends up in (k_out, v_out) which alias one of the two buffers
+int32_t sort_pairs(zkpor_ctx* ctx, void* temp, size_t temp_bytes, u32* k0, u32* k1, u32* v0, u32* v1, size_t n,
+                   int end_bit, u32** k_out, u32** v_out);
+
+}  // namespace zk

@@ -1,0 +1,229 @@
+// Pippenger multi-scalar multiplication for gfx950 — replaces gnark-crypto's G1Jac.MultiExp / G2Jac.MultiExp that
+// groth16.Prove runs on the host (reference call site src/prover/prover/prover.go:269).
+//
+// MI355X-first structure ("sort once, accumulate many"):
+//   1. k_decompose   scalars (Montgomery Fr) -> signed c-bit digits -> compacted (key = window|bucket,
+//                    val = point index|sign) pairs; zero digits are dropped (witness vectors are full of them).
+//   2. rocPRIM radix sort of the pairs by key: every bucket becomes a contiguous run.
+//   3. k_acc_level1  perfectly load-balanced segmented sum: each thread owns exactly L consecutive sorted
+//                    entries (not a bucket), gathers the 64/128-byte affine points and accumulates runs in XYZZ
+//                    registers.  Runs that lie inside the chunk are finished buckets and go straight to HBM;
+//                    the (at most two) runs cut by the chunk boundary go to a partials array.
+//      k_acc_levelN  the same algorithm applied recursively to the partials (XYZZ+XYZZ) until one chunk
+//                    remains.  Any bucket skew (e.g. 25% of witness scalars being 1) costs log_L extra
+//                    tiny launches instead of serialising a thread.
+//   4. k_reduce_groups  running-sum bucket reduction in three group levels (sum and weighted sum per group).
+//   5. host: per-window recombination + Horner over windows (a few hundred group operations).
+// Steps 1-2 depend only on the scalars: groth16's A, B1, B2 and K multi-exponentiations all use the witness, so
+// the prover runs 1-2 once and 3-5 four times against wire-indexed key arrays (DigitStream below).
+#pragma once
+#include "common.cuh"
+
+namespace zk {
+
+static constexpr u32 NOKEY = 0xffffffffu;
+
+struct MsmCfg {
+    int c;     // window bits
+    int W;     // windows = ceil(255 / c)
+    u32 bpw;   // buckets per window = 2^(c-1)
+    u32 NB;    // total buckets
+    int L;     // entries per accumulation thread
+    int key_bits;
+    u32 g1, n1, g2, n2;  // reduce group sizes: g1*n1 = bpw, g2*n2 = n1
+};
+
+inline int log2_ceil(size_t n) {
+    int k = 0;
+    while (((size_t)1 << k) < n) ++k;
+    return k;
+}
+inline MsmCfg msm_cfg(zkpor_ctx* ctx, size_t n) {
+    MsmCfg m;
+    int c = ctx->msm_window;
+    if (c <= 0) {
+        c = log2_ceil(n) - 6;
+        if (c < 4) c = 4;
+        if (c > 20) c = 20;
+    }
+    if (c < 2) c = 2;
+    if (c > 22) c = 22;
+    m.c = c;
+    m.W = (255 + c - 1) / c;
+    m.bpw = 1u << (c - 1);
+    m.NB = m.bpw * (u32)m.W;
+    m.L = ctx->msm_chunk < 4 ? 4 : ctx->msm_chunk;
+    m.key_bits = log2_ceil(m.NB);
+    if (m.key_bits < 1) m.key_bits = 1;
+    m.g1 = m.bpw < 128 ? m.bpw : 128;
+    m.n1 = m.bpw / m.g1;
+    m.g2 = m.n1 < 64 ? m.n1 : 64;
+    m.n2 = m.n1 / m.g2;
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+// defined next to the kernel instantiations (one translation unit per field / inlining policy)
+int32_t launch_decompose(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, u32* keys, u32* vals, u32* counter);
+int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L,
+                      XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part);
+int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L,
+                      XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part);
+int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp>* src, u32 M, int L, XYZZ<Fp>* buckets,
+                      u32* out_keys, XYZZ<Fp>* out_part);
+int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp2>* src, u32 M, int L, XYZZ<Fp2>* buckets,
+                      u32* out_keys, XYZZ<Fp2>* out_part);
+int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp>* in, u32 n_groups, u32 g, XYZZ<Fp>* outS, XYZZ<Fp>* outW);
+int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp2>* in, u32 n_groups, u32 g, XYZZ<Fp2>* outS, XYZZ<Fp2>* outW);
+
+// ------------------------------------------------------------------------------------------------ host driver
+struct DigitStream {  // sorted digits of one scalar vector, reusable across point arrays
+    MsmCfg cfg;
+    u32* keys = nullptr;
+    u32* vals = nullptr;
+    u32 M = 0;
+};
+
+inline size_t digits_ws_bytes(zkpor_ctx* ctx, size_t n, const MsmCfg& cfg, size_t* sort_temp) {
+    size_t cap = n * (size_t)cfg.W;
+    WsPlan p;
+    p.add<u32>(cap); p.add<u32>(cap); p.add<u32>(cap); p.add<u32>(cap); p.add<u32>(64);
+    size_t tb = 0;
+    sort_pairs_temp_bytes(ctx, cap, cfg.key_bits, &tb);
+    *sort_temp = tb;
+    p.add<char>(tb + 256);
+    return p.total;
+}
+
+// decompose + sort.  Workspace must already be reserved; allocates from it.
+inline int32_t msm_digits(zkpor_ctx* ctx, const Fr* d_scalars, size_t n, const MsmCfg& cfg, size_t sort_temp,
+                          DigitStream* out) {
+    size_t cap = n * (size_t)cfg.W;
+    if (cap >= 0xfffffff0ull || n >= (1ull << 31)) { ctx->err = "msm: too many digit entries for 32-bit indexing"; return ZKPOR_E_ARG; }
+    u32* k0 = ws_alloc<u32>(ctx, cap); u32* k1 = ws_alloc<u32>(ctx, cap);
+    u32* v0 = ws_alloc<u32>(ctx, cap); u32* v1 = ws_alloc<u32>(ctx, cap);
+    u32* counter = ws_alloc<u32>(ctx, 64);
+    char* temp = ws_alloc<char>(ctx, sort_temp + 256);
+    if (!k0 || !k1 || !v0 || !v1 || !counter || !temp) { ctx->err = "msm: workspace too small"; return ZKPOR_E_OOM; }
+    out->cfg = cfg;
+    {
+        PhaseScope ps(ctx, "msm_decompose");
+        ZK_HIP(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
+        ZK_TRY(launch_decompose(ctx, d_scalars, (u32)n, cfg, k0, v0, counter));
+    }
+    u32 M = 0;
+    ZK_HIP(ctx, hipMemcpyAsync(&M, counter, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->M = M;
+    out->keys = k0; out->vals = v0;
+    if (M > 1) {
+        PhaseScope ps(ctx, "msm_sort");
+        ZK_TRY(sort_pairs(ctx, temp, sort_temp, k0, k1, v0, v1, M, cfg.key_bits, &out->keys, &out->vals));
+    }
+    return ZKPOR_OK;
+}
+
+template <class F>
+inline size_t accumulate_ws_bytes(const MsmCfg& cfg, size_t max_entries) {
+    WsPlan p;
+    size_t T1 = (max_entries + cfg.L - 1) / cfg.L;
+    size_t T2 = (2 * T1 + cfg.L - 1) / cfg.L;
+    p.add<XYZZ<F>>(cfg.NB);
+    p.add<XYZZ<F>>(2 * T1 + 2); p.add<u32>(2 * T1 + 2);
+    p.add<XYZZ<F>>(2 * T2 + 2); p.add<u32>(2 * T2 + 2);
+    size_t n1tot = (size_t)cfg.n1 * cfg.W, n2tot = (size_t)cfg.n2 * cfg.W;
+    p.add<XYZZ<F>>(n1tot); p.add<XYZZ<F>>(n1tot);   // S1, W1
+    p.add<XYZZ<F>>(n2tot); p.add<XYZZ<F>>(n2tot);   // S2, W2
+    p.add<XYZZ<F>>(n2tot);                          // T1 (partial sums of W1)
+    p.add<XYZZ<F>>(4 * (size_t)cfg.W);              // S3, W3, sumW1, sumW2
+    return p.total;
+}
+
+// bucket accumulation + reduction for one point array against a sorted digit stream; result = sum digits*points
+// as one XYZZ point on the host.
+template <class F>
+inline int32_t msm_accumulate(zkpor_ctx* ctx, const DigitStream& ds, const Affine<F>* d_pts, XYZZ<F>* result) {
+    const MsmCfg& cfg = ds.cfg;
+    if (ds.M == 0) { *result = XYZZ<F>::inf(); return ZKPOR_OK; }
+    const u32 M = ds.M;
+    const int L = cfg.L;
+    size_t T1 = ((size_t)M + L - 1) / L;
+    size_t T2 = (2 * T1 + L - 1) / L;
+    XYZZ<F>* buckets = ws_alloc<XYZZ<F>>(ctx, cfg.NB);
+    XYZZ<F>* pa = ws_alloc<XYZZ<F>>(ctx, 2 * T1 + 2); u32* ka = ws_alloc<u32>(ctx, 2 * T1 + 2);
+    XYZZ<F>* pb = ws_alloc<XYZZ<F>>(ctx, 2 * T2 + 2); u32* kb = ws_alloc<u32>(ctx, 2 * T2 + 2);
+    size_t n1tot = (size_t)cfg.n1 * cfg.W, n2tot = (size_t)cfg.n2 * cfg.W;
+    XYZZ<F>* S1 = ws_alloc<XYZZ<F>>(ctx, n1tot); XYZZ<F>* W1 = ws_alloc<XYZZ<F>>(ctx, n1tot);
+    XYZZ<F>* S2 = ws_alloc<XYZZ<F>>(ctx, n2tot); XYZZ<F>* W2 = ws_alloc<XYZZ<F>>(ctx, n2tot);
+    XYZZ<F>* Tw = ws_alloc<XYZZ<F>>(ctx, n2tot);
+    XYZZ<F>* fin = ws_alloc<XYZZ<F>>(ctx, 4 * (size_t)cfg.W);
+    if (!buckets || !pa || !ka || !pb || !kb || !S1 || !W1 || !S2 || !W2 || !Tw || !fin) {
+        ctx->err = "msm: workspace too small"; return ZKPOR_E_OOM;
+    }
+    {
+        PhaseScope ps(ctx, "msm_accumulate");
+        ZK_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)cfg.NB * sizeof(XYZZ<F>), ctx->stream));
+        ZK_TRY(launch_level1(ctx, ds.keys, ds.vals, d_pts, M, L, buckets, ka, pa));
+        size_t T = T1;
+        XYZZ<F>* src = pa; u32* srck = ka; XYZZ<F>* dst = pb; u32* dstk = kb;
+        while (T > 1) {
+            u32 Mn = (u32)(2 * T);
+            size_t Tn = ((size_t)Mn + L - 1) / L;
+            ZK_TRY(launch_levelN(ctx, srck, src, Mn, L, buckets, dstk, dst));
+            std::swap(src, dst); std::swap(srck, dstk);
+            T = Tn;
+        }
+    }
+    {
+        PhaseScope ps(ctx, "msm_reduce");
+        const u32 Wn = (u32)cfg.W;
+        auto launch = [&](const XYZZ<F>* in, u32 ng, u32 g, XYZZ<F>* oS, XYZZ<F>* oW) {
+            (void)launch_reduce(ctx, in, ng, g, oS, oW);
+        };
+        launch(buckets, cfg.n1 * Wn, cfg.g1, S1, W1);                 // level 1
+        launch(S1, cfg.n2 * Wn, cfg.g2, S2, W2);                      // level 2
+        launch(S2, Wn, cfg.n2, fin, fin + Wn);                        // level 3: S3, W3 per window
+        launch(W1, cfg.n2 * Wn, cfg.g2, Tw, (XYZZ<F>*)nullptr);       // sum of W1: n1 -> n2 per window
+        launch(Tw, Wn, cfg.n2, fin + 2 * Wn, (XYZZ<F>*)nullptr);      //            n2 -> 1
+        launch(W2, Wn, cfg.n2, fin + 3 * Wn, (XYZZ<F>*)nullptr);      // sum of W2
+        ZK_KERNEL_CHECK(ctx);
+    }
+    std::vector<XYZZ<F>> h(4 * (size_t)cfg.W);
+    ZK_HIP(ctx, hipMemcpyAsync(h.data(), fin, h.size() * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // window sum = sumW1 + g1*( sumW2 + g2*(W3 - S3) - S3 ), then Horner with 2^c
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int w = cfg.W - 1; w >= 0; --w) {
+        for (int k = 0; k < cfg.c; ++k) acc = xyzz_dbl<F>(acc);
+        const XYZZ<F>& S3 = h[w];
+        const XYZZ<F>& W3 = h[cfg.W + w];
+        const XYZZ<F>& sW1 = h[2 * cfg.W + w];
+        const XYZZ<F>& sW2 = h[3 * cfg.W + w];
+        XYZZ<F> negS3 = xyzz_neg<F>(S3);
+        XYZZ<F> inner = W3;
+        xyzz_add<F>(inner, negS3);
+        inner = xyzz_mul_u64<F>(inner, cfg.g2);
+        xyzz_add<F>(inner, sW2);
+        xyzz_add<F>(inner, negS3);
+        inner = xyzz_mul_u64<F>(inner, cfg.g1);
+        xyzz_add<F>(inner, sW1);
+        xyzz_add<F>(acc, inner);
+    }
+    *result = acc;
+    return ZKPOR_OK;
+}
+
+// whole MSM for device-resident points and scalars
+template <class F>
+inline int32_t msm_dev(zkpor_ctx* ctx, const Affine<F>* d_pts, const Fr* d_scalars, size_t n, XYZZ<F>* result) {
+    if (n == 0) { *result = XYZZ<F>::inf(); return ZKPOR_OK; }
+    MsmCfg cfg = msm_cfg(ctx, n);
+    size_t sort_temp = 0;
+    size_t need = digits_ws_bytes(ctx, n, cfg, &sort_temp) + accumulate_ws_bytes<F>(cfg, n * (size_t)cfg.W);
+    ZK_TRY(ws_reserve(ctx, need));
+    DigitStream ds;
+    ZK_TRY(msm_digits(ctx, d_scalars, n, cfg, sort_temp, &ds));
+    return msm_accumulate<F>(ctx, ds, d_pts, result);
+}
+
+}  // namespace zk

@@ -1,0 +1,17 @@
+// MSM steps 3 (levels >= 2) and 4 for G1: <10% of the MSM time, built with out-of-line field products
+// (-DZK_MUL_NOINLINE) to keep code size and compile time down.
+#include "msm_kernels.cuh"
+namespace zk {
+int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp>* src, u32 M, int L, XYZZ<Fp>* buckets,
+                      u32* out_keys, XYZZ<Fp>* out_part) {
+    u32 T = (M + (u32)L - 1u) / (u32)L;
+    hipLaunchKernelGGL(k_acc_levelN<Fp>, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, src, M, L, buckets, out_keys, out_part);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp>* in, u32 n_groups, u32 g, XYZZ<Fp>* outS, XYZZ<Fp>* outW) {
+    hipLaunchKernelGGL(k_reduce_groups<Fp>, dim3((n_groups + 63u) / 64u), dim3(64), 0, ctx->stream, in, n_groups, g, outS, outW);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+}  // namespace zk

@@ -1,0 +1,121 @@
+// Device kernels of the Pippenger MSM (see msm.cuh for the algorithm).  Included only by the translation units
+// that instantiate them: msm_digits.hip, msm_g1_hot.hip, msm_g1_cold.hip, msm_g2.hip.
+#pragma once
+#include "msm.cuh"
+
+namespace zk {
+
+// ------------------------------------------------------------------------------------------------ accumulate
+template <class F>
+struct AccOut {
+    XYZZ<F>* buckets;
+    u32* out_keys;
+    XYZZ<F>* out_part;
+};
+
+// Level 1: affine key points gathered through the sorted (key,val) stream.
+template <class F>
+__global__ __launch_bounds__(256) void k_acc_level1(const u32* __restrict__ keys, const u32* __restrict__ vals,
+                                                    const Affine<F>* __restrict__ pts, u32 M, int L,
+                                                    XYZZ<F>* __restrict__ buckets, u32* __restrict__ out_keys,
+                                                    XYZZ<F>* __restrict__ out_part) {
+    const u32 t = blockIdx.x * 256u + threadIdx.x;
+    const u32 T = (M + (u32)L - 1u) / (u32)L;
+    if (t >= T) return;
+    const u32 start = t * (u32)L;
+    const u32 end = (start + (u32)L < M) ? start + (u32)L : M;
+    const u32 prev = start > 0 ? keys[start - 1] : NOKEY;
+    const u32 next = end < M ? keys[end] : NOKEY;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    u32 cur = keys[start];
+    bool first = true, head_written = false, tail_written = false;
+    for (u32 j = start; j < end; ++j) {
+        const u32 k = keys[j];
+        const u32 v = vals[j];
+        if (k != cur) {
+            if (first && cur == prev) { out_part[2 * t] = acc; head_written = true; }
+            else buckets[cur] = acc;
+            first = false;
+            cur = k;
+            acc = XYZZ<F>::inf();
+        }
+        Affine<F> p = pts[v >> 1];
+        if (!p.is_inf()) {
+            if (v & 1u) p.y = F::neg(p.y);
+            xyzz_madd<F>(acc, p.x, p.y);
+        }
+    }
+    if (first && cur == prev) { out_part[2 * t] = acc; head_written = true; }
+    else if (cur == next) { out_part[2 * t + 1] = acc; tail_written = true; }
+    else buckets[cur] = acc;
+    if (T > 1) {
+        if (!head_written) out_part[2 * t] = XYZZ<F>::inf();
+        if (!tail_written) out_part[2 * t + 1] = XYZZ<F>::inf();
+        out_keys[2 * t] = keys[start];
+        out_keys[2 * t + 1] = keys[end - 1];
+    }
+}
+
+// Level >= 2: the entries are XYZZ partial sums (keys still sorted); finished runs are ADDED into their bucket
+// (a bucket is touched by exactly one thread per level, and levels are separate launches).
+template <class F>
+__global__ __launch_bounds__(256) void k_acc_levelN(const u32* __restrict__ keys, const XYZZ<F>* __restrict__ src,
+                                                    u32 M, int L, XYZZ<F>* __restrict__ buckets,
+                                                    u32* __restrict__ out_keys, XYZZ<F>* __restrict__ out_part) {
+    const u32 t = blockIdx.x * 256u + threadIdx.x;
+    const u32 T = (M + (u32)L - 1u) / (u32)L;
+    if (t >= T) return;
+    const u32 start = t * (u32)L;
+    const u32 end = (start + (u32)L < M) ? start + (u32)L : M;
+    const u32 prev = start > 0 ? keys[start - 1] : NOKEY;
+    const u32 next = end < M ? keys[end] : NOKEY;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    u32 cur = keys[start];
+    bool first = true, head_written = false, tail_written = false;
+    auto finish = [&](u32 key) {
+        if (acc.is_inf()) return;
+        XYZZ<F> b = buckets[key];
+        buckets[key] = xyzz_add_nl<F>(b, acc);
+    };
+    for (u32 j = start; j < end; ++j) {
+        const u32 k = keys[j];
+        if (k != cur) {
+            if (first && cur == prev) { out_part[2 * t] = acc; head_written = true; }
+            else finish(cur);
+            first = false;
+            cur = k;
+            acc = XYZZ<F>::inf();
+        }
+        XYZZ<F> p = src[j];
+        acc = xyzz_add_nl<F>(acc, p);
+    }
+    if (first && cur == prev) { out_part[2 * t] = acc; head_written = true; }
+    else if (cur == next) { out_part[2 * t + 1] = acc; tail_written = true; }
+    else finish(cur);
+    if (T > 1) {
+        if (!head_written) out_part[2 * t] = XYZZ<F>::inf();
+        if (!tail_written) out_part[2 * t + 1] = XYZZ<F>::inf();
+        out_keys[2 * t] = keys[start];
+        out_keys[2 * t + 1] = keys[end - 1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ reduce
+// group j covers in[j*g .. j*g+g): outS[j] = sum x_k, outW[j] = sum (k+1) x_k  (running sums from the top)
+template <class F>
+__global__ __launch_bounds__(64) void k_reduce_groups(const XYZZ<F>* __restrict__ in, u32 n_groups, u32 g,
+                                                      XYZZ<F>* __restrict__ outS, XYZZ<F>* __restrict__ outW) {
+    const u32 j = blockIdx.x * 64u + threadIdx.x;
+    if (j >= n_groups) return;
+    XYZZ<F> run = XYZZ<F>::inf(), wacc = XYZZ<F>::inf();
+    const XYZZ<F>* base = in + (size_t)j * g;
+    for (u32 k = g; k-- > 0;) {
+        XYZZ<F> x = base[k];
+        run = xyzz_add_nl<F>(run, x);
+        if (outW) wacc = xyzz_add_nl<F>(wacc, run);
+    }
+    outS[j] = run;
+    if (outW) outW[j] = wacc;
+}
+
+}  // namespace zk
