@@ -1,0 +1,46 @@
+"""-m gpu: bit-exact parity of the HIP NTT / computeH (through the C ABI) with the CPU oracle's restatement of
+gnark-crypto fft.Domain.FFT / FFTInverse and gnark computeH."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("log2n", [1, 2, 3, 7, 8, 9, 10, 13, 17, 18])
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("decimation", [O.DIT, O.DIF])
+@pytest.mark.parametrize("coset", [False, True])
+def test_fft_matches_oracle(zk, log2n, inverse, decimation, coset):
+    a = O.fr_random(1000 + log2n, 1 << log2n)
+    got = zk.fft(a, log2n, inverse, decimation, coset)
+    ref = O.fft(a, log2n, inverse, decimation, coset)
+    assert np.array_equal(got, ref)
+
+
+def test_fft_roundtrip_2_20(zk):
+    # size-independent property at a larger size: iFFT_DIT(FFT_DIF(x)) == x on the coset
+    n = 20
+    a = O.fr_random(77, 1 << n)
+    f = zk.fft(a, n, False, O.DIF, True)
+    back = zk.fft(f, n, True, O.DIT, True)
+    assert np.array_equal(back, a)
+
+
+@pytest.mark.parametrize("log2d,ncons", [(3, 5), (8, 256), (10, 1000), (12, 4096), (17, 100000)])
+def test_compute_h_matches_oracle(zk, log2d, ncons):
+    a = O.fr_random(1, ncons); b = O.fr_random(2, ncons)
+    c = O.fr_mul(a, b)
+    got = zk.compute_h(a, b, c, log2d)
+    ref = O.compute_h(a, b, c, log2d)
+    assert np.array_equal(got, ref)
+
+
+def test_compute_h_zero_and_ragged(zk):
+    # n_constraints = 0..1: zero padding path; h of the zero polynomial is zero
+    z = np.zeros((1, 4), np.uint64)
+    assert not zk.compute_h(z, z, z, 6).any()
+    a = O.fr_random(3, 1)
+    got = zk.compute_h(a, a, O.fr_mul(a, a), 6)
+    assert np.array_equal(got, O.compute_h(a, a, O.fr_mul(a, a), 6))

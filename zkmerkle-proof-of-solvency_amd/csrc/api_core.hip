@@ -1,6 +1,7 @@
 // C ABI (include/zkpor.h): context, device memory helpers, tuning, phase timers, generic MSM entry points.
 #include "common.cuh"
 #include "msm.cuh"
+#include "ntt.cuh"
 
 using namespace zk;
 
@@ -95,6 +96,7 @@ void zkpor_destroy(zkpor_ctx* ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pos_tables) (void)hipFree(ctx->pos_tables);
+    ntt_domains_free(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

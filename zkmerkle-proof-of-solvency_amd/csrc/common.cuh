@@ -31,6 +31,8 @@ struct zkpor_ctx {
     int pos_out = 1, pos_carry = 0;
     // Poseidon parameter tables on device (built lazily)
     void* pos_tables = nullptr;
+    // NTT domains by log2 size (ntt.cuh NttDomain*)
+    std::map<int, void*> ntt_domains;
     // timers
     std::map<std::string, PhaseTimer> phases;
     std::vector<hipEvent_t> event_pool;

@@ -1,0 +1,463 @@
+// HBM-resident Groth16 proving key and the prove tail (everything groth16.Prove does after the R1CS solver):
+// computeH, the A / B1 / B2 / K / Z multi-exponentiations, r/s blinding, and the Pedersen commitment MSMs.
+// Reference: src/prover/prover/prover.go:269 (groth16.Prove), :285-367 (LoadSnarkParamsOnce), :201 (WriteRawTo);
+// algorithm restated from bnb-chain/gnark backend/groth16/bn254/prove.go.
+#include "common.cuh"
+#include "msm.cuh"
+#include "ntt.cuh"
+#include <new>
+
+using namespace zk;
+
+struct zkpor_pk {
+    zkpor_ctx* ctx = nullptr;
+    // as uploaded (gnark's compacted arrays)
+    void* g1_raw[ZKPOR_G1_NUM] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t g1_raw_n[ZKPOR_G1_NUM] = {0, 0, 0, 0, 0, 0};
+    void* g2_raw = nullptr;
+    size_t g2_raw_n = 0;
+    // wire-indexed / final arrays
+    G1Affine *A = nullptr, *B1 = nullptr, *K = nullptr, *Z = nullptr, *CB = nullptr, *CBS = nullptr;
+    G2Affine* B2 = nullptr;
+    size_t n_wires = 0, n_public = 0, nZ = 0, nC = 0;
+    int log2_domain = 0;
+    G1Affine alpha, beta, delta;
+    G2Affine beta2, delta2;
+    bool ready = false;
+};
+
+namespace {
+
+// dst[i] = map[i] == 0xffffffff ? infinity : src[map[i]]
+template <class P>
+__global__ void k_expand(const P* __restrict__ src, const u32* __restrict__ map, P* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 m = map[i];
+    P out;
+    if (m == 0xffffffffu) memset(&out, 0, sizeof(P)); else out = src[m];
+    dst[i] = out;
+}
+
+template <class P>
+int32_t expand(zkpor_ctx* ctx, const void* raw, size_t raw_n, const std::vector<u32>& map, P** out) {
+    size_t n = map.size();
+    u32* dmap = nullptr;
+    P* dst = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&dmap, n * 4 + 4));
+    if (hipMalloc((void**)&dst, n * sizeof(P) + 16) != hipSuccess) { (void)hipFree(dmap); ctx->err = "pk: out of device memory"; return ZKPOR_E_OOM; }
+    ZK_HIP(ctx, hipMemcpyAsync(dmap, map.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_expand<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const P*)raw, dmap, dst, n);
+    ZK_KERNEL_CHECK(ctx);
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dmap);
+    (void)raw_n;
+    *out = dst;
+    return ZKPOR_OK;
+}
+
+// ---- synthetic key generation (TEST/BENCH utility) -------------------------------------------------------
+__host__ __device__ inline u64 smix(u64 x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+static const int SYNTH_RUN = 32;
+// scalar of point i of array `arr`: k(run) + j*q with 64-bit k, q — the trapdoor the parity tests recompute
+__host__ __device__ inline u64 synth_k(u64 seed, int arr, u64 run) {
+    u64 x = seed ^ ((u64)(arr + 1) * 0xa0761d6478bd642fULL) ^ (run * 0xe7037ed1a0b428dbULL);
+    return smix(x) | 1ULL;
+}
+static const u64 SYNTH_Q = 0x9e3779b97f4a7c15ULL;
+
+// infinity pattern of the synthetic wire-indexed arrays: 0 none, else i is infinity when hash(i) % mod == 0
+__host__ __device__ inline bool synth_is_inf(u64 i, u32 mod) {
+    if (!mod) return false;
+    u64 x = i * 0xd6e8feb86659fd93ULL;
+    x ^= x >> 32;
+    return (x % mod) == 0;
+}
+
+template <class F>
+__global__ __launch_bounds__(64) void k_synth_points(Affine<F> gen, Affine<F> qpt, u64 seed, int arr, size_t n,
+                                                     u32 inf_mod, size_t inf_below, Affine<F>* out) {
+    size_t run = (size_t)blockIdx.x * 64 + threadIdx.x;
+    size_t base = run * SYNTH_RUN;
+    if (base >= n) return;
+    u64 k = synth_k(seed, arr, run);
+    XYZZ<F> p = XYZZ<F>::inf();
+    XYZZ<F> g = xyzz_from_affine<F>(gen);
+    for (int b = 63; b >= 0; --b) {
+        p = xyzz_dbl<F>(p);
+        if ((k >> b) & 1) p = xyzz_add_nl<F>(p, g);
+    }
+    // run of SYNTH_RUN points p, p+Q, p+2Q, ... ; batch inversion of ZZ*ZZZ over the run
+    XYZZ<F> pts[SYNTH_RUN];
+    F pref[SYNTH_RUN];
+    F accp = F::one();
+    XYZZ<F> q = xyzz_from_affine<F>(qpt);
+    for (int j = 0; j < SYNTH_RUN; ++j) {
+        pts[j] = p;
+        pref[j] = accp;
+        accp = F::mul(accp, F::mul(p.zz, p.zzz));
+        p = xyzz_add_nl<F>(p, q);
+    }
+    F inv = F::inv(accp);
+    for (int j = SYNTH_RUN - 1; j >= 0; --j) {
+        F zi = F::mul(inv, pref[j]);                       // 1/(zz*zzz) of point j
+        inv = F::mul(inv, F::mul(pts[j].zz, pts[j].zzz));
+        size_t i = base + j;
+        if (i < n) {
+            Affine<F> a;
+            if (i < inf_below || synth_is_inf(i, inf_mod)) { a.x = F::zero(); a.y = F::zero(); }
+            else { a.x = F::mul(pts[j].x, F::mul(zi, pts[j].zzz)); a.y = F::mul(pts[j].y, F::mul(zi, pts[j].zz)); }
+            out[i] = a;
+        }
+    }
+}
+
+G1Affine g1_generator() {
+    G1Affine g;
+    g.x = Fp::from_u32(1);
+    g.y = Fp::from_u32(2);
+    return g;
+}
+G2Affine g2_generator() {
+    static const u32 x0[8] = {0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu};
+    static const u32 x1[8] = {0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u};
+    static const u32 y0[8] = {0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u};
+    static const u32 y1[8] = {0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u};
+    auto mk = [](const u32* l) { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = l[i]; return Fp::to_mont(r); };
+    G2Affine g;
+    g.x = {mk(x0), mk(x1)};
+    g.y = {mk(y0), mk(y1)};
+    return g;
+}
+
+template <class F>
+int32_t synth_array(zkpor_ctx* ctx, const Affine<F>& gen, u64 seed, int arr, size_t n, u32 inf_mod, size_t inf_below,
+                    Affine<F>** out) {
+    Affine<F>* d = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&d, (n ? n : 1) * sizeof(Affine<F>) + 16));
+    if (n) {
+        // Q = SYNTH_Q * gen (host)
+        XYZZ<F> q = xyzz_mul_u64<F>(xyzz_from_affine<F>(gen), SYNTH_Q);
+        Affine<F> qa = xyzz_to_affine<F>(q);
+        size_t runs = (n + SYNTH_RUN - 1) / SYNTH_RUN;
+        hipLaunchKernelGGL(k_synth_points<F>, dim3((unsigned)((runs + 63) / 64)), dim3(64), 0, ctx->stream, gen, qa, seed,
+                           arr, n, inf_mod, inf_below, d);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    *out = d;
+    return ZKPOR_OK;
+}
+
+void pk_free_arrays(zkpor_pk* pk) {
+    for (int i = 0; i < ZKPOR_G1_NUM; ++i) if (pk->g1_raw[i]) { (void)hipFree(pk->g1_raw[i]); pk->g1_raw[i] = nullptr; }
+    if (pk->g2_raw) { (void)hipFree(pk->g2_raw); pk->g2_raw = nullptr; }
+    void* arrs[] = {pk->A, pk->B1, pk->K, pk->Z, pk->CB, pk->CBS, pk->B2};
+    for (void* p : arrs) if (p) (void)hipFree(p);
+    pk->A = pk->B1 = pk->K = pk->Z = pk->CB = pk->CBS = nullptr;
+    pk->B2 = nullptr;
+    pk->ready = false;
+}
+
+inline G1XYZZ g1x(const G1Affine& a) { return xyzz_from_affine<Fp>(a); }
+
+}  // namespace
+
+extern "C" {
+
+int32_t zkpor_pk_create(zkpor_ctx* ctx, zkpor_pk** out) {
+    if (!ctx || !out) return ZKPOR_E_ARG;
+    zkpor_pk* pk = new (std::nothrow) zkpor_pk();
+    if (!pk) return ZKPOR_E_OOM;
+    pk->ctx = ctx;
+    *out = pk;
+    return ZKPOR_OK;
+}
+void zkpor_pk_destroy(zkpor_pk* pk) {
+    if (!pk) return;
+    (void)hipStreamSynchronize(pk->ctx->stream);
+    pk_free_arrays(pk);
+    delete pk;
+}
+
+int32_t zkpor_pk_set_g1(zkpor_pk* pk, int which, const void* pts, size_t n) {
+    if (!pk || which < 0 || which >= ZKPOR_G1_NUM || (n && !pts)) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = pk->ctx;
+    if (pk->g1_raw[which]) { ZK_HIP(ctx, hipFree(pk->g1_raw[which])); pk->g1_raw[which] = nullptr; }
+    ZK_HIP(ctx, hipMalloc(&pk->g1_raw[which], (n ? n : 1) * 64));
+    ZK_HIP(ctx, hipMemcpyAsync(pk->g1_raw[which], pts, n * 64, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pk->g1_raw_n[which] = n;
+    pk->ready = false;
+    return ZKPOR_OK;
+}
+int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n) {
+    if (!pk || which != ZKPOR_G2_B || (n && !pts)) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = pk->ctx;
+    if (pk->g2_raw) { ZK_HIP(ctx, hipFree(pk->g2_raw)); pk->g2_raw = nullptr; }
+    ZK_HIP(ctx, hipMalloc(&pk->g2_raw, (n ? n : 1) * 128));
+    ZK_HIP(ctx, hipMemcpyAsync(pk->g2_raw, pts, n * 128, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pk->g2_raw_n = n;
+    pk->ready = false;
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, const void* delta, const void* beta2,
+                            const void* delta2, int log2_domain, const uint8_t* inf_a, const uint8_t* inf_b,
+                            size_t n_wires, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
+                            int z_order) {
+    if (!pk || !alpha || !beta || !delta || !beta2 || !delta2 || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = pk->ctx;
+    if (n_wires == 0 || n_wires >= 0xffffffffull || n_public > n_wires) { ctx->err = "pk: bad wire counts"; return ZKPOR_E_ARG; }
+    memcpy(&pk->alpha, alpha, 64); memcpy(&pk->beta, beta, 64); memcpy(&pk->delta, delta, 64);
+    memcpy(&pk->beta2, beta2, 128); memcpy(&pk->delta2, delta2, 128);
+    pk->log2_domain = log2_domain;
+    pk->n_wires = n_wires; pk->n_public = n_public;
+    // index maps wire -> position in gnark's compacted arrays
+    std::vector<u32> mapA(n_wires), mapB(n_wires), mapK(n_wires);
+    u32 ra = 0, rb = 0, rk = 0;
+    std::vector<uint8_t> removed(n_wires, 0);
+    for (size_t i = 0; i < n_public; ++i) removed[i] = 1;
+    for (size_t j = 0; j < n_committed; ++j) {
+        if (committed_idx[j] >= n_wires) { ctx->err = "pk: committed index out of range"; return ZKPOR_E_ARG; }
+        removed[committed_idx[j]] = 1;
+    }
+    for (size_t i = 0; i < n_wires; ++i) {
+        mapA[i] = (inf_a && inf_a[i]) ? 0xffffffffu : ra++;
+        mapB[i] = (inf_b && inf_b[i]) ? 0xffffffffu : rb++;
+        mapK[i] = removed[i] ? 0xffffffffu : rk++;
+    }
+    if (ra != pk->g1_raw_n[ZKPOR_G1_A] || rb != pk->g1_raw_n[ZKPOR_G1_B] || rb != pk->g2_raw_n || rk != pk->g1_raw_n[ZKPOR_G1_K]) {
+        ctx->err = "pk: array lengths do not match the infinity / committed masks";
+        return ZKPOR_E_STATE;
+    }
+    size_t D = (size_t)1 << log2_domain;
+    if (pk->g1_raw_n[ZKPOR_G1_Z] != D - 1) { ctx->err = "pk: Z must hold 2^log2_domain - 1 points"; return ZKPOR_E_STATE; }
+    if (pk->g1_raw_n[ZKPOR_G1_COMMIT_BASIS] != pk->g1_raw_n[ZKPOR_G1_COMMIT_BASIS_SIGMA]) { ctx->err = "pk: commitment bases differ in length"; return ZKPOR_E_STATE; }
+    void* olds[] = {pk->A, pk->B1, pk->K, pk->Z, pk->CB, pk->CBS, pk->B2};
+    for (void* p : olds) if (p) (void)hipFree(p);
+    pk->A = pk->B1 = pk->K = pk->Z = pk->CB = pk->CBS = nullptr; pk->B2 = nullptr;
+    ZK_TRY(expand<G1Affine>(ctx, pk->g1_raw[ZKPOR_G1_A], ra, mapA, &pk->A));
+    ZK_TRY(expand<G1Affine>(ctx, pk->g1_raw[ZKPOR_G1_B], rb, mapB, &pk->B1));
+    ZK_TRY(expand<G2Affine>(ctx, pk->g2_raw, rb, mapB, &pk->B2));
+    ZK_TRY(expand<G1Affine>(ctx, pk->g1_raw[ZKPOR_G1_K], rk, mapK, &pk->K));
+    // Z: the prover produces h bit-reversed; bring a natural-order Z into that order once
+    pk->nZ = D - 1;
+    {
+        std::vector<u32> mapZ(D - 1);
+        for (size_t j = 0; j + 1 < D; ++j) {
+            if (z_order == ZKPOR_Z_ORDER_NATURAL) {
+                u32 r = 0;
+                for (int b = 0; b < log2_domain; ++b) r |= (u32)((j >> b) & 1) << (log2_domain - 1 - b);
+                mapZ[j] = r;  // r == D-1 only for j == D-1, which is outside the array
+            } else mapZ[j] = (u32)j;
+        }
+        ZK_TRY(expand<G1Affine>(ctx, pk->g1_raw[ZKPOR_G1_Z], D - 1, mapZ, &pk->Z));
+    }
+    pk->nC = pk->g1_raw_n[ZKPOR_G1_COMMIT_BASIS];
+    // commitment bases are used as uploaded: hand the raw buffers over
+    pk->CB = (G1Affine*)pk->g1_raw[ZKPOR_G1_COMMIT_BASIS]; pk->g1_raw[ZKPOR_G1_COMMIT_BASIS] = nullptr;
+    pk->CBS = (G1Affine*)pk->g1_raw[ZKPOR_G1_COMMIT_BASIS_SIGMA]; pk->g1_raw[ZKPOR_G1_COMMIT_BASIS_SIGMA] = nullptr;
+    // the compacted uploads are no longer needed
+    for (int i = 0; i < ZKPOR_G1_NUM; ++i) if (pk->g1_raw[i]) { (void)hipFree(pk->g1_raw[i]); pk->g1_raw[i] = nullptr; pk->g1_raw_n[i] = 0; }
+    if (pk->g2_raw) { (void)hipFree(pk->g2_raw); pk->g2_raw = nullptr; pk->g2_raw_n = 0; }
+    pk->ready = true;
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, size_t n_committed, uint64_t seed) {
+    if (!pk || log2_domain < 1 || log2_domain > 28 || n_wires == 0 || n_public > n_wires) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = pk->ctx;
+    pk_free_arrays(pk);
+    size_t D = (size_t)1 << log2_domain;
+    G1Affine g1 = g1_generator();
+    G2Affine g2 = g2_generator();
+    pk->log2_domain = log2_domain; pk->n_wires = n_wires; pk->n_public = n_public; pk->nZ = D - 1; pk->nC = n_committed;
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_A, n_wires, 64, 0, &pk->A));          // ~1.6% infinity
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_B, n_wires, 10, 0, &pk->B1));         // ~10% infinity
+    ZK_TRY(synth_array<Fp2>(ctx, g2, seed, ZKPOR_G1_B, n_wires, 10, 0, &pk->B2));        // same scalars as B1
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_K, n_wires, 4, n_public, &pk->K));    // public + ~25% "committed"
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_Z, D - 1, 0, 0, &pk->Z));
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_COMMIT_BASIS, n_committed, 0, 0, &pk->CB));
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_COMMIT_BASIS_SIGMA, n_committed, 0, 0, &pk->CBS));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // alpha, beta, delta: fixed small multiples of the generators (host)
+    pk->alpha = xyzz_to_affine<Fp>(xyzz_mul_u64<Fp>(g1x(g1), synth_k(seed, 100, 0)));
+    pk->beta = xyzz_to_affine<Fp>(xyzz_mul_u64<Fp>(g1x(g1), synth_k(seed, 101, 0)));
+    pk->delta = xyzz_to_affine<Fp>(xyzz_mul_u64<Fp>(g1x(g1), synth_k(seed, 102, 0)));
+    pk->beta2 = xyzz_to_affine<Fp2>(xyzz_mul_u64<Fp2>(xyzz_from_affine<Fp2>(g2), synth_k(seed, 101, 0)));
+    pk->delta2 = xyzz_to_affine<Fp2>(xyzz_mul_u64<Fp2>(xyzz_from_affine<Fp2>(g2), synth_k(seed, 102, 0)));
+    pk->ready = true;
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
+    if (!pk || !dev_ptr || !n) return ZKPOR_E_ARG;
+    if (!pk->ready) return ZKPOR_E_STATE;
+    switch (which) {
+        case ZKPOR_G1_A: *dev_ptr = pk->A; *n = pk->n_wires; break;
+        case ZKPOR_G1_B: *dev_ptr = pk->B1; *n = pk->n_wires; break;
+        case ZKPOR_G1_K: *dev_ptr = pk->K; *n = pk->n_wires; break;
+        case ZKPOR_G1_Z: *dev_ptr = pk->Z; *n = pk->nZ; break;
+        case ZKPOR_G1_COMMIT_BASIS: *dev_ptr = pk->CB; *n = pk->nC; break;
+        case ZKPOR_G1_COMMIT_BASIS_SIGMA: *dev_ptr = pk->CBS; *n = pk->nC; break;
+        default: return ZKPOR_E_ARG;
+    }
+    return ZKPOR_OK;
+}
+int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
+    if (!pk || !dev_ptr || !n || which != ZKPOR_G2_B) return ZKPOR_E_ARG;
+    if (!pk->ready) return ZKPOR_E_STATE;
+    *dev_ptr = pk->B2; *n = pk->n_wires;
+    return ZKPOR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ prove tail
+int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c,
+                             const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+    if (!ctx || !pk || !d_w || !d_a || !d_b || !d_c || !r || !s || !proof_out) return ZKPOR_E_ARG;
+    if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
+    const int n = pk->log2_domain;
+    const size_t D = (size_t)1 << n;
+    // 1. h = computeH(a,b,c), left in d_a (bit-reversed = the order of pk->Z)
+    ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
+    // 2. one digit stream of the witness serves A, B1, B2, K
+    MsmCfg cfgw = msm_cfg(ctx, pk->n_wires);
+    MsmCfg cfgh = msm_cfg(ctx, D - 1);
+    size_t sortw = 0, sorth = 0;
+    size_t needw = digits_ws_bytes(ctx, pk->n_wires, cfgw, &sortw) + accumulate_ws_bytes<Fp2>(cfgw, pk->n_wires * (size_t)cfgw.W);
+    size_t needh = digits_ws_bytes(ctx, D - 1, cfgh, &sorth) + accumulate_ws_bytes<Fp>(cfgh, (D - 1) * (size_t)cfgh.W);
+    ZK_TRY(ws_reserve(ctx, needw > needh ? needw : needh));
+    DigitStream dsw;
+    ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw));
+    size_t mark = ctx->ws_off;
+    G1XYZZ mA, mB1, mK, mZ;
+    G2XYZZ mB2;
+    ZK_TRY(msm_accumulate<Fp>(ctx, dsw, pk->A, &mA));
+    ctx->ws_off = mark;
+    ZK_TRY(msm_accumulate<Fp>(ctx, dsw, pk->B1, &mB1));
+    ctx->ws_off = mark;
+    ZK_TRY(msm_accumulate<Fp>(ctx, dsw, pk->K, &mK));
+    ctx->ws_off = mark;
+    ZK_TRY(msm_accumulate<Fp2>(ctx, dsw, pk->B2, &mB2));
+    // 3. Z . h
+    ctx->ws_off = 0;
+    DigitStream dsh;
+    ZK_TRY(msm_digits(ctx, (const Fr*)d_a, D - 1, cfgh, sorth, &dsh));
+    ZK_TRY(msm_accumulate<Fp>(ctx, dsh, pk->Z, &mZ));
+    // 4. blinding and assembly on the host (a few hundred group operations)
+    Fr rm, sm;
+    memcpy(&rm, r, 32); memcpy(&sm, s, 32);
+    Fr rc = Fr::from_mont(rm), sc = Fr::from_mont(sm);
+    Fr krm = Fr::neg(Fr::mul(rm, sm));
+    Fr krc = Fr::from_mont(krm);
+    G1XYZZ d1 = g1x(pk->delta);
+    G1XYZZ ar = mA;
+    xyzz_add<Fp>(ar, g1x(pk->alpha));
+    xyzz_add<Fp>(ar, xyzz_mul_limbs<Fp>(d1, rc.v));
+    G1XYZZ bs1 = mB1;
+    xyzz_add<Fp>(bs1, g1x(pk->beta));
+    xyzz_add<Fp>(bs1, xyzz_mul_limbs<Fp>(d1, sc.v));
+    G2XYZZ bs2 = mB2;
+    xyzz_add<Fp2>(bs2, xyzz_from_affine<Fp2>(pk->beta2));
+    xyzz_add<Fp2>(bs2, xyzz_mul_limbs<Fp2>(xyzz_from_affine<Fp2>(pk->delta2), sc.v));
+    G1XYZZ krs = mK;
+    xyzz_add<Fp>(krs, mZ);
+    xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(d1, krc.v));
+    xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(ar, sc.v));
+    xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(bs1, rc.v));
+    G1Affine ara = xyzz_to_affine<Fp>(ar), krsa = xyzz_to_affine<Fp>(krs);
+    G2Affine bsa = xyzz_to_affine<Fp2>(bs2);
+    memcpy(proof_out, &ara, 64); memcpy(proof_out + 64, &bsa, 128); memcpy(proof_out + 192, &krsa, 64);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                         const uint64_t* c, size_t n_constraints, const uint64_t r[4], const uint64_t s[4],
+                         uint8_t proof_out[256]) {
+    if (!ctx || !pk || !w || !a || !b || !c) return ZKPOR_E_ARG;
+    if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
+    size_t D = (size_t)1 << pk->log2_domain;
+    if (n_constraints > D) { ctx->err = "prove: more constraints than the domain"; return ZKPOR_E_ARG; }
+    Fr* d = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&d, (3 * D + pk->n_wires) * sizeof(Fr)));
+    int32_t rc = ZKPOR_OK;
+    const uint64_t* src[3] = {a, b, c};
+    for (int i = 0; i < 3 && rc == ZKPOR_OK; ++i) {
+        if (hipMemsetAsync(d + i * D, 0, D * sizeof(Fr), ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d + i * D, src[i], n_constraints * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            ctx->err = "H2D failed"; rc = ZKPOR_E_HIP;
+        }
+    }
+    if (rc == ZKPOR_OK && hipMemcpyAsync(d + 3 * D, w, pk->n_wires * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+    if (rc == ZKPOR_OK) rc = zkpor_prove_tail_dev(ctx, pk, d + 3 * D, d, d + D, d + 2 * D, r, s, proof_out);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) {
+    if (!ctx || !pk || (n && !values) || !out_commit || !out_pok) return ZKPOR_E_ARG;
+    if (!pk->ready) { ctx->err = "commit: key not loaded"; return ZKPOR_E_STATE; }
+    if (n != pk->nC) { ctx->err = "commit: value count differs from the commitment basis"; return ZKPOR_E_ARG; }
+    G1XYZZ c1 = G1XYZZ::inf(), c2 = G1XYZZ::inf();
+    if (n) {
+        Fr* d = nullptr;
+        ZK_HIP(ctx, hipMalloc((void**)&d, n * sizeof(Fr)));
+        int32_t rc = ZKPOR_OK;
+        if (hipMemcpyAsync(d, values, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+        MsmCfg cfg = msm_cfg(ctx, n);
+        size_t st = 0;
+        size_t need = digits_ws_bytes(ctx, n, cfg, &st) + accumulate_ws_bytes<Fp>(cfg, n * (size_t)cfg.W);
+        DigitStream ds;
+        if (rc == ZKPOR_OK) rc = ws_reserve(ctx, need);
+        if (rc == ZKPOR_OK) rc = msm_digits(ctx, d, n, cfg, st, &ds);
+        size_t mark = ctx->ws_off;
+        if (rc == ZKPOR_OK) rc = msm_accumulate<Fp>(ctx, ds, pk->CB, &c1);
+        ctx->ws_off = mark;
+        if (rc == ZKPOR_OK) rc = msm_accumulate<Fp>(ctx, ds, pk->CBS, &c2);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d);
+        if (rc != ZKPOR_OK) return rc;
+    }
+    G1Affine a1 = xyzz_to_affine<Fp>(c1), a2 = xyzz_to_affine<Fp>(c2);
+    memcpy(out_commit, &a1, 64); memcpy(out_pok, &a2, 64);
+    return ZKPOR_OK;
+}
+
+static void fp_be(const Fp& x, uint8_t* out) {
+    Fp c = Fp::from_mont(x);
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) out[31 - (i * 4 + j)] = (uint8_t)(c.v[i] >> (8 * j));
+}
+int32_t zkpor_proof_write_raw(const uint8_t proof[256], const uint8_t* commitments, uint32_t n_commitments,
+                              const uint8_t pok[64], uint8_t* out, size_t out_cap, size_t* out_len) {
+    if (!proof || !out || !out_len || (n_commitments && (!commitments || !pok))) return ZKPOR_E_ARG;
+    size_t need = 256 + 4 + (size_t)n_commitments * 64 + 64;
+    if (out_cap < need) return ZKPOR_E_ARG;
+    const Fp* f = (const Fp*)proof;
+    fp_be(f[0], out); fp_be(f[1], out + 32);                          // Ar
+    fp_be(f[3], out + 64); fp_be(f[2], out + 96);                     // Bs.X = A1 | A0
+    fp_be(f[5], out + 128); fp_be(f[4], out + 160);                   // Bs.Y = A1 | A0
+    fp_be(f[6], out + 192); fp_be(f[7], out + 224);                   // Krs
+    out[256] = (uint8_t)(n_commitments >> 24); out[257] = (uint8_t)(n_commitments >> 16);
+    out[258] = (uint8_t)(n_commitments >> 8); out[259] = (uint8_t)n_commitments;
+    size_t off = 260;
+    for (uint32_t i = 0; i < n_commitments; ++i) {
+        const Fp* c = (const Fp*)(commitments + 64 * (size_t)i);
+        fp_be(c[0], out + off); fp_be(c[1], out + off + 32);
+        off += 64;
+    }
+    if (pok) { const Fp* p = (const Fp*)pok; fp_be(p[0], out + off); fp_be(p[1], out + off + 32); }
+    else memset(out + off, 0, 64);
+    off += 64;
+    *out_len = off;
+    return ZKPOR_OK;
+}
+
+}  // extern "C"

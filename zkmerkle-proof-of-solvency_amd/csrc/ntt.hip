@@ -1,0 +1,349 @@
+// Fr-domain NTT and the H-polynomial quotient for gfx950 — replaces gnark-crypto fr/fft (Domain.FFT / FFTInverse
+// with DIF/DIT and OnCoset) and gnark's computeH (backend/groth16/bn254/prove.go), which groth16.Prove runs on the
+// host (reference call site src/prover/prover/prover.go:269).
+//
+// Structure (index algebra proven against a naive DFT in tools/ntt_model.py, which this file transcribes):
+//   the log2(N) index bits are split into fields of <= 9 bits (26 = 8 + 9 + 9).  One launch ("pass") performs all
+//   radix-2 stages of one field on LDS-resident tiles (2^kb field elements x C adjacent columns, <= 64 KiB), so a
+//   2^26 transform is 3 read+write sweeps of HBM instead of 26.  Between fields the four-step twiddle
+//   w_N^(l * k * 2^s0) is applied on the fly from two L2-resident half-size tables (2 x 2^13 entries) rather than a
+//   1 GiB twiddle array; coset powers g^i and the 1/N factor are folded into the load of the first / store of the
+//   last pass the same way.  DIF passes run high field -> low field (natural in, bit-reversed out), DIT passes
+//   low -> high (bit-reversed in, natural out), so computeH never needs a bit-reversal permutation.
+#include "common.cuh"
+#include "ntt.cuh"
+
+namespace zk {
+
+// Fr constants (Montgomery form)
+__host__ __device__ inline Fr fr_const(const u32 (&l)[8]) {
+    Fr r;
+    for (int i = 0; i < 8; ++i) r.v[i] = l[i];
+    return r;
+}
+static const u32 W28_M[8] = {0x80d13d9cu, 0x636e7355u, 0x2445ffd6u, 0xa22bf374u, 0x1eb203d8u, 0x56452ac0u, 0x2963f9e7u, 0x1860ef94u};
+static const u32 FIVE_M[8] = {0x9fffffe6u, 0x1b0d0ef9u, 0xa32a913fu, 0xeaba68a3u, 0xd8dd0689u, 0x47d8eb76u, 0x20f5bbc3u, 0x15d00855u};
+
+// out[e] = base^(e << shift) * mult, e < count
+__global__ void k_pow_table(Fr base, Fr mult, int shift, u32 count, Fr* out) {
+    u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    u64 ex = (u64)e << shift;
+    Fr r = Fr::one(), b = base;
+    while (ex) {
+        if (ex & 1) r = Fr::mul(r, b);
+        b = Fr::sqr(b);
+        ex >>= 1;
+    }
+    out[e] = Fr::mul(r, mult);
+}
+
+ZK_D u32 brev(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+struct PassArgs {
+    Fr* x;
+    int n, lo, kb, clog;
+    const Fr* small;             // w_512^j (forward or inverse), 256 entries
+    const Fr* tw_lo; const Fr* tw_hi; int tb;  // w_N^e = tw_lo[e & mask] * tw_hi[e >> tb]
+    int scale_load, scale_store;  // 0 none, 1 constant, 2 g^p, 3 g^rev(p)   (g tables may carry a folded constant)
+    const Fr* g_lo; const Fr* g_hi;
+    Fr konst;
+};
+
+ZK_D Fr table_pow(const Fr* lo, const Fr* hi, int tb, u32 e) {
+    return Fr::mul(lo[e & ((1u << tb) - 1u)], hi[e >> tb]);
+}
+ZK_D Fr apply_scale(const PassArgs& A, int mode, const Fr& v, u32 p) {
+    if (mode == 1) return Fr::mul(v, A.konst);
+    u32 e = mode == 2 ? p : brev(p, A.n);
+    return Fr::mul(v, table_pow(A.g_lo, A.g_hi, A.tb, e));
+}
+
+template <bool DIF>
+__global__ __launch_bounds__(256) void k_ntt_pass(PassArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Fr* tile = (Fr*)smem_raw;
+    const int kb = A.kb, lo = A.lo, clog = A.clog;
+    const u32 F = 1u << kb, C = 1u << clog;
+    const int s0 = A.n - lo - kb;
+    // block -> (hi, l0) for lo > 0, or hi0 for lo == 0 (columns = consecutive tiles)
+    u32 hi, l0;
+    if (lo > 0) {
+        u32 lgroups = (1u << lo) >> clog;
+        hi = blockIdx.x / lgroups;
+        l0 = (blockIdx.x % lgroups) << clog;
+    } else {
+        hi = blockIdx.x << clog;
+        l0 = 0;
+    }
+    const u32 total = F << clog;
+    // ---- load (+ DIT pre-twiddle / scale)
+    for (u32 idx = threadIdx.x; idx < total; idx += 256u) {
+        u32 m, c, p, li;
+        if (lo > 0) { c = idx & (C - 1u); m = idx >> clog; p = (hi << (lo + kb)) + (m << lo) + l0 + c; li = m * C + c; }
+        else { m = idx & (F - 1u); c = idx >> kb; p = ((hi + c) << kb) + m; li = c * F + m; }
+        Fr v = A.x[p];
+        if (A.scale_load) v = apply_scale(A, A.scale_load, v, p);
+        if (!DIF && lo > 0) {
+            u32 e = ((l0 + c) * brev(m, kb)) << s0;
+            v = Fr::mul(v, table_pow(A.tw_lo, A.tw_hi, A.tb, e));
+        }
+        tile[li] = v;
+    }
+    __syncthreads();
+    // ---- radix-2 stages inside the field
+    const u32 nbf = total >> 1;
+    for (int j = 0; j < kb; ++j) {
+        const int hlog = DIF ? (kb - 1 - j) : j;
+        const u32 half = 1u << hlog;
+        const int tshift = (DIF ? j : (kb - 1 - j)) + (9 - kb);
+        for (u32 t = threadIdx.x; t < nbf; t += 256u) {
+            u32 q, c;
+            if (lo > 0) { c = t & (C - 1u); q = t >> clog; }
+            else { q = t & ((F >> 1) - 1u); c = t >> (kb - 1); }
+            u32 pos = q & (half - 1u);
+            u32 i0 = ((q >> hlog) << (hlog + 1)) + pos;
+            u32 i1 = i0 + half;
+            u32 a0 = lo > 0 ? i0 * C + c : c * F + i0;
+            u32 a1 = lo > 0 ? i1 * C + c : c * F + i1;
+            Fr a = tile[a0], b = tile[a1];
+            Fr w = A.small[pos << tshift];
+            if (DIF) {
+                tile[a0] = Fr::add(a, b);
+                tile[a1] = Fr::mul(Fr::sub(a, b), w);
+            } else {
+                b = Fr::mul(b, w);
+                tile[a0] = Fr::add(a, b);
+                tile[a1] = Fr::sub(a, b);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- store (+ DIF post-twiddle / scale)
+    for (u32 idx = threadIdx.x; idx < total; idx += 256u) {
+        u32 m, c, p, li;
+        if (lo > 0) { c = idx & (C - 1u); m = idx >> clog; p = (hi << (lo + kb)) + (m << lo) + l0 + c; li = m * C + c; }
+        else { m = idx & (F - 1u); c = idx >> kb; p = ((hi + c) << kb) + m; li = c * F + m; }
+        Fr v = tile[li];
+        if (DIF && lo > 0) {
+            u32 e = ((l0 + c) * brev(m, kb)) << s0;
+            v = Fr::mul(v, table_pow(A.tw_lo, A.tw_hi, A.tb, e));
+        }
+        if (A.scale_store) v = apply_scale(A, A.scale_store, v, p);
+        A.x[p] = v;
+    }
+}
+
+// a = (a*b - c) * den
+__global__ __launch_bounds__(256) void k_h_pointwise(Fr* a, const Fr* b, const Fr* c, Fr den, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    a[i] = Fr::mul(Fr::sub(Fr::mul(a[i], b[i]), c[i]), den);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct Field { int lo, kb; };
+static int plan_fields(int n, Field* f) {  // same rule as tools/ntt_model.py plan_fields(kb_low=8, kb_max=9)
+    const int kb_low = 8, kb_max = 9;
+    if (n <= kb_low) { f[0] = {0, n}; return 1; }
+    int rest = n - kb_low;
+    int k = (rest + kb_max - 1) / kb_max;
+    int base = rest / k, extra = rest % k;
+    f[0] = {0, kb_low};
+    int lo = kb_low;
+    for (int i = 0; i < k; ++i) {
+        int kb = base + (i < extra ? 1 : 0);
+        f[1 + i] = {lo, kb};
+        lo += kb;
+    }
+    return 1 + k;
+}
+
+static int32_t make_table(zkpor_ctx* ctx, const Fr& base, const Fr& mult, int shift, u32 count, Fr* out) {
+    hipLaunchKernelGGL(k_pow_table, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, base, mult, shift, count, out);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+
+int32_t ntt_domain_get(zkpor_ctx* ctx, int n, NttDomain** out) {
+    if (n < 1 || n > 28) { ctx->err = "ntt: log2 size must be in [1,28]"; return ZKPOR_E_ARG; }
+    auto it = ctx->ntt_domains.find(n);
+    if (it != ctx->ntt_domains.end()) { *out = (NttDomain*)it->second; return ZKPOR_OK; }
+    NttDomain* d = new NttDomain();
+    d->n = n;
+    d->tb = (n + 1) / 2;
+    const u32 nlo = 1u << d->tb, nhi = 1u << (n - d->tb);
+    size_t total = (size_t)4 * (nlo + nhi) + (size_t)2 * nhi + 512;
+    ZK_HIP(ctx, hipMalloc((void**)&d->mem, total * sizeof(Fr)));
+    Fr* p = d->mem;
+    auto take = [&](size_t cnt) { Fr* r = p; p += cnt; return r; };
+    d->tw_lo = take(nlo); d->tw_hi = take(nhi); d->twi_lo = take(nlo); d->twi_hi = take(nhi);
+    d->g_lo = take(nlo); d->g_hi = take(nhi); d->gi_lo = take(nlo); d->gi_hi = take(nhi);
+    d->g_hi_ninv = take(nhi); d->gi_hi_ninv = take(nhi);
+    d->small_fwd = take(256); d->small_inv = take(256);
+    Fr w28 = fr_const(W28_M);
+    Fr w = w28;
+    for (int i = n; i < 28; ++i) w = Fr::sqr(w);
+    Fr wi = Fr::inv(w);
+    Fr w512 = w28;
+    for (int i = 9; i < 28; ++i) w512 = Fr::sqr(w512);
+    Fr w512i = Fr::inv(w512);
+    Fr g = fr_const(FIVE_M), gi = Fr::inv(g);
+    Fr one = Fr::one();
+    // 2^n in Montgomery form, then its inverse
+    Fr two = Fr::add(one, one), pw = one;
+    for (int i = 0; i < n; ++i) pw = Fr::mul(pw, two);
+    d->n_inv = Fr::inv(pw);
+    d->den = Fr::inv(Fr::sub(Fr::pow_u64(g, (u64)1 << n), one));
+    ZK_TRY(make_table(ctx, w, one, 0, nlo, d->tw_lo));
+    ZK_TRY(make_table(ctx, w, one, d->tb, nhi, d->tw_hi));
+    ZK_TRY(make_table(ctx, wi, one, 0, nlo, d->twi_lo));
+    ZK_TRY(make_table(ctx, wi, one, d->tb, nhi, d->twi_hi));
+    ZK_TRY(make_table(ctx, g, one, 0, nlo, d->g_lo));
+    ZK_TRY(make_table(ctx, g, one, d->tb, nhi, d->g_hi));
+    ZK_TRY(make_table(ctx, gi, one, 0, nlo, d->gi_lo));
+    ZK_TRY(make_table(ctx, gi, one, d->tb, nhi, d->gi_hi));
+    ZK_TRY(make_table(ctx, g, d->n_inv, d->tb, nhi, d->g_hi_ninv));
+    ZK_TRY(make_table(ctx, gi, d->n_inv, d->tb, nhi, d->gi_hi_ninv));
+    ZK_TRY(make_table(ctx, w512, one, 0, 256, d->small_fwd));
+    ZK_TRY(make_table(ctx, w512i, one, 0, 256, d->small_inv));
+    ctx->ntt_domains[n] = d;
+    *out = d;
+    return ZKPOR_OK;
+}
+
+void ntt_domains_free(zkpor_ctx* ctx) {
+    for (auto& kv : ctx->ntt_domains) {
+        NttDomain* d = (NttDomain*)kv.second;
+        if (d->mem) (void)hipFree(d->mem);
+        delete d;
+    }
+    ctx->ntt_domains.clear();
+}
+
+// scale codes: 0 none, 1 constant, 2 g^p, 3 g^rev(p); g tables chosen by the caller
+struct ScaleSpec { int mode = 0; const Fr* g_lo = nullptr; const Fr* g_hi = nullptr; Fr konst; };
+
+static int32_t run_passes(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
+                          const ScaleSpec& last_store) {
+    Field f[8];
+    int nf = plan_fields(d->n, f);
+    for (int step = 0; step < nf; ++step) {
+        const Field& fl = dif ? f[nf - 1 - step] : f[step];
+        PassArgs A;
+        A.x = x; A.n = d->n; A.lo = fl.lo; A.kb = fl.kb;
+        int cmax = fl.kb >= 9 ? 2 : 3;  // tile <= 64 KiB
+        int avail = fl.lo > 0 ? fl.lo : d->n - fl.kb;
+        A.clog = avail < cmax ? avail : cmax;
+        A.small = inverse ? d->small_inv : d->small_fwd;
+        A.tw_lo = inverse ? d->twi_lo : d->tw_lo;
+        A.tw_hi = inverse ? d->twi_hi : d->tw_hi;
+        A.tb = d->tb;
+        A.scale_load = 0; A.scale_store = 0; A.g_lo = nullptr; A.g_hi = nullptr; A.konst = Fr::one();
+        if (step == 0 && first_load.mode) { A.scale_load = first_load.mode; A.g_lo = first_load.g_lo; A.g_hi = first_load.g_hi; A.konst = first_load.konst; }
+        if (step == nf - 1 && last_store.mode) {
+            if (A.scale_load && (A.g_lo != last_store.g_lo && last_store.mode != 1 && A.scale_load != 1)) { ctx->err = "ntt: conflicting scale tables"; return ZKPOR_E_ARG; }
+            A.scale_store = last_store.mode;
+            if (last_store.mode != 1) { A.g_lo = last_store.g_lo; A.g_hi = last_store.g_hi; } else A.konst = last_store.konst;
+        }
+        u32 blocks = (u32)(((size_t)1 << d->n) >> (fl.kb + A.clog));
+        size_t smem = ((size_t)sizeof(Fr) << fl.kb) << A.clog;
+        if (dif) hipLaunchKernelGGL(k_ntt_pass<true>, dim3(blocks), dim3(256), smem, ctx->stream, A);
+        else hipLaunchKernelGGL(k_ntt_pass<false>, dim3(blocks), dim3(256), smem, ctx->stream, A);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    return ZKPOR_OK;
+}
+
+// gnark-crypto semantics: Domain.FFT / FFTInverse(a, decimation, OnCoset?) in place on the device
+int32_t ntt_dev(zkpor_ctx* ctx, Fr* d_x, int n, bool inverse, bool dif, bool on_coset) {
+    NttDomain* d;
+    ZK_TRY(ntt_domain_get(ctx, n, &d));
+    PhaseScope ps(ctx, "ntt");
+    ScaleSpec load, store;
+    if (!inverse) {
+        if (on_coset) { load.mode = dif ? 2 : 3; load.g_lo = d->g_lo; load.g_hi = d->g_hi; }
+    } else {
+        if (on_coset) { store.mode = dif ? 3 : 2; store.g_lo = d->gi_lo; store.g_hi = d->gi_hi_ninv; }
+        else { store.mode = 1; store.konst = d->n_inv; }
+    }
+    return run_passes(ctx, d, d_x, inverse, dif, load, store);
+}
+
+// computeH in place: a,b,c hold 2^n evaluations (zero padded); on return a = h in BIT-REVERSED order.
+// The 1/N of the three inverse transforms is folded into the coset pre-scale of the forward ones.
+int32_t compute_h_dev(zkpor_ctx* ctx, int n, Fr* a, Fr* b, Fr* c) {
+    NttDomain* d;
+    ZK_TRY(ntt_domain_get(ctx, n, &d));
+    ScaleSpec none, pre, post;
+    pre.mode = 3; pre.g_lo = d->g_lo; pre.g_hi = d->g_hi_ninv;      // g^rev(p) / N at the DIT load
+    post.mode = 3; post.g_lo = d->gi_lo; post.g_hi = d->gi_hi_ninv;  // g^-rev(p) / N at the last DIF store
+    {
+        PhaseScope ps(ctx, "ntt");
+        Fr* v[3] = {a, b, c};
+        for (int i = 0; i < 3; ++i) {
+            ZK_TRY(run_passes(ctx, d, v[i], true, true, none, none));
+            ZK_TRY(run_passes(ctx, d, v[i], false, false, pre, none));
+        }
+    }
+    {
+        PhaseScope ps(ctx, "pointwise");
+        size_t N = (size_t)1 << n;
+        hipLaunchKernelGGL(k_h_pointwise, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, a, b, c, d->den, N);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    {
+        PhaseScope ps(ctx, "ntt");
+        ZK_TRY(run_passes(ctx, d, a, true, true, none, post));
+    }
+    return ZKPOR_OK;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+int32_t zkpor_fft(zkpor_ctx* ctx, uint64_t* a, int log2n, int inverse, int decimation, int on_coset) {
+    if (!ctx || !a || log2n < 1 || log2n > 28) return ZKPOR_E_ARG;
+    size_t bytes = ((size_t)32) << log2n;
+    Fr* d = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&d, bytes));
+    int32_t rc = ZKPOR_OK;
+    if (hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+    if (rc == ZKPOR_OK) rc = ntt_dev(ctx, d, log2n, inverse != 0, decimation == 1, on_coset != 0);
+    if (rc == ZKPOR_OK && hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H failed"; rc = ZKPOR_E_HIP; }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+int32_t zkpor_compute_h_dev(zkpor_ctx* ctx, int log2_domain, void* d_a, void* d_b, void* d_c) {
+    if (!ctx || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
+    return compute_h_dev(ctx, log2_domain, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c);
+}
+
+int32_t zkpor_compute_h(zkpor_ctx* ctx, int log2_domain, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                        size_t n_constraints, uint64_t* h_out) {
+    if (!ctx || !a || !b || !c || !h_out || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
+    size_t N = (size_t)1 << log2_domain;
+    if (n_constraints > N) return ZKPOR_E_ARG;
+    Fr* d = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&d, 3 * N * sizeof(Fr)));
+    int32_t rc = ZKPOR_OK;
+    const uint64_t* src[3] = {a, b, c};
+    for (int i = 0; i < 3 && rc == ZKPOR_OK; ++i) {
+        if (hipMemsetAsync(d + i * N, 0, N * sizeof(Fr), ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d + i * N, src[i], n_constraints * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            ctx->err = "H2D failed"; rc = ZKPOR_E_HIP;
+        }
+    }
+    if (rc == ZKPOR_OK) rc = compute_h_dev(ctx, log2_domain, d, d + N, d + 2 * N);
+    if (rc == ZKPOR_OK && hipMemcpyAsync(h_out, d, N * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H failed"; rc = ZKPOR_E_HIP; }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

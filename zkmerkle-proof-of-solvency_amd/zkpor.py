@@ -131,3 +131,128 @@ class Context:
         out = np.empty(24, dtype=np.uint64)
         self._ck(self.lib.zkpor_msm_g2_dev(self.h, ctypes.c_void_p(d_points), ctypes.c_void_p(d_scalars), ctypes.c_size_t(n), _p(out)))
         return out
+
+    # ---- NTT / H ----
+    def fft(self, a, log2n, inverse=False, decimation=1, on_coset=False):
+        a = _u64(a).copy()
+        self._ck(self.lib.zkpor_fft(self.h, _p(a), ctypes.c_int(log2n), ctypes.c_int(int(inverse)), ctypes.c_int(decimation), ctypes.c_int(int(on_coset))))
+        return a
+
+    def compute_h(self, a, b, c, log2_domain):
+        a = _u64(a); b = _u64(b); c = _u64(c)
+        out = np.empty((1 << log2_domain, 4), dtype=np.uint64)
+        self._ck(self.lib.zkpor_compute_h(self.h, ctypes.c_int(log2_domain), _p(a), _p(b), _p(c), ctypes.c_size_t(a.shape[0]), _p(out)))
+        return out
+
+    def compute_h_dev(self, log2_domain, d_a, d_b, d_c):
+        self._ck(self.lib.zkpor_compute_h_dev(self.h, ctypes.c_int(log2_domain), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c)))
+
+    # ---- Groth16 ----
+    def prove_tail(self, pk, w, a, b, c, r, s):
+        w = _u64(w); a = _u64(a); b = _u64(b); c = _u64(c); r = _u64(r); s = _u64(s)
+        out = np.empty(256, dtype=np.uint8)
+        self._ck(self.lib.zkpor_prove_tail(self.h, pk.h, _p(w), _p(a), _p(b), _p(c), ctypes.c_size_t(a.shape[0]), _p(r), _p(s), _p(out)))
+        return out
+
+    def prove_tail_dev(self, pk, d_w, d_a, d_b, d_c, r, s):
+        r = _u64(r); s = _u64(s)
+        out = np.empty(256, dtype=np.uint8)
+        self._ck(self.lib.zkpor_prove_tail_dev(self.h, pk.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c), _p(r), _p(s), _p(out)))
+        return out
+
+    def commit(self, pk, values):
+        values = _u64(values)
+        c = np.empty(8, dtype=np.uint64); k = np.empty(8, dtype=np.uint64)
+        self._ck(self.lib.zkpor_commit(self.h, pk.h, _p(values), ctypes.c_size_t(values.reshape(-1, 4).shape[0]), _p(c), _p(k)))
+        return c, k
+
+
+def proof_write_raw(proof256, commitments=None, pok=None):
+    lib = load_library()
+    proof256 = np.ascontiguousarray(proof256, dtype=np.uint8)
+    ncom = 0 if commitments is None else np.asarray(commitments).reshape(-1, 8).shape[0]
+    com = None if commitments is None else _u64(commitments)
+    pk_ = None if pok is None else _u64(pok)
+    out = np.empty(256 + 4 + 64 * ncom + 64, dtype=np.uint8)
+    n = ctypes.c_size_t()
+    rc = lib.zkpor_proof_write_raw(_p(proof256), _p(com), ctypes.c_uint32(ncom), _p(pk_), _p(out), ctypes.c_size_t(out.size), ctypes.byref(n))
+    if rc != 0:
+        raise ZkporError(f"zkpor_proof_write_raw failed: {rc}")
+    return out[: n.value]
+
+
+class ProvingKey:
+    """HBM-resident proving key (the device half of gnark's groth16.ProvingKey)"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        ctx._ck(ctx.lib.zkpor_pk_create(ctx.h, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.zkpor_pk_destroy(self.h)
+            self.h = None
+
+    def set_g1(self, which, pts):
+        pts = _u64(pts).reshape(-1, 8)
+        self.ctx._ck(self.ctx.lib.zkpor_pk_set_g1(self.h, ctypes.c_int(which), _p(pts), ctypes.c_size_t(pts.shape[0])))
+
+    def set_g2(self, which, pts):
+        pts = _u64(pts).reshape(-1, 16)
+        self.ctx._ck(self.ctx.lib.zkpor_pk_set_g2(self.h, ctypes.c_int(which), _p(pts), ctypes.c_size_t(pts.shape[0])))
+
+    def set_consts(self, alpha, beta, delta, beta2, delta2, log2_domain, inf_a, inf_b, n_wires, n_public, committed_idx=None, z_order=Z_ORDER_BITREV):
+        ia = None if inf_a is None else np.ascontiguousarray(inf_a, dtype=np.uint8)
+        ib = None if inf_b is None else np.ascontiguousarray(inf_b, dtype=np.uint8)
+        ci = None if committed_idx is None else np.ascontiguousarray(committed_idx, dtype=np.uint32)
+        self.ctx._ck(self.ctx.lib.zkpor_pk_set_consts(
+            self.h, _p(_u64(alpha)), _p(_u64(beta)), _p(_u64(delta)), _p(_u64(beta2)), _p(_u64(delta2)), ctypes.c_int(log2_domain),
+            _p(ia), _p(ib), ctypes.c_size_t(n_wires), ctypes.c_size_t(n_public), _p(ci), ctypes.c_size_t(0 if ci is None else ci.size),
+            ctypes.c_int(z_order)))
+
+    def synth(self, log2_domain, n_wires, n_public, n_committed, seed):
+        self.ctx._ck(self.ctx.lib.zkpor_pk_synth(self.h, ctypes.c_int(log2_domain), ctypes.c_size_t(n_wires), ctypes.c_size_t(n_public),
+                                                 ctypes.c_size_t(n_committed), ctypes.c_uint64(seed)))
+
+    def g1_dev(self, which):
+        p = ctypes.c_void_p(); n = ctypes.c_size_t()
+        self.ctx._ck(self.ctx.lib.zkpor_pk_g1_dev(self.h, ctypes.c_int(which), ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def g2_dev(self, which=G2_B):
+        p = ctypes.c_void_p(); n = ctypes.c_size_t()
+        self.ctx._ck(self.ctx.lib.zkpor_pk_g2_dev(self.h, ctypes.c_int(which), ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+
+# ---- the trapdoor of ProvingKey.synth (mirrors csrc/groth16.hip synth_k / synth_is_inf; used by parity tests) ----
+_M64 = (1 << 64) - 1
+SYNTH_RUN = 32
+SYNTH_Q = 0x9e3779b97f4a7c15
+
+
+def _smix(x):
+    x = (x + 0x9e3779b97f4a7c15) & _M64
+    x = ((x ^ (x >> 30)) * 0xbf58476d1ce4e5b9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94d049bb133111eb) & _M64
+    return x ^ (x >> 31)
+
+
+def synth_scalar(seed, arr, i):
+    """integer s with P_i = s*G for point i of synthetic array `arr` (ignoring the infinity pattern)"""
+    run, j = divmod(i, SYNTH_RUN)
+    x = seed ^ (((arr + 1) * 0xa0761d6478bd642f) & _M64) ^ ((run * 0xe7037ed1a0b428db) & _M64)
+    return (_smix(x) | 1) + j * SYNTH_Q
+
+
+def synth_is_inf(i, mod):
+    if not mod:
+        return False
+    x = (i * 0xd6e8feb86659fd93) & _M64
+    x ^= x >> 32
+    return x % mod == 0
+
+
+SYNTH_INF_MOD = {G1_A: 64, G1_B: 10, G1_K: 4, G1_Z: 0, G1_COMMIT_BASIS: 0, G1_COMMIT_BASIS_SIGMA: 0}
