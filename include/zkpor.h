@@ -58,8 +58,9 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * "poseidon_out_idx", "poseidon_carry_idx" (hash-wrapper convention) */
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);
 /* per-phase GPU time in ms accumulated since the last reset (HIP events on the context's stream).
- * names: "msm_decompose","msm_sort","msm_accumulate","msm_reduce","ntt","pointwise","poseidon_leaf",
- * "poseidon_tree","gather"; returns <0 for an unknown name.  calls = launches counted. */
+ * names: "msm_decompose","msm_sort","msm_accumulate","msm_reduce","k_acc_level1_g1","k_acc_level1_g2" (the
+ * bucket-accumulation kernel alone, one launch per call),"ntt","pointwise","poseidon_leaf","poseidon_tree";
+ * unknown names return 0.  calls = number of timed regions. */
 double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls);
 void zkpor_phase_reset(zkpor_ctx* ctx);
 
@@ -119,6 +120,8 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
  * values: n_committed Fr; out: commitment | knowledge proof, G1 affine 64 B each */
 int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64],
                      uint8_t out_pok[64]);
+int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, size_t n, uint8_t out_commit[64],
+                         uint8_t out_pok[64]);
 /* gnark raw proof bytes (proof.WriteRawTo): big-endian Ar.X|Ar.Y|Bs.X.A1|Bs.X.A0|Bs.Y.A1|Bs.Y.A0|Krs.X|Krs.Y|
  * u32 n_commitments | commitments... | pok  (388 B for one commitment; 324 B... for none) */
 int32_t zkpor_proof_write_raw(const uint8_t proof[256], const uint8_t* commitments, uint32_t n_commitments,
@@ -159,6 +162,10 @@ int32_t zkpor_dev_download(zkpor_ctx* ctx, void* dst, const void* src, size_t by
 /* fill n Montgomery Fr elements with seeded pseudo-random values on the device. kind 0 = uniform,
  * kind 1 = the witness-like mixture of SURVEY.md §8(d) (25% {0,1}, 20% <2^16, 5% <2^64, 50% uniform) */
 int32_t zkpor_dev_fill_fr(zkpor_ctx* ctx, void* d_out, size_t n, uint64_t seed, int kind);
+
+/* out[i] = a[i]*b[i] (Montgomery Fr) and an async device-to-device copy, both on the context's stream */
+int32_t zkpor_dev_fr_mul(zkpor_ctx* ctx, void* d_out, const void* d_a, const void* d_b, size_t n);
+int32_t zkpor_dev_copy(zkpor_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 
 #ifdef __cplusplus
 }

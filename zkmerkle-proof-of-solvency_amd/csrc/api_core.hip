@@ -62,7 +62,25 @@ static int32_t msm_host(zkpor_ctx* ctx, const void* pts, const uint64_t* scalars
     return rc;
 }
 
+__global__ void k_fr_mul(Fr* out, const Fr* a, const Fr* b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = Fr::mul(a[i], b[i]);
+}
+
 extern "C" {
+
+int32_t zkpor_dev_fr_mul(zkpor_ctx* ctx, void* d_out, const void* d_a, const void* d_b, size_t n) {
+    if (!ctx || (n && (!d_out || !d_a || !d_b))) return ZKPOR_E_ARG;
+    if (n == 0) return ZKPOR_OK;
+    hipLaunchKernelGGL(k_fr_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_out, (const Fr*)d_a, (const Fr*)d_b, n);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+int32_t zkpor_dev_copy(zkpor_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !d_src))) return ZKPOR_E_ARG;
+    ZK_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return ZKPOR_OK;
+}
 
 int32_t zkpor_init(int device, void* stream, zkpor_ctx** out) {
     if (!out) return ZKPOR_E_ARG;

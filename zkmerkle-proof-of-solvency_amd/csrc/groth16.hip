@@ -401,33 +401,37 @@ int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const 
     return rc;
 }
 
-int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) {
-    if (!ctx || !pk || (n && !values) || !out_commit || !out_pok) return ZKPOR_E_ARG;
+int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) {
+    if (!ctx || !pk || (n && !d_values) || !out_commit || !out_pok) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "commit: key not loaded"; return ZKPOR_E_STATE; }
     if (n != pk->nC) { ctx->err = "commit: value count differs from the commitment basis"; return ZKPOR_E_ARG; }
     G1XYZZ c1 = G1XYZZ::inf(), c2 = G1XYZZ::inf();
     if (n) {
-        Fr* d = nullptr;
-        ZK_HIP(ctx, hipMalloc((void**)&d, n * sizeof(Fr)));
-        int32_t rc = ZKPOR_OK;
-        if (hipMemcpyAsync(d, values, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
         MsmCfg cfg = msm_cfg(ctx, n);
         size_t st = 0;
         size_t need = digits_ws_bytes(ctx, n, cfg, &st) + accumulate_ws_bytes<Fp>(cfg, n * (size_t)cfg.W);
         DigitStream ds;
-        if (rc == ZKPOR_OK) rc = ws_reserve(ctx, need);
-        if (rc == ZKPOR_OK) rc = msm_digits(ctx, d, n, cfg, st, &ds);
+        ZK_TRY(ws_reserve(ctx, need));
+        ZK_TRY(msm_digits(ctx, (const Fr*)d_values, n, cfg, st, &ds));
         size_t mark = ctx->ws_off;
-        if (rc == ZKPOR_OK) rc = msm_accumulate<Fp>(ctx, ds, pk->CB, &c1);
+        ZK_TRY(msm_accumulate<Fp>(ctx, ds, pk->CB, &c1));
         ctx->ws_off = mark;
-        if (rc == ZKPOR_OK) rc = msm_accumulate<Fp>(ctx, ds, pk->CBS, &c2);
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d);
-        if (rc != ZKPOR_OK) return rc;
+        ZK_TRY(msm_accumulate<Fp>(ctx, ds, pk->CBS, &c2));
     }
     G1Affine a1 = xyzz_to_affine<Fp>(c1), a2 = xyzz_to_affine<Fp>(c2);
     memcpy(out_commit, &a1, 64); memcpy(out_pok, &a2, 64);
     return ZKPOR_OK;
+}
+int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) {
+    if (!ctx || !pk || (n && !values) || !out_commit || !out_pok) return ZKPOR_E_ARG;
+    Fr* d = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&d, (n ? n : 1) * sizeof(Fr)));
+    int32_t rc = ZKPOR_OK;
+    if (n && hipMemcpyAsync(d, values, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+    if (rc == ZKPOR_OK) rc = zkpor_commit_dev(ctx, pk, d, n, out_commit, out_pok);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
 }
 
 static void fp_be(const Fp& x, uint8_t* out) {
