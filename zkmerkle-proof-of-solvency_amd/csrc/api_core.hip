@@ -6,6 +6,7 @@
 using namespace zk;
 
 namespace zk {
+void pos_tables_free(zkpor_ctx* ctx);
 int32_t ensure_pinned(zkpor_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->pinned_cap) return ZKPOR_OK;
     if (ctx->pinned) { ZK_HIP(ctx, hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
@@ -113,7 +114,7 @@ void zkpor_destroy(zkpor_ctx* ctx) {
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
-    if (ctx->pos_tables) (void)hipFree(ctx->pos_tables);
+    pos_tables_free(ctx);
     ntt_domains_free(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

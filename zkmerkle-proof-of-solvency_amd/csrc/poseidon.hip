@@ -1,0 +1,460 @@
+// Poseidon account-tree hashing for gfx950 — replaces the CPU loops of the reference's witness service:
+//   leaf hashes   utils.AccountInfoToHash + ComputeUserAssetsCommitment + PaddingAccountAssets
+//                 (src/utils/utils.go:744-750, :188-221, :147-186; driven by src/witness/main.go:130-199)
+//   tree build    merkletree.FixedDepthMerkleTree.Build / nilHashes / Root
+//                 (src/utils/merkletree/merkletree.go:192-279, :159-170)
+//   hash function poseidon.Poseidon / PoseidonBytes / NewPoseidon of the bnb-chain gnark-crypto fork
+//                 (un-vendored; x^5 HADES permutation, R_F = 8, R_P(t), Grain-LFSR parameters, inputs chained in
+//                 blocks of 12 through the capacity element — SURVEY.md Appendix A.6).
+// The permutation parameters are generated at start-up by the published Grain procedure (poseidon_params below,
+// an independent restatement of the one in oracle/poseidon.hpp; tests compare the two and the iden3 KATs).
+#include "common.cuh"
+#include <vector>
+
+namespace zk {
+
+static const int POS_RF = 8;
+static const int POS_MAX_T = 13;
+static inline int pos_rp(int t) {
+    static const int tab[] = {56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65};
+    return tab[t - 2];
+}
+
+struct PosTables {       // device blob: for every width t in [2,13]: rc[(8+rp)*t] then mds[t*t]
+    Fr* dev = nullptr;
+    u32 rc_off[POS_MAX_T + 1];
+    u32 mds_off[POS_MAX_T + 1];
+    std::vector<Fr> host;
+};
+
+// ---- Grain LFSR (Poseidon reference parameter generation: field = 1, sbox = 0 (x^alpha), n = 254) ----
+struct GrainLfsr {
+    uint8_t s[80];
+    int head = 0;
+    GrainLfsr(int t, int rf, int rp) {
+        int k = 0;
+        auto put = [&](unsigned v, int w) { for (int i = w - 1; i >= 0; --i) s[k++] = (uint8_t)((v >> i) & 1u); };
+        put(1, 2); put(0, 4); put(254, 12); put((unsigned)t, 12); put((unsigned)rf, 10); put((unsigned)rp, 10);
+        while (k < 80) s[k++] = 1;
+        for (int i = 0; i < 160; ++i) clock();
+    }
+    int tap(int i) const { return s[(head + i) % 80]; }
+    int clock() {
+        int nb = tap(62) ^ tap(51) ^ tap(38) ^ tap(23) ^ tap(13) ^ tap(0);
+        s[head] = (uint8_t)nb;
+        head = (head + 1) % 80;
+        return nb;
+    }
+    int next_bit() {  // self-shrinking: keep the second bit of a pair when the first is 1
+        for (;;) {
+            int a = clock(), b = clock();
+            if (a) return b;
+        }
+    }
+    Fr next_254(bool* below_modulus) {  // canonical limbs, MSB first
+        Fr x = Fr::zero();
+        for (int i = 253; i >= 0; --i)
+            if (next_bit()) x.v[i >> 5] |= 1u << (i & 31);
+        bool lt = false;
+        for (int i = 7; i >= 0; --i) {
+            if (x.v[i] != FrParams::mod(i)) { lt = x.v[i] < FrParams::mod(i); break; }
+        }
+        *below_modulus = lt;
+        return x;
+    }
+};
+
+static void poseidon_params(int t, std::vector<Fr>& rc, std::vector<Fr>& mds) {
+    const int rp = pos_rp(t);
+    GrainLfsr g(t, POS_RF, rp);
+    rc.resize((size_t)(POS_RF + rp) * t);
+    for (auto& c : rc) {
+        bool ok;
+        Fr v;
+        do { v = g.next_254(&ok); } while (!ok);  // rejection sampling
+        c = Fr::to_mont(v);
+    }
+    std::vector<Fr> xy(2 * t);
+    for (;;) {
+        for (auto& e : xy) {
+            bool ok;
+            Fr v = g.next_254(&ok);
+            if (!ok) {  // reduce mod r (v < 2^254 < 2r)
+                Fr m; for (int i = 0; i < 8; ++i) m.v[i] = FrParams::mod(i);
+                u32 bw = 0;
+                for (int i = 0; i < 8; ++i) { u64 d = (u64)v.v[i] - m.v[i] - bw; v.v[i] = (u32)d; bw = (u32)(d >> 32) & 1u; }
+            }
+            e = Fr::to_mont(v);
+        }
+        bool good = true;
+        for (int i = 0; i < 2 * t && good; ++i)
+            for (int j = i + 1; j < 2 * t; ++j) if (xy[i] == xy[j]) { good = false; break; }
+        for (int i = 0; i < t && good; ++i)
+            for (int j = 0; j < t; ++j) if (Fr::add(xy[i], xy[t + j]).is_zero()) { good = false; break; }
+        if (good) break;
+    }
+    mds.resize((size_t)t * t);
+    for (int i = 0; i < t; ++i)
+        for (int j = 0; j < t; ++j) mds[(size_t)i * t + j] = Fr::inv(Fr::add(xy[i], xy[t + j]));
+}
+
+static int32_t pos_tables_get(zkpor_ctx* ctx, PosTables** out) {
+    if (ctx->pos_tables) { *out = (PosTables*)ctx->pos_tables; return ZKPOR_OK; }
+    PosTables* T = new PosTables();
+    for (int t = 2; t <= POS_MAX_T; ++t) {
+        std::vector<Fr> rc, mds;
+        poseidon_params(t, rc, mds);
+        T->rc_off[t] = (u32)T->host.size();
+        T->host.insert(T->host.end(), rc.begin(), rc.end());
+        T->mds_off[t] = (u32)T->host.size();
+        T->host.insert(T->host.end(), mds.begin(), mds.end());
+    }
+    ZK_HIP(ctx, hipMalloc((void**)&T->dev, T->host.size() * sizeof(Fr)));
+    ZK_HIP(ctx, hipMemcpyAsync(T->dev, T->host.data(), T->host.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pos_tables = T;
+    *out = T;
+    return ZKPOR_OK;
+}
+void pos_tables_free(zkpor_ctx* ctx) {
+    if (!ctx->pos_tables) return;
+    PosTables* T = (PosTables*)ctx->pos_tables;
+    if (T->dev) (void)hipFree(T->dev);
+    delete T;
+    ctx->pos_tables = nullptr;
+}
+
+ZK_HD Fr pow5(const Fr& x) {
+    Fr x2 = Fr::sqr(x);
+    return Fr::mul(Fr::sqr(x2), x);
+}
+
+// width-3 permutation with the state in registers (the Merkle-node hash: ~N of these per tree build)
+ZK_HD void permute3(Fr& s0, Fr& s1, Fr& s2, const Fr* __restrict__ rc, const Fr* __restrict__ m) {
+    const int rp = 57;
+    for (int r = 0; r < POS_RF + rp; ++r) {
+        s0 = Fr::add(s0, rc[3 * r]); s1 = Fr::add(s1, rc[3 * r + 1]); s2 = Fr::add(s2, rc[3 * r + 2]);
+        s0 = pow5(s0);
+        if (r < POS_RF / 2 || r >= POS_RF / 2 + rp) { s1 = pow5(s1); s2 = pow5(s2); }
+        Fr t0 = Fr::add(Fr::add(Fr::mul(m[0], s0), Fr::mul(m[1], s1)), Fr::mul(m[2], s2));
+        Fr t1 = Fr::add(Fr::add(Fr::mul(m[3], s0), Fr::mul(m[4], s1)), Fr::mul(m[5], s2));
+        Fr t2 = Fr::add(Fr::add(Fr::mul(m[6], s0), Fr::mul(m[7], s1)), Fr::mul(m[8], s2));
+        s0 = t0; s1 = t1; s2 = t2;
+    }
+}
+// generic width (state in memory): used for leaf hashing and the generic hash entry point
+ZK_HD void permute_generic(Fr* st, int t, const Fr* __restrict__ rc, const Fr* __restrict__ m, int rp) {
+    Fr tmp[POS_MAX_T];
+    for (int r = 0; r < POS_RF + rp; ++r) {
+        for (int i = 0; i < t; ++i) st[i] = Fr::add(st[i], rc[r * t + i]);
+        if (r < POS_RF / 2 || r >= POS_RF / 2 + rp) { for (int i = 0; i < t; ++i) st[i] = pow5(st[i]); }
+        else st[0] = pow5(st[0]);
+        for (int i = 0; i < t; ++i) {
+            Fr acc = Fr::mul(m[i * t], st[0]);
+            for (int j = 1; j < t; ++j) acc = Fr::add(acc, Fr::mul(m[i * t + j], st[j]));
+            tmp[i] = acc;
+        }
+        for (int i = 0; i < t; ++i) st[i] = tmp[i];
+    }
+}
+
+struct PosDev {  // everything a kernel needs to hash
+    const Fr* tab;
+    u32 rc_off[POS_MAX_T + 1];
+    u32 mds_off[POS_MAX_T + 1];
+    int rp[POS_MAX_T + 1];
+    int out_idx, carry_idx;
+};
+
+// streaming sponge over blocks of 12 (poseidon.Poseidon of the bnb fork)
+struct Sponge {
+    Fr st[POS_MAX_T];
+    Fr cap, out;
+    int fill;
+    ZK_HD void init() { cap = Fr::zero(); out = Fr::zero(); fill = 0; }
+    ZK_HD void flush(const PosDev& P) {
+        if (!fill) return;
+        int t = fill + 1;
+        st[0] = cap;
+        permute_generic(st, t, P.tab + P.rc_off[t], P.tab + P.mds_off[t], P.rp[t]);
+        cap = st[P.carry_idx];
+        out = st[P.out_idx];
+        fill = 0;
+    }
+    ZK_HD void push(const PosDev& P, const Fr& x) {
+        st[1 + fill] = x;
+        if (++fill == 12) flush(P);
+    }
+    ZK_HD Fr finish(const PosDev& P) { flush(P); return out; }
+};
+
+// out[i] = H(in[2i], in[2i+1]); for an odd count the missing right sibling of the last pair is `nil`
+__global__ __launch_bounds__(256) void k_hash2_level(const Fr* __restrict__ in, u32 n_in, Fr nil, Fr* __restrict__ out,
+                                                     PosDev P) {
+    u32 i = blockIdx.x * 256u + threadIdx.x;
+    u32 n_out = (n_in + 1u) >> 1;
+    if (i >= n_out) return;
+    Fr s0 = Fr::zero();
+    Fr s1 = in[2 * i];
+    Fr s2 = (2 * i + 1 < n_in) ? in[2 * i + 1] : nil;
+    permute3(s0, s1, s2, P.tab + P.rc_off[3], P.tab + P.mds_off[3]);
+    out[i] = P.out_idx == 0 ? s0 : (P.out_idx == 1 ? s1 : s2);
+}
+
+// `count` independent hashes of `len` inputs each
+__global__ __launch_bounds__(64) void k_hash_many(const Fr* __restrict__ in, u32 len, u32 count, Fr* __restrict__ out, PosDev P) {
+    u32 i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= count) return;
+    Sponge sp;
+    sp.init();
+    const Fr* x = in + (size_t)i * len;
+    for (u32 k = 0; k < len; ++k) sp.push(P, x[k]);
+    out[i] = sp.finish(P);
+}
+
+struct AccountHdr {
+    uint8_t id_be[32];
+    u64 equity[2], debt[2], collateral[2];
+    u32 n_assets, asset_off;
+};
+struct AssetRec { u64 equity, debt, loan, margin, portfolio_margin; u32 index, pad; };
+static_assert(sizeof(AccountHdr) == 88 && sizeof(AssetRec) == 48, "zkpor_account_t / zkpor_asset_t layout");
+
+ZK_HD Fr pack3(u64 a, u64 b, u64 c) {  // a*2^128 + b*2^64 + c  (< 2^192 < r)
+    Fr x;
+    x.v[0] = (u32)c; x.v[1] = (u32)(c >> 32); x.v[2] = (u32)b; x.v[3] = (u32)(b >> 32);
+    x.v[4] = (u32)a; x.v[5] = (u32)(a >> 32); x.v[6] = 0; x.v[7] = 0;
+    return Fr::to_mont(x);
+}
+ZK_HD Fr from_u128(const u64* w) {
+    Fr x;
+    x.v[0] = (u32)w[0]; x.v[1] = (u32)(w[0] >> 32); x.v[2] = (u32)w[1]; x.v[3] = (u32)(w[1] >> 32);
+    x.v[4] = x.v[5] = x.v[6] = x.v[7] = 0;
+    return Fr::to_mont(x);
+}
+ZK_HD Fr from_be32(const uint8_t* b) {  // 32 big-endian bytes, reduced mod r
+    Fr x;
+    for (int i = 0; i < 8; ++i) {
+        const uint8_t* p = b + 28 - 4 * i;
+        x.v[i] = ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
+    }
+    for (int k = 0; k < 6; ++k) {  // 2^256 / r < 6
+        u32 t[8];
+        u32 bw = 0;
+        for (int i = 0; i < 8; ++i) { u64 d = (u64)x.v[i] - FrParams::mod(i) - bw; t[i] = (u32)d; bw = (u32)(d >> 32) & 1u; }
+        if (bw) break;
+        for (int i = 0; i < 8; ++i) x.v[i] = t[i];
+    }
+    return Fr::to_mont(x);
+}
+
+// one thread per account: streams the tier-padded asset list (PaddingAccountAssets, utils.go:147-186) through the
+// sponge as 2 field elements per slot, then the 5-input leaf hash
+__global__ __launch_bounds__(64) void k_account_leaves(const AccountHdr* __restrict__ acc, const AssetRec* __restrict__ assets,
+                                                       u32 n, int tier, Fr* __restrict__ out, PosDev P) {
+    u32 i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    const AccountHdr a = acc[i];
+    const AssetRec* as = assets + a.asset_off;
+    Sponge sp;
+    sp.init();
+    int padding = tier - (int)a.n_assets, cur_pad = 0;
+    u32 cur_idx = 0, ai = 0;
+    for (int slot = 0; slot < tier; ++slot) {
+        bool real;
+        if (ai < a.n_assets) real = !(cur_pad < padding && cur_idx < as[ai].index);
+        else real = false;
+        if (real) {
+            const AssetRec r = as[ai];
+            sp.push(P, pack3(r.index, r.equity, r.debt));
+            sp.push(P, pack3(r.loan, r.margin, r.portfolio_margin));
+            cur_idx = r.index + 1;
+            ++ai;
+        } else {
+            sp.push(P, pack3(cur_idx, 0, 0));
+            sp.push(P, Fr::zero());
+            ++cur_idx;
+            ++cur_pad;
+        }
+    }
+    Fr commitment = sp.finish(P);
+    sp.init();
+    sp.push(P, from_be32(a.id_be));
+    sp.push(P, from_u128(a.equity));
+    sp.push(P, from_u128(a.debt));
+    sp.push(P, from_u128(a.collateral));
+    sp.push(P, commitment);
+    out[i] = sp.finish(P);
+}
+
+// Montgomery Fr <-> 32-byte big-endian
+__global__ void k_fr_to_be(const Fr* __restrict__ in, uint8_t* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr c = Fr::from_mont(in[i]);
+    u32* o = (u32*)(out + 32 * i);
+    for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(c.v[7 - j]);
+}
+__global__ void k_fr_from_be(const uint8_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = from_be32(in + 32 * i);
+}
+
+static int32_t pos_dev(zkpor_ctx* ctx, PosDev* P) {
+    PosTables* T;
+    ZK_TRY(pos_tables_get(ctx, &T));
+    P->tab = T->dev;
+    for (int t = 2; t <= POS_MAX_T; ++t) { P->rc_off[t] = T->rc_off[t]; P->mds_off[t] = T->mds_off[t]; P->rp[t] = pos_rp(t); }
+    if (ctx->pos_out < 0 || ctx->pos_out > 1 || ctx->pos_carry < 0 || ctx->pos_carry > 1) { ctx->err = "poseidon: convention indices must be 0 or 1"; return ZKPOR_E_ARG; }
+    P->out_idx = ctx->pos_out; P->carry_idx = ctx->pos_carry;
+    return ZKPOR_OK;
+}
+
+// host copy of the 2->1 hash (nil-subtree chain; 28 evaluations per tree)
+static Fr host_hash2(const PosTables& T, const PosDev& P, const Fr& l, const Fr& r) {
+    Fr s0 = Fr::zero(), s1 = l, s2 = r;
+    permute3(s0, s1, s2, T.host.data() + T.rc_off[3], T.host.data() + T.mds_off[3]);
+    return P.out_idx == 0 ? s0 : s1;
+}
+
+// tree over d_leaves[0..n) (Montgomery); d_levels (optional) receives levels 1..depth concatenated
+static int32_t merkle_build_core(zkpor_ctx* ctx, const Fr* d_leaves, size_t n, int depth, const Fr& nil_leaf,
+                                 Fr* d_levels, Fr* root) {
+    if (depth < 1 || depth > 32 || n > ((size_t)1 << depth)) { ctx->err = "merkle: bad depth / leaf count"; return ZKPOR_E_ARG; }
+    PosDev P;
+    ZK_TRY(pos_dev(ctx, &P));
+    PosTables* T = (PosTables*)ctx->pos_tables;
+    std::vector<Fr> nil(depth + 1);
+    nil[0] = nil_leaf;
+    for (int l = 1; l <= depth; ++l) nil[l] = host_hash2(*T, P, nil[l - 1], nil[l - 1]);
+    if (n == 0) { *root = nil[depth]; return ZKPOR_OK; }
+    PhaseScope ps(ctx, "poseidon_tree");
+    // ping-pong buffers when the caller does not want the levels
+    Fr* scratch = nullptr;
+    size_t half = (n + 1) / 2;
+    if (!d_levels) {
+        ZK_TRY(ws_reserve(ctx, (half + (half + 1) / 2 + 64) * sizeof(Fr)));
+        scratch = ws_alloc<Fr>(ctx, half + (half + 1) / 2 + 32);
+        if (!scratch) { ctx->err = "merkle: workspace"; return ZKPOR_E_OOM; }
+    }
+    const Fr* src = d_leaves;
+    size_t m = n;
+    Fr* lvl_ptr = d_levels;
+    Fr* pp[2] = {scratch, scratch ? scratch + half : nullptr};
+    int pi = 0;
+    const Fr* last = nullptr;
+    for (int l = 1; l <= depth; ++l) {
+        size_t mo = (m + 1) / 2;
+        Fr* dst = d_levels ? lvl_ptr : pp[pi];
+        hipLaunchKernelGGL(k_hash2_level, dim3((unsigned)((mo + 255) / 256)), dim3(256), 0, ctx->stream, src, (u32)m, nil[l - 1], dst, P);
+        ZK_KERNEL_CHECK(ctx);
+        src = dst; m = mo; last = dst;
+        if (d_levels) lvl_ptr += mo; else pi ^= 1;
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(root, last, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+}
+
+static size_t levels_total(size_t n, int depth) {
+    size_t tot = 0, m = n;
+    for (int l = 1; l <= depth; ++l) { m = (m + 1) / 2; tot += m; }
+    return tot;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, size_t count, uint64_t* out) {
+    if (!ctx || !inputs || !out || len < 1 || count == 0) return ZKPOR_E_ARG;
+    PosDev P;
+    ZK_TRY(pos_dev(ctx, &P));
+    Fr *din = nullptr, *dout = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&din, len * count * sizeof(Fr)));
+    if (hipMalloc((void**)&dout, count * sizeof(Fr)) != hipSuccess) { (void)hipFree(din); ctx->err = "out of device memory"; return ZKPOR_E_OOM; }
+    int32_t rc = ZKPOR_OK;
+    if (hipMemcpyAsync(din, inputs, len * count * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+    if (rc == ZKPOR_OK) {
+        if (len == 2) hipLaunchKernelGGL(k_hash2_level, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, din, (u32)(2 * count), Fr::zero(), dout, P);
+        else hipLaunchKernelGGL(k_hash_many, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, din, (u32)len, (u32)count, dout, P);
+        if (hipGetLastError() != hipSuccess) { ctx->err = "poseidon launch failed"; rc = ZKPOR_E_HIP; }
+    }
+    if (rc == ZKPOR_OK && hipMemcpyAsync(out, dout, count * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H failed"; rc = ZKPOR_E_HIP; }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(din); (void)hipFree(dout);
+    return rc;
+}
+
+int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, const zkpor_asset_t* assets,
+                              size_t n_assets_total, size_t n, int tier, uint8_t* out32) {
+    if (!ctx || !accounts || !out32 || n == 0 || tier < 1 || (n_assets_total && !assets)) return ZKPOR_E_ARG;
+    for (size_t i = 0; i < n; ++i) {
+        if (accounts[i].n_assets > (uint32_t)tier || (size_t)accounts[i].asset_off + accounts[i].n_assets > n_assets_total) {
+            ctx->err = "poseidon_leaves: account exceeds the tier or the asset array"; return ZKPOR_E_ARG;
+        }
+    }
+    PosDev P;
+    ZK_TRY(pos_dev(ctx, &P));
+    AccountHdr* dacc = nullptr; AssetRec* das = nullptr; Fr* dout = nullptr; uint8_t* dbe = nullptr;
+    int32_t rc = ZKPOR_OK;
+    if (hipMalloc((void**)&dacc, n * sizeof(AccountHdr)) != hipSuccess || hipMalloc((void**)&das, (n_assets_total + 1) * sizeof(AssetRec)) != hipSuccess ||
+        hipMalloc((void**)&dout, n * sizeof(Fr)) != hipSuccess || hipMalloc((void**)&dbe, n * 32) != hipSuccess) { ctx->err = "out of device memory"; rc = ZKPOR_E_OOM; }
+    if (rc == ZKPOR_OK && (hipMemcpyAsync(dacc, accounts, n * sizeof(AccountHdr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                           (n_assets_total && hipMemcpyAsync(das, assets, n_assets_total * sizeof(AssetRec), hipMemcpyHostToDevice, ctx->stream) != hipSuccess))) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+    if (rc == ZKPOR_OK) {
+        PhaseScope ps(ctx, "poseidon_leaf");
+        hipLaunchKernelGGL(k_account_leaves, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, dacc, das, (u32)n, tier, dout, P);
+        hipLaunchKernelGGL(k_fr_to_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dout, dbe, n);
+        if (hipGetLastError() != hipSuccess) { ctx->err = "poseidon launch failed"; rc = ZKPOR_E_HIP; }
+    }
+    if (rc == ZKPOR_OK && hipMemcpyAsync(out32, dbe, n * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H failed"; rc = ZKPOR_E_HIP; }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dacc); (void)hipFree(das); (void)hipFree(dout); (void)hipFree(dbe);
+    return rc;
+}
+
+int32_t zkpor_merkle_build_dev(zkpor_ctx* ctx, const void* d_leaves_mont, size_t n, int depth,
+                               const uint64_t nil_leaf_mont[4], uint64_t root_mont[4]) {
+    if (!ctx || (n && !d_leaves_mont) || !nil_leaf_mont || !root_mont) return ZKPOR_E_ARG;
+    Fr nil, root;
+    memcpy(&nil, nil_leaf_mont, 32);
+    ZK_TRY(merkle_build_core(ctx, (const Fr*)d_leaves_mont, n, depth, nil, nullptr, &root));
+    memcpy(root_mont, &root, 32);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n, int depth, const uint8_t nil_leaf[32],
+                           uint8_t* levels_out, uint8_t root_out[32]) {
+    if (!ctx || (n && !leaves32_be) || !nil_leaf || !root_out) return ZKPOR_E_ARG;
+    if (depth < 1 || depth > 32 || n > ((size_t)1 << depth)) { ctx->err = "merkle: bad depth / leaf count"; return ZKPOR_E_ARG; }
+    Fr nil = from_be32(nil_leaf);
+    size_t tot = levels_out ? levels_total(n, depth) : 0;
+    uint8_t* dbe = nullptr; Fr* dleaves = nullptr; Fr* dlev = nullptr;
+    int32_t rc = ZKPOR_OK;
+    size_t be_cnt = n > tot ? n : tot;
+    if (hipMalloc((void**)&dbe, (be_cnt + 1) * 32) != hipSuccess || hipMalloc((void**)&dleaves, (n + 1) * sizeof(Fr)) != hipSuccess ||
+        (tot && hipMalloc((void**)&dlev, tot * sizeof(Fr)) != hipSuccess)) { ctx->err = "out of device memory"; rc = ZKPOR_E_OOM; }
+    if (rc == ZKPOR_OK && n) {
+        if (hipMemcpyAsync(dbe, leaves32_be, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+        else hipLaunchKernelGGL(k_fr_from_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dbe, dleaves, n);
+    }
+    Fr root;
+    if (rc == ZKPOR_OK) rc = merkle_build_core(ctx, dleaves, n, depth, nil, dlev, &root);
+    if (rc == ZKPOR_OK) {
+        Fr c = Fr::from_mont(root);
+        for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) root_out[31 - (i * 4 + j)] = (uint8_t)(c.v[i] >> (8 * j));
+        if (tot) {
+            hipLaunchKernelGGL(k_fr_to_be, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, dlev, dbe, tot);
+            if (hipMemcpyAsync(levels_out, dbe, tot * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H failed"; rc = ZKPOR_E_HIP; }
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dbe); (void)hipFree(dleaves); if (dlev) (void)hipFree(dlev);
+    return rc;
+}
+
+}  // extern "C"

@@ -256,3 +256,52 @@ def synth_is_inf(i, mod):
 
 
 SYNTH_INF_MOD = {G1_A: 64, G1_B: 10, G1_K: 4, G1_Z: 0, G1_COMMIT_BASIS: 0, G1_COMMIT_BASIS_SIGMA: 0}
+
+
+# ---- Poseidon account tree (methods attached to Context) ----
+ACCOUNT_DTYPE = np.dtype([("id_be", np.uint8, 32), ("equity", np.uint64, 2), ("debt", np.uint64, 2),
+                          ("collateral", np.uint64, 2), ("n_assets", np.uint32), ("asset_off", np.uint32)])
+ASSET_DTYPE = np.dtype([("equity", np.uint64), ("debt", np.uint64), ("loan", np.uint64), ("margin", np.uint64),
+                        ("portfolio_margin", np.uint64), ("index", np.uint32), ("pad", np.uint32)])
+
+
+def _poseidon_hash(self, inputs, length):
+    """`count` independent poseidon.Poseidon(inputs...) of `length` Montgomery Fr each"""
+    inputs = _u64(inputs).reshape(-1, 4)
+    count = inputs.shape[0] // length
+    out = np.empty((count, 4), dtype=np.uint64)
+    self._ck(self.lib.zkpor_poseidon_hash(self.h, _p(inputs), ctypes.c_size_t(length), ctypes.c_size_t(count), _p(out)))
+    return out
+
+
+def _poseidon_leaves(self, accounts, assets, tier):
+    accounts = np.ascontiguousarray(accounts, dtype=ACCOUNT_DTYPE)
+    assets = np.ascontiguousarray(assets, dtype=ASSET_DTYPE)
+    out = np.empty((accounts.shape[0], 32), dtype=np.uint8)
+    self._ck(self.lib.zkpor_poseidon_leaves(self.h, _p(accounts), _p(assets), ctypes.c_size_t(assets.shape[0]),
+                                            ctypes.c_size_t(accounts.shape[0]), ctypes.c_int(tier), _p(out)))
+    return out
+
+
+def _merkle_build(self, leaves_be, depth, nil_leaf_be, want_levels=False):
+    leaves_be = np.ascontiguousarray(leaves_be, dtype=np.uint8).reshape(-1, 32)
+    n = leaves_be.shape[0]
+    nil_leaf_be = np.ascontiguousarray(nil_leaf_be, dtype=np.uint8)
+    tot = sum((n + (1 << l) - 1) >> l for l in range(1, depth + 1))
+    levels = np.empty((tot, 32), dtype=np.uint8) if want_levels else None
+    root = np.empty(32, dtype=np.uint8)
+    self._ck(self.lib.zkpor_merkle_build(self.h, _p(leaves_be), ctypes.c_size_t(n), ctypes.c_int(depth), _p(nil_leaf_be), _p(levels), _p(root)))
+    return root, levels
+
+
+def _merkle_build_dev(self, d_leaves, n, depth, nil_leaf_mont):
+    nil_leaf_mont = _u64(nil_leaf_mont)
+    root = np.empty(4, dtype=np.uint64)
+    self._ck(self.lib.zkpor_merkle_build_dev(self.h, ctypes.c_void_p(d_leaves), ctypes.c_size_t(n), ctypes.c_int(depth), _p(nil_leaf_mont), _p(root)))
+    return root
+
+
+Context.poseidon_hash = _poseidon_hash
+Context.poseidon_leaves = _poseidon_leaves
+Context.merkle_build = _merkle_build
+Context.merkle_build_dev = _merkle_build_dev
