@@ -73,8 +73,10 @@ int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp>* src, u32 
                       u32* out_keys, XYZZ<Fp>* out_part);
 int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp2>* src, u32 M, int L, XYZZ<Fp2>* buckets,
                       u32* out_keys, XYZZ<Fp2>* out_part);
-int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp>* in, u32 n_groups, u32 g, XYZZ<Fp>* outS, XYZZ<Fp>* outW);
-int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp2>* in, u32 n_groups, u32 g, XYZZ<Fp2>* outS, XYZZ<Fp2>* outW);
+int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp>* Sin, const XYZZ<Fp>* Yin, u32 n_groups, u32 g, int dbl,
+                      XYZZ<Fp>* Sout, XYZZ<Fp>* Yout);
+int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp2>* Sin, const XYZZ<Fp2>* Yin, u32 n_groups, u32 g, int dbl,
+                      XYZZ<Fp2>* Sout, XYZZ<Fp2>* Yout);
 
 // ------------------------------------------------------------------------------------------------ host driver
 struct DigitStream {  // sorted digits of one scalar vector, reusable across point arrays
@@ -131,11 +133,9 @@ inline size_t accumulate_ws_bytes(const MsmCfg& cfg, size_t max_entries) {
     p.add<XYZZ<F>>(cfg.NB);
     p.add<XYZZ<F>>(2 * T1 + 2); p.add<u32>(2 * T1 + 2);
     p.add<XYZZ<F>>(2 * T2 + 2); p.add<u32>(2 * T2 + 2);
-    size_t n1tot = (size_t)cfg.n1 * cfg.W, n2tot = (size_t)cfg.n2 * cfg.W;
-    p.add<XYZZ<F>>(n1tot); p.add<XYZZ<F>>(n1tot);   // S1, W1
-    p.add<XYZZ<F>>(n2tot); p.add<XYZZ<F>>(n2tot);   // S2, W2
-    p.add<XYZZ<F>>(n2tot);                          // T1 (partial sums of W1)
-    p.add<XYZZ<F>>(4 * (size_t)cfg.W);              // S3, W3, sumW1, sumW2
+    size_t half = (size_t)cfg.NB / 2 + 1;
+    p.add<XYZZ<F>>(half); p.add<XYZZ<F>>(half);              // S, Y of odd levels
+    p.add<XYZZ<F>>(half / 2 + 1); p.add<XYZZ<F>>(half / 2 + 1);  // S, Y of even levels
     return p.total;
 }
 
@@ -152,12 +152,10 @@ inline int32_t msm_accumulate(zkpor_ctx* ctx, const DigitStream& ds, const Affin
     XYZZ<F>* buckets = ws_alloc<XYZZ<F>>(ctx, cfg.NB);
     XYZZ<F>* pa = ws_alloc<XYZZ<F>>(ctx, 2 * T1 + 2); u32* ka = ws_alloc<u32>(ctx, 2 * T1 + 2);
     XYZZ<F>* pb = ws_alloc<XYZZ<F>>(ctx, 2 * T2 + 2); u32* kb = ws_alloc<u32>(ctx, 2 * T2 + 2);
-    size_t n1tot = (size_t)cfg.n1 * cfg.W, n2tot = (size_t)cfg.n2 * cfg.W;
-    XYZZ<F>* S1 = ws_alloc<XYZZ<F>>(ctx, n1tot); XYZZ<F>* W1 = ws_alloc<XYZZ<F>>(ctx, n1tot);
-    XYZZ<F>* S2 = ws_alloc<XYZZ<F>>(ctx, n2tot); XYZZ<F>* W2 = ws_alloc<XYZZ<F>>(ctx, n2tot);
-    XYZZ<F>* Tw = ws_alloc<XYZZ<F>>(ctx, n2tot);
-    XYZZ<F>* fin = ws_alloc<XYZZ<F>>(ctx, 4 * (size_t)cfg.W);
-    if (!buckets || !pa || !ka || !pb || !kb || !S1 || !W1 || !S2 || !W2 || !Tw || !fin) {
+    size_t half = (size_t)cfg.NB / 2 + 1;
+    XYZZ<F>* Sa = ws_alloc<XYZZ<F>>(ctx, half); XYZZ<F>* Ya = ws_alloc<XYZZ<F>>(ctx, half);
+    XYZZ<F>* Sb = ws_alloc<XYZZ<F>>(ctx, half / 2 + 1); XYZZ<F>* Yb = ws_alloc<XYZZ<F>>(ctx, half / 2 + 1);
+    if (!buckets || !pa || !ka || !pb || !kb || !Sa || !Ya || !Sb || !Yb) {
         ctx->err = "msm: workspace too small"; return ZKPOR_E_OOM;
     }
     {
@@ -174,40 +172,38 @@ inline int32_t msm_accumulate(zkpor_ctx* ctx, const DigitStream& ds, const Affin
             T = Tn;
         }
     }
+    const XYZZ<F>* fin_S = nullptr;
+    const XYZZ<F>* fin_Y = nullptr;
+    u64 Kmul = 0;  // g_1 + g_1 g_2 + ... + g_1..g_{L-1}
     {
         PhaseScope ps(ctx, "msm_reduce");
-        const u32 Wn = (u32)cfg.W;
-        auto launch = [&](const XYZZ<F>* in, u32 ng, u32 g, XYZZ<F>* oS, XYZZ<F>* oW) {
-            (void)launch_reduce(ctx, in, ng, g, oS, oW);
-        };
-        launch(buckets, cfg.n1 * Wn, cfg.g1, S1, W1);                 // level 1
-        launch(S1, cfg.n2 * Wn, cfg.g2, S2, W2);                      // level 2
-        launch(S2, Wn, cfg.n2, fin, fin + Wn);                        // level 3: S3, W3 per window
-        launch(W1, cfg.n2 * Wn, cfg.g2, Tw, (XYZZ<F>*)nullptr);       // sum of W1: n1 -> n2 per window
-        launch(Tw, Wn, cfg.n2, fin + 2 * Wn, (XYZZ<F>*)nullptr);      //            n2 -> 1
-        launch(W2, Wn, cfg.n2, fin + 3 * Wn, (XYZZ<F>*)nullptr);      // sum of W2
-        ZK_KERNEL_CHECK(ctx);
+        int rem = cfg.c - 1, done_bits = 0, level = 0;
+        u32 count = cfg.NB;  // elements at the current level (all windows)
+        const XYZZ<F>* Sin = buckets;
+        const XYZZ<F>* Yin = nullptr;
+        while (rem > 0) {
+            int gl = rem < 4 ? rem : 4;
+            u32 ng = count >> gl;
+            XYZZ<F>* So = (level & 1) ? Sb : Sa;
+            XYZZ<F>* Yo = (level & 1) ? Yb : Ya;
+            ZK_TRY(launch_reduce(ctx, Sin, Yin, ng, 1u << gl, done_bits, So, Yo));
+            done_bits += gl; rem -= gl; count = ng; Sin = So; Yin = Yo; ++level;
+            if (rem > 0) Kmul += (u64)1 << done_bits;
+        }
+        fin_S = Sin; fin_Y = Yin;
     }
-    std::vector<XYZZ<F>> h(4 * (size_t)cfg.W);
-    ZK_HIP(ctx, hipMemcpyAsync(h.data(), fin, h.size() * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
+    const size_t Wn = (size_t)cfg.W;
+    std::vector<XYZZ<F>> hS(Wn), hY(Wn);
+    ZK_HIP(ctx, hipMemcpyAsync(hS.data(), fin_S, Wn * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(hY.data(), fin_Y, Wn * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // window sum = sumW1 + g1*( sumW2 + g2*(W3 - S3) - S3 ), then Horner with 2^c
+    // window sum = Y_L - Kmul * T, then Horner with 2^c over the windows
     XYZZ<F> acc = XYZZ<F>::inf();
     for (int w = cfg.W - 1; w >= 0; --w) {
         for (int k = 0; k < cfg.c; ++k) acc = xyzz_dbl<F>(acc);
-        const XYZZ<F>& S3 = h[w];
-        const XYZZ<F>& W3 = h[cfg.W + w];
-        const XYZZ<F>& sW1 = h[2 * cfg.W + w];
-        const XYZZ<F>& sW2 = h[3 * cfg.W + w];
-        XYZZ<F> negS3 = xyzz_neg<F>(S3);
-        XYZZ<F> inner = W3;
-        xyzz_add<F>(inner, negS3);
-        inner = xyzz_mul_u64<F>(inner, cfg.g2);
-        xyzz_add<F>(inner, sW2);
-        xyzz_add<F>(inner, negS3);
-        inner = xyzz_mul_u64<F>(inner, cfg.g1);
-        xyzz_add<F>(inner, sW1);
-        xyzz_add<F>(acc, inner);
+        XYZZ<F> win = hY[w];
+        if (Kmul) xyzz_add<F>(win, xyzz_neg<F>(xyzz_mul_u64<F>(hS[w], Kmul)));
+        xyzz_add<F>(acc, win);
     }
     *result = acc;
     return ZKPOR_OK;

@@ -9,8 +9,9 @@ int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp>* src, u32 
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
-int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp>* in, u32 n_groups, u32 g, XYZZ<Fp>* outS, XYZZ<Fp>* outW) {
-    hipLaunchKernelGGL(k_reduce_groups<Fp>, dim3((n_groups + 63u) / 64u), dim3(64), 0, ctx->stream, in, n_groups, g, outS, outW);
+int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp>* Sin, const XYZZ<Fp>* Yin, u32 n_groups, u32 g, int dbl,
+                      XYZZ<Fp>* Sout, XYZZ<Fp>* Yout) {
+    hipLaunchKernelGGL(k_reduce_level<Fp>, dim3((n_groups + 63u) / 64u), dim3(64), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

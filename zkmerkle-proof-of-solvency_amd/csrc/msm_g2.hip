@@ -16,8 +16,9 @@ int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp2>* src, u32
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
-int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp2>* in, u32 n_groups, u32 g, XYZZ<Fp2>* outS, XYZZ<Fp2>* outW) {
-    hipLaunchKernelGGL(k_reduce_groups<Fp2>, dim3((n_groups + 63u) / 64u), dim3(64), 0, ctx->stream, in, n_groups, g, outS, outW);
+int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp2>* Sin, const XYZZ<Fp2>* Yin, u32 n_groups, u32 g, int dbl,
+                      XYZZ<Fp2>* Sout, XYZZ<Fp2>* Yout) {
+    hipLaunchKernelGGL(k_reduce_level<Fp2>, dim3((n_groups + 63u) / 64u), dim3(64), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

@@ -72,10 +72,11 @@ __global__ __launch_bounds__(256) void k_acc_levelN(const u32* __restrict__ keys
     XYZZ<F> acc = XYZZ<F>::inf();
     u32 cur = keys[start];
     bool first = true, head_written = false, tail_written = false;
+    // a bucket receives exactly one non-infinity finished run over the whole recursion (its entries are contiguous:
+    // either it finished inside one chunk at an earlier level, or all of it is still in flight), so a plain
+    // store suffices; entries with an infinity payload only pad the key stream
     auto finish = [&](u32 key) {
-        if (acc.is_inf()) return;
-        XYZZ<F> b = buckets[key];
-        buckets[key] = xyzz_add_nl<F>(b, acc);
+        if (!acc.is_inf()) buckets[key] = acc;
     };
     for (u32 j = start; j < end; ++j) {
         const u32 k = keys[j];
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void k_acc_levelN(const u32* __restrict__ keys
             acc = XYZZ<F>::inf();
         }
         XYZZ<F> p = src[j];
-        acc = xyzz_add_nl<F>(acc, p);
+        xyzz_add<F>(acc, p);
     }
     if (first && cur == prev) { out_part[2 * t] = acc; head_written = true; }
     else if (cur == next) { out_part[2 * t + 1] = acc; tail_written = true; }
@@ -101,21 +102,32 @@ __global__ __launch_bounds__(256) void k_acc_levelN(const u32* __restrict__ keys
 }
 
 // ------------------------------------------------------------------------------------------------ reduce
-// group j covers in[j*g .. j*g+g): outS[j] = sum x_k, outW[j] = sum (k+1) x_k  (running sums from the top)
+// One level of the bucket reduction.  Group j covers Sin[j*g .. j*g+g):
+//   Sout[j] = sum_k x_k                                   (plain sum: the next level's input)
+//   Yout[j] = sum_k Yin[j*g+k]  +  2^dbl * sum_k (k+1) x_k  (weighted sums of all levels so far, pre-scaled)
+// With g_1..g_L the group sizes and T the grand total, the window sum is  Y_L - T * (g_1 + g_1 g_2 + ...)
+// (host side, msm_accumulate).  Small groups (16) keep every level wide and the dependent-add chain short.
 template <class F>
-__global__ __launch_bounds__(64) void k_reduce_groups(const XYZZ<F>* __restrict__ in, u32 n_groups, u32 g,
-                                                      XYZZ<F>* __restrict__ outS, XYZZ<F>* __restrict__ outW) {
+__global__ __launch_bounds__(64) void k_reduce_level(const XYZZ<F>* __restrict__ Sin, const XYZZ<F>* __restrict__ Yin,
+                                                     u32 n_groups, u32 g, int dbl, XYZZ<F>* __restrict__ Sout,
+                                                     XYZZ<F>* __restrict__ Yout) {
     const u32 j = blockIdx.x * 64u + threadIdx.x;
     if (j >= n_groups) return;
-    XYZZ<F> run = XYZZ<F>::inf(), wacc = XYZZ<F>::inf();
-    const XYZZ<F>* base = in + (size_t)j * g;
+    XYZZ<F> run = XYZZ<F>::inf(), wacc = XYZZ<F>::inf(), ysum = XYZZ<F>::inf();
+    const size_t base = (size_t)j * g;
     for (u32 k = g; k-- > 0;) {
-        XYZZ<F> x = base[k];
-        run = xyzz_add_nl<F>(run, x);
-        if (outW) wacc = xyzz_add_nl<F>(wacc, run);
+        XYZZ<F> x = Sin[base + k];
+        xyzz_add<F>(run, x);
+        xyzz_add<F>(wacc, run);
+        if (Yin) {
+            XYZZ<F> y = Yin[base + k];
+            xyzz_add<F>(ysum, y);
+        }
     }
-    outS[j] = run;
-    if (outW) outW[j] = wacc;
+    for (int d = 0; d < dbl; ++d) wacc = xyzz_dbl<F>(wacc);
+    xyzz_add<F>(ysum, wacc);
+    Sout[j] = run;
+    Yout[j] = ysum;
 }
 
 }  // namespace zk
