@@ -1,0 +1,134 @@
+// Fp2 arithmetic with ONE Fp component per lane (gfx950 device code only): lanes 2k / 2k+1 of a wavefront hold the
+// real / imaginary part of the same Fp2 value and exchange operands with DPP quad_perm [1,0,3,2].
+//
+// Why: a G2 bucket accumulator in one lane needs >256 VGPRs (XYZZ<Fp2> = 64 registers + temporaries) and ran at one
+// wave per SIMD with scratch spills.  Split across a lane pair the per-lane state is that of a G1 accumulator, and
+// the complex product needs no Karatsuba: each lane computes its output component as ONE fused double product
+//   even lane: a0*b0 + a1*(p - b1)      odd lane: a1*b0 + a0*b1
+// with a single interleaved Montgomery reduction (192 multiply-add pairs instead of 2 x 128).
+#pragma once
+#include "ec.cuh"
+
+namespace zk {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ u32 lp_swap(u32 x) {
+    return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+#else
+inline u32 lp_swap(u32 x) { return x; }  // host pass only parses this header
+#endif
+
+struct Fp2L {
+    Fp c;  // this lane's component
+
+    ZK_HD static bool odd() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (threadIdx.x & 1u) != 0;
+#else
+        return false;
+#endif
+    }
+    ZK_HD static Fp partner(const Fp& x) {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = lp_swap(x.v[i]);
+        return r;
+    }
+    ZK_HD static Fp2L zero() { return {Fp::zero()}; }
+    ZK_HD static Fp2L one() {
+        Fp o = Fp::one();
+        Fp z = Fp::zero();
+        Fp2L r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.c.v[i] = odd() ? z.v[i] : o.v[i];
+        return r;
+    }
+    ZK_HD bool is_zero() const {
+        u32 o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o |= c.v[i];
+        o |= lp_swap(o);
+        return o == 0;
+    }
+    ZK_HD bool operator==(const Fp2L& b) const {
+        u32 o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o |= c.v[i] ^ b.c.v[i];
+        o |= lp_swap(o);
+        return o == 0;
+    }
+    ZK_HD bool operator!=(const Fp2L& b) const { return !(*this == b); }
+    ZK_HD static Fp2L add(const Fp2L& x, const Fp2L& y) { return {Fp::add(x.c, y.c)}; }
+    ZK_HD static Fp2L sub(const Fp2L& x, const Fp2L& y) { return {Fp::sub(x.c, y.c)}; }
+    ZK_HD static Fp2L neg(const Fp2L& x) { return {Fp::neg(x.c)}; }
+    ZK_HD static Fp2L dbl(const Fp2L& x) { return {Fp::dbl(x.c)}; }
+
+    // (a*X + b*Y) * R^-1 mod p for a,b < p and X,Y <= p: fused product scanning, one reduction, result < 1.5p
+    ZK_HD static Fp mul2(const Fp& a, const Fp& X, const Fp& b, const Fp& Y) {
+        u32 m[8];
+        u32 t[8];
+        u64 acc = 0;
+        u32 ovf = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int i = 0; i <= k; ++i) { mac96(acc, ovf, a.v[i], X.v[k - i]); mac96(acc, ovf, b.v[i], Y.v[k - i]); }
+#pragma unroll
+            for (int i = 0; i < k; ++i) mac96c(acc, ovf, m[i], FpParams::mod(k - i));
+            m[k] = (u32)acc * FpParams::INV;
+            mac96c(acc, ovf, m[k], FpParams::mod(0));
+            acc = (acc >> 32) | ((u64)ovf << 32);
+            ovf = 0;
+        }
+#pragma unroll
+        for (int k = 8; k < 16; ++k) {
+#pragma unroll
+            for (int i = k - 7; i < 8; ++i) { mac96(acc, ovf, a.v[i], X.v[k - i]); mac96(acc, ovf, b.v[i], Y.v[k - i]); }
+#pragma unroll
+            for (int i = k - 7; i < 8; ++i) mac96c(acc, ovf, m[i], FpParams::mod(k - i));
+            t[k - 8] = (u32)acc;
+            acc = (acc >> 32) | ((u64)ovf << 32);
+            ovf = 0;
+        }
+        return Fp::reduce_once(t, (u32)acc);
+    }
+    ZK_HD static Fp2L mul(const Fp2L& x, const Fp2L& y) {
+        const bool od = odd();
+        Fp ao = partner(x.c), bo = partner(y.c);
+        // p - bo (in [1, p]); only the even lane uses it
+        Fp nb;
+        {
+            u32 bw = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u64 d = (u64)FpParams::mod(i) - bo.v[i] - bw;
+                nb.v[i] = (u32)d;
+                bw = (u32)(d >> 32) & 1u;
+            }
+        }
+        Fp X, Y;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            X.v[i] = od ? bo.v[i] : y.c.v[i];
+            Y.v[i] = od ? y.c.v[i] : nb.v[i];
+        }
+        return {mul2(x.c, X, ao, Y)};
+    }
+    // even: (a0 + a1)(a0 - a1)      odd: (a1 + a1) * a0
+    ZK_HD static Fp2L sqr(const Fp2L& x) {
+        const bool od = odd();
+        Fp ao = partner(x.c);
+        Fp s;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.v[i] = od ? x.c.v[i] : ao.v[i];
+        Fp U = Fp::add(x.c, s);
+        Fp d = Fp::sub(x.c, ao);
+        Fp V;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) V.v[i] = od ? ao.v[i] : d.v[i];
+        return {Fp::mul_body(U, V)};
+    }
+};
+
+}  // namespace zk

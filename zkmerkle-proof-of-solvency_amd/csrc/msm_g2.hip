@@ -1,14 +1,7 @@
-// MSM steps 3-4 for G2 (Fp2 coordinates), built with out-of-line Fp products (-DZK_MUL_NOINLINE).
+// MSM step 3 (levels >= 2) and step 4 for G2 (Fp2 coordinates in one lane), built with out-of-line Fp products
+// (-DZK_MUL_NOINLINE).  The hot level-1 kernel lives in msm_g2_pair.hip.
 #include "msm_kernels.cuh"
 namespace zk {
-int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L,
-                      XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part) {
-    u32 T = (M + (u32)L - 1u) / (u32)L;
-    PhaseScope ps(ctx, "k_acc_level1_g2");
-    hipLaunchKernelGGL(k_acc_level1<Fp2>, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
-    ZK_KERNEL_CHECK(ctx);
-    return ZKPOR_OK;
-}
 int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp2>* src, u32 M, int L, XYZZ<Fp2>* buckets,
                       u32* out_keys, XYZZ<Fp2>* out_part) {
     u32 T = (M + (u32)L - 1u) / (u32)L;
