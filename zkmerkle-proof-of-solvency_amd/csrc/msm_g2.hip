@@ -11,7 +11,8 @@ int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp2>* src, u32
 }
 int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp2>* Sin, const XYZZ<Fp2>* Yin, u32 n_groups, u32 g, int dbl,
                       XYZZ<Fp2>* Sout, XYZZ<Fp2>* Yout) {
-    hipLaunchKernelGGL(k_reduce_level<Fp2>, dim3((n_groups + 63u) / 64u), dim3(64), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
+    if (Yin) hipLaunchKernelGGL((k_reduce_level<Fp2, true>), dim3((n_groups + 63u) / 64u), dim3(64), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
+    else hipLaunchKernelGGL((k_reduce_level<Fp2, false>), dim3((n_groups + 63u) / 64u), dim3(64), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_acc_levelN(const u32* __restrict__ keys
 //   Yout[j] = sum_k Yin[j*g+k]  +  2^dbl * sum_k (k+1) x_k  (weighted sums of all levels so far, pre-scaled)
 // With g_1..g_L the group sizes and T the grand total, the window sum is  Y_L - T * (g_1 + g_1 g_2 + ...)
 // (host side, msm_accumulate).  Small groups (16) keep every level wide and the dependent-add chain short.
-template <class F>
+template <class F, bool HAS_Y>
 __global__ __launch_bounds__(64) void k_reduce_level(const XYZZ<F>* __restrict__ Sin, const XYZZ<F>* __restrict__ Yin,
                                                      u32 n_groups, u32 g, int dbl, XYZZ<F>* __restrict__ Sout,
                                                      XYZZ<F>* __restrict__ Yout) {
@@ -119,15 +119,19 @@ __global__ __launch_bounds__(64) void k_reduce_level(const XYZZ<F>* __restrict__
         XYZZ<F> x = Sin[base + k];
         xyzz_add<F>(run, x);
         xyzz_add<F>(wacc, run);
-        if (Yin) {
+        if (HAS_Y) {
             XYZZ<F> y = Yin[base + k];
             xyzz_add<F>(ysum, y);
         }
     }
-    for (int d = 0; d < dbl; ++d) wacc = xyzz_dbl<F>(wacc);
-    xyzz_add<F>(ysum, wacc);
     Sout[j] = run;
-    Yout[j] = ysum;
+    if (HAS_Y) {
+        for (int d = 0; d < dbl; ++d) wacc = xyzz_dbl<F>(wacc);
+        xyzz_add<F>(ysum, wacc);
+        Yout[j] = ysum;
+    } else {
+        Yout[j] = wacc;  // first level: dbl == 0 and there is no previous Y
+    }
 }
 
 }  // namespace zk
