@@ -59,6 +59,35 @@ def cpu_baseline(log2_sample, log2_full, commit_frac):
                       f"scaled x{int(scale)} to D=2^{log2_full}; reference publishes 62 s/proof on 32 vCPU (gnark)"}
 
 
+def shard_heights(n_batches, rank, world):
+    """contiguous shard of batch heights for this rank: every height exactly once (host/prover_host.hpp shard_range)"""
+    base, extra = divmod(n_batches, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def timed_region(dist, sync, run):
+    """the bench contract: barrier + device sync on both sides of the timed work, MAX of the elapsed time over ranks"""
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,22 +198,9 @@ def main():
 
     run_steps(max(args.warmup, len(workers) if args.warmup else 0))
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
     for wk in workers:
         wk[0].phase_reset()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_region(dist, torch.cuda.synchronize, lambda: run_steps(args.steps))
 
     phases = {}
     for name in ("msm_decompose", "msm_sort", "msm_accumulate", "msm_reduce", "k_acc_level1_g1", "k_acc_level1_g2", "ntt", "pointwise"):

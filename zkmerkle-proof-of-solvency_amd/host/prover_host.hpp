@@ -1,0 +1,202 @@
+// Host-side mirror of the reference's prover service for ONE process driving several GPUs
+// (src/prover/prover/prover.go: NewProver :45, FetchBatchWitness :86, FetchBatchWitnessForRerun :107, Run :139).
+// The reference fans work out with N OS processes + a Redis list (BRPOP, prover.go:72-84) + MySQL row status;
+// here the list is an in-process queue and the tables are interfaces, so one process can feed 8 MI355X contexts
+// (one worker thread per GPU, each calling the C ABI of include/zkpor.h through `ProveFn`).
+// Semantics kept: exactly-once hand-out, status CAS Published -> Received -> Finished
+// (witness_model.go:129-152), duplicate-proof guard (prover.go:208-225), rerun scan Received-then-Published
+// (:107-137), exit when the queue is empty (:155-159).  Names follow the reference.
+// The Go toolchain is absent from the build image, so this is C++ (the reference is compiled code).
+#pragma once
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace zkpor_host {
+
+enum { StatusPublished = 0, StatusReceived = 1, StatusFinished = 2 };  // witness_model.go:12-16
+enum Err { Ok = 0, DbErrNotFound = 1, DbErrDuplicate = 2, QueueNil = 3, ProveFailed = 4 };
+
+struct BatchWitness {  // witness_model.go:43-48
+    int64_t Height = 0;
+    std::string WitnessData;  // base64(s2(gob(BatchCreateUserWitness))) in the reference; opaque here
+    int Status = StatusPublished;
+};
+struct Proof {  // proof_model.go:29-39
+    std::string ProofInfo;  // base64(raw proof) in the reference; raw bytes here
+    int64_t BatchNumber = 0;
+    int AssetsCount = 0;
+};
+
+class WitnessModel {  // in-memory stand-in for the gorm table; every method is one "transaction"
+public:
+    void CreateBatchWitness(const BatchWitness& w) { std::lock_guard<std::mutex> g(mu_); rows_[w.Height] = w; }
+    // compare-and-set of the status of the row at `height` (GetAndUpdateBatchesWitnessByHeight, witness_model.go:129)
+    Err GetAndUpdateBatchesWitnessByHeight(int64_t height, int before, int after, std::vector<BatchWitness>* out) {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = rows_.find(height);
+        if (it == rows_.end() || it->second.Status != before) return DbErrNotFound;
+        it->second.Status = after;
+        out->assign(1, it->second);
+        return Ok;
+    }
+    Err GetLatestBatchWitnessByStatus(int status, BatchWitness* out) {
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto it = rows_.rbegin(); it != rows_.rend(); ++it)
+            if (it->second.Status == status) { *out = it->second; return Ok; }
+        return DbErrNotFound;
+    }
+    Err UpdateBatchWitnessStatus(const BatchWitness& w, int status) {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = rows_.find(w.Height);
+        if (it == rows_.end()) return DbErrNotFound;
+        it->second.Status = status;
+        return Ok;
+    }
+    size_t CountByStatus(int status) {
+        std::lock_guard<std::mutex> g(mu_);
+        size_t n = 0;
+        for (auto& kv : rows_) n += kv.second.Status == status;
+        return n;
+    }
+private:
+    std::mutex mu_;
+    std::map<int64_t, BatchWitness> rows_;
+};
+
+class ProofModel {  // BatchNumber is unique (proof_model.go:33)
+public:
+    Err CreateProof(const Proof& p) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!rows_.emplace(p.BatchNumber, p).second) return DbErrDuplicate;
+        return Ok;
+    }
+    Err GetProofByBatchNumber(int64_t n, Proof* out) {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = rows_.find(n);
+        if (it == rows_.end()) return DbErrNotFound;
+        if (out) *out = it->second;
+        return Ok;
+    }
+    size_t Count() { std::lock_guard<std::mutex> g(mu_); return rows_.size(); }
+private:
+    std::mutex mu_;
+    std::map<int64_t, Proof> rows_;
+};
+
+class TaskQueue {  // the Redis list por_batch_task_queue_{suffix}: LPUSH by dbtool, BRPOP by provers
+public:
+    void LPush(int64_t height) {
+        { std::lock_guard<std::mutex> g(mu_); q_.push_front(height); }
+        cv_.notify_one();
+    }
+    Err BRPop(std::chrono::milliseconds timeout, int64_t* height) {  // redis.Nil after the timeout
+        std::unique_lock<std::mutex> g(mu_);
+        if (!cv_.wait_for(g, timeout, [&] { return !q_.empty(); })) return QueueNil;
+        *height = q_.back();
+        q_.pop_back();
+        return Ok;
+    }
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<int64_t> q_;
+};
+
+// proves one batch on one GPU context: fills the raw proof bytes and the tier; non-zero = error
+typedef std::function<int(int gpu, const BatchWitness&, std::string* proof_raw, int* assets_count)> ProveFn;
+
+class Prover {
+public:
+    Prover(WitnessModel* wm, ProofModel* pm, TaskQueue* q, int gpu, ProveFn fn, std::chrono::milliseconds brpop_timeout)
+        : witnessModel(wm), proofModel(pm), queue(q), gpu_(gpu), prove_(std::move(fn)), timeout_(brpop_timeout) {}
+
+    Err FetchBatchWitness(std::vector<BatchWitness>* out) {  // prover.go:86-105
+        int64_t h;
+        Err e = queue->BRPop(timeout_, &h);
+        if (e != Ok) return e;
+        return witnessModel->GetAndUpdateBatchesWitnessByHeight(h, StatusPublished, StatusReceived, out);
+    }
+    Err FetchBatchWitnessForRerun(std::vector<BatchWitness>* out) {  // prover.go:107-137
+        BatchWitness w;
+        Err e = witnessModel->GetLatestBatchWitnessByStatus(StatusReceived, &w);
+        if (e == DbErrNotFound) e = witnessModel->GetLatestBatchWitnessByStatus(StatusPublished, &w);
+        if (e != Ok) return e;
+        out->assign(1, w);
+        return Ok;
+    }
+    // prover.go:139-247.  Returns the number of proofs this worker created, or -1 after a prove failure.
+    int Run(bool rerun) {
+        int made = 0;
+        for (;;) {
+            std::vector<BatchWitness> batch;
+            Err e = rerun ? FetchBatchWitnessForRerun(&batch) : FetchBatchWitness(&batch);
+            if (e == QueueNil) return made;                      // "There is no task left in task queue"
+            if (e == DbErrNotFound) { if (rerun) return made; continue; }  // someone else owns that height
+            for (auto& bw : batch) {
+                std::string raw;
+                int assets = 0;
+                if (prove_(gpu_, bw, &raw, &assets) != 0) return -1;
+                if (proofModel->GetProofByBatchNumber(bw.Height, nullptr) == Ok) {  // duplicate-proof guard
+                    witnessModel->UpdateBatchWitnessStatus(bw, StatusFinished);
+                    continue;
+                }
+                Proof row;
+                row.ProofInfo = raw; row.BatchNumber = bw.Height; row.AssetsCount = assets;
+                if (proofModel->CreateProof(row) != Ok) return -1;
+                witnessModel->UpdateBatchWitnessStatus(bw, StatusFinished);
+                ++made;
+            }
+        }
+    }
+    WitnessModel* witnessModel;
+    ProofModel* proofModel;
+    TaskQueue* queue;
+private:
+    int gpu_;
+    ProveFn prove_;
+    std::chrono::milliseconds timeout_;
+};
+
+// one worker thread (= one Prover, one zkpor_ctx) per GPU
+class Dispatcher {
+public:
+    Dispatcher(int n_gpus, ProveFn fn, std::chrono::milliseconds brpop_timeout = std::chrono::milliseconds(50))
+        : n_(n_gpus), fn_(std::move(fn)), timeout_(brpop_timeout) {}
+    WitnessModel witnessModel;
+    ProofModel proofModel;
+    TaskQueue queue;
+    // returns per-worker proof counts (or -1)
+    std::vector<int> Run(bool rerun) {
+        std::vector<int> made(n_, 0);
+        std::vector<std::thread> th;
+        for (int g = 0; g < n_; ++g)
+            th.emplace_back([&, g] {
+                Prover p(&witnessModel, &proofModel, &queue, g, fn_, timeout_);
+                made[g] = p.Run(rerun);
+            });
+        for (auto& t : th) t.join();
+        return made;
+    }
+private:
+    int n_;
+    ProveFn fn_;
+    std::chrono::milliseconds timeout_;
+};
+
+// static contiguous sharding used by the one-process-per-GPU launcher (bench.py / torchrun): rank r of `world`
+// proves heights [lo, hi) — every height exactly once, sizes differ by at most one
+inline void shard_range(int64_t n_batches, int rank, int world, int64_t* lo, int64_t* hi) {
+    int64_t base = n_batches / world, extra = n_batches % world;
+    *lo = rank * base + (rank < extra ? rank : extra);
+    *hi = *lo + base + (rank < extra ? 1 : 0);
+}
+
+}  // namespace zkpor_host
