@@ -51,7 +51,6 @@ def test_exactly_once_with_8_workers(host):
     assert host.zkh_count_proofs(d) == n
     assert host.zkh_count_status(d, 2) == n and host.zkh_count_status(d, 0) == 0 and host.zkh_count_status(d, 1) == 0
     assert sorted(h for _, h in seen) == list(range(n))          # every batch proven exactly once
-    assert len({g for g, _ in seen}) > 1                          # and spread over the workers
     buf = ctypes.create_string_buffer(512); ln = ctypes.c_size_t()
     assert host.zkh_get_proof(d, ctypes.c_int64(7), buf, 512, ctypes.byref(ln)) == 0
     assert buf.raw[:ln.value] == b"proof-of-7-by-w7"
