@@ -14,34 +14,51 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair(const u32* __restrict
                                                            const Affine<Fp2>* __restrict__ pts, u32 M, int L,
                                                            XYZZ<Fp2>* __restrict__ buckets, u32* __restrict__ out_keys,
                                                            XYZZ<Fp2>* __restrict__ out_part) {
-    const u32 gt = blockIdx.x * 256u + threadIdx.x;
-    const u32 t = gt >> 1, par = gt & 1u;
+    __shared__ u32 sk[128 * ACC_PITCH];
+    __shared__ u32 sv[128 * ACC_PITCH];
+    const u32 row0 = blockIdx.x * 128u;          // 128 lane pairs per block
+    const u32 lr = threadIdx.x >> 1, par = threadIdx.x & 1u;
+    const u32 t = row0 + lr;
     const u32 T = (M + (u32)L - 1u) / (u32)L;
-    if (t >= T) return;  // both lanes of a pair leave together
-    const u32 start = t * (u32)L;
-    const u32 end = (start + (u32)L < M) ? start + (u32)L : M;
-    const u32 prev = start > 0 ? keys[start - 1] : NOKEY;
-    const u32 next = end < M ? keys[end] : NOKEY;
+    const bool live = t < T;                       // both lanes of a pair agree
+    const u32 start = live ? t * (u32)L : 0u;
+    const u32 end = live ? ((start + (u32)L < M) ? start + (u32)L : M) : 0u;
+    const u32 prev = (live && start > 0) ? keys[start - 1] : NOKEY;
+    const u32 next = (live && end < M) ? keys[end] : NOKEY;
     XYZZ<Fp2L> acc = XYZZ<Fp2L>::inf();
-    u32 cur = keys[start];
+    u32 cur = live ? keys[start] : NOKEY;
+    const u32 first_key = cur;
+    u32 last_key = cur;
     bool first = true, head_written = false, tail_written = false;
-    for (u32 j = start; j < end; ++j) {
-        const u32 k = keys[j];
-        const u32 v = vals[j];
-        if (k != cur) {
-            if (first && cur == prev) { lp_store(out_part + 2 * t, acc, par); head_written = true; }
-            else lp_store(buckets + cur, acc, par);
-            first = false;
-            cur = k;
-            acc = XYZZ<Fp2L>::inf();
-        }
-        const Fp* pp = (const Fp*)(pts + (v >> 1));
-        Fp2L px = {pp[par]}, py = {pp[2 + par]};
-        if (!(px.is_zero() & py.is_zero())) {
-            if (v & 1u) py = Fp2L::neg(py);
-            xyzz_madd<Fp2L>(acc, px, py);
+    const int nphase = (L + ACC_SUB - 1) / ACC_SUB;
+    const u32 rows = (T - row0 < 128u) ? T - row0 : 128u;
+    for (int ph = 0; ph < nphase; ++ph) {
+        if (ph) __syncthreads();
+        acc_stage(keys, vals, M, L, row0, rows, ph, sk, sv);
+        __syncthreads();
+        if (!live) continue;
+        const u32 j0 = start + (u32)ph * ACC_SUB;
+        const u32 j1 = (j0 + ACC_SUB < end) ? j0 + ACC_SUB : end;
+        for (u32 j = j0; j < j1; ++j) {
+            const u32 k = sk[lr * ACC_PITCH + (j - j0)];
+            const u32 v = sv[lr * ACC_PITCH + (j - j0)];
+            if (k != cur) {
+                if (first && cur == prev) { lp_store(out_part + 2 * t, acc, par); head_written = true; }
+                else lp_store(buckets + cur, acc, par);
+                first = false;
+                cur = k;
+                acc = XYZZ<Fp2L>::inf();
+            }
+            last_key = k;
+            const Fp* pp = (const Fp*)(pts + (v >> 1));
+            Fp2L px = {pp[par]}, py = {pp[2 + par]};
+            if (!(px.is_zero() & py.is_zero())) {
+                if (v & 1u) py = Fp2L::neg(py);
+                xyzz_madd<Fp2L>(acc, px, py);
+            }
         }
     }
+    if (!live) return;
     if (first && cur == prev) { lp_store(out_part + 2 * t, acc, par); head_written = true; }
     else if (cur == next) { lp_store(out_part + 2 * t + 1, acc, par); tail_written = true; }
     else lp_store(buckets + cur, acc, par);
@@ -50,8 +67,8 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair(const u32* __restrict
         if (!head_written) lp_store(out_part + 2 * t, z, par);
         if (!tail_written) lp_store(out_part + 2 * t + 1, z, par);
         if (par == 0) {
-            out_keys[2 * t] = keys[start];
-            out_keys[2 * t + 1] = keys[end - 1];
+            out_keys[2 * t] = first_key;
+            out_keys[2 * t + 1] = last_key;
         }
     }
 }
@@ -60,7 +77,7 @@ int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Af
                       XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part) {
     u32 T = (M + (u32)L - 1u) / (u32)L;
     PhaseScope ps(ctx, "k_acc_level1_g2");
-    hipLaunchKernelGGL(k_acc_level1_g2pair, dim3((2u * T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
+    hipLaunchKernelGGL(k_acc_level1_g2pair, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

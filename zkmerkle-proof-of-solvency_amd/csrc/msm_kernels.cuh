@@ -14,45 +14,83 @@ struct AccOut {
 };
 
 // Level 1: affine key points gathered through the sorted (key,val) stream.
+// The (key,val) words of a block's chunks are staged through LDS in sub-phases of ACC_SUB entries per thread with
+// coalesced global loads: read one-by-one they cost a 64-byte fabric request per 4-byte word (measured with
+// rocprofv3 FETCH_SIZE: 185 B/entry instead of ~72), which made this kernel HBM-bound.
+static constexpr int ACC_SUB = 16;
+static constexpr int ACC_PITCH = ACC_SUB + 1;  // odd pitch: conflict-free column reads
+
+// cooperative load of phase `ph`: row r of the tile = the ACC_SUB entries [ (row0+r)*L + ph*ACC_SUB, ... ) of thread r
+ZK_D void acc_stage(const u32* __restrict__ keys, const u32* __restrict__ vals, u32 M, int L, u32 row0, u32 rows, int ph,
+                    u32* sk, u32* sv) {
+    const u32 total = rows * (u32)ACC_SUB;
+    for (u32 idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        u32 r = idx / (u32)ACC_SUB, c = idx % (u32)ACC_SUB;
+        u32 col = (u32)ph * ACC_SUB + c;
+        u64 g = (u64)(row0 + r) * (u32)L + col;
+        if (col < (u32)L && g < M) {
+            sk[r * ACC_PITCH + c] = keys[g];
+            sv[r * ACC_PITCH + c] = vals[g];
+        }
+    }
+}
+
 template <class F>
 __global__ __launch_bounds__(256) void k_acc_level1(const u32* __restrict__ keys, const u32* __restrict__ vals,
                                                     const Affine<F>* __restrict__ pts, u32 M, int L,
                                                     XYZZ<F>* __restrict__ buckets, u32* __restrict__ out_keys,
                                                     XYZZ<F>* __restrict__ out_part) {
-    const u32 t = blockIdx.x * 256u + threadIdx.x;
+    __shared__ u32 sk[256 * ACC_PITCH];
+    __shared__ u32 sv[256 * ACC_PITCH];
+    const u32 row0 = blockIdx.x * 256u;
+    const u32 t = row0 + threadIdx.x;
     const u32 T = (M + (u32)L - 1u) / (u32)L;
-    if (t >= T) return;
-    const u32 start = t * (u32)L;
-    const u32 end = (start + (u32)L < M) ? start + (u32)L : M;
-    const u32 prev = start > 0 ? keys[start - 1] : NOKEY;
-    const u32 next = end < M ? keys[end] : NOKEY;
+    const bool live = t < T;
+    const u32 start = live ? t * (u32)L : 0u;
+    const u32 end = live ? ((start + (u32)L < M) ? start + (u32)L : M) : 0u;
+    const u32 prev = (live && start > 0) ? keys[start - 1] : NOKEY;
+    const u32 next = (live && end < M) ? keys[end] : NOKEY;
     XYZZ<F> acc = XYZZ<F>::inf();
-    u32 cur = keys[start];
+    u32 cur = live ? keys[start] : NOKEY;
+    const u32 first_key = cur;
+    u32 last_key = cur;
     bool first = true, head_written = false, tail_written = false;
-    for (u32 j = start; j < end; ++j) {
-        const u32 k = keys[j];
-        const u32 v = vals[j];
-        if (k != cur) {
-            if (first && cur == prev) { out_part[2 * t] = acc; head_written = true; }
-            else buckets[cur] = acc;
-            first = false;
-            cur = k;
-            acc = XYZZ<F>::inf();
-        }
-        Affine<F> p = pts[v >> 1];
-        if (!p.is_inf()) {
-            if (v & 1u) p.y = F::neg(p.y);
-            xyzz_madd<F>(acc, p.x, p.y);
+    const int nphase = (L + ACC_SUB - 1) / ACC_SUB;
+    const u32 rows = (T - row0 < 256u) ? T - row0 : 256u;
+    for (int ph = 0; ph < nphase; ++ph) {
+        if (ph) __syncthreads();
+        acc_stage(keys, vals, M, L, row0, rows, ph, sk, sv);
+        __syncthreads();
+        if (!live) continue;
+        const u32 j0 = start + (u32)ph * ACC_SUB;
+        const u32 j1 = (j0 + ACC_SUB < end) ? j0 + ACC_SUB : end;
+        for (u32 j = j0; j < j1; ++j) {
+            const u32 k = sk[threadIdx.x * ACC_PITCH + (j - j0)];
+            const u32 v = sv[threadIdx.x * ACC_PITCH + (j - j0)];
+            if (k != cur) {
+                if (first && cur == prev) { out_part[2 * t] = acc; head_written = true; }
+                else buckets[cur] = acc;
+                first = false;
+                cur = k;
+                acc = XYZZ<F>::inf();
+            }
+            last_key = k;
+            Affine<F> p = pts[v >> 1];
+            if (!p.is_inf()) {
+                if (v & 1u) p.y = F::neg(p.y);
+                xyzz_madd<F>(acc, p.x, p.y);
+            }
         }
     }
+    if (!live) return;
     if (first && cur == prev) { out_part[2 * t] = acc; head_written = true; }
     else if (cur == next) { out_part[2 * t + 1] = acc; tail_written = true; }
     else buckets[cur] = acc;
     if (T > 1) {
         if (!head_written) out_part[2 * t] = XYZZ<F>::inf();
         if (!tail_written) out_part[2 * t + 1] = XYZZ<F>::inf();
-        out_keys[2 * t] = keys[start];
-        out_keys[2 * t + 1] = keys[end - 1];
+        out_keys[2 * t] = first_key;
+        out_keys[2 * t + 1] = last_key;
     }
 }
 
