@@ -88,6 +88,10 @@ ZK_HD void mac96c(u64& acc, u32& ovf, u32 a, u32 c) {
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fe_asm.inc"
+#endif
+
 template <class P>
 struct Fe {
     u32 v[8];
@@ -178,6 +182,16 @@ struct Fe {
     }
     // Montgomery product a*b*R^-1 mod m, product scanning with interleaved reduction (FIPS)
     ZK_HD static Fe mul_body(const Fe& a, const Fe& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM_MUL)
+        Fe r = a;
+        mont_mul_asm<P>(r.v, b.v);
+        return r;
+#else
+        return mul_portable(a, b);
+#endif
+    }
+    // portable C++ form of the same product-scanning algorithm (host builds; reference for the asm block)
+    ZK_HD static Fe mul_portable(const Fe& a, const Fe& b) {
         u32 m[8];
         u32 t[8];
         u64 acc = 0;
