@@ -105,6 +105,7 @@ int32_t zkpor_compute_h(zkpor_ctx* ctx, int log2_domain, const uint64_t* a, cons
 int32_t zkpor_compute_h_dev(zkpor_ctx* ctx, int log2_domain, void* d_a, void* d_b, void* d_c);
 /* single transforms (gnark-crypto fft.Domain.FFT / FFTInverse): decimation 0 = DIT, 1 = DIF */
 int32_t zkpor_fft(zkpor_ctx* ctx, uint64_t* a, int log2n, int inverse, int decimation, int on_coset);
+int32_t zkpor_fft_dev(zkpor_ctx* ctx, void* d_a, int log2n, int inverse, int decimation, int on_coset);
 
 /* ---- Groth16 prove tail: everything in groth16.Prove after the R1CS solver ------------------------------ */
 /* w: n_wires wire values (full assignment, ONE wire first); a,b,c: n_constraints evaluations; r,s: blinding

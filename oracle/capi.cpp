@@ -62,7 +62,10 @@ void orc_fr_mul(const Fr* a, const Fr* b, Fr* out, size_t n) { for (size_t i = 0
 void orc_fr_add(const Fr* a, const Fr* b, Fr* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = Fr::add(a[i], b[i]); }
 void orc_fr_sub(const Fr* a, const Fr* b, Fr* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = Fr::sub(a[i], b[i]); }
 void orc_fr_inv(const Fr* a, Fr* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = Fr::inv(a[i]); }
-void orc_fr_from_canon(const u64* c, Fr* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = Fr::from_canon(c + 4 * i); }
+void orc_fr_from_canon(const u64* c, Fr* out, size_t n) {
+#pragma omp parallel for schedule(static) if (n > 4096)
+    for (size_t i = 0; i < n; ++i) out[i] = Fr::from_canon(c + 4 * i);
+}
 void orc_fr_to_canon(const Fr* a, u64* out, size_t n) { for (size_t i = 0; i < n; ++i) a[i].to_canon(out + 4 * i); }
 void orc_fp_from_canon(const u64* c, Fp* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = Fp::from_canon(c + 4 * i); }
 void orc_fp_to_canon(const Fp* a, u64* out, size_t n) { for (size_t i = 0; i < n; ++i) a[i].to_canon(out + 4 * i); }

@@ -1,0 +1,155 @@
+"""-m gpu: the hot path at BASELINE.json's FULL size (D = 2^26, zkpor50_1380 shape) checked through size-independent
+properties — the oracle cannot run 2^26-point MSMs in test time:
+  * MSM: the synthetic key's points are s_i*G with a known s_i  =>  MSM(w) == (sum s_i w_i) * G   (G1 over A, G2 over B2)
+  * NTT: inverse(forward(x)) == x on the coset at 2^26
+  * computeH: for A = B = X^(D/2+1), C = X^2 the quotient is exactly H = X^2
+  * Merkle: root(2^27 leaves) == H(H(root(left half), root(right half)), nil) one level up
+Set ZKPOR_FULLSIZE_LOG2 to shrink (default 26)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import zkpor
+
+pytestmark = pytest.mark.gpu
+LOG2 = int(os.environ.get("ZKPOR_FULLSIZE_LOG2", "26"))
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _smix(x):
+    x = x + np.uint64(0x9e3779b97f4a7c15)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+    return x ^ (x >> np.uint64(31))
+
+
+def _synth_scalars_canon(seed, arr, n, inf_mod):
+    """vectorised zkpor.synth_scalar: canonical limbs (n,4) of k(run) + j*q, zeroed where the synthetic point is infinity"""
+    with np.errstate(over="ignore"):
+        i = np.arange(n, dtype=np.uint64)
+        run = i // np.uint64(zkpor.SYNTH_RUN)
+        j = (i % np.uint64(zkpor.SYNTH_RUN)).astype(np.int64)
+        x = np.uint64(seed) ^ np.uint64(((arr + 1) * 0xa0761d6478bd642f) & 0xFFFFFFFFFFFFFFFF) ^ (run * np.uint64(0xe7037ed1a0b428db))
+        k = _smix(x) | np.uint64(1)
+        jq = [jj * zkpor.SYNTH_Q for jj in range(zkpor.SYNTH_RUN)]
+        jq_lo = np.array([v & 0xFFFFFFFFFFFFFFFF for v in jq], dtype=np.uint64)[j]
+        jq_hi = np.array([v >> 64 for v in jq], dtype=np.uint64)[j]
+        lo = k + jq_lo
+        hi = jq_hi + (lo < k).astype(np.uint64)
+        out = np.zeros((n, 4), dtype=np.uint64)
+        out[:, 0] = lo
+        out[:, 1] = hi
+        if inf_mod:
+            h = i * np.uint64(0xd6e8feb86659fd93)
+            h ^= h >> np.uint64(32)
+            out[(h % np.uint64(inf_mod)) == 0] = 0
+    return out
+
+
+def test_synth_scalar_vectorisation_matches_reference():
+    n = 5000
+    c = _synth_scalars_canon(99, zkpor.G1_A, n, 64)
+    ints = O.limbs_to_ints(c)
+    for i in (0, 1, 31, 32, 33, 777, 4999):
+        exp = 0 if zkpor.synth_is_inf(i, 64) else zkpor.synth_scalar(99, zkpor.G1_A, i)
+        assert ints[i] == exp
+
+
+def test_msm_fullsize_trapdoor(zk):
+    n = 1 << LOG2
+    seed = 0x5A4B504F52
+    pk = zkpor.ProvingKey(zk)
+    wbuf = zk.alloc(32 * n)
+    try:
+        pk.synth(LOG2, n, 3, 1024, seed)
+        zk.fill_fr(wbuf, n, 2, 1)                      # witness-like mixture
+        w = wbuf.download(np.uint64, (n, 4))
+        pa, na = pk.g1_dev(zkpor.G1_A)
+        assert na == n
+        got = zk.msm_g1_dev(pa, wbuf.ptr, n)
+        s = O.fr_from_ints([0])                        # force library load
+        sA = np.empty((n, 4), dtype=np.uint64)
+        O.lib().orc_fr_from_canon(O._p(_synth_scalars_canon(seed, zkpor.G1_A, n, 64)), O._p(sA), n)
+        expect = O.g1_from_scalars(O.fr_dot(sA, w).reshape(1, 4))[0]
+        assert np.array_equal(O.g1_jac_to_affine(got)[0], expect)
+        del sA
+        # G2 over B2 (10% infinity, same scalars as B1)
+        pb, nb = pk.g2_dev()
+        got2 = zk.msm_g2_dev(pb, wbuf.ptr, nb)
+        sB = np.empty((n, 4), dtype=np.uint64)
+        O.lib().orc_fr_from_canon(O._p(_synth_scalars_canon(seed, zkpor.G1_B, n, 10)), O._p(sB), n)
+        expect2 = O.g2_from_scalars(O.fr_dot(sB, w).reshape(1, 4))[0]
+        assert np.array_equal(O.g2_jac_to_affine(got2)[0], expect2)
+    finally:
+        wbuf.free()
+        pk.close()
+
+
+def test_ntt_fullsize_roundtrip(zk):
+    n = 1 << LOG2
+    buf = zk.alloc(32 * n)
+    try:
+        zk.fill_fr(buf, n, 7, 0)
+        before = buf.download(np.uint64, (n, 4))
+        zk.fft_dev(buf.ptr, LOG2, False, O.DIF, True)
+        mid = buf.download(np.uint64, (1024, 4))
+        assert not np.array_equal(mid, before[:1024])
+        zk.fft_dev(buf.ptr, LOG2, True, O.DIT, True)
+        assert np.array_equal(buf.download(np.uint64, (n, 4)), before)
+    finally:
+        buf.free()
+
+
+def _rev(x, bits):
+    return int(format(x, "0%db" % bits)[::-1], 2)
+
+
+def test_compute_h_fullsize_known_quotient(zk):
+    """A = B = X^(D/2+1), C = X^2  =>  A*B - C = X^2 (X^D - 1)  =>  H = X^2, i.e. h is the unit vector at (bit-reversed) 2"""
+    n = 1 << LOG2
+    one = O.fr_from_ints([1])
+    bufs = [zk.alloc(32 * n) for _ in range(3)]
+    try:
+        for buf, k in zip(bufs, (n // 2 + 1, n // 2 + 1, 2)):
+            zk.lib.zkpor_dev_fill_fr  # (keep the symbol referenced)
+            z = np.zeros((1 << 16, 4), dtype=np.uint64)
+            for off in range(0, n, 1 << 16):           # zero the buffer in 2 MiB pieces
+                zkpor.DevBuf.upload(_view(zk, buf, off * 32, z.nbytes), z)
+            zkpor.DevBuf.upload(_view(zk, buf, _rev(k, LOG2) * 32, 32), one)   # coefficient vector in bit-reversed order
+            zk.fft_dev(buf.ptr, LOG2, False, O.DIT, False)                     # -> evaluations in natural order
+        zk.compute_h_dev(LOG2, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)
+        h = bufs[0].download(np.uint64, (n, 4))
+        pos = _rev(2, LOG2)
+        assert np.array_equal(h[pos], one[0])
+        h[pos] = 0
+        assert not h.any()
+    finally:
+        for b in bufs:
+            b.free()
+
+
+def _view(zk, buf, offset, nbytes):
+    v = zkpor.DevBuf.__new__(zkpor.DevBuf)
+    v.ctx = zk; v.ptr = buf.ptr + offset; v.nbytes = nbytes
+    return v
+
+
+def test_merkle_fullsize_split_property(zk):
+    log2 = min(27, LOG2 + 1)                                 # the reference's BenchmarkBuild size is 2^27 leaves
+    n, depth = 1 << log2, 28
+    buf = zk.alloc(32 * n)
+    try:
+        zk.fill_fr(buf, n, 5, 0)
+        nil = O.poseidon_hash(O.fr_from_ints([0, 0, 0, 0, 0]))
+        root = zk.merkle_build_dev(buf.ptr, n, depth, nil)
+        left = zk.merkle_build_dev(buf.ptr, n // 2, log2 - 1, nil)
+        right = zk.merkle_build_dev(buf.ptr + 32 * (n // 2), n // 2, log2 - 1, nil)
+        node = O.poseidon_hash(np.stack([left, right]))
+        _, nilh, _ = O.merkle_build(np.zeros((0, 4), np.uint64), depth, nil)
+        for l in range(log2, depth):
+            node = O.poseidon_hash(np.stack([node, nilh[l]]))
+        assert np.array_equal(root, node)
+    finally:
+        buf.free()

@@ -319,6 +319,11 @@ int32_t zkpor_fft(zkpor_ctx* ctx, uint64_t* a, int log2n, int inverse, int decim
     return rc;
 }
 
+int32_t zkpor_fft_dev(zkpor_ctx* ctx, void* d_a, int log2n, int inverse, int decimation, int on_coset) {
+    if (!ctx || !d_a || log2n < 1 || log2n > 28) return ZKPOR_E_ARG;
+    return ntt_dev(ctx, (Fr*)d_a, log2n, inverse != 0, decimation == 1, on_coset != 0);
+}
+
 int32_t zkpor_compute_h_dev(zkpor_ctx* ctx, int log2_domain, void* d_a, void* d_b, void* d_c) {
     if (!ctx || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
     return compute_h_dev(ctx, log2_domain, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c);

@@ -138,6 +138,9 @@ class Context:
         self._ck(self.lib.zkpor_fft(self.h, _p(a), ctypes.c_int(log2n), ctypes.c_int(int(inverse)), ctypes.c_int(decimation), ctypes.c_int(int(on_coset))))
         return a
 
+    def fft_dev(self, d_a, log2n, inverse=False, decimation=1, on_coset=False):
+        self._ck(self.lib.zkpor_fft_dev(self.h, ctypes.c_void_p(d_a), ctypes.c_int(log2n), ctypes.c_int(int(inverse)), ctypes.c_int(decimation), ctypes.c_int(int(on_coset))))
+
     def compute_h(self, a, b, c, log2_domain):
         a = _u64(a); b = _u64(b); c = _u64(c)
         out = np.empty((1 << log2_domain, 4), dtype=np.uint64)
