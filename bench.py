@@ -25,6 +25,21 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def pmc_traffic_bytes_per_launch(kernel="k_acc_level1<Fp>"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 corrections applied as calibrated in the file); None when no profile is committed.  PMC
+    counters cannot be collected from inside this process, so the latest profiles/r*_pmc_traffic.json is used and named."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return float(d["kernels"][kernel]["hbm_bytes_per_launch"]), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def algorithmic_bytes_per_proof(log2, n_wires, n_commit):
     d = 1 << log2
     msm = 4 * 96 * n_wires + 160 * n_wires  # 3 witness G1 MSMs + Z (counted at n_wires ~ D) + G2
@@ -218,6 +233,8 @@ def main():
         avg_launch_s = (k1_ms / max(1, k1_calls)) * 1e-3
         achieved = units_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         bproof = algorithmic_bytes_per_proof(log2, n_wires, n_commit)
+        tb, tsrc = pmc_traffic_bytes_per_launch()
+        traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and log2 == 26 and args.scalars == "witness") else None
         out = {
             "metric": "Groth16 proofs/sec at 2^26 constraints (zkpor50_1380), 1/2/4/8 MI355X",
             "value": world * args.steps / dt,
@@ -234,7 +251,10 @@ def main():
             "config": {"workload": f"zkpor50_1380-shaped prove tail: D=2^{log2}, n_wires=2^{log2}, commit 2^{log2 - 2}, "
                                    f"scalars={args.scalars}, {len(workers)} proof(s) in flight per GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (f"profiles/{tsrc}: {tb / 1e9:.1f} GB HBM bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, "
+                                            "gfx950-calibrated) / live avg launch time; the bucket method re-reads each 64 B point once per "
+                                            "non-zero digit, hence traffic > algorithmic bytes") if traffic else None,
                          "kernel": "k_acc_level1<Fp> (G1 bucket accumulation)",
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "note": "path is VALU-integer bound (~1e3 int-ops/byte); whole-proof algorithmic bytes "
