@@ -43,12 +43,21 @@ static Jac<F> msm_pippenger(const Aff<F>* pts, const Fr* sc, size_t n, int c = 0
     std::vector<U256> canon(n);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) sc[i].to_canon(canon[i].v);
-    std::vector<Jac<F>> wsum(W);
+    // tasks = (window, chunk of points): every task owns a private bucket array, chunk results are added per window
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    int chunks = 1;
+    while (chunks * W < 2 * nthreads && (n / (size_t)(2 * chunks)) >= ((size_t)1 << c)) chunks *= 2;
+    std::vector<Jac<F>> part((size_t)W * chunks);
 #pragma omp parallel for schedule(dynamic, 1)
-    for (int w = 0; w < W; ++w) {
+    for (int task = 0; task < W * chunks; ++task) {
+        const int w = task / chunks, ch = task % chunks;
+        const size_t lo = n * (size_t)ch / chunks, hi = n * (size_t)(ch + 1) / chunks;
         std::vector<Jac<F>> bucket((size_t)1 << c, Jac<F>::inf());
         const int bit0 = w * c;
-        for (size_t i = 0; i < n; ++i) {
+        for (size_t i = lo; i < hi; ++i) {
             if (pts[i].is_inf()) continue;
             u64 d = canon[i].v[bit0 / 64] >> (bit0 % 64);
             if (bit0 % 64 + c > 64 && bit0 / 64 + 1 < 4) d |= canon[i].v[bit0 / 64 + 1] << (64 - bit0 % 64);
@@ -60,8 +69,11 @@ static Jac<F> msm_pippenger(const Aff<F>* pts, const Fr* sc, size_t n, int c = 0
             run = jadd(run, bucket[b]);
             tot = jadd(tot, run);
         }
-        wsum[w] = tot;
+        part[task] = tot;
     }
+    std::vector<Jac<F>> wsum(W, Jac<F>::inf());
+    for (int w = 0; w < W; ++w)
+        for (int ch = 0; ch < chunks; ++ch) wsum[w] = jadd(wsum[w], part[(size_t)w * chunks + ch]);
     Jac<F> acc = Jac<F>::inf();
     for (int w = W - 1; w >= 0; --w) {
         for (int k = 0; k < c; ++k) acc = jdbl(acc);
