@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--streams", type=int, default=2, help="proofs in flight per GPU (in-process dispatcher workers, one HIP stream + workspace each)")
+    ap.add_argument("--g1-variant", type=int, default=-1, help="level-1 G1 arithmetic: 0 = 8x32-bit limbs, 1 = 9x29-bit limbs (library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2", type=int, default=17)
     args = ap.parse_args()
@@ -139,6 +140,8 @@ def main():
         ctx.set_param("msm_window", args.window)
     if args.chunk:
         ctx.set_param("msm_chunk", args.chunk)
+    if args.g1_variant >= 0:
+        ctx.set_param("msm_g1_variant", args.g1_variant)
     lib = ctx.lib
 
     log2 = args.log2

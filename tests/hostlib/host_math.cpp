@@ -43,3 +43,50 @@ void hm_g1_mul(const G1Affine* p, const Fr* k_mont, G1Affine* out) {
     *out = xyzz_to_affine<Fp>(xyzz_mul_limbs<Fp>(xyzz_from_affine<Fp>(*p), c.v));
 }
 }
+
+// ---- 9 x 29-bit representation (csrc/fe29.cuh), portable path ----
+#include "fe29.cuh"
+extern "C" {
+// out = a*b (both gnark 8x32 Montgomery form) computed THROUGH the 29-bit path: (a*32)*(b*32)/2^261 -> /32 -> canonical
+void hm_fp29_mul(const Fp* a, const Fp* b, Fp* o, size_t n) {
+    for (size_t i = 0; i < n; ++i) o[i] = Fp29::to32_div32(Fp29::mul(Fp29::from32<5>(a[i]), Fp29::from32<5>(b[i])));
+}
+void hm_fp29_roundtrip(const Fp* a, Fp* o, size_t n) { for (size_t i = 0; i < n; ++i) o[i] = Fp29::to32_div32(Fp29::mul(Fp29::from32<5>(a[i]), Fp29::one())); }
+// (a - b) and (a + b) through the lazy forms (inputs reduced below 2p by a product with one)
+void hm_fp29_addsub(const Fp* a, const Fp* b, Fp* osum, Fp* odiff, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        Fp29 x = Fp29::mul(Fp29::from32<5>(a[i]), Fp29::one()), y = Fp29::mul(Fp29::from32<5>(b[i]), Fp29::one());
+        osum[i] = Fp29::to32_div32(Fp29::add(x, y));
+        odiff[i] = Fp29::to32_div32(Fp29::sub<4>(x, y));
+    }
+}
+// a*b + c*d fused
+void hm_fp29_mul2(const Fp* a, const Fp* b, const Fp* c, const Fp* d, Fp* o, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        Fp29 one = Fp29::one();
+        Fp29 A = Fp29::mul(Fp29::from32<5>(a[i]), one), B = Fp29::mul(Fp29::from32<5>(b[i]), one);
+        Fp29 C = Fp29::mul(Fp29::from32<5>(c[i]), one), D = Fp29::mul(Fp29::from32<5>(d[i]), one);
+        o[i] = Fp29::to32_div32(Fp29::mul2(A, B, C, D));
+    }
+}
+int hm_fp29_is_zero(const Fp* a, const Fp* b) {  // a - b == 0 mod p through sub<16> + filter
+    Fp29 x = Fp29::mul(Fp29::from32<5>(*a), Fp29::one()), y = Fp29::mul(Fp29::from32<5>(*b), Fp29::one());
+    return Fp29::sub<16>(x, y).is_zero_mod_p() ? 1 : 0;
+}
+// sum of affine points with the 29-bit mixed addition; out XYZZ converted back to 8x32
+void hm_g1_sum29(const G1Affine* p, size_t n, G1Affine* out, uint32_t* max_top_limb) {
+    XYZZ29 acc = XYZZ29::inf();
+    uint32_t mt = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (p[i].is_inf()) continue;
+        xyzz29_madd(acc, Fp29::from32<5>(p[i].x), Fp29::from32<5>(p[i].y));
+        const Fp29* c[4] = {&acc.x, &acc.y, &acc.zz, &acc.zzz};
+        for (auto* f : c) { if (f->l[8] > mt) mt = f->l[8]; for (int k = 0; k < 8; ++k) if (f->l[k] > (1u << 29) + 32) mt = 0xffffffffu; }
+    }
+    *max_top_limb = mt;
+    G1XYZZ o;
+    if (acc.is_inf()) o = G1XYZZ::inf();
+    else { o.x = Fp29::to32_div32(acc.x); o.y = Fp29::to32_div32(acc.y); o.zz = Fp29::to32_div32(acc.zz); o.zzz = Fp29::to32_div32(acc.zzz); }
+    *out = xyzz_to_affine<Fp>(o);
+}
+}

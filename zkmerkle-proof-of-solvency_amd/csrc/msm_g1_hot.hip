@@ -1,11 +1,80 @@
 // MSM step 3, G1, level 1 — the dominant kernel of the prover: field products fully inlined.
 #include "msm_kernels.cuh"
+#include "fe29.cuh"
 namespace zk {
+
+__device__ __forceinline__ void store29(XYZZ<Fp>* dst, const XYZZ29& a) {
+    XYZZ<Fp> o;
+    if (a.is_inf()) o = XYZZ<Fp>::inf();
+    else { o.x = Fp29::to32_div32(a.x); o.y = Fp29::to32_div32(a.y); o.zz = Fp29::to32_div32(a.zz); o.zzz = Fp29::to32_div32(a.zzz); }
+    *dst = o;
+}
+
+// k_acc_level1<Fp> with the accumulator and all arithmetic on 9 x 29-bit limbs (fe29.cuh); memory format unchanged
+__global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__ keys, const u32* __restrict__ vals,
+                                                         const Affine<Fp>* __restrict__ pts, u32 M, int L,
+                                                         XYZZ<Fp>* __restrict__ buckets, u32* __restrict__ out_keys,
+                                                         XYZZ<Fp>* __restrict__ out_part) {
+    __shared__ u32 sk[256 * ACC_PITCH];
+    __shared__ u32 sv[256 * ACC_PITCH];
+    const u32 row0 = blockIdx.x * 256u;
+    const u32 t = row0 + threadIdx.x;
+    const u32 T = (M + (u32)L - 1u) / (u32)L;
+    const bool live = t < T;
+    const u32 start = live ? t * (u32)L : 0u;
+    const u32 end = live ? ((start + (u32)L < M) ? start + (u32)L : M) : 0u;
+    const u32 prev = (live && start > 0) ? keys[start - 1] : NOKEY;
+    const u32 next = (live && end < M) ? keys[end] : NOKEY;
+    XYZZ29 acc = XYZZ29::inf();
+    u32 cur = live ? keys[start] : NOKEY;
+    const u32 first_key = cur;
+    u32 last_key = cur;
+    bool first = true, head_written = false, tail_written = false;
+    const int nphase = (L + ACC_SUB - 1) / ACC_SUB;
+    const u32 rows = (T - row0 < 256u) ? T - row0 : 256u;
+    for (int ph = 0; ph < nphase; ++ph) {
+        if (ph) __syncthreads();
+        acc_stage(keys, vals, M, L, row0, rows, ph, sk, sv);
+        __syncthreads();
+        if (!live) continue;
+        const u32 j0 = start + (u32)ph * ACC_SUB;
+        const u32 j1 = (j0 + ACC_SUB < end) ? j0 + ACC_SUB : end;
+        for (u32 j = j0; j < j1; ++j) {
+            const u32 k = sk[threadIdx.x * ACC_PITCH + (j - j0)];
+            const u32 v = sv[threadIdx.x * ACC_PITCH + (j - j0)];
+            if (k != cur) {
+                if (first && cur == prev) { store29(out_part + 2 * t, acc); head_written = true; }
+                else store29(buckets + cur, acc);
+                first = false;
+                cur = k;
+                acc = XYZZ29::inf();
+            }
+            last_key = k;
+            Affine<Fp> p = pts[v >> 1];
+            if (!p.is_inf()) {
+                if (v & 1u) p.y = Fp::neg(p.y);
+                xyzz29_madd(acc, Fp29::from32<5>(p.x), Fp29::from32<5>(p.y));
+            }
+        }
+    }
+    if (!live) return;
+    if (first && cur == prev) { store29(out_part + 2 * t, acc); head_written = true; }
+    else if (cur == next) { store29(out_part + 2 * t + 1, acc); tail_written = true; }
+    else store29(buckets + cur, acc);
+    if (T > 1) {
+        if (!head_written) out_part[2 * t] = XYZZ<Fp>::inf();
+        if (!tail_written) out_part[2 * t + 1] = XYZZ<Fp>::inf();
+        out_keys[2 * t] = first_key;
+        out_keys[2 * t + 1] = last_key;
+    }
+}
+
 int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L,
                       XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part) {
     u32 T = (M + (u32)L - 1u) / (u32)L;
     PhaseScope ps(ctx, "k_acc_level1_g1");
-    hipLaunchKernelGGL(k_acc_level1<Fp>, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
+    if (ctx->g1_variant == 0) hipLaunchKernelGGL(k_acc_level1<Fp>, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
+    else hipLaunchKernelGGL(k_acc_level1_fp29, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
