@@ -43,6 +43,10 @@ struct Fp29Params {
         constexpr u32 m[9] = {0x47cfd470u, 0x50460b6au, 0x472a34eeu, 0x4d522d0cu, 0x585d977fu, 0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u};
         return m[i];
     }
+    ZK_HD static constexpr u32 subc64(int i) {
+        constexpr u32 m[9] = {0x5f3f51c0u, 0x41182daeu, 0x5ca8d3c0u, 0x5548b436u, 0x41765e03u, 0x56d03029u, 0x49b85043u, 0x57098cffu, 0x0c19139au};
+        return m[i];
+    }
     static constexpr u32 INV29 = 0x04866389u;   // -p^-1 mod 2^29
     static constexpr u32 PINV29 = 0x1b799c77u;  //  p^-1 mod 2^29
 };
@@ -111,8 +115,8 @@ struct Fp29 {
     }
     ZK_HD static Fp29 mul(const Fp29& a, const Fp29& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        Fp29 r = a;
-        mont_mul29_asm<P>(r.l, b.l);
+        Fp29 r;
+        mont_mul29_asm<P>(r.l, a.l, b.l);
         return r;
 #else
         return mul_portable(a, b);
@@ -121,8 +125,8 @@ struct Fp29 {
     ZK_HD static Fp29 sqr(const Fp29& a) { return mul(a, a); }
     ZK_HD static Fp29 mul2(const Fp29& a, const Fp29& b, const Fp29& c, const Fp29& d) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        Fp29 r = a;
-        mont_mul2_29_asm<P>(r.l, b.l, c.l, d.l);
+        Fp29 r;
+        mont_mul2_29_asm<P>(r.l, a.l, b.l, c.l, d.l);
         return r;
 #else
         return mul2_portable(a, b, c, d);
@@ -145,6 +149,17 @@ struct Fp29 {
             r.l[i] = a.l[i] + c - b.l[i];
         }
         norm(r.l);
+        return r;
+    }
+    // neg ? 64p - a : a, limbwise and WITHOUT a carry sweep: limbs stay < 2^31, which a product tolerates in ONE operand
+    // when the other is tight (9 * 2^31 * 2^29.x + 9 * 2^58 < 2^64).  a must be tight and < 64p.
+    ZK_HD static Fp29 cneg_loose(const Fp29& a, bool neg) {
+        Fp29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            u32 t = P::subc64(i) - a.l[i];
+            r.l[i] = neg ? t : a.l[i];
+        }
         return r;
     }
     // x == 0 (mod p) for a tight x < 2^259.  Fast filter on the exact low limb: x = k*p implies k = x0 * p^-1 mod 2^29
