@@ -3,11 +3,13 @@
 namespace zk {
 
 // ------------------------------------------------------------------------------------------------ decompose
-ZK_D u32 digit_at(const Fr& s, int bit, int c) {
-    int limb = bit >> 5, sh = bit & 31;
-    u64 two = s.v[limb];
-    if (limb + 1 < 8) two |= (u64)s.v[limb + 1] << 32;
-    return (u32)((two >> sh) & ((1u << c) - 1u));
+// low c bits of s, then s >>= c (static register indexing only: no scratch)
+ZK_D u32 take_digit(Fr& s, int c) {
+    u32 d = s.v[0] & ((1u << c) - 1u);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s.v[i] = (s.v[i] >> c) | (s.v[i + 1] << (32 - c));
+    s.v[7] >>= c;
+    return d;
 }
 
 // One thread per scalar.  Two passes over the digits (count, then write) so nothing spills; entries of one
@@ -24,9 +26,10 @@ __global__ __launch_bounds__(256) void k_decompose(const Fr* __restrict__ scalar
     const u32 half = 1u << (c - 1);
     if (i < n) {
         s = Fr::from_mont(scalars[i]);
+        Fr t = s;
         u32 carry = 0;
         for (int w = 0; w < W; ++w) {
-            u32 d = digit_at(s, w * c, c) + carry;
+            u32 d = take_digit(t, c) + carry;
             carry = d > half ? 1u : 0u;
             d = carry ? (1u << c) - d : d;
             cnt += d != 0;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void k_decompose(const Fr* __restrict__ scalar
     if (i < n && cnt) {
         u32 carry = 0;
         for (int w = 0; w < W; ++w) {
-            u32 d = digit_at(s, w * c, c) + carry;
+            u32 d = take_digit(s, c) + carry;
             carry = d > half ? 1u : 0u;
             d = carry ? (1u << c) - d : d;
             if (d) {

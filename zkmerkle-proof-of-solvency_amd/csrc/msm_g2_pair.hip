@@ -73,6 +73,99 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair(const u32* __restrict
     }
 }
 
+__device__ __forceinline__ XYZZ<Fp2L> lp_load(const XYZZ<Fp2>* src, u32 par) {
+    const Fp* d = (const Fp*)src;
+    XYZZ<Fp2L> a;
+    a.x.c = d[par]; a.y.c = d[2 + par]; a.zz.c = d[4 + par]; a.zzz.c = d[6 + par];
+    return a;
+}
+
+// k_acc_levelN on lane pairs (see msm_kernels.cuh for the algorithm)
+__global__ __launch_bounds__(256) void k_acc_levelN_g2pair(const u32* __restrict__ keys, const XYZZ<Fp2>* __restrict__ src,
+                                                           u32 M, int L, XYZZ<Fp2>* __restrict__ buckets,
+                                                           u32* __restrict__ out_keys, XYZZ<Fp2>* __restrict__ out_part) {
+    const u32 gt = blockIdx.x * 256u + threadIdx.x;
+    const u32 t = gt >> 1, par = gt & 1u;
+    const u32 T = (M + (u32)L - 1u) / (u32)L;
+    if (t >= T) return;
+    const u32 start = t * (u32)L;
+    const u32 end = (start + (u32)L < M) ? start + (u32)L : M;
+    const u32 prev = start > 0 ? keys[start - 1] : NOKEY;
+    const u32 next = end < M ? keys[end] : NOKEY;
+    XYZZ<Fp2L> acc = XYZZ<Fp2L>::inf();
+    u32 cur = keys[start];
+    bool first = true, head_written = false, tail_written = false;
+    for (u32 j = start; j < end; ++j) {
+        const u32 k = keys[j];
+        if (k != cur) {
+            if (first && cur == prev) { lp_store(out_part + 2 * t, acc, par); head_written = true; }
+            else if (!acc.is_inf()) lp_store(buckets + cur, acc, par);
+            first = false;
+            cur = k;
+            acc = XYZZ<Fp2L>::inf();
+        }
+        XYZZ<Fp2L> p = lp_load(src + j, par);
+        xyzz_add<Fp2L>(acc, p);
+    }
+    if (first && cur == prev) { lp_store(out_part + 2 * t, acc, par); head_written = true; }
+    else if (cur == next) { lp_store(out_part + 2 * t + 1, acc, par); tail_written = true; }
+    else if (!acc.is_inf()) lp_store(buckets + cur, acc, par);
+    if (T > 1) {
+        XYZZ<Fp2L> z = XYZZ<Fp2L>::inf();
+        if (!head_written) lp_store(out_part + 2 * t, z, par);
+        if (!tail_written) lp_store(out_part + 2 * t + 1, z, par);
+        if (par == 0) {
+            out_keys[2 * t] = keys[start];
+            out_keys[2 * t + 1] = keys[end - 1];
+        }
+    }
+}
+
+// k_reduce_level on lane pairs
+template <bool HAS_Y>
+__global__ __launch_bounds__(128) void k_reduce_level_g2pair(const XYZZ<Fp2>* __restrict__ Sin, const XYZZ<Fp2>* __restrict__ Yin,
+                                                             u32 n_groups, u32 g, int dbl, XYZZ<Fp2>* __restrict__ Sout,
+                                                             XYZZ<Fp2>* __restrict__ Yout) {
+    const u32 gt = blockIdx.x * 128u + threadIdx.x;
+    const u32 j = gt >> 1, par = gt & 1u;
+    if (j >= n_groups) return;
+    XYZZ<Fp2L> run = XYZZ<Fp2L>::inf(), wacc = XYZZ<Fp2L>::inf(), ysum = XYZZ<Fp2L>::inf();
+    const size_t base = (size_t)j * g;
+    for (u32 k = g; k-- > 0;) {
+        XYZZ<Fp2L> x = lp_load(Sin + base + k, par);
+        xyzz_add<Fp2L>(run, x);
+        xyzz_add<Fp2L>(wacc, run);
+        if (HAS_Y) {
+            XYZZ<Fp2L> y = lp_load(Yin + base + k, par);
+            xyzz_add<Fp2L>(ysum, y);
+        }
+    }
+    lp_store(Sout + j, run, par);
+    if (HAS_Y) {
+        for (int d = 0; d < dbl; ++d) wacc = xyzz_dbl<Fp2L>(wacc);
+        xyzz_add<Fp2L>(ysum, wacc);
+        lp_store(Yout + j, ysum, par);
+    } else {
+        lp_store(Yout + j, wacc, par);
+    }
+}
+
+int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp2>* src, u32 M, int L, XYZZ<Fp2>* buckets,
+                      u32* out_keys, XYZZ<Fp2>* out_part) {
+    u32 T = (M + (u32)L - 1u) / (u32)L;
+    hipLaunchKernelGGL(k_acc_levelN_g2pair, dim3((2u * T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, src, M, L, buckets, out_keys, out_part);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp2>* Sin, const XYZZ<Fp2>* Yin, u32 n_groups, u32 g, int dbl,
+                      XYZZ<Fp2>* Sout, XYZZ<Fp2>* Yout) {
+    dim3 grid((2u * n_groups + 127u) / 128u);
+    if (Yin) hipLaunchKernelGGL(k_reduce_level_g2pair<true>, grid, dim3(128), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
+    else hipLaunchKernelGGL(k_reduce_level_g2pair<false>, grid, dim3(128), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+
 int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L,
                       XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part) {
     u32 T = (M + (u32)L - 1u) / (u32)L;
