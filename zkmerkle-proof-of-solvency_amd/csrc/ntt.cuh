@@ -10,6 +10,8 @@ struct NttDomain {
     Fr *g_hi_ninv, *gi_hi_ninv;                 // high tables with 1/N folded in
     Fr *small_fwd, *small_inv;                  // w_512^j, w_512^-j
     Fr n_inv, den;                              // 1/N, 1/(g^N - 1)
+    Fr* full_fwd[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // per field: tabulated
+    Fr* full_inv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // inter-pass twiddles
 };
 int32_t ntt_domain_get(zkpor_ctx* ctx, int n, NttDomain** out);
 void ntt_domains_free(zkpor_ctx* ctx);

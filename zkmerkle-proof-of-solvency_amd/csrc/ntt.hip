@@ -38,6 +38,15 @@ __global__ void k_pow_table(Fr base, Fr mult, int shift, u32 count, Fr* out) {
     out[e] = Fr::mul(r, mult);
 }
 
+// full inter-pass twiddle table of one field: out[k << lo | l] = w^((l*k) << s0)
+__global__ void k_twiddle_full(const Fr* lo_t, const Fr* hi_t, int tb, int lo, int kb, int s0, Fr* out) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ((size_t)1 << (lo + kb))) return;
+    u32 l = (u32)(idx & (((size_t)1 << lo) - 1)), k = (u32)(idx >> lo);
+    u32 e = (l * k) << s0;
+    out[idx] = Fr::mul(lo_t[e & ((1u << tb) - 1u)], hi_t[e >> tb]);
+}
+
 ZK_D u32 brev(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
 struct PassArgs {
@@ -45,6 +54,7 @@ struct PassArgs {
     int n, lo, kb, clog;
     const Fr* small;             // w_512^j (forward or inverse), 256 entries
     const Fr* tw_lo; const Fr* tw_hi; int tb;  // w_N^e = tw_lo[e & mask] * tw_hi[e >> tb]
+    const Fr* tw_full;           // optional: the field's inter-pass twiddles tabulated, [k_m << lo | l] (HBM is plentiful)
     int scale_load, scale_store;  // 0 none, 1 constant, 2 g^p, 3 g^rev(p)   (g tables may carry a folded constant)
     const Fr* g_lo; const Fr* g_hi;
     Fr konst;
@@ -85,8 +95,9 @@ __global__ __launch_bounds__(256) void k_ntt_pass(PassArgs A) {
         Fr v = A.x[p];
         if (A.scale_load) v = apply_scale(A, A.scale_load, v, p);
         if (!DIF && lo > 0) {
-            u32 e = ((l0 + c) * brev(m, kb)) << s0;
-            v = Fr::mul(v, table_pow(A.tw_lo, A.tw_hi, A.tb, e));
+            const u32 km = brev(m, kb);
+            if (A.tw_full) v = Fr::mul(v, A.tw_full[((size_t)km << lo) | (l0 + c)]);
+            else v = Fr::mul(v, table_pow(A.tw_lo, A.tw_hi, A.tb, ((l0 + c) * km) << s0));
         }
         tile[li] = v;
     }
@@ -126,8 +137,9 @@ __global__ __launch_bounds__(256) void k_ntt_pass(PassArgs A) {
         else { m = idx & (F - 1u); c = idx >> kb; p = ((hi + c) << kb) + m; li = c * F + m; }
         Fr v = tile[li];
         if (DIF && lo > 0) {
-            u32 e = ((l0 + c) * brev(m, kb)) << s0;
-            v = Fr::mul(v, table_pow(A.tw_lo, A.tw_hi, A.tb, e));
+            const u32 km = brev(m, kb);
+            if (A.tw_full) v = Fr::mul(v, A.tw_full[((size_t)km << lo) | (l0 + c)]);
+            else v = Fr::mul(v, table_pow(A.tw_lo, A.tw_hi, A.tb, ((l0 + c) * km) << s0));
         }
         if (A.scale_store) v = apply_scale(A, A.scale_store, v, p);
         A.x[p] = v;
@@ -207,6 +219,26 @@ int32_t ntt_domain_get(zkpor_ctx* ctx, int n, NttDomain** out) {
     ZK_TRY(make_table(ctx, gi, d->n_inv, d->tb, nhi, d->gi_hi_ninv));
     ZK_TRY(make_table(ctx, w512, one, 0, 256, d->small_fwd));
     ZK_TRY(make_table(ctx, w512i, one, 0, 256, d->small_inv));
+    // tabulated inter-pass twiddles per field (forward and inverse): 2 x 32 B x 2^(lo+kb) bytes each; skipped when the
+    // device is short of memory (the kernels then fall back to the two-table product)
+    {
+        Field f[8];
+        int nf = plan_fields(n, f);
+        for (int i = 0; i < nf && i < 8; ++i) {
+            d->full_fwd[i] = d->full_inv[i] = nullptr;
+            if (f[i].lo == 0) continue;
+            size_t cnt = (size_t)1 << (f[i].lo + f[i].kb);
+            int s0 = n - f[i].lo - f[i].kb;
+            Fr *a = nullptr, *b = nullptr;
+            if (hipMalloc((void**)&a, cnt * sizeof(Fr)) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (hipMalloc((void**)&b, cnt * sizeof(Fr)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(a); continue; }
+            unsigned blocks = (unsigned)((cnt + 255) / 256);
+            hipLaunchKernelGGL(k_twiddle_full, dim3(blocks), dim3(256), 0, ctx->stream, d->tw_lo, d->tw_hi, d->tb, f[i].lo, f[i].kb, s0, a);
+            hipLaunchKernelGGL(k_twiddle_full, dim3(blocks), dim3(256), 0, ctx->stream, d->twi_lo, d->twi_hi, d->tb, f[i].lo, f[i].kb, s0, b);
+            ZK_KERNEL_CHECK(ctx);
+            d->full_fwd[i] = a; d->full_inv[i] = b;
+        }
+    }
     ctx->ntt_domains[n] = d;
     *out = d;
     return ZKPOR_OK;
@@ -216,6 +248,7 @@ void ntt_domains_free(zkpor_ctx* ctx) {
     for (auto& kv : ctx->ntt_domains) {
         NttDomain* d = (NttDomain*)kv.second;
         if (d->mem) (void)hipFree(d->mem);
+        for (int i = 0; i < 8; ++i) { if (d->full_fwd[i]) (void)hipFree(d->full_fwd[i]); if (d->full_inv[i]) (void)hipFree(d->full_inv[i]); }
         delete d;
     }
     ctx->ntt_domains.clear();
@@ -238,6 +271,10 @@ static int32_t run_passes(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, boo
         A.small = inverse ? d->small_inv : d->small_fwd;
         A.tw_lo = inverse ? d->twi_lo : d->tw_lo;
         A.tw_hi = inverse ? d->twi_hi : d->tw_hi;
+        {
+            int fi = dif ? nf - 1 - step : step;
+            A.tw_full = inverse ? d->full_inv[fi] : d->full_fwd[fi];
+        }
         A.tb = d->tb;
         A.scale_load = 0; A.scale_store = 0; A.g_lo = nullptr; A.g_hi = nullptr; A.konst = Fr::one();
         if (step == 0 && first_load.mode) { A.scale_load = first_load.mode; A.g_lo = first_load.g_lo; A.g_hi = first_load.g_hi; A.konst = first_load.konst; }
