@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="proofs in flight per GPU (in-process dispatcher workers, one HIP stream + workspace each)")
     ap.add_argument("--g1-variant", type=int, default=-1, help="level-1 G1 arithmetic: 0 = 8x32-bit limbs, 1 = 9x29-bit limbs (library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2", type=int, default=17)
+    ap.add_argument("--cpu-log2", type=int, default=20)
     args = ap.parse_args()
 
     import torch
