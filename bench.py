@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--scalars", choices=["witness", "uniform"], default="witness")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=2, help="proofs in flight per GPU (in-process dispatcher workers, one HIP stream + workspace each)")
+    ap.add_argument("--streams", type=int, default=1, help="proofs in flight per GPU (in-process dispatcher workers, one HIP stream + workspace each)")
     ap.add_argument("--g1-variant", type=int, default=-1, help="level-1 G1 arithmetic: 0 = 8x32-bit limbs, 1 = 9x29-bit limbs (library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2", type=int, default=20)
