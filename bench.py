@@ -264,7 +264,7 @@ def main():
                                  f"{bproof / 1e9:.1f} GB -> {bproof * (args.steps / dt) / 1e9:.1f} GB/s per GPU"},
             "phases_ms_per_proof": {k: round(v["ms_per_proof"], 3) for k, v in phases.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_log2, log2, 0.25)
             except Exception as e:  # the baseline is informational; never lose the GPU line over it

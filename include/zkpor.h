@@ -96,6 +96,11 @@ int32_t zkpor_msm_g2(zkpor_ctx* ctx, const void* points_affine, const uint64_t* 
 int32_t zkpor_msm_g1_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[96]);
 int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[192]);
 
+/* sum of `count` Jacobian points on the HOST (no device needed): combines the partial results of a multi-GPU split of one
+ * multi-exponentiation after an all-gather (RCCL has no user-defined reduction over curve points) */
+int32_t zkpor_g1_jac_sum(const uint8_t* parts96, size_t count, uint8_t out_jac[96]);
+int32_t zkpor_g2_jac_sum(const uint8_t* parts192, size_t count, uint8_t out_jac[192]);
+
 /* ---- H polynomial (gnark computeH) ---------------------------------------------------------------------- */
 /* a,b,c: n_constraints evaluations each (zero-padded to the domain internally); h_out: 2^log2_domain elements
  * in the order the key's Z expects (bit-reversed for ZKPOR_Z_ORDER_BITREV). */

@@ -118,3 +118,18 @@ def test_g2_msm_edge(zk):
     w = O.fr_random(16, n)
     expect = O.g2_from_scalars(O.fr_dot(s, w).reshape(1, 4))[0]
     assert _g2_eq(zk.msm_g2(pts, w), expect)
+
+
+def test_g1_msm_split_matches_unsplit(zk):
+    """config 5: the MSM sharded by contiguous index ranges over 8 'ranks' (emulated on one device) and combined
+    with the host-side Jacobian sum equals the unsplit result"""
+    import zkpor
+    n = 20000
+    sc = O.fr_random(31, n)
+    pts = O.g1_from_scalars(O.fr_random(32, n))
+    dp = zk.alloc(64 * n).upload(pts); ds = zk.alloc(32 * n).upload(sc)
+    try:
+        parts = np.stack([zkpor.msm_split_g1(zk, dp.ptr, ds.ptr, n, r, 8) for r in range(8)])
+        assert _g1_eq(zkpor.g1_jac_sum(parts), O.g1_msm(pts, sc))
+    finally:
+        dp.free(); ds.free()

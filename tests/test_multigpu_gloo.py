@@ -47,3 +47,38 @@ def test_two_ranks_gloo(tmp_path):
     slow = max(o["own"] for o in outs)
     for o in outs:                                                         # both ranks report the MAX elapsed time
         assert o["dt"] >= slow * 0.95 and abs(o["dt"] - outs[0]["dt"]) < 1e-9
+
+
+SPLIT_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle")); sys.path.insert(0, os.path.join(%(root)r, "zkmerkle-proof-of-solvency_amd"))
+import numpy as np, torch, torch.distributed as dist
+import oracle as O, zkpor
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = 600
+sc = O.fr_random(41, n); pts = O.g1_from_scalars(O.fr_random(42, n))
+lo, hi = n * rank // world, n * (rank + 1) // world
+# the partial sum of this rank's slice: computed by the ORACLE here (no GPU in this test) and handed over as a Jacobian point
+aff = O.g1_msm(pts[lo:hi], sc[lo:hi])
+part = np.concatenate([aff, O.fp_from_ints([1])[0]]) if aff.any() else np.zeros(12, np.uint64)
+mine = torch.from_numpy(part.view(np.int64).copy())
+allp = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(allp, mine)                       # the one collective of the single-proof split (96 B per rank)
+total = zkpor.g1_jac_sum(np.stack([t.numpy().view(np.uint64) for t in allp]))   # product host code, no device
+ok = bool(np.array_equal(O.g1_jac_to_affine(total)[0], O.g1_msm(pts, sc)))
+print(json.dumps({"rank": rank, "ok": ok}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_msm_split_allgather_two_ranks_gloo(tmp_path):
+    script = tmp_path / "split_worker.py"
+    script.write_text(SPLIT_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29614", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        o, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err
+        assert json.loads(o.strip().splitlines()[-1])["ok"]

@@ -45,6 +45,21 @@ __global__ void k_fill_fr(Fr* out, size_t n, u64 seed, int kind) {
     out[i] = Fr::to_mont(x);
 }
 
+// host-side group additions for combining partial results (the single-proof MSM split: every rank sums its slice
+// of the key, the 8 partial Jacobian points are all-gathered and added here — RCCL has no reduction over a curve)
+template <class F>
+static void jac_sum(const Jacobian<F>* parts, size_t count, Jacobian<F>* out) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (size_t i = 0; i < count; ++i) {
+        const Jacobian<F>& j = parts[i];
+        if (j.z.is_zero()) continue;
+        // Jacobian (X,Y,Z) -> XYZZ (X, Y, Z^2, Z^3)
+        XYZZ<F> p = {j.x, j.y, F::sqr(j.z), F::mul(F::sqr(j.z), j.z)};
+        xyzz_add<F>(acc, p);
+    }
+    *out = xyzz_to_jacobian<F>(acc);
+}
+
 template <class F>
 static int32_t msm_host(zkpor_ctx* ctx, const void* pts, const uint64_t* scalars, size_t n, XYZZ<F>* r) {
     if (n == 0) { *r = XYZZ<F>::inf(); return ZKPOR_OK; }
@@ -194,6 +209,21 @@ static void store_jac_g1(const G1XYZZ& r, uint8_t* out) {
 static void store_jac_g2(const G2XYZZ& r, uint8_t* out) {
     G2Jac j = xyzz_to_jacobian<Fp2>(r);
     memcpy(out, &j, 192);
+}
+
+int32_t zkpor_g1_jac_sum(const uint8_t* parts96, size_t count, uint8_t out_jac[96]) {
+    if ((!parts96 && count) || !out_jac) return ZKPOR_E_ARG;
+    G1Jac o;
+    jac_sum<Fp>((const G1Jac*)parts96, count, &o);
+    memcpy(out_jac, &o, 96);
+    return ZKPOR_OK;
+}
+int32_t zkpor_g2_jac_sum(const uint8_t* parts192, size_t count, uint8_t out_jac[192]) {
+    if ((!parts192 && count) || !out_jac) return ZKPOR_E_ARG;
+    G2Jac o;
+    jac_sum<Fp2>((const G2Jac*)parts192, count, &o);
+    memcpy(out_jac, &o, 192);
+    return ZKPOR_OK;
 }
 
 int32_t zkpor_msm_g1_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[96]) {

@@ -213,6 +213,19 @@ inline int32_t msm_accumulate(zkpor_ctx* ctx, const DigitStream& ds, const Affin
 template <class F>
 inline int32_t msm_dev(zkpor_ctx* ctx, const Affine<F>* d_pts, const Fr* d_scalars, size_t n, XYZZ<F>* result) {
     if (n == 0) { *result = XYZZ<F>::inf(); return ZKPOR_OK; }
+    // the digit stream is indexed with 32 bits: above 2^27 points (2^28-constraint keys) run slices and add the results
+    const size_t SLICE = (size_t)1 << 27;
+    if (n > SLICE) {
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (size_t off = 0; off < n; off += SLICE) {
+            XYZZ<F> part;
+            size_t m = n - off < SLICE ? n - off : SLICE;
+            ZK_TRY(msm_dev<F>(ctx, d_pts + off, d_scalars + off, m, &part));
+            xyzz_add<F>(acc, part);
+        }
+        *result = acc;
+        return ZKPOR_OK;
+    }
     MsmCfg cfg = msm_cfg(ctx, n);
     size_t sort_temp = 0;
     size_t need = digits_ws_bytes(ctx, n, cfg, &sort_temp) + accumulate_ws_bytes<F>(cfg, n * (size_t)cfg.W);

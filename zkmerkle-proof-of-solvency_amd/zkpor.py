@@ -184,6 +184,46 @@ def proof_write_raw(proof256, commitments=None, pok=None):
     return out[: n.value]
 
 
+def g1_jac_sum(parts):
+    """host-side sum of Jacobian G1 points (n,12) uint64 -> (12,) — combines partial MSM results, needs no GPU"""
+    lib = load_library()
+    parts = _u64(parts).reshape(-1, 12)
+    out = np.empty(12, dtype=np.uint64)
+    rc = lib.zkpor_g1_jac_sum(_p(parts), ctypes.c_size_t(parts.shape[0]), _p(out))
+    if rc != 0:
+        raise ZkporError(f"zkpor_g1_jac_sum failed: {rc}")
+    return out
+
+
+def g2_jac_sum(parts):
+    lib = load_library()
+    parts = _u64(parts).reshape(-1, 24)
+    out = np.empty(24, dtype=np.uint64)
+    rc = lib.zkpor_g2_jac_sum(_p(parts), ctypes.c_size_t(parts.shape[0]), _p(out))
+    if rc != 0:
+        raise ZkporError(f"zkpor_g2_jac_sum failed: {rc}")
+    return out
+
+
+def msm_split_g1(ctx, d_points, d_scalars, n, rank, world, dist=None):
+    """config 5 of BASELINE.json: one multi-exponentiation sharded by contiguous index range over `world` GPUs.
+    Every rank sums its slice on its own device; the `world` partial Jacobian points (96 B each) are all-gathered
+    (the only collective on the path, latency-bound) and added on the host.  With dist=None the ranks are emulated
+    sequentially on one device (parity test)."""
+    lo = n * rank // world
+    hi = n * (rank + 1) // world
+    part = ctx.msm_g1_dev(d_points + 64 * lo, d_scalars + 32 * lo, hi - lo)
+    if dist is None:
+        return part
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.from_numpy(part.view(np.int64).copy()).to(dev)
+    allp = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allp, mine)
+    parts = np.stack([t.cpu().numpy().view(np.uint64) for t in allp])
+    return g1_jac_sum(parts)
+
+
 class ProvingKey:
     """HBM-resident proving key (the device half of gnark's groth16.ProvingKey)"""
 
