@@ -116,3 +116,73 @@ if __name__ == "__main__":
     print(hex(params(3)[0][0]))
     print(hex(params(3)[1][0][0]))
     print(hex(poseidon([1, 2])))
+
+
+# ---- optimised partial rounds (sparse matrices), the schedule csrc/poseidon.hip uses ------------------------------------
+def _mat_inv(a):
+    n = len(a)
+    m = [row[:] + [1 if i == j else 0 for j in range(n)] for i, row in enumerate(a)]
+    for c in range(n):
+        piv = next(r for r in range(c, n) if m[r][c] % R)
+        m[c], m[piv] = m[piv], m[c]
+        inv = pow(m[c][c], R - 2, R)
+        m[c] = [x * inv % R for x in m[c]]
+        for r in range(n):
+            if r != c and m[r][c]:
+                f = m[r][c]
+                m[r] = [(x - f * y) % R for x, y in zip(m[r], m[c])]
+    return [row[n:] for row in m]
+
+
+def optimise(t):
+    """factor every partial-round matrix N_i = diag(1, Mhat_i) * [[m00, v],[Mhat_i^-1 w, I]] and push the block-diagonal
+    factor through the next round's (element-0-only) S-box: N_(i+1) = M * diag(1, Mhat_i).  Returns per-round
+    (constants k_i, m00, v, what) and the trailing block Mhat_last."""
+    rc, mds = params(t)
+    rp = r_p(t)
+    N = [row[:] for row in mds]
+    rounds = []
+    prev_inv = None
+    for i in range(rp):
+        mhat = [row[1:] for row in N[1:]]
+        w = [N[r][0] for r in range(1, t)]
+        v = N[0][1:]
+        inv = _mat_inv(mhat)
+        what = [sum(inv[r][c] * w[c] for c in range(t - 1)) % R for r in range(t - 1)]
+        c = rc[(R_F // 2 + i) * t:(R_F // 2 + i + 1) * t]
+        if prev_inv is None:
+            k = c[:]
+        else:
+            k = [c[0]] + [sum(prev_inv[r][cc] * c[1 + cc] for cc in range(t - 1)) % R for r in range(t - 1)]
+        rounds.append((k, N[0][0], v, what))
+        prev_inv = inv
+        last = mhat
+        d = [[1 if (r == 0 and cc == 0) else 0 for cc in range(t)] for r in range(t)]
+        for r in range(1, t):
+            for cc in range(1, t):
+                d[r][cc] = mhat[r - 1][cc - 1]
+        N = [[sum(mds[r][x] * d[x][cc] for x in range(t)) % R for cc in range(t)] for r in range(t)]
+    return rounds, last
+
+
+def permute_optimised(state):
+    t = len(state)
+    rc, mds = params(t)
+    rp = r_p(t)
+    rounds, post = optimise(t)
+    s = list(state)
+    def full(s, r):
+        s = [(s[i] + rc[r * t + i]) % R for i in range(t)]
+        s = [pow(x, 5, R) for x in s]
+        return [sum(mds[i][j] * s[j] for j in range(t)) % R for i in range(t)]
+    for r in range(R_F // 2):
+        s = full(s, r)
+    for (k, m00, v, what) in rounds:
+        s = [(s[i] + k[i]) % R for i in range(t)]
+        x0 = pow(s[0], 5, R)
+        new0 = (m00 * x0 + sum(v[j] * s[1 + j] for j in range(t - 1))) % R
+        s = [new0] + [(s[1 + j] + what[j] * x0) % R for j in range(t - 1)]
+    s = [s[0]] + [sum(post[r][c] * s[1 + c] for c in range(t - 1)) % R for r in range(t - 1)]
+    for r in range(R_F // 2 + rp, R_F + rp):
+        s = full(s, r)
+    return s

@@ -20,10 +20,15 @@ static inline int pos_rp(int t) {
     return tab[t - 2];
 }
 
-struct PosTables {       // device blob: for every width t in [2,13]: rc[(8+rp)*t] then mds[t*t]
+// device blob, per width t in [2,13]: rc[(8+rp)*t] | mds[t*t] | prc[rp*t] | sparse[rp*(2t-1)] | post[(t-1)*(t-1)]
+// prc/sparse/post are the optimised partial rounds (see optimise_partial_rounds)
+struct PosTables {
     Fr* dev = nullptr;
     u32 rc_off[POS_MAX_T + 1];
     u32 mds_off[POS_MAX_T + 1];
+    u32 prc_off[POS_MAX_T + 1];
+    u32 sp_off[POS_MAX_T + 1];
+    u32 post_off[POS_MAX_T + 1];
     std::vector<Fr> host;
 };
 
@@ -98,6 +103,83 @@ static void poseidon_params(int t, std::vector<Fr>& rc, std::vector<Fr>& mds) {
         for (int j = 0; j < t; ++j) mds[(size_t)i * t + j] = Fr::inv(Fr::add(xy[i], xy[t + j]));
 }
 
+// Gauss-Jordan inverse of an n x n matrix over Fr (n <= 12); host, start-up only
+static bool fr_mat_inv(std::vector<Fr>& a, int n, std::vector<Fr>& inv) {
+    inv.assign((size_t)n * n, Fr::zero());
+    for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = Fr::one();
+    for (int c = 0; c < n; ++c) {
+        int piv = -1;
+        for (int r = c; r < n; ++r) if (!a[(size_t)r * n + c].is_zero()) { piv = r; break; }
+        if (piv < 0) return false;
+        if (piv != c) for (int k = 0; k < n; ++k) { std::swap(a[(size_t)c * n + k], a[(size_t)piv * n + k]); std::swap(inv[(size_t)c * n + k], inv[(size_t)piv * n + k]); }
+        Fr d = Fr::inv(a[(size_t)c * n + c]);
+        for (int k = 0; k < n; ++k) { a[(size_t)c * n + k] = Fr::mul(a[(size_t)c * n + k], d); inv[(size_t)c * n + k] = Fr::mul(inv[(size_t)c * n + k], d); }
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            Fr f = a[(size_t)r * n + c];
+            if (f.is_zero()) continue;
+            for (int k = 0; k < n; ++k) {
+                a[(size_t)r * n + k] = Fr::sub(a[(size_t)r * n + k], Fr::mul(f, a[(size_t)c * n + k]));
+                inv[(size_t)r * n + k] = Fr::sub(inv[(size_t)r * n + k], Fr::mul(f, inv[(size_t)c * n + k]));
+            }
+        }
+    }
+    return true;
+}
+
+// Optimised partial rounds.  The S-box of a partial round touches state[0] only, so the round matrix
+//   N_i = [[m00, v],[w, Mhat_i]] = diag(1, Mhat_i) * [[m00, v],[Mhat_i^-1 w, I]]
+// can leave its block-diagonal factor to the NEXT round (it commutes with that round's S-box layer): N_(i+1) = M * diag(1, Mhat_i),
+// round constants k_i = diag(1, Mhat_(i-1))^-1 c_i, and one dense (t-1)x(t-1) block Mhat_last after the last partial round.
+// A partial round then costs 3 + (2t-1) products instead of 3 + t^2 (t = 3: 8 vs 12; t = 13: 28 vs 172).
+// Derivation checked against the plain permutation in tools/poseidon_grain.py (permute_optimised) and on the device by the
+// parity tests against the oracle's plain permutation.
+static bool optimise_partial_rounds(int t, const std::vector<Fr>& rc, const std::vector<Fr>& mds, std::vector<Fr>& prc,
+                                    std::vector<Fr>& sparse, std::vector<Fr>& post) {
+    const int rp = pos_rp(t), m = t - 1;
+    std::vector<Fr> N = mds, prev_inv, mhat((size_t)m * m), inv;
+    prc.assign((size_t)rp * t, Fr::zero());
+    sparse.assign((size_t)rp * (2 * t - 1), Fr::zero());
+    for (int i = 0; i < rp; ++i) {
+        for (int r = 0; r < m; ++r) for (int c = 0; c < m; ++c) mhat[(size_t)r * m + c] = N[(size_t)(r + 1) * t + (c + 1)];
+        std::vector<Fr> tmp = mhat;
+        if (m > 0 && !fr_mat_inv(tmp, m, inv)) return false;
+        Fr* sp = &sparse[(size_t)i * (2 * t - 1)];
+        sp[0] = N[0];
+        for (int c = 0; c < m; ++c) sp[1 + c] = N[1 + c];                       // v
+        for (int r = 0; r < m; ++r) {                                           // what = Mhat^-1 w
+            Fr acc = Fr::zero();
+            for (int c = 0; c < m; ++c) acc = Fr::add(acc, Fr::mul(inv[(size_t)r * m + c], N[(size_t)(c + 1) * t]));
+            sp[t + r] = acc;
+        }
+        const Fr* c_i = &rc[(size_t)(POS_RF / 2 + i) * t];
+        Fr* k = &prc[(size_t)i * t];
+        k[0] = c_i[0];
+        for (int r = 0; r < m; ++r) {
+            if (i == 0) k[1 + r] = c_i[1 + r];
+            else {
+                Fr acc = Fr::zero();
+                for (int c = 0; c < m; ++c) acc = Fr::add(acc, Fr::mul(prev_inv[(size_t)r * m + c], c_i[1 + c]));
+                k[1 + r] = acc;
+            }
+        }
+        prev_inv = inv;
+        // N <- M * diag(1, Mhat)
+        std::vector<Fr> Nn((size_t)t * t);
+        for (int r = 0; r < t; ++r) {
+            Nn[(size_t)r * t] = mds[(size_t)r * t];
+            for (int c = 1; c < t; ++c) {
+                Fr acc = Fr::zero();
+                for (int x = 1; x < t; ++x) acc = Fr::add(acc, Fr::mul(mds[(size_t)r * t + x], mhat[(size_t)(x - 1) * m + (c - 1)]));
+                Nn[(size_t)r * t + c] = acc;
+            }
+        }
+        N.swap(Nn);
+    }
+    post = mhat;
+    return true;
+}
+
 static int32_t pos_tables_get(zkpor_ctx* ctx, PosTables** out) {
     if (ctx->pos_tables) { *out = (PosTables*)ctx->pos_tables; return ZKPOR_OK; }
     PosTables* T = new PosTables();
@@ -108,6 +190,14 @@ static int32_t pos_tables_get(zkpor_ctx* ctx, PosTables** out) {
         T->host.insert(T->host.end(), rc.begin(), rc.end());
         T->mds_off[t] = (u32)T->host.size();
         T->host.insert(T->host.end(), mds.begin(), mds.end());
+        std::vector<Fr> prc, sparse, post;
+        if (!optimise_partial_rounds(t, rc, mds, prc, sparse, post)) { delete T; ctx->err = "poseidon: singular partial-round block"; return ZKPOR_E_STATE; }
+        T->prc_off[t] = (u32)T->host.size();
+        T->host.insert(T->host.end(), prc.begin(), prc.end());
+        T->sp_off[t] = (u32)T->host.size();
+        T->host.insert(T->host.end(), sparse.begin(), sparse.end());
+        T->post_off[t] = (u32)T->host.size();
+        T->host.insert(T->host.end(), post.begin(), post.end());
     }
     ZK_HIP(ctx, hipMalloc((void**)&T->dev, T->host.size() * sizeof(Fr)));
     ZK_HIP(ctx, hipMemcpyAsync(T->dev, T->host.data(), T->host.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
@@ -129,32 +219,72 @@ ZK_HD Fr pow5(const Fr& x) {
     return Fr::mul(Fr::sqr(x2), x);
 }
 
+struct PermTab {  // pointers into the table blob for one width
+    const Fr* rc; const Fr* m; const Fr* prc; const Fr* sp; const Fr* post;
+};
+
 // width-3 permutation with the state in registers (the Merkle-node hash: ~N of these per tree build)
-ZK_HD void permute3(Fr& s0, Fr& s1, Fr& s2, const Fr* __restrict__ rc, const Fr* __restrict__ m) {
+ZK_HD void permute3(Fr& s0, Fr& s1, Fr& s2, const PermTab& T) {
     const int rp = 57;
-    for (int r = 0; r < POS_RF + rp; ++r) {
-        s0 = Fr::add(s0, rc[3 * r]); s1 = Fr::add(s1, rc[3 * r + 1]); s2 = Fr::add(s2, rc[3 * r + 2]);
-        s0 = pow5(s0);
-        if (r < POS_RF / 2 || r >= POS_RF / 2 + rp) { s1 = pow5(s1); s2 = pow5(s2); }
-        Fr t0 = Fr::add(Fr::add(Fr::mul(m[0], s0), Fr::mul(m[1], s1)), Fr::mul(m[2], s2));
-        Fr t1 = Fr::add(Fr::add(Fr::mul(m[3], s0), Fr::mul(m[4], s1)), Fr::mul(m[5], s2));
-        Fr t2 = Fr::add(Fr::add(Fr::mul(m[6], s0), Fr::mul(m[7], s1)), Fr::mul(m[8], s2));
-        s0 = t0; s1 = t1; s2 = t2;
+    const Fr* m = T.m;
+    for (int half = 0; half < 2; ++half) {
+        for (int rr = 0; rr < POS_RF / 2; ++rr) {
+            const Fr* c = T.rc + 3 * (half ? POS_RF / 2 + rp + rr : rr);
+            s0 = pow5(Fr::add(s0, c[0])); s1 = pow5(Fr::add(s1, c[1])); s2 = pow5(Fr::add(s2, c[2]));
+            Fr t0 = Fr::add(Fr::add(Fr::mul(m[0], s0), Fr::mul(m[1], s1)), Fr::mul(m[2], s2));
+            Fr t1 = Fr::add(Fr::add(Fr::mul(m[3], s0), Fr::mul(m[4], s1)), Fr::mul(m[5], s2));
+            Fr t2 = Fr::add(Fr::add(Fr::mul(m[6], s0), Fr::mul(m[7], s1)), Fr::mul(m[8], s2));
+            s0 = t0; s1 = t1; s2 = t2;
+        }
+        if (half) break;
+        for (int i = 0; i < rp; ++i) {  // sparse partial rounds: 3 + 5 products
+            const Fr* k = T.prc + 3 * i;
+            const Fr* sp = T.sp + 5 * i;
+            Fr x0 = pow5(Fr::add(s0, k[0]));
+            s1 = Fr::add(s1, k[1]); s2 = Fr::add(s2, k[2]);
+            s0 = Fr::add(Fr::add(Fr::mul(sp[0], x0), Fr::mul(sp[1], s1)), Fr::mul(sp[2], s2));
+            s1 = Fr::add(s1, Fr::mul(sp[3], x0));
+            s2 = Fr::add(s2, Fr::mul(sp[4], x0));
+        }
+        Fr u1 = Fr::add(Fr::mul(T.post[0], s1), Fr::mul(T.post[1], s2));
+        Fr u2 = Fr::add(Fr::mul(T.post[2], s1), Fr::mul(T.post[3], s2));
+        s1 = u1; s2 = u2;
     }
 }
 // generic width (state in memory): used for leaf hashing and the generic hash entry point
-ZK_HD void permute_generic(Fr* st, int t, const Fr* __restrict__ rc, const Fr* __restrict__ m, int rp) {
+ZK_HD void permute_generic(Fr* st, int t, const PermTab& T, int rp) {
     Fr tmp[POS_MAX_T];
-    for (int r = 0; r < POS_RF + rp; ++r) {
-        for (int i = 0; i < t; ++i) st[i] = Fr::add(st[i], rc[r * t + i]);
-        if (r < POS_RF / 2 || r >= POS_RF / 2 + rp) { for (int i = 0; i < t; ++i) st[i] = pow5(st[i]); }
-        else st[0] = pow5(st[0]);
-        for (int i = 0; i < t; ++i) {
-            Fr acc = Fr::mul(m[i * t], st[0]);
-            for (int j = 1; j < t; ++j) acc = Fr::add(acc, Fr::mul(m[i * t + j], st[j]));
-            tmp[i] = acc;
+    const int m1 = t - 1;
+    for (int half = 0; half < 2; ++half) {
+        for (int rr = 0; rr < POS_RF / 2; ++rr) {
+            const Fr* c = T.rc + (size_t)t * (half ? POS_RF / 2 + rp + rr : rr);
+            for (int i = 0; i < t; ++i) st[i] = pow5(Fr::add(st[i], c[i]));
+            for (int i = 0; i < t; ++i) {
+                Fr acc = Fr::mul(T.m[i * t], st[0]);
+                for (int j = 1; j < t; ++j) acc = Fr::add(acc, Fr::mul(T.m[i * t + j], st[j]));
+                tmp[i] = acc;
+            }
+            for (int i = 0; i < t; ++i) st[i] = tmp[i];
         }
-        for (int i = 0; i < t; ++i) st[i] = tmp[i];
+        if (half) break;
+        for (int i = 0; i < rp; ++i) {
+            const Fr* k = T.prc + (size_t)i * t;
+            const Fr* sp = T.sp + (size_t)i * (2 * t - 1);
+            Fr x0 = pow5(Fr::add(st[0], k[0]));
+            Fr acc = Fr::mul(sp[0], x0);
+            for (int j = 1; j < t; ++j) {
+                Fr sj = Fr::add(st[j], k[j]);
+                acc = Fr::add(acc, Fr::mul(sp[j], sj));
+                st[j] = Fr::add(sj, Fr::mul(sp[t + j - 1], x0));
+            }
+            st[0] = acc;
+        }
+        for (int r = 0; r < m1; ++r) {
+            Fr acc = Fr::mul(T.post[r * m1], st[1]);
+            for (int c = 1; c < m1; ++c) acc = Fr::add(acc, Fr::mul(T.post[r * m1 + c], st[1 + c]));
+            tmp[r] = acc;
+        }
+        for (int r = 0; r < m1; ++r) st[1 + r] = tmp[r];
     }
 }
 
@@ -162,6 +292,10 @@ struct PosDev {  // everything a kernel needs to hash
     const Fr* tab;
     u32 rc_off[POS_MAX_T + 1];
     u32 mds_off[POS_MAX_T + 1];
+    u32 prc_off[POS_MAX_T + 1];
+    u32 sp_off[POS_MAX_T + 1];
+    u32 post_off[POS_MAX_T + 1];
+    ZK_HD PermTab tabs(int t) const { return {tab + rc_off[t], tab + mds_off[t], tab + prc_off[t], tab + sp_off[t], tab + post_off[t]}; }
     int rp[POS_MAX_T + 1];
     int out_idx, carry_idx;
 };
@@ -176,7 +310,7 @@ struct Sponge {
         if (!fill) return;
         int t = fill + 1;
         st[0] = cap;
-        permute_generic(st, t, P.tab + P.rc_off[t], P.tab + P.mds_off[t], P.rp[t]);
+        permute_generic(st, t, P.tabs(t), P.rp[t]);
         cap = st[P.carry_idx];
         out = st[P.out_idx];
         fill = 0;
@@ -197,7 +331,7 @@ __global__ __launch_bounds__(256) void k_hash2_level(const Fr* __restrict__ in, 
     Fr s0 = Fr::zero();
     Fr s1 = in[2 * i];
     Fr s2 = (2 * i + 1 < n_in) ? in[2 * i + 1] : nil;
-    permute3(s0, s1, s2, P.tab + P.rc_off[3], P.tab + P.mds_off[3]);
+    permute3(s0, s1, s2, P.tabs(3));
     out[i] = P.out_idx == 0 ? s0 : (P.out_idx == 1 ? s1 : s2);
 }
 
@@ -305,7 +439,10 @@ static int32_t pos_dev(zkpor_ctx* ctx, PosDev* P) {
     PosTables* T;
     ZK_TRY(pos_tables_get(ctx, &T));
     P->tab = T->dev;
-    for (int t = 2; t <= POS_MAX_T; ++t) { P->rc_off[t] = T->rc_off[t]; P->mds_off[t] = T->mds_off[t]; P->rp[t] = pos_rp(t); }
+    for (int t = 2; t <= POS_MAX_T; ++t) {
+        P->rc_off[t] = T->rc_off[t]; P->mds_off[t] = T->mds_off[t]; P->prc_off[t] = T->prc_off[t];
+        P->sp_off[t] = T->sp_off[t]; P->post_off[t] = T->post_off[t]; P->rp[t] = pos_rp(t);
+    }
     if (ctx->pos_out < 0 || ctx->pos_out > 1 || ctx->pos_carry < 0 || ctx->pos_carry > 1) { ctx->err = "poseidon: convention indices must be 0 or 1"; return ZKPOR_E_ARG; }
     P->out_idx = ctx->pos_out; P->carry_idx = ctx->pos_carry;
     return ZKPOR_OK;
@@ -314,7 +451,9 @@ static int32_t pos_dev(zkpor_ctx* ctx, PosDev* P) {
 // host copy of the 2->1 hash (nil-subtree chain; 28 evaluations per tree)
 static Fr host_hash2(const PosTables& T, const PosDev& P, const Fr& l, const Fr& r) {
     Fr s0 = Fr::zero(), s1 = l, s2 = r;
-    permute3(s0, s1, s2, T.host.data() + T.rc_off[3], T.host.data() + T.mds_off[3]);
+    const Fr* h = T.host.data();
+    PermTab pt = {h + T.rc_off[3], h + T.mds_off[3], h + T.prc_off[3], h + T.sp_off[3], h + T.post_off[3]};
+    permute3(s0, s1, s2, pt);
     return P.out_idx == 0 ? s0 : s1;
 }
 
