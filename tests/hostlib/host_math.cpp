@@ -44,44 +44,50 @@ void hm_g1_mul(const G1Affine* p, const Fr* k_mont, G1Affine* out) {
 }
 }
 
-// ---- 9 x 29-bit representation (csrc/fe29.cuh), portable path ----
+// ---- 9 x 29-bit signed lazy representation (csrc/fe29.cuh), portable path ----
 #include "fe29.cuh"
 extern "C" {
 // out = a*b (both gnark 8x32 Montgomery form) computed THROUGH the 29-bit path: (a*32)*(b*32)/2^261 -> /32 -> canonical
 void hm_fp29_mul(const Fp* a, const Fp* b, Fp* o, size_t n) {
     for (size_t i = 0; i < n; ++i) o[i] = Fp29::to32_div32(Fp29::mul(Fp29::from32<5>(a[i]), Fp29::from32<5>(b[i])));
 }
-void hm_fp29_roundtrip(const Fp* a, Fp* o, size_t n) { for (size_t i = 0; i < n; ++i) o[i] = Fp29::to32_div32(Fp29::mul(Fp29::from32<5>(a[i]), Fp29::one())); }
-// (a - b) and (a + b) through the lazy forms (inputs reduced below 2p by a product with one)
-void hm_fp29_addsub(const Fp* a, const Fp* b, Fp* osum, Fp* odiff, size_t n) {
+void hm_fp29_roundtrip(const Fp* a, Fp* o, size_t n) { for (size_t i = 0; i < n; ++i) o[i] = Fp29::to32_div32(Fp29::mul(Fp29::one(), Fp29::from32<5>(a[i]))); }
+// (a - b), (a + b), (-a) through the lazy signed forms
+void hm_fp29_addsub(const Fp* a, const Fp* b, Fp* osum, Fp* odiff, Fp* oneg, size_t n) {
     for (size_t i = 0; i < n; ++i) {
-        Fp29 x = Fp29::mul(Fp29::from32<5>(a[i]), Fp29::one()), y = Fp29::mul(Fp29::from32<5>(b[i]), Fp29::one());
-        osum[i] = Fp29::to32_div32(Fp29::add(x, y));
-        odiff[i] = Fp29::to32_div32(Fp29::sub<4>(x, y));
+        Fp29 x = Fp29::mul(Fp29::one(), Fp29::from32<5>(a[i])), y = Fp29::mul(Fp29::one(), Fp29::from32<5>(b[i]));
+        osum[i] = Fp29::to32_div32(Fp29::add_n(x, y));
+        odiff[i] = Fp29::to32_div32(Fp29::sub_n(x, y));
+        oneg[i] = Fp29::to32_div32(Fp29::neg(x));
     }
 }
-// a*b + c*d fused
+// a*b - c*d fused (the Y3 shape)
 void hm_fp29_mul2(const Fp* a, const Fp* b, const Fp* c, const Fp* d, Fp* o, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         Fp29 one = Fp29::one();
-        Fp29 A = Fp29::mul(Fp29::from32<5>(a[i]), one), B = Fp29::mul(Fp29::from32<5>(b[i]), one);
-        Fp29 C = Fp29::mul(Fp29::from32<5>(c[i]), one), D = Fp29::mul(Fp29::from32<5>(d[i]), one);
-        o[i] = Fp29::to32_div32(Fp29::mul2(A, B, C, D));
+        Fp29 A = Fp29::mul(one, Fp29::from32<5>(a[i])), B = Fp29::mul(one, Fp29::from32<5>(b[i]));
+        Fp29 C = Fp29::mul(one, Fp29::from32<5>(c[i])), D = Fp29::mul(one, Fp29::from32<5>(d[i]));
+        o[i] = Fp29::to32_div32(Fp29::y3(A, B, C, D));
     }
 }
-int hm_fp29_is_zero(const Fp* a, const Fp* b) {  // a - b == 0 mod p through sub<16> + filter
-    Fp29 x = Fp29::mul(Fp29::from32<5>(*a), Fp29::one()), y = Fp29::mul(Fp29::from32<5>(*b), Fp29::one());
-    return Fp29::sub<16>(x, y).is_zero_mod_p() ? 1 : 0;
+int hm_fp29_is_zero(const Fp* a, const Fp* b) {  // a - b == 0 mod p through sub_n + filter
+    Fp29 x = Fp29::mul(Fp29::one(), Fp29::from32<5>(*a)), y = Fp29::mul(Fp29::one(), Fp29::from32<5>(*b));
+    return Fp29::sub_n(x, y).is_zero_mod_p() ? 1 : 0;
 }
-// sum of affine points with the 29-bit mixed addition; out XYZZ converted back to 8x32
-void hm_g1_sum29(const G1Affine* p, size_t n, G1Affine* out, uint32_t* max_top_limb) {
+// signed sum of affine points (sign[i] != 0 subtracts) with the 29-bit mixed addition; tracks limb/value bounds
+void hm_g1_sum29(const G1Affine* p, const uint8_t* sign, size_t n, G1Affine* out, uint32_t* max_top_limb) {
     XYZZ29 acc = XYZZ29::inf();
     uint32_t mt = 0;
     for (size_t i = 0; i < n; ++i) {
         if (p[i].is_inf()) continue;
-        xyzz29_madd(acc, Fp29::from32<5>(p[i].x), Fp29::from32<5>(p[i].y));
+        xyzz29_madd<Fp29>(acc, Fp29::from32<5>(p[i].x), Fp29::cneg(Fp29::from32<5>(p[i].y), sign && sign[i]));
         const Fp29* c[4] = {&acc.x, &acc.y, &acc.zz, &acc.zzz};
-        for (auto* f : c) { if (f->l[8] > mt) mt = f->l[8]; for (int k = 0; k < 8; ++k) if (f->l[k] > (1u << 29) + 32) mt = 0xffffffffu; }
+        for (auto* f : c) {
+            int32_t top = (int32_t)f->l[8];
+            uint32_t a = (uint32_t)(top < 0 ? -top : top);
+            if (a > mt) mt = a;
+            for (int k = 0; k < 8; ++k) { int32_t v = (int32_t)f->l[k]; if (v < -8 || v > (1 << 29) + 8) mt = 0xffffffffu; }
+        }
     }
     *max_top_limb = mt;
     G1XYZZ o;

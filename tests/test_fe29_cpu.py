@@ -1,4 +1,4 @@
-"""CPU suite: the 9 x 29-bit lazy field representation (csrc/fe29.cuh) used inside the MSM hot loop, portable path,
+"""CPU suite: the 9 x 29-bit SIGNED lazy field representation (csrc/fe29.cuh) used inside the MSM hot loop, portable path,
 against the oracle: conversions, product, fused double product, add/sub offsets, the zero filter, and the specialised
 mixed addition (bounds on limb growth included)."""
 import ctypes
@@ -42,13 +42,14 @@ def test_add_sub_mul2():
     L = _lib()
     n = 2000
     a = np.concatenate([_rnd_fp(3, n), O.fp_from_ints(EDGE)]); b = np.concatenate([_rnd_fp(4, n), O.fp_from_ints(EDGE[::-1])])
-    s = np.empty_like(a); d = np.empty_like(a)
-    L.hm_fp29_addsub(_p(a), _p(b), _p(s), _p(d), ctypes.c_size_t(len(a)))
+    s = np.empty_like(a); d = np.empty_like(a); ng = np.empty_like(a)
+    L.hm_fp29_addsub(_p(a), _p(b), _p(s), _p(d), _p(ng), ctypes.c_size_t(len(a)))
     assert np.array_equal(s, O.fp_add(a, b)) and np.array_equal(d, O.fp_sub(a, b))
+    assert np.array_equal(ng, O.fp_sub(O.fp_from_ints([0] * len(a)), a))
     c = np.concatenate([_rnd_fp(5, n), O.fp_from_ints(EDGE)]); e = np.concatenate([_rnd_fp(6, n), O.fp_from_ints(EDGE)])
     o = np.empty_like(a)
     L.hm_fp29_mul2(_p(a), _p(b), _p(c), _p(e), _p(o), ctypes.c_size_t(len(a)))
-    assert np.array_equal(o, O.fp_add(O.fp_mul(a, b), O.fp_mul(c, e)))
+    assert np.array_equal(o, O.fp_sub(O.fp_mul(a, b), O.fp_mul(c, e)))      # y3(A,B,C,D) = A*B - C*D, one reduction
 
 
 def test_zero_filter():
@@ -67,14 +68,19 @@ def test_mixed_addition_matches_oracle_and_stays_bounded():
     pts = O.g1_from_scalars(sc)
     ones = O.fr_from_ints([1] * 400)
     out = np.empty(8, np.uint64); top = ctypes.c_uint32()
-    L.hm_g1_sum29(_p(pts), ctypes.c_size_t(400), _p(out), ctypes.byref(top))
+    L.hm_g1_sum29(_p(pts), None, ctypes.c_size_t(400), _p(out), ctypes.byref(top))
     assert np.array_equal(out, O.g1_msm(pts, ones, -1))
-    assert top.value < (1 << 27)                        # value bound (< 2^259) and tight limbs held at every step
+    assert top.value < (1 << 25)                        # |value| < 2^257 and tight limbs held at every step
+    # signed digits: subtract every third point
+    sign = np.array([1 if i % 3 == 0 else 0 for i in range(400)], dtype=np.uint8)
+    pm = O.fr_from_ints([O.R_MOD - 1 if s else 1 for s in sign])
+    L.hm_g1_sum29(_p(pts), _p(sign), ctypes.c_size_t(400), _p(out), ctypes.byref(top))
+    assert np.array_equal(out, O.g1_msm(pts, pm, -1)) and top.value < (1 << 25)
     # doubling (same point twice), cancellation (P, -P) and restart after infinity
     neg = pts[:1].copy(); neg[:, 4:8] = O.fp_sub(O.fp_from_ints([0]), neg[:, 4:8])
     seq = np.concatenate([pts[:3], pts[:3], pts[5:6], pts[:1], neg, pts[9:12]])
-    L.hm_g1_sum29(_p(seq), ctypes.c_size_t(len(seq)), _p(out), ctypes.byref(top))
-    assert np.array_equal(out, O.g1_msm(seq, ones[:len(seq)], -1)) and top.value < (1 << 27)
+    L.hm_g1_sum29(_p(seq), None, ctypes.c_size_t(len(seq)), _p(out), ctypes.byref(top))
+    assert np.array_equal(out, O.g1_msm(seq, ones[:len(seq)], -1)) and top.value < (1 << 25)
     pair = np.concatenate([pts[:1], neg])
-    L.hm_g1_sum29(_p(pair), ctypes.c_size_t(2), _p(out), ctypes.byref(top))
+    L.hm_g1_sum29(_p(pair), None, ctypes.c_size_t(2), _p(out), ctypes.byref(top))
     assert not out.any()

@@ -8,6 +8,7 @@
 // with a single interleaved Montgomery reduction (192 multiply-add pairs instead of 2 x 128).
 #pragma once
 #include "ec.cuh"
+#include "fe29.cuh"
 
 namespace zk {
 
@@ -16,7 +17,7 @@ __device__ __forceinline__ u32 lp_swap(u32 x) {
     return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
 }
 #else
-inline u32 lp_swap(u32 x) { return x; }  // host pass only parses this header
+__host__ __device__ inline u32 lp_swap(u32 x) { return x; }  // host pass only parses this header
 #endif
 
 struct Fp2L {
@@ -109,6 +110,74 @@ struct Fp2L {
 #pragma unroll
         for (int i = 0; i < 8; ++i) V.v[i] = od ? ao.v[i] : d.v[i];
         return {Fp::mul_body(U, V)};
+    }
+};
+
+// ---- the same lane-pair layout on the 29-bit signed lazy form (fe29.cuh): interface of the generic xyzz29_madd ----
+struct Fp2L29 {
+    Fp29 c;  // this lane's component
+
+    ZK_HD static bool odd() { return Fp2L::odd(); }
+    ZK_HD static Fp29 partner(const Fp29& x) {
+        Fp29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = lp_swap(x.l[i]);
+        return r;
+    }
+    ZK_HD static Fp2L29 zero() { return {Fp29::zero()}; }
+    ZK_HD static Fp2L29 one() {
+        Fp29 o = Fp29::one();
+        Fp2L29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.c.l[i] = odd() ? 0u : o.l[i];
+        return r;
+    }
+    ZK_HD bool all_limbs_zero() const {
+        u32 o = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o |= c.l[i];
+        o |= lp_swap(o);
+        return o == 0;
+    }
+    ZK_HD bool zero_mod_p() const {  // both components = 0 (mod p)
+        u32 z = c.is_zero_mod_p() ? 1u : 0u;
+        z &= lp_swap(z);
+        return z != 0;
+    }
+    ZK_HD static Fp2L29 add_l(const Fp2L29& x, const Fp2L29& y) { return {Fp29::add_l(x.c, y.c)}; }
+    ZK_HD static Fp2L29 sub_l(const Fp2L29& x, const Fp2L29& y) { return {Fp29::sub_l(x.c, y.c)}; }
+    ZK_HD static Fp2L29 add_n(const Fp2L29& x, const Fp2L29& y) { return {Fp29::add_n(x.c, y.c)}; }
+    ZK_HD static Fp2L29 sub_n(const Fp2L29& x, const Fp2L29& y) { return {Fp29::sub_n(x.c, y.c)}; }
+    ZK_HD static Fp2L29 neg(const Fp2L29& x) { return {Fp29::neg(x.c)}; }
+    ZK_HD static Fp2L29 normed(const Fp2L29& x) { return {Fp29::normed(x.c)}; }
+    // (a0 + a1 u)(b0 + b1 u): even lane a0*b0 + a1*(-b1), odd lane a1*b0 + a0*b1 — one fused double product each
+    ZK_HD static Fp2L29 mul(const Fp2L29& x, const Fp2L29& y) {
+        const bool od = odd();
+        Fp29 ao = partner(x.c), bo = partner(y.c);
+        Fp29 X, Y;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            X.l[i] = od ? bo.l[i] : y.c.l[i];
+            Y.l[i] = od ? y.c.l[i] : 0u - bo.l[i];
+        }
+        return {Fp29::mul2(x.c, X, ao, Y)};
+    }
+    // even: (a0 + a1)(a0 - a1)      odd: (a1 + a1) * a0      (U loose, V tight)
+    ZK_HD static Fp2L29 sqr(const Fp2L29& x) {
+        const bool od = odd();
+        Fp29 ao = partner(x.c);
+        Fp29 U, V;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            U.l[i] = x.c.l[i] + (od ? x.c.l[i] : ao.l[i]);
+            V.l[i] = od ? ao.l[i] : x.c.l[i] - ao.l[i];
+        }
+        Fp29::norm(V.l);
+        return {Fp29::mul(V, U)};
+    }
+    // R*D - Y1*PPP: two complex products (a four-product fusion would overflow the signed 64-bit columns)
+    ZK_HD static Fp2L29 y3(const Fp2L29& R, const Fp2L29& D, const Fp2L29& Y1, const Fp2L29& PPP) {
+        return sub_n(mul(R, D), mul(Y1, PPP));
     }
 };
 

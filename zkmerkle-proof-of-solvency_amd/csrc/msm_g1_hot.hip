@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__
             last_key = k;
             Affine<Fp> p = pts[v >> 1];
             if (!p.is_inf()) {
-                xyzz29_madd(acc, Fp29::from32<5>(p.x), Fp29::cneg_loose(Fp29::from32<5>(p.y), (v & 1u) != 0));
+                xyzz29_madd<Fp29>(acc, Fp29::from32<5>(p.x), Fp29::cneg(Fp29::from32<5>(p.y), (v & 1u) != 0));
             }
         }
     }

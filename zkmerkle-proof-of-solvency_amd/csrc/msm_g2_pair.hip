@@ -73,6 +73,87 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair(const u32* __restrict
     }
 }
 
+// ---- 29-bit signed lazy form of the level-1 kernel (fe29.cuh + Fp2L29) ----
+__device__ __forceinline__ void lp_store29(XYZZ<Fp2>* dst, const XYZZ29T<Fp2L29>& a, u32 par) {
+    Fp* d = (Fp*)dst;
+    if (a.is_inf()) {
+        Fp z = Fp::zero();
+        d[par] = z; d[2 + par] = z; d[4 + par] = z; d[6 + par] = z;
+    } else {
+        d[par] = Fp29::to32_div32(a.x.c); d[2 + par] = Fp29::to32_div32(a.y.c);
+        d[4 + par] = Fp29::to32_div32(a.zz.c); d[6 + par] = Fp29::to32_div32(a.zzz.c);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restrict__ keys, const u32* __restrict__ vals,
+                                                             const Affine<Fp2>* __restrict__ pts, u32 M, int L,
+                                                             XYZZ<Fp2>* __restrict__ buckets, u32* __restrict__ out_keys,
+                                                             XYZZ<Fp2>* __restrict__ out_part) {
+    __shared__ u32 sk[128 * ACC_PITCH];
+    __shared__ u32 sv[128 * ACC_PITCH];
+    typedef XYZZ29T<Fp2L29> Acc;
+    const u32 row0 = blockIdx.x * 128u;
+    const u32 lr = threadIdx.x >> 1, par = threadIdx.x & 1u;
+    const u32 t = row0 + lr;
+    const u32 T = (M + (u32)L - 1u) / (u32)L;
+    const bool live = t < T;
+    const u32 start = live ? t * (u32)L : 0u;
+    const u32 end = live ? ((start + (u32)L < M) ? start + (u32)L : M) : 0u;
+    const u32 prev = (live && start > 0) ? keys[start - 1] : NOKEY;
+    const u32 next = (live && end < M) ? keys[end] : NOKEY;
+    Acc acc = Acc::inf();
+    u32 cur = live ? keys[start] : NOKEY;
+    const u32 first_key = cur;
+    u32 last_key = cur;
+    bool first = true, head_written = false, tail_written = false;
+    const int nphase = (L + ACC_SUB - 1) / ACC_SUB;
+    const u32 rows = (T - row0 < 128u) ? T - row0 : 128u;
+    for (int ph = 0; ph < nphase; ++ph) {
+        if (ph) __syncthreads();
+        acc_stage(keys, vals, M, L, row0, rows, ph, sk, sv);
+        __syncthreads();
+        if (!live) continue;
+        const u32 j0 = start + (u32)ph * ACC_SUB;
+        const u32 j1 = (j0 + ACC_SUB < end) ? j0 + ACC_SUB : end;
+        for (u32 j = j0; j < j1; ++j) {
+            const u32 k = sk[lr * ACC_PITCH + (j - j0)];
+            const u32 v = sv[lr * ACC_PITCH + (j - j0)];
+            if (k != cur) {
+                if (first && cur == prev) { lp_store29(out_part + 2 * t, acc, par); head_written = true; }
+                else lp_store29(buckets + cur, acc, par);
+                first = false;
+                cur = k;
+                acc = Acc::inf();
+            }
+            last_key = k;
+            const Fp* pp = (const Fp*)(pts + (v >> 1));
+            Fp px = pp[par], py = pp[2 + par];
+            u32 nz = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nz |= px.v[i] | py.v[i];
+            nz |= lp_swap(nz);
+            if (nz) {
+                Fp2L29 x29 = {Fp29::from32<5>(px)};
+                Fp2L29 y29 = {Fp29::cneg(Fp29::from32<5>(py), (v & 1u) != 0)};
+                xyzz29_madd<Fp2L29>(acc, x29, y29);
+            }
+        }
+    }
+    if (!live) return;
+    if (first && cur == prev) { lp_store29(out_part + 2 * t, acc, par); head_written = true; }
+    else if (cur == next) { lp_store29(out_part + 2 * t + 1, acc, par); tail_written = true; }
+    else lp_store29(buckets + cur, acc, par);
+    if (T > 1) {
+        Acc z = Acc::inf();
+        if (!head_written) lp_store29(out_part + 2 * t, z, par);
+        if (!tail_written) lp_store29(out_part + 2 * t + 1, z, par);
+        if (par == 0) {
+            out_keys[2 * t] = first_key;
+            out_keys[2 * t + 1] = last_key;
+        }
+    }
+}
+
 __device__ __forceinline__ XYZZ<Fp2L> lp_load(const XYZZ<Fp2>* src, u32 par) {
     const Fp* d = (const Fp*)src;
     XYZZ<Fp2L> a;
@@ -170,7 +251,8 @@ int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Af
                       XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part) {
     u32 T = (M + (u32)L - 1u) / (u32)L;
     PhaseScope ps(ctx, "k_acc_level1_g2");
-    hipLaunchKernelGGL(k_acc_level1_g2pair, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
+    if (ctx->g2_variant == 0) hipLaunchKernelGGL(k_acc_level1_g2pair, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
+    else hipLaunchKernelGGL(k_acc_level1_g2pair29, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
