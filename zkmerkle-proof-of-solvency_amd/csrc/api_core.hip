@@ -132,6 +132,7 @@ void zkpor_destroy(zkpor_ctx* ctx) {
     pos_tables_free(ctx);
     ntt_domains_free(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

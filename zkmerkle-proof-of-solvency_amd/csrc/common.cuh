@@ -21,6 +21,7 @@ struct zkpor_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t aux_stream = nullptr;  // digit streams (decompose + sort) of the prove tail run here, beside the ALU-bound kernels
     std::string err;
     // bump-allocated workspace, regrown on demand
     char* ws = nullptr;

@@ -324,32 +324,66 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
     const int n = pk->log2_domain;
     const size_t D = (size_t)1 << n;
-    // 1. h = computeH(a,b,c), left in d_a (bit-reversed = the order of pk->Z)
-    ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
-    // 2. one digit stream of the witness serves A, B1, B2, K
+    // Two HIP streams: the ALU-bound work (NTTs, bucket accumulations) on the context's stream, the HBM-bound digit
+    // streams (decompose + radix sort) on an auxiliary one, so that sort(w) hides under the NTTs and sort(h) under the
+    // four witness accumulations.  No host synchronisation on the main stream until all five sums are queued.
+    if (!ctx->aux_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    hipStream_t main_s = ctx->stream, aux_s = ctx->aux_stream;
+    hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx);
+    struct EvGuard { zkpor_ctx* c; hipEvent_t e[4]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs}, main_s};
     MsmCfg cfgw = msm_cfg(ctx, pk->n_wires);
     MsmCfg cfgh = msm_cfg(ctx, D - 1);
     size_t sortw = 0, sorth = 0;
-    size_t needw = digits_ws_bytes(ctx, pk->n_wires, cfgw, &sortw) + accumulate_ws_bytes<Fp2>(cfgw, pk->n_wires * (size_t)cfgw.W);
-    size_t needh = digits_ws_bytes(ctx, D - 1, cfgh, &sorth) + accumulate_ws_bytes<Fp>(cfgh, (D - 1) * (size_t)cfgh.W);
-    ZK_TRY(ws_reserve(ctx, needw > needh ? needw : needh));
-    DigitStream dsw;
+    size_t need_dw = digits_ws_bytes(ctx, pk->n_wires, cfgw, &sortw);
+    size_t need_dh = digits_ws_bytes(ctx, D - 1, cfgh, &sorth);
+    size_t need_aw = accumulate_ws_bytes<Fp2>(cfgw, pk->n_wires * (size_t)cfgw.W);
+    size_t need_ah = accumulate_ws_bytes<Fp>(cfgh, (D - 1) * (size_t)cfgh.W);
+    ZK_TRY(ws_reserve(ctx, need_dw + need_dh + (need_aw > need_ah ? need_aw : need_ah)));
+    ZK_TRY(ensure_pinned(ctx, 16 * MSM_SLOT_BYTES));
+    char* pin = (char*)ctx->pinned;
+    ZK_HIP(ctx, hipEventRecord(e_start, main_s));
+    // 1. h = computeH(a,b,c) on the main stream, left in d_a (bit-reversed = the order of pk->Z)
+    ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
+    ZK_HIP(ctx, hipEventRecord(e_h, main_s));
+    // 2. digit stream of the witness on the auxiliary stream (serves A, B1, B2, K)
+    DigitStream dsw, dsh;
+    ctx->stream = aux_s;
+    ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_start, 0));
     ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw));
+    ZK_HIP(ctx, hipEventRecord(e_w, aux_s));
+    size_t off_dh = ctx->ws_off;
+    ctx->stream = main_s;
+    // 3. queue the four witness accumulations (they reuse one workspace region in stream order)
+    ctx->ws_off = need_dw + need_dh;
     size_t mark = ctx->ws_off;
+    ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_w, 0));
+    MsmPending pA, pB1, pK, pB2, pZ;
+    ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->A, pin + 0 * MSM_SLOT_BYTES, pin + 1 * MSM_SLOT_BYTES, &pA));
+    ctx->ws_off = mark;
+    ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->B1, pin + 2 * MSM_SLOT_BYTES, pin + 3 * MSM_SLOT_BYTES, &pB1));
+    ctx->ws_off = mark;
+    ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->K, pin + 4 * MSM_SLOT_BYTES, pin + 5 * MSM_SLOT_BYTES, &pK));
+    ctx->ws_off = mark;
+    ZK_TRY(msm_accumulate_launch<Fp2>(ctx, dsw, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2));
+    // 4. digit stream of h on the auxiliary stream, overlapping the accumulations above
+    ctx->stream = aux_s;
+    ctx->ws_off = off_dh;
+    ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_h, 0));
+    ZK_TRY(msm_digits(ctx, (const Fr*)d_a, D - 1, cfgh, sorth, &dsh));
+    ZK_HIP(ctx, hipEventRecord(e_hs, aux_s));
+    ctx->stream = main_s;
+    // 5. Z . h
+    ctx->ws_off = mark;
+    ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_hs, 0));
+    ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsh, pk->Z, pin + 10 * MSM_SLOT_BYTES, pin + 11 * MSM_SLOT_BYTES, &pZ));
+    ZK_HIP(ctx, hipStreamSynchronize(main_s));
     G1XYZZ mA, mB1, mK, mZ;
     G2XYZZ mB2;
-    ZK_TRY(msm_accumulate<Fp>(ctx, dsw, pk->A, &mA));
-    ctx->ws_off = mark;
-    ZK_TRY(msm_accumulate<Fp>(ctx, dsw, pk->B1, &mB1));
-    ctx->ws_off = mark;
-    ZK_TRY(msm_accumulate<Fp>(ctx, dsw, pk->K, &mK));
-    ctx->ws_off = mark;
-    ZK_TRY(msm_accumulate<Fp2>(ctx, dsw, pk->B2, &mB2));
-    // 3. Z . h
-    ctx->ws_off = 0;
-    DigitStream dsh;
-    ZK_TRY(msm_digits(ctx, (const Fr*)d_a, D - 1, cfgh, sorth, &dsh));
-    ZK_TRY(msm_accumulate<Fp>(ctx, dsh, pk->Z, &mZ));
+    msm_accumulate_finish<Fp>(pA, &mA);
+    msm_accumulate_finish<Fp>(pB1, &mB1);
+    msm_accumulate_finish<Fp>(pK, &mK);
+    msm_accumulate_finish<Fp2>(pB2, &mB2);
+    msm_accumulate_finish<Fp>(pZ, &mZ);
     // 4. blinding and assembly on the host (a few hundred group operations)
     Fr rm, sm;
     memcpy(&rm, r, 32); memcpy(&sm, s, 32);
@@ -414,9 +448,15 @@ int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, siz
         ZK_TRY(ws_reserve(ctx, need));
         ZK_TRY(msm_digits(ctx, (const Fr*)d_values, n, cfg, st, &ds));
         size_t mark = ctx->ws_off;
-        ZK_TRY(msm_accumulate<Fp>(ctx, ds, pk->CB, &c1));
+        ZK_TRY(ensure_pinned(ctx, 16 * MSM_SLOT_BYTES));
+        char* pin = (char*)ctx->pinned;
+        MsmPending p1, p2;
+        ZK_TRY(msm_accumulate_launch<Fp>(ctx, ds, pk->CB, pin + 12 * MSM_SLOT_BYTES, pin + 13 * MSM_SLOT_BYTES, &p1));
         ctx->ws_off = mark;
-        ZK_TRY(msm_accumulate<Fp>(ctx, ds, pk->CBS, &c2));
+        ZK_TRY(msm_accumulate_launch<Fp>(ctx, ds, pk->CBS, pin + 14 * MSM_SLOT_BYTES, pin + 15 * MSM_SLOT_BYTES, &p2));
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        msm_accumulate_finish<Fp>(p1, &c1);
+        msm_accumulate_finish<Fp>(p2, &c2);
     }
     G1Affine a1 = xyzz_to_affine<Fp>(c1), a2 = xyzz_to_affine<Fp>(c2);
     memcpy(out_commit, &a1, 64); memcpy(out_pok, &a2, 64);

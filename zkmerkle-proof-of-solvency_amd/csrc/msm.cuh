@@ -139,12 +139,23 @@ inline size_t accumulate_ws_bytes(const MsmCfg& cfg, size_t max_entries) {
     return p.total;
 }
 
-// bucket accumulation + reduction for one point array against a sorted digit stream; result = sum digits*points
-// as one XYZZ point on the host.
+struct MsmPending {  // a multi-exponentiation whose kernels are queued; its per-window finals land in pinned host memory
+    MsmCfg cfg;
+    u64 Kmul = 0;
+    bool empty = true;
+    void* hS = nullptr;  // W x XYZZ<F>, pinned
+    void* hY = nullptr;
+};
+
+// queue bucket accumulation + reduction for one point array on ctx->stream; NO host synchronisation: the W per-window
+// (S, Y) pairs are copied to the pinned slots in stream order, so the next accumulation may reuse the workspace.
 template <class F>
-inline int32_t msm_accumulate(zkpor_ctx* ctx, const DigitStream& ds, const Affine<F>* d_pts, XYZZ<F>* result) {
+inline int32_t msm_accumulate_launch(zkpor_ctx* ctx, const DigitStream& ds, const Affine<F>* d_pts, void* pinned_S,
+                                     void* pinned_Y, MsmPending* out) {
     const MsmCfg& cfg = ds.cfg;
-    if (ds.M == 0) { *result = XYZZ<F>::inf(); return ZKPOR_OK; }
+    out->cfg = cfg; out->hS = pinned_S; out->hY = pinned_Y; out->Kmul = 0;
+    out->empty = ds.M == 0;
+    if (ds.M == 0) return ZKPOR_OK;
     const u32 M = ds.M;
     const int L = cfg.L;
     size_t T1 = ((size_t)M + L - 1) / L;
@@ -193,19 +204,41 @@ inline int32_t msm_accumulate(zkpor_ctx* ctx, const DigitStream& ds, const Affin
         fin_S = Sin; fin_Y = Yin;
     }
     const size_t Wn = (size_t)cfg.W;
-    std::vector<XYZZ<F>> hS(Wn), hY(Wn);
-    ZK_HIP(ctx, hipMemcpyAsync(hS.data(), fin_S, Wn * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipMemcpyAsync(hY.data(), fin_Y, Wn * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // window sum = Y_L - Kmul * T, then Horner with 2^c over the windows
+    out->Kmul = Kmul;
+    ZK_HIP(ctx, hipMemcpyAsync(pinned_S, fin_S, Wn * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(pinned_Y, fin_Y, Wn * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
+    return ZKPOR_OK;
+}
+
+// after the stream has been synchronised: window sum = Y_L - Kmul * T, then Horner with 2^c over the windows (host)
+template <class F>
+inline void msm_accumulate_finish(const MsmPending& p, XYZZ<F>* result) {
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (int w = cfg.W - 1; w >= 0; --w) {
-        for (int k = 0; k < cfg.c; ++k) acc = xyzz_dbl<F>(acc);
-        XYZZ<F> win = hY[w];
-        if (Kmul) xyzz_add<F>(win, xyzz_neg<F>(xyzz_mul_u64<F>(hS[w], Kmul)));
-        xyzz_add<F>(acc, win);
+    if (!p.empty) {
+        const XYZZ<F>* hS = (const XYZZ<F>*)p.hS;
+        const XYZZ<F>* hY = (const XYZZ<F>*)p.hY;
+        for (int w = p.cfg.W - 1; w >= 0; --w) {
+            for (int k = 0; k < p.cfg.c; ++k) acc = xyzz_dbl<F>(acc);
+            XYZZ<F> win = hY[w];
+            if (p.Kmul) xyzz_add<F>(win, xyzz_neg<F>(xyzz_mul_u64<F>(hS[w], p.Kmul)));
+            xyzz_add<F>(acc, win);
+        }
     }
     *result = acc;
+}
+
+static constexpr size_t MSM_SLOT_BYTES = 128 * sizeof(XYZZ<Fp2>);  // one pinned (S or Y) slot: up to 128 windows (c = 2) of G2
+
+int32_t ensure_pinned(zkpor_ctx* ctx, size_t bytes);
+
+// synchronous form: queue, wait, finish
+template <class F>
+inline int32_t msm_accumulate(zkpor_ctx* ctx, const DigitStream& ds, const Affine<F>* d_pts, XYZZ<F>* result) {
+    ZK_TRY(ensure_pinned(ctx, 16 * MSM_SLOT_BYTES));
+    MsmPending p;
+    ZK_TRY(msm_accumulate_launch<F>(ctx, ds, d_pts, ctx->pinned, (char*)ctx->pinned + MSM_SLOT_BYTES, &p));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    msm_accumulate_finish<F>(p, result);
     return ZKPOR_OK;
 }
 
