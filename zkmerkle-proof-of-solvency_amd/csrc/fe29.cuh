@@ -199,6 +199,20 @@ struct Fp29 {
         }
         return r;
     }
+    // from32<5>() output (or its limb-wise negation), |v| < 32p  ->  same residue in (-0.1p, 2.4p), tight limbs, no product:
+    // q = floor(floor(v / 2^254) * 169/128) never exceeds floor(v/p) and falls short of it by at most 2
+    ZK_HD static Fp29 reduce32(const Fp29& a) {
+        const i32 q = (((i32)a.l[8] >> 22) * 169) >> 7;
+        Fp29 r;
+        i64 c = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            i64 t = (i64)(i32)a.l[i] - (i64)q * (i64)P::mod29(i) + c;
+            r.l[i] = i < 8 ? ((u32)t & M29) : (u32)t;
+            c = t >> 29;
+        }
+        return r;
+    }
     // lazy value x (|x| < 16p) -> canonical 8x32 of (x * 2^256 * 2^-261) mod p = x / 32: back to gnark's form
     ZK_HD static Fp to32_div32(const Fp29& x) {
         Fp29 c256 = zero();
@@ -282,9 +296,8 @@ ZK_HD_NOINLINE XYZZ29T<F> xyzz29_dbl_affine(F x2, F y2) {
 //   X3 = R^2 - PPP - 2Q | D = Q - X3 < 5.8 | Y3 = R*D - Y1*PPP (real: one fused reduction)
 template <class F>
 ZK_HD void xyzz29_madd(XYZZ29T<F>& acc, const F& x2, const F& y2) {
-    if (acc.is_inf()) {
-        F one = F::one();
-        acc.x = F::mul(one, x2); acc.y = F::mul(one, y2); acc.zz = one; acc.zzz = one;
+    if (acc.is_inf()) {  // divergent whenever any lane of the wave starts a bucket: keep it free of products
+        acc.x = F::reduce32(x2); acc.y = F::reduce32(y2); acc.zz = F::one(); acc.zzz = acc.zz;
         return;
     }
     F U2 = F::mul(acc.zz, x2);
@@ -308,5 +321,28 @@ ZK_HD void xyzz29_madd(XYZZ29T<F>& acc, const F& x2, const F& y2) {
 }
 
 typedef XYZZ29T<Fp29> XYZZ29;
+
+// Raw accumulator image: the 4 x 9 signed limbs as they sit in registers (144 B, R' domain, lazily reduced; all-zero =
+// infinity).  The level-1 kernels park finished buckets in this form because the store sits on a divergent path
+// (some lane of a wave closes a bucket in ~half of all iterations): 36 plain stores instead of four domain changes.
+static constexpr int RAW29_WORDS = 36;
+ZK_HD void raw29_store(u32* dst, const XYZZ29& a) {
+    uint4* d = (uint4*)dst;
+    u32 w[36];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { w[i] = a.x.l[i]; w[9 + i] = a.y.l[i]; w[18 + i] = a.zz.l[i]; w[27 + i] = a.zzz.l[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+ZK_HD XYZZ29 raw29_load(const u32* src) {
+    const uint4* d = (const uint4*)src;
+    u32 w[36];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { uint4 q = d[i]; w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w; }
+    XYZZ29 a;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { a.x.l[i] = w[i]; a.y.l[i] = w[9 + i]; a.zz.l[i] = w[18 + i]; a.zzz.l[i] = w[27 + i]; }
+    return a;
+}
 
 }  // namespace zk

@@ -150,6 +150,7 @@ struct Fp2L29 {
     ZK_HD static Fp2L29 sub_n(const Fp2L29& x, const Fp2L29& y) { return {Fp29::sub_n(x.c, y.c)}; }
     ZK_HD static Fp2L29 neg(const Fp2L29& x) { return {Fp29::neg(x.c)}; }
     ZK_HD static Fp2L29 normed(const Fp2L29& x) { return {Fp29::normed(x.c)}; }
+    ZK_HD static Fp2L29 reduce32(const Fp2L29& x) { return {Fp29::reduce32(x.c)}; }
     // (a0 + a1 u)(b0 + b1 u): even lane a0*b0 + a1*(-b1), odd lane a1*b0 + a0*b1 — one fused double product each
     ZK_HD static Fp2L29 mul(const Fp2L29& x, const Fp2L29& y) {
         const bool od = odd();

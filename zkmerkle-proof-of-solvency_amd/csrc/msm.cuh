@@ -65,10 +65,13 @@ inline MsmCfg msm_cfg(zkpor_ctx* ctx, size_t n) {
 // ------------------------------------------------------------------------------------------------ launchers
 // defined next to the kernel instantiations (one translation unit per field / inlining policy)
 int32_t launch_decompose(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, u32* keys, u32* vals, u32* counter);
-int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L,
-                      XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part);
-int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L,
-                      XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part);
+int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L, u32 NB,
+                      XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part, void* raw);
+int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L, u32 NB,
+                      XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part, void* raw);
+// level 1 clears the buckets itself; `raw` = scratch for the 29-bit kernels' register images: raw_bytes<F>(NB, T1)
+template <class F>
+inline size_t raw_bytes(size_t NB, size_t T1) { return (NB + T1) * (sizeof(XYZZ<F>) / 32 * 36); }
 int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp>* src, u32 M, int L, XYZZ<Fp>* buckets,
                       u32* out_keys, XYZZ<Fp>* out_part);
 int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp2>* src, u32 M, int L, XYZZ<Fp2>* buckets,
@@ -136,6 +139,7 @@ inline size_t accumulate_ws_bytes(const MsmCfg& cfg, size_t max_entries) {
     size_t half = (size_t)cfg.NB / 2 + 1;
     p.add<XYZZ<F>>(half); p.add<XYZZ<F>>(half);              // S, Y of odd levels
     p.add<XYZZ<F>>(half / 2 + 1); p.add<XYZZ<F>>(half / 2 + 1);  // S, Y of even levels
+    p.add<char>(raw_bytes<F>(cfg.NB, T1));
     return p.total;
 }
 
@@ -166,13 +170,13 @@ inline int32_t msm_accumulate_launch(zkpor_ctx* ctx, const DigitStream& ds, cons
     size_t half = (size_t)cfg.NB / 2 + 1;
     XYZZ<F>* Sa = ws_alloc<XYZZ<F>>(ctx, half); XYZZ<F>* Ya = ws_alloc<XYZZ<F>>(ctx, half);
     XYZZ<F>* Sb = ws_alloc<XYZZ<F>>(ctx, half / 2 + 1); XYZZ<F>* Yb = ws_alloc<XYZZ<F>>(ctx, half / 2 + 1);
-    if (!buckets || !pa || !ka || !pb || !kb || !Sa || !Ya || !Sb || !Yb) {
+    char* raw = ws_alloc<char>(ctx, raw_bytes<F>(cfg.NB, T1));
+    if (!buckets || !pa || !ka || !pb || !kb || !Sa || !Ya || !Sb || !Yb || !raw) {
         ctx->err = "msm: workspace too small"; return ZKPOR_E_OOM;
     }
     {
         PhaseScope ps(ctx, "msm_accumulate");
-        ZK_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)cfg.NB * sizeof(XYZZ<F>), ctx->stream));
-        ZK_TRY(launch_level1(ctx, ds.keys, ds.vals, d_pts, M, L, buckets, ka, pa));
+        ZK_TRY(launch_level1(ctx, ds.keys, ds.vals, d_pts, M, L, (u32)cfg.NB, buckets, ka, pa, raw));
         size_t T = T1;
         XYZZ<F>* src = pa; u32* srck = ka; XYZZ<F>* dst = pb; u32* dstk = kb;
         while (T > 1) {

@@ -10,11 +10,14 @@ __device__ __forceinline__ void store29(XYZZ<Fp>* dst, const XYZZ29& a) {
     *dst = o;
 }
 
-// k_acc_level1<Fp> with the accumulator and all arithmetic on 9 x 29-bit limbs (fe29.cuh); memory format unchanged
+// k_acc_level1<Fp> with the accumulator and all arithmetic on 9 x 29-bit limbs (fe29.cuh).  Everything on the
+// divergent key-change path is a raw register image (raw29_store): finished buckets go to `braw` (converted to the
+// 8 x 32 bucket array by k_raw29_to_buckets afterwards), a chunk's head partial is parked in `hraw` and converted with
+// the tail partial at the end of the chunk, where all lanes of the wave take the same path.
 __global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__ keys, const u32* __restrict__ vals,
                                                          const Affine<Fp>* __restrict__ pts, u32 M, int L,
-                                                         XYZZ<Fp>* __restrict__ buckets, u32* __restrict__ out_keys,
-                                                         XYZZ<Fp>* __restrict__ out_part) {
+                                                         u32* __restrict__ braw, u32* __restrict__ hraw,
+                                                         u32* __restrict__ out_keys, XYZZ<Fp>* __restrict__ out_part) {
     __shared__ u32 sk[256 * ACC_PITCH];
     __shared__ u32 sv[256 * ACC_PITCH];
     const u32 row0 = blockIdx.x * 256u;
@@ -29,7 +32,7 @@ __global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__
     u32 cur = live ? keys[start] : NOKEY;
     const u32 first_key = cur;
     u32 last_key = cur;
-    bool first = true, head_written = false, tail_written = false;
+    bool first = true, head_written = false;
     const int nphase = (L + ACC_SUB - 1) / ACC_SUB;
     const u32 rows = (T - row0 < 256u) ? T - row0 : 256u;
     for (int ph = 0; ph < nphase; ++ph) {
@@ -43,8 +46,9 @@ __global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__
             const u32 k = sk[threadIdx.x * ACC_PITCH + (j - j0)];
             const u32 v = sv[threadIdx.x * ACC_PITCH + (j - j0)];
             if (k != cur) {
-                if (first && cur == prev) { store29(out_part + 2 * t, acc); head_written = true; }
-                else store29(buckets + cur, acc);
+                const bool head = first && cur == prev;
+                raw29_store(head ? hraw + (size_t)t * RAW29_WORDS : braw + (size_t)cur * RAW29_WORDS, acc);
+                head_written |= head;
                 first = false;
                 cur = k;
                 acc = XYZZ29::inf();
@@ -57,23 +61,46 @@ __global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__
         }
     }
     if (!live) return;
-    if (first && cur == prev) { store29(out_part + 2 * t, acc); head_written = true; }
-    else if (cur == next) { store29(out_part + 2 * t + 1, acc); tail_written = true; }
-    else store29(buckets + cur, acc);
+    // the chunk's last run: a head (the previous chunk ends in the same bucket), a tail (the next chunk starts in it) or complete
+    const bool acc_head = first && cur == prev;
+    const bool acc_tail = !acc_head && cur == next;
+    if (!acc_head && !acc_tail) raw29_store(braw + (size_t)cur * RAW29_WORDS, acc);
     if (T > 1) {
-        if (!head_written) out_part[2 * t] = XYZZ<Fp>::inf();
-        if (!tail_written) out_part[2 * t + 1] = XYZZ<Fp>::inf();
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {  // one copy of the conversion code
+            XYZZ29 v = XYZZ29::inf();
+            if (s == 0) {
+                if (head_written) v = raw29_load(hraw + (size_t)t * RAW29_WORDS);
+                else if (acc_head) v = acc;
+            } else if (acc_tail) v = acc;
+            store29(out_part + 2 * t + s, v);
+        }
         out_keys[2 * t] = first_key;
         out_keys[2 * t + 1] = last_key;
     }
 }
 
-int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L,
-                      XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part) {
+__global__ __launch_bounds__(256) void k_raw29_to_buckets(const u32* __restrict__ braw, XYZZ<Fp>* __restrict__ buckets, u32 NB) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= NB) return;
+    store29(buckets + i, raw29_load(braw + (size_t)i * RAW29_WORDS));
+}
+
+int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L, u32 NB,
+                      XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part, void* raw) {
     u32 T = (M + (u32)L - 1u) / (u32)L;
     PhaseScope ps(ctx, "k_acc_level1_g1");
-    if (ctx->g1_variant == 0) hipLaunchKernelGGL(k_acc_level1<Fp>, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
-    else hipLaunchKernelGGL(k_acc_level1_fp29, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
+    if (ctx->g1_variant == 0) {
+        ZK_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)NB * sizeof(XYZZ<Fp>), ctx->stream));
+        hipLaunchKernelGGL(k_acc_level1<Fp>, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
+    } else {
+        u32* braw = (u32*)raw;
+        u32* hraw = braw + (size_t)NB * RAW29_WORDS;
+        ZK_HIP(ctx, hipMemsetAsync(braw, 0, (size_t)NB * RAW29_WORDS * 4, ctx->stream));
+        hipLaunchKernelGGL(k_acc_level1_fp29, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, braw, hraw, out_keys, out_part);
+        ZK_KERNEL_CHECK(ctx);
+        hipLaunchKernelGGL(k_raw29_to_buckets, dim3((NB + 255u) / 256u), dim3(256), 0, ctx->stream, braw, buckets, NB);
+    }
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

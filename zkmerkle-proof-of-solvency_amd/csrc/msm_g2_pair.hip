@@ -85,10 +85,23 @@ __device__ __forceinline__ void lp_store29(XYZZ<Fp2>* dst, const XYZZ29T<Fp2L29>
     }
 }
 
+// raw register image of a lane-pair accumulator: each lane parks its own component (RAW29_WORDS words; pair = 288 B)
+__device__ __forceinline__ void lp_raw_store(u32* dst, const XYZZ29T<Fp2L29>& a, u32 par) {
+    XYZZ29 c = {a.x.c, a.y.c, a.zz.c, a.zzz.c};
+    raw29_store(dst + par * RAW29_WORDS, c);
+}
+__device__ __forceinline__ XYZZ29T<Fp2L29> lp_raw_load(const u32* src, u32 par) {
+    XYZZ29 c = raw29_load(src + par * RAW29_WORDS);
+    XYZZ29T<Fp2L29> a;
+    a.x.c = c.x; a.y.c = c.y; a.zz.c = c.zz; a.zzz.c = c.zzz;
+    return a;
+}
+
+// see k_acc_level1_fp29 (msm_g1_hot.hip) for the raw bucket / head-partial scheme
 __global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restrict__ keys, const u32* __restrict__ vals,
                                                              const Affine<Fp2>* __restrict__ pts, u32 M, int L,
-                                                             XYZZ<Fp2>* __restrict__ buckets, u32* __restrict__ out_keys,
-                                                             XYZZ<Fp2>* __restrict__ out_part) {
+                                                             u32* __restrict__ braw, u32* __restrict__ hraw,
+                                                             u32* __restrict__ out_keys, XYZZ<Fp2>* __restrict__ out_part) {
     __shared__ u32 sk[128 * ACC_PITCH];
     __shared__ u32 sv[128 * ACC_PITCH];
     typedef XYZZ29T<Fp2L29> Acc;
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restri
     u32 cur = live ? keys[start] : NOKEY;
     const u32 first_key = cur;
     u32 last_key = cur;
-    bool first = true, head_written = false, tail_written = false;
+    bool first = true, head_written = false;
     const int nphase = (L + ACC_SUB - 1) / ACC_SUB;
     const u32 rows = (T - row0 < 128u) ? T - row0 : 128u;
     for (int ph = 0; ph < nphase; ++ph) {
@@ -119,8 +132,9 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restri
             const u32 k = sk[lr * ACC_PITCH + (j - j0)];
             const u32 v = sv[lr * ACC_PITCH + (j - j0)];
             if (k != cur) {
-                if (first && cur == prev) { lp_store29(out_part + 2 * t, acc, par); head_written = true; }
-                else lp_store29(buckets + cur, acc, par);
+                const bool head = first && cur == prev;
+                lp_raw_store(head ? hraw + (size_t)t * (2 * RAW29_WORDS) : braw + (size_t)cur * (2 * RAW29_WORDS), acc, par);
+                head_written |= head;
                 first = false;
                 cur = k;
                 acc = Acc::inf();
@@ -140,18 +154,31 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restri
         }
     }
     if (!live) return;
-    if (first && cur == prev) { lp_store29(out_part + 2 * t, acc, par); head_written = true; }
-    else if (cur == next) { lp_store29(out_part + 2 * t + 1, acc, par); tail_written = true; }
-    else lp_store29(buckets + cur, acc, par);
+    const bool acc_head = first && cur == prev;
+    const bool acc_tail = !acc_head && cur == next;
+    if (!acc_head && !acc_tail) lp_raw_store(braw + (size_t)cur * (2 * RAW29_WORDS), acc, par);
     if (T > 1) {
-        Acc z = Acc::inf();
-        if (!head_written) lp_store29(out_part + 2 * t, z, par);
-        if (!tail_written) lp_store29(out_part + 2 * t + 1, z, par);
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            Acc v = Acc::inf();
+            if (s == 0) {
+                if (head_written) v = lp_raw_load(hraw + (size_t)t * (2 * RAW29_WORDS), par);
+                else if (acc_head) v = acc;
+            } else if (acc_tail) v = acc;
+            lp_store29(out_part + 2 * t + s, v, par);
+        }
         if (par == 0) {
             out_keys[2 * t] = first_key;
             out_keys[2 * t + 1] = last_key;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_raw29_to_buckets_g2pair(const u32* __restrict__ braw, XYZZ<Fp2>* __restrict__ buckets, u32 NB) {
+    const u32 gt = blockIdx.x * 256u + threadIdx.x;
+    const u32 i = gt >> 1, par = gt & 1u;
+    if (i >= NB) return;
+    lp_store29(buckets + i, lp_raw_load(braw + (size_t)i * (2 * RAW29_WORDS), par), par);
 }
 
 __device__ __forceinline__ XYZZ<Fp2L> lp_load(const XYZZ<Fp2>* src, u32 par) {
@@ -247,12 +274,21 @@ int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp2>* Sin, const XYZZ<Fp2>* Yin
     return ZKPOR_OK;
 }
 
-int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L,
-                      XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part) {
+int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L, u32 NB,
+                      XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part, void* raw) {
     u32 T = (M + (u32)L - 1u) / (u32)L;
     PhaseScope ps(ctx, "k_acc_level1_g2");
-    if (ctx->g2_variant == 0) hipLaunchKernelGGL(k_acc_level1_g2pair, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
-    else hipLaunchKernelGGL(k_acc_level1_g2pair29, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
+    if (ctx->g2_variant == 0) {
+        ZK_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)NB * sizeof(XYZZ<Fp2>), ctx->stream));
+        hipLaunchKernelGGL(k_acc_level1_g2pair, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
+    } else {
+        u32* braw = (u32*)raw;
+        u32* hraw = braw + (size_t)NB * (2 * RAW29_WORDS);
+        ZK_HIP(ctx, hipMemsetAsync(braw, 0, (size_t)NB * (2 * RAW29_WORDS) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_acc_level1_g2pair29, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, braw, hraw, out_keys, out_part);
+        ZK_KERNEL_CHECK(ctx);
+        hipLaunchKernelGGL(k_raw29_to_buckets_g2pair, dim3((2u * NB + 255u) / 256u), dim3(256), 0, ctx->stream, braw, buckets, NB);
+    }
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
