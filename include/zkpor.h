@@ -157,6 +157,32 @@ int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n,
 /* device-resident leaves in Montgomery form (n x 32 B), root returned in Montgomery form: the bench path */
 int32_t zkpor_merkle_build_dev(zkpor_ctx* ctx, const void* d_leaves_mont, size_t n, int depth,
                                const uint64_t nil_leaf_mont[4], uint64_t root_mont[4]);
+/* ---- FixedDepthMerkleTree (reference src/utils/merkletree/merkletree.go:27-52), resident in HBM ----
+ * The two-phase usage of the reference: Set leaves (no hashing), Build (all internal nodes above a set leaf), then
+ * Root / Get / GetProof.  Hashes cross the boundary as 32-byte big-endian canonical Fr, as the reference holds them.
+ * Hasher = poseidon.NewPoseidon (the only one the reference passes: account_tree.go:14-23). */
+typedef struct zkpor_tree zkpor_tree;
+/* NewFixedDepthMerkleTree (:137-176): depth in [1,32], capacity <= 2^depth (ZKPOR_E_ARG where the reference panics) */
+int32_t zkpor_tree_create(zkpor_ctx* ctx, int depth, const uint8_t nil_leaf[32], uint64_t capacity, zkpor_tree** out);
+void zkpor_tree_destroy(zkpor_tree* tree);
+/* nilHashes[level] (:159-170), level in [0, depth] */
+int32_t zkpor_tree_nil_hash(zkpor_tree* tree, int level, uint8_t out[32]);
+/* Set (:179-187) for n keys at once; a key >= capacity fails the whole call with ZKPOR_E_ARG and stores nothing */
+int32_t zkpor_tree_set(zkpor_tree* tree, const uint32_t* keys, const uint8_t* values32_be, size_t n);
+/* Set of the contiguous keys first_key .. first_key+n-1 from device-resident Montgomery leaves (zkpor_poseidon_leaves
+ * output kept on the device, or the bench's synthetic leaves); asynchronous on the context's stream */
+int32_t zkpor_tree_set_range_dev(zkpor_tree* tree, uint64_t first_key, const void* d_leaves_mont, size_t n);
+/* Build (:192-279) */
+int32_t zkpor_tree_build(zkpor_tree* tree);
+/* Root (:282-284): reflects the last Build */
+int32_t zkpor_tree_root(zkpor_tree* tree, uint8_t out[32]);
+/* Get (:287-294) for n keys: the stored value, or nilHashes[0] for unset / out-of-capacity keys; out: n x 32 B */
+int32_t zkpor_tree_get(zkpor_tree* tree, const uint32_t* keys, size_t n, uint8_t* out32);
+/* GetProof (:297-308) for n keys: out = n x depth x 32 B, leaf-level sibling first; key >= 2^depth is ZKPOR_E_ARG */
+int32_t zkpor_tree_get_proofs(zkpor_tree* tree, const uint32_t* keys, size_t n, uint8_t* out);
+/* VerifyProof (:334-355) for n (key, leaf, proof) triples against one root; ok_out[i] = 1 / 0 */
+int32_t zkpor_merkle_verify_proofs(zkpor_ctx* ctx, const uint8_t root[32], const uint32_t* keys, const uint8_t* proofs,
+                                   const uint8_t* leaves32_be, size_t n, int depth, uint8_t* ok_out);
 /* poseidon.Poseidon(inputs...) for `count` independent inputs of `len` elements each (Montgomery Fr in/out) */
 int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, size_t count, uint64_t* out);
 

@@ -210,6 +210,22 @@ void orc_merkle_build(const Fr* leaves, size_t n, int depth, const Fr* nil_leaf,
     if (nil_out) memcpy(nil_out, t.nil.data(), (depth + 1) * sizeof(Fr));
     *root_out = t.root;
 }
+// sparse tree: set n (key, leaf) pairs, Build, then proofs (nq x depth) for query keys, root and optional verification
+void orc_sparse_tree(const uint32_t* keys, const Fr* leaves, size_t n, int depth, const Fr* nil_leaf,
+                     const uint32_t* qkeys, size_t nq, Fr* proofs_out, Fr* root_out) {
+    SparseMerkleTree t(depth, *nil_leaf);
+    for (size_t i = 0; i < n; ++i) t.set(keys[i], leaves[i]);
+    t.build();
+    for (size_t i = 0; i < nq; ++i) {
+        std::vector<Fr> p = t.proof(qkeys[i]);
+        memcpy(proofs_out + i * depth, p.data(), depth * sizeof(Fr));
+    }
+    *root_out = t.root;
+}
+int orc_merkle_verify(const Fr* root, uint32_t key, const Fr* proof, int depth, const Fr* leaf) {
+    std::vector<Fr> p(proof, proof + depth);
+    return merkle_verify(*root, key, p, *leaf) ? 1 : 0;
+}
 void orc_fr_to_be(const Fr* a, uint8_t* out, size_t n) { for (size_t i = 0; i < n; ++i) a[i].to_be_bytes(out + 32 * i); }
 void orc_fr_from_be(const uint8_t* in, Fr* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = Fr::from_be_bytes(in + 32 * i, 32); }
 

@@ -278,6 +278,22 @@ def merkle_build(leaves, depth, nil_leaf, want_levels=False):
     return root, nil, levels
 
 
+def sparse_tree(keys, leaves, depth, nil_leaf, query_keys):
+    """(root, proofs[nq, depth, 4]) of the tree with `leaves` Set at `keys` (merkletree.go Set/Build/GetProof)"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint32); leaves = _u64(leaves).reshape(-1, 4)
+    q = np.ascontiguousarray(query_keys, dtype=np.uint32)
+    proofs = np.empty((q.shape[0], depth, 4), dtype=np.uint64)
+    root = np.empty((4,), dtype=np.uint64)
+    lib().orc_sparse_tree(_p(keys), _p(leaves), ctypes.c_size_t(keys.shape[0]), ctypes.c_int(depth), _p(_u64(nil_leaf)),
+                          _p(q), ctypes.c_size_t(q.shape[0]), _p(proofs), _p(root))
+    return root, proofs
+
+
+def merkle_verify(root, key, proof, leaf):
+    proof = _u64(proof).reshape(-1, 4)
+    return bool(lib().orc_merkle_verify(_p(_u64(root)), ctypes.c_uint32(key), _p(proof), ctypes.c_int(proof.shape[0]), _p(_u64(leaf))))
+
+
 def fr_to_be(a):
     a = _u64(a).reshape(-1, 4); out = np.empty((a.shape[0], 32), dtype=np.uint8)
     lib().orc_fr_to_be(_p(a), _p(out), ctypes.c_size_t(a.shape[0]))

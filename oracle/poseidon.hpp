@@ -256,6 +256,42 @@ static inline MerkleTree merkle_build(const Fr* leaves, size_t n, int depth, con
     t.root = t.node(depth, 0);
     return t;
 }
+// The same tree with arbitrary (sparse) keys set — merkletree.go Set (:179-187), Build over the dirty positions only
+// (:192-279), getNodeAt falling back to nilHashes for clean positions (:315-331).  Maps instead of flat buffers +
+// bitsets: the oracle only has to agree on values.
+struct SparseMerkleTree {
+    int depth;
+    std::vector<Fr> nil;
+    std::vector<std::map<uint64_t, Fr>> levels;  // levels[0] = set leaves
+    Fr root;
+    SparseMerkleTree(int d, const Fr& nil_leaf) : depth(d), nil(d + 1), levels(d + 1) {
+        nil[0] = nil_leaf;
+        for (int l = 1; l <= d; ++l) nil[l] = hash2(nil[l - 1], nil[l - 1]);
+        root = nil[d];
+    }
+    void set(uint32_t key, const Fr& v) { levels[0][key] = v; }
+    const Fr& node(int level, uint64_t pos) const {
+        auto it = levels[level].find(pos);
+        return it == levels[level].end() ? nil[level] : it->second;
+    }
+    void build() {
+        for (int l = 1; l <= depth; ++l) {
+            levels[l].clear();
+            for (auto& kv : levels[l - 1]) {
+                uint64_t p = kv.first >> 1;
+                if (levels[l].count(p)) continue;
+                levels[l][p] = hash2(node(l - 1, 2 * p), node(l - 1, 2 * p + 1));
+            }
+        }
+        root = node(depth, 0);
+    }
+    std::vector<Fr> proof(uint32_t key) const {
+        std::vector<Fr> p(depth);
+        uint64_t pos = key;
+        for (int l = 0; l < depth; ++l) { p[l] = node(l, pos ^ 1); pos >>= 1; }
+        return p;
+    }
+};
 static inline bool merkle_verify(const Fr& root, uint32_t key, const std::vector<Fr>& proof, const Fr& leaf) {
     Fr node = leaf;
     for (size_t i = 0; i < proof.size(); ++i)

@@ -448,25 +448,182 @@ static int32_t pos_dev(zkpor_ctx* ctx, PosDev* P) {
     return ZKPOR_OK;
 }
 
-// host copy of the 2->1 hash (nil-subtree chain; 28 evaluations per tree)
-static Fr host_hash2(const PosTables& T, const PosDev& P, const Fr& l, const Fr& r) {
-    Fr s0 = Fr::zero(), s1 = l, s2 = r;
-    const Fr* h = T.host.data();
-    PermTab pt = {h + T.rc_off[3], h + T.mds_off[3], h + T.prc_off[3], h + T.sp_off[3], h + T.post_off[3]};
-    permute3(s0, s1, s2, pt);
-    return P.out_idx == 0 ? s0 : s1;
+// ------------------------------------------------------------------------------------------------------------------
+// FixedDepthMerkleTree on the device (reference src/utils/merkletree/merkletree.go:27-52): leaves and every internal
+// level live in HBM in Montgomery form next to one "dirty" bitset per level; a clean position reads as nilHashes[level]
+// exactly as getNodeAt (:315-331) does.  Set (:179-187) only stores leaves and marks them; Build (:192-279) recomputes
+// every node that has a set leaf beneath it (the reference never clears its dirty bits either, so repeated
+// Set -> Build cycles give the same tree in both).
+struct TreeDev {
+    Fr* nodes[33];     // nodes[0] = leaves
+    u32* dirty[33];    // bitset, one bit per position of the level
+    u32 cnt[33];       // positions backed by memory at each level (ceil(capacity / 2^l)); cnt == 0 -> 2^32 leaves
+    const Fr* nil;     // nil[0..depth]
+    int depth;
+};
+ZK_D bool tree_bit(const u32* bs, u64 i) { return (bs[i >> 5] >> (i & 31)) & 1u; }
+ZK_D Fr tree_node(const TreeDev& T, int level, u64 pos, u64 count) {
+    return (pos < count && tree_bit(T.dirty[level], pos)) ? T.nodes[level][pos] : T.nil[level];
 }
 
+// nil[l] = H(nil[l-1], nil[l-1]), l = 1..depth (merkletree.go:159-170); one thread: 32 permutations at most
+__global__ void k_tree_nil_chain(Fr* nil, int depth, PosDev P) {
+    if (threadIdx.x || blockIdx.x) return;
+    for (int l = 1; l <= depth; ++l) {
+        Fr s0 = Fr::zero(), s1 = nil[l - 1], s2 = nil[l - 1];
+        permute3(s0, s1, s2, P.tabs(3));
+        nil[l] = P.out_idx == 0 ? s0 : s1;
+    }
+}
+// Set for a batch of (key, 32-byte big-endian value) pairs; later entries win for duplicate keys only by race, as in the
+// reference (concurrent Set of one key is undefined there too)
+__global__ void k_tree_set(TreeDev T, const u32* __restrict__ keys, const uint8_t* __restrict__ vals, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 k = keys[i];
+    T.nodes[0][k] = from_be32(vals + 32 * i);
+    atomicOr(&T.dirty[0][k >> 5], 1u << (k & 31));
+}
+// Set of a contiguous key range from device-resident Montgomery leaves
+__global__ void k_tree_set_range(TreeDev T, u64 first, const Fr* __restrict__ vals, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 k = first + i;
+    T.nodes[0][k] = vals[i];
+    atomicOr(&T.dirty[0][k >> 5], 1u << (k & 31));
+}
+// one level of Build: node p of `level` is recomputed iff child 2p or 2p+1 is dirty; its dirty bit is (re)written by a
+// wave-wide ballot, so the bitset needs no clearing pass.  Block = 256 consecutive positions.
+__global__ __launch_bounds__(256) void k_tree_level(TreeDev T, int level, u64 count, u64 child_count, PosDev P) {
+    const u64 p = (u64)blockIdx.x * 256u + threadIdx.x;
+    bool d = false;
+    Fr l, r;
+    if (p < count) {
+        const bool dl = 2 * p < child_count && tree_bit(T.dirty[level - 1], 2 * p);
+        const bool dr = 2 * p + 1 < child_count && tree_bit(T.dirty[level - 1], 2 * p + 1);
+        d = dl | dr;
+        if (d) {
+            l = dl ? T.nodes[level - 1][2 * p] : T.nil[level - 1];
+            r = dr ? T.nodes[level - 1][2 * p + 1] : T.nil[level - 1];
+        }
+    }
+    const u64 mask = __ballot(d);
+    const u64 wave_first = p & ~(u64)63;
+    if ((threadIdx.x & 63u) == 0 && wave_first < count) {
+        T.dirty[level][wave_first >> 5] = (u32)mask;
+        if (wave_first + 32 < count) T.dirty[level][(wave_first >> 5) + 1] = (u32)(mask >> 32);
+    }
+    if (!d) return;
+    Fr s0 = Fr::zero();
+    permute3(s0, l, r, P.tabs(3));
+    T.nodes[level][p] = P.out_idx == 0 ? s0 : l;
+}
+// GetProof (:297-308) for n keys: out[(i * depth + level) * 32 ...] = sibling at `level`, big-endian
+__global__ void k_tree_proofs(TreeDev T, const u32* __restrict__ keys, size_t n, uint8_t* __restrict__ out) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * (size_t)T.depth) return;
+    const int level = (int)(g % T.depth);
+    const u64 pos = ((u64)keys[g / T.depth] >> level) ^ 1u;
+    const u64 count = T.cnt[level] ? T.cnt[level] : ((u64)1 << 32);
+    Fr c = Fr::from_mont(tree_node(T, level, pos, count));
+    u32* o = (u32*)(out + 32 * g);
+    for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(c.v[7 - j]);
+}
+// Get (:287-294) for n keys
+__global__ void k_tree_get(TreeDev T, const u32* __restrict__ keys, size_t n, uint8_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 count = T.cnt[0] ? T.cnt[0] : ((u64)1 << 32);
+    Fr c = Fr::from_mont(tree_node(T, 0, keys[i], count));
+    u32* o = (u32*)(out + 32 * i);
+    for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(c.v[7 - j]);
+}
+// VerifyProof (:334-355) for n independent (key, leaf, proof) triples against one root
+__global__ __launch_bounds__(64) void k_verify_proofs(const uint8_t* __restrict__ root, const u32* __restrict__ keys,
+                                                      const uint8_t* __restrict__ proofs, const uint8_t* __restrict__ leaves,
+                                                      size_t n, int depth, uint8_t* __restrict__ ok, PosDev P) {
+    size_t i = (size_t)blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    Fr node = from_be32(leaves + 32 * i);
+    const u32 key = keys[i];
+    for (int l = 0; l < depth; ++l) {
+        Fr sib = from_be32(proofs + 32 * (i * depth + l));
+        Fr s0 = Fr::zero(), s1, s2;
+        if ((key >> l) & 1u) { s1 = sib; s2 = node; } else { s1 = node; s2 = sib; }
+        permute3(s0, s1, s2, P.tabs(3));
+        node = P.out_idx == 0 ? s0 : s1;
+    }
+    Fr want = from_be32(root);
+    bool eq = true;
+    for (int j = 0; j < 8; ++j) eq &= node.v[j] == want.v[j];
+    ok[i] = eq && (depth >= 32 || (key >> depth) == 0) ? 1 : 0;
+}
+
+
+}  // namespace zk
+
+// the handle behind zkpor_tree_* (include/zkpor.h)
+struct zkpor_tree {
+    zkpor_ctx* ctx = nullptr;
+    int depth = 0;
+    uint64_t capacity = 0;
+    uint64_t count[33] = {0};
+    zk::TreeDev dev;
+    zk::Fr* nil_dev = nullptr;
+    zk::Fr nil_host[33];
+    zk::Fr root;
+    std::vector<void*> allocs;
+};
+
+namespace zk {
+
+static void tree_free(zkpor_tree* t) {
+    for (void* p : t->allocs) (void)hipFree(p);
+    delete t;
+}
+template <class T>
+static int32_t tree_alloc(zkpor_tree* t, size_t count, T** out, bool zero) {
+    zkpor_ctx* ctx = t->ctx;
+    void* p = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); ctx->err = "tree: out of device memory"; return ZKPOR_E_OOM; }
+    t->allocs.push_back(p);
+    if (zero) ZK_HIP(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
+    *out = (T*)p;
+    return ZKPOR_OK;
+}
+// staging helper: copy host bytes to a temporary device buffer
+struct DevTmp {
+    void* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    int32_t put(zkpor_ctx* ctx, const void* src, size_t bytes) {
+        ZK_HIP(ctx, hipMalloc(&p, bytes ? bytes : 1));
+        if (bytes) ZK_HIP(ctx, hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return ZKPOR_OK;
+    }
+    int32_t make(zkpor_ctx* ctx, size_t bytes) { ZK_HIP(ctx, hipMalloc(&p, bytes ? bytes : 1)); return ZKPOR_OK; }
+};
+static void fr_to_be_host(const Fr& m, uint8_t out[32]) {
+    Fr c = Fr::from_mont(m);
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) out[31 - (i * 4 + j)] = (uint8_t)(c.v[i] >> (8 * j));
+}
 // tree over d_leaves[0..n) (Montgomery); d_levels (optional) receives levels 1..depth concatenated
 static int32_t merkle_build_core(zkpor_ctx* ctx, const Fr* d_leaves, size_t n, int depth, const Fr& nil_leaf,
                                  Fr* d_levels, Fr* root) {
     if (depth < 1 || depth > 32 || n > ((size_t)1 << depth)) { ctx->err = "merkle: bad depth / leaf count"; return ZKPOR_E_ARG; }
     PosDev P;
     ZK_TRY(pos_dev(ctx, &P));
-    PosTables* T = (PosTables*)ctx->pos_tables;
+    // nil-subtree chain (merkletree.go:159-170), hashed on the device like everything else
     std::vector<Fr> nil(depth + 1);
-    nil[0] = nil_leaf;
-    for (int l = 1; l <= depth; ++l) nil[l] = host_hash2(*T, P, nil[l - 1], nil[l - 1]);
+    {
+        DevTmp dn;
+        ZK_TRY(dn.make(ctx, 33 * sizeof(Fr)));
+        ZK_HIP(ctx, hipMemcpyAsync(dn.p, &nil_leaf, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_tree_nil_chain, dim3(1), dim3(64), 0, ctx->stream, (Fr*)dn.p, depth, P);
+        ZK_KERNEL_CHECK(ctx);
+        ZK_HIP(ctx, hipMemcpyAsync(nil.data(), dn.p, (depth + 1) * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (n == 0) { *root = nil[depth]; return ZKPOR_OK; }
     PhaseScope ps(ctx, "poseidon_tree");
     // ping-pong buffers when the caller does not want the levels
@@ -496,12 +653,12 @@ static int32_t merkle_build_core(zkpor_ctx* ctx, const Fr* d_leaves, size_t n, i
     return ZKPOR_OK;
 }
 
+
 static size_t levels_total(size_t n, int depth) {
     size_t tot = 0, m = n;
     for (int l = 1; l <= depth; ++l) { m = (m + 1) / 2; tot += m; }
     return tot;
 }
-
 }  // namespace zk
 
 using namespace zk;
@@ -594,6 +751,149 @@ int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n,
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dbe); (void)hipFree(dleaves); if (dlev) (void)hipFree(dlev);
     return rc;
+}
+
+// ---- FixedDepthMerkleTree -------------------------------------------------------------------------------------------
+int32_t zkpor_tree_create(zkpor_ctx* ctx, int depth, const uint8_t nil_leaf[32], uint64_t capacity, zkpor_tree** out) {
+    if (!ctx || !nil_leaf || !out) return ZKPOR_E_ARG;
+    // NewFixedDepthMerkleTree panics on these (merkletree.go:138-146); here they are argument errors
+    if (depth <= 0 || depth > 32) { ctx->err = "tree: depth must be in [1,32]"; return ZKPOR_E_ARG; }
+    if (capacity > ((uint64_t)1 << depth)) { ctx->err = "tree: capacity exceeds maximum for given depth"; return ZKPOR_E_ARG; }
+    PosDev P;
+    ZK_TRY(pos_dev(ctx, &P));
+    zkpor_tree* t = new zkpor_tree();
+    t->ctx = ctx; t->depth = depth; t->capacity = capacity;
+    uint64_t m = capacity;
+    int32_t rc = ZKPOR_OK;
+    for (int l = 0; l <= depth && rc == ZKPOR_OK; ++l) {
+        t->count[l] = m;
+        t->dev.cnt[l] = (u32)m;  // 2^32 wraps to 0, which the kernels read as 2^32
+        rc = tree_alloc<Fr>(t, m, &t->dev.nodes[l], false);
+        if (rc == ZKPOR_OK) rc = tree_alloc<u32>(t, (m + 31) / 32 + 2, &t->dev.dirty[l], true);
+        m = (m + 1) / 2;
+    }
+    if (rc == ZKPOR_OK) rc = tree_alloc<Fr>(t, 33, &t->nil_dev, true);
+    if (rc != ZKPOR_OK) { tree_free(t); return rc; }
+    t->dev.nil = t->nil_dev; t->dev.depth = depth;
+    Fr nil0 = from_be32(nil_leaf);
+    if (hipMemcpyAsync(t->nil_dev, &nil0, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "tree: H2D failed"; tree_free(t); return ZKPOR_E_HIP; }
+    hipLaunchKernelGGL(k_tree_nil_chain, dim3(1), dim3(64), 0, ctx->stream, t->nil_dev, depth, P);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(t->nil_host, t->nil_dev, 33 * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "tree: nil-hash chain failed"; tree_free(t); return ZKPOR_E_HIP; }
+    t->root = t->nil_host[depth];  // root of the empty tree (:172)
+    *out = t;
+    return ZKPOR_OK;
+}
+void zkpor_tree_destroy(zkpor_tree* t) {
+    if (!t) return;
+    (void)hipStreamSynchronize(t->ctx->stream);
+    tree_free(t);
+}
+int32_t zkpor_tree_nil_hash(zkpor_tree* t, int level, uint8_t out[32]) {
+    if (!t || !out || level < 0 || level > t->depth) return ZKPOR_E_ARG;
+    fr_to_be_host(t->nil_host[level], out);
+    return ZKPOR_OK;
+}
+int32_t zkpor_tree_set(zkpor_tree* t, const uint32_t* keys, const uint8_t* values32_be, size_t n) {
+    if (!t || (n && (!keys || !values32_be))) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = t->ctx;
+    for (size_t i = 0; i < n; ++i)
+        if ((uint64_t)keys[i] >= t->capacity) {  // Set's error return (:180-182); nothing is stored
+            ctx->err = "tree: key " + std::to_string(keys[i]) + " out of range for capacity " + std::to_string(t->capacity);
+            return ZKPOR_E_ARG;
+        }
+    if (n == 0) return ZKPOR_OK;
+    DevTmp dk, dv;
+    ZK_TRY(dk.put(ctx, keys, n * 4));
+    ZK_TRY(dv.put(ctx, values32_be, n * 32));
+    hipLaunchKernelGGL(k_tree_set, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, t->dev, (const u32*)dk.p, (const uint8_t*)dv.p, n);
+    ZK_KERNEL_CHECK(ctx);
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+}
+int32_t zkpor_tree_set_range_dev(zkpor_tree* t, uint64_t first_key, const void* d_leaves_mont, size_t n) {
+    if (!t || (n && !d_leaves_mont)) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = t->ctx;
+    if (first_key + n > t->capacity) { ctx->err = "tree: key range exceeds capacity"; return ZKPOR_E_ARG; }
+    if (n == 0) return ZKPOR_OK;
+    hipLaunchKernelGGL(k_tree_set_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, t->dev, (u64)first_key, (const Fr*)d_leaves_mont, n);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+int32_t zkpor_tree_build(zkpor_tree* t) {
+    if (!t) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = t->ctx;
+    PosDev P;
+    ZK_TRY(pos_dev(ctx, &P));
+    {
+        PhaseScope ps(ctx, "poseidon_tree");
+        for (int l = 1; l <= t->depth; ++l) {
+            uint64_t cnt = t->count[l];
+            if (cnt == 0) break;
+            hipLaunchKernelGGL(k_tree_level, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, t->dev, l, (u64)cnt, (u64)t->count[l - 1], P);
+            ZK_KERNEL_CHECK(ctx);
+        }
+    }
+    // root: the top node if anything beneath it was ever set, else the nil hash (:268-274)
+    Fr top; u32 bit = 0;
+    if (t->count[t->depth]) {
+        ZK_HIP(ctx, hipMemcpyAsync(&top, t->dev.nodes[t->depth], sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(ctx, hipMemcpyAsync(&bit, t->dev.dirty[t->depth], 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    t->root = (bit & 1u) ? top : t->nil_host[t->depth];
+    return ZKPOR_OK;
+}
+int32_t zkpor_tree_root(zkpor_tree* t, uint8_t out[32]) {
+    if (!t || !out) return ZKPOR_E_ARG;
+    fr_to_be_host(t->root, out);
+    return ZKPOR_OK;
+}
+static int32_t tree_query(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out, bool proofs) {
+    zkpor_ctx* ctx = t->ctx;
+    if (n == 0) return ZKPOR_OK;
+    const size_t per = proofs ? (size_t)t->depth * 32 : 32;
+    DevTmp dk, dout;
+    ZK_TRY(dk.put(ctx, keys, n * 4));
+    ZK_TRY(dout.make(ctx, n * per));
+    size_t threads = proofs ? n * (size_t)t->depth : n;
+    if (proofs) hipLaunchKernelGGL(k_tree_proofs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, t->dev, (const u32*)dk.p, n, (uint8_t*)dout.p);
+    else hipLaunchKernelGGL(k_tree_get, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, t->dev, (const u32*)dk.p, n, (uint8_t*)dout.p);
+    ZK_KERNEL_CHECK(ctx);
+    ZK_HIP(ctx, hipMemcpyAsync(out, dout.p, n * per, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+}
+int32_t zkpor_tree_get(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out32) {
+    if (!t || (n && (!keys || !out32))) return ZKPOR_E_ARG;
+    return tree_query(t, keys, n, out32, false);  // keys >= capacity read as nil (:288-290)
+}
+int32_t zkpor_tree_get_proofs(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out) {
+    if (!t || (n && (!keys || !out))) return ZKPOR_E_ARG;
+    for (size_t i = 0; i < n; ++i)
+        if (t->depth < 32 && ((uint64_t)keys[i] >> t->depth) != 0) {  // GetProof's error return (:298-300)
+            t->ctx->err = "tree: key " + std::to_string(keys[i]) + " out of range for tree depth " + std::to_string(t->depth);
+            return ZKPOR_E_ARG;
+        }
+    return tree_query(t, keys, n, out, true);
+}
+int32_t zkpor_merkle_verify_proofs(zkpor_ctx* ctx, const uint8_t root[32], const uint32_t* keys, const uint8_t* proofs,
+                                   const uint8_t* leaves32_be, size_t n, int depth, uint8_t* ok_out) {
+    if (!ctx || !root || (n && (!keys || !proofs || !leaves32_be || !ok_out))) return ZKPOR_E_ARG;
+    if (depth < 1 || depth > 32) { ctx->err = "merkle: bad depth"; return ZKPOR_E_ARG; }
+    if (n == 0) return ZKPOR_OK;
+    PosDev P;
+    ZK_TRY(pos_dev(ctx, &P));
+    DevTmp dr, dk, dp, dl, dok;
+    ZK_TRY(dr.put(ctx, root, 32)); ZK_TRY(dk.put(ctx, keys, n * 4));
+    ZK_TRY(dp.put(ctx, proofs, n * (size_t)depth * 32)); ZK_TRY(dl.put(ctx, leaves32_be, n * 32));
+    ZK_TRY(dok.make(ctx, n));
+    hipLaunchKernelGGL(k_verify_proofs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)dr.p, (const u32*)dk.p,
+                       (const uint8_t*)dp.p, (const uint8_t*)dl.p, n, depth, (uint8_t*)dok.p, P);
+    ZK_KERNEL_CHECK(ctx);
+    ZK_HIP(ctx, hipMemcpyAsync(ok_out, dok.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
 }
 
 }  // extern "C"

@@ -348,3 +348,89 @@ Context.poseidon_hash = _poseidon_hash
 Context.poseidon_leaves = _poseidon_leaves
 Context.merkle_build = _merkle_build
 Context.merkle_build_dev = _merkle_build_dev
+
+
+class FixedDepthMerkleTree:
+    """Mirror of the reference's merkletree.FixedDepthMerkleTree (src/utils/merkletree/merkletree.go:27-52) over the
+    device-resident tree of libzkpor: same method names, same two-phase Set -> Build -> GetProof/Root usage, hashes as
+    32-byte big-endian `bytes`.  The hasher is fixed to poseidon.NewPoseidon (account_tree.go:14-23).  Where the
+    reference panics (constructor) or returns an error (Set, GetProof) this raises ZkporError."""
+
+    def __init__(self, ctx, depth, nil_leaf_hash, capacity):
+        self.ctx = ctx
+        self.depth = depth
+        self.capacity = capacity
+        nil = np.frombuffer(bytes(nil_leaf_hash), dtype=np.uint8)
+        if nil.shape[0] != 32:
+            raise ZkporError("nil leaf hash must be 32 bytes")
+        h = ctypes.c_void_p()
+        ctx._ck(ctx.lib.zkpor_tree_create(ctx.h, ctypes.c_int(depth), _p(nil), ctypes.c_uint64(capacity), ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.zkpor_tree_destroy(self.h)
+            self.h = None
+
+    def nil_hash(self, level):
+        out = np.empty(32, dtype=np.uint8)
+        self.ctx._ck(self.ctx.lib.zkpor_tree_nil_hash(self.h, ctypes.c_int(level), _p(out)))
+        return out.tobytes()
+
+    def set(self, key, value):
+        self.set_many([key], np.frombuffer(bytes(value), dtype=np.uint8))
+
+    def set_many(self, keys, values_be):
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        values_be = np.ascontiguousarray(values_be, dtype=np.uint8).reshape(-1, 32)
+        assert values_be.shape[0] == keys.shape[0]
+        self.ctx._ck(self.ctx.lib.zkpor_tree_set(self.h, _p(keys), _p(values_be), ctypes.c_size_t(keys.shape[0])))
+
+    def set_range_dev(self, first_key, d_leaves_mont, n):
+        self.ctx._ck(self.ctx.lib.zkpor_tree_set_range_dev(self.h, ctypes.c_uint64(first_key), ctypes.c_void_p(d_leaves_mont), ctypes.c_size_t(n)))
+
+    def build(self):
+        self.ctx._ck(self.ctx.lib.zkpor_tree_build(self.h))
+
+    def root(self):
+        out = np.empty(32, dtype=np.uint8)
+        self.ctx._ck(self.ctx.lib.zkpor_tree_root(self.h, _p(out)))
+        return out.tobytes()
+
+    def get_many(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        out = np.empty((keys.shape[0], 32), dtype=np.uint8)
+        self.ctx._ck(self.ctx.lib.zkpor_tree_get(self.h, _p(keys), ctypes.c_size_t(keys.shape[0]), _p(out)))
+        return out
+
+    def get(self, key):
+        return self.get_many([key])[0].tobytes()
+
+    def get_proofs(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        out = np.empty((keys.shape[0], self.depth, 32), dtype=np.uint8)
+        self.ctx._ck(self.ctx.lib.zkpor_tree_get_proofs(self.h, _p(keys), ctypes.c_size_t(keys.shape[0]), _p(out)))
+        return out
+
+    def get_proof(self, key):
+        return [p.tobytes() for p in self.get_proofs([key])[0]]
+
+
+def verify_proofs(ctx, root, keys, proofs, leaves_be, depth):
+    """merkletree.VerifyProof (merkletree.go:334-355) for a batch; returns a bool array"""
+    root = np.frombuffer(bytes(root), dtype=np.uint8)
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    proofs = np.ascontiguousarray(proofs, dtype=np.uint8).reshape(keys.shape[0], -1)
+    if proofs.shape[1] != depth * 32:
+        return np.zeros(keys.shape[0], dtype=bool)  # len(proof) != depth
+    leaves_be = np.ascontiguousarray(leaves_be, dtype=np.uint8).reshape(-1, 32)
+    ok = np.zeros(keys.shape[0], dtype=np.uint8)
+    ctx._ck(ctx.lib.zkpor_merkle_verify_proofs(ctx.h, _p(root), _p(keys), _p(proofs), _p(leaves_be),
+                                              ctypes.c_size_t(keys.shape[0]), ctypes.c_int(depth), _p(ok)))
+    return ok.astype(bool)
+
+
+def verify_proof(ctx, root, key, proof, leaf, depth):
+    if len(proof) != depth or key >= (1 << depth):
+        return False
+    return bool(verify_proofs(ctx, root, [key], np.frombuffer(b"".join(proof), dtype=np.uint8), np.frombuffer(bytes(leaf), dtype=np.uint8), depth)[0])
