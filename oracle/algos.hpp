@@ -10,6 +10,7 @@
 // (groth16_check_in_exponent).  Poseidon IS pinned by reference data (see poseidon.hpp).
 #pragma once
 #include "bn254.hpp"
+#include "pairing.hpp"
 #include <cassert>
 #include <cstdio>
 #include <algorithm>
@@ -406,6 +407,45 @@ static inline bool groth16_check_in_exponent(const SynthKey& k, const SynthInsta
     if (!(g2.mul_aff(b) == pr.bs)) return false;
     Fr krs = Fr::mul(Fr::sub(Fr::sub(Fr::mul(a, b), Fr::mul(k.alpha, k.beta)), pub), Fr::inv(k.delta));
     return g1.mul_aff(krs) == pr.krs;
+}
+
+// ---- the verifier's view: a verifying key and the pairing equation ------------------------------------------------
+// gnark groth16.Verify (backend/groth16/bn254/verify.go, called at prover.go:276 and src/verifier/main.go:263,284):
+//   e(Ar, Bs) == e(alpha, beta) * e(sum_pub w_i K_i^vk, gamma) * e(Krs, delta),   K_i^vk = (beta A_i + alpha B_i + C_i)/gamma
+// checked as a product of Miller loops equal to one.  The vk is derived from the synthetic key (the toxic waste is only
+// used to FORM the vk, as a real setup does; the check itself uses nothing but the vk, the public wires and the proof).
+struct SynthVK {
+    G1A alpha1;
+    G2A beta2, gamma2, delta2;
+    std::vector<G1A> Kpub;
+};
+static inline SynthVK synth_vk(const SynthKey& k) {
+    SynthVK vk;
+    FixedBase<Fp> g1(g1_gen());
+    FixedBase<Fp2> g2(g2_gen());
+    vk.alpha1 = k.alpha1; vk.beta2 = k.beta2; vk.delta2 = k.delta2;
+    vk.gamma2 = g2.mul_aff(k.gamma);
+    Fr ginv = Fr::inv(k.gamma);
+    for (size_t i = 0; i < k.n_public; ++i) {
+        Fr kv = Fr::add(Fr::add(Fr::mul(k.beta, k.At[i]), Fr::mul(k.alpha, k.Bt[i])), k.Ct[i]);
+        vk.Kpub.push_back(g1.mul_aff(Fr::mul(kv, ginv)));
+    }
+    return vk;
+}
+static inline bool groth16_verify_pairing(const SynthVK& vk, const Fr* public_wires, const ProofPts& pr) {
+    if (!g1_on_curve(pr.ar) || !g1_on_curve(pr.krs) || !g2_on_curve(pr.bs)) return false;
+    G1J acc = G1J::inf();
+    for (size_t i = 0; i < vk.Kpub.size(); ++i) acc = jadd(acc, jmul_fr(to_jac(vk.Kpub[i]), public_wires[i]));
+    G1A P[4] = {pr.ar, aneg(vk.alpha1), aneg(to_aff(acc)), aneg(pr.krs)};
+    G2A Q[4] = {pr.bs, vk.beta2, vk.gamma2, vk.delta2};
+    return pairing_product_is_one(P, Q, 4);
+}
+// Pedersen proof of knowledge (gnark-crypto fr/pedersen VerifyingKey.Verify): with BasisExpSigma_i = sigma * Basis_i,
+//   e(commitment, sigma * G2) == e(pok, G2)
+static inline bool pedersen_verify_pairing(const G1A& commitment, const G1A& pok, const G2A& g2_sigma) {
+    G1A P[2] = {commitment, aneg(pok)};
+    G2A Q[2] = {g2_sigma, g2_gen()};
+    return pairing_product_is_one(P, Q, 2);
 }
 
 }  // namespace orc

@@ -271,6 +271,33 @@ int orc_synth_check(void* p, const Fr* r, const Fr* s, const uint8_t* proof256) 
     memcpy(&pr.ar, proof256, 64); memcpy(&pr.bs, proof256 + 64, 128); memcpy(&pr.krs, proof256 + 192, 64);
     return groth16_check_in_exponent(h->key, h->inst, *r, *s, pr) ? 1 : 0;
 }
+// the verifier's equation with a real pairing (algos.hpp groth16_verify_pairing); public wires = w[0..n_public)
+int orc_synth_verify_pairing(void* p, const uint8_t* proof256) {
+    auto* h = (SynthHandle*)p;
+    ProofPts pr;
+    memcpy(&pr.ar, proof256, 64); memcpy(&pr.bs, proof256 + 64, 128); memcpy(&pr.krs, proof256 + 192, 64);
+    SynthVK vk = synth_vk(h->key);
+    return groth16_verify_pairing(vk, h->inst.w.data(), pr) ? 1 : 0;
+}
+// out: 6 Fp2 coefficients (12 Fp, Montgomery) of the reduced Tate pairing t(P, Q)
+void orc_pairing(const G1A* P, const G2A* Q, Fp* out12) {
+    Fp12 f = pairing(*P, *Q);
+    memcpy(out12, &f, sizeof(Fp12));
+}
+void orc_fp12_mul(const Fp* a, const Fp* b, Fp* out) {
+    Fp12 x, y; memcpy(&x, a, sizeof(Fp12)); memcpy(&y, b, sizeof(Fp12));
+    Fp12 r = Fp12::mul(x, y); memcpy(out, &r, sizeof(Fp12));
+}
+void orc_fp12_pow_fr(const Fp* a, const Fr* e, Fp* out) {
+    Fp12 x; memcpy(&x, a, sizeof(Fp12));
+    u64 c[4]; e->to_canon(c);
+    Fp12 r = Fp12::pow(x, c, 4); memcpy(out, &r, sizeof(Fp12));
+}
+// Pedersen: basis_i = b_i * G1, basis_sigma_i = sigma * basis_i, g2_sigma = sigma * G2 for the caller's scalars
+void orc_g2_mul_gen(const Fr* k, G2A* out) { FixedBase<Fp2> g2(g2_gen()); *out = g2.mul_aff(*k); }
+int orc_pedersen_verify_pairing(const G1A* commitment, const G1A* pok, const G2A* g2_sigma) {
+    return pedersen_verify_pairing(*commitment, *pok, *g2_sigma) ? 1 : 0;
+}
 // gnark raw proof encoding of the three points (proof.WriteRawTo, prover.go:201): big-endian
 // Ar.X|Ar.Y | Bs.X.A1|Bs.X.A0|Bs.Y.A1|Bs.Y.A0 | Krs.X|Krs.Y   (256 B; commitments follow separately)
 void orc_proof_raw(const uint8_t* proof256, uint8_t* out256) {

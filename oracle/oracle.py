@@ -13,7 +13,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("capi.cpp", "algos.hpp", "bn254.hpp", "poseidon.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("capi.cpp", "algos.hpp", "bn254.hpp", "poseidon.hpp", "pairing.hpp", "pairing_consts.inc")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
@@ -337,11 +337,45 @@ class Synth:
         proof256 = np.ascontiguousarray(proof256, dtype=np.uint8)
         return bool(lib().orc_synth_check(self.h, _p(_u64(r)), _p(_u64(s)), _p(proof256)))
 
+    def verify_pairing(self, proof256):
+        """groth16.Verify's equation with a real pairing; uses only the vk, the public wires and the proof"""
+        proof256 = np.ascontiguousarray(proof256, dtype=np.uint8)
+        return bool(lib().orc_synth_verify_pairing(self.h, _p(proof256)))
+
     def __del__(self):
         try:
             lib().orc_synth_destroy(self.h)
         except Exception:
             pass
+
+
+def pairing(P, Q):
+    """reduced Tate pairing t(P, Q) as 12 Fp (oracle/pairing.hpp)"""
+    out = np.empty((12, 4), dtype=np.uint64)
+    lib().orc_pairing(_p(_u64(P)), _p(_u64(Q)), _p(out))
+    return out
+
+
+def fp12_mul(a, b):
+    out = np.empty((12, 4), dtype=np.uint64)
+    lib().orc_fp12_mul(_p(_u64(a)), _p(_u64(b)), _p(out))
+    return out
+
+
+def fp12_pow_fr(a, e):
+    out = np.empty((12, 4), dtype=np.uint64)
+    lib().orc_fp12_pow_fr(_p(_u64(a)), _p(_u64(e)), _p(out))
+    return out
+
+
+def g2_mul_gen(k):
+    out = np.empty(16, dtype=np.uint64)
+    lib().orc_g2_mul_gen(_p(_u64(k)), _p(out))
+    return out
+
+
+def pedersen_verify_pairing(commitment, pok, g2_sigma):
+    return bool(lib().orc_pedersen_verify_pairing(_p(_u64(commitment)), _p(_u64(pok)), _p(_u64(g2_sigma))))
 
 
 def proof_raw(proof256):

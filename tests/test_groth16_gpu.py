@@ -41,12 +41,15 @@ def test_prove_tail_matches_oracle_and_verifies(zk, n_cons, z_bitrev):
         ref = S.prove_tail(r, s)
         assert np.array_equal(got, ref)            # bit-exact with the CPU restatement
         assert S.check(r, s, got)                  # Groth16 equation holds (in the exponent)
+        assert S.verify_pairing(got)               # ... and under a real pairing, from vk + public wires + proof only
         bad = got.copy(); bad[5] ^= 1
         assert not S.check(r, s, bad)
+        swapped = got.copy(); swapped[192:256] = got[0:64]   # Krs := Ar (a point on the curve, wrong value)
+        assert not S.verify_pairing(swapped)
         # a different blinding gives a different but still valid proof
         r2 = O.fr_random(7, 1)[0]
         got2 = zk.prove_tail(pk, S.w, S.a, S.b, S.c, r2, s)
-        assert not np.array_equal(got2, got) and S.check(r2, s, got2)
+        assert not np.array_equal(got2, got) and S.check(r2, s, got2) and S.verify_pairing(got2)
         # raw encoding = oracle's restatement of WriteRawTo (first 256 bytes), then u32 0 commitments + empty pok
         raw = zkpor.proof_write_raw(got)
         assert np.array_equal(raw[:256], O.proof_raw(got)) and raw.size == 324 and not raw[256:260].any()
@@ -84,6 +87,35 @@ def test_commit_matches_two_msms(zk):
         vals = O.fr_random(23, n)
         c, k = zk.commit(pk, vals)
         assert np.array_equal(c, O.g1_msm(basis, vals)) and np.array_equal(k, O.g1_msm(sigma, vals))
+    finally:
+        pk.close()
+
+
+def test_commitment_proof_of_knowledge_verifies_under_pairing(zk):
+    """BSB22 commitment as the verifier sees it (gnark-crypto fr/pedersen VerifyingKey.Verify, run inside groth16.Verify,
+    prover.go:276): BasisExpSigma_i = sigma * Basis_i, and e(commitment, sigma*G2) == e(pok, G2)"""
+    n = 300
+    S = O.Synth(4, 20, n_public=2, seed=4)
+    pk = zkpor.ProvingKey(zk)
+    try:
+        bs = O.fr_random(31, n)
+        sig = O.fr_random(32, 1)[0]
+        basis = O.g1_from_scalars(bs)
+        basis_sigma = O.g1_from_scalars(O.fr_mul(bs, np.repeat(sig[None, :], n, axis=0)))
+        pk.set_g1(zkpor.G1_A, S.A); pk.set_g1(zkpor.G1_B, S.B1); pk.set_g2(zkpor.G2_B, S.B2)
+        pk.set_g1(zkpor.G1_K, S.K[S.n_public:]); pk.set_g1(zkpor.G1_Z, S.Z)
+        pk.set_g1(zkpor.G1_COMMIT_BASIS, basis); pk.set_g1(zkpor.G1_COMMIT_BASIS_SIGMA, basis_sigma)
+        z = np.zeros(S.n_wires, dtype=np.uint8)
+        pk.set_consts(S.abd1[0], S.abd1[1], S.abd1[2], S.bd2[0], S.bd2[1], S.log2d, z, z, S.n_wires, S.n_public)
+        vals = O.fr_random(33, n)
+        c, k = zk.commit(pk, vals)
+        g2s = O.g2_mul_gen(sig)
+        assert O.pedersen_verify_pairing(c, k, g2s)
+        assert not O.pedersen_verify_pairing(c, c, g2s)
+        # the 388-byte wire form with one commitment (SURVEY a6.7) round-trips the same points
+        proof = zk.prove_tail(pk, S.w, S.a, S.b, S.c, O.fr_random(5, 1)[0], O.fr_random(6, 1)[0])
+        raw = zkpor.proof_write_raw(proof, commitments=c[None, :], pok=k)
+        assert raw.size == 388 and raw[256:260].tolist() == [0, 0, 0, 1]
     finally:
         pk.close()
 

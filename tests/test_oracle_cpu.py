@@ -119,6 +119,53 @@ def test_groth16_tail_verifies_in_the_exponent(z_bitrev):
     assert bs_x_a1 == O.fp_to_ints(pr.view(np.uint64).reshape(-1, 4)[3:4])[0]
 
 
+def test_pairing_is_bilinear_and_nondegenerate():
+    """oracle/pairing.hpp (reduced Tate pairing): the properties a verifier relies on"""
+    one = O.fr_from_ints([1])[0]
+    a = O.fr_from_ints([0x1234567890abcdef1234567890abcdef])[0]; b = O.fr_random(9, 1)[0]
+    G = O.g1_from_scalars(one[None, :])[0]; H = O.g2_mul_gen(one)
+    e = O.pairing(G, H)
+    unit = O.fp12_pow_fr(e, O.fr_from_ints([0])[0])
+    assert not np.array_equal(e, unit)                                   # non-degenerate
+    aG = O.g1_from_scalars(a[None, :])[0]; bH = O.g2_mul_gen(b)
+    ab = O.fr_mul(a[None, :], b[None, :])[0]
+    assert np.array_equal(O.pairing(aG, bH), O.fp12_pow_fr(e, ab))       # e(aG, bH) = e(G, H)^(ab)
+    assert np.array_equal(O.pairing(aG, H), O.pairing(G, O.g2_mul_gen(a)))
+    # e(P1 + P2, Q) = e(P1, Q) e(P2, Q)
+    s = O.fr_add(a[None, :], b[None, :])[0]
+    lhs = O.pairing(O.g1_from_scalars(s[None, :])[0], H)
+    assert np.array_equal(lhs, O.fp12_mul(O.pairing(aG, H), O.pairing(O.g1_from_scalars(b[None, :])[0], H)))
+    # order r: e^r = 1  (r = 0 in Fr, so raise to r-1 and multiply once more)
+    rm1 = O.fr_sub(O.fr_from_ints([0]), one[None, :])[0]
+    assert np.array_equal(O.fp12_mul(O.fp12_pow_fr(e, rm1), e), unit)
+    # infinity in either argument pairs to one
+    assert np.array_equal(O.pairing(np.zeros(8, np.uint64), H), unit)
+
+
+def test_groth16_verifies_under_pairing_and_rejects_forgeries():
+    """the acceptance test of the reference (groth16.Verify, prover.go:276) restated with a real pairing"""
+    S = O.Synth(5, 60, 3, seed=8)
+    r = O.fr_random(1, 1)[0]; s = O.fr_random(2, 1)[0]
+    pr = S.prove_tail(r, s)
+    assert S.verify_pairing(pr)
+    forged = pr.copy(); forged[192:256] = pr[0:64]
+    assert not S.verify_pairing(forged)
+    off_curve = pr.copy(); off_curve[3] ^= 1
+    assert not S.verify_pairing(off_curve)
+    # a proof for a different blinding verifies too; mixing Ar of one with Krs of the other does not
+    pr2 = S.prove_tail(O.fr_random(3, 1)[0], s)
+    assert S.verify_pairing(pr2)
+    mixed = pr.copy(); mixed[192:256] = pr2[192:256]
+    assert not S.verify_pairing(mixed)
+    # Pedersen proof of knowledge
+    n = 20
+    bs = O.fr_random(5, n); sig = O.fr_random(6, 1)[0]; v = O.fr_random(7, n)
+    basis = O.g1_from_scalars(bs); basis_s = O.g1_from_scalars(O.fr_mul(bs, np.repeat(sig[None, :], n, axis=0)))
+    c = O.g1_msm(basis, v); k = O.g1_msm(basis_s, v)
+    assert O.pedersen_verify_pairing(c, k, O.g2_mul_gen(sig))
+    assert not O.pedersen_verify_pairing(c, k, O.g2_mul_gen(O.fr_random(8, 1)[0]))
+
+
 def test_merkle_tree_and_leaves_self_consistency():
     # mirrors src/utils/merkletree/merkletree_test.go (build / prove / verify round trip) and utils_test.go:43-136
     # (padding re-implementation); both are self-consistency tests in the reference as well (no golden root there)
