@@ -277,15 +277,18 @@ int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp2>* Sin, const XYZZ<Fp2>* Yin
 int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L, u32 NB,
                       XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part, void* raw) {
     u32 T = (M + (u32)L - 1u) / (u32)L;
-    PhaseScope ps(ctx, "k_acc_level1_g2");
     if (ctx->g2_variant == 0) {
         ZK_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)NB * sizeof(XYZZ<Fp2>), ctx->stream));
+        PhaseScope ps(ctx, "k_acc_level1_g2");
         hipLaunchKernelGGL(k_acc_level1_g2pair, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
     } else {
         u32* braw = (u32*)raw;
         u32* hraw = braw + (size_t)NB * (2 * RAW29_WORDS);
         ZK_HIP(ctx, hipMemsetAsync(braw, 0, (size_t)NB * (2 * RAW29_WORDS) * 4, ctx->stream));
-        hipLaunchKernelGGL(k_acc_level1_g2pair29, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, braw, hraw, out_keys, out_part);
+        {
+            PhaseScope ps(ctx, "k_acc_level1_g2");
+            hipLaunchKernelGGL(k_acc_level1_g2pair29, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, braw, hraw, out_keys, out_part);
+        }
         ZK_KERNEL_CHECK(ctx);
         hipLaunchKernelGGL(k_raw29_to_buckets_g2pair, dim3((2u * NB + 255u) / 256u), dim3(256), 0, ctx->stream, braw, buckets, NB);
     }
