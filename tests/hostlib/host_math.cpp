@@ -95,4 +95,36 @@ void hm_g1_sum29(const G1Affine* p, const uint8_t* sign, size_t n, G1Affine* out
     else { o.x = Fp29::to32_div32(acc.x); o.y = Fp29::to32_div32(acc.y); o.zz = Fp29::to32_div32(acc.zz); o.zzz = Fp29::to32_div32(acc.zzz); }
     *out = xyzz_to_affine<Fp>(o);
 }
+// ---- the scalar field on the same limbs (NTT), and the product-free reductions / packing ----
+void hm_fr29_mul(const Fr* a, const Fr* b, Fr* o, size_t n) {
+    for (size_t i = 0; i < n; ++i) o[i] = Fr29::to32_div32(Fr29::mul(Fr29::from32<5>(a[i]), Fr29::from32<5>(b[i])));
+}
+// reduce32 on +/- (a * 32): the value mod m must be unchanged, limbs tight, magnitude < 3m; returns 0 on a bound violation
+int hm_fe29_reduce32(const Fp* a, const Fr* ar, int negate, Fp* o, Fr* orr, size_t n) {
+    int ok = 1;
+    for (size_t i = 0; i < n; ++i) {
+        Fp29 x = Fp29::reduce32(Fp29::cneg(Fp29::from32<5>(a[i]), negate != 0));
+        Fr29 y = Fr29::reduce32(Fr29::cneg(Fr29::from32<5>(ar[i]), negate != 0));
+        for (int k = 0; k < 8; ++k) ok &= x.l[k] < (1u << 29) && y.l[k] < (1u << 29);
+        ok &= (int32_t)x.l[8] > -(1 << 20) && (int32_t)x.l[8] < (3 << 22) && (int32_t)y.l[8] > -(1 << 20) && (int32_t)y.l[8] < (3 << 22);
+        o[i] = Fp29::to32_div32(x); orr[i] = Fr29::to32_div32(y);
+    }
+    return ok;
+}
+// reduce32_pos -> pack32 -> from32<0>: the NTT's inter-pass memory form; input = sum of two unreduced a*32 (the largest
+// magnitude the NTT feeds it, 64 m) or its negation.  out = 2a (or -2a), and the packed integer must be < 2^256.
+int hm_fr29_pack_roundtrip(const Fr* a, int negate, Fr* o, size_t n) {
+    int ok = 1;
+    for (size_t i = 0; i < n; ++i) {
+        Fr29 x = Fr29::from32<5>(a[i]);
+        Fr29 s = Fr29::cneg(Fr29::add_l(x, x), negate != 0);
+        Fr29 r = Fr29::reduce32_pos(s);
+        ok &= (int32_t)r.l[8] >= 0 && r.l[8] < (1u << 24);
+        Fr packed = r.pack32();
+        Fr29 back = Fr29::from32<0>(packed);
+        for (int k = 0; k < 9; ++k) ok &= back.l[k] == r.l[k];
+        o[i] = Fr29::to32_div32(back);
+    }
+    return ok;
+}
 }

@@ -84,3 +84,26 @@ def test_mixed_addition_matches_oracle_and_stays_bounded():
     pair = np.concatenate([pts[:1], neg])
     L.hm_g1_sum29(_p(pair), None, ctypes.c_size_t(2), _p(out), ctypes.byref(top))
     assert not out.any()
+
+
+def test_scalar_field_product_and_reductions():
+    """Fr on the same limbs (the NTT's arithmetic): product, the product-free reduce32 on +/-32a for both fields, and the
+    reduce32_pos -> pack32 -> from32<0> memory form of the inter-pass arrays"""
+    L = _lib()
+    n = 3000
+    edge_r = [0, 1, 2, O.R_MOD - 1, O.R_MOD - 2, 1 << 253, (1 << 232) - 1, (1 << 29) - 1, 1 << 29]
+    a = np.concatenate([O.fr_random(11, n), O.fr_from_ints(edge_r)]); b = np.concatenate([O.fr_random(12, n), O.fr_from_ints(edge_r[::-1])])
+    o = np.empty_like(a)
+    L.hm_fr29_mul(_p(a), _p(b), _p(o), ctypes.c_size_t(len(a)))
+    assert np.array_equal(o, O.fr_mul(a, b))
+    ap = np.concatenate([_rnd_fp(13, n), O.fp_from_ints(EDGE)])
+    for neg in (0, 1):
+        op = np.empty_like(ap); orr = np.empty_like(a)
+        assert L.hm_fe29_reduce32(_p(ap), _p(a), ctypes.c_int(neg), _p(op), _p(orr), ctypes.c_size_t(len(a))) == 1
+        zero_p = O.fp_from_ints([0] * len(ap)); zero_r = O.fr_from_ints([0] * len(a))
+        assert np.array_equal(op, O.fp_sub(zero_p, ap) if neg else ap)
+        assert np.array_equal(orr, O.fr_sub(zero_r, a) if neg else a)
+        o2 = np.empty_like(a)
+        assert L.hm_fr29_pack_roundtrip(_p(a), ctypes.c_int(neg), _p(o2), ctypes.c_size_t(len(a))) == 1
+        two_a = O.fr_add(a, a)
+        assert np.array_equal(o2, O.fr_sub(zero_r, two_a) if neg else two_a)

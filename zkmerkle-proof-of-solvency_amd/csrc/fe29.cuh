@@ -34,14 +34,31 @@ struct Fp29Params {
     static constexpr u32 PINV29 = 0x1b799c77u;  //  p^-1 mod 2^29
 };
 
+struct Fr29Params {  // the scalar field, same shape (both moduli share their top 125 bits, so every bound carries over)
+    ZK_HD static constexpr u32 mod29(int i) {
+        constexpr u32 m[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+        return m[i];
+    }
+    ZK_HD static constexpr u32 one29(int i) {  // 2^261 mod r
+        constexpr u32 m[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+        return m[i];
+    }
+    static constexpr u32 INV29 = 0x0fffffffu;   // -r^-1 mod 2^29
+    static constexpr u32 PINV29 = 0x10000001u;  //  r^-1 mod 2^29
+};
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #include "fe29_asm.inc"
 #endif
 
-struct Fp29 {
+// PP = limb constants of the modulus, F32 = the 8 x 32 memory type of the same field (Fe<FpParams> / Fe<FrParams>)
+template <class PP, class F32>
+struct Fe29T {
     u32 l[9];  // two's-complement int32 limbs
     static constexpr u32 M29 = 0x1fffffffu;
-    typedef Fp29Params P;
+    typedef PP P;
+    typedef Fe29T Fp29;  // the member functions below were written for the base field; the name is kept local
+    typedef F32 Fp;
     typedef int32_t i32;
     typedef int64_t i64;
 
@@ -213,6 +230,36 @@ struct Fp29 {
         }
         return r;
     }
+    // the same with the quotient estimate lowered by one: result in (0.9p, 3.4p), limbs 0..7 exact in [0, 2^29),
+    // limb 8 >= 0 — the form pack32() stores
+    ZK_HD static Fp29 reduce32_pos(const Fp29& a) {
+        const i32 q = ((((i32)a.l[8] >> 22) * 169) >> 7) - 1;
+        Fp29 r;
+        i64 c = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            i64 t = (i64)(i32)a.l[i] - (i64)q * (i64)P::mod29(i) + c;
+            r.l[i] = i < 8 ? ((u32)t & M29) : (u32)t;
+            c = t >> 29;
+        }
+        return r;
+    }
+    // exact non-negative limbs (reduce32_pos output, value < 2^256) -> 8 x 32 words of the same integer; from32<0>
+    // is the inverse.  The NTT keeps its inter-pass arrays in this form (R' domain, value in [0, 4p)).
+    ZK_HD Fp pack32() const {
+        Fp r;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int bit = 32 * w;
+            const int i = bit / 29, s = bit % 29;
+            u64 v = (u64)l[i] >> s;
+            int have = 29 - s;
+            if (i + 1 < 9) { v |= (u64)l[i + 1] << have; have += 29; }
+            if (have < 32 && i + 2 < 9) v |= (u64)l[i + 2] << have;
+            r.v[w] = (u32)v;
+        }
+        return r;
+    }
     // lazy value x (|x| < 16p) -> canonical 8x32 of (x * 2^256 * 2^-261) mod p = x / 32: back to gnark's form
     ZK_HD static Fp to32_div32(const Fp29& x) {
         Fp29 c256 = zero();
@@ -266,6 +313,8 @@ struct Fp29 {
     // R*D - Y1*PPP with ONE reduction (all four tight)
     ZK_HD static Fp29 y3(const Fp29& R, const Fp29& D, const Fp29& Y1, const Fp29& PPP) { return mul2(R, D, neg(Y1), PPP); }
 };
+typedef Fe29T<Fp29Params, Fe<FpParams>> Fp29;
+typedef Fe29T<Fr29Params, Fe<FrParams>> Fr29;
 
 // ---- XYZZ accumulator on a 29-bit field F (Fp29, or the lane-pair Fp2 of fp2_lanepair.cuh) ------------------------
 template <class F>
@@ -326,6 +375,7 @@ typedef XYZZ29T<Fp29> XYZZ29;
 // infinity).  The level-1 kernels park finished buckets in this form because the store sits on a divergent path
 // (some lane of a wave closes a bucket in ~half of all iterations): 36 plain stores instead of four domain changes.
 static constexpr int RAW29_WORDS = 36;
+#if defined(__HIPCC__)  // uint4 is a HIP vector type; tests/hostlib builds this header with plain g++
 ZK_HD void raw29_store(u32* dst, const XYZZ29& a) {
     uint4* d = (uint4*)dst;
     u32 w[36];
@@ -344,5 +394,6 @@ ZK_HD XYZZ29 raw29_load(const u32* src) {
     for (int i = 0; i < 9; ++i) { a.x.l[i] = w[i]; a.y.l[i] = w[9 + i]; a.zz.l[i] = w[18 + i]; a.zzz.l[i] = w[27 + i]; }
     return a;
 }
+#endif
 
 }  // namespace zk
