@@ -8,15 +8,37 @@ import oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 0], ids=["limbs29", "limbs32"])
+def zkv(zk, request):
+    """both arithmetic variants of the pass kernel: 9 x 29-bit lazy limbs (the default) and 8 x 32-bit limbs"""
+    zk.set_param("ntt_variant", request.param)
+    yield zk
+    zk.set_param("ntt_variant", 1)
+
+
 @pytest.mark.parametrize("log2n", [1, 2, 3, 7, 8, 9, 10, 13, 17, 18])
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("decimation", [O.DIT, O.DIF])
 @pytest.mark.parametrize("coset", [False, True])
-def test_fft_matches_oracle(zk, log2n, inverse, decimation, coset):
+def test_fft_matches_oracle(zkv, log2n, inverse, decimation, coset):
+    zk = zkv
     a = O.fr_random(1000 + log2n, 1 << log2n)
     got = zk.fft(a, log2n, inverse, decimation, coset)
     ref = O.fft(a, log2n, inverse, decimation, coset)
     assert np.array_equal(got, ref)
+
+
+def test_fft_edge_values(zkv):
+    """inputs at the ends of the canonical range and all-equal vectors (worst-case limb carries in the lazy form)"""
+    zk = zkv
+    n = 10
+    edge = [0, 1, 2, O.R_MOD - 1, O.R_MOD - 2, (1 << 253), (1 << 232) - 1, (1 << 29) - 1, 1 << 29, (O.R_MOD - 1) // 2]
+    vals = (edge * ((1 << n) // len(edge) + 1))[: 1 << n]
+    for a in (O.fr_from_ints(vals), O.fr_from_ints([O.R_MOD - 1] * (1 << n)), O.fr_from_ints([0] * (1 << n))):
+        for inverse in (False, True):
+            for dec in (O.DIT, O.DIF):
+                for coset in (False, True):
+                    assert np.array_equal(zk.fft(a, n, inverse, dec, coset), O.fft(a, n, inverse, dec, coset))
 
 
 def test_fft_roundtrip_2_20(zk):
@@ -29,7 +51,8 @@ def test_fft_roundtrip_2_20(zk):
 
 
 @pytest.mark.parametrize("log2d,ncons", [(3, 5), (8, 256), (10, 1000), (12, 4096), (17, 100000)])
-def test_compute_h_matches_oracle(zk, log2d, ncons):
+def test_compute_h_matches_oracle(zkv, log2d, ncons):
+    zk = zkv
     a = O.fr_random(1, ncons); b = O.fr_random(2, ncons)
     c = O.fr_mul(a, b)
     got = zk.compute_h(a, b, c, log2d)

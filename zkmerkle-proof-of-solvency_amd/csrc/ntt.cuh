@@ -12,6 +12,14 @@ struct NttDomain {
     Fr n_inv, den;                              // 1/N, 1/(g^N - 1)
     Fr* full_fwd[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // per field: tabulated
     Fr* full_inv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // inter-pass twiddles
+    // the same constants for the 29-bit kernel (k_ntt_pass29): Montgomery radix 2^261, packed as 8 x 32-bit words
+    bool have29 = false;
+    Fr* mem29 = nullptr;
+    Fr *g_lo29, *g_hi29, *gi_lo29, *gi_hi29, *g_hi_ninv29, *gi_hi_ninv29;
+    u32 *small_fwd29, *small_inv29;             // 256 x 9 limbs each
+    Fr n_inv29;
+    Fr* full_fwd29[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    Fr* full_inv29[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 int32_t ntt_domain_get(zkpor_ctx* ctx, int n, NttDomain** out);
 void ntt_domains_free(zkpor_ctx* ctx);

@@ -12,6 +12,7 @@
 //   low -> high (bit-reversed in, natural out), so computeH never needs a bit-reversal permutation.
 #include "common.cuh"
 #include "ntt.cuh"
+#include "fe29.cuh"
 
 namespace zk {
 
@@ -146,6 +147,113 @@ __global__ __launch_bounds__(256) void k_ntt_pass(PassArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 29-bit pass
+// The same pass on 9 x 29-bit signed lazy limbs (fe29.cuh, Fr29): a butterfly is one 206-instruction product plus a
+// product-free 30-instruction reduction instead of a 313-instruction product and two carry-chained add/sub with
+// conditional corrections.  Between passes the array holds Montgomery-radix-2^261 residues in [0, 4r) packed into the
+// same 8 x 32-bit words (reduce32_pos + pack32 at the store, from32<0> at the load), so passes stay in place; the first
+// pass reads gnark's form (from32<5> = value * 32 = the 2^261 form, unreduced) and the last one writes it
+// (to32_div32).  All constants come from tables already in the 2^261 form.
+struct PassArgs29 {
+    Fr* x;
+    int n, lo, kb, clog;
+    const u32* small29;          // w_512^j, 9 limbs each
+    const Fr* tw_full;           // [k_m << lo | l], packed 2^261 form
+    int scale_load, scale_store;  // 0 none, 1 constant, 2 g^p, 3 g^rev(p)
+    const Fr* g_lo; const Fr* g_hi; int tb;
+    Fr konst;
+    int in_gnark, out_gnark;
+};
+ZK_D Fr29 ld29(const u32* t) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = t[i];
+    return r;
+}
+ZK_D void st29(u32* t, const Fr29& v) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) t[i] = v.l[i];
+}
+ZK_D Fr29 scale29(const PassArgs29& A, int mode, const Fr29& v, u32 p) {
+    if (mode == 1) return Fr29::mul(v, Fr29::from32<0>(A.konst));
+    u32 e = mode == 2 ? p : brev(p, A.n);
+    Fr29 g = Fr29::mul(Fr29::from32<0>(A.g_lo[e & ((1u << A.tb) - 1u)]), Fr29::from32<0>(A.g_hi[e >> A.tb]));
+    return Fr29::mul(v, g);
+}
+
+template <bool DIF>
+__global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32* tile = (u32*)smem_raw;  // element i at tile + 9 i (odd stride: conflict-free)
+    const int kb = A.kb, lo = A.lo, clog = A.clog;
+    const u32 F = 1u << kb, C = 1u << clog;
+    u32 hi, l0;
+    if (lo > 0) {
+        u32 lgroups = (1u << lo) >> clog;
+        hi = blockIdx.x / lgroups;
+        l0 = (blockIdx.x % lgroups) << clog;
+    } else {
+        hi = blockIdx.x << clog;
+        l0 = 0;
+    }
+    const u32 total = F << clog;
+    for (u32 idx = threadIdx.x; idx < total; idx += 256u) {
+        u32 m, c, p, li;
+        if (lo > 0) { c = idx & (C - 1u); m = idx >> clog; p = (hi << (lo + kb)) + (m << lo) + l0 + c; li = m * C + c; }
+        else { m = idx & (F - 1u); c = idx >> kb; p = ((hi + c) << kb) + m; li = c * F + m; }
+        const Fr raw = A.x[p];
+        Fr29 v = A.in_gnark ? Fr29::from32<5>(raw) : Fr29::from32<0>(raw);
+        if (A.scale_load) v = scale29(A, A.scale_load, v, p);
+        if (!DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << lo) | (l0 + c)]));
+        st29(tile + 9u * li, v);
+    }
+    __syncthreads();
+    const u32 nbf = total >> 1;
+    for (int j = 0; j < kb; ++j) {
+        const int hlog = DIF ? (kb - 1 - j) : j;
+        const u32 half = 1u << hlog;
+        const int tshift = (DIF ? j : (kb - 1 - j)) + (9 - kb);
+        for (u32 t = threadIdx.x; t < nbf; t += 256u) {
+            u32 q, c;
+            if (lo > 0) { c = t & (C - 1u); q = t >> clog; }
+            else { q = t & ((F >> 1) - 1u); c = t >> (kb - 1); }
+            u32 pos = q & (half - 1u);
+            u32 i0 = ((q >> hlog) << (hlog + 1)) + pos;
+            u32 i1 = i0 + half;
+            u32* p0 = tile + 9u * (lo > 0 ? i0 * C + c : c * F + i0);
+            u32* p1 = tile + 9u * (lo > 0 ? i1 * C + c : c * F + i1);
+            Fr29 a = ld29(p0), b = ld29(p1);
+            Fr29 w = ld29(A.small29 + 9u * (pos << tshift));
+            if (DIF) {
+                st29(p0, Fr29::reduce32(Fr29::add_l(a, b)));
+                st29(p1, Fr29::mul(w, Fr29::sub_l(a, b)));
+            } else {
+                Fr29 tb_ = Fr29::mul(b, w);
+                st29(p0, Fr29::reduce32(Fr29::add_l(a, tb_)));
+                st29(p1, Fr29::reduce32(Fr29::sub_l(a, tb_)));
+            }
+        }
+        __syncthreads();
+    }
+    for (u32 idx = threadIdx.x; idx < total; idx += 256u) {
+        u32 m, c, p, li;
+        if (lo > 0) { c = idx & (C - 1u); m = idx >> clog; p = (hi << (lo + kb)) + (m << lo) + l0 + c; li = m * C + c; }
+        else { m = idx & (F - 1u); c = idx >> kb; p = ((hi + c) << kb) + m; li = c * F + m; }
+        Fr29 v = ld29(tile + 9u * li);
+        if (DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << lo) | (l0 + c)]));
+        if (A.scale_store) v = scale29(A, A.scale_store, v, p);
+        A.x[p] = A.out_gnark ? Fr29::to32_div32(v) : Fr29::reduce32_pos(v).pack32();
+    }
+}
+
+// packed 2^261-form table -> 9-limb rows
+__global__ void k_unpack29(const Fr* in, u32* out, u32 count) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fr29 v = Fr29::from32<0>(in[i]);
+    for (int k = 0; k < 9; ++k) out[9u * i + k] = v.l[k];
+}
+
 // a = (a*b - c) * den
 __global__ __launch_bounds__(256) void k_h_pointwise(Fr* a, const Fr* b, const Fr* c, Fr den, size_t n) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -239,6 +347,55 @@ int32_t ntt_domain_get(zkpor_ctx* ctx, int n, NttDomain** out) {
             d->full_fwd[i] = a; d->full_inv[i] = b;
         }
     }
+    // ---- constants of the 29-bit kernel: everything multiplied by 32 (Montgomery radix 2^256 -> 2^261)
+    {
+        Fr c32 = one;
+        for (int i = 0; i < 5; ++i) c32 = Fr::add(c32, c32);
+        size_t total29 = (size_t)2 * nlo + (size_t)6 * nhi + 512 + 2 * 288;  // 288 Fr = 256 x 9 words
+        d->have29 = false;
+        if (hipMalloc((void**)&d->mem29, total29 * sizeof(Fr)) == hipSuccess) {
+            Fr* q = d->mem29;
+            auto take29 = [&](size_t cnt) { Fr* r = q; q += cnt; return r; };
+            d->g_lo29 = take29(nlo); d->gi_lo29 = take29(nlo);
+            d->g_hi29 = take29(nhi); d->gi_hi29 = take29(nhi); d->g_hi_ninv29 = take29(nhi); d->gi_hi_ninv29 = take29(nhi);
+            Fr* tw_hi32 = take29(nhi); Fr* twi_hi32 = take29(nhi);
+            Fr* sm_f = take29(256); Fr* sm_i = take29(256);
+            d->small_fwd29 = (u32*)take29(288); d->small_inv29 = (u32*)take29(288);
+            ZK_TRY(make_table(ctx, g, c32, 0, nlo, d->g_lo29));
+            ZK_TRY(make_table(ctx, gi, c32, 0, nlo, d->gi_lo29));
+            ZK_TRY(make_table(ctx, g, c32, d->tb, nhi, d->g_hi29));
+            ZK_TRY(make_table(ctx, gi, c32, d->tb, nhi, d->gi_hi29));
+            ZK_TRY(make_table(ctx, g, Fr::mul(d->n_inv, c32), d->tb, nhi, d->g_hi_ninv29));
+            ZK_TRY(make_table(ctx, gi, Fr::mul(d->n_inv, c32), d->tb, nhi, d->gi_hi_ninv29));
+            ZK_TRY(make_table(ctx, w, c32, d->tb, nhi, tw_hi32));
+            ZK_TRY(make_table(ctx, wi, c32, d->tb, nhi, twi_hi32));
+            ZK_TRY(make_table(ctx, w512, c32, 0, 256, sm_f));
+            ZK_TRY(make_table(ctx, w512i, c32, 0, 256, sm_i));
+            hipLaunchKernelGGL(k_unpack29, dim3(1), dim3(256), 0, ctx->stream, sm_f, d->small_fwd29, 256u);
+            hipLaunchKernelGGL(k_unpack29, dim3(1), dim3(256), 0, ctx->stream, sm_i, d->small_inv29, 256u);
+            ZK_KERNEL_CHECK(ctx);
+            d->n_inv29 = Fr::mul(d->n_inv, c32);
+            bool ok = true;
+            Field f[8];
+            int nf = plan_fields(n, f);
+            for (int i = 0; i < nf && i < 8 && ok; ++i) {
+                if (f[i].lo == 0) continue;
+                size_t cnt = (size_t)1 << (f[i].lo + f[i].kb);
+                int s0 = n - f[i].lo - f[i].kb;
+                Fr *a = nullptr, *b = nullptr;
+                if (hipMalloc((void**)&a, cnt * sizeof(Fr)) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+                if (hipMalloc((void**)&b, cnt * sizeof(Fr)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(a); ok = false; break; }
+                unsigned blocks = (unsigned)((cnt + 255) / 256);
+                hipLaunchKernelGGL(k_twiddle_full, dim3(blocks), dim3(256), 0, ctx->stream, d->tw_lo, tw_hi32, d->tb, f[i].lo, f[i].kb, s0, a);
+                hipLaunchKernelGGL(k_twiddle_full, dim3(blocks), dim3(256), 0, ctx->stream, d->twi_lo, twi_hi32, d->tb, f[i].lo, f[i].kb, s0, b);
+                ZK_KERNEL_CHECK(ctx);
+                d->full_fwd29[i] = a; d->full_inv29[i] = b;
+            }
+            d->have29 = ok;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     ctx->ntt_domains[n] = d;
     *out = d;
     return ZKPOR_OK;
@@ -248,6 +405,8 @@ void ntt_domains_free(zkpor_ctx* ctx) {
     for (auto& kv : ctx->ntt_domains) {
         NttDomain* d = (NttDomain*)kv.second;
         if (d->mem) (void)hipFree(d->mem);
+        if (d->mem29) (void)hipFree(d->mem29);
+        for (int i = 0; i < 8; ++i) { if (d->full_fwd29[i]) (void)hipFree(d->full_fwd29[i]); if (d->full_inv29[i]) (void)hipFree(d->full_inv29[i]); }
         for (int i = 0; i < 8; ++i) { if (d->full_fwd[i]) (void)hipFree(d->full_fwd[i]); if (d->full_inv[i]) (void)hipFree(d->full_inv[i]); }
         delete d;
     }
@@ -257,10 +416,13 @@ void ntt_domains_free(zkpor_ctx* ctx) {
 // scale codes: 0 none, 1 constant, 2 g^p, 3 g^rev(p); g tables chosen by the caller
 struct ScaleSpec { int mode = 0; const Fr* g_lo = nullptr; const Fr* g_hi = nullptr; Fr konst; };
 
+static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
+                            const ScaleSpec& last_store);
 static int32_t run_passes(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
                           const ScaleSpec& last_store) {
     Field f[8];
     int nf = plan_fields(d->n, f);
+    if (ctx->ntt_variant == 1 && d->have29 && !(first_load.mode && last_store.mode && nf == 1)) return run_passes29(ctx, d, x, inverse, dif, first_load, last_store);
     for (int step = 0; step < nf; ++step) {
         const Field& fl = dif ? f[nf - 1 - step] : f[step];
         PassArgs A;
@@ -287,6 +449,57 @@ static int32_t run_passes(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, boo
         size_t smem = ((size_t)sizeof(Fr) << fl.kb) << A.clog;
         if (dif) hipLaunchKernelGGL(k_ntt_pass<true>, dim3(blocks), dim3(256), smem, ctx->stream, A);
         else hipLaunchKernelGGL(k_ntt_pass<false>, dim3(blocks), dim3(256), smem, ctx->stream, A);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    return ZKPOR_OK;
+}
+
+// which 2^261-form table stands in for a 2^256-form one
+static const Fr* table29(const NttDomain* d, const Fr* t) {
+    if (t == d->g_lo) return d->g_lo29;
+    if (t == d->gi_lo) return d->gi_lo29;
+    if (t == d->g_hi) return d->g_hi29;
+    if (t == d->gi_hi) return d->gi_hi29;
+    if (t == d->g_hi_ninv) return d->g_hi_ninv29;
+    if (t == d->gi_hi_ninv) return d->gi_hi_ninv29;
+    return nullptr;
+}
+static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
+                            const ScaleSpec& last_store) {
+    Field f[8];
+    int nf = plan_fields(d->n, f);
+    Fr c32 = Fr::one();
+    for (int i = 0; i < 5; ++i) c32 = Fr::add(c32, c32);
+    for (int step = 0; step < nf; ++step) {
+        const int fi = dif ? nf - 1 - step : step;
+        const Field& fl = f[fi];
+        PassArgs29 A;
+        A.x = x; A.n = d->n; A.lo = fl.lo; A.kb = fl.kb;
+        int cmax = 10 - fl.kb;  // tile of <= 1024 elements x 36 B: four blocks (16 waves) per CU
+        if (cmax < 0) cmax = 0;
+        int avail = fl.lo > 0 ? fl.lo : d->n - fl.kb;
+        A.clog = avail < cmax ? avail : cmax;
+        A.small29 = inverse ? d->small_inv29 : d->small_fwd29;
+        A.tw_full = inverse ? d->full_inv29[fi] : d->full_fwd29[fi];
+        A.tb = d->tb;
+        A.scale_load = 0; A.scale_store = 0; A.g_lo = nullptr; A.g_hi = nullptr; A.konst = c32;
+        A.in_gnark = step == 0; A.out_gnark = step == nf - 1;
+        if (step == 0 && first_load.mode) {
+            A.scale_load = first_load.mode;
+            if (first_load.mode == 1) A.konst = Fr::mul(first_load.konst, c32);
+            else { A.g_lo = table29(d, first_load.g_lo); A.g_hi = table29(d, first_load.g_hi); }
+        }
+        if (step == nf - 1 && last_store.mode) {
+            if (A.scale_load) { ctx->err = "ntt: scale on both ends of one pass"; return ZKPOR_E_ARG; }
+            A.scale_store = last_store.mode;
+            if (last_store.mode == 1) A.konst = Fr::mul(last_store.konst, c32);
+            else { A.g_lo = table29(d, last_store.g_lo); A.g_hi = table29(d, last_store.g_hi); }
+        }
+        if ((A.scale_load > 1 || A.scale_store > 1) && (!A.g_lo || !A.g_hi)) { ctx->err = "ntt: no 2^261-form table for this scale"; return ZKPOR_E_ARG; }
+        u32 blocks = (u32)(((size_t)1 << d->n) >> (fl.kb + A.clog));
+        size_t smem = ((size_t)36 << fl.kb) << A.clog;
+        if (dif) hipLaunchKernelGGL(k_ntt_pass29<true>, dim3(blocks), dim3(256), smem, ctx->stream, A);
+        else hipLaunchKernelGGL(k_ntt_pass29<false>, dim3(blocks), dim3(256), smem, ctx->stream, A);
         ZK_KERNEL_CHECK(ctx);
     }
     return ZKPOR_OK;
