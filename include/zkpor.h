@@ -71,6 +71,16 @@ void zkpor_pk_destroy(zkpor_pk* pk);
  * A and B; public/committed wires are absent for K).  Copied to HBM before returning. */
 int32_t zkpor_pk_set_g1(zkpor_pk* pk, int which, const void* pts, size_t n);
 int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n);
+/* The same arrays in gnark-crypto's COMPRESSED encoding, as pk.WriteTo puts them on disk (src/keygen/main.go:46):
+ * G1 = 32 bytes (big-endian X), G2 = 64 bytes (X.A1 | X.A0); the two top bits of the first byte are 01 infinity,
+ * 10 / 11 compressed with the lexicographically smallest / largest Y.  Decompression (one square root per point) runs on
+ * the device — the step pk.UnsafeReadFrom spends minutes of CPU time on (src/prover/prover/prover.go:336-349).
+ * ZKPOR_E_ARG if an element is not a compressed point, has X >= p, or is not on the curve (last_error names it). */
+int32_t zkpor_pk_set_g1_compressed(zkpor_pk* pk, int which, const uint8_t* compressed32, size_t n);
+int32_t zkpor_pk_set_g2_compressed(zkpor_pk* pk, int which, const uint8_t* compressed64, size_t n);
+/* stand-alone form: n compressed points -> n affine points in gnark's in-memory layout (host buffers) */
+int32_t zkpor_g1_decompress(zkpor_ctx* ctx, const uint8_t* compressed32, size_t n, void* out_affine);
+int32_t zkpor_g2_decompress(zkpor_ctx* ctx, const uint8_t* compressed64, size_t n, void* out_affine);
 /* alpha,beta,delta: G1 affine (64 B each); beta2,delta2: G2 affine (128 B each).
  * inf_a/inf_b: n_wires bytes, non-zero where pk.InfinityA/B[i] is true (may be NULL = none).
  * committed_idx: the n_committed wire indices removed from K besides the public wires (may be NULL).

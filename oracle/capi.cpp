@@ -3,6 +3,7 @@
 // little-endian limbs in Montgomery form; G1 affine = X,Y (64 B); G2 affine = X.A0,X.A1,Y.A0,Y.A1 (128 B).
 #include "algos.hpp"
 #include "poseidon.hpp"
+#include "marshal.hpp"
 #include <memory>
 
 using namespace orc;
@@ -297,6 +298,17 @@ void orc_fp12_pow_fr(const Fp* a, const Fr* e, Fp* out) {
 void orc_g2_mul_gen(const Fr* k, G2A* out) { FixedBase<Fp2> g2(g2_gen()); *out = g2.mul_aff(*k); }
 int orc_pedersen_verify_pairing(const G1A* commitment, const G1A* pok, const G2A* g2_sigma) {
     return pedersen_verify_pairing(*commitment, *pok, *g2_sigma) ? 1 : 0;
+}
+// gnark-crypto compressed point encoding (marshal.hpp)
+void orc_g1_compress(const G1A* p, size_t n, uint8_t* out) { for (size_t i = 0; i < n; ++i) g1_compress(p[i], out + 32 * i); }
+void orc_g2_compress(const G2A* p, size_t n, uint8_t* out) { for (size_t i = 0; i < n; ++i) g2_compress(p[i], out + 64 * i); }
+int orc_g1_decompress(const uint8_t* in, size_t n, G1A* out) {
+    for (size_t i = 0; i < n; ++i) { int rc = g1_decompress(in + 32 * i, &out[i]); if (rc) return rc; }
+    return 0;
+}
+int orc_g2_decompress(const uint8_t* in, size_t n, G2A* out) {
+    for (size_t i = 0; i < n; ++i) { int rc = g2_decompress(in + 64 * i, &out[i]); if (rc) return rc; }
+    return 0;
 }
 // gnark raw proof encoding of the three points (proof.WriteRawTo, prover.go:201): big-endian
 // Ar.X|Ar.Y | Bs.X.A1|Bs.X.A0|Bs.Y.A1|Bs.Y.A0 | Krs.X|Krs.Y   (256 B; commitments follow separately)

@@ -13,7 +13,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("capi.cpp", "algos.hpp", "bn254.hpp", "poseidon.hpp", "pairing.hpp", "pairing_consts.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("capi.cpp", "algos.hpp", "bn254.hpp", "poseidon.hpp", "pairing.hpp", "pairing_consts.inc", "marshal.hpp")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
@@ -376,6 +376,31 @@ def g2_mul_gen(k):
 
 def pedersen_verify_pairing(commitment, pok, g2_sigma):
     return bool(lib().orc_pedersen_verify_pairing(_p(_u64(commitment)), _p(_u64(pok)), _p(_u64(g2_sigma))))
+
+
+def g1_compress(pts):
+    pts = _u64(pts).reshape(-1, 8); out = np.empty((pts.shape[0], 32), dtype=np.uint8)
+    lib().orc_g1_compress(_p(pts), ctypes.c_size_t(pts.shape[0]), _p(out))
+    return out
+
+
+def g2_compress(pts):
+    pts = _u64(pts).reshape(-1, 16); out = np.empty((pts.shape[0], 64), dtype=np.uint8)
+    lib().orc_g2_compress(_p(pts), ctypes.c_size_t(pts.shape[0]), _p(out))
+    return out
+
+
+def g1_decompress(b):
+    """(rc, points): rc 0 ok, 1 not compressed, 2 out of range, 3 not on the curve (first offender)"""
+    b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 32); out = np.zeros((b.shape[0], 8), dtype=np.uint64)
+    rc = lib().orc_g1_decompress(_p(b), ctypes.c_size_t(b.shape[0]), _p(out))
+    return rc, out
+
+
+def g2_decompress(b):
+    b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 64); out = np.zeros((b.shape[0], 16), dtype=np.uint64)
+    rc = lib().orc_g2_decompress(_p(b), ctypes.c_size_t(b.shape[0]), _p(out))
+    return rc, out
 
 
 def proof_raw(proof256):

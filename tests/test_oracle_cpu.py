@@ -166,6 +166,32 @@ def test_groth16_verifies_under_pairing_and_rejects_forgeries():
     assert not O.pedersen_verify_pairing(c, k, O.g2_mul_gen(O.fr_random(8, 1)[0]))
 
 
+def test_compressed_point_encoding_roundtrip():
+    """oracle/marshal.hpp (gnark-crypto ecc/bn254/marshal.go restated): the generator by hand, both root choices,
+    infinity, and the three rejection reasons"""
+    g = O.g1_from_scalars(O.fr_from_ints([1]))
+    assert O.g1_compress(g)[0].tobytes() == bytes([0x80] + [0] * 30 + [1])
+    pts = O.g1_from_scalars(O.fr_random(3, 200)); pts[11] = 0
+    comp = O.g1_compress(pts)
+    rc, back = O.g1_decompress(comp)
+    assert rc == 0 and np.array_equal(back, pts)
+    assert {0x40, 0x80, 0xC0} == set(int(x) for x in np.unique(comp[:, 0] & 0xC0))
+    assert comp[11].tobytes() == bytes([0x40] + [0] * 31)
+    p2 = O.g2_from_scalars(O.fr_random(4, 100)); p2[5] = 0
+    c2 = O.g2_compress(p2)
+    rc, back2 = O.g2_decompress(c2)
+    assert rc == 0 and np.array_equal(back2, p2)
+    # the sign flag really selects the root: flipping it yields the negated point
+    flip = comp[:1].copy(); flip[0, 0] ^= 0x40
+    rc, neg = O.g1_decompress(flip)
+    assert rc == 0 and np.array_equal(neg[0, :4], pts[0, :4]) and not np.array_equal(neg[0, 4:], pts[0, 4:])
+    assert O.g1_on_curve(neg)
+    unc = comp[:1].copy(); unc[0, 0] &= 0x3F
+    assert O.g1_decompress(unc)[0] == 1
+    big = comp[:1].copy(); big[0, :] = 0xFF; big[0, 0] = 0xBF
+    assert O.g1_decompress(big)[0] == 2
+
+
 def test_merkle_tree_and_leaves_self_consistency():
     # mirrors src/utils/merkletree/merkletree_test.go (build / prove / verify round trip) and utils_test.go:43-136
     # (padding re-implementation); both are self-consistency tests in the reference as well (no golden root there)

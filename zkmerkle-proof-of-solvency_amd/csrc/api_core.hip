@@ -153,6 +153,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     else if (n == "msm_g1_variant") ctx->g1_variant = (int)value;
     else if (n == "msm_g2_variant") ctx->g2_variant = (int)value;
     else if (n == "ntt_variant") ctx->ntt_variant = (int)value;
+    else if (n == "ntt_tile_log") { if (value < 9 || value > 12) { ctx->err = "ntt_tile_log must be in [9,12]"; return ZKPOR_E_ARG; } ctx->ntt_tile_log = (int)value; }
     else if (n == "poseidon_out_idx") ctx->pos_out = (int)value;
     else if (n == "poseidon_carry_idx") ctx->pos_carry = (int)value;
     else { ctx->err = "unknown parameter " + n; return ZKPOR_E_ARG; }

@@ -31,6 +31,7 @@ struct zkpor_ctx {
     int msm_chunk = 32;
     int g1_variant = 1;  // level-1 G1 accumulation arithmetic: 0 = 8 x 32-bit limbs, 1 = 9 x 29-bit limbs (fe29.cuh)
     int g2_variant = 1;  // same for the G2 lane-pair kernel
+    int ntt_tile_log = 10;  // log2 of the elements per LDS tile of k_ntt_pass29 (36 B each)
     int ntt_variant = 1; // NTT pass arithmetic: 0 = 8 x 32-bit limbs, 1 = 9 x 29-bit lazy limbs (k_ntt_pass29)
     int pos_out = 1, pos_carry = 0;
     // Poseidon parameter tables on device (built lazily)

@@ -9,6 +9,8 @@
 
 using namespace zk;
 
+namespace zk { int32_t decompress_to_device(zkpor_ctx* ctx, bool g2, const uint8_t* host_in, size_t n, void* d_out); }  // decompress.hip
+
 struct zkpor_pk {
     zkpor_ctx* ctx = nullptr;
     // as uploaded (gnark's compacted arrays)
@@ -204,6 +206,30 @@ int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n) {
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pk->g2_raw_n = n;
     pk->ready = false;
+    return ZKPOR_OK;
+}
+
+// compressed input (what pk.WriteTo put on disk, src/keygen/main.go:46): decompressed on the device, decompress.hip
+int32_t zkpor_pk_set_g1_compressed(zkpor_pk* pk, int which, const uint8_t* compressed32, size_t n) {
+    if (!pk || which < 0 || which >= ZKPOR_G1_NUM || (n && !compressed32)) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = pk->ctx;
+    if (pk->g1_raw[which]) { ZK_HIP(ctx, hipFree(pk->g1_raw[which])); pk->g1_raw[which] = nullptr; }
+    pk->g1_raw_n[which] = 0;
+    pk->ready = false;
+    ZK_HIP(ctx, hipMalloc(&pk->g1_raw[which], (n ? n : 1) * 64));
+    ZK_TRY(zk::decompress_to_device(ctx, false, compressed32, n, pk->g1_raw[which]));
+    pk->g1_raw_n[which] = n;
+    return ZKPOR_OK;
+}
+int32_t zkpor_pk_set_g2_compressed(zkpor_pk* pk, int which, const uint8_t* compressed64, size_t n) {
+    if (!pk || which != ZKPOR_G2_B || (n && !compressed64)) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = pk->ctx;
+    if (pk->g2_raw) { ZK_HIP(ctx, hipFree(pk->g2_raw)); pk->g2_raw = nullptr; }
+    pk->g2_raw_n = 0;
+    pk->ready = false;
+    ZK_HIP(ctx, hipMalloc(&pk->g2_raw, (n ? n : 1) * 128));
+    ZK_TRY(zk::decompress_to_device(ctx, true, compressed64, n, pk->g2_raw));
+    pk->g2_raw_n = n;
     return ZKPOR_OK;
 }
 

@@ -246,6 +246,15 @@ class ProvingKey:
         pts = _u64(pts).reshape(-1, 16)
         self.ctx._ck(self.ctx.lib.zkpor_pk_set_g2(self.h, ctypes.c_int(which), _p(pts), ctypes.c_size_t(pts.shape[0])))
 
+    def set_g1_compressed(self, which, comp32):
+        """gnark-crypto compressed G1 points (n x 32 B, as pk.WriteTo stores them); decompressed on the device"""
+        comp32 = np.ascontiguousarray(comp32, dtype=np.uint8).reshape(-1, 32)
+        self.ctx._ck(self.ctx.lib.zkpor_pk_set_g1_compressed(self.h, ctypes.c_int(which), _p(comp32), ctypes.c_size_t(comp32.shape[0])))
+
+    def set_g2_compressed(self, which, comp64):
+        comp64 = np.ascontiguousarray(comp64, dtype=np.uint8).reshape(-1, 64)
+        self.ctx._ck(self.ctx.lib.zkpor_pk_set_g2_compressed(self.h, ctypes.c_int(which), _p(comp64), ctypes.c_size_t(comp64.shape[0])))
+
     def set_consts(self, alpha, beta, delta, beta2, delta2, log2_domain, inf_a, inf_b, n_wires, n_public, committed_idx=None, z_order=Z_ORDER_BITREV):
         ia = None if inf_a is None else np.ascontiguousarray(inf_a, dtype=np.uint8)
         ib = None if inf_b is None else np.ascontiguousarray(inf_b, dtype=np.uint8)
@@ -344,6 +353,22 @@ def _merkle_build_dev(self, d_leaves, n, depth, nil_leaf_mont):
     return root
 
 
+def _g1_decompress(self, comp32):
+    comp32 = np.ascontiguousarray(comp32, dtype=np.uint8).reshape(-1, 32)
+    out = np.zeros((comp32.shape[0], 8), dtype=np.uint64)
+    self._ck(self.lib.zkpor_g1_decompress(self.h, _p(comp32), ctypes.c_size_t(comp32.shape[0]), _p(out)))
+    return out
+
+
+def _g2_decompress(self, comp64):
+    comp64 = np.ascontiguousarray(comp64, dtype=np.uint8).reshape(-1, 64)
+    out = np.zeros((comp64.shape[0], 16), dtype=np.uint64)
+    self._ck(self.lib.zkpor_g2_decompress(self.h, _p(comp64), ctypes.c_size_t(comp64.shape[0]), _p(out)))
+    return out
+
+
+Context.g1_decompress = _g1_decompress
+Context.g2_decompress = _g2_decompress
 Context.poseidon_hash = _poseidon_hash
 Context.poseidon_leaves = _poseidon_leaves
 Context.merkle_build = _merkle_build
