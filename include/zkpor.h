@@ -167,6 +167,25 @@ int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n,
 /* device-resident leaves in Montgomery form (n x 32 B), root returned in Montgomery form: the bench path */
 int32_t zkpor_merkle_build_dev(zkpor_ctx* ctx, const void* d_leaves_mont, size_t n, int depth,
                                const uint64_t nil_leaf_mont[4], uint64_t root_mont[4]);
+/* ---- R1CS resident in HBM: a = L.w, b = R.w, c = O.w on the device (the evaluations computeH consumes) ----
+ * gnark evaluates these inside groth16.Prove (src/prover/prover/prover.go:269) on the CPU; with the matrices resident only
+ * the wire vector w has to cross PCIe per proof instead of a, b and c (3 x 2^26 x 32 B).  Shape follows gnark's compiled
+ * system: a term is (coefficient id, wire id), coefficients sit in one shared table, each matrix is CSR over constraints.
+ * The one-off export of (table, row_ptr, ids) from a gnark constraint system is sketched in INTEGRATION.md. */
+typedef struct zkpor_r1cs zkpor_r1cs;
+int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, const uint64_t* coeff_table /* n_coeff x 4, Montgomery */,
+                          size_t n_coeff, zkpor_r1cs** out);
+void zkpor_r1cs_destroy(zkpor_r1cs* r1cs);
+/* which: 0 = L (a), 1 = R (b), 2 = O (c); row_ptr has n_constraints + 1 entries, row_ptr[n_constraints] == nnz.
+ * Indices are validated here (ZKPOR_E_ARG), so the kernel can trust them. */
+int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r1cs, int which, const uint64_t* row_ptr, const uint32_t* coeff_ids,
+                              const uint32_t* wire_ids, size_t nnz);
+/* device buffers: w (n_wires Fr) in; a, b, c (domain_size Fr each) out, rows >= n_constraints written as zero (the
+ * padding zkpor_compute_h_dev / zkpor_prove_tail_dev expect); asynchronous on the context's stream */
+int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r1cs, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size);
+/* host buffers: a, b, c receive n_constraints elements each */
+int32_t zkpor_r1cs_eval(zkpor_r1cs* r1cs, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c);
+
 /* ---- FixedDepthMerkleTree (reference src/utils/merkletree/merkletree.go:27-52), resident in HBM ----
  * The two-phase usage of the reference: Set leaves (no hashing), Build (all internal nodes above a set leaf), then
  * Root / Get / GetProof.  Hashes cross the boundary as 32-byte big-endian canonical Fr, as the reference holds them.

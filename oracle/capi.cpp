@@ -299,6 +299,23 @@ void orc_g2_mul_gen(const Fr* k, G2A* out) { FixedBase<Fp2> g2(g2_gen()); *out =
 int orc_pedersen_verify_pairing(const G1A* commitment, const G1A* pok, const G2A* g2_sigma) {
     return pedersen_verify_pairing(*commitment, *pok, *g2_sigma) ? 1 : 0;
 }
+// the synthetic instance's R1CS as term lists: which 0 = a (L), 1 = b (R), 2 = c (O).  Pass NULL outputs to get nnz.
+size_t orc_synth_r1cs(void* p, int which, u64* row_ptr, uint32_t* wire_ids, Fr* coeffs) {
+    auto* h = (SynthHandle*)p;
+    size_t nnz = 0;
+    for (size_t j = 0; j < h->inst.rows.size(); ++j) {
+        const R1CSRow& r = h->inst.rows[j];
+        const auto& terms = which == 0 ? r.a : (which == 1 ? r.b : r.c);
+        if (row_ptr) row_ptr[j] = nnz;
+        for (auto& t : terms) {
+            if (wire_ids) wire_ids[nnz] = t.first;
+            if (coeffs) coeffs[nnz] = t.second;
+            ++nnz;
+        }
+    }
+    if (row_ptr) row_ptr[h->inst.rows.size()] = nnz;
+    return nnz;
+}
 // gnark-crypto compressed point encoding (marshal.hpp)
 void orc_g1_compress(const G1A* p, size_t n, uint8_t* out) { for (size_t i = 0; i < n; ++i) g1_compress(p[i], out + 32 * i); }
 void orc_g2_compress(const G2A* p, size_t n, uint8_t* out) { for (size_t i = 0; i < n; ++i) g2_compress(p[i], out + 64 * i); }

@@ -337,6 +337,23 @@ class Synth:
         proof256 = np.ascontiguousarray(proof256, dtype=np.uint8)
         return bool(lib().orc_synth_check(self.h, _p(_u64(r)), _p(_u64(s)), _p(proof256)))
 
+    def r1cs(self):
+        """the instance's constraint system in the product's layout: (coeff_table[n_coeff,4], [(row_ptr, coeff_ids, wire_ids)] x 3)"""
+        L = lib()
+        L.orc_synth_r1cs.restype = ctypes.c_size_t
+        mats = []; all_coeffs = []
+        for which in range(3):
+            nnz = L.orc_synth_r1cs(self.h, ctypes.c_int(which), None, None, None)
+            row_ptr = np.empty(self.n_cons + 1, dtype=np.uint64); wid = np.empty(nnz, dtype=np.uint32); co = np.empty((nnz, 4), dtype=np.uint64)
+            L.orc_synth_r1cs(self.h, ctypes.c_int(which), _p(row_ptr), _p(wid), _p(co))
+            mats.append((row_ptr, wid, co)); all_coeffs.append(co)
+        table, inv = np.unique(np.concatenate(all_coeffs), axis=0, return_inverse=True)
+        inv = inv.reshape(-1).astype(np.uint32)
+        out = []; off = 0
+        for row_ptr, wid, co in mats:
+            out.append((row_ptr, inv[off:off + co.shape[0]].copy(), wid)); off += co.shape[0]
+        return np.ascontiguousarray(table), out
+
     def verify_pairing(self, proof256):
         """groth16.Verify's equation with a real pairing; uses only the vk, the public wires and the proof"""
         proof256 = np.ascontiguousarray(proof256, dtype=np.uint8)

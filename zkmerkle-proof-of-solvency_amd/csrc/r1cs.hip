@@ -1,0 +1,149 @@
+// Constraint evaluation on the device: a = L.w, b = R.w, c = O.w for an R1CS held in HBM — SURVEY.md §8 row f1, the step
+// that feeds computeH.  In the reference this is part of gnark's solver (constraint/bn254 solver, reached through
+// groth16.Prove at src/prover/prover/prover.go:269): after the wire vector w is known, every constraint's three linear
+// expressions are evaluated on the CPU and the three 2^26 x 32 B vectors would have to cross PCIe per proof (6.4 GB).
+// With the matrices resident (about 12 GB per tier) only w crosses.
+// Layout follows gnark's compiled constraint system: a linear expression is a list of terms (coefficient id, wire id),
+// coefficients live in a small shared table (most terms use 1 or -1); three CSR matrices share the table.
+#include "common.cuh"
+
+struct zkpor_r1cs {
+    zkpor_ctx* ctx = nullptr;
+    size_t n_constraints = 0, n_wires = 0, n_coeff = 0;
+    zk::Fr* coeff = nullptr;       // Montgomery
+    uint8_t* coeff_kind = nullptr;  // 0 generic, 1 = one, 2 = minus one, 3 = zero
+    uint64_t* row_ptr[3] = {nullptr, nullptr, nullptr};
+    uint32_t* cid[3] = {nullptr, nullptr, nullptr};
+    uint32_t* wid[3] = {nullptr, nullptr, nullptr};
+    size_t nnz[3] = {0, 0, 0};
+};
+
+namespace zk {
+
+struct R1csDev {
+    const Fr* coeff; const uint8_t* kind;
+    const uint64_t* row_ptr[3]; const u32* cid[3]; const u32* wid[3];
+};
+
+// one thread per (matrix, row); rows beyond n_constraints are the zero padding computeH expects
+__global__ __launch_bounds__(256) void k_r1cs_eval(R1csDev M, const Fr* __restrict__ w, size_t n_constraints, size_t domain,
+                                                   Fr* __restrict__ a, Fr* __restrict__ b, Fr* __restrict__ c) {
+    const size_t row = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const int m = blockIdx.y;
+    if (row >= domain) return;
+    Fr acc = Fr::zero();
+    if (row < n_constraints) {
+        const uint64_t t0 = M.row_ptr[m][row], t1 = M.row_ptr[m][row + 1];
+        for (uint64_t t = t0; t < t1; ++t) {
+            const u32 ci = M.cid[m][t];
+            const uint8_t kind = M.kind[ci];
+            if (kind == 3) continue;
+            const Fr x = w[M.wid[m][t]];
+            if (kind == 1) acc = Fr::add(acc, x);
+            else if (kind == 2) acc = Fr::sub(acc, x);
+            else acc = Fr::add(acc, Fr::mul(M.coeff[ci], x));
+        }
+    }
+    Fr* out = m == 0 ? a : (m == 1 ? b : c);
+    out[row] = acc;
+}
+
+static void r1cs_free(zkpor_r1cs* r) {
+    if (r->coeff) (void)hipFree(r->coeff);
+    if (r->coeff_kind) (void)hipFree(r->coeff_kind);
+    for (int m = 0; m < 3; ++m) {
+        if (r->row_ptr[m]) (void)hipFree(r->row_ptr[m]);
+        if (r->cid[m]) (void)hipFree(r->cid[m]);
+        if (r->wid[m]) (void)hipFree(r->wid[m]);
+    }
+    delete r;
+}
+
+}  // namespace zk
+
+using namespace zk;
+extern "C" {
+
+int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, const uint64_t* coeff_table, size_t n_coeff,
+                          zkpor_r1cs** out) {
+    if (!ctx || !out || !coeff_table || n_coeff == 0 || n_wires == 0 || n_wires > 0xffffffffull) return ZKPOR_E_ARG;
+    zkpor_r1cs* r = new zkpor_r1cs();
+    r->ctx = ctx; r->n_constraints = n_constraints; r->n_wires = n_wires; r->n_coeff = n_coeff;
+    std::vector<uint8_t> kind(n_coeff, 0);
+    const Fr* tab = (const Fr*)coeff_table;
+    const Fr one = Fr::one(), mone = Fr::neg(one);
+    for (size_t i = 0; i < n_coeff; ++i) {
+        if (tab[i].is_zero()) kind[i] = 3;
+        else if (memcmp(&tab[i], &one, sizeof(Fr)) == 0) kind[i] = 1;
+        else if (memcmp(&tab[i], &mone, sizeof(Fr)) == 0) kind[i] = 2;
+    }
+    if (hipMalloc((void**)&r->coeff, n_coeff * sizeof(Fr)) != hipSuccess || hipMalloc((void**)&r->coeff_kind, n_coeff) != hipSuccess) {
+        (void)hipGetLastError(); r1cs_free(r); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM;
+    }
+    if (hipMemcpy(r->coeff, tab, n_coeff * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(r->coeff_kind, kind.data(), n_coeff, hipMemcpyHostToDevice) != hipSuccess) { r1cs_free(r); ctx->err = "r1cs: H2D failed"; return ZKPOR_E_HIP; }
+    *out = r;
+    return ZKPOR_OK;
+}
+void zkpor_r1cs_destroy(zkpor_r1cs* r) {
+    if (!r) return;
+    (void)hipStreamSynchronize(r->ctx->stream);
+    r1cs_free(r);
+}
+int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr, const uint32_t* coeff_ids, const uint32_t* wire_ids,
+                              size_t nnz) {
+    if (!r || which < 0 || which > 2 || !row_ptr || (nnz && (!coeff_ids || !wire_ids))) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = r->ctx;
+    // validate on the host: the kernel indexes with these
+    if (row_ptr[0] != 0 || row_ptr[r->n_constraints] != nnz) { ctx->err = "r1cs: row_ptr does not span the terms"; return ZKPOR_E_ARG; }
+    for (size_t i = 0; i < r->n_constraints; ++i) if (row_ptr[i + 1] < row_ptr[i]) { ctx->err = "r1cs: row_ptr is not monotone"; return ZKPOR_E_ARG; }
+    for (size_t t = 0; t < nnz; ++t)
+        if (coeff_ids[t] >= r->n_coeff || wire_ids[t] >= r->n_wires) { ctx->err = "r1cs: term " + std::to_string(t) + " indexes outside the tables"; return ZKPOR_E_ARG; }
+    if (r->row_ptr[which]) { (void)hipFree(r->row_ptr[which]); r->row_ptr[which] = nullptr; }
+    if (r->cid[which]) { (void)hipFree(r->cid[which]); r->cid[which] = nullptr; }
+    if (r->wid[which]) { (void)hipFree(r->wid[which]); r->wid[which] = nullptr; }
+    if (hipMalloc((void**)&r->row_ptr[which], (r->n_constraints + 1) * 8) != hipSuccess || hipMalloc((void**)&r->cid[which], (nnz ? nnz : 1) * 4) != hipSuccess ||
+        hipMalloc((void**)&r->wid[which], (nnz ? nnz : 1) * 4) != hipSuccess) { (void)hipGetLastError(); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM; }
+    ZK_HIP(ctx, hipMemcpy(r->row_ptr[which], row_ptr, (r->n_constraints + 1) * 8, hipMemcpyHostToDevice));
+    if (nnz) {
+        ZK_HIP(ctx, hipMemcpy(r->cid[which], coeff_ids, nnz * 4, hipMemcpyHostToDevice));
+        ZK_HIP(ctx, hipMemcpy(r->wid[which], wire_ids, nnz * 4, hipMemcpyHostToDevice));
+    }
+    r->nnz[which] = nnz;
+    return ZKPOR_OK;
+}
+int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
+    if (!r || !d_w || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = r->ctx;
+    if (domain_size < r->n_constraints) { ctx->err = "r1cs: domain smaller than the constraint count"; return ZKPOR_E_ARG; }
+    for (int m = 0; m < 3; ++m) if (!r->row_ptr[m]) { ctx->err = "r1cs: matrix " + std::to_string(m) + " not loaded"; return ZKPOR_E_STATE; }
+    if (domain_size == 0) return ZKPOR_OK;
+    R1csDev M;
+    M.coeff = r->coeff; M.kind = r->coeff_kind;
+    for (int m = 0; m < 3; ++m) { M.row_ptr[m] = r->row_ptr[m]; M.cid[m] = r->cid[m]; M.wid[m] = r->wid[m]; }
+    PhaseScope ps(ctx, "r1cs_eval");
+    hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((domain_size + 255) / 256), 3), dim3(256), 0, ctx->stream, M, (const Fr*)d_w,
+                       r->n_constraints, domain_size, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+/* host-buffer form for tests and small circuits: w in, a/b/c (n_constraints each) out */
+int32_t zkpor_r1cs_eval(zkpor_r1cs* r, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c) {
+    if (!r || !w || !a || !b || !c) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = r->ctx;
+    const size_t n = r->n_constraints;
+    Fr* d = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&d, (r->n_wires + 3 * (n ? n : 1)) * sizeof(Fr)));
+    int32_t rc = ZKPOR_OK;
+    if (hipMemcpyAsync(d, w, r->n_wires * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "r1cs: H2D failed"; rc = ZKPOR_E_HIP; }
+    Fr* da = d + r->n_wires;
+    if (rc == ZKPOR_OK) rc = zkpor_r1cs_eval_dev(r, d, da, da + n, da + 2 * n, n);
+    uint64_t* outs[3] = {a, b, c};
+    for (int m = 0; m < 3 && rc == ZKPOR_OK && n; ++m)
+        if (hipMemcpyAsync(outs[m], da + m * n, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "r1cs: D2H failed"; rc = ZKPOR_E_HIP; }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

@@ -459,3 +459,37 @@ def verify_proof(ctx, root, key, proof, leaf, depth):
     if len(proof) != depth or key >= (1 << depth):
         return False
     return bool(verify_proofs(ctx, root, [key], np.frombuffer(b"".join(proof), dtype=np.uint8), np.frombuffer(bytes(leaf), dtype=np.uint8), depth)[0])
+
+
+class R1CS:
+    """constraint matrices resident on the device (include/zkpor.h zkpor_r1cs_*): a, b, c = L.w, R.w, O.w"""
+
+    def __init__(self, ctx, n_constraints, n_wires, coeff_table):
+        self.ctx = ctx
+        self.n_constraints = n_constraints; self.n_wires = n_wires
+        coeff_table = _u64(coeff_table).reshape(-1, 4)
+        h = ctypes.c_void_p()
+        ctx._ck(ctx.lib.zkpor_r1cs_create(ctx.h, ctypes.c_size_t(n_constraints), ctypes.c_size_t(n_wires), _p(coeff_table),
+                                          ctypes.c_size_t(coeff_table.shape[0]), ctypes.byref(h)))
+        self.h = h
+
+    def set_matrix(self, which, row_ptr, coeff_ids, wire_ids):
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        coeff_ids = np.ascontiguousarray(coeff_ids, dtype=np.uint32); wire_ids = np.ascontiguousarray(wire_ids, dtype=np.uint32)
+        assert row_ptr.shape[0] == self.n_constraints + 1 and coeff_ids.shape == wire_ids.shape
+        self.ctx._ck(self.ctx.lib.zkpor_r1cs_set_matrix(self.h, ctypes.c_int(which), _p(row_ptr), _p(coeff_ids), _p(wire_ids), ctypes.c_size_t(coeff_ids.shape[0])))
+
+    def eval(self, w):
+        w = _u64(w).reshape(-1, 4)
+        assert w.shape[0] == self.n_wires
+        a = np.empty((self.n_constraints, 4), np.uint64); b = np.empty_like(a); c = np.empty_like(a)
+        self.ctx._ck(self.ctx.lib.zkpor_r1cs_eval(self.h, _p(w), _p(a), _p(b), _p(c)))
+        return a, b, c
+
+    def eval_dev(self, d_w, d_a, d_b, d_c, domain_size):
+        self.ctx._ck(self.ctx.lib.zkpor_r1cs_eval_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c), ctypes.c_size_t(domain_size)))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.zkpor_r1cs_destroy(self.h)
+            self.h = None
