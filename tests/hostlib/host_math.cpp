@@ -127,4 +127,42 @@ int hm_fr29_pack_roundtrip(const Fr* a, int negate, Fr* o, size_t n) {
     }
     return ok;
 }
+// general XYZZ + XYZZ in the 29-bit form (xyzz29_add / xyzz29_dbl): the points are first summed in `groups` round-robin
+// accumulators with mixed additions, then the accumulators are folded with the general addition; `dup` folds accumulator 0
+// in twice (forces the doubling branch), and finally the total is added to its own negation when `cancel` is set.
+void hm_g1_sum29_general(const G1Affine* p, size_t n, int groups, int dup, int cancel, G1Affine* out, uint32_t* max_top_limb) {
+    XYZZ29 acc[16];
+    for (int g = 0; g < groups; ++g) acc[g] = XYZZ29::inf();
+    for (size_t i = 0; i < n; ++i) {
+        if (p[i].is_inf()) continue;
+        xyzz29_madd<Fp29>(acc[i % groups], Fp29::from32<5>(p[i].x), Fp29::from32<5>(p[i].y));
+    }
+    uint32_t mt = 0;
+    auto track = [&](const XYZZ29& a) {
+        const Fp29* c[4] = {&a.x, &a.y, &a.zz, &a.zzz};
+        for (auto* f : c) {
+            int32_t top = (int32_t)f->l[8];
+            uint32_t v = (uint32_t)(top < 0 ? -top : top);
+            if (v > mt) mt = v;
+            for (int k = 0; k < 8; ++k) { int32_t l = (int32_t)f->l[k]; if (l < -8 || l > (1 << 29) + 8) mt = 0xffffffffu; }
+        }
+    };
+    XYZZ29 tot = XYZZ29::inf();
+    for (int g = 0; g < groups; ++g) { xyzz29_add<Fp29>(tot, acc[g]); track(tot); }
+    if (dup) {  // tot := 2 * tot through the P == Q branch, then a plain general doubling on top
+        XYZZ29 copy = tot;
+        xyzz29_add<Fp29>(tot, copy); track(tot);
+        tot = xyzz29_dbl<Fp29>(tot); track(tot);
+    }
+    if (cancel) {
+        XYZZ29 neg = tot;
+        neg.y = Fp29::neg(neg.y);
+        xyzz29_add<Fp29>(tot, neg);
+    }
+    *max_top_limb = mt;
+    G1XYZZ o;
+    if (tot.is_inf()) o = G1XYZZ::inf();
+    else { o.x = Fp29::to32_div32(tot.x); o.y = Fp29::to32_div32(tot.y); o.zz = Fp29::to32_div32(tot.zz); o.zzz = Fp29::to32_div32(tot.zzz); }
+    *out = xyzz_to_affine<Fp>(o);
+}
 }

@@ -86,6 +86,27 @@ def test_mixed_addition_matches_oracle_and_stays_bounded():
     assert not out.any()
 
 
+def test_general_addition_and_doubling():
+    """xyzz29_add / xyzz29_dbl (the partial-sum recursion and the bucket reduction): fold round-robin partial sums, the
+    P == Q branch, a general doubling, and P + (-P)"""
+    L = _lib()
+    n = 300
+    pts = O.g1_from_scalars(O.fr_random(21, n)); pts[17] = 0
+    ones = O.fr_from_ints([1] * n)
+    total = O.g1_msm(pts, ones, -1)
+    out = np.empty(8, np.uint64); top = ctypes.c_uint32()
+    for groups in (1, 2, 7, 16):
+        L.hm_g1_sum29_general(_p(pts), ctypes.c_size_t(n), groups, 0, 0, _p(out), ctypes.byref(top))
+        assert np.array_equal(out, total) and top.value < (1 << 25)
+    L.hm_g1_sum29_general(_p(pts), ctypes.c_size_t(n), 5, 1, 0, _p(out), ctypes.byref(top))
+    assert np.array_equal(out, O.g1_msm(pts, O.fr_from_ints([4] * n), -1)) and top.value < (1 << 25)
+    L.hm_g1_sum29_general(_p(pts), ctypes.c_size_t(n), 5, 1, 1, _p(out), ctypes.byref(top))
+    assert not out.any()
+    # fewer points than accumulators: empty accumulators are skipped
+    L.hm_g1_sum29_general(_p(pts[:3].copy()), ctypes.c_size_t(3), 16, 0, 0, _p(out), ctypes.byref(top))
+    assert np.array_equal(out, O.g1_msm(pts[:3], ones[:3], -1))
+
+
 def test_scalar_field_product_and_reductions():
     """Fr on the same limbs (the NTT's arithmetic): product, the product-free reduce32 on +/-32a for both fields, and the
     reduce32_pos -> pack32 -> from32<0> memory form of the inter-pass arrays"""

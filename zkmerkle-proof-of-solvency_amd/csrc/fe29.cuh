@@ -369,6 +369,49 @@ ZK_HD void xyzz29_madd(XYZZ29T<F>& acc, const F& x2, const F& y2) {
     acc.zzz = F::mul(acc.zzz, PPP);
 }
 
+// general doubling, dbl-2008-s-1 (a = 0).  Bounds: X1 < 4.7, Y1 < 2.3 | U < 4.6, V < 1.2, W,S < 1.1 | M = 3 X1^2 < 3.4 |
+// X3 = M^2 - 2S < 3.2 | D = S - X3 < 4.3 | Y3 = M*D - W*Y1 < 1.1
+template <class F>
+ZK_HD XYZZ29T<F> xyzz29_dbl(const XYZZ29T<F>& p) {
+    if (p.is_inf()) return p;
+    F U = F::add_n(p.y, p.y);
+    F V = F::sqr(U);
+    F W = F::mul(U, V);
+    F S = F::mul(p.x, V);
+    F X2 = F::sqr(p.x);
+    F M = F::normed(F::add_l(F::add_l(X2, X2), X2));
+    F X3 = F::normed(F::sub_l(F::sub_l(F::sqr(M), S), S));
+    F Y3 = F::y3(M, F::sub_n(S, X3), p.y, W);
+    return {X3, Y3, F::mul(V, p.zz), F::mul(W, p.zzz)};
+}
+
+// acc += p, both XYZZ: add-2008-s with the exceptional cases.  Bounds (inputs as left by madd / add / dbl: X < 4.7, Y < 2.3,
+// ZZ, ZZZ < 1.1): U1,U2,S1,S2 < 1.1 | P,R < 2.2 | PP,PPP,Q < 1.1 | X3 = R^2 - PPP - 2Q < 4.2 | D = Q - X3 < 5.3 |
+// Y3 = R*D - S1*PPP < 1.1 | ZZ3, ZZZ3 < 1.1
+template <class F>
+ZK_HD void xyzz29_add(XYZZ29T<F>& acc, const XYZZ29T<F>& p) {
+    if (p.is_inf()) return;
+    if (acc.is_inf()) { acc = p; return; }
+    F U1 = F::mul(acc.x, p.zz), U2 = F::mul(p.x, acc.zz);
+    F S1 = F::mul(acc.y, p.zzz), S2 = F::mul(p.y, acc.zzz);
+    F Pd = F::sub_n(U2, U1);
+    F Rd = F::sub_n(S2, S1);
+    if (Pd.zero_mod_p()) {
+        if (Rd.zero_mod_p()) acc = xyzz29_dbl<F>(p);
+        else acc = XYZZ29T<F>::inf();
+        return;
+    }
+    F PP = F::sqr(Pd);
+    F PPP = F::mul(Pd, PP);
+    F Q = F::mul(U1, PP);
+    F X3 = F::normed(F::sub_l(F::sub_l(F::sub_l(F::sqr(Rd), PPP), Q), Q));
+    F D = F::sub_n(Q, X3);
+    acc.y = F::y3(Rd, D, S1, PPP);
+    acc.x = X3;
+    acc.zz = F::mul(F::mul(acc.zz, p.zz), PP);
+    acc.zzz = F::mul(F::mul(acc.zzz, p.zzz), PPP);
+}
+
 typedef XYZZ29T<Fp29> XYZZ29;
 
 // Raw accumulator image: the 4 x 9 signed limbs as they sit in registers (144 B, R' domain, lazily reduced; all-zero =

@@ -18,6 +18,8 @@
 // the prover runs 1-2 once and 3-5 four times against wire-indexed key arrays (DigitStream below).
 #pragma once
 #include "common.cuh"
+#include "fe29.cuh"
+#include <type_traits>
 
 namespace zk {
 
@@ -66,12 +68,25 @@ inline MsmCfg msm_cfg(zkpor_ctx* ctx, size_t n) {
 // defined next to the kernel instantiations (one translation unit per field / inlining policy)
 int32_t launch_decompose(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, u32* keys, u32* vals, u32* counter);
 int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L, u32 NB,
-                      XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part, void* raw);
+                      XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part);
 int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L, u32 NB,
-                      XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part, void* raw);
-// level 1 clears the buckets itself; `raw` = scratch for the 29-bit kernels' register images: raw_bytes<F>(NB, T1)
+                      XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part);
+// the 29-bit pipeline: buckets, partials and running sums are raw XYZZ29 register images (36 words per Fp component);
+// level 1 clears the buckets itself
+int32_t launch_level1_29(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L, u32 NB,
+                         u32* braw, u32* out_keys, u32* praw);
+int32_t launch_level1_29(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L, u32 NB,
+                         u32* braw, u32* out_keys, u32* praw);
 template <class F>
-inline size_t raw_bytes(size_t NB, size_t T1) { return (NB + T1) * (sizeof(XYZZ<F>) / 32 * 36); }
+int32_t launch_levelN29(zkpor_ctx* ctx, const u32* keys, const u32* src, u32 M, int L, u32* braw, u32* out_keys, u32* out_part);
+template <class F>
+int32_t launch_reduce29(zkpor_ctx* ctx, const u32* Sin, const u32* Yin, u32 n_groups, u32 g, int dbl, u32* Sout, u32* Yout);
+template <> int32_t launch_levelN29<Fp>(zkpor_ctx*, const u32*, const u32*, u32, int, u32*, u32*, u32*);
+template <> int32_t launch_levelN29<Fp2>(zkpor_ctx*, const u32*, const u32*, u32, int, u32*, u32*, u32*);
+template <> int32_t launch_reduce29<Fp>(zkpor_ctx*, const u32*, const u32*, u32, u32, int, u32*, u32*);
+template <> int32_t launch_reduce29<Fp2>(zkpor_ctx*, const u32*, const u32*, u32, u32, int, u32*, u32*);
+template <class F>
+constexpr size_t raw_words() { return sizeof(XYZZ<F>) / 128 * 36; }  // 36 (G1) or 72 (G2) u32 per accumulator image
 int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp>* src, u32 M, int L, XYZZ<Fp>* buckets,
                       u32* out_keys, XYZZ<Fp>* out_part);
 int32_t launch_levelN(zkpor_ctx* ctx, const u32* keys, const XYZZ<Fp2>* src, u32 M, int L, XYZZ<Fp2>* buckets,
@@ -133,13 +148,13 @@ inline size_t accumulate_ws_bytes(const MsmCfg& cfg, size_t max_entries) {
     WsPlan p;
     size_t T1 = (max_entries + cfg.L - 1) / cfg.L;
     size_t T2 = (2 * T1 + cfg.L - 1) / cfg.L;
-    p.add<XYZZ<F>>(cfg.NB);
-    p.add<XYZZ<F>>(2 * T1 + 2); p.add<u32>(2 * T1 + 2);
-    p.add<XYZZ<F>>(2 * T2 + 2); p.add<u32>(2 * T2 + 2);
+    const size_t img = raw_words<F>() * 4;  // the raw 29-bit image is the larger of the two element formats
+    p.add<char>(cfg.NB * img);
+    p.add<char>((2 * T1 + 2) * img); p.add<u32>(2 * T1 + 2);
+    p.add<char>((2 * T2 + 2) * img); p.add<u32>(2 * T2 + 2);
     size_t half = (size_t)cfg.NB / 2 + 1;
-    p.add<XYZZ<F>>(half); p.add<XYZZ<F>>(half);              // S, Y of odd levels
-    p.add<XYZZ<F>>(half / 2 + 1); p.add<XYZZ<F>>(half / 2 + 1);  // S, Y of even levels
-    p.add<char>(raw_bytes<F>(cfg.NB, T1));
+    p.add<char>(half * img); p.add<char>(half * img);                  // S, Y of odd levels
+    p.add<char>((half / 2 + 1) * img); p.add<char>((half / 2 + 1) * img);  // S, Y of even levels
     return p.total;
 }
 
@@ -147,7 +162,8 @@ struct MsmPending {  // a multi-exponentiation whose kernels are queued; its per
     MsmCfg cfg;
     u64 Kmul = 0;
     bool empty = true;
-    void* hS = nullptr;  // W x XYZZ<F>, pinned
+    bool raw29 = false;  // finals are raw 29-bit images (converted on the host) rather than XYZZ<F>
+    void* hS = nullptr;  // W finals, pinned
     void* hY = nullptr;
 };
 
@@ -164,54 +180,84 @@ inline int32_t msm_accumulate_launch(zkpor_ctx* ctx, const DigitStream& ds, cons
     const int L = cfg.L;
     size_t T1 = ((size_t)M + L - 1) / L;
     size_t T2 = (2 * T1 + L - 1) / L;
-    XYZZ<F>* buckets = ws_alloc<XYZZ<F>>(ctx, cfg.NB);
-    XYZZ<F>* pa = ws_alloc<XYZZ<F>>(ctx, 2 * T1 + 2); u32* ka = ws_alloc<u32>(ctx, 2 * T1 + 2);
-    XYZZ<F>* pb = ws_alloc<XYZZ<F>>(ctx, 2 * T2 + 2); u32* kb = ws_alloc<u32>(ctx, 2 * T2 + 2);
+    const bool raw = std::is_same<F, Fp>::value ? ctx->g1_variant == 1 : ctx->g2_variant == 1;
+    const size_t img = raw_words<F>() * 4;
+    char* buckets = ws_alloc<char>(ctx, cfg.NB * img);
+    char* pa = ws_alloc<char>(ctx, (2 * T1 + 2) * img); u32* ka = ws_alloc<u32>(ctx, 2 * T1 + 2);
+    char* pb = ws_alloc<char>(ctx, (2 * T2 + 2) * img); u32* kb = ws_alloc<u32>(ctx, 2 * T2 + 2);
     size_t half = (size_t)cfg.NB / 2 + 1;
-    XYZZ<F>* Sa = ws_alloc<XYZZ<F>>(ctx, half); XYZZ<F>* Ya = ws_alloc<XYZZ<F>>(ctx, half);
-    XYZZ<F>* Sb = ws_alloc<XYZZ<F>>(ctx, half / 2 + 1); XYZZ<F>* Yb = ws_alloc<XYZZ<F>>(ctx, half / 2 + 1);
-    char* raw = ws_alloc<char>(ctx, raw_bytes<F>(cfg.NB, T1));
-    if (!buckets || !pa || !ka || !pb || !kb || !Sa || !Ya || !Sb || !Yb || !raw) {
+    char* Sa = ws_alloc<char>(ctx, half * img); char* Ya = ws_alloc<char>(ctx, half * img);
+    char* Sb = ws_alloc<char>(ctx, (half / 2 + 1) * img); char* Yb = ws_alloc<char>(ctx, (half / 2 + 1) * img);
+    if (!buckets || !pa || !ka || !pb || !kb || !Sa || !Ya || !Sb || !Yb) {
         ctx->err = "msm: workspace too small"; return ZKPOR_E_OOM;
     }
+    out->raw29 = raw;
     {
         PhaseScope ps(ctx, "msm_accumulate");
-        ZK_TRY(launch_level1(ctx, ds.keys, ds.vals, d_pts, M, L, (u32)cfg.NB, buckets, ka, pa, raw));
+        if (raw) ZK_TRY(launch_level1_29(ctx, ds.keys, ds.vals, d_pts, M, L, (u32)cfg.NB, (u32*)buckets, ka, (u32*)pa));
+        else ZK_TRY(launch_level1(ctx, ds.keys, ds.vals, d_pts, M, L, (u32)cfg.NB, (XYZZ<F>*)buckets, ka, (XYZZ<F>*)pa));
         size_t T = T1;
-        XYZZ<F>* src = pa; u32* srck = ka; XYZZ<F>* dst = pb; u32* dstk = kb;
+        char* src = pa; u32* srck = ka; char* dst = pb; u32* dstk = kb;
         while (T > 1) {
             u32 Mn = (u32)(2 * T);
             size_t Tn = ((size_t)Mn + L - 1) / L;
-            ZK_TRY(launch_levelN(ctx, srck, src, Mn, L, buckets, dstk, dst));
+            if (raw) ZK_TRY(launch_levelN29<F>(ctx, srck, (const u32*)src, Mn, L, (u32*)buckets, dstk, (u32*)dst));
+            else ZK_TRY(launch_levelN(ctx, srck, (const XYZZ<F>*)src, Mn, L, (XYZZ<F>*)buckets, dstk, (XYZZ<F>*)dst));
             std::swap(src, dst); std::swap(srck, dstk);
             T = Tn;
         }
     }
-    const XYZZ<F>* fin_S = nullptr;
-    const XYZZ<F>* fin_Y = nullptr;
+    const char* fin_S = nullptr;
+    const char* fin_Y = nullptr;
     u64 Kmul = 0;  // g_1 + g_1 g_2 + ... + g_1..g_{L-1}
     {
         PhaseScope ps(ctx, "msm_reduce");
         int rem = cfg.c - 1, done_bits = 0, level = 0;
         u32 count = cfg.NB;  // elements at the current level (all windows)
-        const XYZZ<F>* Sin = buckets;
-        const XYZZ<F>* Yin = nullptr;
+        const char* Sin = buckets;
+        const char* Yin = nullptr;
         while (rem > 0) {
             int gl = rem < 4 ? rem : 4;
             u32 ng = count >> gl;
-            XYZZ<F>* So = (level & 1) ? Sb : Sa;
-            XYZZ<F>* Yo = (level & 1) ? Yb : Ya;
-            ZK_TRY(launch_reduce(ctx, Sin, Yin, ng, 1u << gl, done_bits, So, Yo));
+            char* So = (level & 1) ? Sb : Sa;
+            char* Yo = (level & 1) ? Yb : Ya;
+            if (raw) ZK_TRY(launch_reduce29<F>(ctx, (const u32*)Sin, (const u32*)Yin, ng, 1u << gl, done_bits, (u32*)So, (u32*)Yo));
+            else ZK_TRY(launch_reduce(ctx, (const XYZZ<F>*)Sin, (const XYZZ<F>*)Yin, ng, 1u << gl, done_bits, (XYZZ<F>*)So, (XYZZ<F>*)Yo));
             done_bits += gl; rem -= gl; count = ng; Sin = So; Yin = Yo; ++level;
             if (rem > 0) Kmul += (u64)1 << done_bits;
         }
         fin_S = Sin; fin_Y = Yin;
     }
     const size_t Wn = (size_t)cfg.W;
+    const size_t fin_bytes = Wn * (raw ? img : sizeof(XYZZ<F>));
     out->Kmul = Kmul;
-    ZK_HIP(ctx, hipMemcpyAsync(pinned_S, fin_S, Wn * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipMemcpyAsync(pinned_Y, fin_Y, Wn * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(pinned_S, fin_S, fin_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(pinned_Y, fin_Y, fin_bytes, hipMemcpyDeviceToHost, ctx->stream));
     return ZKPOR_OK;
+}
+
+// raw 29-bit image -> XYZZ<F> on the host (portable path of fe29.cuh)
+inline Fp raw29_fp_host(const u32* w) {
+    Fp29 v;
+    for (int i = 0; i < 9; ++i) v.l[i] = w[i];
+    return Fp29::to32_div32(v);
+}
+inline XYZZ<Fp> raw29_to_xyzz_host(const u32* img, const Fp*) {
+    bool inf = true;
+    for (int i = 0; i < 9; ++i) inf &= img[18 + i] == 0;
+    if (inf) return XYZZ<Fp>::inf();
+    return {raw29_fp_host(img), raw29_fp_host(img + 9), raw29_fp_host(img + 18), raw29_fp_host(img + 27)};
+}
+inline XYZZ<Fp2> raw29_to_xyzz_host(const u32* img, const Fp2*) {  // [component 0: x y zz zzz][component 1: x y zz zzz]
+    bool inf = true;
+    for (int i = 0; i < 9; ++i) inf &= img[18 + i] == 0 && img[36 + 18 + i] == 0;
+    if (inf) return XYZZ<Fp2>::inf();
+    XYZZ<Fp2> r;
+    r.x = {raw29_fp_host(img), raw29_fp_host(img + 36)};
+    r.y = {raw29_fp_host(img + 9), raw29_fp_host(img + 36 + 9)};
+    r.zz = {raw29_fp_host(img + 18), raw29_fp_host(img + 36 + 18)};
+    r.zzz = {raw29_fp_host(img + 27), raw29_fp_host(img + 36 + 27)};
+    return r;
 }
 
 // after the stream has been synchronised: window sum = Y_L - Kmul * T, then Horner with 2^c over the windows (host)
@@ -221,17 +267,19 @@ inline void msm_accumulate_finish(const MsmPending& p, XYZZ<F>* result) {
     if (!p.empty) {
         const XYZZ<F>* hS = (const XYZZ<F>*)p.hS;
         const XYZZ<F>* hY = (const XYZZ<F>*)p.hY;
+        const size_t rw = raw_words<F>();
         for (int w = p.cfg.W - 1; w >= 0; --w) {
             for (int k = 0; k < p.cfg.c; ++k) acc = xyzz_dbl<F>(acc);
-            XYZZ<F> win = hY[w];
-            if (p.Kmul) xyzz_add<F>(win, xyzz_neg<F>(xyzz_mul_u64<F>(hS[w], p.Kmul)));
+            XYZZ<F> win = p.raw29 ? raw29_to_xyzz_host((const u32*)p.hY + (size_t)w * rw, (const F*)nullptr) : hY[w];
+            XYZZ<F> sw = p.raw29 ? raw29_to_xyzz_host((const u32*)p.hS + (size_t)w * rw, (const F*)nullptr) : hS[w];
+            if (p.Kmul) xyzz_add<F>(win, xyzz_neg<F>(xyzz_mul_u64<F>(sw, p.Kmul)));
             xyzz_add<F>(acc, win);
         }
     }
     *result = acc;
 }
 
-static constexpr size_t MSM_SLOT_BYTES = 128 * sizeof(XYZZ<Fp2>);  // one pinned (S or Y) slot: up to 128 windows (c = 2) of G2
+static constexpr size_t MSM_SLOT_BYTES = 128 * 288;  // one pinned (S or Y) slot: up to 128 windows (c = 2) of G2 raw images (288 B)
 
 int32_t ensure_pinned(zkpor_ctx* ctx, size_t bytes);
 

@@ -1,23 +1,15 @@
 // MSM step 3, G1, level 1 — the dominant kernel of the prover: field products fully inlined.
 #include "msm_kernels.cuh"
-#include "fe29.cuh"
+#include "msm_kernels29.cuh"
 namespace zk {
 
-__device__ __forceinline__ void store29(XYZZ<Fp>* dst, const XYZZ29& a) {
-    XYZZ<Fp> o;
-    if (a.is_inf()) o = XYZZ<Fp>::inf();
-    else { o.x = Fp29::to32_div32(a.x); o.y = Fp29::to32_div32(a.y); o.zz = Fp29::to32_div32(a.zz); o.zzz = Fp29::to32_div32(a.zzz); }
-    *dst = o;
-}
-
-// k_acc_level1<Fp> with the accumulator and all arithmetic on 9 x 29-bit limbs (fe29.cuh).  Everything on the
-// divergent key-change path is a raw register image (raw29_store): finished buckets go to `braw` (converted to the
-// 8 x 32 bucket array by k_raw29_to_buckets afterwards), a chunk's head partial is parked in `hraw` and converted with
-// the tail partial at the end of the chunk, where all lanes of the wave take the same path.
+// k_acc_level1<Fp> with the accumulator and all arithmetic on 9 x 29-bit limbs (fe29.cuh).  Everything it writes is a
+// raw register image (raw29_store): finished buckets go to `braw`, the <= 2 runs cut by the chunk edge to `praw` (2 per
+// chunk) — the key-change path, taken by some lane of a wave in about half of all iterations, is 36 plain stores.  The
+// later stages (msm_kernels29.cuh) consume the images as they are.
 __global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__ keys, const u32* __restrict__ vals,
                                                          const Affine<Fp>* __restrict__ pts, u32 M, int L,
-                                                         u32* __restrict__ braw, u32* __restrict__ hraw,
-                                                         u32* __restrict__ out_keys, XYZZ<Fp>* __restrict__ out_part) {
+                                                         u32* __restrict__ braw, u32* __restrict__ out_keys, u32* __restrict__ praw) {
     __shared__ u32 sk[256 * ACC_PITCH];
     __shared__ u32 sv[256 * ACC_PITCH];
     const u32 row0 = blockIdx.x * 256u;
@@ -47,7 +39,7 @@ __global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__
             const u32 v = sv[threadIdx.x * ACC_PITCH + (j - j0)];
             if (k != cur) {
                 const bool head = first && cur == prev;
-                raw29_store(head ? hraw + (size_t)t * RAW29_WORDS : braw + (size_t)cur * RAW29_WORDS, acc);
+                raw29_store(head ? praw + 2 * (size_t)t * RAW29_WORDS : braw + (size_t)cur * RAW29_WORDS, acc);
                 head_written |= head;
                 first = false;
                 cur = k;
@@ -66,44 +58,50 @@ __global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__
     const bool acc_tail = !acc_head && cur == next;
     if (!acc_head && !acc_tail) raw29_store(braw + (size_t)cur * RAW29_WORDS, acc);
     if (T > 1) {
-#pragma unroll 1
-        for (int s = 0; s < 2; ++s) {  // one copy of the conversion code
-            XYZZ29 v = XYZZ29::inf();
-            if (s == 0) {
-                if (head_written) v = raw29_load(hraw + (size_t)t * RAW29_WORDS);
-                else if (acc_head) v = acc;
-            } else if (acc_tail) v = acc;
-            store29(out_part + 2 * t + s, v);
-        }
+        const XYZZ29 z = XYZZ29::inf();
+        if (acc_head) raw29_store(praw + 2 * (size_t)t * RAW29_WORDS, acc);
+        else if (!head_written) raw29_store(praw + 2 * (size_t)t * RAW29_WORDS, z);
+        raw29_store(praw + (2 * (size_t)t + 1) * RAW29_WORDS, acc_tail ? acc : z);
         out_keys[2 * t] = first_key;
         out_keys[2 * t + 1] = last_key;
     }
 }
 
-__global__ __launch_bounds__(256) void k_raw29_to_buckets(const u32* __restrict__ braw, XYZZ<Fp>* __restrict__ buckets, u32 NB) {
-    const u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= NB) return;
-    store29(buckets + i, raw29_load(braw + (size_t)i * RAW29_WORDS));
-}
-
 int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L, u32 NB,
-                      XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part, void* raw) {
+                      XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part) {
     u32 T = (M + (u32)L - 1u) / (u32)L;
-    if (ctx->g1_variant == 0) {
-        ZK_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)NB * sizeof(XYZZ<Fp>), ctx->stream));
+    ZK_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)NB * sizeof(XYZZ<Fp>), ctx->stream));
+    {
         PhaseScope ps(ctx, "k_acc_level1_g1");  // the kernel alone: bench.py's roofline launch time must match rocprofv3's
         hipLaunchKernelGGL(k_acc_level1<Fp>, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
-    } else {
-        u32* braw = (u32*)raw;
-        u32* hraw = braw + (size_t)NB * RAW29_WORDS;
-        ZK_HIP(ctx, hipMemsetAsync(braw, 0, (size_t)NB * RAW29_WORDS * 4, ctx->stream));
-        {
-            PhaseScope ps(ctx, "k_acc_level1_g1");
-            hipLaunchKernelGGL(k_acc_level1_fp29, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, braw, hraw, out_keys, out_part);
-        }
-        ZK_KERNEL_CHECK(ctx);
-        hipLaunchKernelGGL(k_raw29_to_buckets, dim3((NB + 255u) / 256u), dim3(256), 0, ctx->stream, braw, buckets, NB);
     }
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+// ---- the 29-bit pipeline (raw images end to end) ----
+int32_t launch_level1_29(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L, u32 NB,
+                         u32* braw, u32* out_keys, u32* praw) {
+    u32 T = (M + (u32)L - 1u) / (u32)L;
+    ZK_HIP(ctx, hipMemsetAsync(braw, 0, (size_t)NB * RAW29_WORDS * 4, ctx->stream));
+    {
+        PhaseScope ps(ctx, "k_acc_level1_g1");
+        hipLaunchKernelGGL(k_acc_level1_fp29, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, braw, out_keys, praw);
+    }
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+template <>
+int32_t launch_levelN29<Fp>(zkpor_ctx* ctx, const u32* keys, const u32* src, u32 M, int L, u32* braw, u32* out_keys, u32* out_part) {
+    u32 T = (M + (u32)L - 1u) / (u32)L;
+    hipLaunchKernelGGL(k_acc_levelN29<Pol29G1>, dim3((T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, src, M, L, braw, out_keys, out_part);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+template <>
+int32_t launch_reduce29<Fp>(zkpor_ctx* ctx, const u32* Sin, const u32* Yin, u32 n_groups, u32 g, int dbl, u32* Sout, u32* Yout) {
+    dim3 grid((n_groups + 127u) / 128u);
+    if (Yin) hipLaunchKernelGGL((k_reduce_level29<Pol29G1, true>), grid, dim3(128), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
+    else hipLaunchKernelGGL((k_reduce_level29<Pol29G1, false>), grid, dim3(128), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

@@ -1,6 +1,7 @@
 // MSM step 3, G2, level 1: the single most expensive launch of a proof.  One G2 accumulator per LANE PAIR
 // (fp2_lanepair.cuh): even lanes carry the real, odd lanes the imaginary Fp component.
 #include "msm_kernels.cuh"
+#include "msm_kernels29.cuh"
 #include "fp2_lanepair.cuh"
 
 namespace zk {
@@ -74,17 +75,6 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair(const u32* __restrict
 }
 
 // ---- 29-bit signed lazy form of the level-1 kernel (fe29.cuh + Fp2L29) ----
-__device__ __forceinline__ void lp_store29(XYZZ<Fp2>* dst, const XYZZ29T<Fp2L29>& a, u32 par) {
-    Fp* d = (Fp*)dst;
-    if (a.is_inf()) {
-        Fp z = Fp::zero();
-        d[par] = z; d[2 + par] = z; d[4 + par] = z; d[6 + par] = z;
-    } else {
-        d[par] = Fp29::to32_div32(a.x.c); d[2 + par] = Fp29::to32_div32(a.y.c);
-        d[4 + par] = Fp29::to32_div32(a.zz.c); d[6 + par] = Fp29::to32_div32(a.zzz.c);
-    }
-}
-
 // raw register image of a lane-pair accumulator: each lane parks its own component (RAW29_WORDS words; pair = 288 B)
 __device__ __forceinline__ void lp_raw_store(u32* dst, const XYZZ29T<Fp2L29>& a, u32 par) {
     XYZZ29 c = {a.x.c, a.y.c, a.zz.c, a.zzz.c};
@@ -97,11 +87,19 @@ __device__ __forceinline__ XYZZ29T<Fp2L29> lp_raw_load(const u32* src, u32 par) 
     return a;
 }
 
-// see k_acc_level1_fp29 (msm_g1_hot.hip) for the raw bucket / head-partial scheme
+// the lane-pair policy of the 29-bit pipeline (msm_kernels29.cuh)
+struct Pol29G2 {
+    typedef Fp2L29 F;
+    typedef XYZZ29T<Fp2L29> Acc;
+    static constexpr u32 LANES = 2, WORDS = 2 * RAW29_WORDS;
+    ZK_D static Acc load(const u32* base, size_t idx, u32 par) { return lp_raw_load(base + idx * WORDS, par); }
+    ZK_D static void store(u32* base, size_t idx, const Acc& a, u32 par) { lp_raw_store(base + idx * WORDS, a, par); }
+};
+
+// see k_acc_level1_fp29 (msm_g1_hot.hip): raw images for buckets (braw) and the chunk's two partials (praw)
 __global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restrict__ keys, const u32* __restrict__ vals,
                                                              const Affine<Fp2>* __restrict__ pts, u32 M, int L,
-                                                             u32* __restrict__ braw, u32* __restrict__ hraw,
-                                                             u32* __restrict__ out_keys, XYZZ<Fp2>* __restrict__ out_part) {
+                                                             u32* __restrict__ braw, u32* __restrict__ out_keys, u32* __restrict__ praw) {
     __shared__ u32 sk[128 * ACC_PITCH];
     __shared__ u32 sv[128 * ACC_PITCH];
     typedef XYZZ29T<Fp2L29> Acc;
@@ -133,7 +131,7 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restri
             const u32 v = sv[lr * ACC_PITCH + (j - j0)];
             if (k != cur) {
                 const bool head = first && cur == prev;
-                lp_raw_store(head ? hraw + (size_t)t * (2 * RAW29_WORDS) : braw + (size_t)cur * (2 * RAW29_WORDS), acc, par);
+                lp_raw_store(head ? praw + 2 * (size_t)t * (2 * RAW29_WORDS) : braw + (size_t)cur * (2 * RAW29_WORDS), acc, par);
                 head_written |= head;
                 first = false;
                 cur = k;
@@ -158,27 +156,15 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restri
     const bool acc_tail = !acc_head && cur == next;
     if (!acc_head && !acc_tail) lp_raw_store(braw + (size_t)cur * (2 * RAW29_WORDS), acc, par);
     if (T > 1) {
-#pragma unroll 1
-        for (int s = 0; s < 2; ++s) {
-            Acc v = Acc::inf();
-            if (s == 0) {
-                if (head_written) v = lp_raw_load(hraw + (size_t)t * (2 * RAW29_WORDS), par);
-                else if (acc_head) v = acc;
-            } else if (acc_tail) v = acc;
-            lp_store29(out_part + 2 * t + s, v, par);
-        }
+        const Acc z = Acc::inf();
+        if (acc_head) lp_raw_store(praw + 2 * (size_t)t * (2 * RAW29_WORDS), acc, par);
+        else if (!head_written) lp_raw_store(praw + 2 * (size_t)t * (2 * RAW29_WORDS), z, par);
+        lp_raw_store(praw + (2 * (size_t)t + 1) * (2 * RAW29_WORDS), acc_tail ? acc : z, par);
         if (par == 0) {
             out_keys[2 * t] = first_key;
             out_keys[2 * t + 1] = last_key;
         }
     }
-}
-
-__global__ __launch_bounds__(256) void k_raw29_to_buckets_g2pair(const u32* __restrict__ braw, XYZZ<Fp2>* __restrict__ buckets, u32 NB) {
-    const u32 gt = blockIdx.x * 256u + threadIdx.x;
-    const u32 i = gt >> 1, par = gt & 1u;
-    if (i >= NB) return;
-    lp_store29(buckets + i, lp_raw_load(braw + (size_t)i * (2 * RAW29_WORDS), par), par);
 }
 
 __device__ __forceinline__ XYZZ<Fp2L> lp_load(const XYZZ<Fp2>* src, u32 par) {
@@ -275,23 +261,40 @@ int32_t launch_reduce(zkpor_ctx* ctx, const XYZZ<Fp2>* Sin, const XYZZ<Fp2>* Yin
 }
 
 int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L, u32 NB,
-                      XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part, void* raw) {
+                      XYZZ<Fp2>* buckets, u32* out_keys, XYZZ<Fp2>* out_part) {
     u32 T = (M + (u32)L - 1u) / (u32)L;
-    if (ctx->g2_variant == 0) {
-        ZK_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)NB * sizeof(XYZZ<Fp2>), ctx->stream));
+    ZK_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)NB * sizeof(XYZZ<Fp2>), ctx->stream));
+    {
         PhaseScope ps(ctx, "k_acc_level1_g2");
         hipLaunchKernelGGL(k_acc_level1_g2pair, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, buckets, out_keys, out_part);
-    } else {
-        u32* braw = (u32*)raw;
-        u32* hraw = braw + (size_t)NB * (2 * RAW29_WORDS);
-        ZK_HIP(ctx, hipMemsetAsync(braw, 0, (size_t)NB * (2 * RAW29_WORDS) * 4, ctx->stream));
-        {
-            PhaseScope ps(ctx, "k_acc_level1_g2");
-            hipLaunchKernelGGL(k_acc_level1_g2pair29, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, braw, hraw, out_keys, out_part);
-        }
-        ZK_KERNEL_CHECK(ctx);
-        hipLaunchKernelGGL(k_raw29_to_buckets_g2pair, dim3((2u * NB + 255u) / 256u), dim3(256), 0, ctx->stream, braw, buckets, NB);
     }
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+// ---- the 29-bit pipeline ----
+int32_t launch_level1_29(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L, u32 NB,
+                         u32* braw, u32* out_keys, u32* praw) {
+    u32 T = (M + (u32)L - 1u) / (u32)L;
+    ZK_HIP(ctx, hipMemsetAsync(braw, 0, (size_t)NB * (2 * RAW29_WORDS) * 4, ctx->stream));
+    {
+        PhaseScope ps(ctx, "k_acc_level1_g2");
+        hipLaunchKernelGGL(k_acc_level1_g2pair29, dim3((T + 127u) / 128u), dim3(256), 0, ctx->stream, keys, vals, pts, M, L, braw, out_keys, praw);
+    }
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+template <>
+int32_t launch_levelN29<Fp2>(zkpor_ctx* ctx, const u32* keys, const u32* src, u32 M, int L, u32* braw, u32* out_keys, u32* out_part) {
+    u32 T = (M + (u32)L - 1u) / (u32)L;
+    hipLaunchKernelGGL(k_acc_levelN29<Pol29G2>, dim3((2u * T + 255u) / 256u), dim3(256), 0, ctx->stream, keys, src, M, L, braw, out_keys, out_part);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+template <>
+int32_t launch_reduce29<Fp2>(zkpor_ctx* ctx, const u32* Sin, const u32* Yin, u32 n_groups, u32 g, int dbl, u32* Sout, u32* Yout) {
+    dim3 grid((2u * n_groups + 127u) / 128u);
+    if (Yin) hipLaunchKernelGGL((k_reduce_level29<Pol29G2, true>), grid, dim3(128), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
+    else hipLaunchKernelGGL((k_reduce_level29<Pol29G2, false>), grid, dim3(128), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
