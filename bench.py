@@ -248,7 +248,7 @@ def main():
     dt = timed_region(dist, torch.cuda.synchronize, lambda: run_steps(args.steps))
 
     phases = {}
-    for name in ("msm_decompose", "msm_sort", "msm_accumulate", "msm_reduce", "k_acc_level1_g1", "k_acc_level1_g2", "ntt", "pointwise"):
+    for name in ("msm_decompose", "msm_sort", "msm_accumulate", "msm_reduce", "k_acc_level1_g1", "k_acc_level1_g2", "ntt", "pointwise", "host_assembly"):
         ms = 0.0; calls = 0
         for wk in workers:
             m_, c_ = wk[0].phase_ms(name)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <chrono>
 #include <vector>
 #include <map>
 #include <stdio.h>
@@ -113,6 +114,12 @@ struct PhaseScope {  // RAII: GPU time of everything enqueued on the stream whil
         t->pending.push_back({a, b});
         t->calls++;
     }
+};
+struct HostPhase {  // RAII: wall-clock time of host code, reported through the same phase table
+    PhaseTimer* t;
+    std::chrono::steady_clock::time_point t0;
+    HostPhase(zkpor_ctx* c, const char* name) : t(&c->phases[name]), t0(std::chrono::steady_clock::now()) {}
+    ~HostPhase() { t->ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); t->calls++; }
 };
 inline void phase_resolve(zkpor_ctx* ctx, PhaseTimer& t) {
     for (auto& pr : t.pending) {

@@ -405,6 +405,7 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
     ZK_HIP(ctx, hipStreamSynchronize(main_s));
     G1XYZZ mA, mB1, mK, mZ;
     G2XYZZ mB2;
+    HostPhase hp(ctx, "host_assembly");
     msm_accumulate_finish<Fp>(pA, &mA);
     msm_accumulate_finish<Fp>(pB1, &mB1);
     msm_accumulate_finish<Fp>(pK, &mK);
