@@ -170,9 +170,11 @@ struct Fe29T {
     ZK_HD bool is_zero_mod_p() const {
         u32 k = (l[0] * P::PINV29) & M29;
         if (k >= 64u && k <= M29 - 63u) return false;
-        return equals_kp((i32)(k << 3) >> 3);  // sign-extend the 29-bit residue
+        // limbs by value: an out-of-line MEMBER would force *this into scratch in every iteration of the callers' loops
+        return equals_kp9(l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7], l[8], (i32)(k << 3) >> 3);  // sign-extend the 29-bit residue
     }
-    ZK_HD_NOINLINE bool equals_kp(i32 k) const {
+    ZK_HD bool equals_kp(i32 k) const { return equals_kp9(l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7], l[8], k); }
+    ZK_HD_NOINLINE static bool equals_kp9(u32 a0, u32 a1, u32 a2, u32 a3, u32 a4, u32 a5, u32 a6, u32 a7, u32 a8, i32 k) {
         u32 t[9];
         i64 carry = 0;
         for (int i = 0; i < 9; ++i) {
@@ -180,8 +182,7 @@ struct Fe29T {
             t[i] = i < 8 ? (u32)(v & M29) : (u32)v;
             carry = v >> 29;
         }
-        u32 x[9];
-        for (int i = 0; i < 9; ++i) x[i] = l[i];
+        u32 x[9] = {a0, a1, a2, a3, a4, a5, a6, a7, a8};
         carry_exact(x);
         u32 d = 0;
         for (int i = 0; i < 9; ++i) d |= x[i] ^ t[i];
@@ -343,8 +344,11 @@ ZK_HD_NOINLINE XYZZ29T<F> xyzz29_dbl_affine(F x2, F y2) {
 // acc += (x2, y2): madd-2008-s.  Magnitude bounds (units of p, R'/p = 169; real | complex components):
 //   x2,y2 < 32 | ZZ,ZZZ < 1.1 | X1 < 4.2|4.7, Y1 < 1.1|2.3 | U2,S2 < 1.4 | P < 5.4|6.1, R < 2.3|3.7 | PP < 1.9, PPP,Q < 1.2
 //   X3 = R^2 - PPP - 2Q | D = Q - X3 < 5.8 | Y3 = R*D - Y1*PPP (real: one fused reduction)
-template <class F>
-ZK_HD void xyzz29_madd(XYZZ29T<F>& acc, const F& x2, const F& y2) {
+// `dbl` supplies 2*(x2, y2) in the (rare) P == Q case.  The kernels pass a callable that re-reads the point from memory
+// inside an out-of-line function: handing x2, y2 to one by value made the compiler park 72 bytes in scratch in EVERY
+// iteration (measured: 25 GB of extra HBM writes per launch).
+template <class F, class Dbl>
+ZK_HD void xyzz29_madd(XYZZ29T<F>& acc, const F& x2, const F& y2, Dbl dbl) {
     if (acc.is_inf()) {  // divergent whenever any lane of the wave starts a bucket: keep it free of products
         acc.x = F::reduce32(x2); acc.y = F::reduce32(y2); acc.zz = F::one(); acc.zzz = acc.zz;
         return;
@@ -354,7 +358,7 @@ ZK_HD void xyzz29_madd(XYZZ29T<F>& acc, const F& x2, const F& y2) {
     F Pd = F::sub_n(U2, acc.x);
     F Rd = F::sub_n(S2, acc.y);
     if (Pd.zero_mod_p()) {
-        if (Rd.zero_mod_p()) acc = xyzz29_dbl_affine<F>(x2, y2);
+        if (Rd.zero_mod_p()) acc = dbl();
         else acc = XYZZ29T<F>::inf();
         return;
     }
@@ -410,6 +414,11 @@ ZK_HD void xyzz29_add(XYZZ29T<F>& acc, const XYZZ29T<F>& p) {
     acc.x = X3;
     acc.zz = F::mul(F::mul(acc.zz, p.zz), PP);
     acc.zzz = F::mul(F::mul(acc.zzz, p.zzz), PPP);
+}
+
+template <class F>
+ZK_HD void xyzz29_madd(XYZZ29T<F>& acc, const F& x2, const F& y2) {
+    xyzz29_madd<F>(acc, x2, y2, [&]() { return xyzz29_dbl_affine<F>(x2, y2); });
 }
 
 typedef XYZZ29T<Fp29> XYZZ29;

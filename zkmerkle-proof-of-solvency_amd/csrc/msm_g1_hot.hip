@@ -3,6 +3,12 @@
 #include "msm_kernels29.cuh"
 namespace zk {
 
+// 2 * (+/- P) for a key point, out of line and fed from memory (see xyzz29_madd)
+__device__ __noinline__ XYZZ29 dbl_point_g1(const Affine<Fp>* p, bool neg) {
+    Affine<Fp> q = *p;
+    return xyzz29_dbl_affine<Fp29>(Fp29::from32<5>(q.x), Fp29::cneg(Fp29::from32<5>(q.y), neg));
+}
+
 // k_acc_level1<Fp> with the accumulator and all arithmetic on 9 x 29-bit limbs (fe29.cuh).  Everything it writes is a
 // raw register image (raw29_store): finished buckets go to `braw`, the <= 2 runs cut by the chunk edge to `praw` (2 per
 // chunk) — the key-change path, taken by some lane of a wave in about half of all iterations, is 36 plain stores.  The
@@ -48,7 +54,9 @@ __global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__
             last_key = k;
             Affine<Fp> p = pts[v >> 1];
             if (!p.is_inf()) {
-                xyzz29_madd<Fp29>(acc, Fp29::from32<5>(p.x), Fp29::cneg(Fp29::from32<5>(p.y), (v & 1u) != 0));
+                const Affine<Fp>* pp = pts + (v >> 1);
+                const bool neg = (v & 1u) != 0;
+                xyzz29_madd<Fp29>(acc, Fp29::from32<5>(p.x), Fp29::cneg(Fp29::from32<5>(p.y), neg), [=]() { return dbl_point_g1(pp, neg); });
             }
         }
     }

@@ -87,6 +87,13 @@ __device__ __forceinline__ XYZZ29T<Fp2L29> lp_raw_load(const u32* src, u32 par) 
     return a;
 }
 
+// 2 * (+/- P) for a key point, out of line and fed from memory (see xyzz29_madd in fe29.cuh)
+__device__ __noinline__ XYZZ29T<Fp2L29> dbl_point_g2(const Fp* pp, u32 par, bool neg) {
+    Fp2L29 x = {Fp29::from32<5>(pp[par])};
+    Fp2L29 y = {Fp29::cneg(Fp29::from32<5>(pp[2 + par]), neg)};
+    return xyzz29_dbl_affine<Fp2L29>(x, y);
+}
+
 // the lane-pair policy of the 29-bit pipeline (msm_kernels29.cuh)
 struct Pol29G2 {
     typedef Fp2L29 F;
@@ -147,7 +154,8 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restri
             if (nz) {
                 Fp2L29 x29 = {Fp29::from32<5>(px)};
                 Fp2L29 y29 = {Fp29::cneg(Fp29::from32<5>(py), (v & 1u) != 0)};
-                xyzz29_madd<Fp2L29>(acc, x29, y29);
+                const bool neg = (v & 1u) != 0;
+                xyzz29_madd<Fp2L29>(acc, x29, y29, [=]() { return dbl_point_g2(pp, par, neg); });
             }
         }
     }
