@@ -65,13 +65,11 @@ __global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__
     const bool acc_head = first && cur == prev;
     const bool acc_tail = !acc_head && cur == next;
     if (!acc_head && !acc_tail) raw29_store(braw + (size_t)cur * RAW29_WORDS, acc);
-    if (T > 1) {
-        const XYZZ29 z = XYZZ29::inf();
+    if (T > 1) {  // a partial that does not exist is flagged in its key (PART_EMPTY) instead of being written as zeros
         if (acc_head) raw29_store(praw + 2 * (size_t)t * RAW29_WORDS, acc);
-        else if (!head_written) raw29_store(praw + 2 * (size_t)t * RAW29_WORDS, z);
-        raw29_store(praw + (2 * (size_t)t + 1) * RAW29_WORDS, acc_tail ? acc : z);
-        out_keys[2 * t] = first_key;
-        out_keys[2 * t + 1] = last_key;
+        if (acc_tail) raw29_store(praw + (2 * (size_t)t + 1) * RAW29_WORDS, acc);
+        out_keys[2 * t] = first_key | ((acc_head || head_written) ? 0u : PART_EMPTY);
+        out_keys[2 * t + 1] = last_key | (acc_tail ? 0u : PART_EMPTY);
     }
 }
 

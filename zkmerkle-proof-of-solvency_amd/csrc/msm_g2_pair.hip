@@ -164,13 +164,11 @@ __global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restri
     const bool acc_tail = !acc_head && cur == next;
     if (!acc_head && !acc_tail) lp_raw_store(braw + (size_t)cur * (2 * RAW29_WORDS), acc, par);
     if (T > 1) {
-        const Acc z = Acc::inf();
         if (acc_head) lp_raw_store(praw + 2 * (size_t)t * (2 * RAW29_WORDS), acc, par);
-        else if (!head_written) lp_raw_store(praw + 2 * (size_t)t * (2 * RAW29_WORDS), z, par);
-        lp_raw_store(praw + (2 * (size_t)t + 1) * (2 * RAW29_WORDS), acc_tail ? acc : z, par);
+        if (acc_tail) lp_raw_store(praw + (2 * (size_t)t + 1) * (2 * RAW29_WORDS), acc, par);
         if (par == 0) {
-            out_keys[2 * t] = first_key;
-            out_keys[2 * t + 1] = last_key;
+            out_keys[2 * t] = first_key | ((acc_head || head_written) ? 0u : PART_EMPTY);
+            out_keys[2 * t + 1] = last_key | (acc_tail ? 0u : PART_EMPTY);
         }
     }
 }

@@ -10,6 +10,8 @@
 
 namespace zk {
 
+static constexpr u32 PART_EMPTY = 0x80000000u, PART_KEY = 0x7fffffffu;  // see k_acc_levelN29
+
 struct Pol29G1 {
     typedef Fp29 F;
     typedef XYZZ29T<Fp29> Acc;
@@ -29,13 +31,18 @@ __global__ __launch_bounds__(256) void k_acc_levelN29(const u32* __restrict__ ke
     if (t >= T) return;
     const u32 start = t * (u32)L;
     const u32 end = (start + (u32)L < M) ? start + (u32)L : M;
-    const u32 prev = start > 0 ? keys[start - 1] : NOKEY;
-    const u32 next = end < M ? keys[end] : NOKEY;
+    // bit 31 of a key marks an entry whose partial sum is infinity and was never written (PART_EMPTY): most chunks lie
+    // inside one bucket, so half of all partials are; skipping their 144-byte images halves this kernel's HBM traffic
+    const u32 prev = start > 0 ? (keys[start - 1] & PART_KEY) : NOKEY;
+    const u32 next = end < M ? (keys[end] & PART_KEY) : NOKEY;
     Acc acc = Acc::inf();
-    u32 cur = keys[start];
+    u32 cur = keys[start] & PART_KEY;
+    const u32 first_key = cur;
+    u32 last_key = cur;
     bool first = true, head_written = false;
     for (u32 j = start; j < end; ++j) {
-        const u32 k = keys[j];
+        const u32 kraw = keys[j];
+        const u32 k = kraw & PART_KEY;
         if (k != cur) {
             const bool head = first && cur == prev;
             if (head) { Pol::store(out_part, 2 * (size_t)t, acc, par); head_written = true; }
@@ -44,20 +51,21 @@ __global__ __launch_bounds__(256) void k_acc_levelN29(const u32* __restrict__ ke
             cur = k;
             acc = Acc::inf();
         }
-        Acc p = Pol::load(src, j, par);
-        xyzz29_add<typename Pol::F>(acc, p);
+        last_key = k;
+        if (!(kraw & PART_EMPTY)) {
+            Acc p = Pol::load(src, j, par);
+            xyzz29_add<typename Pol::F>(acc, p);
+        }
     }
     const bool acc_head = first && cur == prev;
     const bool acc_tail = !acc_head && cur == next;
     if (!acc_head && !acc_tail && !acc.is_inf()) Pol::store(buckets, cur, acc, par);
     if (T > 1) {
-        const Acc z = Acc::inf();
         if (acc_head) Pol::store(out_part, 2 * (size_t)t, acc, par);
-        else if (!head_written) Pol::store(out_part, 2 * (size_t)t, z, par);
-        Pol::store(out_part, 2 * (size_t)t + 1, acc_tail ? acc : z, par);
+        if (acc_tail) Pol::store(out_part, 2 * (size_t)t + 1, acc, par);
         if (par == 0) {
-            out_keys[2 * t] = keys[start];
-            out_keys[2 * t + 1] = keys[end - 1];
+            out_keys[2 * t] = first_key | ((acc_head || head_written) ? 0u : PART_EMPTY);
+            out_keys[2 * t + 1] = last_key | (acc_tail ? 0u : PART_EMPTY);
         }
     }
 }
