@@ -7,7 +7,7 @@ mixture for w, uniform a,b with c = a.b).  One process per GP
 own independent batches (weak scaling, no data-path collective — witness batches are independent proofs).
 
 Output: ONE JSON line (rank 0) with value = proofs/s over all ranks, plus
-  roofline     — the dominant kernel (G1 bucket accumulation k_acc_level1<Fp>): algorithmic bytes per launch
+  roofline     — the dominant kernel (G1 bucket accumulation k_acc_level1_fp29): algorithmic bytes per launch
                  (n x (64 B point + 32 B scalar)) / its average launch time, vs the 8 TB/s HBM peak
   cpu_baseline — the CPU oracle (a port of the reference's algorithm) timed on a bounded sample, scaled to proofs/s
 """
@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def pmc_traffic_bytes_per_launch(kernel="k_acc_level1<Fp>"):
+def pmc_traffic_bytes_per_launch(kernel="k_acc_level1_fp29"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
     separate runs, gfx950 corrections applied as calibrated in the file); None when no profile is committed.  PMC
     counters cannot be collected from inside this process, so the latest profiles/r*_pmc_traffic.json is used and named."""
@@ -258,7 +258,7 @@ def main():
     if rank == 0:
         k1_ms = sum(wk[0].phase_ms("k_acc_level1_g1")[0] for wk in workers)
         k1_calls = sum(wk[0].phase_ms("k_acc_level1_g1")[1] for wk in workers)
-        # launches of k_acc_level1<Fp> per proof: A, B1, K, Z (n ~ D points each) + 2 commitment MSMs (n/4 points)
+        # launches of k_acc_level1_fp29 per proof: A, B1, K, Z (n ~ D points each) + 2 commitment MSMs (n/4 points)
         units_bytes = (4 * n_wires + 2 * n_commit) * 96.0 / 6.0  # mean algorithmic bytes per launch
         avg_launch_s = (k1_ms / max(1, k1_calls)) * 1e-3
         achieved = units_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
