@@ -220,6 +220,12 @@ int32_t zkpor_dev_alloc(zkpor_ctx* ctx, size_t bytes, void** out);
 int32_t zkpor_dev_free(zkpor_ctx* ctx, void* p);
 int32_t zkpor_dev_upload(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes);
 int32_t zkpor_dev_download(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* queued copy: returns immediately, the host range must stay valid until zkpor_sync (pin it with zkpor_host_register) */
+int32_t zkpor_dev_upload_async(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* page-lock / release a caller-owned host range (e.g. the backing array of a Go []fr.Element): uploads from pinned memory
+ * run at PCIe rate and overlap with kernels */
+int32_t zkpor_host_register(zkpor_ctx* ctx, void* ptr, size_t bytes);
+int32_t zkpor_host_unregister(zkpor_ctx* ctx, void* ptr);
 /* fill n Montgomery Fr elements with seeded pseudo-random values on the device. kind 0 = uniform,
  * kind 1 = the witness-like mixture of SURVEY.md §8(d) (25% {0,1}, 20% <2^16, 5% <2^64, 50% uniform) */
 int32_t zkpor_dev_fill_fr(zkpor_ctx* ctx, void* d_out, size_t n, uint64_t seed, int kind);

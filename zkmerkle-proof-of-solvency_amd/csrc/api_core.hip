@@ -191,6 +191,25 @@ int32_t zkpor_dev_upload(zkpor_ctx* ctx, void* dst, const void* src, size_t byte
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer is not retained
     return ZKPOR_OK;
 }
+// asynchronous upload: returns once the copy is queued; the host buffer must stay valid (and should be pinned, see
+// zkpor_host_register) until zkpor_sync.  Lets the next proof's witness cross PCIe under the current proof's kernels.
+int32_t zkpor_dev_upload_async(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return ZKPOR_E_ARG;
+    ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ZKPOR_OK;
+}
+// page-lock a caller-owned host range (a Go slice's backing array) so uploads from it run at PCIe rate and truly
+// asynchronously; the caller unregisters it before freeing the memory
+int32_t zkpor_host_register(zkpor_ctx* ctx, void* ptr, size_t bytes) {
+    if (!ctx || !ptr || !bytes) return ZKPOR_E_ARG;
+    ZK_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return ZKPOR_OK;
+}
+int32_t zkpor_host_unregister(zkpor_ctx* ctx, void* ptr) {
+    if (!ctx || !ptr) return ZKPOR_E_ARG;
+    ZK_HIP(ctx, hipHostUnregister(ptr));
+    return ZKPOR_OK;
+}
 int32_t zkpor_dev_download(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
