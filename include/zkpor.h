@@ -186,6 +186,24 @@ int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r1cs, const void* d_w, void* d_a, void* 
 /* host buffers: a, b, c receive n_constraints elements each */
 int32_t zkpor_r1cs_eval(zkpor_r1cs* r1cs, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c);
 
+/* ---- CEX asset-list commitments and batch commitments (src/witness/witness/witness.go:159-198, utils.go:26-88,779-800) ----
+ * One commitment = the chained Poseidon over 20 elements per asset (ConvertAssetInfoToBytes).  Prices and tier ratios are
+ * constant over a run, the five running totals change per batch: pass the constants once and one totals row per CEX
+ * state (before / after every batch); states are hashed independently, one per GPU thread. */
+typedef struct { uint64_t boundary[2]; /* BoundaryValue, little-endian 128 bit, <= 2^118 */ uint8_t ratio; uint8_t pad[7]; } zkpor_tier_ratio_t;
+typedef struct {               /* the constant part of utils.CexAssetInfo (src/utils/types.go:11-23), padded as PaddingTierRatios does */
+    uint64_t base_price;
+    zkpor_tier_ratio_t loan[12], margin[12], portfolio_margin[12];
+} zkpor_cex_asset_const_t;     /* 872 bytes */
+typedef struct { uint64_t total_equity, total_debt, loan_collateral, margin_collateral, portfolio_margin_collateral; } zkpor_cex_totals_t;
+/* totals: n_states x n_assets rows (state-major); out32: n_states x 32 B big-endian.  n_assets = utils.AssetCounts (500)
+ * in the reference, with the reserved slots already filled in (utils.go:781-792). */
+int32_t zkpor_cex_commitments(zkpor_ctx* ctx, const zkpor_cex_asset_const_t* assets, size_t n_assets, const zkpor_cex_totals_t* totals,
+                              size_t n_states, uint8_t* out32);
+/* BatchCommitment = PoseidonBytes(AccountTreeRoot, Before, After, MinAccountIndex, MaxAccountIndex) for n batches */
+int32_t zkpor_batch_commitments(zkpor_ctx* ctx, const uint8_t* roots32, const uint8_t* before32, const uint8_t* after32,
+                                const uint32_t* min_index, const uint32_t* max_index, size_t n, uint8_t* out32);
+
 /* ---- FixedDepthMerkleTree (reference src/utils/merkletree/merkletree.go:27-52), resident in HBM ----
  * The two-phase usage of the reference: Set leaves (no hashing), Build (all internal nodes above a set leaf), then
  * Root / Get / GetProof.  Hashes cross the boundary as 32-byte big-endian canonical Fr, as the reference holds them.

@@ -197,6 +197,23 @@ void orc_account_leaves(const PackedAccountHdr* acc, const PackedAsset* assets, 
                                    aa.size(), tier);
     }
 }
+// CEX commitments in the product's packed layout (include/zkpor.h zkpor_cex_asset_const_t / zkpor_cex_totals_t)
+struct PackedTier { u64 boundary[2]; uint8_t ratio; uint8_t pad[7]; };
+struct PackedCexConst { u64 base_price; PackedTier loan[12], margin[12], pm[12]; };
+static_assert(sizeof(PackedCexConst) == 872 && sizeof(CexTotals) == 40, "layout");
+void orc_cex_commitments(const PackedCexConst* consts, size_t n_assets, const CexTotals* totals, size_t n_states, Fr* out) {
+    std::vector<CexAssetConst> c(n_assets);
+    for (size_t a = 0; a < n_assets; ++a) {
+        c[a].base_price = consts[a].base_price;
+        for (int i = 0; i < 12; ++i) {
+            c[a].loan[i] = {{consts[a].loan[i].boundary[0], consts[a].loan[i].boundary[1]}, consts[a].loan[i].ratio};
+            c[a].margin[i] = {{consts[a].margin[i].boundary[0], consts[a].margin[i].boundary[1]}, consts[a].margin[i].ratio};
+            c[a].pm[i] = {{consts[a].pm[i].boundary[0], consts[a].pm[i].boundary[1]}, consts[a].pm[i].ratio};
+        }
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t s = 0; s < n_states; ++s) out[s] = cex_assets_commitment(c.data(), totals + s * n_assets, n_assets);
+}
 // levels_out (optional): concatenation of levels 1..depth, level l holding ceil(n/2^l) nodes
 void orc_merkle_build(const Fr* leaves, size_t n, int depth, const Fr* nil_leaf, Fr* levels_out, Fr* nil_out,
                       Fr* root_out) {

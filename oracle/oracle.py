@@ -266,6 +266,22 @@ def account_leaves(accounts, assets, tier):
     return out
 
 
+TIER_DTYPE = np.dtype([("boundary", np.uint64, 2), ("ratio", np.uint8), ("pad", np.uint8, 7)])
+CEX_CONST_DTYPE = np.dtype([("base_price", np.uint64), ("loan", TIER_DTYPE, 12), ("margin", TIER_DTYPE, 12), ("portfolio_margin", TIER_DTYPE, 12)])
+CEX_TOTALS_DTYPE = np.dtype([("total_equity", np.uint64), ("total_debt", np.uint64), ("loan_collateral", np.uint64),
+                             ("margin_collateral", np.uint64), ("portfolio_margin_collateral", np.uint64)])
+assert TIER_DTYPE.itemsize == 24 and CEX_CONST_DTYPE.itemsize == 872 and CEX_TOTALS_DTYPE.itemsize == 40
+
+
+def cex_commitments(consts, totals):
+    """utils.ComputeCexAssetsCommitment for every row of totals[n_states, n_assets]"""
+    consts = np.ascontiguousarray(consts, dtype=CEX_CONST_DTYPE); totals = np.ascontiguousarray(totals, dtype=CEX_TOTALS_DTYPE)
+    n_assets = consts.shape[0]; n_states = totals.size // n_assets
+    out = np.empty((n_states, 4), dtype=np.uint64)
+    lib().orc_cex_commitments(_p(consts), ctypes.c_size_t(n_assets), _p(totals), ctypes.c_size_t(n_states), _p(out))
+    return out
+
+
 def merkle_build(leaves, depth, nil_leaf, want_levels=False):
     leaves = _u64(leaves).reshape(-1, 4); n = leaves.shape[0]
     nil_leaf = _u64(nil_leaf)

@@ -216,6 +216,58 @@ static inline Fr account_leaf_hash(const Fr& id, const Fr& equity, const Fr& deb
     return poseidon_hash(in, 5);
 }
 
+// --------------------------------------------------------------------------------- CEX asset list
+// src/utils/utils.go: ConvertTierRatiosToBytes (:26-51), ConvertAssetInfoToBytes (:53-88), ComputeCexAssetsCommitment
+// (:779-800) and the two per-batch commitments of Witness.Run (src/witness/witness/witness.go:159-183): every byte string
+// is a big-endian big integer that hasher.Write turns into an Fr (mod r); the integers are sums of shifted fields.
+struct TierRatio { u64 boundary[2]; uint8_t ratio; };  // BoundaryValue as a little-endian 128-bit integer
+struct CexAssetConst { u64 base_price; TierRatio loan[12], margin[12], pm[12]; };
+struct CexTotals { u64 total_equity, total_debt, loan_collateral, margin_collateral, portfolio_margin_collateral; };
+
+static inline void be_add_shifted(uint8_t be[40], const u64 v[2], int shift) {  // be (320-bit big-endian) += v << shift
+    unsigned carry = 0;
+    for (int bit_byte = 0; bit_byte < 17 || carry; ++bit_byte) {
+        // byte `bit_byte` of (v << (shift % 8)), placed at byte offset shift / 8
+        unsigned __int128 vv = ((unsigned __int128)v[1] << 64) | v[0];
+        unsigned byte = 0;
+        if (bit_byte < 17) {
+            int sh = 8 * bit_byte - (shift % 8);
+            unsigned __int128 part = sh >= 128 ? 0 : (sh >= 0 ? (vv >> sh) : (vv << (-sh)));
+            byte = (unsigned)(part & 0xff);
+        }
+        int pos = 39 - (shift / 8 + bit_byte);
+        if (pos < 0) break;
+        unsigned t = be[pos] + byte + carry;
+        be[pos] = (uint8_t)t;
+        carry = t >> 8;
+    }
+}
+static inline Fr tier_pair_element(const TierRatio& lo, const TierRatio& hi) {
+    uint8_t be[40] = {0};
+    u64 r0[2] = {lo.ratio, 0}, r1[2] = {hi.ratio, 0};
+    be_add_shifted(be, r0, 0);
+    be_add_shifted(be, lo.boundary, 8);     // * Uint8MaxValueBigInt  (256)
+    be_add_shifted(be, r1, 126);            // * Uint126MaxValueBigInt
+    be_add_shifted(be, hi.boundary, 134);   // * Uint134MaxValueBigInt
+    return Fr::from_be_bytes(be, 40);
+}
+static inline Fr pack3_u64(u64 a, u64 b, u64 c) {  // a * 2^128 + b * 2^64 + c
+    u64 limbs[4] = {c, b, a, 0};
+    return Fr::from_canon(limbs);
+}
+static inline Fr cex_assets_commitment(const CexAssetConst* consts, const CexTotals* totals, size_t n_assets) {
+    std::vector<Fr> el;
+    el.reserve(n_assets * 20);
+    for (size_t a = 0; a < n_assets; ++a) {
+        el.push_back(pack3_u64(totals[a].total_equity, totals[a].total_debt, consts[a].base_price));
+        el.push_back(pack3_u64(totals[a].loan_collateral, totals[a].margin_collateral, totals[a].portfolio_margin_collateral));
+        const TierRatio* groups[3] = {consts[a].loan, consts[a].margin, consts[a].pm};
+        for (auto* g : groups)
+            for (int i = 0; i < 12; i += 2) el.push_back(tier_pair_element(g[i], g[i + 1]));
+    }
+    return poseidon_hash(el.data(), el.size());
+}
+
 // --------------------------------------------------------------------------------- Merkle tree
 // src/utils/merkletree/merkletree.go: nilHashes (:159-170), Build (:192-279), GetProof (:297-308),
 // VerifyProof (:334-355).  levels[l] holds ceil(n/2^l) computed nodes; anything to the right is

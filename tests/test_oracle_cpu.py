@@ -192,6 +192,21 @@ def test_compressed_point_encoding_roundtrip():
     assert O.g1_decompress(big)[0] == 2
 
 
+def test_cex_commitment_matches_bigint_restatement():
+    """oracle/poseidon.hpp cex_assets_commitment against Python big integers built as utils.go:26-88 builds them"""
+    import cex_cases as C
+    consts = C.make_assets(9, seed=4)
+    totals = C.make_totals(3, 9, seed=5)
+    got = O.cex_commitments(consts, totals)
+    for s in range(3):
+        ints = [v % O.R_MOD for v in C.elements_bigint(consts, totals[s])]
+        assert len(ints) == 9 * 20
+        assert np.array_equal(got[s], O.poseidon_hash(O.fr_from_ints(ints)))
+    # a padding boundary of exactly 2^118 carries into the neighbouring field (2^118 * 2^8 = 2^126): the integer sum is what counts
+    ints = C.elements_bigint(consts, totals[0])
+    assert any(v >> 252 for v in ints) or any((v >> 126) & 1 for v in ints)
+
+
 def test_merkle_tree_and_leaves_self_consistency():
     # mirrors src/utils/merkletree/merkletree_test.go (build / prove / verify round trip) and utils_test.go:43-136
     # (padding re-implementation); both are self-consistency tests in the reference as well (no golden root there)

@@ -449,6 +449,89 @@ static int32_t pos_dev(zkpor_ctx* ctx, PosDev* P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// CEX asset-list commitments and batch commitments: what Witness.Run computes per batch
+// (src/witness/witness/witness.go:159-198) and utils.ComputeCexAssetsCommitment (src/utils/utils.go:779-800).
+// The commitment of a CEX state is one chained Poseidon over 20 elements per asset (ConvertAssetInfoToBytes,
+// utils.go:53-88): two packed totals and 3 x 6 packed tier-ratio pairs (ConvertTierRatiosToBytes, utils.go:26-51).
+// The reference computes it twice per batch on one core (running totals); once the running totals of all batches are
+// known (a prefix sum over the user operations) every batch's commitments are independent, so they are hashed here one
+// state per thread.  Tier ratios and prices do not change between batches: they are packed once.
+struct TierRatioRec { u64 boundary[2]; uint8_t ratio; uint8_t pad[7]; };                      // zkpor_tier_ratio_t
+struct CexAssetConst { u64 base_price; TierRatioRec loan[12], margin[12], portfolio_margin[12]; };  // zkpor_cex_asset_const_t
+struct CexTotals { u64 total_equity, total_debt, loan_collateral, margin_collateral, portfolio_margin_collateral; };
+static_assert(sizeof(TierRatioRec) == 24 && sizeof(CexAssetConst) == 872 && sizeof(CexTotals) == 40, "zkpor_cex_* layout");
+
+// ratio_i + boundary_i * 2^8 + ratio_{i+1} * 2^126 + boundary_{i+1} * 2^134 as a 256-bit integer (utils.go:33-47: plain
+// big-integer sums; a boundary of exactly 2^118, the padding value, carries into the next field exactly as there)
+ZK_D void add_shifted(u32* acc, const u64* v128, int shift) {  // acc += v128 << shift, 8 x 32-bit limbs
+    u32 w[4] = {(u32)v128[0], (u32)(v128[0] >> 32), (u32)v128[1], (u32)(v128[1] >> 32)};
+    u64 carry = 0;
+    const int ws = shift >> 5, bs = shift & 31;
+    u32 prev = 0;
+    for (int i = 0; i + ws < 8; ++i) {
+        u32 cur = i < 4 ? w[i] : 0u;
+        u32 part = bs ? ((cur << bs) | (prev >> (32 - bs))) : cur;
+        prev = cur;
+        u64 t = (u64)acc[i + ws] + part + carry;
+        acc[i + ws] = (u32)t;
+        carry = t >> 32;
+        if (i >= 5 && !carry && !prev) break;
+    }
+}
+__global__ void k_cex_tier_elems(const CexAssetConst* __restrict__ consts, u32 n_assets, Fr* __restrict__ out /* n_assets x 18 */) {
+    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_assets * 18u) return;
+    const u32 a = g / 18u, e = g % 18u;
+    const TierRatioRec* tr = e < 6 ? consts[a].loan : (e < 12 ? consts[a].margin : consts[a].portfolio_margin);
+    const TierRatioRec& lo = tr[2 * (e % 6)];
+    const TierRatioRec& hi = tr[2 * (e % 6) + 1];
+    Fr x = Fr::zero();
+    u64 r0[2] = {lo.ratio, 0}, r1[2] = {hi.ratio, 0};
+    add_shifted(x.v, r0, 0);
+    add_shifted(x.v, lo.boundary, 8);
+    add_shifted(x.v, r1, 126);
+    add_shifted(x.v, hi.boundary, 134);
+    // the sum is < 2^253 < 2r: one conditional subtraction makes it canonical (hasher.Write reduces mod r)
+    u32 t[8]; u32 bw = 0;
+    for (int i = 0; i < 8; ++i) { u64 d = (u64)x.v[i] - FrParams::mod(i) - bw; t[i] = (u32)d; bw = (u32)(d >> 32) & 1u; }
+    if (!bw) for (int i = 0; i < 8; ++i) x.v[i] = t[i];
+    out[g] = Fr::to_mont(x);
+}
+// one CEX state per thread: 20 elements per asset through the streaming sponge
+__global__ __launch_bounds__(64) void k_cex_commitments(const CexAssetConst* __restrict__ consts, const Fr* __restrict__ tier_elems,
+                                                        u32 n_assets, const CexTotals* __restrict__ totals, u32 n_states,
+                                                        Fr* __restrict__ out, PosDev P) {
+    u32 i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n_states) return;
+    Sponge sp;
+    sp.init();
+    const CexTotals* t = totals + (size_t)i * n_assets;
+    for (u32 a = 0; a < n_assets; ++a) {
+        const CexTotals c = t[a];
+        sp.push(P, pack3(c.total_equity, c.total_debt, consts[a].base_price));
+        sp.push(P, pack3(c.loan_collateral, c.margin_collateral, c.portfolio_margin_collateral));
+        for (int e = 0; e < 18; ++e) sp.push(P, tier_elems[a * 18u + e]);
+    }
+    out[i] = sp.finish(P);
+}
+// BatchCommitment = PoseidonBytes(root, before, after, min index, max index) (witness.go:185-198); an index of 0 is the
+// byte string [0x00] there, i.e. the element 0 either way
+__global__ __launch_bounds__(64) void k_batch_commitments(const uint8_t* __restrict__ roots, const uint8_t* __restrict__ before,
+                                                          const uint8_t* __restrict__ after, const u32* __restrict__ min_idx,
+                                                          const u32* __restrict__ max_idx, u32 n, Fr* __restrict__ out, PosDev P) {
+    u32 i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    Sponge sp;
+    sp.init();
+    sp.push(P, from_be32(roots + 32 * (size_t)i));
+    sp.push(P, from_be32(before + 32 * (size_t)i));
+    sp.push(P, from_be32(after + 32 * (size_t)i));
+    sp.push(P, pack3(0, 0, min_idx[i]));
+    sp.push(P, pack3(0, 0, max_idx[i]));
+    out[i] = sp.finish(P);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // FixedDepthMerkleTree on the device (reference src/utils/merkletree/merkletree.go:27-52): leaves and every internal
 // level live in HBM in Montgomery form next to one "dirty" bitset per level; a clean position reads as nilHashes[level]
 // exactly as getNodeAt (:315-331) does.  Set (:179-187) only stores leaves and marks them; Build (:192-279) recomputes
@@ -892,6 +975,55 @@ int32_t zkpor_merkle_verify_proofs(zkpor_ctx* ctx, const uint8_t root[32], const
                        (const uint8_t*)dp.p, (const uint8_t*)dl.p, n, depth, (uint8_t*)dok.p, P);
     ZK_KERNEL_CHECK(ctx);
     ZK_HIP(ctx, hipMemcpyAsync(ok_out, dok.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+}
+
+// ---- CEX asset-list commitments / batch commitments -------------------------------------------------------------------
+int32_t zkpor_cex_commitments(zkpor_ctx* ctx, const zkpor_cex_asset_const_t* assets, size_t n_assets, const zkpor_cex_totals_t* totals,
+                              size_t n_states, uint8_t* out32) {
+    if (!ctx || !assets || !totals || !out32 || n_assets == 0 || n_assets > 0xffffu) return ZKPOR_E_ARG;
+    if (n_states == 0) return ZKPOR_OK;
+    if (n_states > 0xffffffffull) return ZKPOR_E_ARG;
+    PosDev P;
+    ZK_TRY(pos_dev(ctx, &P));
+    DevTmp dc, dt, de, dout, dbe;
+    ZK_TRY(dc.put(ctx, assets, n_assets * sizeof(CexAssetConst)));
+    ZK_TRY(dt.put(ctx, totals, n_states * n_assets * sizeof(CexTotals)));
+    ZK_TRY(de.make(ctx, n_assets * 18 * sizeof(Fr)));
+    ZK_TRY(dout.make(ctx, n_states * sizeof(Fr)));
+    ZK_TRY(dbe.make(ctx, n_states * 32));
+    {
+        PhaseScope ps(ctx, "cex_commitments");
+        hipLaunchKernelGGL(k_cex_tier_elems, dim3((unsigned)((n_assets * 18 + 127) / 128)), dim3(128), 0, ctx->stream, (const CexAssetConst*)dc.p,
+                           (u32)n_assets, (Fr*)de.p);
+        ZK_KERNEL_CHECK(ctx);
+        hipLaunchKernelGGL(k_cex_commitments, dim3((unsigned)((n_states + 63) / 64)), dim3(64), 0, ctx->stream, (const CexAssetConst*)dc.p,
+                           (const Fr*)de.p, (u32)n_assets, (const CexTotals*)dt.p, (u32)n_states, (Fr*)dout.p, P);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(k_fr_to_be, dim3((unsigned)((n_states + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)dout.p, (uint8_t*)dbe.p, n_states);
+    ZK_KERNEL_CHECK(ctx);
+    ZK_HIP(ctx, hipMemcpyAsync(out32, dbe.p, n_states * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+}
+int32_t zkpor_batch_commitments(zkpor_ctx* ctx, const uint8_t* roots32, const uint8_t* before32, const uint8_t* after32,
+                                const uint32_t* min_index, const uint32_t* max_index, size_t n, uint8_t* out32) {
+    if (!ctx || (n && (!roots32 || !before32 || !after32 || !min_index || !max_index || !out32))) return ZKPOR_E_ARG;
+    if (n == 0) return ZKPOR_OK;
+    PosDev P;
+    ZK_TRY(pos_dev(ctx, &P));
+    DevTmp dr, db, da, dmin, dmax, dout, dbe;
+    ZK_TRY(dr.put(ctx, roots32, n * 32)); ZK_TRY(db.put(ctx, before32, n * 32)); ZK_TRY(da.put(ctx, after32, n * 32));
+    ZK_TRY(dmin.put(ctx, min_index, n * 4)); ZK_TRY(dmax.put(ctx, max_index, n * 4));
+    ZK_TRY(dout.make(ctx, n * sizeof(Fr))); ZK_TRY(dbe.make(ctx, n * 32));
+    hipLaunchKernelGGL(k_batch_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)dr.p, (const uint8_t*)db.p,
+                       (const uint8_t*)da.p, (const u32*)dmin.p, (const u32*)dmax.p, (u32)n, (Fr*)dout.p, P);
+    ZK_KERNEL_CHECK(ctx);
+    hipLaunchKernelGGL(k_fr_to_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)dout.p, (uint8_t*)dbe.p, n);
+    ZK_KERNEL_CHECK(ctx);
+    ZK_HIP(ctx, hipMemcpyAsync(out32, dbe.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
 }

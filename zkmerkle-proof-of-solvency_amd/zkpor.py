@@ -367,6 +367,32 @@ def _g2_decompress(self, comp64):
     return out
 
 
+TIER_DTYPE = np.dtype([("boundary", np.uint64, 2), ("ratio", np.uint8), ("pad", np.uint8, 7)])
+CEX_CONST_DTYPE = np.dtype([("base_price", np.uint64), ("loan", TIER_DTYPE, 12), ("margin", TIER_DTYPE, 12), ("portfolio_margin", TIER_DTYPE, 12)])
+CEX_TOTALS_DTYPE = np.dtype([("total_equity", np.uint64), ("total_debt", np.uint64), ("loan_collateral", np.uint64),
+                             ("margin_collateral", np.uint64), ("portfolio_margin_collateral", np.uint64)])
+
+
+def _cex_commitments(self, consts, totals):
+    """one 32-byte commitment per CEX state: totals[n_states, n_assets] rows over the constant asset table"""
+    consts = np.ascontiguousarray(consts, dtype=CEX_CONST_DTYPE); totals = np.ascontiguousarray(totals, dtype=CEX_TOTALS_DTYPE)
+    n_assets = consts.shape[0]; n_states = totals.size // n_assets
+    out = np.empty((n_states, 32), dtype=np.uint8)
+    self._ck(self.lib.zkpor_cex_commitments(self.h, _p(consts), ctypes.c_size_t(n_assets), _p(totals), ctypes.c_size_t(n_states), _p(out)))
+    return out
+
+
+def _batch_commitments(self, roots, before, after, min_idx, max_idx):
+    roots = np.ascontiguousarray(roots, dtype=np.uint8).reshape(-1, 32); n = roots.shape[0]
+    before = np.ascontiguousarray(before, dtype=np.uint8).reshape(n, 32); after = np.ascontiguousarray(after, dtype=np.uint8).reshape(n, 32)
+    min_idx = np.ascontiguousarray(min_idx, dtype=np.uint32); max_idx = np.ascontiguousarray(max_idx, dtype=np.uint32)
+    out = np.empty((n, 32), dtype=np.uint8)
+    self._ck(self.lib.zkpor_batch_commitments(self.h, _p(roots), _p(before), _p(after), _p(min_idx), _p(max_idx), ctypes.c_size_t(n), _p(out)))
+    return out
+
+
+Context.cex_commitments = _cex_commitments
+Context.batch_commitments = _batch_commitments
 Context.g1_decompress = _g1_decompress
 Context.g2_decompress = _g2_decompress
 Context.poseidon_hash = _poseidon_hash
