@@ -8,6 +8,17 @@ import oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["limbs29", "limbs32"])
+def _pipeline(zk, request):
+    """every case runs through both accumulation pipelines: the 9 x 29-bit lazy one with raw register images end to end
+    (the default) and the 8 x 32-bit one"""
+    zk.set_param("msm_g1_variant", request.param)
+    zk.set_param("msm_g2_variant", request.param)
+    yield
+    zk.set_param("msm_g1_variant", 1)
+    zk.set_param("msm_g2_variant", 1)
+
+
 def _g1_eq(jac, aff_expected):
     return np.array_equal(O.g1_jac_to_affine(jac)[0], aff_expected)
 
