@@ -343,6 +343,16 @@ ZK_D void permute29(Fr29 (&st)[T], const u32* rc, const u32* m, const u32* prc, 
             const u32* c = rc + 9 * T * (half ? POS_RF / 2 + rp + rr : rr);
             // the full rounds (8 of 73) run from private arrays with ROLLED loops: one copy of the S-box and of the dot
             // product instead of 13 (the unrolled form was 90 KB of code, beyond the 64 KB instruction cache)
+            if (T <= 4) {  // narrow states (the 2-to-1 node hash): everything unrolled, everything in registers
+                Fr29 tmp[T];
+#pragma unroll
+                for (int i = 0; i < T; ++i) st[i] = pow5_29(Fr29::reduce32(Fr29::add_l(st[i], k29(c, i))));
+#pragma unroll
+                for (int i = 0; i < T; ++i) tmp[i] = dot29<T>(m + 9 * i * T, st);
+#pragma unroll
+                for (int i = 0; i < T; ++i) st[i] = tmp[i];
+                continue;
+            }
             Fr29 sb[T], tmp[T];
 #pragma unroll
             for (int i = 0; i < T; ++i) sb[i] = st[i];
@@ -370,8 +380,13 @@ ZK_D void permute29(Fr29 (&st)[T], const u32* rc, const u32* m, const u32* prc, 
             Fr29 tmp[T - 1];
 #pragma unroll
             for (int r = 1; r < T; ++r) st[r] = Fr29::reduce32(st[r]);
+            if (T <= 4) {
+#pragma unroll
+                for (int r = 0; r < T - 1; ++r) tmp[r] = dot29<T - 1>(post + 9 * r * (T - 1), st + 1);
+            } else {
 #pragma unroll 1
-            for (int r = 0; r < T - 1; ++r) tmp[r] = dot29<T - 1>(post + 9 * r * (T - 1), st + 1);
+                for (int r = 0; r < T - 1; ++r) tmp[r] = dot29<T - 1>(post + 9 * r * (T - 1), st + 1);
+            }
 #pragma unroll
             for (int r = 0; r < T - 1; ++r) st[1 + r] = tmp[r];
         }
@@ -416,6 +431,19 @@ __device__ __noinline__ void full_block29(const Fr* st, const PosDev& P, Fr* cap
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// the 2-to-1 node hash of the account tree on the 29-bit path: H(l, r) = permute([0, l, r])[out_idx]
+ZK_D Fr hash2_29(const Fr& l, const Fr& r, const PosDev& P) {
+    Fr29 st[3] = {Fr29::zero(), Fr29::from32<5>(l), Fr29::from32<5>(r)};
+    const u32* b = P.tab29;
+    permute29<3>(st, b + 9 * (size_t)P.rc_off[3], b + 9 * (size_t)P.mds_off[3], b + 9 * (size_t)P.prc_off[3],
+                 b + 9 * (size_t)P.sp_off[3], b + 9 * (size_t)P.post_off[3], 57);
+    return Fr29::to32_div32(P.out_idx ? st[1] : st[0]);
+}
+#else
+__device__ Fr hash2_29(const Fr& l, const Fr& r, const PosDev& P);  // host pass: kernels only need the declaration
+#endif
+
 // streaming sponge over blocks of 12 (poseidon.Poseidon of the bnb fork)
 struct Sponge {
     Fr st[POS_MAX_T];
@@ -451,11 +479,9 @@ __global__ __launch_bounds__(256) void k_hash2_level(const Fr* __restrict__ in, 
     u32 i = blockIdx.x * 256u + threadIdx.x;
     u32 n_out = (n_in + 1u) >> 1;
     if (i >= n_out) return;
-    Fr s0 = Fr::zero();
     Fr s1 = in[2 * i];
     Fr s2 = (2 * i + 1 < n_in) ? in[2 * i + 1] : nil;
-    permute3(s0, s1, s2, P.tabs(3));
-    out[i] = P.out_idx == 0 ? s0 : (P.out_idx == 1 ? s1 : s2);
+    out[i] = hash2_29(s1, s2, P);
 }
 
 // `count` independent hashes of `len` inputs each
@@ -721,9 +747,7 @@ __global__ __launch_bounds__(256) void k_tree_level(TreeDev T, int level, u64 co
         if (wave_first + 32 < count) T.dirty[level][(wave_first >> 5) + 1] = (u32)(mask >> 32);
     }
     if (!d) return;
-    Fr s0 = Fr::zero();
-    permute3(s0, l, r, P.tabs(3));
-    T.nodes[level][p] = P.out_idx == 0 ? s0 : l;
+    T.nodes[level][p] = hash2_29(l, r, P);
 }
 // GetProof (:297-308) for n keys: out[(i * depth + level) * 32 ...] = sibling at `level`, big-endian
 __global__ void k_tree_proofs(TreeDev T, const u32* __restrict__ keys, size_t n, uint8_t* __restrict__ out) {
