@@ -208,8 +208,59 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
         st29(tile + 9u * li, v);
     }
     __syncthreads();
+    // stages two at a time: a thread takes the four elements that differ in the two index bits of stages j and j+1,
+    // does both stages in registers (4 products, as two radix-2 stages would) and touches LDS once instead of twice
+    int j = 0;
+    for (; j + 1 < kb; j += 2) {
+        const int hA = DIF ? (kb - 1 - j) : j;          // bit of the first stage of the pair
+        const int hB = DIF ? hA - 1 : hA + 1;           // bit of the second
+        const int hl = DIF ? hB : hA;                   // the lower of the two
+        const int tsA = (DIF ? j : (kb - 1 - j)) + (9 - kb);
+        const int tsB = (DIF ? j + 1 : (kb - 2 - j)) + (9 - kb);
+        const u32 ngrp = total >> 2;
+        for (u32 t = threadIdx.x; t < ngrp; t += 256u) {
+            u32 q, c;
+            if (lo > 0) { c = t & (C - 1u); q = t >> clog; }
+            else { q = t & ((F >> 2) - 1u); c = t >> (kb - 2); }
+            const u32 low = q & ((1u << hl) - 1u);
+            const u32 base = ((q >> hl) << (hl + 2)) + low;
+            const u32 s1 = 1u << hl, s2 = 2u << hl;
+            // x0..x3 = base + {0, s1, s2, s1+s2}
+            u32* p0 = tile + 9u * (lo > 0 ? base * C + c : c * F + base);
+            const u32 estep = 9u * (lo > 0 ? C : 1u);
+            u32* p1 = p0 + estep * s1; u32* p2 = p0 + estep * s2; u32* p3 = p2 + estep * s1;
+            Fr29 x0 = ld29(p0), x1 = ld29(p1), x2 = ld29(p2), x3 = ld29(p3);
+            if (DIF) {
+                // stage A pairs elements 2^hA apart (x0,x2),(x1,x3): twiddle position = index below bit hA
+                const u32 posA0 = low, posA1 = low + s1;
+                Fr29 wa0 = ld29(A.small29 + 9u * (posA0 << tsA)), wa1 = ld29(A.small29 + 9u * (posA1 << tsA));
+                Fr29 a0 = Fr29::reduce32(Fr29::add_l(x0, x2)), a2 = Fr29::mul(wa0, Fr29::sub_l(x0, x2));
+                Fr29 a1 = Fr29::reduce32(Fr29::add_l(x1, x3)), a3 = Fr29::mul(wa1, Fr29::sub_l(x1, x3));
+                // stage B pairs elements 2^hB apart (a0,a1),(a2,a3): position = index below bit hB = low
+                Fr29 wb = ld29(A.small29 + 9u * (low << tsB));
+                st29(p0, Fr29::reduce32(Fr29::add_l(a0, a1)));
+                st29(p1, Fr29::mul(wb, Fr29::sub_l(a0, a1)));
+                st29(p2, Fr29::reduce32(Fr29::add_l(a2, a3)));
+                st29(p3, Fr29::mul(wb, Fr29::sub_l(a2, a3)));
+            } else {
+                // stage A pairs (x0,x1),(x2,x3) (distance 2^hA), position = low
+                Fr29 wa = ld29(A.small29 + 9u * (low << tsA));
+                Fr29 t1 = Fr29::mul(x1, wa), t3 = Fr29::mul(x3, wa);
+                Fr29 a0 = Fr29::reduce32(Fr29::add_l(x0, t1)), a1 = Fr29::reduce32(Fr29::sub_l(x0, t1));
+                Fr29 a2 = Fr29::reduce32(Fr29::add_l(x2, t3)), a3 = Fr29::reduce32(Fr29::sub_l(x2, t3));
+                // stage B pairs (a0,a2),(a1,a3) (distance 2^hB), positions low and low + 2^hA
+                Fr29 wb0 = ld29(A.small29 + 9u * (low << tsB)), wb1 = ld29(A.small29 + 9u * ((low + s1) << tsB));
+                Fr29 u2 = Fr29::mul(a2, wb0), u3 = Fr29::mul(a3, wb1);
+                st29(p0, Fr29::reduce32(Fr29::add_l(a0, u2)));
+                st29(p2, Fr29::reduce32(Fr29::sub_l(a0, u2)));
+                st29(p1, Fr29::reduce32(Fr29::add_l(a1, u3)));
+                st29(p3, Fr29::reduce32(Fr29::sub_l(a1, u3)));
+            }
+        }
+        __syncthreads();
+    }
     const u32 nbf = total >> 1;
-    for (int j = 0; j < kb; ++j) {
+    for (; j < kb; ++j) {
         const int hlog = DIF ? (kb - 1 - j) : j;
         const u32 half = 1u << hlog;
         const int tshift = (DIF ? j : (kb - 1 - j)) + (9 - kb);
