@@ -16,7 +16,11 @@
  *     (fr.Element / fp.Element).  G1 affine = X,Y (64 B); G2 affine = X.A0,X.A1,Y.A0,Y.A1 (128 B);
  *     G1 Jacobian = X,Y,Z (96 B); G2 Jacobian 192 B.  Affine infinity = all-zero.
  *   - a zkpor_ctx is bound to one GPU and one HIP stream and is single-caller; different contexts are
- *     independent (one per GPU, one process or thread each).
+ *     independent (one per GPU, one process or thread each).  HIP's current device is per host thread: a process
+ *     that drives several GPUs calls every function of a context from the thread that ran zkpor_init for it
+ *     (Go: runtime.LockOSThread in the worker goroutine), which is how host/prover_host.hpp dispatches.
+ *   - zkpor_host_register / zkpor_dev_upload_async are the only calls that keep reading a host range after they
+ *     return (until zkpor_sync): the caller pins that memory for exactly that reason.
  *   - *_dev variants take DEVICE pointers (inputs already resident in HBM) and are asynchronous on the
  *     context's stream unless they return a result to the host.
  *   - there is NO CPU fallback: without a usable gfx950 device every call fails with ZKPOR_E_NODEVICE.

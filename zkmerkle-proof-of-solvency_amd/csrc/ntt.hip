@@ -549,13 +549,9 @@ static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, b
         if ((A.scale_load > 1 || A.scale_store > 1) && (!A.g_lo || !A.g_hi)) { ctx->err = "ntt: no 2^261-form table for this scale"; return ZKPOR_E_ARG; }
         u32 blocks = (u32)(((size_t)1 << d->n) >> (fl.kb + A.clog));
         size_t smem = ((size_t)36 << fl.kb) << A.clog;
-        if (smem > 64 * 1024) {  // beyond the default dynamic-LDS limit (gfx950 has 160 KiB per CU)
-            static bool raised = false;
-            if (!raised) {
-                ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                raised = true;
-            }
+        if (smem > 64 * 1024) {  // beyond the default dynamic-LDS limit (gfx950 has 160 KiB per CU); per device, so no caching here
+            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         if (dif) hipLaunchKernelGGL(k_ntt_pass29<true>, dim3(blocks), dim3(256), smem, ctx->stream, A);
         else hipLaunchKernelGGL(k_ntt_pass29<false>, dim3(blocks), dim3(256), smem, ctx->stream, A);
