@@ -1,0 +1,72 @@
+// Drives zkpor_host::Witness (host/witness_host.hpp) the way src/witness/witness/witness.go:138-206 runs a tier.
+// Input file (binary, written by tests/test_witness_host_gpu.py):
+//   u32 nAssetsCex, u32 nOps, u32 opsPerBatch, u32 nLeaves, u8 nil[32]
+//   zkpor_cex_asset_const_t consts[nAssetsCex]; zkpor_cex_totals_t totals[nAssetsCex];
+//   u8 leaves[nLeaves][32];   per op: u32 accountIndex, u32 nAssets, zkpor_asset_t assets[nAssets]
+// Output (stdout): per batch one line "batch <i> <commitment> <before> <after> <min> <max> <proof0-of-first-user>"; then
+// "overflow 1" if re-running with a balance of 2^64-1 added throws the reference's panic.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <vector>
+#include "../../zkmerkle-proof-of-solvency_amd/host/merkle_tree.hpp"
+#include "../../zkmerkle-proof-of-solvency_amd/host/witness_host.hpp"
+using namespace zkpor_host;
+
+static void hex(const uint8_t* p) { for (int i = 0; i < 32; ++i) printf("%02x", p[i]); }
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    std::ifstream f(argv[1], std::ios::binary);
+    uint32_t hdr[4];
+    f.read((char*)hdr, 16);
+    const uint32_t nA = hdr[0], nOps = hdr[1], perBatch = hdr[2], nLeaves = hdr[3];
+    Hash32 nil;
+    f.read((char*)nil.data(), 32);
+    std::vector<zkpor_cex_asset_const_t> consts(nA);
+    std::vector<zkpor_cex_totals_t> totals(nA);
+    f.read((char*)consts.data(), nA * sizeof(zkpor_cex_asset_const_t));
+    f.read((char*)totals.data(), nA * sizeof(zkpor_cex_totals_t));
+    std::vector<uint8_t> leaves((size_t)nLeaves * 32);
+    f.read((char*)leaves.data(), leaves.size());
+    std::vector<std::vector<zkpor_asset_t>> assetStore(nOps);
+    std::vector<CreateUserOperation> ops(nOps);
+    for (uint32_t i = 0; i < nOps; ++i) {
+        uint32_t h[2];
+        f.read((char*)h, 8);
+        assetStore[i].resize(h[1]);
+        f.read((char*)assetStore[i].data(), h[1] * sizeof(zkpor_asset_t));
+        ops[i].AccountIndex = h[0]; ops[i].Assets = assetStore[i].data(); ops[i].nAssets = h[1];
+    }
+    if (!f) { fprintf(stderr, "short input\n"); return 2; }
+    zkpor_ctx* ctx = nullptr;
+    if (zkpor_init(0, nullptr, &ctx) != ZKPOR_OK) return 3;
+    int bad = 0;
+    {
+        FixedDepthMerkleTree tree(ctx, AccountTreeDepth, nil, nLeaves);
+        std::vector<uint32_t> keys(nLeaves);
+        for (uint32_t i = 0; i < nLeaves; ++i) keys[i] = i;
+        if (!tree.SetMany(keys.data(), leaves.data(), nLeaves)) bad = 1;
+        tree.Build();
+        Witness w(ctx, tree.handle(), AccountTreeDepth, consts, totals);
+        std::vector<BatchCreateUserWitness> wit = w.Run(ops, perBatch);
+        for (size_t b = 0; b < wit.size(); ++b) {
+            printf("batch %zu ", b); hex(wit[b].BatchCommitment.data()); printf(" "); hex(wit[b].BeforeCEXAssetsCommitment.data()); printf(" ");
+            hex(wit[b].AfterCEXAssetsCommitment.data()); printf(" %u %u ", wit[b].MinAccountIndex, wit[b].MaxAccountIndex);
+            hex(wit[b].AccountProofs[0].data()); printf("\n");
+        }
+        // SafeAdd's panic: one more batch whose first asset carries 2^64 - 1 of equity on top of a non-zero total
+        std::vector<zkpor_asset_t> big(1);
+        memset(&big[0], 0, sizeof(big[0]));
+        big[0].index = assetStore[0].empty() ? 0 : assetStore[0][0].index;
+        big[0].equity = ~0ull;
+        std::vector<CreateUserOperation> ops2(perBatch, ops[0]);
+        ops2[0].Assets = big.data(); ops2[0].nAssets = 1;
+        int thrown = 0;
+        try { Witness w2(ctx, tree.handle(), AccountTreeDepth, consts, w.CexTotals()); w2.Run(ops2, perBatch); } catch (const std::overflow_error&) { thrown = 1; }
+        printf("overflow %d\n", thrown);
+    }
+    zkpor_destroy(ctx);
+    return bad;
+}
