@@ -78,4 +78,19 @@ assert ok.all()
 out["account_tree"] = {"leaves": N, "build_ms": round(dt_build * 1e3, 1), "leaves_per_s": round(N / dt_build),
                        "get_proofs_1380_ms": round(dt_proofs * 1e3, 2)}
 t.close(); leaves.free()
+# ---- a12 / f3: CEX asset-list commitments, 4096 boundary states x 500 assets (one state per thread) ----
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cex_cases as C
+consts = C.make_assets(500, seed=3)
+nst = 4096
+totals = np.zeros((nst, 500), dtype=O.CEX_TOTALS_DTYPE)
+for name in O.CEX_TOTALS_DTYPE.names:
+    totals[name] = np.random.default_rng(5).integers(0, 1 << 62, size=(nst, 500), dtype=np.uint64)
+ctx.cex_commitments(consts, totals[:64])
+ctx.phase_reset()
+com = ctx.cex_commitments(consts, totals)
+ms, _ = ctx.phase_ms("cex_commitments")
+assert np.array_equal(com[:2], O.fr_to_be(O.cex_commitments(consts, totals[:2])))
+out["cex_commitments"] = {"states": nst, "assets": 500, "kernel_ms": round(ms, 1), "states_per_s": round(nst / (ms * 1e-3)),
+                          "width13_permutations_per_s": round(nst * 834 / (ms * 1e-3))}
 print(json.dumps(out))
