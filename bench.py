@@ -310,7 +310,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32x8 (254-bit Montgomery Fp/Fr)",
+            "dtype": "i32x9 (254-bit Fp/Fr on 9 x 29-bit signed lazy Montgomery limbs in registers; u32x8 Montgomery in memory)",
             "data": "synthetic",
             "config": {"workload": f"zkpor50_1380-shaped prove tail: D=2^{log2}, n_wires=2^{log2}, commit 2^{log2 - 2}, "
                                    f"scalars={args.scalars}, {len(workers)} proof(s) in flight per GPU"},
