@@ -47,6 +47,68 @@ def gen(two=False):
             L.append(f"v_ashrrev_i64 {acc}, 29, {acc}")
     return L
 
+def gen_sqr():
+    """a*a: the 36 off-diagonal products are taken once against the doubled limbs d_j = 2 a_j, plus the 9 diagonal ones:
+    45 + 9 (doubling) instead of 81 operand products.  Input TIGHT (the doubled limbs must stay below 2^31)."""
+    L = []
+    A = lambda i: f"%[a{i}]"
+    Dd = lambda i: f"%[d{i}]"
+    Q = lambda i: f"%[q{i}]"
+    P = lambda i: f"%[p{i}]"
+    acc = "v[0:1]"
+    for i in range(1, 9):
+        L.append(f"v_lshlrev_b32_e32 {Dd(i)}, 1, {A(i)}")
+    for k in range(18):
+        prods = []
+        for i in range(max(0, k - 8), min(k, 8) + 1):
+            j = k - i
+            if i < j:
+                prods.append((A(i), Dd(j)))
+            elif i == j:
+                prods.append((A(i), A(i)))
+        for i in range(max(0, k - 8), min(k - 1, 8) + 1):
+            if i < k and k - i <= 8:
+                prods.append((Q(i), P(k - i)))
+        first = (k == 0)
+        for (x, y) in prods:
+            if first:
+                L.append(f"v_mad_i64_i32 {acc}, vcc, {x}, {y}, 0")
+                first = False
+            else:
+                L.append(f"v_mad_i64_i32 {acc}, vcc, {x}, {y}, {acc}")
+        if k < 9:
+            L.append(f"v_mul_lo_u32 {Q(k)}, v0, %[inv]")
+            L.append(f"v_and_b32_e32 {Q(k)}, 0x1fffffff, {Q(k)}")
+            L.append(f"v_mad_i64_i32 {acc}, vcc, {Q(k)}, {P(0)}, {acc}")
+        elif k < 17:
+            L.append(f"v_and_b32_e32 %[r{k - 9}], 0x1fffffff, v0")
+        else:
+            L.append(f"v_mov_b32_e32 %[r8], v0")
+        if k < 17:
+            L.append(f"v_ashrrev_i64 {acc}, 29, {acc}")
+    return L
+
+
+def emit_sqr(name):
+    lines = gen_sqr()
+    body = "\n".join(f'        "{l}\\n\\t"' for l in lines)
+    outs = (", ".join(f'[r{i}] "=&v"(r[{i}])' for i in range(9)) + ", " + ", ".join(f'[q{i}] "=&v"(q[{i}])' for i in range(9)) + ", "
+            + ", ".join(f'[d{i}] "=&v"(d[{i}])' for i in range(1, 9)))
+    ins = ", ".join(f'[a{i}] "v"(a[{i}])' for i in range(9))
+    ins += ", " + ", ".join(f'[p{i}] "s"(P::mod29({i}))' for i in range(9)) + ', [inv] "s"(P::INV29)'
+    return f'''// r <- a*a*2^-261 mod m; signed limbs, input TIGHT; {len(lines)} instructions (45 operand products instead of 81)
+template <class P>
+__device__ __forceinline__ void {name}(u32 (&r)[9], const u32 (&a)[9]) {{
+    u32 q[9], d[9];
+    asm(
+{body}
+        : {outs}
+        : {ins}
+        : "vcc", "v0", "v1");
+}}
+'''
+
+
 def emit(name, two):
     lines = gen(two)
     body = "\n".join(f'        "{l}\\n\\t"' for l in lines)
@@ -73,9 +135,9 @@ __device__ __forceinline__ void {name}({sig}) {{
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    txt = "// GENERATED by tools/gen_fe29_asm.py — do not edit.  gfx950 device code only.\n\n" + emit("mont_mul29_asm", False) + "\n" + emit("mont_mul2_29_asm", True)
+    txt = "// GENERATED by tools/gen_fe29_asm.py — do not edit.  gfx950 device code only.\n\n" + emit("mont_mul29_asm", False) + "\n" + emit("mont_mul2_29_asm", True) + "\n" + emit_sqr("mont_sqr29_asm")
     open(os.path.join(here, "..", "zkmerkle-proof-of-solvency_amd", "csrc", "fe29_asm.inc"), "w").write(txt)
-    print("mul29:", len(gen(False)), "mul2_29:", len(gen(True)))
+    print("mul29:", len(gen(False)), "mul2_29:", len(gen(True)), "sqr29:", len(gen_sqr()))
 
 
 if __name__ == "__main__":
