@@ -1,6 +1,7 @@
 """Throughput of the rows either side of the prove tail, on one MI355X:
 decompression of compressed key points, device-side constraint evaluation, and the device-resident account tree.
-usage: python tools/bench_aux.py   -> one JSON line"""
+usage: python tests/bench_aux.py   -> one JSON line.  Lives under tests/ because it uses the oracle (to produce compressed
+inputs and to check outputs), which only test code may touch."""
 import ctypes, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -79,7 +80,6 @@ out["account_tree"] = {"leaves": N, "build_ms": round(dt_build * 1e3, 1), "leave
                        "get_proofs_1380_ms": round(dt_proofs * 1e3, 2)}
 t.close(); leaves.free()
 # ---- a12 / f3: CEX asset-list commitments, 4096 boundary states x 500 assets (one state per thread) ----
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cex_cases as C
 consts = C.make_assets(500, seed=3)
 nst = 4096

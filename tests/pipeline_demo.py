@@ -8,12 +8,12 @@
   wire vector w --zkpor_r1cs_eval_dev--> a, b, c in HBM --zkpor_prove_tail_dev--> proof --oracle pairing verifier--> accept
 
 The circuit is the oracle's small synthetic R1CS (the real BatchCreateUserCircuit needs gnark to compile it, INTEGRATION.md);
-every interface used is the one the real circuit would go through.  usage: python examples/pipeline_demo.py [n_accounts]"""
+every interface used is the one the real circuit would go through.  usage: python tests/pipeline_demo.py [n_accounts]"""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+for p in (os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):  # lives under tests/: it uses the oracle as checker
     sys.path.insert(0, p)
 import numpy as np
 import oracle as O

@@ -1,4 +1,4 @@
-"""-m gpu: the whole accelerated path in service order (examples/pipeline_demo.py): leaves -> tree -> proofs -> CEX / batch
+"""-m gpu: the whole accelerated path in service order (tests/pipeline_demo.py): leaves -> tree -> proofs -> CEX / batch
 commitments -> compressed key -> resident R1CS -> proof -> pairing verification, every step checked against the oracle."""
 import importlib.util
 import os
@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_pipeline_demo():
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "pipeline_demo.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pipeline_demo.py")
     spec = importlib.util.spec_from_file_location("pipeline_demo", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -10,7 +10,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd"))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import zkpor
 
