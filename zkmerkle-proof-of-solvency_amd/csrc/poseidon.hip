@@ -408,10 +408,12 @@ struct PosDev {  // everything a kernel needs to hash
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// one full sponge block (width 13) out of line: its register allocation (state of 117 limbs) stays separate from the
-// callers' (account parsing, the 32-bit generic path for the ragged block)
-__device__ __noinline__ void full_block29(const Fr* st, const PosDev& P, Fr* cap, Fr* out) {
-    constexpr int t = POS_MAX_T;
+// one sponge block of compile-time width out of line: its register allocation (13 x 9 limbs for the full block) stays
+// separate from the callers' (account parsing, the 32-bit generic path for the remaining widths).  Instantiated for the
+// full block (13) and for the two ragged widths the reference's inputs produce: 5 (100, 1000 or 10 000 elements leave 4) and
+// 6 (the 5-element account leaf).
+template <int t>
+__device__ __noinline__ void sponge_block29(const Fr* st, const PosDev& P, Fr* cap, Fr* out) {
     Fr29 s29[t];
 #pragma unroll
     for (int i = 0; i < t; ++i) s29[i] = Fr29::from32<5>(st[i]);
@@ -455,8 +457,10 @@ struct Sponge {
         int t = fill + 1;
         st[0] = cap;
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (t == POS_MAX_T && P.tab29) {  // the full block: registers + 29-bit limbs
-            full_block29(st, P, &cap, &out);
+        if (P.tab29 && (t == POS_MAX_T || t == 5 || t == 6)) {  // registers + 29-bit limbs
+            if (t == POS_MAX_T) sponge_block29<POS_MAX_T>(st, P, &cap, &out);
+            else if (t == 5) sponge_block29<5>(st, P, &cap, &out);
+            else sponge_block29<6>(st, P, &cap, &out);
             fill = 0;
             return;
         }
