@@ -109,17 +109,23 @@ __device__ __forceinline__ void {name}(u32 (&r)[9], const u32 (&a)[9]) {{
 '''
 
 
-def emit(name, two):
+def emit(name, two, ksgpr=False):
+    """ksgpr: the first factor of each product (a, and c for the double product) is a wave-uniform CONSTANT held in SGPRs
+    (table rows read through the scalar cache): no VGPR copies, 9 or 18 registers less pressure.  VOP3 reads one scalar
+    per instruction, which is all a partial product k_i * x_j needs."""
     lines = gen(two)
     body = "\n".join(f'        "{l}\\n\\t"' for l in lines)
     outs = ", ".join(f'[r{i}] "=&v"(r[{i}])' for i in range(9)) + ", " + ", ".join(f'[q{i}] "=&v"(q[{i}])' for i in range(9))
-    ins = ", ".join(f'[a{i}] "v"(a[{i}])' for i in range(9)) + ", " + ", ".join(f'[b{i}] "v"(b[{i}])' for i in range(9))
+    kc = "s" if ksgpr else "v"
+    ins = ", ".join(f'[a{i}] "{kc}"(a[{i}])' for i in range(9)) + ", " + ", ".join(f'[b{i}] "v"(b[{i}])' for i in range(9))
     if two:
-        ins += ", " + ", ".join(f'[c{i}] "v"(c[{i}])' for i in range(9)) + ", " + ", ".join(f'[d{i}] "v"(d[{i}])' for i in range(9))
+        ins += ", " + ", ".join(f'[c{i}] "{kc}"(c[{i}])' for i in range(9)) + ", " + ", ".join(f'[d{i}] "v"(d[{i}])' for i in range(9))
     ins += ", " + ", ".join(f'[p{i}] "s"(P::mod29({i}))' for i in range(9)) + ', [inv] "s"(P::INV29)'
     sig = "u32 (&r)[9], const u32 (&a)[9], const u32 (&b)[9]" + (", const u32 (&c)[9], const u32 (&d)[9]" if two else "")
     doc = ("r <- (a*b + c*d) * 2^-261 mod m; signed limbs, all four inputs TIGHT (|limb| <= 2^29 + 2)" if two
            else "r <- a*b*2^-261 mod m; signed limbs, one input tight, the other |limb| < 2^30")
+    if ksgpr:
+        doc += "; a" + (" and c" if two else "") + " wave-uniform constants in SGPRs"
     return f'''// {doc}; {len(lines)} instructions, no carry collection, no final subtraction (lazy range)
 template <class P>
 __device__ __forceinline__ void {name}({sig}) {{
@@ -135,7 +141,7 @@ __device__ __forceinline__ void {name}({sig}) {{
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    txt = "// GENERATED by tools/gen_fe29_asm.py — do not edit.  gfx950 device code only.\n\n" + emit("mont_mul29_asm", False) + "\n" + emit("mont_mul2_29_asm", True) + "\n" + emit_sqr("mont_sqr29_asm")
+    txt = "// GENERATED by tools/gen_fe29_asm.py — do not edit.  gfx950 device code only.\n\n" + emit("mont_mul29_asm", False) + "\n" + emit("mont_mul2_29_asm", True) + "\n" + emit_sqr("mont_sqr29_asm") + "\n" + emit("mont_mul29_k_asm", False, True) + "\n" + emit("mont_mul2_29_k_asm", True, True)
     open(os.path.join(here, "..", "zkmerkle-proof-of-solvency_amd", "csrc", "fe29_asm.inc"), "w").write(txt)
     print("mul29:", len(gen(False)), "mul2_29:", len(gen(True)), "sqr29:", len(gen_sqr()))
 

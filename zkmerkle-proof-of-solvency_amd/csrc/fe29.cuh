@@ -144,6 +144,20 @@ struct Fe29T {
         return mul2_portable(a, b, c, d);
 #endif
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // products whose first factor(s) are WAVE-UNIFORM constants (table rows read through the scalar cache): the constant
+    // limbs are SGPR operands of the multiply-adds — no VGPR copies.  A non-uniform `k` would silently use lane 0's value.
+    __device__ __forceinline__ static Fp29 mulk(const Fp29& k, const Fp29& b) {
+        Fp29 r;
+        mont_mul29_k_asm<P>(r.l, k.l, b.l);
+        return r;
+    }
+    __device__ __forceinline__ static Fp29 mul2k(const Fp29& k0, const Fp29& b, const Fp29& k1, const Fp29& d) {
+        Fp29 r;
+        mont_mul2_29_k_asm<P>(r.l, k0.l, b.l, k1.l, d.l);
+        return r;
+    }
+#endif
     // limb-wise, no carry sweep: tight (+/-) tight -> loose
     ZK_HD static Fp29 add_l(const Fp29& a, const Fp29& b) {
         Fp29 r;

@@ -323,11 +323,11 @@ ZK_D Fr29 k29(const u32* base, int idx) {
 }
 template <int N>
 ZK_D Fr29 dot29(const u32* consts, const Fr29* v) {  // sum_j consts[j] * v[j]; all operands tight
-    Fr29 acc = Fr29::mul2(k29(consts, 0), v[0], k29(consts, 1), v[1]);
+    Fr29 acc = Fr29::mul2k(k29(consts, 0), v[0], k29(consts, 1), v[1]);
 #pragma unroll
     for (int p = 1; p < N / 2; ++p)
-        acc = Fr29::reduce32(Fr29::add_l(acc, Fr29::mul2(k29(consts, 2 * p), v[2 * p], k29(consts, 2 * p + 1), v[2 * p + 1])));
-    if (N & 1) acc = Fr29::reduce32(Fr29::add_l(acc, Fr29::mul(k29(consts, N - 1), v[N - 1])));
+        acc = Fr29::reduce32(Fr29::add_l(acc, Fr29::mul2k(k29(consts, 2 * p), v[2 * p], k29(consts, 2 * p + 1), v[2 * p + 1])));
+    if (N & 1) acc = Fr29::reduce32(Fr29::add_l(acc, Fr29::mulk(k29(consts, N - 1), v[N - 1])));
     return acc;
 }
 ZK_D Fr29 pow5_29(const Fr29& x) {
@@ -373,7 +373,7 @@ ZK_D void permute29(Fr29 (&st)[T], const u32* rc, const u32* m, const u32* prc, 
             for (int j = 1; j < T; ++j) st[j] = Fr29::reduce32(Fr29::add_l(st[j], k29(k, j)));
             Fr29 acc = dot29<T>(s, st);
 #pragma unroll
-            for (int j = 1; j < T; ++j) st[j] = Fr29::add_l(st[j], Fr29::mul(k29(s, T + j - 1), st[0]));  // loose: reduced at the next round's constant add
+            for (int j = 1; j < T; ++j) st[j] = Fr29::add_l(st[j], Fr29::mulk(k29(s, T + j - 1), st[0]));  // loose: reduced at the next round's constant add
             st[0] = acc;
         }
         {
