@@ -208,6 +208,16 @@ int32_t zkpor_cex_commitments(zkpor_ctx* ctx, const zkpor_cex_asset_const_t* ass
 int32_t zkpor_batch_commitments(zkpor_ctx* ctx, const uint8_t* roots32, const uint8_t* before32, const uint8_t* after32,
                                 const uint32_t* min_index, const uint32_t* max_index, size_t n, uint8_t* out32);
 
+/* Account totals and collateral tiers: fills equity / debt / collateral of every zkpor_account_t from its assets and the CEX asset
+ * table — TotalEquity = sum equity_i * price_i, TotalDebt likewise, TotalCollateral = sum of the three tiered collateral values
+ * (src/utils/utils.go:608-615, CalculateAssetValueForCollateral :648-661) — i.e. the big integers zkpor_poseidon_leaves then
+ * hashes.  tier_info_out (may be NULL): 6 bytes per asset record = (loan index, loan flag, margin index, margin flag,
+ * portfolio-margin index, flag), the claims calcAndSetCollateralInfo puts into the circuit witness (circuit/utils.go:227-278).
+ * valid_out (may be NULL): 1 per account that passes the parser's checks (asset collateral <= equity, total collateral >=
+ * total debt, no overflow), else 0. */
+int32_t zkpor_account_totals(zkpor_ctx* ctx, zkpor_account_t* accounts, const zkpor_asset_t* assets, size_t n_assets_total, size_t n,
+                             const zkpor_cex_asset_const_t* cex, size_t n_cex, uint8_t* tier_info_out, uint8_t* valid_out);
+
 /* ---- FixedDepthMerkleTree (reference src/utils/merkletree/merkletree.go:27-52), resident in HBM ----
  * The two-phase usage of the reference: Set leaves (no hashing), Build (all internal nodes above a set leaf), then
  * Root / Get / GetProof.  Hashes cross the boundary as 32-byte big-endian canonical Fr, as the reference holds them.

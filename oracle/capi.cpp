@@ -214,6 +214,45 @@ void orc_cex_commitments(const PackedCexConst* consts, size_t n_assets, const Ce
 #pragma omp parallel for schedule(dynamic, 1)
     for (size_t s = 0; s < n_states; ++s) out[s] = cex_assets_commitment(c.data(), totals + s * n_assets, n_assets);
 }
+// collateral valuation.  tiers: n x (boundary lo, boundary hi, ratio) as 3 u64 each; value / results as 2 u64 (little-endian 128 bit)
+void orc_tier_query(const u64* tiers3, int n, const u64 value[2], int* index, int* flag, u64 out_value[2], u64* precomputed2) {
+    std::vector<TierRatio> t(n);
+    for (int i = 0; i < n; ++i) t[i] = {{tiers3[3 * i], tiers3[3 * i + 1]}, (uint8_t)tiers3[3 * i + 2]};
+    u128 v = ((u128)value[1] << 64) | value[0];
+    tier_index_flag(v, t.data(), n, index, flag);
+    u128 r = asset_value_via_tiers(v, t.data(), n);
+    out_value[0] = (u64)r; out_value[1] = (u64)(r >> 64);
+    if (precomputed2) {
+        u128 pre[64];
+        tier_precomputed(t.data(), n, pre);
+        for (int i = 0; i < n; ++i) { precomputed2[2 * i] = (u64)pre[i]; precomputed2[2 * i + 1] = (u64)(pre[i] >> 64); }
+    }
+}
+// fills equity / debt / collateral of the packed account headers, valid[i] = 1 / 0
+void orc_account_totals(PackedAccountHdr* acc, const PackedAsset* assets, size_t n, const PackedCexConst* consts, size_t n_cex, uint8_t* valid) {
+    std::vector<CexAssetConst> c(n_cex);
+    for (size_t a = 0; a < n_cex; ++a) {
+        c[a].base_price = consts[a].base_price;
+        for (int i = 0; i < 12; ++i) {
+            c[a].loan[i] = {{consts[a].loan[i].boundary[0], consts[a].loan[i].boundary[1]}, consts[a].loan[i].ratio};
+            c[a].margin[i] = {{consts[a].margin[i].boundary[0], consts[a].margin[i].boundary[1]}, consts[a].margin[i].ratio};
+            c[a].pm[i] = {{consts[a].pm[i].boundary[0], consts[a].pm[i].boundary[1]}, consts[a].pm[i].ratio};
+        }
+    }
+#pragma omp parallel for schedule(dynamic, 64)
+    for (size_t i = 0; i < n; ++i) {
+        std::vector<AccountAsset> aa(acc[i].n_assets);
+        for (uint32_t j = 0; j < acc[i].n_assets; ++j) {
+            const PackedAsset& p = assets[acc[i].asset_off + j];
+            aa[j] = {(uint16_t)p.index, p.equity, p.debt, p.loan, p.margin, p.portfolio_margin};
+        }
+        AccountTotals t = account_totals(aa.data(), aa.size(), c.data());
+        acc[i].equity[0] = (u64)t.equity; acc[i].equity[1] = (u64)(t.equity >> 64);
+        acc[i].debt[0] = (u64)t.debt; acc[i].debt[1] = (u64)(t.debt >> 64);
+        acc[i].collateral[0] = (u64)t.collateral; acc[i].collateral[1] = (u64)(t.collateral >> 64);
+        if (valid) valid[i] = t.valid ? 1 : 0;
+    }
+}
 // levels_out (optional): concatenation of levels 1..depth, level l holding ceil(n/2^l) nodes
 void orc_merkle_build(const Fr* leaves, size_t n, int depth, const Fr* nil_leaf, Fr* levels_out, Fr* nil_out,
                       Fr* root_out) {

@@ -282,6 +282,27 @@ def cex_commitments(consts, totals):
     return out
 
 
+def tier_query(tiers, value):
+    """(index, flag, collateral value, precomputed[]) for one tier list [(boundary, ratio), ...] and an integer value"""
+    n = len(tiers)
+    t3 = np.zeros((n, 3), dtype=np.uint64)
+    for i, (b, r) in enumerate(tiers):
+        t3[i] = (b & ((1 << 64) - 1), b >> 64, r)
+    v = np.array([value & ((1 << 64) - 1), value >> 64], dtype=np.uint64)
+    idx = ctypes.c_int(); flag = ctypes.c_int(); out = np.zeros(2, dtype=np.uint64); pre = np.zeros((n, 2), dtype=np.uint64)
+    lib().orc_tier_query(_p(t3), ctypes.c_int(n), _p(v), ctypes.byref(idx), ctypes.byref(flag), _p(out), _p(pre))
+    return idx.value, flag.value, int(out[0]) | (int(out[1]) << 64), [int(a) | (int(b) << 64) for a, b in pre]
+
+
+def account_totals(accounts, assets, consts):
+    """fills equity / debt / collateral of a copy of `accounts`; returns (accounts, valid[n])"""
+    accounts = np.ascontiguousarray(accounts, dtype=ACCOUNT_DTYPE).copy(); assets = np.ascontiguousarray(assets, dtype=ASSET_DTYPE)
+    consts = np.ascontiguousarray(consts, dtype=CEX_CONST_DTYPE)
+    valid = np.zeros(accounts.shape[0], dtype=np.uint8)
+    lib().orc_account_totals(_p(accounts), _p(assets), ctypes.c_size_t(accounts.shape[0]), _p(consts), ctypes.c_size_t(consts.shape[0]), _p(valid))
+    return accounts, valid
+
+
 def merkle_build(leaves, depth, nil_leaf, want_levels=False):
     leaves = _u64(leaves).reshape(-1, 4); n = leaves.shape[0]
     nil_leaf = _u64(nil_leaf)

@@ -268,6 +268,62 @@ static inline Fr cex_assets_commitment(const CexAssetConst* consts, const CexTot
     return poseidon_hash(el.data(), el.size());
 }
 
+// --------------------------------------------------------------------------------- collateral valuation
+// src/utils/utils.go: CalculatePrecomputedValue (:420-432), CalculateAssetValueViaTiersRatio (:663-685),
+// CalculateAssetValueForCollateral (:648-661), the account totals of ParseUserDataSet (:608-615), and the tier index /
+// flag choice of circuit/utils.go calcAndSetCollateralInfo (:227-278).  Integers are big.Int there; every value on this
+// path is below 2^128 for inputs the parser accepts (u64 balance x u64 price, boundaries <= 2^118), so unsigned __int128
+// restates it exactly; `overflow` reports the cases where it would not.
+typedef unsigned __int128 u128;
+static inline u128 tier_boundary(const TierRatio& t) { return ((u128)t.boundary[1] << 64) | t.boundary[0]; }
+static inline void tier_precomputed(const TierRatio* tiers, int n, u128* pre) {
+    u128 acc = 0, prev = 0;
+    for (int i = 0; i < n; ++i) {
+        u128 b = tier_boundary(tiers[i]);
+        acc += (b - prev) * tiers[i].ratio / 100;
+        pre[i] = acc;
+        prev = b;
+    }
+}
+// calcAndSetCollateralInfo: the first tier whose boundary is >= value, flag 0; above every boundary: last tier, flag 1
+static inline void tier_index_flag(u128 value, const TierRatio* tiers, int n, int* index, int* flag) {
+    for (int i = 0; i < n; ++i)
+        if (value <= tier_boundary(tiers[i])) { *index = i; *flag = 0; return; }
+    *index = n - 1; *flag = 1;
+}
+static inline u128 asset_value_via_tiers(u128 value, const TierRatio* tiers, int n) {
+    if (n == 0) return 0;
+    u128 pre[64];
+    tier_precomputed(tiers, n, pre);
+    for (int i = 0; i < n; ++i)
+        if (value <= tier_boundary(tiers[i])) {
+            u128 v = i ? value - tier_boundary(tiers[i - 1]) : value;
+            u128 res = v * tiers[i].ratio / 100;
+            return i ? res + pre[i - 1] : res;
+        }
+    return pre[n - 1];
+}
+struct AccountTotals { u128 equity, debt, collateral; bool valid; };
+// totals of one account over its asset list; valid = the checks of ParseUserDataSet (:599-606, :620): every asset's
+// loan + margin + portfolio margin <= equity (no u64 overflow), total collateral >= total debt
+static inline AccountTotals account_totals(const AccountAsset* assets, size_t n, const CexAssetConst* cex) {
+    AccountTotals t = {0, 0, 0, true};
+    for (size_t i = 0; i < n; ++i) {
+        const AccountAsset& a = assets[i];
+        const CexAssetConst& c = cex[a.index];
+        u64 s1 = a.loan + a.margin;
+        u64 s2 = s1 + a.portfolio_margin;
+        if (s1 < a.loan || s2 < s1 || s2 > a.equity) t.valid = false;
+        t.equity += (u128)a.equity * c.base_price;
+        t.debt += (u128)a.debt * c.base_price;
+        t.collateral += asset_value_via_tiers((u128)a.loan * c.base_price, c.loan, 12) +
+                        asset_value_via_tiers((u128)a.margin * c.base_price, c.margin, 12) +
+                        asset_value_via_tiers((u128)a.portfolio_margin * c.base_price, c.pm, 12);
+    }
+    if (t.collateral < t.debt) t.valid = false;
+    return t;
+}
+
 // --------------------------------------------------------------------------------- Merkle tree
 // src/utils/merkletree/merkletree.go: nilHashes (:159-170), Build (:192-279), GetProof (:297-308),
 // VerifyProof (:334-355).  levels[l] holds ceil(n/2^l) computed nodes; anything to the right is

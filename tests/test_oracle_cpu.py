@@ -207,6 +207,40 @@ def test_cex_commitment_matches_bigint_restatement():
     assert any(v >> 252 for v in ints) or any((v >> 126) & 1 for v in ints)
 
 
+def _expected_collateral_value(tiers, collateral, price, index, flag):
+    """the closed form the reference's test derives its expectations from (get_and_check_tier_ratios_query_results_test.go
+    expectedCollateralValue :327-364), restated: floor((B_i - B_{i-1}) * ratio_i / 100) accumulated, then the partial tier"""
+    pre, acc, prev = [], 0, 0
+    for b, r in tiers:
+        acc += (b - prev) * r // 100
+        pre.append(acc); prev = b
+    if flag == 1:
+        return pre[-1]
+    lb = tiers[index - 1][0] if index > 0 else 0
+    lp = pre[index - 1] if index > 0 else 0
+    return lp + (collateral * price - lb) * tiers[index][1] // 100
+
+
+def test_collateral_tier_table_of_the_reference():
+    """GOLDEN: the 21-row table of circuit/get_and_check_tier_ratios_query_results_test.go:145-170 (tests/golden/
+    collateral_tier_cases.json).  A row the reference expects to PASS carries the (index, flag) the native code must choose
+    (calcAndSetCollateralInfo) and its value must match the closed form; a row expected to FAIL carries a claim the native
+    code must NOT produce (or a value above 2^118)."""
+    d = json.load(open(os.path.join(HERE, "golden", "collateral_tier_cases.json")))
+    MAX = int(d["max_tier_boundary"])
+    assert len(d["cases"]) == 21
+    for c in d["cases"]:
+        tiers = [tuple(t) for t in c["tiers"]]
+        v = int(c["collateral"]) * d["price"]
+        idx, flag, val, pre = O.tier_query(tiers, v)
+        consistent = (idx, flag) == (c["index"], c["flag"]) and v <= MAX
+        assert consistent == (not c["expect_fail"]), c["name"]
+        if not c["expect_fail"]:
+            assert val == _expected_collateral_value(tiers, int(c["collateral"]), d["price"], c["index"], c["flag"]), c["name"]
+    # CalculatePrecomputedValue on the floor case: 100*100/100 = 100, then floor(100*33/100) = 33
+    assert O.tier_query([(100, 100), (200, 33)], 150)[3] == [100, 133]
+
+
 def test_merkle_tree_and_leaves_self_consistency():
     # mirrors src/utils/merkletree/merkletree_test.go (build / prove / verify round trip) and utils_test.go:43-136
     # (padding re-implementation); both are self-consistency tests in the reference as well (no golden root there)

@@ -686,6 +686,61 @@ __global__ __launch_bounds__(64) void k_batch_commitments(const uint8_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Account totals and collateral tiers: TotalEquity, TotalDebt, TotalCollateral of every account —
+// the three big integers that enter its leaf hash (src/utils/utils.go:608-615, CalculateAssetValueForCollateral :648-661,
+// CalculateAssetValueViaTiersRatio :663-685, CalculatePrecomputedValue :420-432) — and, per asset, the tier index / flag the
+// circuit witness carries (circuit/utils.go calcAndSetCollateralInfo :227-278).  One thread per account; integers are
+// big.Int in the reference and fit unsigned 128-bit here (u64 balance x u64 price, boundaries <= 2^118).
+typedef unsigned __int128 u128;
+ZK_D u128 tr_boundary(const TierRatioRec& t) { return ((u128)t.boundary[1] << 64) | t.boundary[0]; }
+// value of a collateral position through one tier list, and the (index, flag) claim for the circuit
+ZK_D u128 tier_value(u128 value, const TierRatioRec* tiers, uint8_t* idx_out, uint8_t* flag_out) {
+    u128 pre = 0, prev_b = 0;
+    for (int i = 0; i < 12; ++i) {
+        const u128 b = tr_boundary(tiers[i]);
+        if (value <= b) {
+            *idx_out = (uint8_t)i; *flag_out = 0;
+            return pre + (value - prev_b) * tiers[i].ratio / 100;
+        }
+        pre += (b - prev_b) * tiers[i].ratio / 100;
+        prev_b = b;
+    }
+    *idx_out = 11; *flag_out = 1;
+    return pre;
+}
+__global__ __launch_bounds__(128) void k_account_totals(AccountHdr* __restrict__ acc, const AssetRec* __restrict__ assets, u32 n,
+                                                        const CexAssetConst* __restrict__ cex, u32 n_cex, uint8_t* __restrict__ tier_info,
+                                                        uint8_t* __restrict__ valid) {
+    u32 i = blockIdx.x * 128u + threadIdx.x;
+    if (i >= n) return;
+    const u32 na = acc[i].n_assets, off = acc[i].asset_off;
+    u128 eq = 0, debt = 0, col = 0;
+    bool ok = true;
+    for (u32 j = 0; j < na; ++j) {
+        const AssetRec a = assets[off + j];
+        if (a.index >= n_cex) { ok = false; continue; }
+        const CexAssetConst& c = cex[a.index];
+        const u64 s1 = a.loan + a.margin, s2 = s1 + a.portfolio_margin;
+        if (s1 < a.loan || s2 < s1 || s2 > a.equity) ok = false;                 // ParseUserDataSet :599-606
+        const u128 price = c.base_price;
+        const u128 e = (u128)a.equity * price, d = (u128)a.debt * price;
+        if (eq + e < eq || debt + d < debt) ok = false;
+        eq += e; debt += d;
+        uint8_t ti[6];
+        const u128 v = tier_value((u128)a.loan * price, c.loan, &ti[0], &ti[1]) + tier_value((u128)a.margin * price, c.margin, &ti[2], &ti[3]) +
+                       tier_value((u128)a.portfolio_margin * price, c.portfolio_margin, &ti[4], &ti[5]);
+        if (col + v < col) ok = false;
+        col += v;
+        if (tier_info) for (int k = 0; k < 6; ++k) tier_info[6 * (size_t)(off + j) + k] = ti[k];
+    }
+    if (col < debt) ok = false;                                                  // :620
+    acc[i].equity[0] = (u64)eq; acc[i].equity[1] = (u64)(eq >> 64);
+    acc[i].debt[0] = (u64)debt; acc[i].debt[1] = (u64)(debt >> 64);
+    acc[i].collateral[0] = (u64)col; acc[i].collateral[1] = (u64)(col >> 64);
+    if (valid) valid[i] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // FixedDepthMerkleTree on the device (reference src/utils/merkletree/merkletree.go:27-52): leaves and every internal
 // level live in HBM in Montgomery form next to one "dirty" bitset per level; a clean position reads as nilHashes[level]
 // exactly as getNodeAt (:315-331) does.  Set (:179-187) only stores leaves and marks them; Build (:192-279) recomputes
@@ -1176,6 +1231,33 @@ int32_t zkpor_batch_commitments(zkpor_ctx* ctx, const uint8_t* roots32, const ui
     hipLaunchKernelGGL(k_fr_to_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)dout.p, (uint8_t*)dbe.p, n);
     ZK_KERNEL_CHECK(ctx);
     ZK_HIP(ctx, hipMemcpyAsync(out32, dbe.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+}
+
+// ---- account totals / collateral tiers ----------------------------------------------------------------------------------
+int32_t zkpor_account_totals(zkpor_ctx* ctx, zkpor_account_t* accounts, const zkpor_asset_t* assets, size_t n_assets_total, size_t n,
+                             const zkpor_cex_asset_const_t* cex, size_t n_cex, uint8_t* tier_info_out, uint8_t* valid_out) {
+    if (!ctx || !accounts || !cex || n_cex == 0 || (n_assets_total && !assets)) return ZKPOR_E_ARG;
+    if (n == 0) return ZKPOR_OK;
+    if (n > 0xffffffffull || n_cex > 0xffffffffull) return ZKPOR_E_ARG;
+    for (size_t i = 0; i < n; ++i)
+        if ((size_t)accounts[i].asset_off + accounts[i].n_assets > n_assets_total) { ctx->err = "totals: asset range outside the asset array"; return ZKPOR_E_ARG; }
+    DevTmp da, ds, dc, dt, dv;
+    ZK_TRY(da.put(ctx, accounts, n * sizeof(AccountHdr)));
+    ZK_TRY(ds.put(ctx, assets, n_assets_total * sizeof(AssetRec)));
+    ZK_TRY(dc.put(ctx, cex, n_cex * sizeof(CexAssetConst)));
+    if (tier_info_out) ZK_TRY(dt.make(ctx, n_assets_total * 6));
+    if (valid_out) ZK_TRY(dv.make(ctx, n));
+    {
+        PhaseScope ps(ctx, "account_totals");
+        hipLaunchKernelGGL(k_account_totals, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, (AccountHdr*)da.p, (const AssetRec*)ds.p, (u32)n,
+                           (const CexAssetConst*)dc.p, (u32)n_cex, (uint8_t*)dt.p, (uint8_t*)dv.p);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(accounts, da.p, n * sizeof(AccountHdr), hipMemcpyDeviceToHost, ctx->stream));
+    if (tier_info_out && n_assets_total) ZK_HIP(ctx, hipMemcpyAsync(tier_info_out, dt.p, n_assets_total * 6, hipMemcpyDeviceToHost, ctx->stream));
+    if (valid_out) ZK_HIP(ctx, hipMemcpyAsync(valid_out, dv.p, n, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
 }

@@ -391,6 +391,18 @@ def _batch_commitments(self, roots, before, after, min_idx, max_idx):
     return out
 
 
+def _account_totals(self, accounts, assets, consts, want_tiers=False):
+    """(accounts with equity/debt/collateral filled, valid[n], tier_info[n_assets_total, 6] or None)"""
+    accounts = np.ascontiguousarray(accounts, dtype=ACCOUNT_DTYPE).copy(); assets = np.ascontiguousarray(assets, dtype=ASSET_DTYPE)
+    consts = np.ascontiguousarray(consts, dtype=CEX_CONST_DTYPE)
+    valid = np.zeros(accounts.shape[0], dtype=np.uint8)
+    tiers = np.zeros((assets.shape[0], 6), dtype=np.uint8) if want_tiers else None
+    self._ck(self.lib.zkpor_account_totals(self.h, _p(accounts), _p(assets), ctypes.c_size_t(assets.shape[0]), ctypes.c_size_t(accounts.shape[0]),
+                                           _p(consts), ctypes.c_size_t(consts.shape[0]), _p(tiers), _p(valid)))
+    return accounts, valid, tiers
+
+
+Context.account_totals = _account_totals
 Context.cex_commitments = _cex_commitments
 Context.batch_commitments = _batch_commitments
 Context.g1_decompress = _g1_decompress
