@@ -96,3 +96,24 @@ def test_reference_tier_table_through_the_device(zk):
             tl = [tuple(t) for t in c["tiers"]]
             want = O.tier_query(tl, int(c["collateral"]) * d["price"])[2]
             assert int(got[i]["collateral"][0]) | (int(got[i]["collateral"][1]) << 64) == want, c["name"]
+
+
+def test_reference_sample_data_on_the_device(zk):
+    """the same golden data as tests/test_oracle_cpu.py::test_reference_sample_data_totals_and_validity, through
+    zkpor_account_totals: the fixture account's three totals and the 90 / 10 and 80 / 20 valid / invalid counts"""
+    import refdata as R
+    symbols, consts = R.load_cex_assets()
+    cfg = json.load(open(os.path.join(HERE, "golden", "reference_user_config.json")))
+    acc, assets = R.fixture_account(cfg)
+    tot, valid, _ = zk.account_totals(acc, assets, consts)
+    assert (R.u128(tot[0]["equity"]), R.u128(tot[0]["debt"]), R.u128(tot[0]["collateral"])) == (cfg["TotalEquity"], cfg["TotalDebt"], cfg["TotalCollateral"])
+    assert valid[0] == 1
+    for name, want in (("reference_sample_users0.csv", (90, 10)), ("reference_sample_users1.csv", (80, 20))):
+        acc, assets, parsed = R.load_users(os.path.join(HERE, "golden", name), symbols)
+        got, valid, _ = zk.account_totals(acc, assets, consts)
+        ref, ref_valid = O.account_totals(acc, assets, consts)
+        good = valid.astype(bool) & parsed
+        assert (int(good.sum()), int((~good).sum())) == want, name
+        assert np.array_equal(valid, ref_valid)
+        for field in ("equity", "debt", "collateral"):
+            assert np.array_equal(got[field], ref[field])

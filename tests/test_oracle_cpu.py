@@ -241,6 +241,29 @@ def test_collateral_tier_table_of_the_reference():
     assert O.tier_query([(100, 100), (200, 33)], 150)[3] == [100, 133]
 
 
+def test_reference_sample_data_totals_and_validity():
+    """GOLDEN (reference data): (1) the account of src/verifier/config/user_config.json: its TotalEquity / TotalDebt /
+    TotalCollateral follow from its four assets and src/sampledata/cex_assets_info.csv (prices, real tier tables) — pins
+    the collateral valuation end to end; (2) TestParseUserDataSet (src/utils/utils_test.go:138-177): sample_users0.csv has
+    90 valid + 10 invalid accounts, sample_users1.csv 80 + 20 — pins the validity rules (position collateral <= equity,
+    total collateral >= total debt)."""
+    import refdata as R
+    symbols, consts = R.load_cex_assets()
+    assert symbols == ["btc", "eth", "bnb", "shib"]
+    cfg = json.load(open(os.path.join(HERE, "golden", "reference_user_config.json")))
+    acc, assets = R.fixture_account(cfg)
+    tot, valid = O.account_totals(acc, assets, consts)
+    assert R.u128(tot[0]["equity"]) == cfg["TotalEquity"]
+    assert R.u128(tot[0]["debt"]) == cfg["TotalDebt"]
+    assert R.u128(tot[0]["collateral"]) == cfg["TotalCollateral"]
+    assert valid[0] == 1
+    for name, want in (("reference_sample_users0.csv", (90, 10)), ("reference_sample_users1.csv", (80, 20))):
+        acc, assets, parsed = R.load_users(os.path.join(HERE, "golden", name), symbols)
+        _, valid = O.account_totals(acc, assets, consts)
+        good = valid.astype(bool) & parsed
+        assert (int(good.sum()), int((~good).sum())) == want, name
+
+
 def test_merkle_tree_and_leaves_self_consistency():
     # mirrors src/utils/merkletree/merkletree_test.go (build / prove / verify round trip) and utils_test.go:43-136
     # (padding re-implementation); both are self-consistency tests in the reference as well (no golden root there)
