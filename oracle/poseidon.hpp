@@ -14,10 +14,13 @@
 //    src/verifier/config/user_config.json — for every level k >= 15 its Merkle proof satisfies
 //    Proof[k+1] == permute([0, Proof[k], Proof[k]])[1]  (12 exact 254-bit matches; element [0] does NOT
 //    match).  So: capacity element state[0] = 0, inputs in state[1..], digest = state[1].
-//  * NOT pinned by reference data: the digest index for other widths (taken to be the same single
-//    `state[1]`), and which element chains blocks of 12 for inputs longer than 12 (taken to be the
-//    capacity element state[0]: the block copy overwrites state[1..] — SURVEY.md Appendix A.6).  Both
-//    are run-time conventions (PoseidonConv) so a maintainer with the Go toolchain can flip them.
+//  * chaining over blocks of 12, ragged last block, the 5-input leaf hash: the SAME fixture end to end — its account (350
+//    assets x five u64, packed three per element = 584 elements: 48 full blocks + a block of 8; then
+//    Poseidon(id, TotalEquity, TotalDebt, TotalCollateral, commitment)) hashes to a leaf whose 28 siblings reach the
+//    fixture's Root with digest = state[1] and the capacity element state[0] carried between blocks; the three other
+//    (digest, carry) conventions do not (tests/test_oracle_cpu.py test_reference_fixture_end_to_end_leaf_pins_the_sponge).
+//    The fixture's FIELD layout is that of an earlier revision of the reference (tests/refdata.py); the hash is today's.
+//    The conventions stay run-time parameters (PoseidonConv), default (1, 0) = what the data pins.
 #pragma once
 #include "bn254.hpp"
 #include <map>

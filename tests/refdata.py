@@ -98,3 +98,20 @@ def fixture_account(cfg):
 
 def u128(pair):
     return int(pair[0]) | (int(pair[1]) << 64)
+
+
+def fixture_leaf_inputs(cfg, n_assets=350):
+    """The element lists behind the account leaf of tests/golden/reference_user_config.json.  The fixture was produced by an
+    EARLIER revision of the reference (found by search): 350 assets, five u64 per asset in positional
+    order with no index field — (equity, debt, loan, margin, portfolio margin) — packed three per element as
+    a * 2^128 + b * 2^64 + c, hashed as one chained Poseidon; leaf = Poseidon(id, TotalEquity, TotalDebt, TotalCollateral,
+    commitment).  The field layout is history; what it pins is the hash: 584 elements = 48 full blocks of 12 + a block of 8."""
+    by_index = {a["Index"]: a for a in cfg["Assets"]}
+    flat = []
+    for i in range(n_assets):
+        a = by_index.get(i)
+        flat += [a["Equity"], a["Debt"], a["Loan"], a["Margin"], a["PortfolioMargin"]] if a else [0, 0, 0, 0, 0]
+    flat += [0] * ((-len(flat)) % 3)
+    elements = [flat[i] * (1 << 128) + flat[i + 1] * (1 << 64) + flat[i + 2] for i in range(0, len(flat), 3)]
+    leaf_head = [int(cfg["AccountIdHash"], 16), cfg["TotalEquity"], cfg["TotalDebt"], cfg["TotalCollateral"]]
+    return elements, leaf_head

@@ -264,6 +264,31 @@ def test_reference_sample_data_totals_and_validity():
         assert (int(good.sum()), int((~good).sum())) == want, name
 
 
+def test_reference_fixture_end_to_end_leaf_pins_the_sponge():
+    """GOLDEN (reference data): the account of src/verifier/config/user_config.json hashes to a leaf whose 28-level Merkle
+    path reaches the fixture's Root.  This pins, on the reference's own data: the chained sponge over a long input (584
+    elements: 48 blocks of 12 and a ragged block of 8, capacity element carried in state[0], digest = state[1]), the
+    5-input leaf hash (width 6), the pack-three-u64 element format and the 2-to-1 node hash at every level."""
+    import refdata as R
+    cfg = json.load(open(os.path.join(HERE, "golden", "reference_user_config.json")))
+    elements, head = R.fixture_leaf_inputs(cfg)
+    assert len(elements) == 584
+    commitment = O.poseidon_hash(O.fr_from_ints(elements))
+    leaf = O.poseidon_hash(np.concatenate([O.fr_from_ints(head), commitment[None, :]]))
+    proof = O.fr_from_ints([int.from_bytes(base64.b64decode(p), "big") for p in cfg["Proof"]])
+    root = O.fr_from_ints([int(cfg["Root"], 16)])[0]
+    assert O.merkle_verify(root, cfg["AccountIndex"], proof, leaf)
+    # the other candidate conventions do not reach the root: the data really discriminates
+    for conv in ((1, 1), (0, 0), (0, 1)):
+        O.poseidon_set_convention(*conv)
+        try:
+            c2 = O.poseidon_hash(O.fr_from_ints(elements))
+            l2 = O.poseidon_hash(np.concatenate([O.fr_from_ints(head), c2[None, :]]))
+            assert not O.merkle_verify(root, cfg["AccountIndex"], proof, l2)
+        finally:
+            O.poseidon_set_convention(1, 0)
+
+
 def test_merkle_tree_and_leaves_self_consistency():
     # mirrors src/utils/merkletree/merkletree_test.go (build / prove / verify round trip) and utils_test.go:43-136
     # (padding re-implementation); both are self-consistency tests in the reference as well (no golden root there)

@@ -124,3 +124,20 @@ def test_account_leaves_padding_edge_cases(zk):
     with pytest.raises(zkpor.ZkporError):
         bad = acc.copy(); bad[0]["n_assets"] = 51
         zk.poseidon_leaves(bad, assets, tier)
+
+
+def test_reference_fixture_end_to_end_leaf_on_device(zk):
+    """the reference's user_config.json account through the device: chained sponge over 584 elements, 5-input leaf hash,
+    then its 28-sibling Merkle proof against the fixture Root (see test_oracle_cpu.py for what this pins)"""
+    import refdata as R
+    import zkpor
+    cfg = json.load(open(os.path.join(HERE, "golden", "reference_user_config.json")))
+    elements, head = R.fixture_leaf_inputs(cfg)
+    commitment = zk.poseidon_hash(O.fr_from_ints(elements), len(elements))
+    assert np.array_equal(commitment[0], O.poseidon_hash(O.fr_from_ints(elements)))
+    leaf = zk.poseidon_hash(np.concatenate([O.fr_from_ints(head), commitment]), 5)
+    proofs = np.stack([np.frombuffer(base64.b64decode(p), dtype=np.uint8) for p in cfg["Proof"]])
+    ok = zkpor.verify_proofs(zk, bytes.fromhex(cfg["Root"]), [cfg["AccountIndex"]], proofs, O.fr_to_be(leaf), 28)
+    assert ok.all()
+    bad = zkpor.verify_proofs(zk, bytes.fromhex(cfg["Root"]), [cfg["AccountIndex"] ^ 1], proofs, O.fr_to_be(leaf), 28)
+    assert not bad.any()
