@@ -144,3 +144,12 @@ def test_g1_msm_split_matches_unsplit(zk):
         assert _g1_eq(zkpor.g1_jac_sum(parts), O.g1_msm(pts, sc))
     finally:
         dp.free(); ds.free()
+
+
+def test_g1_public_known_answer(zk):
+    """2 * (1, 2) = the EIP-196 doubling vector, as a one-point MSM and as G + G (two points, unit scalars)"""
+    g = O.g1_from_scalars(O.fr_from_ints([1]))
+    want = np.concatenate([O.fp_from_ints([0x030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3]),
+                           O.fp_from_ints([0x15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4])]).reshape(8)
+    assert _g1_eq(zk.msm_g1(g, O.fr_from_ints([2])), want)
+    assert _g1_eq(zk.msm_g1(np.concatenate([g, g]), O.fr_from_ints([1, 1])), want)

@@ -119,6 +119,15 @@ def test_groth16_tail_verifies_in_the_exponent(z_bitrev):
     assert bs_x_a1 == O.fp_to_ints(pr.view(np.uint64).reshape(-1, 4)[3:4])[0]
 
 
+def test_g1_doubling_public_known_answer():
+    """public known answer for the curve arithmetic: 2 * (1, 2) on alt_bn128 (the doubling vector of the EIP-196 precompile
+    tests, a constant of every BN254 implementation)"""
+    two_g = O.g1_from_scalars(O.fr_from_ints([2]))[0]
+    x, y = O.fp_to_ints(two_g.reshape(2, 4))
+    assert x == 0x030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3
+    assert y == 0x15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4
+
+
 def test_pairing_is_bilinear_and_nondegenerate():
     """oracle/pairing.hpp (reduced Tate pairing): the properties a verifier relies on"""
     one = O.fr_from_ints([1])[0]
