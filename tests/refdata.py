@@ -115,3 +115,16 @@ def fixture_leaf_inputs(cfg, n_assets=350):
     elements = [flat[i] * (1 << 128) + flat[i + 1] * (1 << 64) + flat[i + 2] for i in range(0, len(flat), 3)]
     leaf_head = [int(cfg["AccountIdHash"], 16), cfg["TotalEquity"], cfg["TotalDebt"], cfg["TotalCollateral"]]
     return elements, leaf_head
+
+
+def load_cex_assets_500(path=os.path.join(HERE, "golden", "reference_cex_assets_info_483.csv")):
+    """the production-sized table of src/utils/cex_assets_info.csv (TestParseCexAssetInfoFromFile: 483 real assets), filled up
+    to utils.AssetCounts = 500 with the reserved entries of ParseCexAssetInfoFromFile (:494-503): price 0, padding tiers"""
+    symbols, consts = load_cex_assets(path)
+    full = np.zeros(500, dtype=O.CEX_CONST_DTYPE)
+    full[:len(symbols)] = consts
+    for i in range(len(symbols), 500):
+        for group in ("loan", "margin", "portfolio_margin"):
+            for t in range(12):
+                full[i][group][t]["boundary"] = (MAX_BOUNDARY & ((1 << 64) - 1), MAX_BOUNDARY >> 64)
+    return symbols + ["reserved"] * (500 - len(symbols)), full

@@ -42,3 +42,30 @@ def test_batch_commitments_match_oracle(zk):
         el = np.concatenate([O.fr_from_be(roots[i:i + 1]), O.fr_from_be(before[i:i + 1]), O.fr_from_be(after[i:i + 1]),
                              O.fr_from_ints([int(mn[i]), int(mx[i])])])
         assert got[i].tobytes() == O.fr_to_be(O.poseidon_hash(el)[None, :])[0].tobytes()
+
+
+def test_production_asset_table_on_the_device(zk):
+    """the reference's 483-asset table (src/utils/cex_assets_info.csv, padded to 500): commitments of a few CEX states and
+    the totals of random accounts over its real tier lists, device = oracle"""
+    import refdata as R
+    import zkpor
+    _, consts = R.load_cex_assets_500()
+    totals = C.make_totals(3, 500, seed=8)
+    assert np.array_equal(zk.cex_commitments(consts, totals), O.fr_to_be(O.cex_commitments(consts, totals)))
+    rng = np.random.default_rng(4)
+    n_acc = 2000
+    acc = np.zeros(n_acc, dtype=zkpor.ACCOUNT_DTYPE)
+    k = rng.integers(0, 51, size=n_acc)
+    off = np.concatenate([[0], np.cumsum(k)[:-1]])
+    acc["n_assets"] = k; acc["asset_off"] = off
+    assets = np.zeros(int(k.sum()), dtype=zkpor.ASSET_DTYPE)
+    for i in range(n_acc):
+        assets["index"][off[i]:off[i] + k[i]] = np.sort(rng.choice(483, size=k[i], replace=False))
+    eq = rng.integers(0, 1 << 46, size=assets.shape[0], dtype=np.uint64)
+    assets["equity"] = eq; assets["debt"] = rng.integers(0, 1 << 34, size=assets.shape[0], dtype=np.uint64)
+    assets["loan"] = eq // np.uint64(3); assets["margin"] = eq // np.uint64(5); assets["portfolio_margin"] = eq // np.uint64(7)
+    got, valid, _ = zk.account_totals(acc, assets, consts)
+    ref, ref_valid = O.account_totals(acc, assets, consts)
+    assert np.array_equal(valid, ref_valid)
+    for field in ("equity", "debt", "collateral"):
+        assert np.array_equal(got[field], ref[field])

@@ -298,6 +298,24 @@ def test_reference_fixture_end_to_end_leaf_pins_the_sponge():
             O.poseidon_set_convention(1, 0)
 
 
+def test_reference_production_asset_table_parses():
+    """TestParseCexAssetInfoFromFile (src/utils/utils_test.go:179-210): src/utils/cex_assets_info.csv holds 483 real assets;
+    every price and tier list goes through the restated parsing rules, and the commitment of the resulting 500-entry
+    table (reserved slots filled) is what the witness service publishes — computed here with the oracle and re-checked
+    against the big-integer rendering of the Go packing"""
+    import cex_cases as C
+    import refdata as R
+    symbols, consts = R.load_cex_assets_500()
+    assert sum(1 for s_ in symbols if s_ != "reserved") == 483 and consts.shape[0] == 500
+    assert (consts["base_price"][:483] > 0).all() and not consts["base_price"][483:].any()
+    totals = np.zeros((1, 500), dtype=O.CEX_TOTALS_DTYPE)
+    totals["total_equity"][0, :483] = np.arange(1, 484, dtype=np.uint64) * np.uint64(10 ** 9)
+    com = O.cex_commitments(consts, totals)[0]
+    ints = [v % O.R_MOD for v in C.elements_bigint(consts, totals[0])]
+    assert len(ints) == 10000
+    assert np.array_equal(com, O.poseidon_hash(O.fr_from_ints(ints)))
+
+
 def test_merkle_tree_and_leaves_self_consistency():
     # mirrors src/utils/merkletree/merkletree_test.go (build / prove / verify round trip) and utils_test.go:43-136
     # (padding re-implementation); both are self-consistency tests in the reference as well (no golden root there)
