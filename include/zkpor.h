@@ -7,6 +7,12 @@
  *   AccountInfoToHash / buildAccountTree        src/utils/utils.go:744-750, src/witness/main.go:130-199 -> zkpor_poseidon_leaves
  *   FixedDepthMerkleTree.Build / Root           src/utils/merkletree/merkletree.go:192-279 -> zkpor_merkle_build
  *   poseidon.Poseidon / hash.Hash Write+Sum     src/utils/account_tree.go:19,27 (hasher factory) -> zkpor_poseidon_hash
+ *   merkletree.FixedDepthMerkleTree (object)    src/utils/merkletree/merkletree.go:137-355, account_tree.go:14-29 -> zkpor_tree_*
+ *   account totals, collateral tier claims      src/utils/utils.go:608-615,648-685, circuit/utils.go:227-278 -> zkpor_account_totals
+ *   Witness.Run per-batch commitments           src/witness/witness/witness.go:159-198, utils.go:26-88,779-800 -> zkpor_cex_commitments,
+ *                                                                                                 zkpor_batch_commitments
+ *   compressed key arrays (pk.WriteTo form)     src/keygen/main.go:46, prover.go:336-349 -> zkpor_pk_set_g1/g2_compressed
+ *   constraint evaluation a, b, c = L.w, R.w, O.w (inside groth16.Prove, prover.go:269) -> zkpor_r1cs_*
  * The cgo binding a maintainer adds on the reference side is shown in INTEGRATION.md.
  *
  * Conventions
