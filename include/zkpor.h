@@ -250,6 +250,13 @@ int32_t zkpor_tree_get_proofs(zkpor_tree* tree, const uint32_t* keys, size_t n, 
 /* VerifyProof (:334-355) for n (key, leaf, proof) triples against one root; ok_out[i] = 1 / 0 */
 int32_t zkpor_merkle_verify_proofs(zkpor_ctx* ctx, const uint8_t root[32], const uint32_t* keys, const uint8_t* proofs,
                                    const uint8_t* leaves32_be, size_t n, int depth, uint8_t* ok_out);
+/* buildAccountTree (src/witness/main.go:130-199) for one chunk of accounts, device-resident end to end: (optionally) the account
+ * totals from the CEX table, the leaf hashes, and Set at keys first_key .. first_key+n-1 — the 32-byte leaves never cross PCIe.
+ * With cex != NULL the totals are computed first (zkpor_account_totals) and written back into `accounts`; with cex == NULL the
+ * totals already in `accounts` are hashed.  Stream a large data set through this in chunks, then zkpor_tree_build once. */
+int32_t zkpor_tree_set_accounts(zkpor_tree* tree, uint64_t first_key, zkpor_account_t* accounts, const zkpor_asset_t* assets,
+                                size_t n_assets_total, size_t n, int tier, const zkpor_cex_asset_const_t* cex_or_null, size_t n_cex,
+                                uint8_t* valid_out_or_null);
 /* poseidon.Poseidon(inputs...) for `count` independent inputs of `len` elements each (Montgomery Fr in/out) */
 int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, size_t count, uint64_t* out);
 

@@ -221,3 +221,41 @@ def test_cpp_host_mirror_driver(zk):
         assert parts[0] == "proof" and int(parts[1]) == k
         assert [bytes.fromhex(h) for h in parts[2:]] == [p.tobytes() for p in want_proofs[i]]
     assert lines[-1] == "verify 1"
+
+
+def test_accounts_straight_into_the_tree(zk):
+    """zkpor_tree_set_accounts: totals -> leaf hashes -> Set without the leaves leaving the device (src/witness/main.go:130-199),
+    in two chunks, equal to the step-by-step path and to the oracle"""
+    import cex_cases as C
+    rng = np.random.default_rng(21)
+    n_acc, n_cex, tier = 700, 60, 50
+    consts = C.make_assets(n_cex, seed=9)
+    consts["base_price"] = rng.integers(1, 1 << 50, size=n_cex, dtype=np.uint64)
+    acc = np.zeros(n_acc, dtype=zkpor.ACCOUNT_DTYPE)
+    k = rng.integers(0, 21, size=n_acc)
+    off = np.concatenate([[0], np.cumsum(k)[:-1]])
+    acc["n_assets"] = k; acc["asset_off"] = off
+    acc["id_be"] = rng.integers(0, 256, size=(n_acc, 32), dtype=np.uint8); acc["id_be"][:, 0] &= 0x0F
+    assets = np.zeros(int(k.sum()), dtype=zkpor.ASSET_DTYPE)
+    for i in range(n_acc):
+        assets["index"][off[i]:off[i] + k[i]] = np.sort(rng.choice(n_cex, size=k[i], replace=False))
+    eq = rng.integers(0, 1 << 44, size=assets.shape[0], dtype=np.uint64)
+    assets["equity"] = eq; assets["debt"] = rng.integers(0, 1 << 30, size=assets.shape[0], dtype=np.uint64)
+    assets["loan"] = eq // np.uint64(3); assets["margin"] = eq // np.uint64(6); assets["portfolio_margin"] = eq // np.uint64(12)
+    t = new_test_tree(zk, 1024)
+    try:
+        half = n_acc // 2
+        a0, v0 = t.set_accounts(0, acc[:half], assets, tier, consts)
+        a1, v1 = t.set_accounts(half, acc[half:], assets, tier, consts)
+        t.build()
+        filled = np.concatenate([a0, a1])
+        ref, ref_valid = O.account_totals(acc, assets, consts)
+        for field in ("equity", "debt", "collateral"):
+            assert np.array_equal(filled[field], ref[field])
+        assert np.array_equal(np.concatenate([v0, v1]), ref_valid)
+        leaves = O.account_leaves(ref, assets, tier)
+        want_root, _, _ = O.merkle_build(leaves, DEPTH, nil_account_hash())
+        assert t.root() == O.fr_to_be(want_root)[0].tobytes()
+        assert np.array_equal(t.get_many(np.arange(n_acc, dtype=np.uint32)), O.fr_to_be(leaves))
+    finally:
+        t.close()

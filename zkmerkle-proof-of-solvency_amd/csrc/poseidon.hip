@@ -1262,4 +1262,50 @@ int32_t zkpor_account_totals(zkpor_ctx* ctx, zkpor_account_t* accounts, const zk
     return ZKPOR_OK;
 }
 
+// ---- accounts straight into the tree -------------------------------------------------------------------------------------
+// buildAccountTree (src/witness/main.go:130-199) for one chunk of accounts, without the leaves ever leaving the device:
+// totals (optional) -> leaf hashes -> Set at keys first_key .. first_key + n - 1.  The caller streams a 10^8-account data
+// set through this in chunks and calls zkpor_tree_build once.
+int32_t zkpor_tree_set_accounts(zkpor_tree* t, uint64_t first_key, zkpor_account_t* accounts, const zkpor_asset_t* assets,
+                                size_t n_assets_total, size_t n, int tier, const zkpor_cex_asset_const_t* cex_or_null, size_t n_cex,
+                                uint8_t* valid_out_or_null) {
+    if (!t || !accounts || n == 0 || tier < 1 || (n_assets_total && !assets)) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = t->ctx;
+    if (first_key + n > t->capacity) { ctx->err = "tree: key range exceeds capacity"; return ZKPOR_E_ARG; }
+    if (n > 0xffffffffull) return ZKPOR_E_ARG;
+    for (size_t i = 0; i < n; ++i)
+        if (accounts[i].n_assets > (uint32_t)tier || (size_t)accounts[i].asset_off + accounts[i].n_assets > n_assets_total) {
+            ctx->err = "tree: account exceeds the tier or the asset array"; return ZKPOR_E_ARG;
+        }
+    PosDev P;
+    ZK_TRY(pos_dev(ctx, &P));
+    DevTmp da, ds, dc, dv, dl;
+    ZK_TRY(da.put(ctx, accounts, n * sizeof(AccountHdr)));
+    ZK_TRY(ds.put(ctx, assets, n_assets_total * sizeof(AssetRec)));
+    ZK_TRY(dl.make(ctx, n * sizeof(Fr)));
+    if (cex_or_null) {
+        if (n_cex == 0 || n_cex > 0xffffffffull) return ZKPOR_E_ARG;
+        ZK_TRY(dc.put(ctx, cex_or_null, n_cex * sizeof(CexAssetConst)));
+        if (valid_out_or_null) ZK_TRY(dv.make(ctx, n));
+        PhaseScope ps(ctx, "account_totals");
+        hipLaunchKernelGGL(k_account_totals, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, (AccountHdr*)da.p, (const AssetRec*)ds.p, (u32)n,
+                           (const CexAssetConst*)dc.p, (u32)n_cex, (uint8_t*)nullptr, (uint8_t*)dv.p);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    {
+        PhaseScope ps(ctx, "poseidon_leaf");
+        hipLaunchKernelGGL(k_account_leaves, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const AccountHdr*)da.p, (const AssetRec*)ds.p, (u32)n, tier,
+                           (Fr*)dl.p, P);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(k_tree_set_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, t->dev, (u64)first_key, (const Fr*)dl.p, n);
+    ZK_KERNEL_CHECK(ctx);
+    if (cex_or_null) {
+        ZK_HIP(ctx, hipMemcpyAsync(accounts, da.p, n * sizeof(AccountHdr), hipMemcpyDeviceToHost, ctx->stream));  // the totals, for the caller's records
+        if (valid_out_or_null) ZK_HIP(ctx, hipMemcpyAsync(valid_out_or_null, dv.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+}
+
 }  // extern "C"

@@ -452,6 +452,17 @@ class FixedDepthMerkleTree:
     def set_range_dev(self, first_key, d_leaves_mont, n):
         self.ctx._ck(self.ctx.lib.zkpor_tree_set_range_dev(self.h, ctypes.c_uint64(first_key), ctypes.c_void_p(d_leaves_mont), ctypes.c_size_t(n)))
 
+    def set_accounts(self, first_key, accounts, assets, tier, consts=None):
+        """leaves of a chunk of accounts computed and Set on the device; returns (accounts with totals, valid) when the CEX
+        table is given (totals computed on the device too), else None"""
+        accounts = np.ascontiguousarray(accounts, dtype=ACCOUNT_DTYPE).copy(); assets = np.ascontiguousarray(assets, dtype=ASSET_DTYPE)
+        valid = np.zeros(accounts.shape[0], dtype=np.uint8) if consts is not None else None
+        c = np.ascontiguousarray(consts, dtype=CEX_CONST_DTYPE) if consts is not None else None
+        self.ctx._ck(self.ctx.lib.zkpor_tree_set_accounts(self.h, ctypes.c_uint64(first_key), _p(accounts), _p(assets), ctypes.c_size_t(assets.shape[0]),
+                                                        ctypes.c_size_t(accounts.shape[0]), ctypes.c_int(tier), _p(c),
+                                                        ctypes.c_size_t(0 if c is None else c.shape[0]), _p(valid)))
+        return (accounts, valid) if consts is not None else None
+
     def build(self):
         self.ctx._ck(self.ctx.lib.zkpor_tree_build(self.h))
 
