@@ -259,3 +259,18 @@ def test_accounts_straight_into_the_tree(zk):
         assert np.array_equal(t.get_many(np.arange(n_acc, dtype=np.uint32)), O.fr_to_be(leaves))
     finally:
         t.close()
+
+
+def test_empty_capacity_tree(zk):
+    """capacity 0: nothing can be Set; root, Get and GetProof all read nil hashes"""
+    t = new_test_tree(zk, 0)
+    try:
+        with pytest.raises(zkpor.ZkporError):
+            t.set(0, make_leaf_values([0])[0].tobytes())
+        t.build()
+        assert t.root() == t.nil_hash(28)
+        assert t.get(0) == t.nil_hash(0)
+        proof = t.get_proof(12345)
+        assert proof == [t.nil_hash(l) for l in range(28)]
+    finally:
+        t.close()

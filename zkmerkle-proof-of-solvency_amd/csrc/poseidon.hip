@@ -749,7 +749,7 @@ __global__ __launch_bounds__(128) void k_account_totals(AccountHdr* __restrict__
 struct TreeDev {
     Fr* nodes[33];     // nodes[0] = leaves
     u32* dirty[33];    // bitset, one bit per position of the level
-    u32 cnt[33];       // positions backed by memory at each level (ceil(capacity / 2^l)); cnt == 0 -> 2^32 leaves
+    u64 cnt[33];       // positions backed by memory at each level: ceil(capacity / 2^l), up to 2^32
     const Fr* nil;     // nil[0..depth]
     int depth;
 };
@@ -814,7 +814,7 @@ __global__ void k_tree_proofs(TreeDev T, const u32* __restrict__ keys, size_t n,
     if (g >= n * (size_t)T.depth) return;
     const int level = (int)(g % T.depth);
     const u64 pos = ((u64)keys[g / T.depth] >> level) ^ 1u;
-    const u64 count = T.cnt[level] ? T.cnt[level] : ((u64)1 << 32);
+    const u64 count = T.cnt[level];
     Fr c = Fr::from_mont(tree_node(T, level, pos, count));
     u32* o = (u32*)(out + 32 * g);
     for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(c.v[7 - j]);
@@ -823,7 +823,7 @@ __global__ void k_tree_proofs(TreeDev T, const u32* __restrict__ keys, size_t n,
 __global__ void k_tree_get(TreeDev T, const u32* __restrict__ keys, size_t n, uint8_t* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const u64 count = T.cnt[0] ? T.cnt[0] : ((u64)1 << 32);
+    const u64 count = T.cnt[0];
     Fr c = Fr::from_mont(tree_node(T, 0, keys[i], count));
     u32* o = (u32*)(out + 32 * i);
     for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(c.v[7 - j]);
@@ -1057,7 +1057,7 @@ int32_t zkpor_tree_create(zkpor_ctx* ctx, int depth, const uint8_t nil_leaf[32],
     int32_t rc = ZKPOR_OK;
     for (int l = 0; l <= depth && rc == ZKPOR_OK; ++l) {
         t->count[l] = m;
-        t->dev.cnt[l] = (u32)m;  // 2^32 wraps to 0, which the kernels read as 2^32
+        t->dev.cnt[l] = m;
         rc = tree_alloc<Fr>(t, m, &t->dev.nodes[l], false);
         if (rc == ZKPOR_OK) rc = tree_alloc<u32>(t, (m + 31) / 32 + 2, &t->dev.dirty[l], true);
         m = (m + 1) / 2;
