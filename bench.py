@@ -40,6 +40,23 @@ def pmc_traffic_bytes_per_launch(kernel="k_acc_level1_fp29"):
         return None, None
 
 
+def pmc_valu_issue_bound_ms(kernel="k_acc_level1_fp29"):
+    """VALU issue-rate bound of one average launch of `kernel` (ms): wave-instructions counted by rocprofv3 SQ_INSTS_VALU in
+    the committed profile x 4 issue cycles / (1024 SIMDs x nominal clock).  The path is integer-VALU work, so this — not
+    HBM bandwidth — is the ceiling the kernel is measured against (reported beside the contract's HBM figure)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        k = d["kernels"][kernel]
+        per_launch = float(k["valu_wave_insts_total"]) / k["launches"]
+        return per_launch * d["issue_cycles_per_wave_instruction"] / (d["simds"] * d["nominal_clock_hz"]) * 1e3, os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def algorithmic_bytes_per_proof(log2, n_wires, n_commit):
     d = 1 << log2
     msm = 4 * 96 * n_wires + 160 * n_wires  # 3 witness G1 MSMs + Z (counted at n_wires ~ D) + G2
@@ -298,7 +315,12 @@ def main():
         achieved = units_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         bproof = algorithmic_bytes_per_proof(log2, n_wires, n_commit)
         tb, tsrc = pmc_traffic_bytes_per_launch()
-        traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and log2 == 26 and args.scalars == "witness") else None
+        profiled_cfg = log2 == 26 and args.scalars == "witness" and not args.window and not args.chunk
+        traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and profiled_cfg) else None
+        vb_ms, vsrc = pmc_valu_issue_bound_ms()
+        valu = ({"issue_bound_ms_per_launch": vb_ms, "frac": vb_ms / (avg_launch_s * 1e3),
+                 "source": f"profiles/{vsrc}: SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz) / live avg launch time"}
+                if (vb_ms and avg_launch_s > 0 and profiled_cfg) else None)
         out = {
             "metric": "Groth16 proofs/sec at 2^26 constraints (zkpor50_1380), 1/2/4/8 MI355X",
             "value": world * args.steps / dt,
@@ -321,6 +343,7 @@ def main():
                                             "non-zero digit, hence traffic > algorithmic bytes") if traffic else None,
                          "kernel": "k_acc_level1_fp29 (G1 bucket accumulation, 9x29-bit limbs)",
                          "avg_launch_ms": avg_launch_s * 1e3,
+                         "valu_issue": valu,
                          "note": "path is VALU-integer bound (~1e3 int-ops/byte); whole-proof algorithmic bytes "
                                  f"{bproof / 1e9:.1f} GB -> {bproof * (args.steps / dt) / 1e9:.1f} GB/s per GPU"},
             "phases_ms_per_proof": {k: round(v["ms_per_proof"], 3) for k, v in phases.items()},
