@@ -3,6 +3,7 @@
  * Drop-in boundary.  Every entry point replaces work the reference does inside ONE call:
  *   groth16.Prove(r1cs, pk, witness)            src/prover/prover/prover.go:269   -> zkpor_prove_tail (+ zkpor_commit)
  *   pk.UnsafeReadFrom / LoadSnarkParamsOnce     src/prover/prover/prover.go:285-367 -> zkpor_pk_* (one-time HBM upload)
+ *   pk.WriteTo / UnsafeReadFrom container         src/keygen/main.go:46, prover.go:343 -> zkpor_pk_load_gnark(_mem), zkpor_pk_gnark_layout
  *   proof.WriteRawTo                            src/prover/prover/prover.go:201   -> zkpor_proof_write_raw
  *   AccountInfoToHash / buildAccountTree        src/utils/utils.go:744-750, src/witness/main.go:130-199 -> zkpor_poseidon_leaves
  *   FixedDepthMerkleTree.Build / Root           src/utils/merkletree/merkletree.go:192-279 -> zkpor_merkle_build
@@ -100,6 +101,32 @@ int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, c
                             const void* beta2, const void* delta2, int log2_domain, const uint8_t* inf_a,
                             const uint8_t* inf_b, size_t n_wires, size_t n_public,
                             const uint32_t* committed_idx, size_t n_committed, int z_order);
+/* ---- gnark key FILE: the container pk.WriteTo writes (src/keygen/main.go:46) and
+ * pk.UnsafeReadFrom reads (src/prover/prover/prover.go:343).  Layout restated in csrc/keyfile.hip; all counts/offsets of
+ * one stream, found by walking its headers on the host (no device needed for zkpor_pk_gnark_layout). */
+typedef struct {
+    uint64_t domain_cardinality;
+    uint64_t n_a, n_b1, n_z, n_k, n_b2;                 /* points in gnark's compacted arrays */
+    uint64_t off_alpha, off_a, off_b1, off_z, off_k;    /* byte offset of the first point of each section */
+    uint64_t off_beta2, off_b2;
+    uint64_t n_wires, n_inf_a, n_inf_b, off_inf_a, off_inf_b;
+    uint64_t n_basis, off_basis, n_basis_sigma, off_basis_sigma; /* CommitmentKeys[0] */
+    uint64_t bytes_total;
+    uint32_t domain_header_bytes;                       /* 169, or 168 for streams without the withPrecompute byte */
+    uint32_t n_commitment_keys;
+} zkpor_pk_layout_t;
+/* ZKPOR_E_ARG (+ text in err, if given) when the bytes are not a well-formed compressed bn254 Groth16 proving key:
+ * every count is cross-checked (len(A)+NbInfinityA = nbWires, masks add up, the stream ends at its last byte ...). */
+int32_t zkpor_pk_gnark_layout(const uint8_t* data, size_t len, zkpor_pk_layout_t* out, char* err, size_t err_len);
+/* Load a whole key from the stream: arrays are decompressed on the device straight from `data` (e.g. the mapped file) and
+ * re-laid out wire-indexed, exactly as after zkpor_pk_set_*_compressed + zkpor_pk_set_consts.  The stream does not say
+ * which wires K leaves out, so the caller passes what the constraint system knows: n_public (ONE wire included) and the
+ * committed + commitment wire indices (gnark r1cs.CommitmentInfo); len(K) must equal nbWires - n_public - n_committed.
+ * info (may be NULL) receives the layout.  zkpor_pk_load_gnark maps `path` read-only and calls the _mem form. */
+int32_t zkpor_pk_load_gnark_mem(zkpor_pk* pk, const uint8_t* data, size_t len, size_t n_public,
+                                const uint32_t* committed_idx, size_t n_committed, zkpor_pk_layout_t* info);
+int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx,
+                            size_t n_committed, zkpor_pk_layout_t* info);
 /* TEST/BENCH utility (no reference counterpart): fill every array of the key with valid curve points generated
  * on the device (random walks from seeded multiples of the generators).  Sizes follow SURVEY.md §8(d) C2 when
  * n_wires = 2^log2_domain.  The key is NOT a sound Groth16 key; it exercises the prover's data path at scale. */

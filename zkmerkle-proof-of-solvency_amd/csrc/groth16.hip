@@ -28,6 +28,8 @@ struct zkpor_pk {
     bool ready = false;
 };
 
+zkpor_ctx* zk_pk_ctx(zkpor_pk* pk) { return pk->ctx; }  // for keyfile.hip
+
 namespace {
 
 // dst[i] = map[i] == 0xffffffff ? infinity : src[map[i]]

@@ -224,6 +224,28 @@ def msm_split_g1(ctx, d_points, d_scalars, n, rank, world, dist=None):
     return g1_jac_sum(parts)
 
 
+class PkLayout(ctypes.Structure):
+    """zkpor_pk_layout_t (include/zkpor.h): counts and byte offsets of the sections of a gnark pk.WriteTo stream"""
+    _fields_ = [(n, ctypes.c_uint64) for n in (
+        "domain_cardinality", "n_a", "n_b1", "n_z", "n_k", "n_b2", "off_alpha", "off_a", "off_b1", "off_z", "off_k", "off_beta2",
+        "off_b2", "n_wires", "n_inf_a", "n_inf_b", "off_inf_a", "off_inf_b", "n_basis", "off_basis", "n_basis_sigma",
+        "off_basis_sigma", "bytes_total")] + [("domain_header_bytes", ctypes.c_uint32), ("n_commitment_keys", ctypes.c_uint32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def pk_gnark_layout(data):
+    """walk the headers of a gnark proving-key stream on the host (no device): dict of counts/offsets, ZkporError if malformed"""
+    lib = load_library()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    out = PkLayout(); err = ctypes.create_string_buffer(512)
+    rc = lib.zkpor_pk_gnark_layout(_p(buf), ctypes.c_size_t(buf.size), ctypes.byref(out), err, ctypes.c_size_t(512))
+    if rc != 0:
+        raise ZkporError(f"zkpor error {rc}: {err.value.decode()}")
+    return out.as_dict()
+
+
 class ProvingKey:
     """HBM-resident proving key (the device half of gnark's groth16.ProvingKey)"""
 
@@ -263,6 +285,21 @@ class ProvingKey:
             self.h, _p(_u64(alpha)), _p(_u64(beta)), _p(_u64(delta)), _p(_u64(beta2)), _p(_u64(delta2)), ctypes.c_int(log2_domain),
             _p(ia), _p(ib), ctypes.c_size_t(n_wires), ctypes.c_size_t(n_public), _p(ci), ctypes.c_size_t(0 if ci is None else ci.size),
             ctypes.c_int(z_order)))
+
+    def load_gnark(self, src, n_public, committed_idx=None):
+        """load a whole key from gnark's pk.WriteTo container (src/keygen/main.go:46): `src` is a path or the bytes;
+        n_public counts the ONE wire; committed_idx = committed + commitment wire indices (r1cs.CommitmentInfo).
+        Returns the container layout as a dict."""
+        ci = None if committed_idx is None else np.ascontiguousarray(committed_idx, dtype=np.uint32)
+        nci = ctypes.c_size_t(0 if ci is None else ci.size)
+        info = PkLayout()
+        if isinstance(src, (str, os.PathLike)):
+            rc = self.ctx.lib.zkpor_pk_load_gnark(self.h, os.fsencode(src), ctypes.c_size_t(n_public), _p(ci), nci, ctypes.byref(info))
+        else:
+            buf = np.frombuffer(bytes(src), dtype=np.uint8)
+            rc = self.ctx.lib.zkpor_pk_load_gnark_mem(self.h, _p(buf), ctypes.c_size_t(buf.size), ctypes.c_size_t(n_public), _p(ci), nci, ctypes.byref(info))
+        self.ctx._ck(rc)
+        return info.as_dict()
 
     def synth(self, log2_domain, n_wires, n_public, n_committed, seed):
         self.ctx._ck(self.ctx.lib.zkpor_pk_synth(self.h, ctypes.c_int(log2_domain), ctypes.c_size_t(n_wires), ctypes.c_size_t(n_public),
