@@ -169,6 +169,25 @@ int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const 
 /* device-resident inputs; d_a/d_b/d_c must hold 2^log2_domain elements (zero padded) and are overwritten */
 int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c,
                              const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]);
+/* ---- single-proof split over several GPUs (BASELINE.json configs[4]: one 2^28 proof, 8 MI355X) ----------
+ * Every GPU keeps one contiguous range of each key array and of the matching scalars, computes the five partial
+ * multi-exponentiations, the partial sums (576 B per GPU) are all-gathered (RCCL; the only collective of the path besides
+ * scattering h from the GPU that ran computeH), added with zkpor_g1/g2_jac_sum, and the proof is assembled on the host.
+ * split.py shows the exchange; gnark has no counterpart (its MultiExp splits over CPU tasks). */
+/* turn a loaded key into a shard: keep wires [wire_lo, wire_hi) of A, B1, B2, K (wire-indexed) and points [z_lo, z_hi) of Z
+ * (in the order the prover's h has: bit-reversed), free the rest.  zkpor_prove_tail* then refuse the key (ZKPOR_E_STATE). */
+int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi);
+/* the five sums over the key's (or shard's) arrays: d_w = wire values of the kept wire range, d_h = h scalars of the kept Z
+ * range (device, Montgomery Fr; d_h may be NULL when the shard holds no Z point).  sums_out = Jacobian points as
+ * gnark-crypto holds them (X, Y, Z Montgomery limbs): A.w (96 B) | B1.w (96 B) | B2.w (192 B) | K.w (96 B) | Z.h (96 B). */
+int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_h, uint8_t sums_out[576]);
+/* HOST ONLY (no device): blinding + assembly of the proof from the (already added) sums, as groth16.Prove does after its
+ * MultiExps: Ar = alpha + A.w + r delta, Bs = beta2 + B2.w + s delta2, Krs = K.w + Z.h + s Ar + r Bs1 - rs delta. */
+int32_t zkpor_prove_assemble(const void* alpha, const void* beta, const void* delta, const void* beta2, const void* delta2,
+                             const uint8_t sums[576], const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]);
+/* the five fixed points of a loaded key (G1 affine 64 B x3, G2 affine 128 B x2), e.g. to feed zkpor_prove_assemble */
+int32_t zkpor_pk_consts(zkpor_pk* pk, void* alpha, void* beta, void* delta, void* beta2, void* delta2);
+
 /* Pedersen commitment over the committed wires (gnark-crypto pedersen.ProvingKey.Commit / ProveKnowledge):
  * values: n_committed Fr; out: commitment | knowledge proof, G1 affine 64 B each */
 int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64],

@@ -1,0 +1,55 @@
+"""CPU suite: the exchange of the single-proof split (zkmerkle-proof-of-solvency_amd/split.py: scatter of h, all-gather of the
+576-byte partial sums, host-side addition and proof assembly) with two ranks over gloo.  There is no GPU here, so step 3 — each
+rank's five partial multi-exponentiations, zkpor_prove_sums_dev on a GPU box — is stood in for by the oracle's MSMs over the same
+ranges; everything else is the product's code (split.py, zkpor_g1/g2_jac_sum, zkpor_prove_assemble are host-only)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys
+root = %(root)r
+for p in (root, os.path.join(root, "oracle"), os.path.join(root, "zkmerkle-proof-of-solvency_amd")):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+import oracle as O, zkpor, split
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+S = O.Synth(5, 60, n_public=2, seed=37)
+D = 1 << S.log2d
+r = O.fr_random(5, 1)[0]; s = O.fr_random(6, 1)[0]
+one = O.fp_from_ints([1])[0]
+def jac1(aff): return np.concatenate([aff, one]) if aff.any() else np.zeros(12, np.uint64)
+def jac2(aff): return np.concatenate([aff, one, np.zeros(4, np.uint64)]) if aff.any() else np.zeros(24, np.uint64)
+w_lo, w_hi = split.wire_range(S.n_wires, rank, world)
+z_lo, z_hi = split.z_range(D, rank, world)
+K = S.K.copy(); K[:S.n_public] = 0                       # the prover's K leaves the public wires out
+def sums_fn(h_mine):                                     # stand-in for zkpor_prove_sums_dev on this rank's shard
+    h = h_mine.numpy().view(np.uint64).reshape(-1, 4)
+    w = S.w[w_lo:w_hi]
+    out = np.concatenate([jac1(O.g1_msm(S.A[w_lo:w_hi], w)), jac1(O.g1_msm(S.B1[w_lo:w_hi], w)), jac2(O.g2_msm(S.B2[w_lo:w_hi], w)),
+                          jac1(O.g1_msm(K[w_lo:w_hi], w)), jac1(O.g1_msm(S.Z[z_lo:z_hi], h[:z_hi - z_lo]))])
+    return out.view(np.uint8)
+h_full = torch.from_numpy(O.compute_h(S.a, S.b, S.c, S.log2d).view(np.uint8).reshape(-1).copy()) if rank == 0 else None
+h_mine = torch.empty(32 * split.z_block(D, world), dtype=torch.uint8)
+consts = (S.abd1[0], S.abd1[1], S.abd1[2], S.bd2[0], S.bd2[1])
+proof = split.exchange_and_assemble(dist, rank, world, h_full, h_mine, sums_fn, consts, r, s)
+ok = bool(np.array_equal(proof, S.prove_tail(r, s))) and S.verify_pairing(proof)
+print(json.dumps({"rank": rank, "ok": ok}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_split_exchange_two_ranks_gloo(tmp_path):
+    script = tmp_path / "split_worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        o, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-3000:]
+        assert json.loads(o.strip().splitlines()[-1])["ok"]

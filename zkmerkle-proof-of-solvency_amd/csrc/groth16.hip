@@ -6,6 +6,7 @@
 #include "msm.cuh"
 #include "ntt.cuh"
 #include <new>
+#include <type_traits>
 
 using namespace zk;
 
@@ -26,6 +27,7 @@ struct zkpor_pk {
     G1Affine alpha, beta, delta;
     G2Affine beta2, delta2;
     bool ready = false;
+    bool shard = false;  // holds only a contiguous range of every array (zkpor_pk_keep_range): sums only, no whole proof
 };
 
 zkpor_ctx* zk_pk_ctx(zkpor_pk* pk) { return pk->ctx; }  // for keyfile.hip
@@ -295,6 +297,7 @@ int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, c
     for (int i = 0; i < ZKPOR_G1_NUM; ++i) if (pk->g1_raw[i]) { (void)hipFree(pk->g1_raw[i]); pk->g1_raw[i] = nullptr; pk->g1_raw_n[i] = 0; }
     if (pk->g2_raw) { (void)hipFree(pk->g2_raw); pk->g2_raw = nullptr; pk->g2_raw_n = 0; }
     pk->ready = true;
+    pk->shard = false;
     return ZKPOR_OK;
 }
 
@@ -321,6 +324,7 @@ int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_p
     pk->beta2 = xyzz_to_affine<Fp2>(xyzz_mul_u64<Fp2>(xyzz_from_affine<Fp2>(g2), synth_k(seed, 101, 0)));
     pk->delta2 = xyzz_to_affine<Fp2>(xyzz_mul_u64<Fp2>(xyzz_from_affine<Fp2>(g2), synth_k(seed, 102, 0)));
     pk->ready = true;
+    pk->shard = false;
     return ZKPOR_OK;
 }
 
@@ -346,12 +350,17 @@ int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
 }
 
 // ------------------------------------------------------------------------------------------------ prove tail
-int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c,
-                             const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
-    if (!ctx || !pk || !d_w || !d_a || !d_b || !d_c || !r || !s || !proof_out) return ZKPOR_E_ARG;
-    if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
+}  // extern "C"
+namespace {
+
+struct ProveSums { G1XYZZ A, B1, K, Z; G2XYZZ B2; };  // the five multi-exponentiations of groth16.Prove
+
+// Queue everything in groth16.Prove between the solver and the blinding: h = computeH(a, b, c) when d_b is given (else d_a
+// already holds the h scalars matching pk->Z), then A.w, B1.w, B2.w, K.w over one sorted digit stream of w and Z.h.
+// Works on a whole key and on a shard (pk->n_wires / pk->nZ are then the shard's lengths and d_w / d_a its scalar ranges).
+int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c, ProveSums* out) {
     const int n = pk->log2_domain;
-    const size_t D = (size_t)1 << n;
+    const size_t nZ = pk->nZ;
     // Two HIP streams: the ALU-bound work (NTTs, bucket accumulations) on the context's stream, the HBM-bound digit
     // streams (decompose + radix sort) on an auxiliary one, so that sort(w) hides under the NTTs and sort(h) under the
     // four witness accumulations.  No host synchronisation on the main stream until all five sums are queued.
@@ -360,18 +369,18 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
     hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx);
     struct EvGuard { zkpor_ctx* c; hipEvent_t e[4]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs}, main_s};
     MsmCfg cfgw = msm_cfg(ctx, pk->n_wires);
-    MsmCfg cfgh = msm_cfg(ctx, D - 1);
+    MsmCfg cfgh = msm_cfg(ctx, nZ ? nZ : 1);
     size_t sortw = 0, sorth = 0;
     size_t need_dw = digits_ws_bytes(ctx, pk->n_wires, cfgw, &sortw);
-    size_t need_dh = digits_ws_bytes(ctx, D - 1, cfgh, &sorth);
+    size_t need_dh = digits_ws_bytes(ctx, nZ ? nZ : 1, cfgh, &sorth);
     size_t need_aw = accumulate_ws_bytes<Fp2>(cfgw, pk->n_wires * (size_t)cfgw.W);
-    size_t need_ah = accumulate_ws_bytes<Fp>(cfgh, (D - 1) * (size_t)cfgh.W);
+    size_t need_ah = accumulate_ws_bytes<Fp>(cfgh, (nZ ? nZ : 1) * (size_t)cfgh.W);
     ZK_TRY(ws_reserve(ctx, need_dw + need_dh + (need_aw > need_ah ? need_aw : need_ah)));
     ZK_TRY(ensure_pinned(ctx, 16 * MSM_SLOT_BYTES));
     char* pin = (char*)ctx->pinned;
     ZK_HIP(ctx, hipEventRecord(e_start, main_s));
     // 1. h = computeH(a,b,c) on the main stream, left in d_a (bit-reversed = the order of pk->Z)
-    ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
+    if (d_b) ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
     ZK_HIP(ctx, hipEventRecord(e_h, main_s));
     // 2. digit stream of the witness on the auxiliary stream (serves A, B1, B2, K)
     DigitStream dsw, dsh;
@@ -393,50 +402,143 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
     ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->K, pin + 4 * MSM_SLOT_BYTES, pin + 5 * MSM_SLOT_BYTES, &pK));
     ctx->ws_off = mark;
     ZK_TRY(msm_accumulate_launch<Fp2>(ctx, dsw, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2));
-    // 4. digit stream of h on the auxiliary stream, overlapping the accumulations above
-    ctx->stream = aux_s;
-    ctx->ws_off = off_dh;
-    ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_h, 0));
-    ZK_TRY(msm_digits(ctx, (const Fr*)d_a, D - 1, cfgh, sorth, &dsh));
-    ZK_HIP(ctx, hipEventRecord(e_hs, aux_s));
-    ctx->stream = main_s;
-    // 5. Z . h
-    ctx->ws_off = mark;
-    ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_hs, 0));
-    ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsh, pk->Z, pin + 10 * MSM_SLOT_BYTES, pin + 11 * MSM_SLOT_BYTES, &pZ));
+    if (nZ) {
+        // 4. digit stream of h on the auxiliary stream, overlapping the accumulations above
+        ctx->stream = aux_s;
+        ctx->ws_off = off_dh;
+        ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_h, 0));
+        ZK_TRY(msm_digits(ctx, (const Fr*)d_a, nZ, cfgh, sorth, &dsh));
+        ZK_HIP(ctx, hipEventRecord(e_hs, aux_s));
+        ctx->stream = main_s;
+        // 5. Z . h
+        ctx->ws_off = mark;
+        ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_hs, 0));
+        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsh, pk->Z, pin + 10 * MSM_SLOT_BYTES, pin + 11 * MSM_SLOT_BYTES, &pZ));
+    }
     ZK_HIP(ctx, hipStreamSynchronize(main_s));
-    G1XYZZ mA, mB1, mK, mZ;
-    G2XYZZ mB2;
     HostPhase hp(ctx, "host_assembly");
-    msm_accumulate_finish<Fp>(pA, &mA);
-    msm_accumulate_finish<Fp>(pB1, &mB1);
-    msm_accumulate_finish<Fp>(pK, &mK);
-    msm_accumulate_finish<Fp2>(pB2, &mB2);
-    msm_accumulate_finish<Fp>(pZ, &mZ);
-    // 4. blinding and assembly on the host (a few hundred group operations)
+    msm_accumulate_finish<Fp>(pA, &out->A);
+    msm_accumulate_finish<Fp>(pB1, &out->B1);
+    msm_accumulate_finish<Fp>(pK, &out->K);
+    msm_accumulate_finish<Fp2>(pB2, &out->B2);
+    if (nZ) msm_accumulate_finish<Fp>(pZ, &out->Z); else out->Z = G1XYZZ::inf();
+    return ZKPOR_OK;
+}
+
+// blinding and assembly on the host (a few hundred group operations): Ar = alpha + A.w + r delta,
+// Bs = beta + B.w + s delta (G1 and G2), Krs = K.w + Z.h + s Ar + r Bs1 - rs delta
+void assemble(const G1Affine& alpha, const G1Affine& beta, const G1Affine& delta, const G2Affine& beta2, const G2Affine& delta2,
+              const ProveSums& m, const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
     Fr rm, sm;
     memcpy(&rm, r, 32); memcpy(&sm, s, 32);
     Fr rc = Fr::from_mont(rm), sc = Fr::from_mont(sm);
     Fr krm = Fr::neg(Fr::mul(rm, sm));
     Fr krc = Fr::from_mont(krm);
-    G1XYZZ d1 = g1x(pk->delta);
-    G1XYZZ ar = mA;
-    xyzz_add<Fp>(ar, g1x(pk->alpha));
+    G1XYZZ d1 = g1x(delta);
+    G1XYZZ ar = m.A;
+    xyzz_add<Fp>(ar, g1x(alpha));
     xyzz_add<Fp>(ar, xyzz_mul_limbs<Fp>(d1, rc.v));
-    G1XYZZ bs1 = mB1;
-    xyzz_add<Fp>(bs1, g1x(pk->beta));
+    G1XYZZ bs1 = m.B1;
+    xyzz_add<Fp>(bs1, g1x(beta));
     xyzz_add<Fp>(bs1, xyzz_mul_limbs<Fp>(d1, sc.v));
-    G2XYZZ bs2 = mB2;
-    xyzz_add<Fp2>(bs2, xyzz_from_affine<Fp2>(pk->beta2));
-    xyzz_add<Fp2>(bs2, xyzz_mul_limbs<Fp2>(xyzz_from_affine<Fp2>(pk->delta2), sc.v));
-    G1XYZZ krs = mK;
-    xyzz_add<Fp>(krs, mZ);
+    G2XYZZ bs2 = m.B2;
+    xyzz_add<Fp2>(bs2, xyzz_from_affine<Fp2>(beta2));
+    xyzz_add<Fp2>(bs2, xyzz_mul_limbs<Fp2>(xyzz_from_affine<Fp2>(delta2), sc.v));
+    G1XYZZ krs = m.K;
+    xyzz_add<Fp>(krs, m.Z);
     xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(d1, krc.v));
     xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(ar, sc.v));
     xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(bs1, rc.v));
     G1Affine ara = xyzz_to_affine<Fp>(ar), krsa = xyzz_to_affine<Fp>(krs);
     G2Affine bsa = xyzz_to_affine<Fp2>(bs2);
     memcpy(proof_out, &ara, 64); memcpy(proof_out + 64, &bsa, 128); memcpy(proof_out + 192, &krsa, 64);
+}
+
+template <class F>
+XYZZ<F> jac_in(const uint8_t* p) {
+    Jacobian<F> j;
+    memcpy(&j, p, sizeof(j));
+    if (j.z.is_zero()) return XYZZ<F>::inf();
+    F zz = F::sqr(j.z);
+    return XYZZ<F>{j.x, j.y, zz, F::mul(zz, j.z)};
+}
+template <class F>
+void jac_out(const XYZZ<F>& p, uint8_t* out) {
+    Jacobian<F> j = xyzz_to_jacobian<F>(p);
+    memcpy(out, &j, sizeof(j));
+}
+
+}  // namespace
+extern "C" {
+
+int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c,
+                             const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+    if (!ctx || !pk || !d_w || !d_a || !d_b || !d_c || !r || !s || !proof_out) return ZKPOR_E_ARG;
+    if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
+    if (pk->shard) { ctx->err = "prove: the key is a shard (zkpor_pk_keep_range): use zkpor_prove_sums_dev + zkpor_prove_assemble"; return ZKPOR_E_STATE; }
+    ProveSums m;
+    ZK_TRY(prove_sums(ctx, pk, d_w, d_a, d_b, d_c, &m));
+    HostPhase hp(ctx, "host_assembly");
+    assemble(pk->alpha, pk->beta, pk->delta, pk->beta2, pk->delta2, m, r, s, proof_out);
+    return ZKPOR_OK;
+}
+
+// ---- single-proof split (BASELINE.json configs[4]): every GPU holds a contiguous range of each key array
+int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi) {
+    if (!pk) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = pk->ctx;
+    if (!pk->ready) { ctx->err = "pk: key not loaded"; return ZKPOR_E_STATE; }
+    if (wire_lo >= wire_hi || wire_hi > pk->n_wires || z_lo > z_hi || z_hi > pk->nZ) { ctx->err = "pk: shard range outside the key"; return ZKPOR_E_ARG; }
+    auto cut = [&](auto** arr, size_t lo, size_t hi) -> int32_t {
+        using P = std::remove_pointer_t<std::remove_pointer_t<decltype(arr)>>;
+        P* fresh = nullptr;
+        size_t n = hi - lo;
+        if (hipMalloc((void**)&fresh, (n ? n : 1) * sizeof(P)) != hipSuccess) { ctx->err = "pk: shard allocation failed"; return ZKPOR_E_OOM; }
+        if (n && hipMemcpyAsync(fresh, *arr + lo, n * sizeof(P), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { (void)hipFree(fresh); ctx->err = "pk: shard copy failed"; return ZKPOR_E_HIP; }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipFree(fresh); ctx->err = "pk: shard copy failed"; return ZKPOR_E_HIP; }
+        (void)hipFree(*arr);
+        *arr = fresh;
+        return ZKPOR_OK;
+    };
+    ZK_TRY(cut(&pk->A, wire_lo, wire_hi));
+    ZK_TRY(cut(&pk->B1, wire_lo, wire_hi));
+    ZK_TRY(cut(&pk->K, wire_lo, wire_hi));
+    ZK_TRY(cut(&pk->B2, wire_lo, wire_hi));
+    ZK_TRY(cut(&pk->Z, z_lo, z_hi));
+    pk->n_wires = wire_hi - wire_lo;
+    pk->nZ = z_hi - z_lo;
+    pk->shard = true;
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_h, uint8_t sums_out[576]) {
+    if (!ctx || !pk || !d_w || !sums_out) return ZKPOR_E_ARG;
+    if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
+    if (pk->nZ && !d_h) return ZKPOR_E_ARG;
+    ProveSums m;
+    ZK_TRY(prove_sums(ctx, pk, d_w, const_cast<void*>(d_h), nullptr, nullptr, &m));
+    jac_out<Fp>(m.A, sums_out); jac_out<Fp>(m.B1, sums_out + 96); jac_out<Fp2>(m.B2, sums_out + 192);
+    jac_out<Fp>(m.K, sums_out + 384); jac_out<Fp>(m.Z, sums_out + 480);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_prove_assemble(const void* alpha, const void* beta, const void* delta, const void* beta2, const void* delta2,
+                             const uint8_t sums[576], const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+    if (!alpha || !beta || !delta || !beta2 || !delta2 || !sums || !r || !s || !proof_out) return ZKPOR_E_ARG;
+    G1Affine a1, b1, d1; G2Affine b2, d2;
+    memcpy(&a1, alpha, 64); memcpy(&b1, beta, 64); memcpy(&d1, delta, 64); memcpy(&b2, beta2, 128); memcpy(&d2, delta2, 128);
+    ProveSums m;
+    m.A = jac_in<Fp>(sums); m.B1 = jac_in<Fp>(sums + 96); m.B2 = jac_in<Fp2>(sums + 192);
+    m.K = jac_in<Fp>(sums + 384); m.Z = jac_in<Fp>(sums + 480);
+    assemble(a1, b1, d1, b2, d2, m, r, s, proof_out);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_pk_consts(zkpor_pk* pk, void* alpha, void* beta, void* delta, void* beta2, void* delta2) {
+    if (!pk || !alpha || !beta || !delta || !beta2 || !delta2) return ZKPOR_E_ARG;
+    if (!pk->ready) { pk->ctx->err = "pk: key not loaded"; return ZKPOR_E_STATE; }
+    memcpy(alpha, &pk->alpha, 64); memcpy(beta, &pk->beta, 64); memcpy(delta, &pk->delta, 64);
+    memcpy(beta2, &pk->beta2, 128); memcpy(delta2, &pk->delta2, 128);
     return ZKPOR_OK;
 }
 

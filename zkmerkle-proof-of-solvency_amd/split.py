@@ -1,0 +1,100 @@
+"""One Groth16 proof split over several MI355X (SURVEY.md §8e "optional single-proof split"; BASELINE.json configs[4]: a
+2^28-constraint proof whose key + workspace do not fit one GPU's 288 GB next to its vectors).
+
+Every rank keeps one contiguous range of each key array (zkpor_pk_keep_range) and the matching range of the wire vector.
+Per proof:
+  1. rank 0 runs computeH on the full a, b, c                               (the NTTs do not shard without an all-to-all)
+  2. h is scattered in `world` equal blocks                                  RCCL scatter: (world-1)/world of 32*D bytes leave
+                                                                             rank 0, one block per peer, one xGMI link each
+  3. every rank: A.w, B1.w, B2.w, K.w over one sorted digit stream of its w range, Z.h over its h block  (zkpor_prove_sums_dev)
+  4. the 576-byte partial sums are all-gathered                              RCCL all-gather, latency-bound (4.6 KB at 8 ranks)
+  5. every rank adds the partials on the host (zkpor_g1/g2_jac_sum: RCCL has no reduction over curve points) and assembles the
+     proof (zkpor_prove_assemble) — all ranks end with the same 256 bytes.
+gnark has no counterpart: its MultiExp splits over CPU tasks inside one process.
+torch.distributed is plumbing here (backend "nccl" = RCCL on the GPUs, "gloo" in the CPU test of the exchange logic)."""
+import numpy as np
+
+import zkpor
+
+SUM_BYTES = 576
+_G1_SLOTS = ((0, 96), (96, 192), (384, 480), (480, 576))   # A.w, B1.w, K.w, Z.h
+_G2_SLOT = (192, 384)                                      # B2.w
+
+
+def wire_range(n_wires, rank, world):
+    return n_wires * rank // world, n_wires * (rank + 1) // world
+
+
+def z_block(D, world):
+    if D % world:
+        raise ValueError("the domain size must be a multiple of the number of ranks")
+    return D // world
+
+
+def z_range(D, rank, world):
+    """h is scattered in equal blocks of D/world scalars; Z has D-1 points, so the last block's final scalar has no point"""
+    blk = z_block(D, world)
+    return rank * blk, min((rank + 1) * blk, D - 1)
+
+
+def add_partial_sums(parts):
+    """parts: (world, 576) uint8 -> (576,) uint8, component-wise group addition on the host"""
+    parts = np.ascontiguousarray(parts, dtype=np.uint8).reshape(-1, SUM_BYTES)
+    out = np.empty(SUM_BYTES, dtype=np.uint8)
+    for lo, hi in _G1_SLOTS:
+        out[lo:hi] = zkpor.g1_jac_sum(np.ascontiguousarray(parts[:, lo:hi]).view(np.uint64)).view(np.uint8)
+    lo, hi = _G2_SLOT
+    out[lo:hi] = zkpor.g2_jac_sum(np.ascontiguousarray(parts[:, lo:hi]).view(np.uint64)).view(np.uint8)
+    return out
+
+
+def exchange_and_assemble(dist, rank, world, h_full, h_mine, sums_fn, consts, r, s, device_sync=None):
+    """steps 2-5.  h_full: 1-D uint8 tensor of 32*D bytes on rank 0 (None elsewhere); h_mine: this rank's receive buffer of
+    32*D/world bytes; sums_fn(h_mine) -> 576 uint8 (step 3: zkpor_prove_sums_dev on the GPUs).  Returns the proof."""
+    import torch
+    blk = h_mine.numel()
+    if device_sync is not None:
+        device_sync()                  # computeH ran on the library's stream, which the collective's stream does not follow
+    if dist is None:
+        h_mine.copy_(h_full[:blk])
+    else:
+        chunks = [h_full[i * blk:(i + 1) * blk] for i in range(world)] if rank == 0 else None
+        dist.scatter(h_mine, chunks, src=0)
+    if device_sync is not None:
+        device_sync()                  # ... and the library's streams do not follow the collective's stream either
+    mine = np.ascontiguousarray(sums_fn(h_mine), dtype=np.uint8).reshape(SUM_BYTES)
+    if dist is None:
+        parts = mine[None, :]
+    else:
+        t = torch.from_numpy(mine.copy()).to(h_mine.device)
+        allp = torch.empty(world * SUM_BYTES, dtype=torch.uint8, device=h_mine.device)
+        dist.all_gather_into_tensor(allp, t)
+        parts = allp.cpu().numpy().reshape(world, SUM_BYTES)
+    return zkpor.prove_assemble(consts, add_partial_sums(parts), r, s)
+
+
+class SplitProver:
+    """rank-local half of the split: owns the shard of the key on this GPU.  `pk` must be fully loaded (every rank loads or
+    synthesises the same key); it is cut down to this rank's ranges here."""
+
+    def __init__(self, ctx, pk, rank, world, dist):
+        self.ctx, self.pk, self.rank, self.world, self.dist = ctx, pk, rank, world, dist
+        _, self.n_wires = pk.g1_dev(zkpor.G1_A)
+        _, nz = pk.g1_dev(zkpor.G1_Z)
+        self.D = nz + 1
+        self.consts = pk.consts()
+        self.w_lo, self.w_hi = wire_range(self.n_wires, rank, world)
+        self.z_lo, self.z_hi = z_range(self.D, rank, world)
+        pk.keep_range(self.w_lo, self.w_hi, self.z_lo, self.z_hi)
+
+    def h_block_bytes(self):
+        return 32 * z_block(self.D, self.world)
+
+    def prove(self, d_w_full, h_full, h_mine, r, s):
+        """d_w_full: device pointer of the whole wire vector on this GPU (only this rank's range is read); h_full: rank 0's h
+        (torch uint8 on the device, as compute_h_dev left it), None on the other ranks; h_mine: receive buffer"""
+        import torch
+        d_w = d_w_full + 32 * self.w_lo
+        fn = lambda hm: self.ctx.prove_sums_dev(self.pk, d_w, hm.data_ptr())
+        return exchange_and_assemble(self.dist, self.rank, self.world, h_full, h_mine, fn, self.consts, r, s,
+                                     device_sync=torch.cuda.synchronize)

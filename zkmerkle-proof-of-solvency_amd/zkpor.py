@@ -163,6 +163,12 @@ class Context:
         self._ck(self.lib.zkpor_prove_tail_dev(self.h, pk.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c), _p(r), _p(s), _p(out)))
         return out
 
+    def prove_sums_dev(self, pk, d_w, d_h):
+        """the five multi-exponentiations over the key's (or shard's) arrays: 576 B of Jacobian points A.w | B1.w | B2.w | K.w | Z.h"""
+        out = np.empty(576, dtype=np.uint8)
+        self._ck(self.lib.zkpor_prove_sums_dev(self.h, pk.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_h) if d_h else None, _p(out)))
+        return out
+
     def commit(self, pk, values):
         values = _u64(values)
         c = np.empty(8, dtype=np.uint64); k = np.empty(8, dtype=np.uint64)
@@ -182,6 +188,19 @@ def proof_write_raw(proof256, commitments=None, pok=None):
     if rc != 0:
         raise ZkporError(f"zkpor_proof_write_raw failed: {rc}")
     return out[: n.value]
+
+
+def prove_assemble(consts, sums, r, s):
+    """host only: blinding + assembly of the proof (256 B, as prove_tail returns it) from the five added sums (576 B)"""
+    lib = load_library()
+    alpha, beta, delta, beta2, delta2 = (_u64(x) for x in consts)
+    sums = np.ascontiguousarray(sums, dtype=np.uint8).reshape(576)
+    r = _u64(r); s = _u64(s)
+    out = np.empty(256, dtype=np.uint8)
+    rc = lib.zkpor_prove_assemble(_p(alpha), _p(beta), _p(delta), _p(beta2), _p(delta2), _p(sums), _p(r), _p(s), _p(out))
+    if rc != 0:
+        raise ZkporError(f"zkpor_prove_assemble failed: {rc}")
+    return out
 
 
 def g1_jac_sum(parts):
@@ -300,6 +319,17 @@ class ProvingKey:
             rc = self.ctx.lib.zkpor_pk_load_gnark_mem(self.h, _p(buf), ctypes.c_size_t(buf.size), ctypes.c_size_t(n_public), _p(ci), nci, ctypes.byref(info))
         self.ctx._ck(rc)
         return info.as_dict()
+
+    def keep_range(self, wire_lo, wire_hi, z_lo, z_hi):
+        """turn the loaded key into a shard of the single-proof split (zkpor_pk_keep_range)"""
+        self.ctx._ck(self.ctx.lib.zkpor_pk_keep_range(self.h, ctypes.c_size_t(wire_lo), ctypes.c_size_t(wire_hi), ctypes.c_size_t(z_lo), ctypes.c_size_t(z_hi)))
+
+    def consts(self):
+        """(alpha, beta, delta, beta2, delta2) of the loaded key as uint64 limb arrays"""
+        a = np.empty(8, np.uint64); b = np.empty(8, np.uint64); d = np.empty(8, np.uint64)
+        b2 = np.empty(16, np.uint64); d2 = np.empty(16, np.uint64)
+        self.ctx._ck(self.ctx.lib.zkpor_pk_consts(self.h, _p(a), _p(b), _p(d), _p(b2), _p(d2)))
+        return a, b, d, b2, d2
 
     def synth(self, log2_domain, n_wires, n_public, n_committed, seed):
         self.ctx._ck(self.ctx.lib.zkpor_pk_synth(self.h, ctypes.c_int(log2_domain), ctypes.c_size_t(n_wires), ctypes.c_size_t(n_public),
