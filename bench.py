@@ -149,9 +149,45 @@ def pcie_inclusive(ctx, lib, pk, D, n_wires, dev_inputs, dev_work, cv, n_commit,
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gb = sum(h.numel() for h in host) / 1e9
-    return {"value": n_proofs / dt, "unit": "proofs/s", "ms_per_proof": dt / n_proofs * 1e3, "h2d_ms_per_proof": t_h2d / n_proofs * 1e3,
-            "h2d_GBps": gb * n_proofs / t_h2d, "bytes_per_proof": int(gb * 1e9),
-            "note": "w,a,b,c copied from pinned host memory before each proof, not overlapped with the previous proof"}
+    out = {"value": n_proofs / dt, "unit": "proofs/s", "ms_per_proof": dt / n_proofs * 1e3, "h2d_ms_per_proof": t_h2d / n_proofs * 1e3,
+           "h2d_GBps": gb * n_proofs / t_h2d, "bytes_per_proof": int(gb * 1e9),
+           "note": "w,a,b,c copied from pinned host memory before each proof, not overlapped with the previous proof"}
+    # the same hand-over double-buffered: a second context (its own HIP stream) carries proof i+1's vectors across PCIe while
+    # proof i runs; the proving call blocks the host, so one zkpor_sync on the copy context before the swap orders the two
+    up = None
+    sets = None
+    try:
+        up = _z.Context(torch.cuda.current_device(), None)
+        sets = [(dw, a, b, c), tuple(torch.empty_like(t) for t in (dw, a, b, c))]
+
+        def upload(k):
+            for dst, h in zip(sets[k], host):
+                up._ck(lib.zkpor_dev_upload_async(up.h, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(h.data_ptr()), ctypes.c_size_t(h.numel())))
+
+        n2 = n_proofs + 1
+        upload(0); up.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n2):
+            cur = sets[i & 1]
+            if i + 1 < n2:
+                upload((i + 1) & 1)
+            com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
+            ck(lib.zkpor_commit_dev(ctx.h, pk.h, ctypes.c_void_p(cv.data_ptr()), ctypes.c_size_t(n_commit), _z._p(com), _z._p(pok)))
+            ctx.prove_tail_dev(pk, cur[0].data_ptr(), cur[1].data_ptr(), cur[2].data_ptr(), cur[3].data_ptr(), r, s)
+            up.sync()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        out["double_buffered"] = {"value": n2 / dt2, "unit": "proofs/s", "ms_per_proof": dt2 / n2 * 1e3,
+                                  "note": "next proof's w,a,b,c uploaded on a second stream under the current proof's kernels "
+                                          "(steady state; the first upload is outside the timed region)"}
+    except Exception as e:  # informational leg
+        out["double_buffered"] = {"value": None, "note": f"failed: {e}"}
+    finally:
+        if up is not None:
+            up.close()
+        del sets
+    return out
 
 
 def verifier_acceptance(ctx, n_proofs=4):
