@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
         Fr29 v = A.in_gnark ? Fr29::from32<5>(raw) : Fr29::from32<0>(raw);
         if (A.scale_load) v = scale29(A, A.scale_load, v, p);
         if (!DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << lo) | (l0 + c)]));
+        else if (!DIF && A.in_gnark && !A.scale_load) v = Fr29::reduce32(v);  // the product-free first stage adds two loaded values: keep |v| < 32r
         st29(tile + 9u * li, v);
     }
     __syncthreads();
@@ -237,15 +238,23 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
                 Fr29 a0 = Fr29::reduce32(Fr29::add_l(x0, x2)), a2 = Fr29::mul(wa0, Fr29::sub_l(x0, x2));
                 Fr29 a1 = Fr29::reduce32(Fr29::add_l(x1, x3)), a3 = Fr29::mul(wa1, Fr29::sub_l(x1, x3));
                 // stage B pairs elements 2^hB apart (a0,a1),(a2,a3): position = index below bit hB = low
-                Fr29 wb = ld29(A.small29 + 9u * (low << tsB));
                 st29(p0, Fr29::reduce32(Fr29::add_l(a0, a1)));
-                st29(p1, Fr29::mul(wb, Fr29::sub_l(a0, a1)));
                 st29(p2, Fr29::reduce32(Fr29::add_l(a2, a3)));
-                st29(p3, Fr29::mul(wb, Fr29::sub_l(a2, a3)));
+                if (hl == 0) {  // the field's last stage: every twiddle is w^0 = 1, a product-free reduction replaces the product
+                    st29(p1, Fr29::reduce32(Fr29::sub_l(a0, a1)));
+                    st29(p3, Fr29::reduce32(Fr29::sub_l(a2, a3)));
+                } else {
+                    Fr29 wb = ld29(A.small29 + 9u * (low << tsB));
+                    st29(p1, Fr29::mul(wb, Fr29::sub_l(a0, a1)));
+                    st29(p3, Fr29::mul(wb, Fr29::sub_l(a2, a3)));
+                }
             } else {
                 // stage A pairs (x0,x1),(x2,x3) (distance 2^hA), position = low
-                Fr29 wa = ld29(A.small29 + 9u * (low << tsA));
-                Fr29 t1 = Fr29::mul(x1, wa), t3 = Fr29::mul(x3, wa);
+                Fr29 t1 = x1, t3 = x3;
+                if (hl != 0) {  // (the field's first stage has twiddle w^0 = 1 throughout: no product)
+                    Fr29 wa = ld29(A.small29 + 9u * (low << tsA));
+                    t1 = Fr29::mul(x1, wa); t3 = Fr29::mul(x3, wa);
+                }
                 Fr29 a0 = Fr29::reduce32(Fr29::add_l(x0, t1)), a1 = Fr29::reduce32(Fr29::sub_l(x0, t1));
                 Fr29 a2 = Fr29::reduce32(Fr29::add_l(x2, t3)), a3 = Fr29::reduce32(Fr29::sub_l(x2, t3));
                 // stage B pairs (a0,a2),(a1,a3) (distance 2^hB), positions low and low + 2^hA
@@ -274,12 +283,12 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
             u32* p0 = tile + 9u * (lo > 0 ? i0 * C + c : c * F + i0);
             u32* p1 = tile + 9u * (lo > 0 ? i1 * C + c : c * F + i1);
             Fr29 a = ld29(p0), b = ld29(p1);
-            Fr29 w = ld29(A.small29 + 9u * (pos << tshift));
             if (DIF) {
                 st29(p0, Fr29::reduce32(Fr29::add_l(a, b)));
-                st29(p1, Fr29::mul(w, Fr29::sub_l(a, b)));
+                if (half == 1u) st29(p1, Fr29::reduce32(Fr29::sub_l(a, b)));      // last stage: twiddle 1
+                else st29(p1, Fr29::mul(ld29(A.small29 + 9u * (pos << tshift)), Fr29::sub_l(a, b)));
             } else {
-                Fr29 tb_ = Fr29::mul(b, w);
+                Fr29 tb_ = half == 1u ? b : Fr29::mul(b, ld29(A.small29 + 9u * (pos << tshift)));
                 st29(p0, Fr29::reduce32(Fr29::add_l(a, tb_)));
                 st29(p1, Fr29::reduce32(Fr29::sub_l(a, tb_)));
             }
