@@ -174,6 +174,15 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
  * multi-exponentiations, the partial sums (576 B per GPU) are all-gathered (RCCL; the only collective of the path besides
  * scattering h from the GPU that ran computeH), added with zkpor_g1/g2_jac_sum, and the proof is assembled on the host.
  * split.py shows the exchange; gnark has no counterpart (its MultiExp splits over CPU tasks). */
+/* one rank's share straight from the key file: only wires [wire_lo, wire_hi) of A, B1, B2, K (located in gnark's compacted
+ * arrays by counting the infinity / removed masks in front of the range) and points [z_lo, z_hi) of Z are uploaded and
+ * decompressed, so no GPU ever holds more than its share; the result is a shard exactly as after zkpor_pk_keep_range. */
+int32_t zkpor_pk_load_gnark_shard_mem(zkpor_pk* pk, const uint8_t* data, size_t len, size_t n_public,
+                                      const uint32_t* committed_idx, size_t n_committed, size_t wire_lo, size_t wire_hi,
+                                      size_t z_lo, size_t z_hi, zkpor_pk_layout_t* info);
+int32_t zkpor_pk_load_gnark_shard(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx,
+                                  size_t n_committed, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi,
+                                  zkpor_pk_layout_t* info);
 /* turn a loaded key into a shard: keep wires [wire_lo, wire_hi) of A, B1, B2, K (wire-indexed) and points [z_lo, z_hi) of Z
  * (in the order the prover's h has: bit-reversed), free the rest.  zkpor_prove_tail* then refuse the key (ZKPOR_E_STATE). */
 int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi);

@@ -101,6 +101,50 @@ def test_split_at_2p18_synthetic_key(zk):
             b.free()
 
 
+@pytest.mark.parametrize("world,from_file", [(2, False), (4, True)])
+def test_shards_loaded_straight_from_the_key_file(zk, tmp_path, world, from_file):
+    """every rank decompresses only its ranges of the container (zkpor_pk_load_gnark_shard): same sums as trimming a whole key,
+    and the reassembled proof is the oracle's"""
+    import gnark_keyfile as GK
+    S = O.Synth(6, 300, n_public=2, seed=43)
+    D = 1 << S.log2d
+    r = O.fr_random(5, 1)[0]; s = O.fr_random(6, 1)[0]
+    data, inf_a, inf_b = GK.pk_bytes_from_synth(S)
+    assert inf_a.any() or inf_b.any()          # the compacted-index translation is exercised
+    src = data
+    if from_file:
+        src = str(tmp_path / "split.pk"); open(src, "wb").write(data)
+    h = O.compute_h(S.a, S.b, S.c, S.log2d)
+    dw = zk.alloc(32 * S.n_wires).upload(S.w); dh = zk.alloc(32 * D).upload(h)
+    parts = []; consts = None
+    try:
+        for rank in range(world):
+            w_lo, w_hi = split.wire_range(S.n_wires, rank, world); z_lo, z_hi = split.z_range(D, rank, world)
+            pk = zkpor.ProvingKey(zk); ref = _load(zk, S)
+            try:
+                L = pk.load_gnark_shard(src, S.n_public, w_lo, w_hi, z_lo, z_hi)
+                assert L["n_wires"] == S.n_wires
+                consts = pk.consts()
+                got = zk.prove_sums_dev(pk, dw.ptr + 32 * w_lo, dh.ptr + 32 * z_lo)
+                ref.keep_range(w_lo, w_hi, z_lo, z_hi)
+                assert np.array_equal(got, zk.prove_sums_dev(ref, dw.ptr + 32 * w_lo, dh.ptr + 32 * z_lo))
+                with pytest.raises(zkpor.ZkporError, match="the key is a shard"):
+                    zk.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
+                parts.append(got)
+            finally:
+                pk.close(); ref.close()
+    finally:
+        dw.free(); dh.free()
+    proof = zkpor.prove_assemble(consts, split.add_partial_sums(np.stack(parts)), r, s)
+    assert np.array_equal(proof, S.prove_tail(r, s)) and S.verify_pairing(proof)
+    pk = zkpor.ProvingKey(zk)
+    try:
+        with pytest.raises(zkpor.ZkporError, match="shard range outside the key"):
+            pk.load_gnark_shard(data, S.n_public, 0, S.n_wires + 1, 0, 1)
+    finally:
+        pk.close()
+
+
 def test_keep_range_rejects_bad_ranges(zk):
     S = O.Synth(4, 20, n_public=2, seed=4)
     pk = _load(zk, S)

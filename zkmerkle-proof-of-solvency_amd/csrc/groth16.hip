@@ -237,13 +237,15 @@ int32_t zkpor_pk_set_g2_compressed(zkpor_pk* pk, int which, const uint8_t* compr
     return ZKPOR_OK;
 }
 
-int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, const void* delta, const void* beta2,
-                            const void* delta2, int log2_domain, const uint8_t* inf_a, const uint8_t* inf_b,
-                            size_t n_wires, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
-                            int z_order) {
-    if (!pk || !alpha || !beta || !delta || !beta2 || !delta2 || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
+}  // extern "C"
+
+// Re-lay the uploaded (compacted) arrays out wire-indexed and mark the key ready.  `removed[i]` != 0: wire i has no K point.
+// For a shard (one rank's contiguous range of a split key, keyfile.hip) the arrays and masks cover that range only and Z holds
+// z_n points already in the prover's (bit-reversed) order.
+int32_t zk_pk_finalize(zkpor_pk* pk, const void* alpha, const void* beta, const void* delta, const void* beta2, const void* delta2,
+                       int log2_domain, const uint8_t* inf_a, const uint8_t* inf_b, size_t n_wires, const uint8_t* removed,
+                       size_t n_public, int z_order, bool shard, size_t z_n) {
     zkpor_ctx* ctx = pk->ctx;
-    if (n_wires == 0 || n_wires >= 0xffffffffull || n_public > n_wires) { ctx->err = "pk: bad wire counts"; return ZKPOR_E_ARG; }
     memcpy(&pk->alpha, alpha, 64); memcpy(&pk->beta, beta, 64); memcpy(&pk->delta, delta, 64);
     memcpy(&pk->beta2, beta2, 128); memcpy(&pk->delta2, delta2, 128);
     pk->log2_domain = log2_domain;
@@ -251,12 +253,6 @@ int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, c
     // index maps wire -> position in gnark's compacted arrays
     std::vector<u32> mapA(n_wires), mapB(n_wires), mapK(n_wires);
     u32 ra = 0, rb = 0, rk = 0;
-    std::vector<uint8_t> removed(n_wires, 0);
-    for (size_t i = 0; i < n_public; ++i) removed[i] = 1;
-    for (size_t j = 0; j < n_committed; ++j) {
-        if (committed_idx[j] >= n_wires) { ctx->err = "pk: committed index out of range"; return ZKPOR_E_ARG; }
-        removed[committed_idx[j]] = 1;
-    }
     for (size_t i = 0; i < n_wires; ++i) {
         mapA[i] = (inf_a && inf_a[i]) ? 0xffffffffu : ra++;
         mapB[i] = (inf_b && inf_b[i]) ? 0xffffffffu : rb++;
@@ -267,7 +263,9 @@ int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, c
         return ZKPOR_E_STATE;
     }
     size_t D = (size_t)1 << log2_domain;
-    if (pk->g1_raw_n[ZKPOR_G1_Z] != D - 1) { ctx->err = "pk: Z must hold 2^log2_domain - 1 points"; return ZKPOR_E_STATE; }
+    if (!shard) z_n = D - 1;
+    if (pk->g1_raw_n[ZKPOR_G1_Z] != z_n) { ctx->err = shard ? "pk: Z does not hold the shard's range" : "pk: Z must hold 2^log2_domain - 1 points"; return ZKPOR_E_STATE; }
+    if (shard && z_order != ZKPOR_Z_ORDER_BITREV) { ctx->err = "pk: a shard's Z must already be in the prover's order"; return ZKPOR_E_ARG; }
     if (pk->g1_raw_n[ZKPOR_G1_COMMIT_BASIS] != pk->g1_raw_n[ZKPOR_G1_COMMIT_BASIS_SIGMA]) { ctx->err = "pk: commitment bases differ in length"; return ZKPOR_E_STATE; }
     void* olds[] = {pk->A, pk->B1, pk->K, pk->Z, pk->CB, pk->CBS, pk->B2};
     for (void* p : olds) if (p) (void)hipFree(p);
@@ -277,17 +275,17 @@ int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, c
     ZK_TRY(expand<G2Affine>(ctx, pk->g2_raw, rb, mapB, &pk->B2));
     ZK_TRY(expand<G1Affine>(ctx, pk->g1_raw[ZKPOR_G1_K], rk, mapK, &pk->K));
     // Z: the prover produces h bit-reversed; bring a natural-order Z into that order once
-    pk->nZ = D - 1;
+    pk->nZ = z_n;
     {
-        std::vector<u32> mapZ(D - 1);
-        for (size_t j = 0; j + 1 < D; ++j) {
+        std::vector<u32> mapZ(z_n);
+        for (size_t j = 0; j < z_n; ++j) {
             if (z_order == ZKPOR_Z_ORDER_NATURAL) {
                 u32 r = 0;
                 for (int b = 0; b < log2_domain; ++b) r |= (u32)((j >> b) & 1) << (log2_domain - 1 - b);
                 mapZ[j] = r;  // r == D-1 only for j == D-1, which is outside the array
             } else mapZ[j] = (u32)j;
         }
-        ZK_TRY(expand<G1Affine>(ctx, pk->g1_raw[ZKPOR_G1_Z], D - 1, mapZ, &pk->Z));
+        ZK_TRY(expand<G1Affine>(ctx, pk->g1_raw[ZKPOR_G1_Z], z_n, mapZ, &pk->Z));
     }
     pk->nC = pk->g1_raw_n[ZKPOR_G1_COMMIT_BASIS];
     // commitment bases are used as uploaded: hand the raw buffers over
@@ -297,8 +295,27 @@ int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, c
     for (int i = 0; i < ZKPOR_G1_NUM; ++i) if (pk->g1_raw[i]) { (void)hipFree(pk->g1_raw[i]); pk->g1_raw[i] = nullptr; pk->g1_raw_n[i] = 0; }
     if (pk->g2_raw) { (void)hipFree(pk->g2_raw); pk->g2_raw = nullptr; pk->g2_raw_n = 0; }
     pk->ready = true;
-    pk->shard = false;
+    pk->shard = shard;
     return ZKPOR_OK;
+}
+
+extern "C" {
+
+int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, const void* delta, const void* beta2,
+                            const void* delta2, int log2_domain, const uint8_t* inf_a, const uint8_t* inf_b,
+                            size_t n_wires, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
+                            int z_order) {
+    if (!pk || !alpha || !beta || !delta || !beta2 || !delta2 || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = pk->ctx;
+    if (n_wires == 0 || n_wires >= 0xffffffffull || n_public > n_wires) { ctx->err = "pk: bad wire counts"; return ZKPOR_E_ARG; }
+    std::vector<uint8_t> removed(n_wires, 0);
+    for (size_t i = 0; i < n_public; ++i) removed[i] = 1;
+    for (size_t j = 0; j < n_committed; ++j) {
+        if (committed_idx[j] >= n_wires) { ctx->err = "pk: committed index out of range"; return ZKPOR_E_ARG; }
+        removed[committed_idx[j]] = 1;
+    }
+    return zk_pk_finalize(pk, alpha, beta, delta, beta2, delta2, log2_domain, inf_a, inf_b, n_wires, removed.data(), n_public, z_order,
+                          false, 0);
 }
 
 int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, size_t n_committed, uint64_t seed) {

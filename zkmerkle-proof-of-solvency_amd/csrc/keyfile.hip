@@ -25,10 +25,14 @@
 
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
 zkpor_ctx* zk_pk_ctx(zkpor_pk* pk);  // groth16.hip
+int32_t zk_pk_finalize(zkpor_pk* pk, const void* alpha, const void* beta, const void* delta, const void* beta2, const void* delta2,
+                       int log2_domain, const uint8_t* inf_a, const uint8_t* inf_b, size_t n_wires, const uint8_t* removed,
+                       size_t n_public, int z_order, bool shard, size_t z_n);  // groth16.hip
 
 namespace {
 
@@ -176,10 +180,66 @@ int32_t zkpor_pk_load_gnark_mem(zkpor_pk* pk, const uint8_t* data, size_t len, s
                                (size_t)L.n_wires, n_public, committed_idx, n_committed, ZKPOR_Z_ORDER_BITREV);
 }
 
-int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
-                            zkpor_pk_layout_t* info) {
-    if (!pk || !path) return ZKPOR_E_ARG;
+// One rank's share of a split key: wires [wire_lo, wire_hi) and Z points [z_lo, z_hi) only.  A, B and K are
+// stored compacted, so the wire range is translated into ranges of the compacted arrays by counting the mask bytes in front of it;
+// only those sub-ranges are uploaded and decompressed — a GPU never holds more than its share of a 2^28 key.
+int32_t zkpor_pk_load_gnark_shard_mem(zkpor_pk* pk, const uint8_t* data, size_t len, size_t n_public, const uint32_t* committed_idx,
+                                      size_t n_committed, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi,
+                                      zkpor_pk_layout_t* info) {
+    if (!pk) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = zk_pk_ctx(pk);
+    zkpor_pk_layout_t L;
+    std::string why;
+    int32_t rc = layout(data, len, &L, &why);
+    if (rc != ZKPOR_OK) { ctx->err = why; return rc; }
+    if (info) *info = L;
+    if (L.n_wires == 0 || L.n_wires >= 0xffffffffull) { ctx->err = "pk file: wire count out of range"; return ZKPOR_E_ARG; }
+    if (n_public > L.n_wires || L.n_k + n_public + n_committed != L.n_wires) {
+        ctx->err = "pk file: len(K) does not equal nbWires - n_public - n_committed"; return ZKPOR_E_ARG;
+    }
+    if (L.n_commitment_keys > 1) { ctx->err = "pk file: more than one commitment key (the reference circuit has one)"; return ZKPOR_E_ARG; }
+    if (wire_lo >= wire_hi || wire_hi > L.n_wires || z_lo > z_hi || z_hi > L.domain_cardinality - 1) {
+        ctx->err = "pk file: shard range outside the key"; return ZKPOR_E_ARG;
+    }
+    int log2d = 0;
+    while ((1ull << log2d) < L.domain_cardinality) ++log2d;
+    std::vector<uint8_t> removed(L.n_wires, 0);
+    for (size_t i = 0; i < n_public; ++i) removed[i] = 1;
+    for (size_t j = 0; j < n_committed; ++j) {
+        if (committed_idx[j] >= L.n_wires) { ctx->err = "pk file: committed index out of range"; return ZKPOR_E_ARG; }
+        removed[committed_idx[j]] = 1;
+    }
+    const uint8_t* ia = data + L.off_inf_a;
+    const uint8_t* ib = data + L.off_inf_b;
+    uint64_t a_lo = 0, b_lo = 0, k_lo = 0, a_n = 0, b_n = 0, k_n = 0, pub = 0;
+    for (size_t i = 0; i < wire_hi; ++i) {
+        const bool in = i >= wire_lo;
+        (in ? a_n : a_lo) += !ia[i];
+        (in ? b_n : b_lo) += !ib[i];
+        (in ? k_n : k_lo) += !removed[i];
+        if (in && i < n_public) ++pub;
+    }
+    uint8_t g1c[3 * 64], g2c[2 * 128];
+    rc = zkpor_g1_decompress(ctx, data + L.off_alpha, 3, g1c);
+    if (rc != ZKPOR_OK) { ctx->err = "pk file: G1 alpha/beta/delta: " + ctx->err; return rc; }
+    rc = zkpor_g2_decompress(ctx, data + L.off_beta2, 2, g2c);
+    if (rc != ZKPOR_OK) { ctx->err = "pk file: G2 beta/delta: " + ctx->err; return rc; }
+    struct { int which; uint64_t off, n; const char* name; } g1s[] = {
+        {ZKPOR_G1_A, L.off_a + 32 * a_lo, a_n, "G1.A"}, {ZKPOR_G1_B, L.off_b1 + 32 * b_lo, b_n, "G1.B"},
+        {ZKPOR_G1_K, L.off_k + 32 * k_lo, k_n, "G1.K"}, {ZKPOR_G1_Z, L.off_z + 32 * z_lo, z_hi - z_lo, "G1.Z"},
+        {ZKPOR_G1_COMMIT_BASIS, L.off_basis, L.n_basis, "CommitmentKeys[0].Basis"},
+        {ZKPOR_G1_COMMIT_BASIS_SIGMA, L.off_basis_sigma, L.n_basis_sigma, "CommitmentKeys[0].BasisExpSigma"}};
+    for (auto& a : g1s) {
+        rc = zkpor_pk_set_g1_compressed(pk, a.which, a.n ? data + a.off : data, a.n);
+        if (rc != ZKPOR_OK) { ctx->err = std::string("pk file: ") + a.name + ": " + ctx->err; return rc; }
+    }
+    rc = zkpor_pk_set_g2_compressed(pk, ZKPOR_G2_B, b_n ? data + L.off_b2 + 64 * b_lo : data, b_n);
+    if (rc != ZKPOR_OK) { ctx->err = "pk file: G2.B: " + ctx->err; return rc; }
+    return zk_pk_finalize(pk, g1c, g1c + 64, g1c + 128, g2c, g2c + 128, log2d, ia + wire_lo, ib + wire_lo, wire_hi - wire_lo,
+                          removed.data() + wire_lo, (size_t)pub, ZKPOR_Z_ORDER_BITREV, true, z_hi - z_lo);
+}
+
+static int32_t with_mapped_file(zkpor_ctx* ctx, const char* path, const std::function<int32_t(const uint8_t*, size_t)>& fn) {
     int fd = open(path, O_RDONLY);
     if (fd < 0) { ctx->err = std::string("pk file: cannot open ") + path; return ZKPOR_E_ARG; }
     struct stat st;
@@ -188,9 +248,25 @@ int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, con
     close(fd);
     if (m == MAP_FAILED) { ctx->err = std::string("pk file: cannot map ") + path; return ZKPOR_E_ARG; }
     (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
-    int32_t rc = zkpor_pk_load_gnark_mem(pk, (const uint8_t*)m, (size_t)st.st_size, n_public, committed_idx, n_committed, info);
+    int32_t rc = fn((const uint8_t*)m, (size_t)st.st_size);
     munmap(m, (size_t)st.st_size);
     return rc;
+}
+
+int32_t zkpor_pk_load_gnark_shard(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
+                                  size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi, zkpor_pk_layout_t* info) {
+    if (!pk || !path) return ZKPOR_E_ARG;
+    return with_mapped_file(zk_pk_ctx(pk), path, [&](const uint8_t* d, size_t n) {
+        return zkpor_pk_load_gnark_shard_mem(pk, d, n, n_public, committed_idx, n_committed, wire_lo, wire_hi, z_lo, z_hi, info);
+    });
+}
+
+int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
+                            zkpor_pk_layout_t* info) {
+    if (!pk || !path) return ZKPOR_E_ARG;
+    return with_mapped_file(zk_pk_ctx(pk), path, [&](const uint8_t* d, size_t n) {
+        return zkpor_pk_load_gnark_mem(pk, d, n, n_public, committed_idx, n_committed, info);
+    });
 }
 
 }  // extern "C"

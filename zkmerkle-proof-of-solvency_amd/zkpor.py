@@ -320,6 +320,20 @@ class ProvingKey:
         self.ctx._ck(rc)
         return info.as_dict()
 
+    def load_gnark_shard(self, src, n_public, wire_lo, wire_hi, z_lo, z_hi, committed_idx=None):
+        """one rank's share of a split key straight from the container (path or bytes): see zkpor_pk_load_gnark_shard"""
+        ci = None if committed_idx is None else np.ascontiguousarray(committed_idx, dtype=np.uint32)
+        nci = ctypes.c_size_t(0 if ci is None else ci.size)
+        info = PkLayout()
+        rng = [ctypes.c_size_t(v) for v in (wire_lo, wire_hi, z_lo, z_hi)]
+        if isinstance(src, (str, os.PathLike)):
+            rc = self.ctx.lib.zkpor_pk_load_gnark_shard(self.h, os.fsencode(src), ctypes.c_size_t(n_public), _p(ci), nci, *rng, ctypes.byref(info))
+        else:
+            buf = np.frombuffer(bytes(src), dtype=np.uint8)
+            rc = self.ctx.lib.zkpor_pk_load_gnark_shard_mem(self.h, _p(buf), ctypes.c_size_t(buf.size), ctypes.c_size_t(n_public), _p(ci), nci, *rng, ctypes.byref(info))
+        self.ctx._ck(rc)
+        return info.as_dict()
+
     def keep_range(self, wire_lo, wire_hi, z_lo, z_hi):
         """turn the loaded key into a shard of the single-proof split (zkpor_pk_keep_range)"""
         self.ctx._ck(self.ctx.lib.zkpor_pk_keep_range(self.h, ctypes.c_size_t(wire_lo), ctypes.c_size_t(wire_hi), ctypes.c_size_t(z_lo), ctypes.c_size_t(z_hi)))
