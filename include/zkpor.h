@@ -187,7 +187,8 @@ int32_t zkpor_pk_load_gnark_shard(zkpor_pk* pk, const char* path, size_t n_publi
  * (in the order the prover's h has: bit-reversed), free the rest.  zkpor_prove_tail* then refuse the key (ZKPOR_E_STATE). */
 int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi);
 /* the five sums over the key's (or shard's) arrays: d_w = wire values of the kept wire range, d_h = h scalars of the kept Z
- * range (device, Montgomery Fr; d_h may be NULL when the shard holds no Z point).  sums_out = Jacobian points as
+ * range (device, Montgomery Fr).  Either pointer may be NULL: then only the other half is computed and the missing sums are
+ * infinity — a peer runs the four w-sums while the GPU that owns computeH is still busy and adds Z.h when its h block arrives.  sums_out = Jacobian points as
  * gnark-crypto holds them (X, Y, Z Montgomery limbs): A.w (96 B) | B1.w (96 B) | B2.w (192 B) | K.w (96 B) | Z.h (96 B). */
 int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_h, uint8_t sums_out[576]);
 /* HOST ONLY (no device): blinding + assembly of the proof from the (already added) sums, as groth16.Prove does after its

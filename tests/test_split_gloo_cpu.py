@@ -27,17 +27,24 @@ def jac2(aff): return np.concatenate([aff, one, np.zeros(4, np.uint64)]) if aff.
 w_lo, w_hi = split.wire_range(S.n_wires, rank, world)
 z_lo, z_hi = split.z_range(D, rank, world)
 K = S.K.copy(); K[:S.n_public] = 0                       # the prover's K leaves the public wires out
-def sums_fn(h_mine):                                     # stand-in for zkpor_prove_sums_dev on this rank's shard
-    h = h_mine.numpy().view(np.uint64).reshape(-1, 4)
+calls = []
+def w_sums():                                            # stand-ins for zkpor_prove_sums_dev on this rank's shard
     w = S.w[w_lo:w_hi]
-    out = np.concatenate([jac1(O.g1_msm(S.A[w_lo:w_hi], w)), jac1(O.g1_msm(S.B1[w_lo:w_hi], w)), jac2(O.g2_msm(S.B2[w_lo:w_hi], w)),
-                          jac1(O.g1_msm(K[w_lo:w_hi], w)), jac1(O.g1_msm(S.Z[z_lo:z_hi], h[:z_hi - z_lo]))])
-    return out.view(np.uint8)
+    return np.concatenate([jac1(O.g1_msm(S.A[w_lo:w_hi], w)), jac1(O.g1_msm(S.B1[w_lo:w_hi], w)), jac2(O.g2_msm(S.B2[w_lo:w_hi], w)),
+                           jac1(O.g1_msm(K[w_lo:w_hi], w)), np.zeros(12, np.uint64)]).view(np.uint8)
+def early_fn():
+    calls.append("early"); return w_sums()
+def sums_fn(h_mine, early):
+    calls.append("late")
+    h = h_mine.numpy().view(np.uint64).reshape(-1, 4)
+    z = np.concatenate([np.zeros(60, np.uint64), jac1(O.g1_msm(S.Z[z_lo:z_hi], h[:z_hi - z_lo]))]).view(np.uint8)
+    return split.merge_sums(early if early is not None else w_sums(), z)
 h_full = torch.from_numpy(O.compute_h(S.a, S.b, S.c, S.log2d).view(np.uint8).reshape(-1).copy()) if rank == 0 else None
 h_mine = torch.empty(32 * split.z_block(D, world), dtype=torch.uint8)
 consts = (S.abd1[0], S.abd1[1], S.abd1[2], S.bd2[0], S.bd2[1])
-proof = split.exchange_and_assemble(dist, rank, world, h_full, h_mine, sums_fn, consts, r, s)
+proof = split.exchange_and_assemble(dist, rank, world, h_full, h_mine, sums_fn, consts, r, s, early_fn=early_fn)
 ok = bool(np.array_equal(proof, S.prove_tail(r, s))) and S.verify_pairing(proof)
+ok = ok and calls == (["late"] if rank == 0 else ["early", "late"])     # only the peers run the early phase
 print(json.dumps({"rank": rank, "ok": ok}), flush=True)
 dist.destroy_process_group()
 '''

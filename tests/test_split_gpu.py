@@ -30,6 +30,13 @@ def _load(zk, S):
     return pk
 
 
+def _affine5(sums):
+    """the five Jacobian sums as affine coordinates (representation-independent)"""
+    u = np.ascontiguousarray(sums, dtype=np.uint8).view(np.uint64)
+    g1 = [O.g1_jac_to_affine(u[a:a + 12].copy())[0].tolist() for a in (0, 12, 48, 60)]
+    return g1 + [O.g2_jac_to_affine(u[24:48].copy())[0].tolist()]
+
+
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_split_sums_reassemble_to_the_unsplit_proof(zk, world):
     S = O.Synth(6, 300, n_public=2, seed=31)
@@ -56,6 +63,13 @@ def test_split_sums_reassemble_to_the_unsplit_proof(zk, world):
                 with pytest.raises(zkpor.ZkporError, match="the key is a shard"):
                     zk.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
                 parts.append(zk.prove_sums_dev(pk, dw.ptr + 32 * w_lo, dh.ptr + 32 * z_lo))
+                # the two halves a peer computes before / after h arrives add up to the same five sums
+                w_part = zk.prove_sums_dev(pk, dw.ptr + 32 * w_lo, None)
+                assert not w_part[544:576].any()                       # Z.h slot: the point at infinity (Jacobian Z = 0)
+                if z_hi > z_lo:
+                    h_part = zk.prove_sums_dev(pk, None, dh.ptr + 32 * z_lo)
+                    assert not any(h_part[a:b].any() for a, b in ((64, 96), (160, 192), (320, 384), (448, 480)))
+                    assert _affine5(split.merge_sums(w_part, h_part)) == _affine5(parts[-1])
             finally:
                 pk.close()
     finally:

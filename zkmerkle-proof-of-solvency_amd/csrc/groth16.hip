@@ -375,9 +375,10 @@ struct ProveSums { G1XYZZ A, B1, K, Z; G2XYZZ B2; };  // the five multi-exponent
 // Queue everything in groth16.Prove between the solver and the blinding: h = computeH(a, b, c) when d_b is given (else d_a
 // already holds the h scalars matching pk->Z), then A.w, B1.w, B2.w, K.w over one sorted digit stream of w and Z.h.
 // Works on a whole key and on a shard (pk->n_wires / pk->nZ are then the shard's lengths and d_w / d_a its scalar ranges).
-int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c, ProveSums* out) {
+int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c, ProveSums* out, bool do_w = true,
+                   bool do_h = true) {
     const int n = pk->log2_domain;
-    const size_t nZ = pk->nZ;
+    const size_t nZ = do_h ? pk->nZ : 0;
     // Two HIP streams: the ALU-bound work (NTTs, bucket accumulations) on the context's stream, the HBM-bound digit
     // streams (decompose + radix sort) on an auxiliary one, so that sort(w) hides under the NTTs and sort(h) under the
     // four witness accumulations.  No host synchronisation on the main stream until all five sums are queued.
@@ -401,24 +402,27 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     ZK_HIP(ctx, hipEventRecord(e_h, main_s));
     // 2. digit stream of the witness on the auxiliary stream (serves A, B1, B2, K)
     DigitStream dsw, dsh;
-    ctx->stream = aux_s;
-    ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_start, 0));
-    ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw));
-    ZK_HIP(ctx, hipEventRecord(e_w, aux_s));
-    size_t off_dh = ctx->ws_off;
-    ctx->stream = main_s;
-    // 3. queue the four witness accumulations (they reuse one workspace region in stream order)
-    ctx->ws_off = need_dw + need_dh;
-    size_t mark = ctx->ws_off;
-    ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_w, 0));
+    size_t off_dh = need_dw;
+    const size_t mark = need_dw + need_dh;
     MsmPending pA, pB1, pK, pB2, pZ;
-    ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->A, pin + 0 * MSM_SLOT_BYTES, pin + 1 * MSM_SLOT_BYTES, &pA));
-    ctx->ws_off = mark;
-    ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->B1, pin + 2 * MSM_SLOT_BYTES, pin + 3 * MSM_SLOT_BYTES, &pB1));
-    ctx->ws_off = mark;
-    ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->K, pin + 4 * MSM_SLOT_BYTES, pin + 5 * MSM_SLOT_BYTES, &pK));
-    ctx->ws_off = mark;
-    ZK_TRY(msm_accumulate_launch<Fp2>(ctx, dsw, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2));
+    if (do_w) {
+        ctx->stream = aux_s;
+        ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_start, 0));
+        ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw));
+        ZK_HIP(ctx, hipEventRecord(e_w, aux_s));
+        off_dh = ctx->ws_off;
+        ctx->stream = main_s;
+        // 3. queue the four witness accumulations (they reuse one workspace region in stream order)
+        ctx->ws_off = mark;
+        ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_w, 0));
+        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->A, pin + 0 * MSM_SLOT_BYTES, pin + 1 * MSM_SLOT_BYTES, &pA));
+        ctx->ws_off = mark;
+        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->B1, pin + 2 * MSM_SLOT_BYTES, pin + 3 * MSM_SLOT_BYTES, &pB1));
+        ctx->ws_off = mark;
+        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->K, pin + 4 * MSM_SLOT_BYTES, pin + 5 * MSM_SLOT_BYTES, &pK));
+        ctx->ws_off = mark;
+        ZK_TRY(msm_accumulate_launch<Fp2>(ctx, dsw, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2));
+    }
     if (nZ) {
         // 4. digit stream of h on the auxiliary stream, overlapping the accumulations above
         ctx->stream = aux_s;
@@ -434,10 +438,15 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     }
     ZK_HIP(ctx, hipStreamSynchronize(main_s));
     HostPhase hp(ctx, "host_assembly");
-    msm_accumulate_finish<Fp>(pA, &out->A);
-    msm_accumulate_finish<Fp>(pB1, &out->B1);
-    msm_accumulate_finish<Fp>(pK, &out->K);
-    msm_accumulate_finish<Fp2>(pB2, &out->B2);
+    if (do_w) {
+        msm_accumulate_finish<Fp>(pA, &out->A);
+        msm_accumulate_finish<Fp>(pB1, &out->B1);
+        msm_accumulate_finish<Fp>(pK, &out->K);
+        msm_accumulate_finish<Fp2>(pB2, &out->B2);
+    } else {
+        out->A = out->B1 = out->K = G1XYZZ::inf();
+        out->B2 = G2XYZZ::inf();
+    }
     if (nZ) msm_accumulate_finish<Fp>(pZ, &out->Z); else out->Z = G1XYZZ::inf();
     return ZKPOR_OK;
 }
@@ -529,11 +538,10 @@ int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t
 }
 
 int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_h, uint8_t sums_out[576]) {
-    if (!ctx || !pk || !d_w || !sums_out) return ZKPOR_E_ARG;
+    if (!ctx || !pk || (!d_w && !d_h) || !sums_out) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
-    if (pk->nZ && !d_h) return ZKPOR_E_ARG;
     ProveSums m;
-    ZK_TRY(prove_sums(ctx, pk, d_w, const_cast<void*>(d_h), nullptr, nullptr, &m));
+    ZK_TRY(prove_sums(ctx, pk, d_w, const_cast<void*>(d_h), nullptr, nullptr, &m, d_w != nullptr, d_h != nullptr));
     jac_out<Fp>(m.A, sums_out); jac_out<Fp>(m.B1, sums_out + 96); jac_out<Fp2>(m.B2, sums_out + 192);
     jac_out<Fp>(m.K, sums_out + 384); jac_out<Fp>(m.Z, sums_out + 480);
     return ZKPOR_OK;

@@ -6,7 +6,8 @@ Per proof:
   1. rank 0 runs computeH on the full a, b, c                               (the NTTs do not shard without an all-to-all)
   2. h is scattered in `world` equal blocks                                  RCCL scatter: (world-1)/world of 32*D bytes leave
                                                                              rank 0, one block per peer, one xGMI link each
-  3. every rank: A.w, B1.w, B2.w, K.w over one sorted digit stream of its w range, Z.h over its h block  (zkpor_prove_sums_dev)
+  3. every rank: A.w, B1.w, B2.w, K.w over one sorted digit stream of its w range, Z.h over its h block  (zkpor_prove_sums_dev);
+     the peers run the four w-sums BEFORE step 2, under rank 0's computeH, and only Z.h after it
   4. the 576-byte partial sums are all-gathered                              RCCL all-gather, latency-bound (4.6 KB at 8 ranks)
   5. every rank adds the partials on the host (zkpor_g1/g2_jac_sum: RCCL has no reduction over curve points) and assembles the
      proof (zkpor_prove_assemble) — all ranks end with the same 256 bytes.
@@ -48,11 +49,21 @@ def add_partial_sums(parts):
     return out
 
 
-def exchange_and_assemble(dist, rank, world, h_full, h_mine, sums_fn, consts, r, s, device_sync=None):
+def merge_sums(w_part, h_part):
+    """w_part: 576 bytes with the four w-sums (Z.h slot = infinity); h_part: 576 bytes with only Z.h -> all five"""
+    out = np.array(w_part, dtype=np.uint8, copy=True).reshape(SUM_BYTES)
+    out[480:576] = np.asarray(h_part, dtype=np.uint8).reshape(SUM_BYTES)[480:576]
+    return out
+
+
+def exchange_and_assemble(dist, rank, world, h_full, h_mine, sums_fn, consts, r, s, device_sync=None, early_fn=None):
     """steps 2-5.  h_full: 1-D uint8 tensor of 32*D bytes on rank 0 (None elsewhere); h_mine: this rank's receive buffer of
-    32*D/world bytes; sums_fn(h_mine) -> 576 uint8 (step 3: zkpor_prove_sums_dev on the GPUs).  Returns the proof."""
+    32*D/world bytes; sums_fn(h_mine, early) -> 576 uint8 (step 3: zkpor_prove_sums_dev on the GPUs).  early_fn() -> the four
+    w-sums: the peers run it BEFORE the scatter, i.e. while rank 0 is still inside computeH (they do not need h for A, B1, B2, K);
+    its result is handed to sums_fn, which then only adds Z.h.  Returns the proof."""
     import torch
     blk = h_mine.numel()
+    early = early_fn() if (early_fn is not None and rank != 0) else None
     if device_sync is not None:
         device_sync()                  # computeH ran on the library's stream, which the collective's stream does not follow
     if dist is None:
@@ -62,7 +73,7 @@ def exchange_and_assemble(dist, rank, world, h_full, h_mine, sums_fn, consts, r,
         dist.scatter(h_mine, chunks, src=0)
     if device_sync is not None:
         device_sync()                  # ... and the library's streams do not follow the collective's stream either
-    mine = np.ascontiguousarray(sums_fn(h_mine), dtype=np.uint8).reshape(SUM_BYTES)
+    mine = np.ascontiguousarray(sums_fn(h_mine, early), dtype=np.uint8).reshape(SUM_BYTES)
     if dist is None:
         parts = mine[None, :]
     else:
@@ -95,6 +106,14 @@ class SplitProver:
         (torch uint8 on the device, as compute_h_dev left it), None on the other ranks; h_mine: receive buffer"""
         import torch
         d_w = d_w_full + 32 * self.w_lo
-        fn = lambda hm: self.ctx.prove_sums_dev(self.pk, d_w, hm.data_ptr())
-        return exchange_and_assemble(self.dist, self.rank, self.world, h_full, h_mine, fn, self.consts, r, s,
-                                     device_sync=torch.cuda.synchronize)
+
+        def early():                       # peers, during rank 0's computeH: A.w, B1.w, B2.w, K.w of this shard
+            return self.ctx.prove_sums_dev(self.pk, d_w, None)
+
+        def sums(hm, w_part):
+            if w_part is None:             # rank 0 (or no early phase): all five over one call
+                return self.ctx.prove_sums_dev(self.pk, d_w, hm.data_ptr())
+            return merge_sums(w_part, self.ctx.prove_sums_dev(self.pk, None, hm.data_ptr()))
+
+        return exchange_and_assemble(self.dist, self.rank, self.world, h_full, h_mine, sums, self.consts, r, s,
+                                     device_sync=torch.cuda.synchronize, early_fn=early if self.z_hi > self.z_lo else None)
