@@ -20,7 +20,11 @@ def host():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, src])
     lib = ctypes.CDLL(so)
     lib.zkh_create.restype = ctypes.c_void_p
-    for f in ("zkh_count_status", "zkh_count_proofs", "zkh_prove_calls"):
+    hdr = os.path.join(PKG, "host", "proof_row.hpp")
+    if os.path.getmtime(hdr) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, src])
+        lib = ctypes.CDLL(so)
+    for f in ("zkh_count_status", "zkh_count_proofs", "zkh_prove_calls", "zkh_proof_csv"):
         getattr(lib, f).restype = ctypes.c_long
     return lib
 
@@ -112,3 +116,38 @@ def test_shard_range_partitions(host):
             assert list(bench.shard_heights(n, r, world)) == list(range(lo.value, hi.value))
             got += list(range(lo.value, hi.value))
         assert got == list(range(n))
+
+
+def test_proof_row_csv_is_what_the_reference_verifier_reads(host):
+    """prover.go:180-236 + dbtool/main.go:260-289: base64.StdEncoding, json.Marshal([][]byte), encoding/csv quoting — checked
+    against Python's independent base64 / json / csv implementations, read back the way src/verifier/main.go:127-141 does"""
+    import base64, csv, io, json, random
+    rng = random.Random(5)
+    for trial, raw_len in enumerate((388, 324, 1, 2, 3)):
+        raw = bytes(rng.randrange(256) for _ in range(raw_len))
+        before, after, root = (bytes(rng.randrange(256) for _ in range(32)) for _ in range(3))
+        commit = bytes(rng.randrange(256) for _ in range(32 if trial else 31))
+        out = ctypes.create_string_buffer(4096)
+        n = host.zkh_proof_csv(raw, ctypes.c_size_t(len(raw)), before, after, root, commit, ctypes.c_size_t(len(commit)),
+                               ctypes.c_uint32(7 * trial), ctypes.c_uint32(7 * trial + 1379), 50, ctypes.c_int64(trial), 1, out, ctypes.c_size_t(4096))
+        assert n > 0
+        text = out.raw[:n].decode()
+        # the same row written by an independent CSV writer
+        buf = io.StringIO()
+        wr = csv.writer(buf, lineterminator="\n")
+        wr.writerow(["batch_number", "proof_info", "cex_asset_list_commitments", "account_tree_roots", "batch_commitment",
+                     "min_account_index", "max_account_index", "assets_count"])
+        b64 = lambda b: base64.b64encode(b).decode()
+        wr.writerow([trial, b64(raw), json.dumps([b64(before), b64(after)], separators=(",", ":")), json.dumps([b64(root)]), b64(commit),
+                     7 * trial, 7 * trial + 1379, 50])
+        assert text == buf.getvalue()
+        # and read back as the verifier does: CSV -> JSON arrays -> base64
+        rows = list(csv.DictReader(io.StringIO(text)))
+        assert len(rows) == 1
+        r = rows[0]
+        assert base64.b64decode(r["proof_info"]) == raw and base64.b64decode(r["batch_commitment"]) == commit
+        assert [base64.b64decode(x) for x in json.loads(r["cex_asset_list_commitments"])] == [before, after]
+        assert [base64.b64decode(x) for x in json.loads(r["account_tree_roots"])] == [root]
+        assert int(r["batch_number"]) == trial and int(r["max_account_index"]) == 7 * trial + 1379 and int(r["assets_count"]) == 50
+    assert host.zkh_proof_csv(b"x", ctypes.c_size_t(1), bytes(32), bytes(32), bytes(32), bytes(32), ctypes.c_size_t(32), 0, 0, 50, ctypes.c_int64(0), 1,
+                              ctypes.create_string_buffer(8), ctypes.c_size_t(8)) == -1

@@ -1,6 +1,7 @@
 // C entry points over prover_host.hpp so the CPU test-suite (ctypes) can drive the dispatcher the way
 // src/prover/prover/prover_test.go:TestMockProver drives the reference (many fake provers, no SNARK).
 #include "prover_host.hpp"
+#include "proof_row.hpp"
 #include <atomic>
 #include <cstring>
 using namespace zkpor_host;
@@ -49,4 +50,14 @@ int zkh_get_proof(zkh_dispatcher* h, int64_t batch, char* out, size_t cap, size_
 }
 int zkh_insert_proof(zkh_dispatcher* h, int64_t batch) { Proof p; p.BatchNumber = batch; return h->d->proofModel.CreateProof(p); }
 void zkh_shard_range(int64_t n, int rank, int world, int64_t* lo, int64_t* hi) { shard_range(n, rank, world, lo, hi); }
+// one proof-table row as a CSV line (header first when with_header != 0); returns the length, or -1 if `cap` is too small
+long zkh_proof_csv(const char* raw, size_t raw_len, const char* before32, const char* after32, const char* root32, const char* commit,
+                   size_t commit_len, uint32_t min_idx, uint32_t max_idx, int assets, int64_t batch, int with_header, char* out, size_t cap) {
+    ProofRow r = MakeProofRow(std::string(raw, raw_len), std::string(before32, 32), std::string(after32, 32), std::string(root32, 32),
+                              std::string(commit, commit_len), min_idx, max_idx, assets, batch);
+    std::string line = (with_header ? std::string(ProofCsvHeader()) : std::string()) + ProofCsvLine(r);
+    if (line.size() > cap) return -1;
+    memcpy(out, line.data(), line.size());
+    return (long)line.size();
+}
 }
