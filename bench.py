@@ -242,7 +242,15 @@ def split_main(args, torch, zkpor, ctx, dist, rank, world, json_fd):
     ck(lib.zkpor_dev_fill_fr(ctx.h, vp(w.data_ptr()), ctypes.c_size_t(n_wires), ctypes.c_uint64(2), ctypes.c_int(kind)))
     h_mine = dev(sp.h_block_bytes())
     a0 = b0 = c0 = a = b = c = None
-    if rank == 0:
+    shard_h = args.split_h == "sharded" and world >= 2 and (world & (world - 1)) == 0
+    if shard_h:
+        # every rank holds its D_low slice of a, b, c (elements at positions p = rank mod world); c = a.b position-wise
+        nloc = D // world
+        a0, b0, c0, a, b, c, tmp = (dev(32 * nloc) for _ in range(7))
+        ck(lib.zkpor_dev_fill_fr(ctx.h, vp(a0.data_ptr()), ctypes.c_size_t(nloc), ctypes.c_uint64(11 + 100 * rank), ctypes.c_int(0)))
+        ck(lib.zkpor_dev_fill_fr(ctx.h, vp(b0.data_ptr()), ctypes.c_size_t(nloc), ctypes.c_uint64(12 + 100 * rank), ctypes.c_int(0)))
+        ck(lib.zkpor_dev_fr_mul(ctx.h, vp(c0.data_ptr()), vp(a0.data_ptr()), vp(b0.data_ptr()), ctypes.c_size_t(nloc)))
+    elif rank == 0:
         a0, b0, c0, a, b, c = (dev(32 * D) for _ in range(6))
         ck(lib.zkpor_dev_fill_fr(ctx.h, vp(a0.data_ptr()), ctypes.c_size_t(D), ctypes.c_uint64(11), ctypes.c_int(0)))
         ck(lib.zkpor_dev_fill_fr(ctx.h, vp(b0.data_ptr()), ctypes.c_size_t(D), ctypes.c_uint64(12), ctypes.c_int(0)))
@@ -251,6 +259,11 @@ def split_main(args, torch, zkpor, ctx, dist, rank, world, json_fd):
     proofs = []
 
     def one_proof():
+        if shard_h:
+            for dst, src in ((a, a0), (b, b0), (c, c0)):
+                ck(lib.zkpor_dev_copy(ctx.h, vp(dst.data_ptr()), vp(src.data_ptr()), ctypes.c_size_t(src.numel())))
+            proofs.append(sp.prove_sharded_h(w.data_ptr(), a, b, c, tmp, r, s))
+            return
         if rank == 0:
             for dst, src in ((a, a0), (b, b0), (c, c0)):
                 ck(lib.zkpor_dev_copy(ctx.h, vp(dst.data_ptr()), vp(src.data_ptr()), ctypes.c_size_t(32 * D)))
@@ -272,7 +285,8 @@ def split_main(args, torch, zkpor, ctx, dist, rank, world, json_fd):
                "dtype": "i32x9 (254-bit Fp/Fr on 9 x 29-bit signed lazy Montgomery limbs in registers; u32x8 Montgomery in memory)",
                "data": "synthetic",
                "config": {"workload": f"single-proof split: D=2^{log2}, n_wires=2^{log2}, scalars={args.scalars}, key sharded {world}-way by "
-                                      "contiguous range, h scattered from rank 0, 576-byte partial sums all-gathered"},
+                                      "contiguous range, " + ("computeH sharded (7 all-to-alls)" if shard_h else "h scattered from rank 0") +
+                                      ", 576-byte partial sums all-gathered"},
                "proofs_identical": bool(same), "phases_ms_per_proof_rank0": phases}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     pk.close()
@@ -291,6 +305,9 @@ def main():
     ap.add_argument("--g1-variant", type=int, default=-1, help="level-1 G1 arithmetic: 0 = 8x32-bit limbs, 1 = 9x29-bit limbs (library default)")
     ap.add_argument("--split", action="store_true", help="ONE proof at a time split over all ranks (BASELINE.json configs[4]; "
                     "zkmerkle-proof-of-solvency_amd/split.py) instead of one independent proof per GPU")
+    ap.add_argument("--split-h", choices=["rank0", "sharded"], default="sharded",
+                    help="with --split: computeH on rank 0 + scatter of h, or sharded over all ranks with all-to-alls "
+                         "(needs a power-of-two number of ranks >= 2; falls back to rank0 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2", type=int, default=20)
     args = ap.parse_args()

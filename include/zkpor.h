@@ -198,6 +198,20 @@ int32_t zkpor_prove_assemble(const void* alpha, const void* beta, const void* de
 /* the five fixed points of a loaded key (G1 affine 64 B x3, G2 affine 128 B x2), e.g. to feed zkpor_prove_assemble */
 int32_t zkpor_pk_consts(zkpor_pk* pk, void* alpha, void* beta, void* delta, void* beta2, void* delta2);
 
+/* computeH itself spread over the same 2^world_log2 GPUs (csrc/ntt.hip ntt_shard_stage; index algebra in tools/ntt_model.py):
+ * every rank holds 2^(log2_domain - world_log2) elements of a, b, c.  Each field pass of the transform is local under one of
+ * two distributions of the memory position p — D_low (rank = low bits of p, local index p >> world_log2) or D_high (rank = top
+ * bits, local index p mod local size) — so one all-to-all per transform replaces the NTT on a single GPU and the scatter of h:
+ *   step 0 (a, b, c in D_low) | all-to-all to D_high | step 1 | all-to-all to D_low | step 2 (leaves the product in a) |
+ *   all-to-all of a to D_high | step 3: a = this rank's contiguous block of h, in the order of the key's Z.
+ * An all-to-all to D_high is: all_to_all_single of the local array (chunk d = elements [d M, (d+1) M), M = local size / W), then
+ * zkpor_shard_transpose_dev(interleave = 1); to D_low: zkpor_shard_transpose_dev(interleave = 0), then all_to_all_single. */
+int32_t zkpor_compute_h_shard_dev(zkpor_ctx* ctx, int log2_domain, int world_log2, int rank, void* d_a, void* d_b, void* d_c,
+                                  int step);
+/* out-of-place [W][M] -> [M][W] (interleave = 1: out[i W + r] = in[r M + i]) or back (interleave = 0) on 32-byte elements;
+ * log2_local = log2 of the local array, W = 2^world_log2 */
+int32_t zkpor_shard_transpose_dev(zkpor_ctx* ctx, void* d_out, const void* d_in, int log2_local, int world_log2, int interleave);
+
 /* Pedersen commitment over the committed wires (gnark-crypto pedersen.ProvingKey.Commit / ProveKnowledge):
  * values: n_committed Fr; out: commitment | knowledge proof, G1 affine 64 B each */
 int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64],

@@ -90,6 +90,13 @@ def test_ntt_model_matches_naive_dft():
     assert M.fft(O.fr_to_ints(a), n, False, True, True) == O.fr_to_ints(O.fft(a, n, False, O.DIF, True))
 
 
+def test_sharded_ntt_model_matches_the_unsharded_passes():
+    """tools/ntt_model.py fft_sharded: the index algebra of csrc/ntt.hip ntt_shard_stage (two distributions, one all-to-all per
+    transform, global positions only in the twiddle / scale exponents) reproduces the unsharded transform exactly"""
+    import ntt_model as M
+    assert M._selftest_sharded()
+
+
 def test_msm_identities():
     n = 300
     s = O.fr_random(1, n); w = O.fr_random(2, n)

@@ -60,3 +60,81 @@ def test_split_exchange_two_ranks_gloo(tmp_path):
         o, err = p.communicate(timeout=240)
         assert p.returncode == 0, err[-3000:]
         assert json.loads(o.strip().splitlines()[-1])["ok"]
+
+
+H_WORKER = r'''
+import json, os, sys
+root = %(root)r
+for p in (root, os.path.join(root, "tools"), os.path.join(root, "zkmerkle-proof-of-solvency_amd")):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+import ntt_model as M, split
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n, kl, km, wlog = 7, 3, 2, 1                       # fields (0,3) (3,2) (5,2); 2 ranks
+N = 1 << n; nl = n - wlog
+import random
+random.seed(3)
+full = {k: [random.randrange(M.R) for _ in range(N)] for k in "abc"}
+enc = lambda vals: torch.from_numpy(np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).copy())
+dec = lambda t: [int.from_bytes(t.numpy().tobytes()[32 * i:32 * i + 32], "little") for i in range(t.numel() // 32)]
+ten = {k: enc(full[k][rank::world]) for k in "abc"}           # D_low slices
+tmp = torch.empty_like(ten["a"])
+Tf, Ti = M.Tables(n, False), M.Tables(n, True)
+fields = M.plan_fields(n, kl, km)
+ginv = pow(M.G, M.R - 2, M.R); ninv = pow(N, M.R - 2, M.R)
+den = pow((pow(M.G, N, M.R) - 1) %% M.R, M.R - 2, M.R)
+pre = lambda p: pow(M.G, M.rev(p, n), M.R) * ninv %% M.R       # g^rev(p) / N, as compute_h_dev folds it
+post = lambda p: pow(ginv, M.rev(p, n), M.R) * ninv %% M.R
+def run(k, T, dif, dist_, flds, first=None, last=None):        # stand-in for one ntt_shard_stage on tensor k
+    v = dec(ten[k])
+    order = list(reversed(fields)) if dif else list(fields)
+    for idx, (lo, kb) in enumerate(order):
+        if (lo, kb) not in flds: continue
+        sc = first if idx == 0 else (last if idx == len(order) - 1 else None)
+        M.pass_local(v, n, wlog, rank, dist_, lo, kb, T, dif, sc)
+    ten[k].copy_(enc(v))
+upper, lowest = fields[1:], fields[:1]
+def step_fn(s):                                                # the four steps of zkpor_compute_h_shard_dev, on the model
+    if s == 0:
+        for k in "abc": run(k, Ti, True, "low", upper)
+    elif s == 1:
+        for k in "abc": run(k, Ti, True, "high", lowest); run(k, Tf, False, "high", lowest, first=pre)
+    elif s == 2:
+        for k in "abc": run(k, Tf, False, "low", upper)
+        a, b, c = dec(ten["a"]), dec(ten["b"]), dec(ten["c"])
+        ten["a"].copy_(enc([(x * y - z) * den %% M.R for x, y, z in zip(a, b, c)]))
+        run("a", Ti, True, "low", upper)
+    else:
+        run("a", Ti, True, "high", lowest, last=post)
+def transpose_fn(out, inp, interleave):                        # stand-in for zkpor_shard_transpose_dev
+    Mch = (1 << nl) // world
+    x = inp.view(world, Mch, 32) if interleave else inp.view(Mch, world, 32)
+    out.copy_(x.transpose(0, 1).contiguous().view(-1))
+split.compute_h_sharded(dist, world, step_fn, transpose_fn, ten["a"], ten["b"], ten["c"], tmp)
+# reference: the unsharded sequence of compute_h_dev on the model
+def fwd_inv(x):
+    x = M.fft(x, n, True, True, False, kl, km)                                 # inverse DIF (1/N inside)
+    return M.fft(x, n, False, False, True, kl, km)                             # forward DIT on the coset
+A, B, C = (fwd_inv(full[k]) for k in "abc")
+P = [(x * y - z) * den %% M.R for x, y, z in zip(A, B, C)]
+H = M.fft(P, n, True, True, True, kl, km)
+blk = N // world
+ok = dec(ten["a"]) == H[rank * blk:(rank + 1) * blk]
+print(json.dumps({"rank": rank, "ok": bool(ok)}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_compute_h_exchange_two_ranks_gloo(tmp_path):
+    """split.compute_h_sharded (the order of steps, transposes and all_to_all_single calls) over gloo with two ranks; the device
+    steps are stood in for by tools/ntt_model.py's index-exact passes on a 128-point domain"""
+    script = tmp_path / "h_worker.py"
+    script.write_text(H_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29619", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        o, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-3000:]
+        assert json.loads(o.strip().splitlines()[-1])["ok"]

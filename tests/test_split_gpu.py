@@ -219,3 +219,63 @@ def test_split_nccl_single_rank(tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]      # RCCL prints its library path on stdout at exit
     assert lines and json.loads(lines[-1])["ok"]
+
+
+def _emulated_all_to_all(zk, bufs, tmp, n_local, wlog, to_high):
+    """what dist.all_to_all_single + zkpor_shard_transpose_dev do between the ranks, with device-to-device copies on one GPU"""
+    W = 1 << wlog
+    chunk = 32 << (n_local - wlog)
+    cp = lambda dst, src: zk._ck(zk.lib.zkpor_dev_copy(zk.h, ctypes.c_void_p(dst), ctypes.c_void_p(src), ctypes.c_size_t(chunk)))
+    if not to_high:                                       # sender-side de-interleave, then the exchange
+        for r in range(W):
+            zk.shard_transpose_dev(tmp[r].ptr, bufs[r].ptr, n_local, wlog, False)
+        for s in range(W):
+            for d in range(W):
+                cp(bufs[d].ptr + s * chunk, tmp[s].ptr + d * chunk)
+    else:                                                 # the exchange, then the receiver-side interleave
+        for s in range(W):
+            for d in range(W):
+                cp(tmp[d].ptr + s * chunk, bufs[s].ptr + d * chunk)
+        for r in range(W):
+            zk.shard_transpose_dev(bufs[r].ptr, tmp[r].ptr, n_local, wlog, True)
+
+
+@pytest.mark.parametrize("log2,wlog", [(20, 2), (20, 3), (17, 1), (22, 3)])
+def test_compute_h_sharded_equals_unsharded(zk, log2, wlog):
+    """computeH spread over 2^wlog ranks (run one after the other here, the all-to-alls emulated by copies): the blocks of h that
+    the ranks end with, concatenated, are bit for bit the h of the unsharded computeH"""
+    n = 1 << log2; W = 1 << wlog; nl = log2 - wlog
+    full = {k: zk.alloc(32 * n) for k in "abc"}
+    loc = {k: [zk.alloc(32 << nl) for _ in range(W)] for k in "abc"}
+    tmp = [zk.alloc(32 << nl) for _ in range(W)]
+    try:
+        zk.fill_fr(full["a"], n, 11, 0); zk.fill_fr(full["b"], n, 12, 0)
+        zk._ck(zk.lib.zkpor_dev_fr_mul(zk.h, ctypes.c_void_p(full["c"].ptr), ctypes.c_void_p(full["a"].ptr), ctypes.c_void_p(full["b"].ptr), ctypes.c_size_t(n)))
+        host = {k: full[k].download(np.uint64, (n, 4)) for k in "abc"}
+        host["c"][5] = host["a"][7]                         # a*b - c not identically zero on the domain
+        full["c"].upload(host["c"])
+        for k in "abc":                                     # D_low: rank r holds the elements at positions p = r mod W
+            for r in range(W):
+                loc[k][r].upload(np.ascontiguousarray(host[k][r::W]))
+        zk.compute_h_dev(log2, full["a"].ptr, full["b"].ptr, full["c"].ptr)
+        expect = full["a"].download(np.uint64, (n, 4))
+        assert expect.any()
+        ptrs = lambda r: (loc["a"][r].ptr, loc["b"][r].ptr, loc["c"][r].ptr)
+        for r in range(W):
+            zk.compute_h_shard_dev(log2, wlog, r, *ptrs(r), 0)
+        for k in "abc":
+            _emulated_all_to_all(zk, loc[k], tmp, nl, wlog, True)
+        for r in range(W):
+            zk.compute_h_shard_dev(log2, wlog, r, *ptrs(r), 1)
+        for k in "abc":
+            _emulated_all_to_all(zk, loc[k], tmp, nl, wlog, False)
+        for r in range(W):
+            zk.compute_h_shard_dev(log2, wlog, r, *ptrs(r), 2)
+        _emulated_all_to_all(zk, loc["a"], tmp, nl, wlog, True)
+        for r in range(W):
+            zk.compute_h_shard_dev(log2, wlog, r, loc["a"][r].ptr, None, None, 3)
+        got = np.concatenate([loc["a"][r].download(np.uint64, (1 << nl, 4)) for r in range(W)])
+        assert np.array_equal(got, expect)
+    finally:
+        for b in list(full.values()) + tmp + [x for v in loc.values() for x in v]:
+            b.free()

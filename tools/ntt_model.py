@@ -175,3 +175,134 @@ if __name__ == "__main__":
                 got2 = fft(xin, n, inverse, False, coset, kl, km)
                 ok2 = got2 == ref
                 print(n, kl, km, plan_fields(n, kl, km), "inv" if inverse else "fwd", "coset" if coset else "     ", ok1, ok2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sharded transform (csrc/ntt.hip ntt_shard_stage): the array is spread over W = 2^wlog ranks.  Every pass over an
+# index field is local under one of two distributions of the memory position p:
+#   D_low  : rank = low wlog bits of p, local index = p >> wlog            -> all fields above the lowest are local
+#   D_high : rank = top wlog bits of p, local index = p mod 2^(n - wlog)   -> all fields below the highest are local
+# A pass runs on the local array exactly as on an array of 2^(n-wlog) elements (lo shifted down by wlog under D_low); only the
+# exponents of the inter-pass twiddles and of the coset scale need the GLOBAL position: p_glob = ((p_loc << sh) | orv) + add.
+def _gmap(n, wlog, rank, dist):
+    if dist == "low":
+        return wlog, rank, 0
+    return 0, 0, rank << (n - wlog)
+
+
+def pass_local(xloc, n, wlog, rank, dist, lo, kb, T, dif, scale=None):
+    """one field pass on a rank's local array; (lo, kb) is the GLOBAL field, T the GLOBAL tables"""
+    sh, orv, add = _gmap(n, wlog, rank, dist)
+    nl = n - wlog
+    lol = lo - sh
+    assert (dist == "low" and lol > 0) or (dist == "high" and lo + kb <= nl)
+    s0g = n - lo - kb
+    for hi in range(1 << (nl - lol - kb)):
+        for l in range(1 << lol):
+            base = (hi << (lol + kb)) + l
+            lg = (l << sh) | orv
+            pos = [base + (m << lol) for m in range(1 << kb)]
+            pg = [((p << sh) | orv) + add for p in pos]
+            v = [xloc[p] for p in pos]
+            if not dif:
+                for m in range(1 << kb):
+                    if scale is not None:
+                        v[m] = v[m] * scale(pg[m]) % R
+                    if lo > 0:
+                        v[m] = v[m] * T.tw((lg * rev(m, kb)) << s0g) % R
+            for j in range(kb):
+                half = 1 << ((kb - 1 - j) if dif else j)
+                for q in range(1 << (kb - 1)):
+                    grp, ps = divmod(q, half)
+                    i0 = grp * 2 * half + ps
+                    i1 = i0 + half
+                    if dif:
+                        a, b = v[i0], v[i1]
+                        v[i0] = (a + b) % R
+                        v[i1] = (a - b) * T.small_tw(kb, ps << j) % R
+                    else:
+                        a, b = v[i0], v[i1] * T.small_tw(kb, ps << (kb - 1 - j)) % R
+                        v[i0] = (a + b) % R
+                        v[i1] = (a - b) % R
+            for m in range(1 << kb):
+                val = v[m]
+                if dif:
+                    if lo > 0:
+                        val = val * T.tw((lg * rev(m, kb)) << s0g) % R
+                    if scale is not None:
+                        val = val * scale(pg[m]) % R
+                xloc[pos[m]] = val
+
+
+def exchange(locs, n, wlog, to_high):
+    """all-to-all between the distributions.  low -> high: rank r's local array is already grouped by destination (chunk d =
+    local indices [d*M, (d+1)*M)); the receiver interleaves the W chunks (index i*W + r).  high -> low: the sender first
+    de-interleaves (chunk d = its elements with local index = d mod W), the receiver concatenates the chunks by sender."""
+    W = 1 << wlog
+    M = 1 << (n - 2 * wlog)
+    out = [[None] * (M * W) for _ in range(W)]
+    for s in range(W):
+        for d in range(W):
+            if to_high:
+                chunk = locs[s][d * M:(d + 1) * M]                      # send buffer: contiguous
+                for i in range(M):
+                    out[d][i * W + s] = chunk[i]                         # receiver-side transpose [W][M] -> [M][W]
+            else:
+                chunk = [locs[s][i * W + d] for i in range(M)]           # sender-side transpose [M][W] -> [W][M]
+                out[d][s * M:(s + 1) * M] = chunk
+    return out
+
+
+def fft_sharded(x, n, wlog, inverse, dif, scale_first=None, scale_last=None, kb_low=8, kb_max=9):
+    """the same passes as fft() (without its up-front / trailing host-side scalings: pass them as scale_first / scale_last on
+    GLOBAL positions), run rank by rank.  DIF: input in D_low, output in D_high; DIT: input in D_high, output in D_low."""
+    W = 1 << wlog
+    T = Tables(n, inverse)
+    fields = plan_fields(n, kb_low, kb_max)
+    assert len(fields) >= 2 and wlog <= fields[0][1] and wlog <= fields[-1][1]
+    if dif:
+        locs = [[x[(j << wlog) | r] for j in range(1 << (n - wlog))] for r in range(W)]
+        steps = list(reversed(fields))
+    else:
+        locs = [x[r << (n - wlog):(r + 1) << (n - wlog)] for r in range(W)]
+        steps = list(fields)
+    dist = "low" if dif else "high"
+    for idx, (lo, kb) in enumerate(steps):
+        need = "high" if lo == 0 else "low"
+        if need != dist:
+            locs = exchange(locs, n, wlog, to_high=(need == "high"))
+            dist = need
+        sc = scale_first if idx == 0 else (scale_last if idx == len(steps) - 1 else None)
+        for r in range(W):
+            pass_local(locs[r], n, wlog, r, dist, lo, kb, T, dif, sc)
+    out = [None] * (1 << n)
+    for r in range(W):
+        for j, v in enumerate(locs[r]):
+            out[(r << (n - wlog)) + j if dist == "high" else (j << wlog) | r] = v
+    return out
+
+
+def _selftest_sharded():
+    import random
+    random.seed(2)
+    ok = True
+    for n, kl, km, wlog in [(7, 3, 2, 1), (7, 3, 2, 2), (8, 3, 3, 2), (9, 3, 3, 2), (10, 4, 3, 3), (6, 3, 3, 2)]:
+        x = [random.randrange(R) for _ in range(1 << n)]
+        ginv = pow(G, R - 2, R); ninv = pow(1 << n, R - 2, R)
+        for inverse in (False, True):
+            # DIF, plain (inverse: 1/N at the last store, as fft() does inside its last pass)
+            last = (lambda p: ninv) if inverse else None
+            ref = fft(x, n, inverse, True, False, kl, km)
+            got = fft_sharded(x, n, wlog, inverse, True, None, last, kl, km)
+            ok &= got == ref
+            # DIT on the coset (forward: g^rev(p) at the first load)
+            if not inverse:
+                ref = fft(x, n, False, False, True, kl, km)
+                got = fft_sharded(x, n, wlog, False, False, (lambda p: pow(G, rev(p, n), R)), None, kl, km)
+                ok &= got == ref
+            else:   # inverse DIF on the coset: g^-rev(p)/N at the last store
+                ref = fft(x, n, True, True, True, kl, km)
+                got = fft_sharded(x, n, wlog, True, True, None, (lambda p: pow(ginv, rev(p, n), R) * ninv % R), kl, km)
+                ok &= got == ref
+        print("sharded", n, kl, km, "W =", 1 << wlog, ok)
+    return ok

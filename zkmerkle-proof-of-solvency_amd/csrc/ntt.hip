@@ -163,6 +163,10 @@ struct PassArgs29 {
     const Fr* g_lo; const Fr* g_hi; int tb;
     Fr konst;
     int in_gnark, out_gnark;
+    // sharded transforms (ntt_shard_stage): x is one rank's local array of 2^n elements of a 2^n_glob transform; the exponents of
+    // the inter-pass twiddles and of the scale need the GLOBAL memory position: p_glob = ((p << p_shift) | p_or) + p_add
+    int n_glob, p_shift;
+    u32 p_or, p_add;
 };
 ZK_D Fr29 ld29(const u32* t) {
     Fr29 r;
@@ -176,7 +180,7 @@ ZK_D void st29(u32* t, const Fr29& v) {
 }
 ZK_D Fr29 scale29(const PassArgs29& A, int mode, const Fr29& v, u32 p) {
     if (mode == 1) return Fr29::mul(v, Fr29::from32<0>(A.konst));
-    u32 e = mode == 2 ? p : brev(p, A.n);
+    u32 e = mode == 2 ? p : brev(p, A.n_glob);
     Fr29 g = Fr29::mul(Fr29::from32<0>(A.g_lo[e & ((1u << A.tb) - 1u)]), Fr29::from32<0>(A.g_hi[e >> A.tb]));
     return Fr29::mul(v, g);
 }
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
         else { m = idx & (F - 1u); c = idx >> kb; p = ((hi + c) << kb) + m; li = c * F + m; }
         const Fr raw = A.x[p];
         Fr29 v = A.in_gnark ? Fr29::from32<5>(raw) : Fr29::from32<0>(raw);
-        if (A.scale_load) v = scale29(A, A.scale_load, v, p);
-        if (!DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << lo) | (l0 + c)]));
+        if (A.scale_load) v = scale29(A, A.scale_load, v, ((p << A.p_shift) | A.p_or) + A.p_add);
+        if (!DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << (lo + A.p_shift)) | (((l0 + c) << A.p_shift) | A.p_or)]));
         else if (!DIF && A.in_gnark && !A.scale_load) v = Fr29::reduce32(v);  // the product-free first stage adds two loaded values: keep |v| < 32r
         st29(tile + 9u * li, v);
     }
@@ -300,8 +304,8 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
         if (lo > 0) { c = idx & (C - 1u); m = idx >> clog; p = (hi << (lo + kb)) + (m << lo) + l0 + c; li = m * C + c; }
         else { m = idx & (F - 1u); c = idx >> kb; p = ((hi + c) << kb) + m; li = c * F + m; }
         Fr29 v = ld29(tile + 9u * li);
-        if (DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << lo) | (l0 + c)]));
-        if (A.scale_store) v = scale29(A, A.scale_store, v, p);
+        if (DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << (lo + A.p_shift)) | (((l0 + c) << A.p_shift) | A.p_or)]));
+        if (A.scale_store) v = scale29(A, A.scale_store, v, ((p << A.p_shift) | A.p_or) + A.p_add);
         A.x[p] = A.out_gnark ? Fr29::to32_div32(v) : Fr29::reduce32_pos(v).pack32();
     }
 }
@@ -544,6 +548,7 @@ static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, b
         A.tb = d->tb;
         A.scale_load = 0; A.scale_store = 0; A.g_lo = nullptr; A.g_hi = nullptr; A.konst = c32;
         A.in_gnark = step == 0; A.out_gnark = step == nf - 1;
+        A.n_glob = d->n; A.p_shift = 0; A.p_or = 0; A.p_add = 0;
         if (step == 0 && first_load.mode) {
             A.scale_load = first_load.mode;
             if (first_load.mode == 1) A.konst = Fr::mul(first_load.konst, c32);
@@ -566,6 +571,127 @@ static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, b
         else hipLaunchKernelGGL(k_ntt_pass29<false>, dim3(blocks), dim3(256), smem, ctx->stream, A);
         ZK_KERNEL_CHECK(ctx);
     }
+    return ZKPOR_OK;
+}
+
+// ---- one transform spread over W = 2^wlog GPUs (index algebra modelled in tools/ntt_model.py fft_sharded) ----
+// x is this rank's local array of 2^(n - wlog) elements.  Every field pass is local under one of two distributions of the
+// memory position p: D_low (rank = low wlog bits, local index p >> wlog) for the fields above the lowest, D_high (rank = top
+// wlog bits, local index p mod 2^(n-wlog)) for the lowest field.  stage 0 runs the passes before the exchange, stage 1 the ones
+// after it (DIF: upper fields under D_low, then the lowest under D_high; DIT: the reverse).  The passes are the unsharded kernels
+// on the local array; only the exponents of the inter-pass twiddles and of the scale use the global position.
+static int32_t ntt_shard_stage(zkpor_ctx* ctx, NttDomain* d, Fr* x, int wlog, int rank, bool inverse, bool dif,
+                               const ScaleSpec& first_load, const ScaleSpec& last_store, int stage) {
+    Field f[8];
+    const int nf = plan_fields(d->n, f);
+    if (!d->have29 || ctx->ntt_variant != 1) { ctx->err = "ntt: the sharded transform needs the 29-bit kernels"; return ZKPOR_E_STATE; }
+    if (nf < 2 || wlog < 1 || wlog >= f[0].kb || wlog > f[nf - 1].kb || rank < 0 || rank >= (1 << wlog)) {
+        ctx->err = "ntt: this size cannot be split over that many ranks"; return ZKPOR_E_ARG;
+    }
+    const int nl = d->n - wlog;
+    Fr c32 = Fr::one();
+    for (int i = 0; i < 5; ++i) c32 = Fr::add(c32, c32);
+    for (int step = 0; step < nf; ++step) {
+        const int fi = dif ? nf - 1 - step : step;
+        const bool high = fi == 0;                       // the lowest field runs under D_high
+        const int st = dif ? (high ? 1 : 0) : (high ? 0 : 1);
+        if (st != stage) continue;
+        const Field& fl = f[fi];
+        PassArgs29 A;
+        A.x = x; A.n = nl; A.kb = fl.kb;
+        A.lo = high ? 0 : fl.lo - wlog;
+        A.n_glob = d->n;
+        A.p_shift = high ? 0 : wlog; A.p_or = high ? 0u : (u32)rank; A.p_add = high ? ((u32)rank << nl) : 0u;
+        int cmax = ctx->ntt_tile_log - fl.kb;
+        if (cmax < 0) cmax = 0;
+        int avail = A.lo > 0 ? A.lo : nl - fl.kb;
+        A.clog = avail < cmax ? avail : cmax;
+        A.small29 = inverse ? d->small_inv29 : d->small_fwd29;
+        A.tw_full = inverse ? d->full_inv29[fi] : d->full_fwd29[fi];
+        A.tb = d->tb;
+        A.scale_load = 0; A.scale_store = 0; A.g_lo = nullptr; A.g_hi = nullptr; A.konst = c32;
+        A.in_gnark = step == 0; A.out_gnark = step == nf - 1;
+        if (step == 0 && first_load.mode) {
+            A.scale_load = first_load.mode;
+            if (first_load.mode == 1) A.konst = Fr::mul(first_load.konst, c32);
+            else { A.g_lo = table29(d, first_load.g_lo); A.g_hi = table29(d, first_load.g_hi); }
+        }
+        if (step == nf - 1 && last_store.mode) {
+            A.scale_store = last_store.mode;
+            if (last_store.mode == 1) A.konst = Fr::mul(last_store.konst, c32);
+            else { A.g_lo = table29(d, last_store.g_lo); A.g_hi = table29(d, last_store.g_hi); }
+        }
+        if ((A.scale_load > 1 || A.scale_store > 1) && (!A.g_lo || !A.g_hi)) { ctx->err = "ntt: no 2^261-form table for this scale"; return ZKPOR_E_ARG; }
+        u32 blocks = (u32)(((size_t)1 << nl) >> (fl.kb + A.clog));
+        size_t smem = ((size_t)36 << fl.kb) << A.clog;
+        if (smem > 64 * 1024) {
+            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        if (dif) hipLaunchKernelGGL(k_ntt_pass29<true>, dim3(blocks), dim3(256), smem, ctx->stream, A);
+        else hipLaunchKernelGGL(k_ntt_pass29<false>, dim3(blocks), dim3(256), smem, ctx->stream, A);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    return ZKPOR_OK;
+}
+
+// the local transposes either side of the all-to-all: [W][M] <-> [M][W] (M = 2^(n - 2 wlog) elements per chunk)
+__global__ void k_shard_transpose(const Fr* __restrict__ in, Fr* __restrict__ out, u32 mlog, u32 wlog, int interleave) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ((size_t)1 << (mlog + wlog))) return;
+    const u32 W1 = (1u << wlog) - 1u;
+    if (interleave) { size_t i = t >> wlog; u32 r = (u32)t & W1; out[t] = in[((size_t)r << mlog) + i]; }       // out[i*W + r] = in[r*M + i]
+    else { size_t i = t & (((size_t)1 << mlog) - 1); u32 r = (u32)(t >> mlog); out[t] = in[(i << wlog) + r]; }  // out[r*M + i] = in[i*W + r]
+}
+
+// computeH of one proof over 2^wlog ranks, in four steps with an all-to-all after steps 0, 1 and 2 (split.py drives them):
+//   step 0  a, b, c (D_low):  inverse DIF, upper fields                                   -> exchange a, b, c to D_high
+//   step 1  a, b, c (D_high): inverse DIF lowest field; forward coset DIT lowest field    -> exchange a, b, c to D_low
+//   step 2  a, b, c (D_low):  forward DIT upper fields; a = (a b - c) den; inverse coset DIF upper fields on a -> exchange a
+//   step 3  a (D_high):       inverse DIF lowest field with the g^-rev(p)/N scale: this rank's block of h, in the order of pk->Z
+int32_t compute_h_shard_step(zkpor_ctx* ctx, int n, int wlog, int rank, Fr* a, Fr* b, Fr* c, int step) {
+    NttDomain* d;
+    ZK_TRY(ntt_domain_get(ctx, n, &d));
+    ScaleSpec none, pre, post;
+    pre.mode = 3; pre.g_lo = d->g_lo; pre.g_hi = d->g_hi_ninv;
+    post.mode = 3; post.g_lo = d->gi_lo; post.g_hi = d->gi_hi_ninv;
+    Fr* v[3] = {a, b, c};
+    const size_t NL = (size_t)1 << (n - wlog);
+    if (step == 0) {
+        PhaseScope ps(ctx, "ntt");
+        for (int i = 0; i < 3; ++i) ZK_TRY(ntt_shard_stage(ctx, d, v[i], wlog, rank, true, true, none, none, 0));
+    } else if (step == 1) {
+        PhaseScope ps(ctx, "ntt");
+        for (int i = 0; i < 3; ++i) {
+            ZK_TRY(ntt_shard_stage(ctx, d, v[i], wlog, rank, true, true, none, none, 1));
+            ZK_TRY(ntt_shard_stage(ctx, d, v[i], wlog, rank, false, false, pre, none, 0));
+        }
+    } else if (step == 2) {
+        {
+            PhaseScope ps(ctx, "ntt");
+            for (int i = 0; i < 3; ++i) ZK_TRY(ntt_shard_stage(ctx, d, v[i], wlog, rank, false, false, pre, none, 1));
+        }
+        {
+            PhaseScope ps(ctx, "pointwise");
+            hipLaunchKernelGGL(k_h_pointwise, dim3((unsigned)((NL + 255) / 256)), dim3(256), 0, ctx->stream, a, b, c, d->den, NL);
+            ZK_KERNEL_CHECK(ctx);
+        }
+        PhaseScope ps(ctx, "ntt");
+        ZK_TRY(ntt_shard_stage(ctx, d, a, wlog, rank, true, true, none, post, 0));
+    } else if (step == 3) {
+        PhaseScope ps(ctx, "ntt");
+        ZK_TRY(ntt_shard_stage(ctx, d, a, wlog, rank, true, true, none, post, 1));
+    } else {
+        ctx->err = "computeH shard: step must be 0..3"; return ZKPOR_E_ARG;
+    }
+    return ZKPOR_OK;
+}
+
+int32_t shard_transpose(zkpor_ctx* ctx, Fr* out, const Fr* in, int n_local, int wlog, bool interleave) {
+    if (n_local < wlog) { ctx->err = "shard transpose: array smaller than the rank count"; return ZKPOR_E_ARG; }
+    size_t total = (size_t)1 << n_local;
+    hipLaunchKernelGGL(k_shard_transpose, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, in, out, (u32)(n_local - wlog), (u32)wlog, interleave ? 1 : 0);
+    ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
 
@@ -636,6 +762,16 @@ int32_t zkpor_fft(zkpor_ctx* ctx, uint64_t* a, int log2n, int inverse, int decim
 int32_t zkpor_fft_dev(zkpor_ctx* ctx, void* d_a, int log2n, int inverse, int decimation, int on_coset) {
     if (!ctx || !d_a || log2n < 1 || log2n > 28) return ZKPOR_E_ARG;
     return ntt_dev(ctx, (Fr*)d_a, log2n, inverse != 0, decimation == 1, on_coset != 0);
+}
+
+int32_t zkpor_compute_h_shard_dev(zkpor_ctx* ctx, int log2_domain, int world_log2, int rank, void* d_a, void* d_b, void* d_c, int step) {
+    if (!ctx || !d_a || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
+    if (step < 3 && (!d_b || !d_c)) return ZKPOR_E_ARG;
+    return compute_h_shard_step(ctx, log2_domain, world_log2, rank, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, step);
+}
+int32_t zkpor_shard_transpose_dev(zkpor_ctx* ctx, void* d_out, const void* d_in, int log2_local, int world_log2, int interleave) {
+    if (!ctx || !d_out || !d_in || d_out == d_in || world_log2 < 1 || log2_local < 2 * world_log2) return ZKPOR_E_ARG;
+    return shard_transpose(ctx, (Fr*)d_out, (const Fr*)d_in, log2_local, world_log2, interleave != 0);
 }
 
 int32_t zkpor_compute_h_dev(zkpor_ctx* ctx, int log2_domain, void* d_a, void* d_b, void* d_c) {

@@ -11,6 +11,9 @@ Per proof:
   4. the 576-byte partial sums are all-gathered                              RCCL all-gather, latency-bound (4.6 KB at 8 ranks)
   5. every rank adds the partials on the host (zkpor_g1/g2_jac_sum: RCCL has no reduction over curve points) and assembles the
      proof (zkpor_prove_assemble) — all ranks end with the same 256 bytes.
+With a power-of-two number of ranks computeH shards as well (SplitProver.prove_sharded_h / compute_h_sharded): every field pass of
+the transform is local under one of two distributions of the index bits, so steps 1-2 become seven all-to-alls of 1/world of a
+vector per rank and nobody waits for rank 0.
 gnark has no counterpart: its MultiExp splits over CPU tasks inside one process.
 torch.distributed is plumbing here (backend "nccl" = RCCL on the GPUs, "gloo" in the CPU test of the exchange logic)."""
 import numpy as np
@@ -84,6 +87,37 @@ def exchange_and_assemble(dist, rank, world, h_full, h_mine, sums_fn, consts, r,
     return zkpor.prove_assemble(consts, add_partial_sums(parts), r, s)
 
 
+def compute_h_sharded(dist, world, step_fn, transpose_fn, a, b, c, tmp, device_sync=None):
+    """computeH over all ranks (zkpor_compute_h_shard_dev, csrc/ntt.hip): a, b, c are this rank's D_low slices (elements at
+    positions p = rank mod world) as 1-D uint8 tensors, tmp a scratch tensor of the same size; on return `a` holds this rank's
+    contiguous block of h.  step_fn(k) runs step k on (a, b, c); transpose_fn(out, inp, interleave) is zkpor_shard_transpose_dev.
+    Seven all-to-alls of 1/world of a vector per rank — all seven xGMI links of a GPU busy at once — replace the NTT on one GPU."""
+    sync = device_sync if device_sync is not None else (lambda: None)
+
+    def to_high(x):                      # D_low -> D_high: chunk d of the local array goes to rank d, the receiver interleaves
+        sync()
+        dist.all_to_all_single(tmp, x)
+        sync()
+        transpose_fn(x, tmp, True)
+
+    def to_low(x):                       # D_high -> D_low: de-interleave, chunk d goes to rank d
+        transpose_fn(tmp, x, False)
+        sync()
+        dist.all_to_all_single(x, tmp)
+        sync()
+
+    step_fn(0)
+    for x in (a, b, c):
+        to_high(x)
+    step_fn(1)
+    for x in (a, b, c):
+        to_low(x)
+    step_fn(2)
+    to_high(a)
+    step_fn(3)
+    sync()
+
+
 class SplitProver:
     """rank-local half of the split: owns the shard of the key on this GPU.  `pk` must be fully loaded (every rank loads or
     synthesises the same key); it is cut down to this rank's ranges here."""
@@ -97,6 +131,26 @@ class SplitProver:
         self.w_lo, self.w_hi = wire_range(self.n_wires, rank, world)
         self.z_lo, self.z_hi = z_range(self.D, rank, world)
         pk.keep_range(self.w_lo, self.w_hi, self.z_lo, self.z_hi)
+
+    def prove_sharded_h(self, d_w_full, a, b, c, tmp, r, s):
+        """everything sharded: a, b, c = this rank's D_low slices of the constraint evaluations (torch uint8 on the device,
+        32 * D / world bytes each), overwritten; no scatter — computeH ends with every rank holding its block of h"""
+        import torch
+        wlog = self.world.bit_length() - 1
+        if (1 << wlog) != self.world or wlog < 1:
+            raise ValueError("the sharded computeH needs a power-of-two number of ranks >= 2")
+        log2 = self.D.bit_length() - 1
+        nl = log2 - wlog
+        compute_h_sharded(self.dist, self.world,
+                          lambda k: self.ctx.compute_h_shard_dev(log2, wlog, self.rank, a.data_ptr(), b.data_ptr(), c.data_ptr(), k),
+                          lambda out, inp, il: self.ctx.shard_transpose_dev(out.data_ptr(), inp.data_ptr(), nl, wlog, il),
+                          a, b, c, tmp, device_sync=torch.cuda.synchronize)
+        mine = self.ctx.prove_sums_dev(self.pk, d_w_full + 32 * self.w_lo, a.data_ptr())
+        t = torch.from_numpy(np.ascontiguousarray(mine).copy()).to(a.device)
+        allp = torch.empty(self.world * SUM_BYTES, dtype=torch.uint8, device=a.device)
+        self.dist.all_gather_into_tensor(allp, t)
+        parts = allp.cpu().numpy().reshape(self.world, SUM_BYTES)
+        return zkpor.prove_assemble(self.consts, add_partial_sums(parts), r, s)
 
     def h_block_bytes(self):
         return 32 * z_block(self.D, self.world)

@@ -150,6 +150,15 @@ class Context:
     def compute_h_dev(self, log2_domain, d_a, d_b, d_c):
         self._ck(self.lib.zkpor_compute_h_dev(self.h, ctypes.c_int(log2_domain), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c)))
 
+    def compute_h_shard_dev(self, log2_domain, world_log2, rank, d_a, d_b, d_c, step):
+        vp = lambda x: ctypes.c_void_p(x) if x else None
+        self._ck(self.lib.zkpor_compute_h_shard_dev(self.h, ctypes.c_int(log2_domain), ctypes.c_int(world_log2), ctypes.c_int(rank),
+                                                     vp(d_a), vp(d_b), vp(d_c), ctypes.c_int(step)))
+
+    def shard_transpose_dev(self, d_out, d_in, log2_local, world_log2, interleave):
+        self._ck(self.lib.zkpor_shard_transpose_dev(self.h, ctypes.c_void_p(d_out), ctypes.c_void_p(d_in), ctypes.c_int(log2_local),
+                                                     ctypes.c_int(world_log2), ctypes.c_int(int(interleave))))
+
     # ---- Groth16 ----
     def prove_tail(self, pk, w, a, b, c, r, s):
         w = _u64(w); a = _u64(a); b = _u64(b); c = _u64(c); r = _u64(r); s = _u64(s)
