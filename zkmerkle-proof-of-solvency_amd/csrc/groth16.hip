@@ -526,6 +526,7 @@ int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t
         *arr = fresh;
         return ZKPOR_OK;
     };
+    pk->ready = false;  // a failure half-way leaves arrays of different lengths: the key must be reloaded
     ZK_TRY(cut(&pk->A, wire_lo, wire_hi));
     ZK_TRY(cut(&pk->B1, wire_lo, wire_hi));
     ZK_TRY(cut(&pk->K, wire_lo, wire_hi));
@@ -534,6 +535,7 @@ int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t
     pk->n_wires = wire_hi - wire_lo;
     pk->nZ = z_hi - z_lo;
     pk->shard = true;
+    pk->ready = true;
     return ZKPOR_OK;
 }
 
