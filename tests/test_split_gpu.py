@@ -205,6 +205,13 @@ for it in range(3):                       # back to back: computeH is still in f
         ctx.compute_h_dev(log2, a.data_ptr(), b.data_ptr(), c.data_ptr())
     proof = sp.prove(w.data_ptr(), a if rank == 0 else None, h_mine, r, s)
     ok = ok and bool(np.array_equal(proof, expect))
+if world >= 2 and (world & (world - 1)) == 0:      # computeH sharded too: every rank starts from its D_low slices of a, b, c
+    sl = lambda t: t.view(n, 32)[rank::world].contiguous().view(-1)
+    for it in range(2):
+        la, lb, lc = sl(a2), sl(b2), sl(c2)
+        tmp = torch.empty_like(la)
+        proof = sp.prove_sharded_h(w.data_ptr(), la, lb, lc, tmp, r, s)
+        ok = ok and bool(np.array_equal(proof, expect))
 print(json.dumps({"rank": rank, "ok": ok}), flush=True)
 pk.close(); ctx.close(); dist.destroy_process_group()
 '''
@@ -279,3 +286,23 @@ def test_compute_h_sharded_equals_unsharded(zk, log2, wlog):
     finally:
         for b in list(full.values()) + tmp + [x for v in loc.values() for x in v]:
             b.free()
+
+
+def test_split_nccl_all_visible_gpus(tmp_path):
+    """the same worker with one rank per visible GPU (2, 4 or 8): scatter / all-to-all / all-gather over RCCL between real devices,
+    rank-0 computeH and sharded computeH; skipped on a one-GPU box"""
+    import torch
+    world = torch.cuda.device_count()
+    world = 8 if world >= 8 else 4 if world >= 4 else 2 if world >= 2 else 1
+    if world < 2:
+        pytest.skip("needs at least two GPUs")
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    for p in procs:
+        o, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        lines = [l for l in o.splitlines() if l.startswith("{")]
+        assert lines and json.loads(lines[-1])["ok"]
