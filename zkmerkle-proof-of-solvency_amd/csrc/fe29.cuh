@@ -58,6 +58,9 @@ struct Fe29T {
     static constexpr u32 M29 = 0x1fffffffu;
     typedef PP P;
     typedef Fe29T Fp29;  // the member functions below were written for the base field; the name is kept local
+    // differences of two (near-)tight values may feed mul / sqr / mul2 as they are: |limb| < 2^29 + 4 keeps every column of
+    // 9 (18) operand products + 9 reduction products below 27 * 2^58 < 2^63, and the zero test reads only l[0] mod 2^29
+    static constexpr bool kLazyDiff = true;
     typedef F32 Fp;
     typedef int32_t i32;
     typedef int64_t i64;
@@ -378,8 +381,8 @@ ZK_HD void xyzz29_madd(XYZZ29T<F>& acc, const F& x2, const F& y2, Dbl dbl) {
     }
     F U2 = F::mul(acc.zz, x2);
     F S2 = F::mul(acc.zzz, y2);
-    F Pd = F::sub_n(U2, acc.x);
-    F Rd = F::sub_n(S2, acc.y);
+    F Pd = F::kLazyDiff ? F::sub_l(U2, acc.x) : F::sub_n(U2, acc.x);
+    F Rd = F::kLazyDiff ? F::sub_l(S2, acc.y) : F::sub_n(S2, acc.y);
     if (Pd.zero_mod_p()) {
         if (Rd.zero_mod_p()) acc = dbl();
         else acc = XYZZ29T<F>::inf();
@@ -389,7 +392,7 @@ ZK_HD void xyzz29_madd(XYZZ29T<F>& acc, const F& x2, const F& y2, Dbl dbl) {
     F PPP = F::mul(Pd, PP);
     F Q = F::mul(acc.x, PP);
     F X3 = F::normed(F::sub_l(F::sub_l(F::sub_l(F::sqr(Rd), PPP), Q), Q));
-    F D = F::sub_n(Q, X3);
+    F D = F::kLazyDiff ? F::sub_l(Q, X3) : F::sub_n(Q, X3);
     acc.y = F::y3(Rd, D, acc.y, PPP);
     acc.x = X3;
     acc.zz = F::mul(acc.zz, PP);

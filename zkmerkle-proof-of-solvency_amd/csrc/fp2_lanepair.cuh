@@ -116,6 +116,7 @@ struct Fp2L {
 // ---- the same lane-pair layout on the 29-bit signed lazy form (fe29.cuh): interface of the generic xyzz29_madd ----
 struct Fp2L29 {
     Fp29 c;  // this lane's component
+    static constexpr bool kLazyDiff = false;  // the mixed addition keeps its normalising differences on this field
 
     ZK_HD static bool odd() { return Fp2L::odd(); }
     ZK_HD static Fp29 partner(const Fp29& x) {
