@@ -91,3 +91,33 @@ def test_verifying_key_is_524_bytes_for_the_reference_shape():
     g1 = O.g1_from_scalars(O.fr_random(3, 6)); g2 = O.g2_from_scalars(O.fr_random(4, 5))
     vk = GK.vk_bytes(g1[0], g1[1], g2[0], g2[1], g1[2], g2[2], g1[3:6], [[]], g2[3], g2[4])
     assert len(vk) == 524
+
+
+def test_layout_walk_survives_corrupted_streams(synth):
+    """random truncations, byte flips and spliced length fields: the walk either accepts a stream whose counts are all
+    consistent or rejects it with a message — it never reads outside the buffer (the process would not survive that)"""
+    rng = np.random.default_rng(11)
+    data, _, _ = GK.pk_bytes_from_synth(synth, [(O.g1_from_scalars(O.fr_random(1, 3)), O.g1_from_scalars(O.fr_random(2, 3)))])
+    base = zkpor.pk_gnark_layout(data)
+    accepted = rejected = 0
+    for trial in range(1500):
+        m = bytearray(data)
+        kind = trial % 4
+        if kind == 0:
+            m = m[:int(rng.integers(0, len(m)))]
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 2:                                   # overwrite one of the length / count fields with a huge value
+            off = [8 * 0, base["off_a"] - 4, base["off_b1"] - 4, base["off_z"] - 4, base["off_k"] - 4, base["off_b2"] - 4,
+                   base["off_inf_a"] - 24, base["off_inf_a"] - 16, base["off_inf_a"] - 8][int(rng.integers(0, 9))]
+            m[off:off + 4] = int(rng.integers(0, 1 << 32)).to_bytes(4, "big")
+        else:
+            m += bytes(int(rng.integers(1, 64)))
+        try:
+            L = zkpor.pk_gnark_layout(bytes(m))
+            accepted += 1
+            assert L["bytes_total"] == len(m) and L["n_a"] + L["n_inf_a"] == L["n_wires"]
+        except zkpor.ZkporError:
+            rejected += 1
+    assert rejected > 1000 and accepted + rejected == 1500
