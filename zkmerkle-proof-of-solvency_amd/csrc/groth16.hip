@@ -5,6 +5,7 @@
 #include "common.cuh"
 #include "msm.cuh"
 #include "ntt.cuh"
+#include <functional>
 #include <new>
 #include <type_traits>
 
@@ -376,7 +377,7 @@ struct ProveSums { G1XYZZ A, B1, K, Z; G2XYZZ B2; };  // the five multi-exponent
 // already holds the h scalars matching pk->Z), then A.w, B1.w, B2.w, K.w over one sorted digit stream of w and Z.h.
 // Works on a whole key and on a shard (pk->n_wires / pk->nZ are then the shard's lengths and d_w / d_a its scalar ranges).
 int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c, ProveSums* out, bool do_w = true,
-                   bool do_h = true) {
+                   bool do_h = true, const std::function<void()>* while_gpu_runs = nullptr) {
     const int n = pk->log2_domain;
     const size_t nZ = do_h ? pk->nZ : 0;
     // Two HIP streams: the ALU-bound work (NTTs, bucket accumulations) on the context's stream, the HBM-bound digit
@@ -436,6 +437,7 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_hs, 0));
         ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsh, pk->Z, pin + 10 * MSM_SLOT_BYTES, pin + 11 * MSM_SLOT_BYTES, &pZ));
     }
+    if (while_gpu_runs) (*while_gpu_runs)();  // host work that needs no device result: everything is queued, nothing is waited for yet
     ZK_HIP(ctx, hipStreamSynchronize(main_s));
     HostPhase hp(ctx, "host_assembly");
     if (do_w) {
@@ -451,30 +453,39 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     return ZKPOR_OK;
 }
 
-// blinding and assembly on the host (a few hundred group operations): Ar = alpha + A.w + r delta,
-// Bs = beta + B.w + s delta (G1 and G2), Krs = K.w + Z.h + s Ar + r Bs1 - rs delta
-void assemble(const G1Affine& alpha, const G1Affine& beta, const G1Affine& delta, const G2Affine& beta2, const G2Affine& delta2,
-              const ProveSums& m, const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+// blinding and assembly on the host: Ar = alpha + A.w + r delta, Bs = beta + B.w + s delta (G1 and G2),
+// Krs = K.w + Z.h + s Ar + r Bs1 - rs delta.  Four of the six scalar multiplications involve only the key and (r, s): they are
+// done by blind_prepare() while the GPU is still busy with the sums (the host thread would otherwise just wait for the stream).
+struct Blind { Fr rc, sc; G1XYZZ dr, ds, dkrs; G2XYZZ d2s; };
+Blind blind_prepare(const G1Affine& delta, const G2Affine& delta2, const uint64_t r[4], const uint64_t s[4]) {
+    Blind b;
     Fr rm, sm;
     memcpy(&rm, r, 32); memcpy(&sm, s, 32);
-    Fr rc = Fr::from_mont(rm), sc = Fr::from_mont(sm);
-    Fr krm = Fr::neg(Fr::mul(rm, sm));
-    Fr krc = Fr::from_mont(krm);
+    b.rc = Fr::from_mont(rm); b.sc = Fr::from_mont(sm);
+    Fr krc = Fr::from_mont(Fr::neg(Fr::mul(rm, sm)));
     G1XYZZ d1 = g1x(delta);
+    b.dr = xyzz_mul_limbs<Fp>(d1, b.rc.v);
+    b.ds = xyzz_mul_limbs<Fp>(d1, b.sc.v);
+    b.dkrs = xyzz_mul_limbs<Fp>(d1, krc.v);
+    b.d2s = xyzz_mul_limbs<Fp2>(xyzz_from_affine<Fp2>(delta2), b.sc.v);
+    return b;
+}
+void assemble(const G1Affine& alpha, const G1Affine& beta, const G2Affine& beta2, const ProveSums& m, const Blind& b,
+              uint8_t proof_out[256]) {
     G1XYZZ ar = m.A;
     xyzz_add<Fp>(ar, g1x(alpha));
-    xyzz_add<Fp>(ar, xyzz_mul_limbs<Fp>(d1, rc.v));
+    xyzz_add<Fp>(ar, b.dr);
     G1XYZZ bs1 = m.B1;
     xyzz_add<Fp>(bs1, g1x(beta));
-    xyzz_add<Fp>(bs1, xyzz_mul_limbs<Fp>(d1, sc.v));
+    xyzz_add<Fp>(bs1, b.ds);
     G2XYZZ bs2 = m.B2;
     xyzz_add<Fp2>(bs2, xyzz_from_affine<Fp2>(beta2));
-    xyzz_add<Fp2>(bs2, xyzz_mul_limbs<Fp2>(xyzz_from_affine<Fp2>(delta2), sc.v));
+    xyzz_add<Fp2>(bs2, b.d2s);
     G1XYZZ krs = m.K;
     xyzz_add<Fp>(krs, m.Z);
-    xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(d1, krc.v));
-    xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(ar, sc.v));
-    xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(bs1, rc.v));
+    xyzz_add<Fp>(krs, b.dkrs);
+    xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(ar, b.sc.v));
+    xyzz_add<Fp>(krs, xyzz_mul_limbs<Fp>(bs1, b.rc.v));
     G1Affine ara = xyzz_to_affine<Fp>(ar), krsa = xyzz_to_affine<Fp>(krs);
     G2Affine bsa = xyzz_to_affine<Fp2>(bs2);
     memcpy(proof_out, &ara, 64); memcpy(proof_out + 64, &bsa, 128); memcpy(proof_out + 192, &krsa, 64);
@@ -503,9 +514,11 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
     if (pk->shard) { ctx->err = "prove: the key is a shard (zkpor_pk_keep_range): use zkpor_prove_sums_dev + zkpor_prove_assemble"; return ZKPOR_E_STATE; }
     ProveSums m;
-    ZK_TRY(prove_sums(ctx, pk, d_w, d_a, d_b, d_c, &m));
+    Blind bl;
+    const std::function<void()> prep = [&] { bl = blind_prepare(pk->delta, pk->delta2, r, s); };
+    ZK_TRY(prove_sums(ctx, pk, d_w, d_a, d_b, d_c, &m, true, true, &prep));
     HostPhase hp(ctx, "host_assembly");
-    assemble(pk->alpha, pk->beta, pk->delta, pk->beta2, pk->delta2, m, r, s, proof_out);
+    assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
 }
 
@@ -557,7 +570,7 @@ int32_t zkpor_prove_assemble(const void* alpha, const void* beta, const void* de
     ProveSums m;
     m.A = jac_in<Fp>(sums); m.B1 = jac_in<Fp>(sums + 96); m.B2 = jac_in<Fp2>(sums + 192);
     m.K = jac_in<Fp>(sums + 384); m.Z = jac_in<Fp>(sums + 480);
-    assemble(a1, b1, d1, b2, d2, m, r, s, proof_out);
+    assemble(a1, b1, b2, m, blind_prepare(d1, d2, r, s), proof_out);
     return ZKPOR_OK;
 }
 
