@@ -41,3 +41,40 @@ def test_proof_write_raw_is_host_only_and_sized():
     assert raw.size == 324
     raw = zkpor.proof_write_raw(proof, np.zeros((1, 8), np.uint64), np.zeros(8, np.uint64))
     assert raw.size == 388 and raw[259] == 1   # the reference's 388-byte proof (one commitment), SURVEY.md a6.7
+
+
+def test_prove_assemble_matches_the_groth16_formulas_on_the_oracle():
+    """zkpor_prove_assemble (host only): Ar = alpha + A.w + r delta, Bs = beta2 + B2.w + s delta2,
+    Krs = K.w + Z.h + s Ar + r Bs1 - rs delta, from Jacobian sums in any projective form (one of them the point at infinity),
+    against the same linear combinations evaluated by the oracle's multi-exponentiation"""
+    import numpy as np
+    import oracle as O
+    import zkpor
+    one = O.fp_from_ints([1])[0]
+    g1 = O.g1_from_scalars(O.fr_random(51, 7))          # alpha, beta, delta, A.w, B1.w, K.w, Z.h
+    g2 = O.g2_from_scalars(O.fr_random(52, 3))          # beta2, delta2, B2.w
+    ones = O.fr_from_ints([1, 1])
+    for trial, zero_slot in enumerate((None, "A", "Z", "B2")):
+        r = O.fr_random(60 + trial, 1)[0]; s = O.fr_random(70 + trial, 1)[0]
+        A, B1, K, Z = (g1[i].copy() for i in (3, 4, 5, 6)); B2 = g2[2].copy()
+        if zero_slot == "A": A[:] = 0
+        if zero_slot == "Z": Z[:] = 0
+        if zero_slot == "B2": B2[:] = 0
+        # Jacobian inputs in a NON-trivial projective form: (X l^2, Y l^3, l)
+        def jac1(aff, seed):
+            if not aff.any():
+                return np.zeros(12, np.uint64)
+            l = O.fp_from_ints([seed])[0]; l2 = O.fp_mul(l[None], l[None])[0]; l3 = O.fp_mul(l2[None], l[None])[0]
+            return np.concatenate([O.fp_mul(aff[None, :4], l2[None])[0], O.fp_mul(aff[None, 4:], l3[None])[0], l])
+        def jac2(aff):
+            return np.concatenate([aff, one, np.zeros(4, np.uint64)]) if aff.any() else np.zeros(24, np.uint64)
+        sums = np.concatenate([jac1(A, 3), jac1(B1, 5), jac2(B2), jac1(K, 7), jac1(Z, 11)]).view(np.uint8)
+        proof = zkpor.prove_assemble((g1[0], g1[1], g1[2], g2[0], g2[1]), sums, r, s).view(np.uint64)
+        rs_neg = O.fr_sub(O.fr_from_ints([0]), O.fr_mul(r[None], s[None]))[0]
+        lin1 = lambda pts, sc: O.g1_msm(np.stack(pts), np.stack(sc))
+        one_fr = O.fr_from_ints([1])[0]
+        ar = lin1([g1[0], A, g1[2]], [one_fr, one_fr, r])
+        bs1 = lin1([g1[1], B1, g1[2]], [one_fr, one_fr, s])
+        krs = lin1([K, Z, ar, bs1, g1[2]], [one_fr, one_fr, s, r, rs_neg])
+        bs2 = O.g2_msm(np.stack([g2[0], B2, g2[1]]), np.stack([one_fr, one_fr, s]))
+        assert np.array_equal(proof[0:8], ar) and np.array_equal(proof[8:24], bs2) and np.array_equal(proof[24:32], krs)
