@@ -78,3 +78,31 @@ def test_prove_assemble_matches_the_groth16_formulas_on_the_oracle():
         krs = lin1([K, Z, ar, bs1, g1[2]], [one_fr, one_fr, s, r, rs_neg])
         bs2 = O.g2_msm(np.stack([g2[0], B2, g2[1]]), np.stack([one_fr, one_fr, s]))
         assert np.array_equal(proof[0:8], ar) and np.array_equal(proof[8:24], bs2) and np.array_equal(proof[24:32], krs)
+
+
+def test_jac_sum_edge_cases_host_only():
+    """zkpor_g1/g2_jac_sum (the host-side reduction of the partial sums of a split proof): equal parts (doubling), opposite parts
+    (infinity), infinity parts, a single part, no part"""
+    import numpy as np
+    import oracle as O
+    import zkpor
+    one = O.fp_from_ints([1])[0]
+    P = O.g1_from_scalars(O.fr_random(81, 3))
+    j1 = lambda a: np.concatenate([a, one]) if a.any() else np.zeros(12, np.uint64)
+    neg = P[0].copy(); neg[4:] = O.fp_sub(O.fp_from_ints([0]), P[0][None, 4:])[0]
+    aff = lambda parts: O.g1_jac_to_affine(zkpor.g1_jac_sum(np.stack(parts)))[0]
+    two = O.fr_from_ints([2]); ones3 = O.fr_from_ints([1, 1, 1])
+    assert np.array_equal(aff([j1(P[0]), j1(P[0])]), O.g1_msm(P[:1], two))                       # P + P
+    assert not aff([j1(P[0]), j1(neg)]).any()                                                     # P - P
+    assert np.array_equal(aff([j1(P[0]), j1(neg), j1(P[1])]), P[1])                               # through infinity and on
+    assert np.array_equal(aff([np.zeros(12, np.uint64), j1(P[2]), np.zeros(12, np.uint64)]), P[2])
+    assert np.array_equal(aff([j1(P[0]), j1(P[1]), j1(P[2])]), O.g1_msm(P, ones3))
+    assert np.array_equal(aff([j1(P[1])]), P[1])
+    assert not O.g1_jac_to_affine(zkpor.g1_jac_sum(np.zeros((0, 12), np.uint64)))[0].any()
+    Q = O.g2_from_scalars(O.fr_random(82, 2))
+    j2 = lambda a: np.concatenate([a, one, np.zeros(4, np.uint64)]) if a.any() else np.zeros(24, np.uint64)
+    negq = Q[0].copy(); negq[8:] = np.concatenate([O.fp_sub(O.fp_from_ints([0]), Q[0][None, 8:12])[0], O.fp_sub(O.fp_from_ints([0]), Q[0][None, 12:16])[0]])
+    aff2 = lambda parts: O.g2_jac_to_affine(zkpor.g2_jac_sum(np.stack(parts)))[0]
+    assert np.array_equal(aff2([j2(Q[0]), j2(Q[0])]), O.g2_msm(Q[:1], two))
+    assert not aff2([j2(Q[0]), j2(negq)]).any()
+    assert np.array_equal(aff2([j2(Q[0]), j2(Q[1])]), O.g2_msm(Q, O.fr_from_ints([1, 1])))
