@@ -10,6 +10,9 @@ Output: ONE JSON line (rank 0) with value = proofs/s over all ranks, plus
   roofline     — the dominant kernel (G1 bucket accumulation k_acc_level1_fp29): algorithmic bytes per launch
                  (n x (64 B point + 32 B scalar)) / its average launch time, vs the 8 TB/s HBM peak
   cpu_baseline — the CPU oracle (a port of the reference's algorithm) timed on a bounded sample, scaled to proofs/s
+  checked      — every timed proof verified in the exponent from the synthetic key's trapdoor (untimed)
+  value_uniform — the same step with uniform witness scalars (the worst case), timed in a second region
+  boundary     — the host-pointer ABI a cgo caller binds, from pageable host memory (untimed leg, N = 1)
 """
 import argparse
 import ctypes
@@ -23,6 +26,16 @@ sys.path.insert(0, os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# BASELINE.json configs[1] / configs[2]: both production tiers target D = 2^26 with the same array sizes;
+# they differ in the witness scalar mixture (zkpor_dev_fill_fr kind) — estimates from a static count of Define (Appendix B)
+CONFIGS = {
+    "zkpor50_1380": {"fill_kind": 1, "users": 1380, "assets": 50,
+                     "mixture": "25% {0,1}, 20% <2^16, 5% <2^64, 50% uniform"},
+    "zkpor500_200": {"fill_kind": 2, "users": 200, "assets": 500,
+                     "mixture": "35% {0,1}, 30% <2^16, 5% <2^64, 30% uniform"},
+}
+SYNTH_SEED = 0x5A4B504F52
 
 
 def pmc_traffic_bytes_per_launch(kernel="k_acc_level1_fp29"):
@@ -120,74 +133,77 @@ def timed_region(dist, sync, run):
     return dt
 
 
-def pcie_inclusive(ctx, lib, pk, D, n_wires, dev_inputs, dev_work, cv, n_commit, r, s, n_proofs=2):
-    """The rate when the boundary hands over HOST buffers (what a cgo caller holding gnark's []fr.Element does): w, a, b, c
-    (4 x 2.1 GB at 2^26) are copied from pinned host memory before every proof, un-overlapped — the worst case; with the
-    R1CS resident (zkpor_r1cs_*) only w crosses.  Reported beside `value`, never as `value`.  Rank 0, N = 1 only."""
+def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vectors, td, blinding, resident_ms, n_proofs=3):
+    """The call a cgo caller actually makes (INTEGRATION.md `ProveTail` / `Commit`): the HOST-pointer entry points
+    zkpor_commit + zkpor_prove_tail on PAGEABLE host memory (numpy heap arrays standing in for gnark's []fr.Element), 8.6 GB + 0.5 GB
+    per proof across PCIe inside the call.  Two shapes: one caller (a proof's latency from host memory: w crosses first, a/b/c cross
+    under the A, B1, K accumulations) and two callers on two contexts of the same GPU (what host/prover_host.hpp runs per GPU: one
+    proof's copies hide under the other's kernels) — the steady-state rate a deployment sees, to be compared with `value`.
+    Every proof is verified against the trapdoor.  Reported beside `value`, never as `value`.  Rank 0, N = 1 only."""
+    import threading
     import numpy as np
-    import torch
     import zkpor as _z
-    w, a0, b0, c0 = dev_inputs
-    a, b, c = dev_work
-    host = [torch.empty(t.numel(), dtype=torch.uint8).pin_memory() for t in (w, a0, b0, c0)]
-    for h, t in zip(host, (w, a0, b0, c0)):
-        h.copy_(t)
-    dw = torch.empty_like(w)
-    torch.cuda.synchronize()
-    ck = ctx._ck
-    t_h2d = 0.0
-    t0 = time.perf_counter()
-    for _ in range(n_proofs):
-        t1 = time.perf_counter()
-        for dst, h in ((dw, host[0]), (a, host[1]), (b, host[2]), (c, host[3])):
-            ck(lib.zkpor_dev_upload_async(ctx.h, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(h.data_ptr()), ctypes.c_size_t(h.numel())))
-        ctx.sync()
-        t_h2d += time.perf_counter() - t1
-        com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
-        ck(lib.zkpor_commit_dev(ctx.h, pk.h, ctypes.c_void_p(cv.data_ptr()), ctypes.c_size_t(n_commit), _z._p(com), _z._p(pok)))
-        ctx.prove_tail_dev(pk, dw.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), r, s)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    gb = sum(h.numel() for h in host) / 1e9
-    out = {"value": n_proofs / dt, "unit": "proofs/s", "ms_per_proof": dt / n_proofs * 1e3, "h2d_ms_per_proof": t_h2d / n_proofs * 1e3,
-           "h2d_GBps": gb * n_proofs / t_h2d, "bytes_per_proof": int(gb * 1e9),
-           "note": "w,a,b,c copied from pinned host memory before each proof, not overlapped with the previous proof"}
-    # the same hand-over double-buffered: a second context (its own HIP stream) carries proof i+1's vectors across PCIe while
-    # proof i runs; the proving call blocks the host, so one zkpor_sync on the copy context before the swap orders the two
-    up = None
-    sets = None
+    lib = ctx.lib
+    w, a0, b0, c0, cv = dev_vectors
+
+    def host(t, n):  # plain numpy heap memory: pageable, not registered
+        out = np.empty((n, 4), dtype=np.uint64)
+        ctx._ck(lib.zkpor_dev_download(ctx.h, _z._p(out), ctypes.c_void_p(t.data_ptr()), ctypes.c_size_t(out.nbytes)))
+        return out
+
+    hw, ha, hb, hc, hcv = host(w, n_wires), host(a0, D), host(b0, D), host(c0, D), host(cv, n_commit)
+    bytes_per_proof = hw.nbytes + ha.nbytes + hb.nbytes + hc.nbytes + hcv.nbytes
+    results = []
+
+    def prove(wctx, i):
+        r, s = blinding(i)
+        com, pok = wctx.commit(pk, hcv)
+        proof = wctx.prove_tail(pk, hw, ha, hb, hc, r, s)
+        results.append((i, proof))
+
+    other = zkpor.Context(device, None)
     try:
-        up = _z.Context(torch.cuda.current_device(), None)
-        sets = [(dw, a, b, c), tuple(torch.empty_like(t) for t in (dw, a, b, c))]
-
-        def upload(k):
-            for dst, h in zip(sets[k], host):
-                up._ck(lib.zkpor_dev_upload_async(up.h, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(h.data_ptr()), ctypes.c_size_t(h.numel())))
-
-        n2 = n_proofs + 1
-        upload(0); up.sync()
-        torch.cuda.synchronize()
+        ctxs = [ctx, other]
+        for k, wctx in enumerate(ctxs):       # warm-up: staging areas, bounce buffers, copy threads, workspaces
+            prove(wctx, 9000 + k)
         t0 = time.perf_counter()
-        for i in range(n2):
-            cur = sets[i & 1]
-            if i + 1 < n2:
-                upload((i + 1) & 1)
-            com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
-            ck(lib.zkpor_commit_dev(ctx.h, pk.h, ctypes.c_void_p(cv.data_ptr()), ctypes.c_size_t(n_commit), _z._p(com), _z._p(pok)))
-            ctx.prove_tail_dev(pk, cur[0].data_ptr(), cur[1].data_ptr(), cur[2].data_ptr(), cur[3].data_ptr(), r, s)
-            up.sync()
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t0
-        out["double_buffered"] = {"value": n2 / dt2, "unit": "proofs/s", "ms_per_proof": dt2 / n2 * 1e3,
-                                  "note": "next proof's w,a,b,c uploaded on a second stream under the current proof's kernels "
-                                          "(steady state; the first upload is outside the timed region)"}
-    except Exception as e:  # informational leg
-        out["double_buffered"] = {"value": None, "note": f"failed: {e}"}
+        for i in range(n_proofs):
+            prove(ctx, 9100 + i)
+        one_ms = (time.perf_counter() - t0) / n_proofs * 1e3
+        n2 = 2 * n_proofs
+        nxt = [0]
+        lock = threading.Lock()
+        errs = []
+
+        def loop(wctx):
+            torch.cuda.set_device(device)
+            try:
+                while True:
+                    with lock:
+                        if nxt[0] >= n2:
+                            return
+                        i = nxt[0]; nxt[0] += 1
+                    prove(wctx, 9200 + i)
+            except Exception as e:
+                errs.append(e)
+
+        th = [threading.Thread(target=loop, args=(c_,)) for c_ in ctxs]
+        t0 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        two_ms = (time.perf_counter() - t0) / n2 * 1e3
+        if errs:
+            raise errs[0]
     finally:
-        if up is not None:
-            up.close()
-        del sets
-    return out
+        other.close()
+    ok = sum(int(td.check(p, *blinding(i))) for i, p in results) if td is not None else None
+    return {"value": 1e3 / two_ms, "unit": "proofs/s", "ms_per_proof": two_ms, "frac_of_resident_value": resident_ms / two_ms,
+            "callers": 2, "one_caller_ms_per_proof": one_ms, "one_caller_value": 1e3 / one_ms,
+            "bytes_per_proof": int(bytes_per_proof), "proofs": len(results), "checked_ok": ok,
+            "note": "zkpor_commit + zkpor_prove_tail (host-pointer ABI) on pageable numpy memory; persistent HBM staging, pinned bounce "
+                    "buffers filled by copy threads, w first then a/b/c under the A/B1/K accumulations; two callers = two contexts on one GPU"}
 
 
 def verifier_acceptance(ctx, n_proofs=4):
@@ -298,7 +314,15 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2", type=int, default=26, help="log2 of the FFT domain / wire count (26 = zkpor50_1380)")
-    ap.add_argument("--scalars", choices=["witness", "uniform"], default="witness")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="zkpor50_1380",
+                    help="BASELINE.json configs[1] (zkpor50_1380, the headline) or configs[2] (zkpor500_200): same D = 2^26 and array "
+                         "sizes, different witness scalar mixture (SURVEY.md §8d C2/C3, Appendix B)")
+    ap.add_argument("--scalars", choices=["witness", "uniform"], default="witness",
+                    help="witness = the mixture of --config; uniform = the worst case (every scalar 254 bits)")
+    ap.add_argument("--uniform-steps", type=int, default=-1,
+                    help="steps of the second, uniform-scalar timed region reported as value_uniform (-1 = max(2, steps/4); 0 = skip)")
+    ap.add_argument("--no-check", action="store_true", help="skip the trapdoor verification of the timed proofs")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the host-pointer (cgo-shaped) boundary leg")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1, help="proofs in flight per GPU (in-process dispatcher workers, one HIP stream + workspace each)")
@@ -314,6 +338,24 @@ def main():
 
     import torch
     import zkpor
+
+    # --gpus N is a promise about the line that gets printed: under torch.distributed.run (WORLD_SIZE set, how the driver launches
+    # N > 1) it must agree with the launcher; started bare with N > 1 this process becomes the launcher of N ranks on this node.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a number for a different GPU count")
+    if env_world is None and args.gpus > 1:
+        visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if visible < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {visible} GPU(s) are visible")
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     # RCCL (and other native libraries) write banners such as "Librccl path : ..." to stdout; the contract is ONE JSON line there.
     # Keep a private handle to the real stdout for that line and point fd 1 at stderr for everything else.
@@ -355,24 +397,33 @@ def main():
     D = 1 << log2
     n_wires = D
     n_commit = D >> 2
+    cfg = CONFIGS[args.config]
+    seed = SYNTH_SEED + rank
     pk = zkpor.ProvingKey(ctx)
-    pk.synth(log2, n_wires, 3, n_commit, seed=0x5A4B504F52 + rank)
+    pk.synth(log2, n_wires, 3, n_commit, seed=seed)
 
     def dev(nbytes):
         return torch.empty(nbytes, dtype=torch.uint8, device="cuda")
 
+    vp = ctypes.c_void_p
     w = dev(32 * n_wires); a0 = dev(32 * D); b0 = dev(32 * D); c0 = dev(32 * D)
     a = dev(32 * D); b = dev(32 * D); c = dev(32 * D); cv = dev(32 * n_commit)
-    kind = 1 if args.scalars == "witness" else 0
+    kind = cfg["fill_kind"] if args.scalars == "witness" else 0
     ck = ctx._ck
-    ck(lib.zkpor_dev_fill_fr(ctx.h, ctypes.c_void_p(w.data_ptr()), ctypes.c_size_t(n_wires), ctypes.c_uint64(2 + rank), ctypes.c_int(kind)))
-    ck(lib.zkpor_dev_fill_fr(ctx.h, ctypes.c_void_p(a0.data_ptr()), ctypes.c_size_t(D), ctypes.c_uint64(11 + rank), ctypes.c_int(0)))
-    ck(lib.zkpor_dev_fill_fr(ctx.h, ctypes.c_void_p(b0.data_ptr()), ctypes.c_size_t(D), ctypes.c_uint64(12 + rank), ctypes.c_int(0)))
-    ck(lib.zkpor_dev_fr_mul(ctx.h, ctypes.c_void_p(c0.data_ptr()), ctypes.c_void_p(a0.data_ptr()), ctypes.c_void_p(b0.data_ptr()), ctypes.c_size_t(D)))
-    ck(lib.zkpor_dev_fill_fr(ctx.h, ctypes.c_void_p(cv.data_ptr()), ctypes.c_size_t(n_commit), ctypes.c_uint64(13 + rank), ctypes.c_int(kind)))
+    ck(lib.zkpor_dev_fill_fr(ctx.h, vp(w.data_ptr()), ctypes.c_size_t(n_wires), ctypes.c_uint64(2 + rank), ctypes.c_int(kind)))
+    ck(lib.zkpor_dev_fill_fr(ctx.h, vp(a0.data_ptr()), ctypes.c_size_t(D), ctypes.c_uint64(11 + rank), ctypes.c_int(0)))
+    ck(lib.zkpor_dev_fill_fr(ctx.h, vp(b0.data_ptr()), ctypes.c_size_t(D), ctypes.c_uint64(12 + rank), ctypes.c_int(0)))
+    ck(lib.zkpor_dev_fr_mul(ctx.h, vp(c0.data_ptr()), vp(a0.data_ptr()), vp(b0.data_ptr()), ctypes.c_size_t(D)))
+    ck(lib.zkpor_dev_fill_fr(ctx.h, vp(cv.data_ptr()), ctypes.c_size_t(n_commit), ctypes.c_uint64(13 + rank), ctypes.c_int(kind)))
     import numpy as np
     import zkpor as _z
-    r = np.array([3, 1, 4, 1], dtype=np.uint64); s = np.array([2, 7, 1, 8], dtype=np.uint64)  # any Fr limbs < r
+
+    def blinding(i):
+        """fresh (r, s) for proof i: any limbs below the modulus are a valid Montgomery residue (top limb < 2^60 => < 2^252 < r).
+        Seeded so that the untimed checker can recompute them — a production caller draws them from a CSPRNG (zkpor.h)."""
+        g = np.random.default_rng(0xB11D + 7919 * i + rank)
+        v = g.integers(0, 1 << 60, size=8, dtype=np.uint64)
+        return v[:4].copy(), v[4:].copy()
 
     # in-process dispatcher: `streams` workers per GPU, each with its own context (HIP stream + workspace) and its own
     # a/b/c working buffers; the key and the input vectors are shared read-only.  Worker 0 reuses `ctx`.
@@ -381,24 +432,26 @@ def main():
     for _ in range(1, max(1, args.streams)):
         workers.append((zkpor.Context(local_rank, None), dev(32 * D), dev(32 * D), dev(32 * D)))
 
-    def one_proof(wk):
+    def one_proof(wk, w_buf, i, sink):
         wctx, wa, wb, wc = wk
         wck = wctx._ck
         for dst, src in ((wa, a0), (wb, b0), (wc, c0)):
-            wck(lib.zkpor_dev_copy(wctx.h, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), ctypes.c_size_t(32 * D)))
+            wck(lib.zkpor_dev_copy(wctx.h, vp(dst.data_ptr()), vp(src.data_ptr()), ctypes.c_size_t(32 * D)))
         com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
-        wck(lib.zkpor_commit_dev(wctx.h, pk.h, ctypes.c_void_p(cv.data_ptr()), ctypes.c_size_t(n_commit), _z._p(com), _z._p(pok)))
-        proof = wctx.prove_tail_dev(pk, w.data_ptr(), wa.data_ptr(), wb.data_ptr(), wc.data_ptr(), r, s)
-        return proof, com, pok
+        wck(lib.zkpor_commit_dev(wctx.h, pk.h, vp(cv.data_ptr()), ctypes.c_size_t(n_commit), _z._p(com), _z._p(pok)))
+        r, s = blinding(i)
+        proof = wctx.prove_tail_dev(pk, w_buf.data_ptr(), wa.data_ptr(), wb.data_ptr(), wc.data_ptr(), r, s)
+        if sink is not None:
+            sink.append((i, proof, com, pok))
 
-    def run_steps(nsteps):
-        """nsteps proofs in total, pulled from a shared counter by the workers"""
+    def run_steps(nsteps, w_buf, sink=None, first=0):
+        """nsteps proofs in total, pulled from a shared counter by the workers; every proof has its own blinding"""
         if len(workers) == 1:
-            for _ in range(nsteps):
-                one_proof(workers[0])
+            for i in range(nsteps):
+                one_proof(workers[0], w_buf, first + i, sink)
             return
         lock = threading.Lock()
-        left = [nsteps]
+        nxt = [0]
         errs = []
 
         def loop(wk):
@@ -406,10 +459,10 @@ def main():
             try:
                 while True:
                     with lock:
-                        if left[0] <= 0:
+                        if nxt[0] >= nsteps:
                             return
-                        left[0] -= 1
-                    one_proof(wk)
+                        i = nxt[0]; nxt[0] += 1
+                    one_proof(wk, w_buf, first + i, sink)
             except Exception as e:  # surface worker failures
                 errs.append(e)
 
@@ -421,11 +474,12 @@ def main():
         if errs:
             raise errs[0]
 
-    run_steps(max(args.warmup, len(workers) if args.warmup else 0))
+    run_steps(max(args.warmup, len(workers) if args.warmup else 0), w)
     torch.cuda.synchronize()
     for wk in workers:
         wk[0].phase_reset()
-    dt = timed_region(dist, torch.cuda.synchronize, lambda: run_steps(args.steps))
+    proofs = []
+    dt = timed_region(dist, torch.cuda.synchronize, lambda: run_steps(args.steps, w, proofs, first=1000))
 
     phases = {}
     for name in ("msm_decompose", "msm_sort", "msm_accumulate", "msm_reduce", "k_acc_level1_g1", "k_acc_level1_g2", "ntt", "pointwise", "host_assembly"):
@@ -434,22 +488,77 @@ def main():
             m_, c_ = wk[0].phase_ms(name)
             ms += m_; calls += c_
         phases[name] = {"ms_per_proof": ms / max(1, args.steps), "calls_per_proof": calls / max(1, args.steps)}
+    k1_ms = sum(wk[0].phase_ms("k_acc_level1_g1")[0] for wk in workers)
+    k1_calls = sum(wk[0].phase_ms("k_acc_level1_g1")[1] for wk in workers)
+
+    # second timed region, same contract: the worst-case scalar distribution (every witness scalar uniform in Fr) — SURVEY.md §8d:
+    # the witness mixture is an estimate, so the uniform rate is always printed beside it
+    uni = None
+    usteps = args.uniform_steps if args.uniform_steps >= 0 else max(2, args.steps // 4)
+    uproofs = []
+    wu = None
+    if args.scalars == "witness" and usteps > 0:
+        wu = dev(32 * n_wires)
+        ck(lib.zkpor_dev_fill_fr(ctx.h, vp(wu.data_ptr()), ctypes.c_size_t(n_wires), ctypes.c_uint64(2 + rank), ctypes.c_int(0)))
+        run_steps(len(workers), wu)
+        torch.cuda.synchronize()
+        dtu = timed_region(dist, torch.cuda.synchronize, lambda: run_steps(usteps, wu, uproofs, first=5000))
+        uni = {"value": world * usteps / dtu, "ms_per_step": dtu / usteps * 1e3, "steps": usteps}
+
+    # ---- every timed proof is verified, untimed: prove, then verify (prover.go:269-276).  The synthetic key is trapdoor-known, so
+    # Ar / Bs / Krs and the two commitment sums are checked in the exponent at the exact size and mixture that was timed
+    # (oracle/trapdoor.py: four dot products over Fr on the host + fixed-base products by the CPU oracle).
+    checked = None
+    td = None
+    if not args.no_check:
+        t_chk = time.perf_counter()
+        import oracle as O
+        import trapdoor as T
+
+        def host(t, n):
+            out = np.empty((n, 4), dtype=np.uint64)
+            ck(lib.zkpor_dev_download(ctx.h, _z._p(out), vp(t.data_ptr()), ctypes.c_size_t(out.nbytes)))
+            return out
+
+        ok = 0
+        h_host = host(workers[0][1], D)[: D - 1]       # prove_tail_dev leaves h in `a`, in the order of the key's Z
+        td = T.SynthKeyTrapdoor(seed, 3, host(w, n_wires), h_host)
+        ec, ek = T.expected_commitment(seed, host(cv, n_commit))
+        for i, proof, com, pok in proofs:
+            r, s = blinding(i)
+            ok += int(td.check(proof, r, s) and np.array_equal(com, ec) and np.array_equal(pok, ek))
+        total = len(proofs)
+        if uproofs:
+            tdu = T.SynthKeyTrapdoor(seed, 3, host(wu, n_wires), h_host)
+            for i, proof, com, pok in uproofs:
+                r, s = blinding(i)
+                ok += int(tdu.check(proof, r, s) and np.array_equal(com, ec) and np.array_equal(pok, ek))
+            total += len(uproofs)
+            del tdu
+        if dist is not None:
+            t = torch.tensor([ok, total], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t)
+            ok, total = int(t[0].item()), int(t[1].item())
+        checked = {"proofs": total, "ok": ok,
+                   "how": "Ar, Bs, Krs of every timed proof (own blinding each) and the two Pedersen sums equal the values predicted in the "
+                          "exponent from the synthetic key's trapdoor (oracle/trapdoor.py), at the timed size and scalar mixture",
+                   "seconds": round(time.perf_counter() - t_chk, 2)}
+    del wu
 
     if rank == 0:
-        k1_ms = sum(wk[0].phase_ms("k_acc_level1_g1")[0] for wk in workers)
-        k1_calls = sum(wk[0].phase_ms("k_acc_level1_g1")[1] for wk in workers)
         # launches of k_acc_level1_fp29 per proof: A, B1, K, Z (n ~ D points each) + 2 commitment MSMs (n/4 points)
         units_bytes = (4 * n_wires + 2 * n_commit) * 96.0 / 6.0  # mean algorithmic bytes per launch
         avg_launch_s = (k1_ms / max(1, k1_calls)) * 1e-3
         achieved = units_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         bproof = algorithmic_bytes_per_proof(log2, n_wires, n_commit)
         tb, tsrc = pmc_traffic_bytes_per_launch()
-        profiled_cfg = log2 == 26 and args.scalars == "witness" and not args.window and not args.chunk
+        profiled_cfg = log2 == 26 and args.scalars == "witness" and args.config == "zkpor50_1380" and not args.window and not args.chunk
         traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and profiled_cfg) else None
         vb_ms, vsrc = pmc_valu_issue_bound_ms()
         valu = ({"issue_bound_ms_per_launch": vb_ms, "frac": vb_ms / (avg_launch_s * 1e3),
                  "source": f"profiles/{vsrc}: SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz) / live avg launch time"}
                 if (vb_ms and avg_launch_s > 0 and profiled_cfg) else None)
+        main_stream = ("k_acc_level1_g1", "k_acc_level1_g2", "msm_accumulate", "msm_reduce", "ntt", "pointwise", "host_assembly")
         out = {
             "metric": "Groth16 proofs/sec at 2^26 constraints (zkpor50_1380), 1/2/4/8 MI355X",
             "value": world * args.steps / dt,
@@ -463,8 +572,16 @@ def main():
             "vs_baseline": None,
             "dtype": "i32x9 (254-bit Fp/Fr on 9 x 29-bit signed lazy Montgomery limbs in registers; u32x8 Montgomery in memory)",
             "data": "synthetic",
-            "config": {"workload": f"zkpor50_1380-shaped prove tail: D=2^{log2}, n_wires=2^{log2}, commit 2^{log2 - 2}, "
-                                   f"scalars={args.scalars}, {len(workers)} proof(s) in flight per GPU"},
+            "config": {"workload": f"{args.config}-shaped Groth16 PROVE TAIL (everything in groth16.Prove after the R1CS solver: computeH, "
+                                   f"A/B1/K/Z + B2 multi-exponentiations, blinding, + the 2 Pedersen commitment sums): D=2^{log2}, "
+                                   f"n_wires=2^{log2}, commit 2^{log2 - 2}, scalars={args.scalars}"
+                                   + (f" ({cfg['mixture']})" if args.scalars == "witness" else "")
+                                   + f", {len(workers)} proof(s) in flight per GPU, w/a/b/c resident in HBM; the solver is NOT included",
+                       "tier": args.config, "users_per_batch": cfg["users"], "assets_per_user": cfg["assets"]},
+            "value_uniform": uni["value"] if uni else None,
+            "uniform": ({**uni, "note": "same step with every witness scalar uniform in Fr (worst case; the witness mixture is an estimate)"}
+                        if uni else None),
+            "checked": checked,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (f"profiles/{tsrc}: {tb / 1e9:.1f} GB HBM bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, "
@@ -475,17 +592,23 @@ def main():
                          "valu_issue": valu,
                          "note": "path is VALU-integer bound (~1e3 int-ops/byte); whole-proof algorithmic bytes "
                                  f"{bproof / 1e9:.1f} GB -> {bproof * (args.steps / dt) / 1e9:.1f} GB/s per GPU"},
-            "phases_ms_per_proof": {k: round(v["ms_per_proof"], 3) for k, v in phases.items()},
+            # additive: regions on the context's main stream.  NOT additive: the digit streams run on the auxiliary stream beside
+            # them, their event pairs measure elapsed time while time-sliced with the main stream (see profiles/ for kernel times)
+            "phases_ms_per_proof": {k: round(phases[k]["ms_per_proof"], 3) for k in main_stream},
+            "overlapped_aux_stream_elapsed_ms_per_proof": {k: round(phases[k]["ms_per_proof"], 3) for k in ("msm_decompose", "msm_sort")},
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
-            try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_log2, log2, 0.25)
-            except Exception as e:  # the baseline is informational; never lose the GPU line over it
-                out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-            try:
-                out["pcie_inclusive"] = pcie_inclusive(ctx, lib, pk, D, n_wires, (w, a0, b0, c0), (a, b, c), cv, n_commit, r, s)
-            except Exception as e:
-                out["pcie_inclusive"] = {"value": None, "note": f"failed: {e}"}
+        if world == 1:  # the untimed legs run at N = 1 only
+            if not args.no_boundary:
+                try:
+                    out["boundary"] = boundary_leg(torch, zkpor, ctx, local_rank, pk, D, n_wires, n_commit, (w, a0, b0, c0, cv), td, blinding,
+                                                   resident_ms=dt / args.steps * 1e3)
+                except Exception as e:
+                    out["boundary"] = {"value": None, "note": f"failed: {e}"}
+            if not args.no_cpu_baseline:
+                try:
+                    out["cpu_baseline"] = cpu_baseline(args.cpu_log2, log2, 0.25)
+                except Exception as e:  # the baseline is informational; never lose the GPU line over it
+                    out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
             try:
                 out["acceptance"] = verifier_acceptance(ctx)
             except Exception as e:

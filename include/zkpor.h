@@ -22,10 +22,13 @@
  *   - field elements are gnark-crypto's in-memory form: 4 x uint64 little-endian limbs, MONTGOMERY form
  *     (fr.Element / fp.Element).  G1 affine = X,Y (64 B); G2 affine = X.A0,X.A1,Y.A0,Y.A1 (128 B);
  *     G1 Jacobian = X,Y,Z (96 B); G2 Jacobian 192 B.  Affine infinity = all-zero.
- *   - a zkpor_ctx is bound to one GPU and one HIP stream and is single-caller; different contexts are
- *     independent (one per GPU, one process or thread each).  HIP's current device is per host thread: a process
- *     that drives several GPUs calls every function of a context from the thread that ran zkpor_init for it
- *     (Go: runtime.LockOSThread in the worker goroutine), which is how host/prover_host.hpp dispatches.
+ *   - a zkpor_ctx is bound to one GPU and one HIP stream and is single-caller (one call at a time per context); different
+ *     contexts are independent — one per GPU, or several per GPU to keep more than one proof in flight.  HIP's current
+ *     device is a per-host-thread setting; every entry point that takes a context / key / tree / R1CS handle switches the
+ *     calling thread to the handle's GPU for the duration of the call and restores the previous device on return, so a
+ *     handle may be used from ANY thread (a goroutine need not be locked to an OS thread) and its allocations, events and
+ *     launches always land on its own GPU.  A key belongs to the GPU of the context it was created with; proving with a
+ *     context of another GPU is ZKPOR_E_ARG.
  *   - zkpor_host_register / zkpor_dev_upload_async are the only calls that keep reading a host range after they
  *     return (until zkpor_sync): the caller pins that memory for exactly that reason.
  *   - *_dev variants take DEVICE pointers (inputs already resident in HBM) and are asynchronous on the
@@ -66,6 +69,7 @@ void zkpor_destroy(zkpor_ctx* ctx);
 const char* zkpor_last_error(zkpor_ctx* ctx);
 int32_t zkpor_sync(zkpor_ctx* ctx);
 /* tuning knobs: "msm_window" (bits, 0 = auto), "msm_chunk" (entries per accumulation thread),
+ * "copy_threads" (host threads that fill the pinned bounce buffers of the host-pointer entry points, default 4),
  * "poseidon_out_idx", "poseidon_carry_idx" (hash-wrapper convention) */
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);
 /* per-phase GPU time in ms accumulated since the last reset (HIP events on the context's stream).
@@ -162,10 +166,29 @@ int32_t zkpor_fft_dev(zkpor_ctx* ctx, void* d_a, int log2n, int inverse, int dec
 /* ---- Groth16 prove tail: everything in groth16.Prove after the R1CS solver ------------------------------ */
 /* w: n_wires wire values (full assignment, ONE wire first); a,b,c: n_constraints evaluations; r,s: blinding
  * scalars (Montgomery Fr).  proof_out: Ar (G1 affine 64 B) | Bs (G2 affine 128 B) | Krs (G1 affine 64 B) as
- * Montgomery limbs.  Computes h, the A/B1/B2/K/Z multi-exponentiations and the r/s blinding on the device. */
+ * Montgomery limbs.  Computes h, the A/B1/B2/K/Z multi-exponentiations and the r/s blinding on the device.
+ *
+ * BLINDING: r and s are the zero-knowledge randomness of the proof.  gnark draws them with fr.SetRandom (crypto/rand) inside
+ * groth16.Prove; a caller of this ABI must do the same: uniform CSPRNG output, FRESH for every proof, canonical (< the
+ * modulus; ZKPOR_E_ARG otherwise), never seeded or reused (reuse leaks linear relations between witnesses), and — for the
+ * single-proof split — identical on all ranks and still secret.  The host-side multiplications by r and s are
+ * variable-time double-and-add: do not run the prover where a co-tenant can time it.  zkpor_prove_tail_rand below draws
+ * r and s itself from the operating system (getrandom) for callers without a CSPRNG at hand.
+ *
+ * HOST-POINTER FORM (what a cgo shim binds): w, a, b, c may be ordinary pageable memory (a Go slice).  The context keeps a
+ * persistent staging area in HBM (no allocation per proof) and moves the vectors across PCIe itself — through pinned bounce
+ * buffers filled by "copy_threads" host threads, or by direct DMA if the range was page-locked with zkpor_host_register —
+ * w first, then a, b, c underneath the A, B1 and K accumulations.  Nothing of the caller's memory is read after the call
+ * returns.  To hide the transfer completely keep two proofs in flight per GPU (two contexts, one caller each): one proof's
+ * copies then run under the other's kernels (bench.py `boundary`; host/prover_host.hpp does this). */
 int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                          const uint64_t* c, size_t n_constraints, const uint64_t r[4], const uint64_t s[4],
                          uint8_t proof_out[256]);
+/* the same, with r and s drawn inside the library from getrandom(2) and returned (Montgomery limbs) for the caller's records;
+ * either output pointer may be NULL */
+int32_t zkpor_prove_tail_rand(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                              const uint64_t* c, size_t n_constraints, uint64_t r_out[4], uint64_t s_out[4],
+                              uint8_t proof_out[256]);
 /* device-resident inputs; d_a/d_b/d_c must hold 2^log2_domain elements (zero padded) and are overwritten */
 int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c,
                              const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]);

@@ -386,11 +386,17 @@ int orc_g2_decompress(const uint8_t* in, size_t n, G2A* out) {
 // gnark raw proof encoding of the three points (proof.WriteRawTo, prover.go:201): big-endian
 // Ar.X|Ar.Y | Bs.X.A1|Bs.X.A0|Bs.Y.A1|Bs.Y.A0 | Krs.X|Krs.Y   (256 B; commitments follow separately)
 void orc_proof_raw(const uint8_t* proof256, uint8_t* out256) {
+    // gnark-crypto marshal.go RawBytes: infinity = flag 0b01 in the two top bits of byte 0 (0x40), rest zero
     const Fp* f = (const Fp*)proof256;
-    f[0].to_be_bytes(out256); f[1].to_be_bytes(out256 + 32);
-    f[3].to_be_bytes(out256 + 64); f[2].to_be_bytes(out256 + 96);
-    f[5].to_be_bytes(out256 + 128); f[4].to_be_bytes(out256 + 160);
-    f[6].to_be_bytes(out256 + 192); f[7].to_be_bytes(out256 + 224);
+    auto zero = [&](int lo, int hi) { for (int i = lo; i < hi; ++i) if (!f[i].is_zero()) return false; return true; };
+    memset(out256, 0, 256);
+    if (zero(0, 2)) out256[0] = 0x40; else { f[0].to_be_bytes(out256); f[1].to_be_bytes(out256 + 32); }
+    if (zero(2, 6)) out256[64] = 0x40;
+    else {
+        f[3].to_be_bytes(out256 + 64); f[2].to_be_bytes(out256 + 96);
+        f[5].to_be_bytes(out256 + 128); f[4].to_be_bytes(out256 + 160);
+    }
+    if (zero(6, 8)) out256[192] = 0x40; else { f[6].to_be_bytes(out256 + 192); f[7].to_be_bytes(out256 + 224); }
 }
 
 }  // extern "C"

@@ -1,0 +1,70 @@
+// TEST DRIVER (-m gpu): the reference's prover service loop (host/prover_host.hpp: Dispatcher -> Prover::Run, mirroring
+// src/prover/prover/prover.go:139-247) driving REAL proofs through the C ABI with several contexts — one worker thread per
+// context, contexts mapped round-robin onto the visible GPUs (on a one-GPU box: several contexts on device 0, which is also
+// how two proofs are kept in flight per GPU).  Plays the role of the Go caller; loaded by tests/test_dispatcher_gpu.py.
+#include "../../zkmerkle-proof-of-solvency_amd/host/prover_host.hpp"
+#include "../../include/zkpor.h"
+#include <atomic>
+#include <cstring>
+
+using namespace zkpor_host;
+
+extern "C" {
+
+// WitnessData of batch h = w | a | b | c (n_wires + 3 n_constraints Fr, Montgomery limbs) — what the solver would hand over.
+// blinding: r = r_s[8 h .. 8 h + 4), s = r_s[8 h + 4 .. 8 h + 8).  proofs_out: n_batches x 256 B, indexed by height.
+// worker_of (n_batches ints): which worker proved each height.  Returns 0, or a negative code (last error text in err).
+int dispatch_gpu_run(int n_workers, int n_devices, int64_t n_batches, int log2_domain, size_t n_wires, size_t n_constraints,
+                     uint64_t key_seed, const uint64_t* vectors, const uint64_t* r_s, uint8_t* proofs_out, int* worker_of, int* made_out,
+                     char* err, size_t err_len) {
+    std::vector<zkpor_ctx*> ctx(n_workers, nullptr);
+    std::vector<zkpor_pk*> pk(n_devices, nullptr);
+    auto fail = [&](const char* what, zkpor_ctx* c) {
+        snprintf(err, err_len, "%s: %s", what, c ? zkpor_last_error(c) : "");
+        return -1;
+    };
+    // contexts are created HERE, on the caller's thread, and used from the worker threads: the library binds every call to the
+    // handle's device itself (device affinity)
+    for (int g = 0; g < n_workers; ++g)
+        if (zkpor_init(g % n_devices, nullptr, &ctx[g]) != ZKPOR_OK) return fail("zkpor_init", nullptr);
+    for (int d = 0; d < n_devices; ++d) {  // one key per GPU, shared by that GPU's contexts
+        if (zkpor_pk_create(ctx[d], &pk[d]) != ZKPOR_OK) return fail("pk_create", ctx[d]);
+        if (zkpor_pk_synth(pk[d], log2_domain, n_wires, 3, 0, key_seed) != ZKPOR_OK) return fail("pk_synth", ctx[d]);
+    }
+    const size_t per = (n_wires + 3 * n_constraints) * 4;
+    std::atomic<int> bad{0};
+    Dispatcher disp(n_workers, [&](int g, const BatchWitness& bw, std::string* raw, int* assets) -> int {
+        const uint64_t* v = (const uint64_t*)bw.WitnessData.data();
+        const uint64_t* w = v; const uint64_t* a = w + 4 * n_wires; const uint64_t* b = a + 4 * n_constraints; const uint64_t* c = b + 4 * n_constraints;
+        uint8_t proof[256];
+        int32_t rc = zkpor_prove_tail(ctx[g], pk[g % n_devices], w, a, b, c, n_constraints, r_s + 8 * bw.Height, r_s + 8 * bw.Height + 4, proof);
+        if (rc != ZKPOR_OK) { bad++; return 1; }
+        raw->assign((const char*)proof, 256);
+        *assets = 50;
+        worker_of[bw.Height] = g;
+        return 0;
+    });
+    for (int64_t h = 0; h < n_batches; ++h) {
+        BatchWitness bw;
+        bw.Height = h;
+        bw.WitnessData.assign((const char*)(vectors + (size_t)h * per), per * 8);
+        disp.witnessModel.CreateBatchWitness(bw);
+        disp.queue.LPush(h);
+    }
+    std::vector<int> made = disp.Run(false);
+    int rc = 0;
+    for (int g = 0; g < n_workers; ++g) { made_out[g] = made[g]; if (made[g] < 0) rc = -2; }
+    if (bad.load()) { rc = -3; snprintf(err, err_len, "prove failed: %s", zkpor_last_error(ctx[0])); }
+    if (rc == 0 && (disp.proofModel.Count() != (size_t)n_batches || disp.witnessModel.CountByStatus(StatusFinished) != (size_t)n_batches)) {
+        rc = -4; snprintf(err, err_len, "rows: %zu proofs, %zu finished of %ld", disp.proofModel.Count(), disp.witnessModel.CountByStatus(StatusFinished), (long)n_batches);
+    }
+    for (int64_t h = 0; h < n_batches && rc == 0; ++h) {
+        Proof p;
+        if (disp.proofModel.GetProofByBatchNumber(h, &p) != Ok || p.ProofInfo.size() != 256) { rc = -5; break; }
+        memcpy(proofs_out + 256 * h, p.ProofInfo.data(), 256);
+    }
+    for (auto* k : pk) if (k) zkpor_pk_destroy(k);
+    for (auto* c : ctx) if (c) zkpor_destroy(c);
+    return rc;
+}
+}

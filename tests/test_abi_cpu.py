@@ -41,6 +41,18 @@ def test_proof_write_raw_is_host_only_and_sized():
     assert raw.size == 324
     raw = zkpor.proof_write_raw(proof, np.zeros((1, 8), np.uint64), np.zeros(8, np.uint64))
     assert raw.size == 388 and raw[259] == 1   # the reference's 388-byte proof (one commitment), SURVEY.md a6.7
+    # every point of this proof is the identity: gnark-crypto's RawBytes writes the flag mUncompressedInfinity (0b01 << 6) into
+    # byte 0 and zeros behind it — not 64 zero bytes (marshal.go); Ar | Bs | Krs | count | commitment | knowledge proof
+    expect = np.zeros(388, dtype=np.uint8)
+    expect[[0, 64, 192, 260, 324]] = 0x40
+    expect[259] = 1
+    assert np.array_equal(raw, expect)
+    import oracle as O
+    assert np.array_equal(O.proof_raw(proof), expect[:256])
+    # a real point keeps its two flag bits clear: (1, 2) is on the curve
+    p1 = np.zeros(32, dtype=np.uint64); p1[0:4] = O.fp_from_ints([1])[0]; p1[4:8] = O.fp_from_ints([2])[0]
+    raw = zkpor.proof_write_raw(p1.view(np.uint8))
+    assert raw[0] == 0 and raw[31] == 1 and raw[63] == 2 and raw[64] == 0x40
 
 
 def test_prove_assemble_matches_the_groth16_formulas_on_the_oracle():

@@ -16,14 +16,12 @@ CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_char_
 def host():
     so = os.path.join(PKG, "libzkpor_host.so")
     src = os.path.join(PKG, "host", "host_capi.cpp")
-    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+    import glob
+    deps = [src] + glob.glob(os.path.join(PKG, "host", "*.hpp"))
+    if not os.path.exists(so) or max(os.path.getmtime(f) for f in deps) > os.path.getmtime(so):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, src])
     lib = ctypes.CDLL(so)
     lib.zkh_create.restype = ctypes.c_void_p
-    hdr = os.path.join(PKG, "host", "proof_row.hpp")
-    if os.path.getmtime(hdr) > os.path.getmtime(so):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, src])
-        lib = ctypes.CDLL(so)
     for f in ("zkh_count_status", "zkh_count_proofs", "zkh_prove_calls", "zkh_proof_csv"):
         getattr(lib, f).restype = ctypes.c_long
     return lib
@@ -90,6 +88,39 @@ def test_rerun_picks_received_then_published(host):
     host.zkh_run(d, 1, made, 1)
     assert [h for _, h in seen] == [3, 1, 2]    # latest Received first, then Published (prover.go:107-137)
     assert host.zkh_count_status(d, 2) == 3
+    host.zkh_destroy(d)
+
+
+def test_rerun_with_several_workers_proves_every_row_once(host):
+    """rerun under the in-process dispatcher: GetLatestBatchWitnessByStatus does not claim a row, so without the in-memory claim
+    every worker would prove the same latest height (N times the GPU work) and the losers of the CreateProof race would look
+    like failures"""
+    seen = []
+    cb = _fake_prover(seen)
+    d = ctypes.c_void_p(host.zkh_create(4, cb, 10))
+    n = 40
+    for h in range(n):
+        host.zkh_add_witness(d, ctypes.c_int64(h), b"r", 1, 1 if h % 3 else 0)   # a mix of Received and Published leftovers
+    made = (ctypes.c_int * 4)()
+    host.zkh_run(d, 1, made, 4)
+    assert all(m >= 0 for m in made) and sum(made) == n
+    assert sorted(h for _, h in seen) == list(range(n)) and host.zkh_prove_calls(d) == n
+    assert host.zkh_count_proofs(d) == n and host.zkh_count_status(d, 2) == n
+    host.zkh_destroy(d)
+
+
+def test_queue_mode_quits_on_a_height_without_published_row(host):
+    """prover.go:150-154: DbErrNotFound from FetchBatchWitness ends Run ("no published status witness in db, so quit")"""
+    seen = []
+    cb = _fake_prover(seen)
+    d = ctypes.c_void_p(host.zkh_create(1, cb, 10))
+    for h in (0, 1):
+        host.zkh_add_witness(d, ctypes.c_int64(h), b"q", 1, 0)
+    for h in (0, 77, 1):                       # 77 has no row: the single worker stops there, height 1 stays Published
+        host.zkh_push_task(d, ctypes.c_int64(h))
+    made = (ctypes.c_int * 1)()
+    host.zkh_run(d, 0, made, 1)
+    assert made[0] == 1 and [h for _, h in seen] == [0] and host.zkh_count_status(d, 0) == 1
     host.zkh_destroy(d)
 
 

@@ -3,14 +3,18 @@ properties — the oracle cannot run 2^26-point MSMs in test time:
   * MSM: the synthetic key's points are s_i*G with a known s_i  =>  MSM(w) == (sum s_i w_i) * G   (G1 over A, G2 over B2)
   * NTT: inverse(forward(x)) == x on the coset at 2^26
   * computeH: for A = B = X^(D/2+1), C = X^2 the quotient is exactly H = X^2
+  * prove tail: the fused path bench.py times (one digit stream -> A, B1, K, B2; h -> Z; blinding; commitment) gives
+    exactly the proof the key's discrete logs predict (oracle/trapdoor.py)
   * Merkle: root(2^27 leaves) == H(H(root(left half), root(right half)), nil) one level up
 Set ZKPOR_FULLSIZE_LOG2 to shrink (default 26)."""
+import ctypes
 import os
 
 import numpy as np
 import pytest
 
 import oracle as O
+import trapdoor as T
 import zkpor
 
 pytestmark = pytest.mark.gpu
@@ -18,34 +22,8 @@ LOG2 = int(os.environ.get("ZKPOR_FULLSIZE_LOG2", "26"))
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-def _smix(x):
-    x = x + np.uint64(0x9e3779b97f4a7c15)
-    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
-    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
-    return x ^ (x >> np.uint64(31))
-
-
 def _synth_scalars_canon(seed, arr, n, inf_mod):
-    """vectorised zkpor.synth_scalar: canonical limbs (n,4) of k(run) + j*q, zeroed where the synthetic point is infinity"""
-    with np.errstate(over="ignore"):
-        i = np.arange(n, dtype=np.uint64)
-        run = i // np.uint64(zkpor.SYNTH_RUN)
-        j = (i % np.uint64(zkpor.SYNTH_RUN)).astype(np.int64)
-        x = np.uint64(seed) ^ np.uint64(((arr + 1) * 0xa0761d6478bd642f) & 0xFFFFFFFFFFFFFFFF) ^ (run * np.uint64(0xe7037ed1a0b428db))
-        k = _smix(x) | np.uint64(1)
-        jq = [jj * zkpor.SYNTH_Q for jj in range(zkpor.SYNTH_RUN)]
-        jq_lo = np.array([v & 0xFFFFFFFFFFFFFFFF for v in jq], dtype=np.uint64)[j]
-        jq_hi = np.array([v >> 64 for v in jq], dtype=np.uint64)[j]
-        lo = k + jq_lo
-        hi = jq_hi + (lo < k).astype(np.uint64)
-        out = np.zeros((n, 4), dtype=np.uint64)
-        out[:, 0] = lo
-        out[:, 1] = hi
-        if inf_mod:
-            h = i * np.uint64(0xd6e8feb86659fd93)
-            h ^= h >> np.uint64(32)
-            out[(h % np.uint64(inf_mod)) == 0] = 0
-    return out
+    return T.synth_scalars_canon(seed, arr, 0, n, inf_mod)
 
 
 def test_synth_scalar_vectorisation_matches_reference():
@@ -85,6 +63,48 @@ def test_msm_fullsize_trapdoor(zk):
     finally:
         wbuf.free()
         pk.close()
+
+
+def test_prove_tail_fullsize_trapdoor(zk):
+    """The fused path that bench.py times (zkpor_commit_dev + zkpor_prove_tail_dev: ONE sorted digit stream of w -> A, B1, K,
+    B2; computeH -> h in the order of Z -> Z.h; blinding; the 2^(LOG2-2) Pedersen sums) at the bench's size and scalar
+    mixture, verified in the exponent from the synthetic key's trapdoor — prove, then verify, as prover.go:269-276 does."""
+    n = 1 << LOG2
+    nc = n >> 2
+    seed = 0x5A4B504F52
+    pk = zkpor.ProvingKey(zk)
+    bufs = {k: zk.alloc(32 * n) for k in ("w", "a", "b", "c")}
+    cv = zk.alloc(32 * nc)
+    try:
+        pk.synth(LOG2, n, 3, nc, seed)
+        zk.fill_fr(bufs["w"], n, 2, 1)                 # witness-like mixture (bench default)
+        zk.fill_fr(bufs["a"], n, 11, 0)
+        zk.fill_fr(bufs["b"], n, 12, 0)
+        zk._ck(zk.lib.zkpor_dev_fr_mul(zk.h, _vp(bufs["c"].ptr), _vp(bufs["a"].ptr), _vp(bufs["b"].ptr), ctypes.c_size_t(n)))
+        zk.fill_fr(cv, nc, 13, 1)
+        com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
+        zk._ck(zk.lib.zkpor_commit_dev(zk.h, pk.h, _vp(cv.ptr), ctypes.c_size_t(nc), zkpor._p(com), zkpor._p(pok)))
+        r = O.fr_random(71, 1)[0]; s = O.fr_random(72, 1)[0]
+        proof = zk.prove_tail_dev(pk, bufs["w"].ptr, bufs["a"].ptr, bufs["b"].ptr, bufs["c"].ptr, r, s)
+        w = bufs["w"].download(np.uint64, (n, 4))
+        h = bufs["a"].download(np.uint64, (n, 4))     # prove_tail_dev leaves h in a, in the order of the key's Z
+        assert h.any()
+        td = T.SynthKeyTrapdoor(seed, 3, w, h[: n - 1])
+        assert td.check(proof, r, s)
+        # a second proof over the same sums with other blinding must check as well, and a tampered one must not
+        r2 = O.fr_random(73, 1)[0]; s2 = O.fr_random(74, 1)[0]
+        assert not td.check(proof, r2, s2)
+        ec, ek = T.expected_commitment(seed, cv.download(np.uint64, (nc, 4)))
+        assert np.array_equal(com, ec) and np.array_equal(pok, ek)
+    finally:
+        for b in bufs.values():
+            b.free()
+        cv.free()
+        pk.close()
+
+
+def _vp(x):
+    return ctypes.c_void_p(x)
 
 
 def test_ntt_fullsize_roundtrip(zk):

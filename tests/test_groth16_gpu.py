@@ -149,3 +149,82 @@ def test_synth_key_trapdoor(zk):
         assert np.array_equal(p2, exp2)
     finally:
         pk.close()
+
+
+@pytest.mark.parametrize("log2,ncons_short", [(14, 3), (21, 1000)])
+def test_prove_tail_host_pointer_form_equals_resident_form(zk, log2, ncons_short):
+    """zkpor_prove_tail (the entry point a cgo shim binds: pageable host vectors, persistent HBM staging, pinned bounce buffers,
+    w first and a/b/c under the A/B1/K accumulations — a different ORDER of the same work) against zkpor_prove_tail_dev on the
+    same vectors placed in HBM by the test: bit-exact, for a domain whose vectors span several bounce chunks (2^21: 64 MiB each),
+    with fewer constraints than the domain (the padding rows are zeroed by the library), from page-locked memory too, twice in a row
+    (the staging area is reused), and with the trapdoor check on top."""
+    import ctypes
+    import trapdoor as T
+    n = 1 << log2
+    ncons = n - ncons_short
+    seed = 0xB0B + log2
+    pk = zkpor.ProvingKey(zk)
+    bufs = [zk.alloc(32 * n) for _ in range(4)]
+    try:
+        pk.synth(log2, n, 3, 0, seed)
+        rng = np.random.default_rng(log2)
+        def fr(m, small):
+            x = rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64)      # < 2^254-ish canonical-as-Montgomery limbs
+            x[:, 3] &= np.uint64((1 << 60) - 1)
+            if small:
+                x[rng.random(m) < 0.4, 1:] = 0
+                x[rng.random(m) < 0.2] = 0
+            return x
+        w = fr(n, True); a = fr(ncons, False); b = fr(ncons, False)
+        c = np.empty_like(a); O.lib().orc_fr_mul(O._p(a), O._p(b), O._p(c), ctypes.c_size_t(ncons))
+        r = O.fr_random(5, 1)[0]; s = O.fr_random(6, 1)[0]
+        got = zk.prove_tail(pk, w, a, b, c, r, s)
+        # resident form: the test pads and uploads
+        pad = lambda v: np.concatenate([v, np.zeros((n - v.shape[0], 4), np.uint64)])
+        for buf, v in zip(bufs, (w, pad(a), pad(b), pad(c))):
+            buf.upload(v)
+        ref = zk.prove_tail_dev(pk, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, r, s)
+        assert np.array_equal(got, ref)
+        h = bufs[1].download(np.uint64, (n, 4))
+        assert T.SynthKeyTrapdoor(seed, 3, w, h[: n - 1]).check(got, r, s)
+        # again (reused staging), other blinding; then from page-locked memory (direct DMA instead of the bounce buffers)
+        r2 = O.fr_random(7, 1)[0]
+        got2 = zk.prove_tail(pk, w, a, b, c, r2, s)
+        for buf, v in zip(bufs[1:], (pad(a), pad(b), pad(c))):
+            buf.upload(v)
+        assert np.array_equal(got2, zk.prove_tail_dev(pk, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, r2, s))
+        for v in (w, a, b, c):
+            zk._ck(zk.lib.zkpor_host_register(zk.h, zkpor._p(v), ctypes.c_size_t(v.nbytes)))
+        try:
+            assert np.array_equal(zk.prove_tail(pk, w, a, b, c, r, s), got)
+        finally:
+            for v in (w, a, b, c):
+                zk._ck(zk.lib.zkpor_host_unregister(zk.h, zkpor._p(v)))
+        # the library draws its own blinding: two calls give two different proofs, each correct for the (r, s) it reports
+        out = np.empty(256, np.uint8); ro = np.empty(4, np.uint64); so = np.empty(4, np.uint64)
+        seen = []
+        for _ in range(2):
+            zk._ck(zk.lib.zkpor_prove_tail_rand(zk.h, pk.h, zkpor._p(w), zkpor._p(a), zkpor._p(b), zkpor._p(c), ctypes.c_size_t(ncons),
+                                                zkpor._p(ro), zkpor._p(so), zkpor._p(out)))
+            assert T.SynthKeyTrapdoor(seed, 3, w, h[: n - 1]).check(out, ro, so)
+            seen.append((ro.copy(), so.copy()))
+        assert not np.array_equal(seen[0][0], seen[1][0]) and not np.array_equal(seen[0][1], seen[1][1])
+    finally:
+        for b_ in bufs:
+            b_.free()
+        pk.close()
+
+
+def test_blinding_must_be_canonical(zk):
+    S = O.Synth(4, 50, n_public=2, seed=3)
+    pk = _load_pk(zk, S, zkpor.Z_ORDER_BITREV)
+    try:
+        modulus = O.ints_to_limbs([0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001])[0]
+        ok = O.fr_random(1, 1)[0]
+        for r, s in ((modulus, ok), (ok, modulus), (np.full(4, 2**64 - 1, np.uint64), ok)):
+            with pytest.raises(zkpor.ZkporError):
+                zk.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
+        below = O.ints_to_limbs([0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000000])[0]
+        assert S.check(below, ok, zk.prove_tail(pk, S.w, S.a, S.b, S.c, below, ok))
+    finally:
+        pk.close()

@@ -2,6 +2,9 @@
 #include "common.cuh"
 #include "msm.cuh"
 #include "ntt.cuh"
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 using namespace zk;
 
@@ -12,6 +15,133 @@ int32_t ensure_pinned(zkpor_ctx* ctx, size_t bytes) {
     if (ctx->pinned) { ZK_HIP(ctx, hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
     ZK_HIP(ctx, hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
     ctx->pinned_cap = bytes;
+    return ZKPOR_OK;
+}
+
+int32_t stage_reserve(zkpor_ctx* ctx, size_t bytes) {
+    bytes = align_up(bytes, 1 << 20);
+    if (bytes <= ctx->stage_cap) return ZKPOR_OK;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream) ZK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (ctx->stage) { ZK_HIP(ctx, hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_cap = 0; }
+    ZK_HIP(ctx, hipMalloc((void**)&ctx->stage, bytes));
+    ctx->stage_cap = bytes;
+    return ZKPOR_OK;
+}
+
+// Pinned bounce buffers + the host threads that fill them.  One per context, created on the first pageable upload.
+struct Bounce {
+    static constexpr int SLOTS = 4;
+    static constexpr size_t CHUNK = (size_t)32 << 20;
+    char* buf[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool used[SLOTS] = {false, false, false, false};
+    int next = 0;
+    // worker threads: each copies slice t of the current chunk
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool quit = false;
+    char* dst = nullptr;
+    const char* src = nullptr;
+    size_t len = 0;
+    int parts = 1;
+
+    static void slice(size_t len, int parts, int t, size_t* off, size_t* n) {
+        size_t per = (len / parts + 63) & ~(size_t)63;
+        size_t o = per * t;
+        if (o > len) o = len;
+        *off = o;
+        *n = (t == parts - 1) ? len - o : (o + per > len ? len - o : per);
+    }
+    void worker(int t) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&] { return quit || gen != seen; });
+            if (quit) return;
+            seen = gen;
+            char* d = dst; const char* s = src; size_t l = len; int p = parts;
+            lk.unlock();
+            size_t off, n;
+            slice(l, p, t, &off, &n);
+            if (n) memcpy(d + off, s + off, n);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_one();
+        }
+    }
+    void start(int n_threads) {
+        parts = n_threads < 1 ? 1 : n_threads;
+        for (int t = 1; t < parts; ++t) th.emplace_back([this, t] { worker(t); });
+    }
+    void copy(char* d, const char* s, size_t l) {  // all threads (the caller is thread 0)
+        if (parts > 1) {
+            std::unique_lock<std::mutex> lk(mu);
+            dst = d; src = s; len = l; pending = parts - 1; ++gen;
+            cv_go.notify_all();
+        }
+        size_t off, n;
+        slice(l, parts, 0, &off, &n);
+        if (n) memcpy(d + off, s + off, n);
+        if (parts > 1) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return pending == 0; });
+        }
+    }
+    ~Bounce() {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            quit = true;
+            cv_go.notify_all();
+        }
+        for (auto& t : th) t.join();
+        for (int i = 0; i < SLOTS; ++i) {
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (buf[i]) (void)hipHostFree(buf[i]);
+        }
+    }
+};
+
+void bounce_free(zkpor_ctx* ctx) {
+    if (ctx->bounce && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);  // no DMA may still read the buffers
+    delete (Bounce*)ctx->bounce;
+    ctx->bounce = nullptr;
+}
+
+int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!bytes) return ZKPOR_OK;
+    if (!ctx->copy_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, h_src) == hipSuccess && at.type == hipMemoryTypeHost) {
+        ZK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        return ZKPOR_OK;
+    }
+    (void)hipGetLastError();  // an unregistered pointer is the expected case, not an error
+    Bounce* b = (Bounce*)ctx->bounce;
+    if (!b) {
+        b = new (std::nothrow) Bounce();
+        if (!b) { ctx->err = "host_upload: out of host memory"; return ZKPOR_E_OOM; }
+        ctx->bounce = b;
+        for (int i = 0; i < Bounce::SLOTS; ++i) {
+            ZK_HIP(ctx, hipHostMalloc((void**)&b->buf[i], Bounce::CHUNK, hipHostMallocDefault));
+            ZK_HIP(ctx, hipEventCreateWithFlags(&b->ev[i], hipEventDisableTiming));
+        }
+        b->start(ctx->copy_threads);
+    }
+    const char* src = (const char*)h_src;
+    char* dst = (char*)d_dst;
+    for (size_t off = 0; off < bytes; off += Bounce::CHUNK) {
+        size_t n = bytes - off < Bounce::CHUNK ? bytes - off : Bounce::CHUNK;
+        int s = b->next;
+        b->next = (s + 1) % Bounce::SLOTS;
+        if (b->used[s]) ZK_HIP(ctx, hipEventSynchronize(b->ev[s]));  // the DMA that last read this slot is done
+        b->copy(b->buf[s], src + off, n);
+        ZK_HIP(ctx, hipMemcpyAsync(dst + off, b->buf[s], n, hipMemcpyHostToDevice, ctx->copy_stream));
+        ZK_HIP(ctx, hipEventRecord(b->ev[s], ctx->copy_stream));
+        b->used[s] = true;
+    }
     return ZKPOR_OK;
 }
 }  // namespace zk
@@ -30,10 +160,14 @@ __global__ void k_fill_fr(Fr* out, size_t n, u64 seed, int kind) {
     u64 sel = splitmix(s) % 100;
     Fr x = Fr::zero();
     int bits = 254;
-    if (kind == 1) {
+    if (kind == 1) {          // zkpor50_1380 estimate: 25% {0,1}, 20% < 2^16, 5% < 2^64, 50% uniform
         if (sel < 25) bits = 1;
         else if (sel < 45) bits = 16;
         else if (sel < 50) bits = 64;
+    } else if (kind == 2) {   // zkpor500_200 estimate (Appendix B: Poseidon share falls, limb / boolean share rises): 35 / 30 / 5 / 30
+        if (sel < 35) bits = 1;
+        else if (sel < 65) bits = 16;
+        else if (sel < 70) bits = 64;
     }
     u64 r0 = splitmix(s), r1 = splitmix(s), r2 = splitmix(s), r3 = splitmix(s);
     if (bits == 1) { r0 &= 1; r1 = r2 = r3 = 0; }
@@ -86,6 +220,7 @@ __global__ void k_fr_mul(Fr* out, const Fr* a, const Fr* b, size_t n) {
 extern "C" {
 
 int32_t zkpor_dev_fr_mul(zkpor_ctx* ctx, void* d_out, const void* d_a, const void* d_b, size_t n) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && (!d_out || !d_a || !d_b))) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
     hipLaunchKernelGGL(k_fr_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_out, (const Fr*)d_a, (const Fr*)d_b, n);
@@ -93,6 +228,7 @@ int32_t zkpor_dev_fr_mul(zkpor_ctx* ctx, void* d_out, const void* d_a, const voi
     return ZKPOR_OK;
 }
 int32_t zkpor_dev_copy(zkpor_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (bytes && (!d_dst || !d_src))) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return ZKPOR_OK;
@@ -123,7 +259,7 @@ int32_t zkpor_init(int device, void* stream, zkpor_ctx** out) {
 
 void zkpor_destroy(zkpor_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    ZK_ENTER(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->phases)
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -132,6 +268,9 @@ void zkpor_destroy(zkpor_ctx* ctx) {
     pos_tables_free(ctx);
     ntt_domains_free(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    bounce_free(ctx);
+    if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -140,12 +279,14 @@ void zkpor_destroy(zkpor_ctx* ctx) {
 const char* zkpor_last_error(zkpor_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int32_t zkpor_sync(zkpor_ctx* ctx) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
 }
 
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !name) return ZKPOR_E_ARG;
     std::string n(name);
     if (n == "msm_window") ctx->msm_window = (int)value;
@@ -154,6 +295,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     else if (n == "msm_g2_variant") ctx->g2_variant = (int)value;
     else if (n == "ntt_variant") ctx->ntt_variant = (int)value;
     else if (n == "ntt_tile_log") { if (value < 9 || value > 12) { ctx->err = "ntt_tile_log must be in [9,12]"; return ZKPOR_E_ARG; } ctx->ntt_tile_log = (int)value; }
+    else if (n == "copy_threads") { if (value < 1 || value > 64) { ctx->err = "copy_threads must be in [1,64]"; return ZKPOR_E_ARG; } if (ctx->bounce) bounce_free(ctx); ctx->copy_threads = (int)value; }
     else if (n == "poseidon_out_idx") ctx->pos_out = (int)value;
     else if (n == "poseidon_carry_idx") ctx->pos_carry = (int)value;
     else { ctx->err = "unknown parameter " + n; return ZKPOR_E_ARG; }
@@ -161,6 +303,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
 }
 
 double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !name) return -1.0;
     auto it = ctx->phases.find(name);
     if (it == ctx->phases.end()) { if (calls) *calls = 0; return 0.0; }
@@ -169,23 +312,26 @@ double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls) {
     return it->second.ms;
 }
 void zkpor_phase_reset(zkpor_ctx* ctx) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return;
     for (auto& kv : ctx->phases) { phase_resolve(ctx, kv.second); kv.second.ms = 0; kv.second.calls = 0; }
 }
 
 int32_t zkpor_dev_alloc(zkpor_ctx* ctx, size_t bytes, void** out) {
     if (!ctx || !out) return ZKPOR_E_ARG;
-    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    ZK_ENTER(ctx->device);
     ZK_HIP(ctx, hipMalloc(out, bytes ? bytes : 1));
     return ZKPOR_OK;
 }
 int32_t zkpor_dev_free(zkpor_ctx* ctx, void* p) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZK_HIP(ctx, hipFree(p));
     return ZKPOR_OK;
 }
 int32_t zkpor_dev_upload(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer is not retained
@@ -194,6 +340,7 @@ int32_t zkpor_dev_upload(zkpor_ctx* ctx, void* dst, const void* src, size_t byte
 // asynchronous upload: returns once the copy is queued; the host buffer must stay valid (and should be pinned, see
 // zkpor_host_register) until zkpor_sync.  Lets the next proof's witness cross PCIe under the current proof's kernels.
 int32_t zkpor_dev_upload_async(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return ZKPOR_OK;
@@ -201,22 +348,26 @@ int32_t zkpor_dev_upload_async(zkpor_ctx* ctx, void* dst, const void* src, size_
 // page-lock a caller-owned host range (a Go slice's backing array) so uploads from it run at PCIe rate and truly
 // asynchronously; the caller unregisters it before freeing the memory
 int32_t zkpor_host_register(zkpor_ctx* ctx, void* ptr, size_t bytes) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !ptr || !bytes) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     return ZKPOR_OK;
 }
 int32_t zkpor_host_unregister(zkpor_ctx* ctx, void* ptr) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !ptr) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipHostUnregister(ptr));
     return ZKPOR_OK;
 }
 int32_t zkpor_dev_download(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
 }
 int32_t zkpor_dev_fill_fr(zkpor_ctx* ctx, void* d_out, size_t n, uint64_t seed, int kind) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (!d_out && n)) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
     hipLaunchKernelGGL(k_fill_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_out, n, seed, kind);
@@ -250,6 +401,7 @@ int32_t zkpor_g2_jac_sum(const uint8_t* parts192, size_t count, uint8_t out_jac[
 }
 
 int32_t zkpor_msm_g1_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[96]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out_jac || (n && (!d_points || !d_scalars))) return ZKPOR_E_ARG;
     G1XYZZ r;
     ZK_TRY(msm_dev<Fp>(ctx, (const G1Affine*)d_points, (const Fr*)d_scalars, n, &r));
@@ -257,6 +409,7 @@ int32_t zkpor_msm_g1_dev(zkpor_ctx* ctx, const void* d_points, const void* d_sca
     return ZKPOR_OK;
 }
 int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[192]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out_jac || (n && (!d_points || !d_scalars))) return ZKPOR_E_ARG;
     G2XYZZ r;
     ZK_TRY(msm_dev<Fp2>(ctx, (const G2Affine*)d_points, (const Fr*)d_scalars, n, &r));
@@ -265,6 +418,7 @@ int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_sca
 }
 
 int32_t zkpor_msm_g1(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[96]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out_jac || (n && (!points_affine || !scalars))) return ZKPOR_E_ARG;
     G1XYZZ r;
     ZK_TRY(msm_host<Fp>(ctx, points_affine, scalars, n, &r));
@@ -272,6 +426,7 @@ int32_t zkpor_msm_g1(zkpor_ctx* ctx, const void* points_affine, const uint64_t* 
     return ZKPOR_OK;
 }
 int32_t zkpor_msm_g2(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[192]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out_jac || (n && (!points_affine || !scalars))) return ZKPOR_E_ARG;
     G2XYZZ r;
     ZK_TRY(msm_host<Fp2>(ctx, points_affine, scalars, n, &r));

@@ -45,6 +45,13 @@ struct zkpor_ctx {
     // small pinned host staging buffer
     void* pinned = nullptr;
     size_t pinned_cap = 0;
+    // host-pointer boundary (zkpor_prove_tail, zkpor_commit): persistent device staging for the caller's vectors, a copy
+    // stream, and pinned bounce buffers that carry pageable host memory across PCIe (api_core.hip host_upload)
+    char* stage = nullptr;
+    size_t stage_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    void* bounce = nullptr;          // zk::Bounce*
+    int copy_threads = 4;
 };
 
 #define ZK_HIP(ctx, call)                                                                             \
@@ -63,6 +70,24 @@ struct zkpor_ctx {
 #define ZK_KERNEL_CHECK(ctx) ZK_HIP(ctx, hipGetLastError())
 
 namespace zk {
+
+// HIP's current device is a per-host-thread setting and new threads start on device 0: every entry point that takes a
+// context / key / tree / R1CS handle binds the calling thread to the handle's GPU for the duration of the call and restores
+// what was there before, so a handle may be used from any thread (one caller at a time) — allocations, events and launches
+// always land on the GPU the handle was created for.
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) {
+        if (dev < 0) return;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != dev) { (void)hipSetDevice(dev); prev = cur; }
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+#define ZK_ENTER(dev_expr) zk::DevGuard zk_dev_guard__(dev_expr)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -132,6 +157,15 @@ inline void phase_resolve(zkpor_ctx* ctx, PhaseTimer& t) {
     }
     t.pending.clear();
 }
+
+// api_core.hip: grow-only device staging area of the context (contents undefined after a growth)
+int32_t stage_reserve(zkpor_ctx* ctx, size_t bytes);
+// queue a host -> device copy on ctx->copy_stream.  Page-locked sources (hipHostMalloc / zkpor_host_register) are handed to
+// the DMA engine directly; pageable ones (a Go / numpy heap slice) go through pinned bounce buffers filled by a few host
+// threads, chunk k+1 being copied by the CPU while chunk k crosses PCIe.  Returns when the last chunk is QUEUED: the source
+// range is no longer needed afterwards unless it was page-locked (then: until the copy stream has drained).
+int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+void bounce_free(zkpor_ctx* ctx);
 
 // sort.hip (rocPRIM radix sort of (key,value) u32 pairs, keys in [0, 2^end_bit))
 int32_t sort_pairs_temp_bytes(zkpor_ctx* ctx, size_t n, int end_bit, size_t* bytes);

@@ -186,6 +186,7 @@ using namespace zk;
 extern "C" {
 
 int32_t zkpor_g1_decompress(zkpor_ctx* ctx, const uint8_t* compressed32, size_t n, void* out_affine) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && (!compressed32 || !out_affine))) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
     void* d = nullptr;
@@ -196,6 +197,7 @@ int32_t zkpor_g1_decompress(zkpor_ctx* ctx, const uint8_t* compressed32, size_t 
     return rc;
 }
 int32_t zkpor_g2_decompress(zkpor_ctx* ctx, const uint8_t* compressed64, size_t n, void* out_affine) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && (!compressed64 || !out_affine))) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
     void* d = nullptr;

@@ -5,8 +5,10 @@
 #include "common.cuh"
 #include "msm.cuh"
 #include "ntt.cuh"
+#include <errno.h>
 #include <functional>
 #include <new>
+#include <sys/random.h>
 #include <type_traits>
 
 using namespace zk;
@@ -177,6 +179,7 @@ inline G1XYZZ g1x(const G1Affine& a) { return xyzz_from_affine<Fp>(a); }
 extern "C" {
 
 int32_t zkpor_pk_create(zkpor_ctx* ctx, zkpor_pk** out) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out) return ZKPOR_E_ARG;
     zkpor_pk* pk = new (std::nothrow) zkpor_pk();
     if (!pk) return ZKPOR_E_OOM;
@@ -185,6 +188,7 @@ int32_t zkpor_pk_create(zkpor_ctx* ctx, zkpor_pk** out) {
     return ZKPOR_OK;
 }
 void zkpor_pk_destroy(zkpor_pk* pk) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk) return;
     (void)hipStreamSynchronize(pk->ctx->stream);
     pk_free_arrays(pk);
@@ -192,6 +196,7 @@ void zkpor_pk_destroy(zkpor_pk* pk) {
 }
 
 int32_t zkpor_pk_set_g1(zkpor_pk* pk, int which, const void* pts, size_t n) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || which < 0 || which >= ZKPOR_G1_NUM || (n && !pts)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
     if (pk->g1_raw[which]) { ZK_HIP(ctx, hipFree(pk->g1_raw[which])); pk->g1_raw[which] = nullptr; }
@@ -203,6 +208,7 @@ int32_t zkpor_pk_set_g1(zkpor_pk* pk, int which, const void* pts, size_t n) {
     return ZKPOR_OK;
 }
 int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || which != ZKPOR_G2_B || (n && !pts)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
     if (pk->g2_raw) { ZK_HIP(ctx, hipFree(pk->g2_raw)); pk->g2_raw = nullptr; }
@@ -216,6 +222,7 @@ int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n) {
 
 // compressed input (what pk.WriteTo put on disk, src/keygen/main.go:46): decompressed on the device, decompress.hip
 int32_t zkpor_pk_set_g1_compressed(zkpor_pk* pk, int which, const uint8_t* compressed32, size_t n) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || which < 0 || which >= ZKPOR_G1_NUM || (n && !compressed32)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
     if (pk->g1_raw[which]) { ZK_HIP(ctx, hipFree(pk->g1_raw[which])); pk->g1_raw[which] = nullptr; }
@@ -227,6 +234,7 @@ int32_t zkpor_pk_set_g1_compressed(zkpor_pk* pk, int which, const uint8_t* compr
     return ZKPOR_OK;
 }
 int32_t zkpor_pk_set_g2_compressed(zkpor_pk* pk, int which, const uint8_t* compressed64, size_t n) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || which != ZKPOR_G2_B || (n && !compressed64)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
     if (pk->g2_raw) { ZK_HIP(ctx, hipFree(pk->g2_raw)); pk->g2_raw = nullptr; }
@@ -306,6 +314,7 @@ int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, c
                             const void* delta2, int log2_domain, const uint8_t* inf_a, const uint8_t* inf_b,
                             size_t n_wires, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
                             int z_order) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !alpha || !beta || !delta || !beta2 || !delta2 || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
     if (n_wires == 0 || n_wires >= 0xffffffffull || n_public > n_wires) { ctx->err = "pk: bad wire counts"; return ZKPOR_E_ARG; }
@@ -320,6 +329,7 @@ int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, c
 }
 
 int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, size_t n_committed, uint64_t seed) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || log2_domain < 1 || log2_domain > 28 || n_wires == 0 || n_public > n_wires) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
     pk_free_arrays(pk);
@@ -347,6 +357,7 @@ int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_p
 }
 
 int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !dev_ptr || !n) return ZKPOR_E_ARG;
     if (!pk->ready) return ZKPOR_E_STATE;
     switch (which) {
@@ -361,6 +372,7 @@ int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
     return ZKPOR_OK;
 }
 int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !dev_ptr || !n || which != ZKPOR_G2_B) return ZKPOR_E_ARG;
     if (!pk->ready) return ZKPOR_E_STATE;
     *dev_ptr = pk->B2; *n = pk->n_wires;
@@ -373,20 +385,28 @@ namespace {
 
 struct ProveSums { G1XYZZ A, B1, K, Z; G2XYZZ B2; };  // the five multi-exponentiations of groth16.Prove
 
+// the caller's vectors when they are still in HOST memory (zkpor_prove_tail): prove_sums then carries them across PCIe itself,
+// in the order the GPU needs them, under its own kernels
+struct HostInputs { const void *w, *a, *b, *c; size_t n_constraints; };
+
 // Queue everything in groth16.Prove between the solver and the blinding: h = computeH(a, b, c) when d_b is given (else d_a
 // already holds the h scalars matching pk->Z), then A.w, B1.w, B2.w, K.w over one sorted digit stream of w and Z.h.
 // Works on a whole key and on a shard (pk->n_wires / pk->nZ are then the shard's lengths and d_w / d_a its scalar ranges).
+//
+// Two orders of the same work.  Inputs resident in HBM: computeH first on the main stream with decompose + sort of w hidden
+// under it on the auxiliary stream, then A, B1, K, B2 (sort of h hidden under them), then Z.  Inputs in host memory (`host`):
+// w crosses PCIe first, its digit stream is built, A, B1 and K start — and a, b, c (3/4 of the bytes) cross on the copy stream
+// while those three accumulations run; then computeH, B2 (sort of h hidden under it) and Z.
 int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c, ProveSums* out, bool do_w = true,
-                   bool do_h = true, const std::function<void()>* while_gpu_runs = nullptr) {
+                   bool do_h = true, const std::function<void()>* while_gpu_runs = nullptr, const HostInputs* host = nullptr) {
     const int n = pk->log2_domain;
     const size_t nZ = do_h ? pk->nZ : 0;
     // Two HIP streams: the ALU-bound work (NTTs, bucket accumulations) on the context's stream, the HBM-bound digit
-    // streams (decompose + radix sort) on an auxiliary one, so that sort(w) hides under the NTTs and sort(h) under the
-    // four witness accumulations.  No host synchronisation on the main stream until all five sums are queued.
+    // streams (decompose + radix sort) on an auxiliary one.  No host synchronisation on the main stream until all five sums are queued.
     if (!ctx->aux_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     hipStream_t main_s = ctx->stream, aux_s = ctx->aux_stream;
-    hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx);
-    struct EvGuard { zkpor_ctx* c; hipEvent_t e[4]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs}, main_s};
+    hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx), e_up = ev_get(ctx);
+    struct EvGuard { zkpor_ctx* c; hipEvent_t e[5]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up}, main_s};
     MsmCfg cfgw = msm_cfg(ctx, pk->n_wires);
     MsmCfg cfgh = msm_cfg(ctx, nZ ? nZ : 1);
     size_t sortw = 0, sorth = 0;
@@ -397,23 +417,34 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     ZK_TRY(ws_reserve(ctx, need_dw + need_dh + (need_aw > need_ah ? need_aw : need_ah)));
     ZK_TRY(ensure_pinned(ctx, 16 * MSM_SLOT_BYTES));
     char* pin = (char*)ctx->pinned;
+    const size_t D = (size_t)1 << n;
     ZK_HIP(ctx, hipEventRecord(e_start, main_s));
-    // 1. h = computeH(a,b,c) on the main stream, left in d_a (bit-reversed = the order of pk->Z)
-    if (d_b) ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
-    ZK_HIP(ctx, hipEventRecord(e_h, main_s));
+    if (host) {
+        // w first: everything the witness sums need
+        ZK_TRY(host_upload(ctx, const_cast<void*>(d_w), host->w, pk->n_wires * sizeof(Fr)));
+        ZK_HIP(ctx, hipEventRecord(e_up, ctx->copy_stream));
+    } else if (d_b) {
+        // 1. h = computeH(a,b,c) on the main stream, left in d_a (bit-reversed = the order of pk->Z)
+        ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
+    }
+    if (!host) ZK_HIP(ctx, hipEventRecord(e_h, main_s));
     // 2. digit stream of the witness on the auxiliary stream (serves A, B1, B2, K)
     DigitStream dsw, dsh;
     size_t off_dh = need_dw;
     const size_t mark = need_dw + need_dh;
     MsmPending pA, pB1, pK, pB2, pZ;
+    auto queue_b2 = [&]() -> int32_t {
+        ctx->ws_off = mark;
+        return msm_accumulate_launch<Fp2>(ctx, dsw, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2);
+    };
     if (do_w) {
         ctx->stream = aux_s;
-        ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_start, 0));
+        ZK_HIP(ctx, hipStreamWaitEvent(aux_s, host ? e_up : e_start, 0));
         ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw));
         ZK_HIP(ctx, hipEventRecord(e_w, aux_s));
         off_dh = ctx->ws_off;
         ctx->stream = main_s;
-        // 3. queue the four witness accumulations (they reuse one workspace region in stream order)
+        // 3. queue the witness accumulations (they reuse one workspace region in stream order)
         ctx->ws_off = mark;
         ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_w, 0));
         ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->A, pin + 0 * MSM_SLOT_BYTES, pin + 1 * MSM_SLOT_BYTES, &pA));
@@ -421,11 +452,25 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->B1, pin + 2 * MSM_SLOT_BYTES, pin + 3 * MSM_SLOT_BYTES, &pB1));
         ctx->ws_off = mark;
         ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->K, pin + 4 * MSM_SLOT_BYTES, pin + 5 * MSM_SLOT_BYTES, &pK));
-        ctx->ws_off = mark;
-        ZK_TRY(msm_accumulate_launch<Fp2>(ctx, dsw, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2));
+        if (!host) ZK_TRY(queue_b2());
+    }
+    if (host) {
+        // a, b, c cross PCIe while A, B1, K run; the rows past n_constraints are the zero padding computeH expects
+        const void* src[3] = {host->a, host->b, host->c};
+        void* dst[3] = {d_a, d_b, d_c};
+        for (int i = 0; i < 3; ++i) {
+            if (host->n_constraints < D)
+                ZK_HIP(ctx, hipMemsetAsync((Fr*)dst[i] + host->n_constraints, 0, (D - host->n_constraints) * sizeof(Fr), ctx->copy_stream));
+            ZK_TRY(host_upload(ctx, dst[i], src[i], host->n_constraints * sizeof(Fr)));
+        }
+        ZK_HIP(ctx, hipEventRecord(e_up, ctx->copy_stream));
+        ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_up, 0));
+        ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
+        ZK_HIP(ctx, hipEventRecord(e_h, main_s));
+        if (do_w) ZK_TRY(queue_b2());
     }
     if (nZ) {
-        // 4. digit stream of h on the auxiliary stream, overlapping the accumulations above
+        // 4. digit stream of h on the auxiliary stream, overlapping the accumulations queued after computeH
         ctx->stream = aux_s;
         ctx->ws_off = off_dh;
         ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_h, 0));
@@ -491,6 +536,23 @@ void assemble(const G1Affine& alpha, const G1Affine& beta, const G2Affine& beta2
     memcpy(proof_out, &ara, 64); memcpy(proof_out + 64, &bsa, 128); memcpy(proof_out + 192, &krsa, 64);
 }
 
+// r, s must be canonical residues (limbs, as an integer, below the modulus): anything else is not an fr.Element gnark could hold
+bool fr_canonical(const uint64_t x[4]) {
+    for (int i = 3; i >= 0; --i) {
+        u64 m = ((u64)FrParams::mod(2 * i + 1) << 32) | FrParams::mod(2 * i);
+        if (x[i] != m) return x[i] < m;
+    }
+    return false;
+}
+int32_t check_blinding(zkpor_ctx* ctx, const uint64_t r[4], const uint64_t s[4]) {
+    if (!fr_canonical(r) || !fr_canonical(s)) { if (ctx) ctx->err = "prove: blinding scalar not below the modulus"; return ZKPOR_E_ARG; }
+    return ZKPOR_OK;
+}
+int32_t check_same_gpu(zkpor_ctx* ctx, zkpor_pk* pk) {
+    if (pk->ctx->device != ctx->device) { ctx->err = "prove: the key lives on another GPU than the context"; return ZKPOR_E_ARG; }
+    return ZKPOR_OK;
+}
+
 template <class F>
 XYZZ<F> jac_in(const uint8_t* p) {
     Jacobian<F> j;
@@ -510,9 +572,12 @@ extern "C" {
 
 int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c,
                              const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || !d_w || !d_a || !d_b || !d_c || !r || !s || !proof_out) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
     if (pk->shard) { ctx->err = "prove: the key is a shard (zkpor_pk_keep_range): use zkpor_prove_sums_dev + zkpor_prove_assemble"; return ZKPOR_E_STATE; }
+    ZK_TRY(check_same_gpu(ctx, pk));
+    ZK_TRY(check_blinding(ctx, r, s));
     ProveSums m;
     Blind bl;
     const std::function<void()> prep = [&] { bl = blind_prepare(pk->delta, pk->delta2, r, s); };
@@ -524,6 +589,7 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
 
 // ---- single-proof split (BASELINE.json configs[4]): every GPU holds a contiguous range of each key array
 int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
     if (!pk->ready) { ctx->err = "pk: key not loaded"; return ZKPOR_E_STATE; }
@@ -553,6 +619,7 @@ int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t
 }
 
 int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_h, uint8_t sums_out[576]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || (!d_w && !d_h) || !sums_out) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
     ProveSums m;
@@ -565,6 +632,7 @@ int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, cons
 int32_t zkpor_prove_assemble(const void* alpha, const void* beta, const void* delta, const void* beta2, const void* delta2,
                              const uint8_t sums[576], const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
     if (!alpha || !beta || !delta || !beta2 || !delta2 || !sums || !r || !s || !proof_out) return ZKPOR_E_ARG;
+    ZK_TRY(check_blinding(nullptr, r, s));
     G1Affine a1, b1, d1; G2Affine b2, d2;
     memcpy(&a1, alpha, 64); memcpy(&b1, beta, 64); memcpy(&d1, delta, 64); memcpy(&b2, beta2, 128); memcpy(&d2, delta2, 128);
     ProveSums m;
@@ -575,6 +643,7 @@ int32_t zkpor_prove_assemble(const void* alpha, const void* beta, const void* de
 }
 
 int32_t zkpor_pk_consts(zkpor_pk* pk, void* alpha, void* beta, void* delta, void* beta2, void* delta2) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !alpha || !beta || !delta || !beta2 || !delta2) return ZKPOR_E_ARG;
     if (!pk->ready) { pk->ctx->err = "pk: key not loaded"; return ZKPOR_E_STATE; }
     memcpy(alpha, &pk->alpha, 64); memcpy(beta, &pk->beta, 64); memcpy(delta, &pk->delta, 64);
@@ -585,28 +654,65 @@ int32_t zkpor_pk_consts(zkpor_pk* pk, void* alpha, void* beta, void* delta, void
 int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                          const uint64_t* c, size_t n_constraints, const uint64_t r[4], const uint64_t s[4],
                          uint8_t proof_out[256]) {
-    if (!ctx || !pk || !w || !a || !b || !c) return ZKPOR_E_ARG;
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !pk || !w || !a || !b || !c || !r || !s || !proof_out) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
+    if (pk->shard) { ctx->err = "prove: the key is a shard (zkpor_pk_keep_range): use zkpor_prove_sums_dev + zkpor_prove_assemble"; return ZKPOR_E_STATE; }
     size_t D = (size_t)1 << pk->log2_domain;
     if (n_constraints > D) { ctx->err = "prove: more constraints than the domain"; return ZKPOR_E_ARG; }
-    Fr* d = nullptr;
-    ZK_HIP(ctx, hipMalloc((void**)&d, (3 * D + pk->n_wires) * sizeof(Fr)));
-    int32_t rc = ZKPOR_OK;
-    const uint64_t* src[3] = {a, b, c};
-    for (int i = 0; i < 3 && rc == ZKPOR_OK; ++i) {
-        if (hipMemsetAsync(d + i * D, 0, D * sizeof(Fr), ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(d + i * D, src[i], n_constraints * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-            ctx->err = "H2D failed"; rc = ZKPOR_E_HIP;
-        }
+    ZK_TRY(check_same_gpu(ctx, pk));
+    ZK_TRY(check_blinding(ctx, r, s));
+    // persistent staging in HBM (no allocation per proof); the copies are queued by prove_sums in the order the GPU needs them
+    ZK_TRY(stage_reserve(ctx, (3 * D + pk->n_wires) * sizeof(Fr)));
+    Fr* d = (Fr*)ctx->stage;
+    HostInputs host{w, a, b, c, n_constraints};
+    ProveSums m;
+    Blind bl;
+    const std::function<void()> prep = [&] { bl = blind_prepare(pk->delta, pk->delta2, r, s); };
+    int32_t rc = prove_sums(ctx, pk, d + 3 * D, d, d + D, d + 2 * D, &m, true, true, &prep, &host);
+    if (rc != ZKPOR_OK) {  // nothing may still read the caller's memory or the staging area when the call returns
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+        return rc;
     }
-    if (rc == ZKPOR_OK && hipMemcpyAsync(d + 3 * D, w, pk->n_wires * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
-    if (rc == ZKPOR_OK) rc = zkpor_prove_tail_dev(ctx, pk, d + 3 * D, d, d + D, d + 2 * D, r, s, proof_out);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
+    HostPhase hp(ctx, "host_assembly");
+    assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
+    return ZKPOR_OK;
+}
+
+// uniform Fr from the operating system's CSPRNG: 32 bytes from getrandom(2), top two bits cleared, rejected unless below the
+// modulus (acceptance ~ 0.76) — the construction of gnark-crypto's fr.Element.SetRandom.  The canonical limbs are used as the
+// Montgomery representation directly: x -> x R^-1 is a bijection of Fr, so the residue is uniform either way.
+static int32_t fr_random_os(zkpor_ctx* ctx, uint64_t out[4]) {
+    for (int tries = 0; tries < 256; ++tries) {
+        size_t got = 0;
+        while (got < 32) {
+            ssize_t k = getrandom((char*)out + got, 32 - got, 0);
+            if (k < 0) { if (errno == EINTR) continue; ctx->err = "prove: getrandom failed"; return ZKPOR_E_STATE; }
+            got += (size_t)k;
+        }
+        out[3] &= 0x3fffffffffffffffULL;
+        if (fr_canonical(out)) return ZKPOR_OK;
+    }
+    ctx->err = "prove: getrandom returned no canonical value";
+    return ZKPOR_E_STATE;
+}
+int32_t zkpor_prove_tail_rand(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
+                              const uint64_t* c, size_t n_constraints, uint64_t r_out[4], uint64_t s_out[4],
+                              uint8_t proof_out[256]) {
+    if (!ctx) return ZKPOR_E_ARG;
+    uint64_t r[4], s[4];
+    ZK_TRY(fr_random_os(ctx, r));
+    ZK_TRY(fr_random_os(ctx, s));
+    int32_t rc = zkpor_prove_tail(ctx, pk, w, a, b, c, n_constraints, r, s, proof_out);
+    if (r_out) memcpy(r_out, r, 32);
+    if (s_out) memcpy(s_out, s, 32);
     return rc;
 }
 
 int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || (n && !d_values) || !out_commit || !out_pok) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "commit: key not loaded"; return ZKPOR_E_STATE; }
     if (n != pk->nC) { ctx->err = "commit: value count differs from the commitment basis"; return ZKPOR_E_ARG; }
@@ -634,15 +740,20 @@ int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, siz
     return ZKPOR_OK;
 }
 int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || (n && !values) || !out_commit || !out_pok) return ZKPOR_E_ARG;
-    Fr* d = nullptr;
-    ZK_HIP(ctx, hipMalloc((void**)&d, (n ? n : 1) * sizeof(Fr)));
-    int32_t rc = ZKPOR_OK;
-    if (n && hipMemcpyAsync(d, values, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
-    if (rc == ZKPOR_OK) rc = zkpor_commit_dev(ctx, pk, d, n, out_commit, out_pok);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
-    return rc;
+    if (!pk->ready) { ctx->err = "commit: key not loaded"; return ZKPOR_E_STATE; }
+    // the committed values go behind the prove tail's vectors in the staging area, so a commit between two proofs (the BSB22
+    // hint runs inside the solver) never forces the area to be re-laid out
+    size_t D = (size_t)1 << pk->log2_domain;
+    size_t off = (3 * D + pk->n_wires) * sizeof(Fr);
+    ZK_TRY(stage_reserve(ctx, off + (n ? n : 1) * sizeof(Fr)));
+    Fr* d = (Fr*)(ctx->stage + off);
+    if (n) {
+        ZK_TRY(host_upload(ctx, d, values, n * sizeof(Fr)));
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    }
+    return zkpor_commit_dev(ctx, pk, d, n, out_commit, out_pok);
 }
 
 static void fp_be(const Fp& x, uint8_t* out) {
@@ -650,26 +761,35 @@ static void fp_be(const Fp& x, uint8_t* out) {
     for (int i = 0; i < 8; ++i)
         for (int j = 0; j < 4; ++j) out[31 - (i * 4 + j)] = (uint8_t)(c.v[i] >> (8 * j));
 }
+// gnark-crypto RawBytes: an uncompressed point is X | Y big-endian with the two top bits of byte 0 clear (mUncompressed = 0b00);
+// the point at infinity is the flag mUncompressedInfinity = 0b01 << 6 = 0x40 in byte 0 and zeros after it (marshal.go) — NOT 64 zero
+// bytes, which a strict decoder would read as the off-curve point (0, 0)
+static void g1_raw(const Fp* xy, uint8_t* out) {
+    if (xy[0].is_zero() && xy[1].is_zero()) { memset(out, 0, 64); out[0] = 0x40; return; }
+    fp_be(xy[0], out); fp_be(xy[1], out + 32);
+}
+static void g2_raw(const Fp* p, uint8_t* out) {  // p = X.A0, X.A1, Y.A0, Y.A1 -> X.A1 | X.A0 | Y.A1 | Y.A0
+    if (p[0].is_zero() && p[1].is_zero() && p[2].is_zero() && p[3].is_zero()) { memset(out, 0, 128); out[0] = 0x40; return; }
+    fp_be(p[1], out); fp_be(p[0], out + 32); fp_be(p[3], out + 64); fp_be(p[2], out + 96);
+}
 int32_t zkpor_proof_write_raw(const uint8_t proof[256], const uint8_t* commitments, uint32_t n_commitments,
                               const uint8_t pok[64], uint8_t* out, size_t out_cap, size_t* out_len) {
     if (!proof || !out || !out_len || (n_commitments && (!commitments || !pok))) return ZKPOR_E_ARG;
     size_t need = 256 + 4 + (size_t)n_commitments * 64 + 64;
     if (out_cap < need) return ZKPOR_E_ARG;
     const Fp* f = (const Fp*)proof;
-    fp_be(f[0], out); fp_be(f[1], out + 32);                          // Ar
-    fp_be(f[3], out + 64); fp_be(f[2], out + 96);                     // Bs.X = A1 | A0
-    fp_be(f[5], out + 128); fp_be(f[4], out + 160);                   // Bs.Y = A1 | A0
-    fp_be(f[6], out + 192); fp_be(f[7], out + 224);                   // Krs
+    g1_raw(f, out);                                                   // Ar
+    g2_raw(f + 2, out + 64);                                          // Bs
+    g1_raw(f + 6, out + 192);                                         // Krs
     out[256] = (uint8_t)(n_commitments >> 24); out[257] = (uint8_t)(n_commitments >> 16);
     out[258] = (uint8_t)(n_commitments >> 8); out[259] = (uint8_t)n_commitments;
     size_t off = 260;
     for (uint32_t i = 0; i < n_commitments; ++i) {
-        const Fp* c = (const Fp*)(commitments + 64 * (size_t)i);
-        fp_be(c[0], out + off); fp_be(c[1], out + off + 32);
+        g1_raw((const Fp*)(commitments + 64 * (size_t)i), out + off);
         off += 64;
     }
-    if (pok) { const Fp* p = (const Fp*)pok; fp_be(p[0], out + off); fp_be(p[1], out + off + 32); }
-    else memset(out + off, 0, 64);
+    if (pok) g1_raw((const Fp*)pok, out + off);
+    else { memset(out + off, 0, 64); out[off] = 0x40; }               // no commitment: the knowledge proof is the identity
     off += 64;
     *out_len = off;
     return ZKPOR_OK;

@@ -139,6 +139,7 @@ int32_t zkpor_pk_gnark_layout(const uint8_t* data, size_t len, zkpor_pk_layout_t
 
 int32_t zkpor_pk_load_gnark_mem(zkpor_pk* pk, const uint8_t* data, size_t len, size_t n_public, const uint32_t* committed_idx,
                                 size_t n_committed, zkpor_pk_layout_t* info) {
+    ZK_ENTER(pk ? zk_pk_ctx(pk)->device : -1);
     if (!pk) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = zk_pk_ctx(pk);
     zkpor_pk_layout_t L;
@@ -186,6 +187,7 @@ int32_t zkpor_pk_load_gnark_mem(zkpor_pk* pk, const uint8_t* data, size_t len, s
 int32_t zkpor_pk_load_gnark_shard_mem(zkpor_pk* pk, const uint8_t* data, size_t len, size_t n_public, const uint32_t* committed_idx,
                                       size_t n_committed, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi,
                                       zkpor_pk_layout_t* info) {
+    ZK_ENTER(pk ? zk_pk_ctx(pk)->device : -1);
     if (!pk) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = zk_pk_ctx(pk);
     zkpor_pk_layout_t L;
@@ -255,6 +257,7 @@ static int32_t with_mapped_file(zkpor_ctx* ctx, const char* path, const std::fun
 
 int32_t zkpor_pk_load_gnark_shard(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
                                   size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi, zkpor_pk_layout_t* info) {
+    ZK_ENTER(pk ? zk_pk_ctx(pk)->device : -1);
     if (!pk || !path) return ZKPOR_E_ARG;
     return with_mapped_file(zk_pk_ctx(pk), path, [&](const uint8_t* d, size_t n) {
         return zkpor_pk_load_gnark_shard_mem(pk, d, n, n_public, committed_idx, n_committed, wire_lo, wire_hi, z_lo, z_hi, info);
@@ -263,6 +266,7 @@ int32_t zkpor_pk_load_gnark_shard(zkpor_pk* pk, const char* path, size_t n_publi
 
 int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
                             zkpor_pk_layout_t* info) {
+    ZK_ENTER(pk ? zk_pk_ctx(pk)->device : -1);
     if (!pk || !path) return ZKPOR_E_ARG;
     return with_mapped_file(zk_pk_ctx(pk), path, [&](const uint8_t* d, size_t n) {
         return zkpor_pk_load_gnark_mem(pk, d, n, n_public, committed_idx, n_committed, info);

@@ -956,6 +956,7 @@ using namespace zk;
 extern "C" {
 
 int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, size_t count, uint64_t* out) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !inputs || !out || len < 1 || count == 0) return ZKPOR_E_ARG;
     PosDev P;
     ZK_TRY(pos_dev(ctx, &P));
@@ -977,6 +978,7 @@ int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, 
 
 int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, const zkpor_asset_t* assets,
                               size_t n_assets_total, size_t n, int tier, uint8_t* out32) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !accounts || !out32 || n == 0 || tier < 1 || (n_assets_total && !assets)) return ZKPOR_E_ARG;
     for (size_t i = 0; i < n; ++i) {
         if (accounts[i].n_assets > (uint32_t)tier || (size_t)accounts[i].asset_off + accounts[i].n_assets > n_assets_total) {
@@ -1005,6 +1007,7 @@ int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, c
 
 int32_t zkpor_merkle_build_dev(zkpor_ctx* ctx, const void* d_leaves_mont, size_t n, int depth,
                                const uint64_t nil_leaf_mont[4], uint64_t root_mont[4]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && !d_leaves_mont) || !nil_leaf_mont || !root_mont) return ZKPOR_E_ARG;
     Fr nil, root;
     memcpy(&nil, nil_leaf_mont, 32);
@@ -1015,6 +1018,7 @@ int32_t zkpor_merkle_build_dev(zkpor_ctx* ctx, const void* d_leaves_mont, size_t
 
 int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n, int depth, const uint8_t nil_leaf[32],
                            uint8_t* levels_out, uint8_t root_out[32]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && !leaves32_be) || !nil_leaf || !root_out) return ZKPOR_E_ARG;
     if (depth < 1 || depth > 32 || n > ((size_t)1 << depth)) { ctx->err = "merkle: bad depth / leaf count"; return ZKPOR_E_ARG; }
     Fr nil = from_be32(nil_leaf);
@@ -1045,6 +1049,7 @@ int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n,
 
 // ---- FixedDepthMerkleTree -------------------------------------------------------------------------------------------
 int32_t zkpor_tree_create(zkpor_ctx* ctx, int depth, const uint8_t nil_leaf[32], uint64_t capacity, zkpor_tree** out) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !nil_leaf || !out) return ZKPOR_E_ARG;
     // NewFixedDepthMerkleTree panics on these (merkletree.go:138-146); here they are argument errors
     if (depth <= 0 || depth > 32) { ctx->err = "tree: depth must be in [1,32]"; return ZKPOR_E_ARG; }
@@ -1075,16 +1080,19 @@ int32_t zkpor_tree_create(zkpor_ctx* ctx, int depth, const uint8_t nil_leaf[32],
     return ZKPOR_OK;
 }
 void zkpor_tree_destroy(zkpor_tree* t) {
+    ZK_ENTER(t ? t->ctx->device : -1);
     if (!t) return;
     (void)hipStreamSynchronize(t->ctx->stream);
     tree_free(t);
 }
 int32_t zkpor_tree_nil_hash(zkpor_tree* t, int level, uint8_t out[32]) {
+    ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || !out || level < 0 || level > t->depth) return ZKPOR_E_ARG;
     fr_to_be_host(t->nil_host[level], out);
     return ZKPOR_OK;
 }
 int32_t zkpor_tree_set(zkpor_tree* t, const uint32_t* keys, const uint8_t* values32_be, size_t n) {
+    ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && (!keys || !values32_be))) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = t->ctx;
     for (size_t i = 0; i < n; ++i)
@@ -1102,6 +1110,7 @@ int32_t zkpor_tree_set(zkpor_tree* t, const uint32_t* keys, const uint8_t* value
     return ZKPOR_OK;
 }
 int32_t zkpor_tree_set_range_dev(zkpor_tree* t, uint64_t first_key, const void* d_leaves_mont, size_t n) {
+    ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && !d_leaves_mont)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = t->ctx;
     if (first_key + n > t->capacity) { ctx->err = "tree: key range exceeds capacity"; return ZKPOR_E_ARG; }
@@ -1111,6 +1120,7 @@ int32_t zkpor_tree_set_range_dev(zkpor_tree* t, uint64_t first_key, const void* 
     return ZKPOR_OK;
 }
 int32_t zkpor_tree_build(zkpor_tree* t) {
+    ZK_ENTER(t ? t->ctx->device : -1);
     if (!t) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = t->ctx;
     PosDev P;
@@ -1135,6 +1145,7 @@ int32_t zkpor_tree_build(zkpor_tree* t) {
     return ZKPOR_OK;
 }
 int32_t zkpor_tree_root(zkpor_tree* t, uint8_t out[32]) {
+    ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || !out) return ZKPOR_E_ARG;
     fr_to_be_host(t->root, out);
     return ZKPOR_OK;
@@ -1155,10 +1166,12 @@ static int32_t tree_query(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t
     return ZKPOR_OK;
 }
 int32_t zkpor_tree_get(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out32) {
+    ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && (!keys || !out32))) return ZKPOR_E_ARG;
     return tree_query(t, keys, n, out32, false);  // keys >= capacity read as nil (:288-290)
 }
 int32_t zkpor_tree_get_proofs(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out) {
+    ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && (!keys || !out))) return ZKPOR_E_ARG;
     for (size_t i = 0; i < n; ++i)
         if (t->depth < 32 && ((uint64_t)keys[i] >> t->depth) != 0) {  // GetProof's error return (:298-300)
@@ -1169,6 +1182,7 @@ int32_t zkpor_tree_get_proofs(zkpor_tree* t, const uint32_t* keys, size_t n, uin
 }
 int32_t zkpor_merkle_verify_proofs(zkpor_ctx* ctx, const uint8_t root[32], const uint32_t* keys, const uint8_t* proofs,
                                    const uint8_t* leaves32_be, size_t n, int depth, uint8_t* ok_out) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !root || (n && (!keys || !proofs || !leaves32_be || !ok_out))) return ZKPOR_E_ARG;
     if (depth < 1 || depth > 32) { ctx->err = "merkle: bad depth"; return ZKPOR_E_ARG; }
     if (n == 0) return ZKPOR_OK;
@@ -1189,6 +1203,7 @@ int32_t zkpor_merkle_verify_proofs(zkpor_ctx* ctx, const uint8_t root[32], const
 // ---- CEX asset-list commitments / batch commitments -------------------------------------------------------------------
 int32_t zkpor_cex_commitments(zkpor_ctx* ctx, const zkpor_cex_asset_const_t* assets, size_t n_assets, const zkpor_cex_totals_t* totals,
                               size_t n_states, uint8_t* out32) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !assets || !totals || !out32 || n_assets == 0 || n_assets > 0xffffu) return ZKPOR_E_ARG;
     if (n_states == 0) return ZKPOR_OK;
     if (n_states > 0xffffffffull) return ZKPOR_E_ARG;
@@ -1217,6 +1232,7 @@ int32_t zkpor_cex_commitments(zkpor_ctx* ctx, const zkpor_cex_asset_const_t* ass
 }
 int32_t zkpor_batch_commitments(zkpor_ctx* ctx, const uint8_t* roots32, const uint8_t* before32, const uint8_t* after32,
                                 const uint32_t* min_index, const uint32_t* max_index, size_t n, uint8_t* out32) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && (!roots32 || !before32 || !after32 || !min_index || !max_index || !out32))) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
     PosDev P;
@@ -1238,6 +1254,7 @@ int32_t zkpor_batch_commitments(zkpor_ctx* ctx, const uint8_t* roots32, const ui
 // ---- account totals / collateral tiers ----------------------------------------------------------------------------------
 int32_t zkpor_account_totals(zkpor_ctx* ctx, zkpor_account_t* accounts, const zkpor_asset_t* assets, size_t n_assets_total, size_t n,
                              const zkpor_cex_asset_const_t* cex, size_t n_cex, uint8_t* tier_info_out, uint8_t* valid_out) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !accounts || !cex || n_cex == 0 || (n_assets_total && !assets)) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
     if (n > 0xffffffffull || n_cex > 0xffffffffull) return ZKPOR_E_ARG;
@@ -1269,6 +1286,7 @@ int32_t zkpor_account_totals(zkpor_ctx* ctx, zkpor_account_t* accounts, const zk
 int32_t zkpor_tree_set_accounts(zkpor_tree* t, uint64_t first_key, zkpor_account_t* accounts, const zkpor_asset_t* assets,
                                 size_t n_assets_total, size_t n, int tier, const zkpor_cex_asset_const_t* cex_or_null, size_t n_cex,
                                 uint8_t* valid_out_or_null) {
+    ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || !accounts || n == 0 || tier < 1 || (n_assets_total && !assets)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = t->ctx;
     if (first_key + n > t->capacity) { ctx->err = "tree: key range exceeds capacity"; return ZKPOR_E_ARG; }

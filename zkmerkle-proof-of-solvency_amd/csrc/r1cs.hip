@@ -66,6 +66,7 @@ extern "C" {
 
 int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, const uint64_t* coeff_table, size_t n_coeff,
                           zkpor_r1cs** out) {
+    ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out || !coeff_table || n_coeff == 0 || n_wires == 0 || n_wires > 0xffffffffull) return ZKPOR_E_ARG;
     zkpor_r1cs* r = new zkpor_r1cs();
     r->ctx = ctx; r->n_constraints = n_constraints; r->n_wires = n_wires; r->n_coeff = n_coeff;
@@ -86,12 +87,14 @@ int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, 
     return ZKPOR_OK;
 }
 void zkpor_r1cs_destroy(zkpor_r1cs* r) {
+    ZK_ENTER(r ? r->ctx->device : -1);
     if (!r) return;
     (void)hipStreamSynchronize(r->ctx->stream);
     r1cs_free(r);
 }
 int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr, const uint32_t* coeff_ids, const uint32_t* wire_ids,
                               size_t nnz) {
+    ZK_ENTER(r ? r->ctx->device : -1);
     if (!r || which < 0 || which > 2 || !row_ptr || (nnz && (!coeff_ids || !wire_ids))) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = r->ctx;
     // validate on the host: the kernel indexes with these
@@ -113,6 +116,7 @@ int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr,
     return ZKPOR_OK;
 }
 int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
+    ZK_ENTER(r ? r->ctx->device : -1);
     if (!r || !d_w || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = r->ctx;
     if (domain_size < r->n_constraints) { ctx->err = "r1cs: domain smaller than the constraint count"; return ZKPOR_E_ARG; }
@@ -129,6 +133,7 @@ int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b
 }
 /* host-buffer form for tests and small circuits: w in, a/b/c (n_constraints each) out */
 int32_t zkpor_r1cs_eval(zkpor_r1cs* r, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c) {
+    ZK_ENTER(r ? r->ctx->device : -1);
     if (!r || !w || !a || !b || !c) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = r->ctx;
     const size_t n = r->n_constraints;

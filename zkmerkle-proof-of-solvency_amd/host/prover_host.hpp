@@ -53,6 +53,17 @@ public:
             if (it->second.Status == status) { *out = it->second; return Ok; }
         return DbErrNotFound;
     }
+    // Rerun with several workers in ONE process: GetLatestBatchWitnessByStatus does not change the row (the reference's rerun is
+    // one process per invocation, prover.go:107-137), so N workers would all fetch — and prove — the same height.  A worker
+    // therefore takes the latest row of `status` that no other worker of this process is holding; the claim is in-memory only
+    // (a crash loses it, which is what rerun is for) and is dropped by ReleaseClaim once the row is Finished.
+    Err ClaimLatestBatchWitnessByStatus(int status, BatchWitness* out) {
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto it = rows_.rbegin(); it != rows_.rend(); ++it)
+            if (it->second.Status == status && !claimed_.count(it->first)) { claimed_[it->first] = true; *out = it->second; return Ok; }
+        return DbErrNotFound;
+    }
+    void ReleaseClaim(int64_t height) { std::lock_guard<std::mutex> g(mu_); claimed_.erase(height); }
     Err UpdateBatchWitnessStatus(const BatchWitness& w, int status) {
         std::lock_guard<std::mutex> g(mu_);
         auto it = rows_.find(w.Height);
@@ -69,6 +80,7 @@ public:
 private:
     std::mutex mu_;
     std::map<int64_t, BatchWitness> rows_;
+    std::map<int64_t, bool> claimed_;
 };
 
 class ProofModel {  // BatchNumber is unique (proof_model.go:33)
@@ -126,8 +138,8 @@ public:
     }
     Err FetchBatchWitnessForRerun(std::vector<BatchWitness>* out) {  // prover.go:107-137
         BatchWitness w;
-        Err e = witnessModel->GetLatestBatchWitnessByStatus(StatusReceived, &w);
-        if (e == DbErrNotFound) e = witnessModel->GetLatestBatchWitnessByStatus(StatusPublished, &w);
+        Err e = witnessModel->ClaimLatestBatchWitnessByStatus(StatusReceived, &w);
+        if (e == DbErrNotFound) e = witnessModel->ClaimLatestBatchWitnessByStatus(StatusPublished, &w);
         if (e != Ok) return e;
         out->assign(1, w);
         return Ok;
@@ -138,21 +150,27 @@ public:
         for (;;) {
             std::vector<BatchWitness> batch;
             Err e = rerun ? FetchBatchWitnessForRerun(&batch) : FetchBatchWitness(&batch);
-            if (e == QueueNil) return made;                      // "There is no task left in task queue"
-            if (e == DbErrNotFound) { if (rerun) return made; continue; }  // someone else owns that height
+            if (e == QueueNil) return made;                      // "There is no task left in task queue" (:155-159)
+            if (e == DbErrNotFound) return made;                 // queue mode: "no published status witness in db, so quit" (:150-154);
+                                                                 // rerun: "no received status witness in db, so quit" (:167-171)
             for (auto& bw : batch) {
                 std::string raw;
                 int assets = 0;
-                if (prove_(gpu_, bw, &raw, &assets) != 0) return -1;
-                if (proofModel->GetProofByBatchNumber(bw.Height, nullptr) == Ok) {  // duplicate-proof guard
+                if (prove_(gpu_, bw, &raw, &assets) != 0) { if (rerun) witnessModel->ReleaseClaim(bw.Height); return -1; }
+                if (proofModel->GetProofByBatchNumber(bw.Height, nullptr) == Ok) {  // duplicate-proof guard (:208-225)
                     witnessModel->UpdateBatchWitnessStatus(bw, StatusFinished);
+                    if (rerun) witnessModel->ReleaseClaim(bw.Height);
                     continue;
                 }
                 Proof row;
                 row.ProofInfo = raw; row.BatchNumber = bw.Height; row.AssetsCount = assets;
-                if (proofModel->CreateProof(row) != Ok) return -1;
+                Err ce = proofModel->CreateProof(row);
+                // the unique index on BatchNumber decided a race between the guard above and this insert: the height IS proved
+                // (by whoever won), which is all the status column records — not a failure of this worker
+                if (ce != Ok && ce != DbErrDuplicate) { if (rerun) witnessModel->ReleaseClaim(bw.Height); return -1; }
                 witnessModel->UpdateBatchWitnessStatus(bw, StatusFinished);
-                ++made;
+                if (rerun) witnessModel->ReleaseClaim(bw.Height);
+                if (ce == Ok) ++made;
             }
         }
     }
