@@ -4,6 +4,7 @@
 #include "algos.hpp"
 #include "poseidon.hpp"
 #include "marshal.hpp"
+#include "cpubase.hpp"
 #include <memory>
 
 using namespace orc;
@@ -398,5 +399,26 @@ void orc_proof_raw(const uint8_t* proof256, uint8_t* out256) {
     }
     if (zero(6, 8)) out256[192] = 0x40; else { f[6].to_be_bytes(out256 + 192); f[7].to_be_bytes(out256 + 224); }
 }
+
+
+// ---- the CPU baseline of bench.py (cpubase.hpp): performance-minded port, checked against the plain oracle in tests ----
+void orc_fast_g1_msm(const G1A* pts, const Fr* sc, size_t n, int window, G1A* out) {
+    *out = fast::to_oracle_affine(fast::multi_exp<fast::FFp>(pts, sc, n, window));
+}
+void orc_fast_g2_msm(const G2A* pts, const Fr* sc, size_t n, int window, G2A* out) {
+    *out = fast::to_oracle_affine(fast::multi_exp<fast::FFp2>(pts, sc, n, window));
+}
+// a, b, c: 2^log2d elements each (zero padded); h is left in a (bit-reversed order)
+void orc_fast_compute_h(Fr* a, Fr* b, Fr* c, int log2d) {
+    fast::FastDomain d(log2d);
+    fast::compute_h(d, (fast::FFr*)a, (fast::FFr*)b, (fast::FFr*)c);
+}
+// times: fft, 4 x G1, G2, 2 x commitment (seconds); outputs keep the work observable
+void orc_fast_prove_tail_work(int log2d, const G1A* g1, const G2A* g2, const Fr* w, Fr* a, Fr* b, Fr* c, size_t n_commit, double* times,
+                              G1A* g1_out, G2A* g2_out) {
+    fast::TailTimes t = fast::prove_tail_work(log2d, g1, g2, w, a, b, c, n_commit, g1_out, g2_out);
+    times[0] = t.fft_s; times[1] = t.msm_g1_s; times[2] = t.msm_g2_s; times[3] = t.commit_s;
+}
+int orc_threads() { return fast::threads(); }
 
 }  // extern "C"

@@ -466,3 +466,43 @@ def proof_raw(proof256):
 
 def selftest():
     return lib().orc_selftest()
+
+
+# ---- the CPU baseline port (cpubase.hpp): used by bench.py's cpu_baseline leg, checked against the plain oracle in tests ----
+def fast_g1_msm(pts, sc, window=0):
+    pts = _u64(pts); sc = _u64(sc)
+    out = np.empty((8,), dtype=np.uint64)
+    lib().orc_fast_g1_msm(_p(pts), _p(sc), ctypes.c_size_t(sc.shape[0]), ctypes.c_int(window), _p(out))
+    return out
+
+
+def fast_g2_msm(pts, sc, window=0):
+    pts = _u64(pts); sc = _u64(sc)
+    out = np.empty((16,), dtype=np.uint64)
+    lib().orc_fast_g2_msm(_p(pts), _p(sc), ctypes.c_size_t(sc.shape[0]), ctypes.c_int(window), _p(out))
+    return out
+
+
+def fast_compute_h(a, b, c, log2d):
+    """a, b, c: n_cons rows; returns h (2^log2d rows, the order compute_h returns)"""
+    n = 1 << log2d
+    bufs = []
+    for v in (a, b, c):
+        v = _u64(v)
+        p = np.zeros((n, 4), dtype=np.uint64)
+        p[: v.shape[0]] = v
+        bufs.append(p)
+    lib().orc_fast_compute_h(_p(bufs[0]), _p(bufs[1]), _p(bufs[2]), ctypes.c_int(log2d))
+    return bufs[0]
+
+
+def fast_prove_tail_work(log2d, g1, g2, w, a, b, c, n_commit):
+    """one prove tail's worth of CPU work on all cores; a, b, c are overwritten.  Returns (fft_s, g1_s, g2_s, commit_s)"""
+    times = np.zeros(4, dtype=np.float64)
+    o1 = np.empty(8, dtype=np.uint64); o2 = np.empty(16, dtype=np.uint64)
+    lib().orc_fast_prove_tail_work(ctypes.c_int(log2d), _p(g1), _p(g2), _p(w), _p(a), _p(b), _p(c), ctypes.c_size_t(n_commit), _p(times), _p(o1), _p(o2))
+    return tuple(float(t) for t in times)
+
+
+def threads():
+    return int(lib().orc_threads())
