@@ -110,6 +110,27 @@ def cpu_baseline(log2_sample, log2_full, commit_frac):
                       "32 vCPU for gnark (docs/updated_proof_of_solvency_to_mitigate_dummy_user_attack.md:201)"}
 
 
+def solver_budget(gpu_ms_per_proof, host_threads, gpus_per_node=8):
+    """The Amdahl term of a deployed prover as a printed number.  `value` is the prove TAIL; r1cs.Solve + hints
+    stay gnark's Go code on host cores and run as the first stage of a two-stage pipeline (host/prover_host.hpp Pipeline:
+    solve(i+1) || prove(i), bounded queue).  The GPU absorbs one solved witness per `gpu_ms_per_proof`; what gnark's solver needs is
+    not measurable here (no Go) and is bracketed from the reference's published 62 s per proof on 32 vCPU
+    (docs/updated_proof_of_solvency_to_mitigate_dummy_user_attack.md:201) and the survey's 15-25 % solver share."""
+    lo, hi = 62.0 * 32 * 0.15, 62.0 * 32 * 0.25                     # vCPU-seconds per solve
+    tpg = host_threads / float(gpus_per_node)
+    gpu_rate = 1e3 / gpu_ms_per_proof
+    return {"gpu_ms_per_proof": gpu_ms_per_proof,
+            "solver_ms_per_proof_absorbed_per_solver_thread_group": gpu_ms_per_proof,
+            "gnark_solver_vcpu_seconds_per_proof_est": [round(lo, 1), round(hi, 1)],
+            "host_threads": host_threads, "gpus_per_node": gpus_per_node, "host_threads_per_gpu": tpg,
+            "vcpus_per_gpu_to_keep_the_gpu_busy": [round(lo * gpu_rate), round(hi * gpu_rate)],
+            "solver_bound_proofs_per_s_per_gpu_on_this_host": [round(tpg / hi, 4), round(tpg / lo, 4)],
+            "gpu_busy_fraction_if_fed_by_gnarks_solver_on_this_host": [round(min(1.0, tpg / hi / gpu_rate), 4), round(min(1.0, tpg / lo / gpu_rate), 4)],
+            "note": "model, not a measurement: assumes the solver scales linearly over the host threads of one GPU's share; the fix on the "
+                    "roadmap is SURVEY.md §8 f4 (a structured witness generator for BatchCreateUserCircuit on the device) with f1 "
+                    "(a, b, c evaluated in HBM, zkpor_r1cs_*) already built"}
+
+
 def shard_heights(n_batches, rank, world):
     """contiguous shard of batch heights for this rank: every height exactly once (host/prover_host.hpp shard_range)"""
     base, extra = divmod(n_batches, world)
@@ -615,6 +636,7 @@ def main():
                     out["cpu_baseline"] = cpu_baseline(args.cpu_log2, log2, 0.25)
                 except Exception as e:  # the baseline is informational; never lose the GPU line over it
                     out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+            out["solver_budget"] = solver_budget(dt / args.steps * 1e3, os.cpu_count() or 1)
             try:
                 out["acceptance"] = verifier_acceptance(ctx)
             except Exception as e:

@@ -126,11 +126,15 @@ int32_t zkpor_pk_gnark_layout(const uint8_t* data, size_t len, zkpor_pk_layout_t
  * re-laid out wire-indexed, exactly as after zkpor_pk_set_*_compressed + zkpor_pk_set_consts.  The stream does not say
  * which wires K leaves out, so the caller passes what the constraint system knows: n_public (ONE wire included) and the
  * committed + commitment wire indices (gnark r1cs.CommitmentInfo); len(K) must equal nbWires - n_public - n_committed.
+ * z_order says how the file's G1.Z relates to the coefficient index of h (ZKPOR_Z_ORDER_*): the stream does not record it and the
+ * two conventions load equally cleanly — a wrong choice yields proofs the verifier rejects, so it is the caller's statement about
+ * the gnark version that wrote the key (bit-reversed at setup since gnark 0.9, which includes the fork pinned at go.mod:57-60;
+ * natural before), to be confirmed once per key by verifying one proof.
  * info (may be NULL) receives the layout.  zkpor_pk_load_gnark maps `path` read-only and calls the _mem form. */
 int32_t zkpor_pk_load_gnark_mem(zkpor_pk* pk, const uint8_t* data, size_t len, size_t n_public,
-                                const uint32_t* committed_idx, size_t n_committed, zkpor_pk_layout_t* info);
+                                const uint32_t* committed_idx, size_t n_committed, int z_order, zkpor_pk_layout_t* info);
 int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx,
-                            size_t n_committed, zkpor_pk_layout_t* info);
+                            size_t n_committed, int z_order, zkpor_pk_layout_t* info);
 /* TEST/BENCH utility (no reference counterpart): fill every array of the key with valid curve points generated
  * on the device (random walks from seeded multiples of the generators).  Sizes follow SURVEY.md §8(d) C2 when
  * n_wires = 2^log2_domain.  The key is NOT a sound Groth16 key; it exercises the prover's data path at scale. */
@@ -199,12 +203,14 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
  * split.py shows the exchange; gnark has no counterpart (its MultiExp splits over CPU tasks). */
 /* one rank's share straight from the key file: only wires [wire_lo, wire_hi) of A, B1, B2, K (located in gnark's compacted
  * arrays by counting the infinity / removed masks in front of the range) and points [z_lo, z_hi) of Z are uploaded and
- * decompressed, so no GPU ever holds more than its share; the result is a shard exactly as after zkpor_pk_keep_range. */
+ * decompressed, so no GPU ever holds more than its share; the result is a shard exactly as after zkpor_pk_keep_range.
+ * z_order must be ZKPOR_Z_ORDER_BITREV (a range of the prover's order is contiguous only in such a file; for a natural-order key
+ * load it whole and use zkpor_pk_keep_range). */
 int32_t zkpor_pk_load_gnark_shard_mem(zkpor_pk* pk, const uint8_t* data, size_t len, size_t n_public,
                                       const uint32_t* committed_idx, size_t n_committed, size_t wire_lo, size_t wire_hi,
-                                      size_t z_lo, size_t z_hi, zkpor_pk_layout_t* info);
+                                      size_t z_lo, size_t z_hi, int z_order, zkpor_pk_layout_t* info);
 int32_t zkpor_pk_load_gnark_shard(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx,
-                                  size_t n_committed, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi,
+                                  size_t n_committed, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi, int z_order,
                                   zkpor_pk_layout_t* info);
 /* turn a loaded key into a shard: keep wires [wire_lo, wire_hi) of A, B1, B2, K (wire-indexed) and points [z_lo, z_hi) of Z
  * (in the order the prover's h has: bit-reversed), free the rest.  zkpor_prove_tail* then refuse the key (ZKPOR_E_STATE). */

@@ -3,6 +3,7 @@
 // context, contexts mapped round-robin onto the visible GPUs (on a one-GPU box: several contexts on device 0, which is also
 // how two proofs are kept in flight per GPU).  Plays the role of the Go caller; loaded by tests/test_dispatcher_gpu.py.
 #include "../../zkmerkle-proof-of-solvency_amd/host/prover_host.hpp"
+#include "../../zkmerkle-proof-of-solvency_amd/host/r1cs_file.hpp"
 #include "../../include/zkpor.h"
 #include <atomic>
 #include <cstring>
@@ -65,6 +66,22 @@ int dispatch_gpu_run(int n_workers, int n_devices, int64_t n_batches, int log2_d
     }
     for (auto* k : pk) if (k) zkpor_pk_destroy(k);
     for (auto* c : ctx) if (c) zkpor_destroy(c);
+    return rc;
+}
+
+// f1 ingestion: the exported constraint system (go/export_r1cs container) -> HBM -> a, b, c = L.w, R.w, O.w
+int r1cs_file_eval(const uint8_t* data, size_t len, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c, char* err, size_t err_len) {
+    R1csFileView v;
+    std::string why;
+    if (ParseR1csFile(data, len, &v, &why) != 0) { snprintf(err, err_len, "%s", why.c_str()); return -1; }
+    zkpor_ctx* ctx = nullptr;
+    if (zkpor_init(0, nullptr, &ctx) != ZKPOR_OK) { snprintf(err, err_len, "zkpor_init"); return -2; }
+    zkpor_r1cs* r = nullptr;
+    int rc = 0;
+    if (LoadR1cs(ctx, v, &r) != ZKPOR_OK) { snprintf(err, err_len, "load: %s", zkpor_last_error(ctx)); rc = -3; }
+    else if (zkpor_r1cs_eval(r, w, a, b, c) != ZKPOR_OK) { snprintf(err, err_len, "eval: %s", zkpor_last_error(ctx)); rc = -4; }
+    if (r) zkpor_r1cs_destroy(r);
+    zkpor_destroy(ctx);
     return rc;
 }
 }

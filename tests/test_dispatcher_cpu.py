@@ -182,3 +182,29 @@ def test_proof_row_csv_is_what_the_reference_verifier_reads(host):
         assert int(r["batch_number"]) == trial and int(r["max_account_index"]) == 7 * trial + 1379 and int(r["assets_count"]) == 50
     assert host.zkh_proof_csv(b"x", ctypes.c_size_t(1), bytes(32), bytes(32), bytes(32), bytes(32), ctypes.c_size_t(32), 0, 0, 50, ctypes.c_int64(0), 1,
                               ctypes.create_string_buffer(8), ctypes.c_size_t(8)) == -1
+
+
+def _pipe(host, ns, ng, depth, n, solve_ms, prove_ms, fail_at=-1):
+    stats = (ctypes.c_double * 7)()
+    heights = (ctypes.c_int64 * n)()
+    rc = host.zkh_pipeline_sim(ns, ng, ctypes.c_size_t(depth), ctypes.c_int64(n), solve_ms, prove_ms, ctypes.c_int64(fail_at), stats, heights)
+    keys = ("wall_s", "proofs", "solver_busy_s", "solver_blocked_s", "gpu_busy_s", "gpu_starved_s", "max_queued")
+    return rc, dict(zip(keys, stats)), list(heights)
+
+
+def test_pipeline_overlaps_solver_and_gpu_stages(host):
+    """solver || GPU (host/prover_host.hpp Pipeline): with enough solver threads the GPU stage sets the pace, the bounded queue
+    holds the solvers back, and every batch is proved exactly once; with too few the GPU starves — the two regimes of the
+    Amdahl number bench.py prints"""
+    n = 24
+    # GPU-bound: 8 solvers x 40 ms feed one 10 ms GPU worker: ~n x 10 ms (not n x 50 ms as back-to-back would take)
+    rc, st, hs = _pipe(host, 8, 1, 2, n, 40, 10)
+    assert rc == 0 and st["proofs"] == n and sorted(hs) == list(range(n))
+    assert st["max_queued"] <= 2 and st["solver_blocked_s"] > 0.1
+    assert st["wall_s"] < 0.6 * n * 0.050
+    # solver-bound: one 40 ms solver in front of a 10 ms GPU: the GPU waits ~3/4 of the time
+    rc, st, hs = _pipe(host, 1, 1, 2, 12, 40, 10)
+    assert rc == 0 and st["proofs"] == 12 and st["gpu_starved_s"] > 2 * st["gpu_busy_s"]
+    # a failing solve stops the pipeline with its code; what was proved before it is still exactly-once
+    rc, st, hs = _pipe(host, 2, 1, 2, 12, 5, 5, fail_at=6)
+    assert rc == 7 and st["proofs"] < 12 and len(set(hs[: int(st["proofs"])])) == int(st["proofs"])

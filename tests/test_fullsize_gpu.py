@@ -65,7 +65,8 @@ def test_msm_fullsize_trapdoor(zk):
         pk.close()
 
 
-def test_prove_tail_fullsize_trapdoor(zk):
+@pytest.mark.parametrize("tier,fill_kind", [("zkpor50_1380", 1), ("zkpor500_200", 2)])
+def test_prove_tail_fullsize_trapdoor(zk, tier, fill_kind):
     """The fused path that bench.py times (zkpor_commit_dev + zkpor_prove_tail_dev: ONE sorted digit stream of w -> A, B1, K,
     B2; computeH -> h in the order of Z -> Z.h; blinding; the 2^(LOG2-2) Pedersen sums) at the bench's size and scalar
     mixture, verified in the exponent from the synthetic key's trapdoor — prove, then verify, as prover.go:269-276 does."""
@@ -77,11 +78,11 @@ def test_prove_tail_fullsize_trapdoor(zk):
     cv = zk.alloc(32 * nc)
     try:
         pk.synth(LOG2, n, 3, nc, seed)
-        zk.fill_fr(bufs["w"], n, 2, 1)                 # witness-like mixture (bench default)
+        zk.fill_fr(bufs["w"], n, 2, fill_kind)         # the tier's witness-like mixture (BASELINE.json configs[1] / configs[2])
         zk.fill_fr(bufs["a"], n, 11, 0)
         zk.fill_fr(bufs["b"], n, 12, 0)
         zk._ck(zk.lib.zkpor_dev_fr_mul(zk.h, _vp(bufs["c"].ptr), _vp(bufs["a"].ptr), _vp(bufs["b"].ptr), ctypes.c_size_t(n)))
-        zk.fill_fr(cv, nc, 13, 1)
+        zk.fill_fr(cv, nc, 13, fill_kind)
         com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
         zk._ck(zk.lib.zkpor_commit_dev(zk.h, pk.h, _vp(cv.ptr), ctypes.c_size_t(nc), zkpor._p(com), zkpor._p(pok)))
         r = O.fr_random(71, 1)[0]; s = O.fr_random(72, 1)[0]

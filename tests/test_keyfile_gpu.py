@@ -37,6 +37,30 @@ def test_key_loaded_from_container_proves_like_the_oracle(zk, tmp_path, flag_byt
         pk.close()
 
 
+@pytest.mark.parametrize("z_full", [True, False])
+def test_z_order_of_the_file_is_the_callers_statement(zk, z_full):
+    """The stream does not record whether G1.Z was bit-reversed at setup: both conventions load cleanly, only one verifies.  A key
+    written in natural order proves correctly when loaded as ZKPOR_Z_ORDER_NATURAL, and the SAME bytes loaded as bit-reversed give
+    a proof the pairing check rejects (why z_order is an argument of the loaders, not a constant)."""
+    S = O.Synth(6, 300, n_public=2, seed=31, z_bitrev=False)
+    data, _, _ = GK.pk_bytes_from_synth(S, z_full_domain=z_full)
+    r = O.fr_random(5, 1)[0]; s = O.fr_random(6, 1)[0]
+    pk = zkpor.ProvingKey(zk)
+    try:
+        pk.load_gnark(data, S.n_public, z_order=zkpor.Z_ORDER_NATURAL)
+        good = zk.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
+        assert np.array_equal(good, S.prove_tail(r, s)) and S.verify_pairing(good)
+        pk.load_gnark(data, S.n_public, z_order=zkpor.Z_ORDER_BITREV)
+        bad = zk.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
+        assert not S.verify_pairing(bad)
+        with pytest.raises(zkpor.ZkporError, match="unknown z_order"):
+            pk.load_gnark(data, S.n_public, z_order=7)
+        with pytest.raises(zkpor.ZkporError, match="bit-reversed"):
+            pk.load_gnark_shard(data, S.n_public, 0, S.n_wires, 0, 4, z_order=zkpor.Z_ORDER_NATURAL)
+    finally:
+        pk.close()
+
+
 def test_container_errors_are_reported(zk, tmp_path):
     S = O.Synth(4, 20, n_public=2, seed=4)
     data, inf_a, inf_b = GK.pk_bytes_from_synth(S)

@@ -138,10 +138,11 @@ int32_t zkpor_pk_gnark_layout(const uint8_t* data, size_t len, zkpor_pk_layout_t
 }
 
 int32_t zkpor_pk_load_gnark_mem(zkpor_pk* pk, const uint8_t* data, size_t len, size_t n_public, const uint32_t* committed_idx,
-                                size_t n_committed, zkpor_pk_layout_t* info) {
+                                size_t n_committed, int z_order, zkpor_pk_layout_t* info) {
     ZK_ENTER(pk ? zk_pk_ctx(pk)->device : -1);
     if (!pk) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = zk_pk_ctx(pk);
+    if (z_order != ZKPOR_Z_ORDER_BITREV && z_order != ZKPOR_Z_ORDER_NATURAL) { ctx->err = "pk file: unknown z_order"; return ZKPOR_E_ARG; }
     zkpor_pk_layout_t L;
     std::string why;
     int32_t rc = layout(data, len, &L, &why);
@@ -178,16 +179,22 @@ int32_t zkpor_pk_load_gnark_mem(zkpor_pk* pk, const uint8_t* data, size_t len, s
     rc = zkpor_pk_set_g2_compressed(pk, ZKPOR_G2_B, L.n_b2 ? data + L.off_b2 : data, L.n_b2);
     if (rc != ZKPOR_OK) { ctx->err = "pk file: G2.B: " + ctx->err; return rc; }
     return zkpor_pk_set_consts(pk, g1c, g1c + 64, g1c + 128, g2c, g2c + 128, log2d, data + L.off_inf_a, data + L.off_inf_b,
-                               (size_t)L.n_wires, n_public, committed_idx, n_committed, ZKPOR_Z_ORDER_BITREV);
+                               (size_t)L.n_wires, n_public, committed_idx, n_committed, z_order);
 }
 
 // One rank's share of a split key: wires [wire_lo, wire_hi) and Z points [z_lo, z_hi) only.  A, B and K are
 // stored compacted, so the wire range is translated into ranges of the compacted arrays by counting the mask bytes in front of it;
 // only those sub-ranges are uploaded and decompressed — a GPU never holds more than its share of a 2^28 key.
 int32_t zkpor_pk_load_gnark_shard_mem(zkpor_pk* pk, const uint8_t* data, size_t len, size_t n_public, const uint32_t* committed_idx,
-                                      size_t n_committed, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi,
+                                      size_t n_committed, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi, int z_order,
                                       zkpor_pk_layout_t* info) {
     ZK_ENTER(pk ? zk_pk_ctx(pk)->device : -1);
+    if (pk && z_order != ZKPOR_Z_ORDER_BITREV) {
+        // [z_lo, z_hi) is a range of the PROVER's order of h; in a natural-order file those points are scattered over the whole
+        // Z section.  Load the whole key with ZKPOR_Z_ORDER_NATURAL and cut it with zkpor_pk_keep_range instead.
+        zk_pk_ctx(pk)->err = "pk file: a shard can only be cut from a Z stored in the prover's (bit-reversed) order";
+        return ZKPOR_E_ARG;
+    }
     if (!pk) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = zk_pk_ctx(pk);
     zkpor_pk_layout_t L;
@@ -256,20 +263,20 @@ static int32_t with_mapped_file(zkpor_ctx* ctx, const char* path, const std::fun
 }
 
 int32_t zkpor_pk_load_gnark_shard(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
-                                  size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi, zkpor_pk_layout_t* info) {
+                                  size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi, int z_order, zkpor_pk_layout_t* info) {
     ZK_ENTER(pk ? zk_pk_ctx(pk)->device : -1);
     if (!pk || !path) return ZKPOR_E_ARG;
     return with_mapped_file(zk_pk_ctx(pk), path, [&](const uint8_t* d, size_t n) {
-        return zkpor_pk_load_gnark_shard_mem(pk, d, n, n_public, committed_idx, n_committed, wire_lo, wire_hi, z_lo, z_hi, info);
+        return zkpor_pk_load_gnark_shard_mem(pk, d, n, n_public, committed_idx, n_committed, wire_lo, wire_hi, z_lo, z_hi, z_order, info);
     });
 }
 
 int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
-                            zkpor_pk_layout_t* info) {
+                            int z_order, zkpor_pk_layout_t* info) {
     ZK_ENTER(pk ? zk_pk_ctx(pk)->device : -1);
     if (!pk || !path) return ZKPOR_E_ARG;
     return with_mapped_file(zk_pk_ctx(pk), path, [&](const uint8_t* d, size_t n) {
-        return zkpor_pk_load_gnark_mem(pk, d, n, n_public, committed_idx, n_committed, info);
+        return zkpor_pk_load_gnark_mem(pk, d, n, n_public, committed_idx, n_committed, z_order, info);
     });
 }
 

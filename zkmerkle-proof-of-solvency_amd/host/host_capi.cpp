@@ -2,6 +2,7 @@
 // src/prover/prover/prover_test.go:TestMockProver drives the reference (many fake provers, no SNARK).
 #include "prover_host.hpp"
 #include "proof_row.hpp"
+#include "r1cs_file.hpp"
 #include <atomic>
 #include <cstring>
 using namespace zkpor_host;
@@ -59,5 +60,41 @@ long zkh_proof_csv(const char* raw, size_t raw_len, const char* before32, const 
     if (line.size() > cap) return -1;
     memcpy(out, line.data(), line.size());
     return (long)line.size();
+}
+// header walk of the flat constraint-system container (host/r1cs_file.hpp; no device): counts = n_constraints, n_wires, n_public,
+// n_secret, n_coeff, nnzL, nnzR, nnzO, n_commitments, number of wires K leaves out; committed_out (may be NULL) receives those wires
+int zkh_r1cs_parse(const uint8_t* data, size_t len, uint64_t counts[10], uint32_t* committed_out, size_t committed_cap, char* err, size_t err_len) {
+    R1csFileView v;
+    std::string why;
+    if (ParseR1csFile(data, len, &v, &why) != 0) {
+        if (err && err_len) { size_t n = why.size() < err_len - 1 ? why.size() : err_len - 1; memcpy(err, why.data(), n); err[n] = 0; }
+        return 1;
+    }
+    std::vector<uint32_t> cw = v.CommittedWires();
+    uint64_t c[10] = {v.n_constraints, v.n_wires, v.n_public, v.n_secret, v.n_coeff, v.nnz[0], v.nnz[1], v.nnz[2], v.commitments.size(), cw.size()};
+    memcpy(counts, c, sizeof c);
+    if (committed_out) for (size_t i = 0; i < cw.size() && i < committed_cap; ++i) committed_out[i] = cw[i];
+    return 0;
+}
+// the solver || GPU pipeline with sleeping stages (CPU test of the queueing logic): stats = wall_s, proofs, solver_busy_s,
+// solver_blocked_s, gpu_busy_s, gpu_starved_s, max_queued; fail_at >= 0 makes the solve of that height fail
+int zkh_pipeline_sim(int n_solvers, int n_gpu_workers, size_t depth, int64_t n_batches, int solve_ms, int prove_ms, int64_t fail_at,
+                     double stats[7], int64_t* proved_heights) {
+    Pipeline<int64_t> p(n_solvers, n_gpu_workers, depth);
+    std::mutex mu;
+    size_t k = 0;
+    PipelineStats st;
+    int rc = p.Run(n_batches,
+        [&](int64_t h, int64_t* out) { std::this_thread::sleep_for(std::chrono::milliseconds(solve_ms)); if (h == fail_at) return 7; *out = h * 3 + 1; return 0; },
+        [&](int, int64_t h, int64_t& in) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(prove_ms));
+            if (in != h * 3 + 1) return 9;
+            std::lock_guard<std::mutex> g(mu);
+            proved_heights[k++] = h;
+            return 0;
+        }, &st);
+    double o[7] = {st.wall_s, (double)st.proofs, st.solver_busy_s, st.solver_blocked_s, st.gpu_busy_s, st.gpu_starved_s, (double)st.max_queued};
+    memcpy(stats, o, sizeof o);
+    return rc;
 }
 }

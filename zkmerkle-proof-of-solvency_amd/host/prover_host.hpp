@@ -209,6 +209,103 @@ private:
     std::chrono::milliseconds timeout_;
 };
 
+// ---- solver || GPU pipeline (SURVEY.md §7 hard part 2) -------------------------------------------------------------------
+// groth16.Prove is two very different halves: r1cs.Solve + hints on host cores (seconds per proof, a6.1 — stays gnark's Go code),
+// then the prove tail on the GPU (~0.4 s).  Run back to back per proof the GPU idles > 90 % of the time; the service loop therefore
+// runs them as two stages: `n_solvers` host threads solve batch i+1, i+2, ... while the GPU workers prove batch i, joined by a
+// BOUNDED queue (a solved witness is ~8.6 GB of vectors: the bound is what keeps host memory finite when the GPU is the slow
+// side).  Order of completion is free, every batch is handed over exactly once.
+struct PipelineStats {
+    double wall_s = 0;
+    size_t proofs = 0;
+    double solver_busy_s = 0;   // summed over solver threads: time inside solve()
+    double solver_blocked_s = 0;  // ... waiting for room in the queue (GPU is the bottleneck)
+    double gpu_busy_s = 0;      // summed over GPU workers: time inside prove()
+    double gpu_starved_s = 0;   // ... waiting for a solved witness (solver is the bottleneck)
+    size_t max_queued = 0;
+};
+
+template <class Solved>
+class Pipeline {
+public:
+    typedef std::function<int(int64_t height, Solved* out)> SolveFn;            // host: witness row -> w, a, b, c
+    typedef std::function<int(int gpu_worker, int64_t height, Solved& in)> ProveFn;  // device: prove tail + row insert
+    Pipeline(int n_solvers, int n_gpu_workers, size_t queue_depth) : ns_(n_solvers), ng_(n_gpu_workers), depth_(queue_depth ? queue_depth : 1) {}
+
+    // heights [0, n_batches); returns 0, or the first non-zero code of a stage (the pipeline then drains and stops)
+    int Run(int64_t n_batches, SolveFn solve, ProveFn prove, PipelineStats* st) {
+        typedef std::chrono::steady_clock clk;
+        auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        std::mutex mu;
+        std::condition_variable cv_room, cv_item;
+        std::deque<std::pair<int64_t, Solved>> q;
+        int64_t next = 0;
+        int solvers_left = ns_, rc = 0;
+        PipelineStats s;
+        auto t0 = clk::now();
+        std::vector<std::thread> th;
+        for (int i = 0; i < ns_; ++i)
+            th.emplace_back([&] {
+                double busy = 0, blocked = 0;
+                for (;;) {
+                    int64_t h;
+                    {
+                        std::lock_guard<std::mutex> g(mu);
+                        if (rc != 0 || next >= n_batches) break;
+                        h = next++;
+                    }
+                    Solved item;
+                    auto a = clk::now();
+                    int e = solve(h, &item);
+                    auto b = clk::now();
+                    busy += secs(a, b);
+                    std::unique_lock<std::mutex> g(mu);
+                    if (e != 0) { if (rc == 0) rc = e; break; }
+                    cv_room.wait(g, [&] { return q.size() < depth_ || rc != 0; });
+                    blocked += secs(b, clk::now());
+                    if (rc != 0) break;
+                    q.emplace_back(h, std::move(item));
+                    if (q.size() > s.max_queued) s.max_queued = q.size();
+                    cv_item.notify_one();
+                }
+                std::lock_guard<std::mutex> g(mu);
+                s.solver_busy_s += busy; s.solver_blocked_s += blocked;
+                if (--solvers_left == 0) cv_item.notify_all();
+                cv_room.notify_all();
+            });
+        for (int w = 0; w < ng_; ++w)
+            th.emplace_back([&, w] {
+                double busy = 0, starved = 0;
+                size_t done = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> g(mu);
+                    auto a = clk::now();
+                    cv_item.wait(g, [&] { return !q.empty() || solvers_left == 0 || rc != 0; });
+                    starved += secs(a, clk::now());
+                    if (q.empty()) break;  // solvers are gone (or failed) and nothing is queued
+                    auto item = std::move(q.front());
+                    q.pop_front();
+                    cv_room.notify_one();
+                    g.unlock();
+                    auto b = clk::now();
+                    int e = prove(w, item.first, item.second);
+                    busy += secs(b, clk::now());
+                    if (e != 0) { std::lock_guard<std::mutex> g2(mu); if (rc == 0) rc = e; cv_room.notify_all(); cv_item.notify_all(); break; }
+                    ++done;
+                }
+                std::lock_guard<std::mutex> g(mu);
+                s.gpu_busy_s += busy; s.gpu_starved_s += starved; s.proofs += done;
+            });
+        for (auto& t : th) t.join();
+        s.wall_s = secs(t0, clk::now());
+        if (st) *st = s;
+        return rc;
+    }
+private:
+    int ns_, ng_;
+    size_t depth_;
+};
+
 // static contiguous sharding used by the one-process-per-GPU launcher (bench.py / torchrun): rank r of `world`
 // proves heights [lo, hi) — every height exactly once, sizes differ by at most one
 inline void shard_range(int64_t n_batches, int rank, int world, int64_t* lo, int64_t* hi) {

@@ -314,7 +314,7 @@ class ProvingKey:
             _p(ia), _p(ib), ctypes.c_size_t(n_wires), ctypes.c_size_t(n_public), _p(ci), ctypes.c_size_t(0 if ci is None else ci.size),
             ctypes.c_int(z_order)))
 
-    def load_gnark(self, src, n_public, committed_idx=None):
+    def load_gnark(self, src, n_public, committed_idx=None, z_order=Z_ORDER_BITREV):
         """load a whole key from gnark's pk.WriteTo container (src/keygen/main.go:46): `src` is a path or the bytes;
         n_public counts the ONE wire; committed_idx = committed + commitment wire indices (r1cs.CommitmentInfo).
         Returns the container layout as a dict."""
@@ -322,24 +322,24 @@ class ProvingKey:
         nci = ctypes.c_size_t(0 if ci is None else ci.size)
         info = PkLayout()
         if isinstance(src, (str, os.PathLike)):
-            rc = self.ctx.lib.zkpor_pk_load_gnark(self.h, os.fsencode(src), ctypes.c_size_t(n_public), _p(ci), nci, ctypes.byref(info))
+            rc = self.ctx.lib.zkpor_pk_load_gnark(self.h, os.fsencode(src), ctypes.c_size_t(n_public), _p(ci), nci, ctypes.c_int(z_order), ctypes.byref(info))
         else:
             buf = np.frombuffer(bytes(src), dtype=np.uint8)
-            rc = self.ctx.lib.zkpor_pk_load_gnark_mem(self.h, _p(buf), ctypes.c_size_t(buf.size), ctypes.c_size_t(n_public), _p(ci), nci, ctypes.byref(info))
+            rc = self.ctx.lib.zkpor_pk_load_gnark_mem(self.h, _p(buf), ctypes.c_size_t(buf.size), ctypes.c_size_t(n_public), _p(ci), nci, ctypes.c_int(z_order), ctypes.byref(info))
         self.ctx._ck(rc)
         return info.as_dict()
 
-    def load_gnark_shard(self, src, n_public, wire_lo, wire_hi, z_lo, z_hi, committed_idx=None):
+    def load_gnark_shard(self, src, n_public, wire_lo, wire_hi, z_lo, z_hi, committed_idx=None, z_order=Z_ORDER_BITREV):
         """one rank's share of a split key straight from the container (path or bytes): see zkpor_pk_load_gnark_shard"""
         ci = None if committed_idx is None else np.ascontiguousarray(committed_idx, dtype=np.uint32)
         nci = ctypes.c_size_t(0 if ci is None else ci.size)
         info = PkLayout()
         rng = [ctypes.c_size_t(v) for v in (wire_lo, wire_hi, z_lo, z_hi)]
         if isinstance(src, (str, os.PathLike)):
-            rc = self.ctx.lib.zkpor_pk_load_gnark_shard(self.h, os.fsencode(src), ctypes.c_size_t(n_public), _p(ci), nci, *rng, ctypes.byref(info))
+            rc = self.ctx.lib.zkpor_pk_load_gnark_shard(self.h, os.fsencode(src), ctypes.c_size_t(n_public), _p(ci), nci, *rng, ctypes.c_int(z_order), ctypes.byref(info))
         else:
             buf = np.frombuffer(bytes(src), dtype=np.uint8)
-            rc = self.ctx.lib.zkpor_pk_load_gnark_shard_mem(self.h, _p(buf), ctypes.c_size_t(buf.size), ctypes.c_size_t(n_public), _p(ci), nci, *rng, ctypes.byref(info))
+            rc = self.ctx.lib.zkpor_pk_load_gnark_shard_mem(self.h, _p(buf), ctypes.c_size_t(buf.size), ctypes.c_size_t(n_public), _p(ci), nci, *rng, ctypes.c_int(z_order), ctypes.byref(info))
         self.ctx._ck(rc)
         return info.as_dict()
 
