@@ -3,7 +3,9 @@
 //   u32 nAssetsCex, u32 nOps, u32 opsPerBatch, u32 nLeaves, u8 nil[32]
 //   zkpor_cex_asset_const_t consts[nAssetsCex]; zkpor_cex_totals_t totals[nAssetsCex];
 //   u8 leaves[nLeaves][32];   per op: u32 accountIndex, u32 nAssets, zkpor_asset_t assets[nAssets]
-// Output (stdout): per batch one line "batch <i> <commitment> <before> <after> <min> <max> <proof0-of-first-user>"; then
+// Output (stdout): per batch one line "batch <i> <commitment> <before> <after> <min> <max> <proof0-of-first-user>", one line
+// "row <height> <status> <WitnessData>" (the witness table row in the reference's encoding) and one line "rt <0|1>" (1 = the row decoded
+// by DecodeBatchWitness equals what was encoded, asset lists expanded to the dense form); then
 // "overflow 1" if re-running with a balance of 2^64-1 added throws the reference's panic.
 #include <cstdio>
 #include <cstdlib>
@@ -55,6 +57,37 @@ int main(int argc, char** argv) {
             printf("batch %zu ", b); hex(wit[b].BatchCommitment.data()); printf(" "); hex(wit[b].BeforeCEXAssetsCommitment.data()); printf(" ");
             hex(wit[b].AfterCEXAssetsCommitment.data()); printf(" %u %u ", wit[b].MinAccountIndex, wit[b].MaxAccountIndex);
             hex(wit[b].AccountProofs[0].data()); printf("\n");
+        }
+        std::vector<std::string> symbols(nA);
+        for (uint32_t i = 0; i < nA; ++i) symbols[i] = "a" + std::to_string(i);
+        std::vector<WitnessRow> rows = MakeWitnessRows(wit, ops, perBatch, AccountTreeDepth, consts, 100, &symbols);
+        for (size_t b = 0; b < rows.size(); ++b) {
+            printf("row %lld %d %s\n", (long long)rows[b].Height, rows[b].Status, rows[b].WitnessData.c_str());
+            BatchCreateUserWitnessW back = DecodeBatchWitness(rows[b].WitnessData);
+            BatchCreateUserWitnessW sent = ToWire(wit[b], ops, perBatch, AccountTreeDepth, consts, &symbols);
+            int same = back.BatchCommitment == sent.BatchCommitment && back.AccountTreeRoot == sent.AccountTreeRoot &&
+                       back.MinAccountIndex == sent.MinAccountIndex && back.MaxAccountIndex == sent.MaxAccountIndex &&
+                       back.BeforeCexAssets.size() == sent.BeforeCexAssets.size() && back.CreateUserOps.size() == sent.CreateUserOps.size();
+            for (size_t i = 0; same && i < sent.BeforeCexAssets.size(); ++i) {
+                const CexAssetInfoW &x = back.BeforeCexAssets[i], &y = sent.BeforeCexAssets[i];
+                same = x.TotalEquity == y.TotalEquity && x.TotalDebt == y.TotalDebt && x.BasePrice == y.BasePrice && x.Symbol == y.Symbol && x.Index == y.Index &&
+                       x.LoanCollateral == y.LoanCollateral && x.MarginCollateral == y.MarginCollateral && x.PortfolioMarginCollateral == y.PortfolioMarginCollateral;
+                for (int t = 0; same && t < kTierCount; ++t)
+                    same = x.LoanRatios[t].BoundaryValue == y.LoanRatios[t].BoundaryValue && x.LoanRatios[t].Ratio == y.LoanRatios[t].Ratio &&
+                           x.LoanRatios[t].PrecomputedValue == y.LoanRatios[t].PrecomputedValue &&
+                           x.PortfolioMarginRatios[t].PrecomputedValue == y.PortfolioMarginRatios[t].PrecomputedValue;
+            }
+            for (size_t j = 0; same && j < sent.CreateUserOps.size(); ++j) {
+                const CreateUserOperationW &x = back.CreateUserOps[j], &y = sent.CreateUserOps[j];
+                same = x.AccountIndex == y.AccountIndex && x.AccountIdHash == y.AccountIdHash && x.AccountProof == y.AccountProof && x.Assets.size() == (size_t)kAssetCounts;
+                size_t nz = 0;
+                for (auto& a : x.Assets) nz += (a.Equity | a.Debt | a.Loan | a.Margin | a.PortfolioMargin) != 0;
+                for (auto& a : y.Assets) same = same && x.Assets[a.Index].Equity == a.Equity && x.Assets[a.Index].PortfolioMargin == a.PortfolioMargin;
+                size_t want = 0;
+                for (auto& a : y.Assets) want += (a.Equity | a.Debt | a.Loan | a.Margin | a.PortfolioMargin) != 0;
+                same = same && nz == want;
+            }
+            printf("rt %d\n", same);
         }
         // SafeAdd's panic: one more batch whose first asset carries 2^64 - 1 of equity on top of a non-zero total
         std::vector<zkpor_asset_t> big(1);

@@ -45,8 +45,11 @@ def test_witness_run_matches_serial_restatement(zk, tmp_path):
             f.write(struct.pack("<2I", idx, a.shape[0])); f.write(a.tobytes())
     res = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=180)
     assert res.returncode == 0, res.stderr
-    lines = res.stdout.strip().splitlines()
-    assert lines[-1] == "overflow 1"                               # SafeAdd's panic surfaces as std::overflow_error
+    all_lines = res.stdout.strip().splitlines()
+    assert all_lines[-1] == "overflow 1"                           # SafeAdd's panic surfaces as std::overflow_error
+    lines = [l for l in all_lines if l.startswith("batch ")]
+    rows = [l.split(" ", 3) for l in all_lines if l.startswith("row ")]
+    assert [l for l in all_lines if l.startswith("rt ")] == ["rt 1"] * n_batches and len(rows) == n_batches
     # the serial restatement: walk the batches, update the totals op by op, hash before / after
     root, proofs = O.sparse_tree(np.arange(n_ops, dtype=np.uint32), O.fr_from_be(leaves), 28, O.fr_from_be(nil[None, :])[0],
                                  np.arange(n_ops, dtype=np.uint32))
@@ -68,3 +71,32 @@ def test_witness_run_matches_serial_restatement(zk, tmp_path):
         assert parts[4] == O.fr_to_be(after[None, :])[0].tobytes().hex()
         assert (int(parts[5]), int(parts[6])) == (mn, mx)
         assert parts[7] == O.fr_to_be(proofs[mn, 0][None, :])[0].tobytes().hex()      # leaf-level sibling of the batch's first user
+
+        # the witness table row of this batch, in the reference's own encoding (base64(s2(gob(...))), witness.go:215-232), read with the
+        # test-side independent decoder: what utils.DecodeBatchWitness would see
+        import base64
+        import gobs2 as G
+        assert rows[b][1] == str(100 + b) and rows[b][2] == "0"
+        v, _ = G.gob_decode(G.s2_decode(base64.b64decode(rows[b][3], validate=True)))
+        be = lambda x: O.fr_to_be(x[None, :])[0].tobytes()
+        assert v["BatchCommitment"] == be(bc) and v["AccountTreeRoot"] == be(root)
+        assert v["BeforeCEXAssetsCommitment"] == be(before) and v["AfterCEXAssetsCommitment"] == be(after)
+        assert v.get("MinAccountIndex", 0) == mn and v["MaxAccountIndex"] == mx
+        assert len(v["BeforeCexAssets"]) == n_cex and len(v["CreateUserOps"]) == per_batch
+        for j, (idx, a) in enumerate(ops[b * per_batch:(b + 1) * per_batch]):
+            op = v["CreateUserOps"][j]
+            assert op.get("AccountIndex", 0) == idx and len(op["AccountProof"]) == 28
+            assert op["AccountProof"] == [be(proofs[idx, k]) for k in range(28)]
+            sent = op.get("Assets", [])
+            assert [x.get("Index", 0) for x in sent] == [int(i) for i in a["index"]]
+            assert [x.get("Equity", 0) for x in sent] == [int(e) for e in a["equity"]]
+        # the CEX asset list carries the totals that ENTERED the batch and the tier tables with CalculatePrecomputedValue's sums
+        c0 = v["BeforeCexAssets"][3]
+        assert c0["Symbol"] == b"a3" and c0["Index"] == 3 and c0.get("BasePrice", 0) == int(consts[3]["base_price"])
+        pre, prev = 0, 0
+        for t in range(12):
+            bnd = int(consts[3]["loan"][t]["boundary"][0]) | (int(consts[3]["loan"][t]["boundary"][1]) << 64)
+            pre += (bnd - prev) * int(consts[3]["loan"][t]["ratio"]) // 100; prev = bnd
+            tr = c0["LoanRatios"][t]
+            assert int.from_bytes(tr["BoundaryValue"][1:], "big") == bnd and tr["BoundaryValue"][0] == 2 and tr.get("Ratio", 0) == int(consts[3]["loan"][t]["ratio"])
+            assert int.from_bytes(tr["PrecomputedValue"][1:], "big") == pre

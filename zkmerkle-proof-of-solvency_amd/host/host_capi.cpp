@@ -3,6 +3,7 @@
 #include "prover_host.hpp"
 #include "proof_row.hpp"
 #include "r1cs_file.hpp"
+#include "witness_codec.hpp"
 #include <atomic>
 #include <cstring>
 using namespace zkpor_host;
@@ -96,5 +97,92 @@ int zkh_pipeline_sim(int n_solvers, int n_gpu_workers, size_t depth, int64_t n_b
     double o[7] = {st.wall_s, (double)st.proofs, st.solver_busy_s, st.solver_blocked_s, st.gpu_busy_s, st.gpu_starved_s, (double)st.max_queued};
     memcpy(stats, o, sizeof o);
     return rc;
+}
+// ---- witness row codec (host/witness_codec.hpp), driven by tests/test_witness_codec_cpu.py ----
+static uint64_t tmix(uint64_t& s) { uint64_t z = (s += 0x9e3779b97f4a7c15ULL); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); }
+static Bytes tbytes(uint64_t& s, size_t n) { Bytes b; for (size_t i = 0; i < n; ++i) b.push_back((char)(uint8_t)tmix(s)); return b; }
+// a deterministic witness the Python test regenerates from the same seed (tests/gobs2.py synth_witness)
+static BatchCreateUserWitnessW synth_witness(uint64_t seed, int users, int assets_per_user, int cex_assets) {
+    uint64_t s = seed;
+    BatchCreateUserWitnessW w;
+    w.BatchCommitment = tbytes(s, 32); w.AccountTreeRoot = tbytes(s, 32);
+    w.BeforeCEXAssetsCommitment = tbytes(s, 32); w.AfterCEXAssetsCommitment = tbytes(s, 32);
+    w.MinAccountIndex = (uint32_t)tmix(s); w.MaxAccountIndex = (uint32_t)tmix(s);
+    for (int i = 0; i < cex_assets; ++i) {
+        CexAssetInfoW c;
+        c.TotalEquity = tmix(s); c.TotalDebt = tmix(s) >> 20; c.BasePrice = tmix(s) >> 40;
+        c.Symbol = (i % 3 == 0) ? std::string() : ("sym" + std::to_string(i));
+        c.Index = (uint32_t)i;
+        c.LoanCollateral = tmix(s) >> 8; c.MarginCollateral = (i % 2) ? tmix(s) : 0; c.PortfolioMarginCollateral = tmix(s) >> 1;
+        std::array<TierRatioW, kTierCount>* lists[3] = {&c.LoanRatios, &c.MarginRatios, &c.PortfolioMarginRatios};
+        for (int l = 0; l < 3; ++l)
+            for (int t = 0; t < kTierCount; ++t) {
+                TierRatioW& tr = (*lists[l])[t];
+                if (l == 2 && i % 4 == 0) continue;   // an all-zero array: omitted on the wire
+                tr.BoundaryValue = BigIntW::from_u128(((unsigned __int128)(tmix(s) >> 10) << 64) | tmix(s));
+                tr.Ratio = (uint8_t)(tmix(s) % 101);
+                tr.PrecomputedValue = BigIntW::from_u128(t == 0 ? 0 : (unsigned __int128)tmix(s) * (unsigned)(t));  // zero but present for t = 0
+            }
+        w.BeforeCexAssets.push_back(c);
+    }
+    for (int u = 0; u < users; ++u) {
+        CreateUserOperationW op;
+        for (int a = 0; a < assets_per_user; ++a) {
+            AccountAssetW x;
+            x.Index = (uint16_t)((a * 7 + u) % kAssetCounts);
+            x.Equity = tmix(s) >> 24; x.Debt = (a % 2) ? tmix(s) >> 30 : 0; x.Loan = tmix(s) >> 50; x.Margin = 0; x.PortfolioMargin = tmix(s);
+            op.Assets.push_back(x);
+        }
+        op.AccountIndex = (uint32_t)(1000 + u);
+        op.AccountIdHash = tbytes(s, 32);
+        for (int k = 0; k < kAccountTreeDepth; ++k) op.AccountProof[k] = tbytes(s, 32);
+        w.CreateUserOps.push_back(op);
+    }
+    return w;
+}
+static long put_out(const std::string& r, char* out, size_t cap) {
+    if (r.size() > cap) return -(long)r.size();
+    memcpy(out, r.data(), r.size());
+    return (long)r.size();
+}
+// stage: 0 = gob bytes, 1 = s2 block of them, 2 = the base64 column.  Returns the length (negative: needed capacity), -1 on error
+long zkh_witness_synth_encode(uint64_t seed, int users, int assets_per_user, int cex_assets, int s2_level, int stage, char* out, size_t cap) {
+    try {
+        BatchCreateUserWitnessW w = synth_witness(seed, users, assets_per_user, cex_assets);
+        Bytes g = witness_gob::Encode(w);
+        if (stage == 0) return put_out(g, out, cap);
+        Bytes z = s2::Encode(g, s2_level);
+        if (stage == 1) return put_out(z, out, cap);
+        return put_out(base64_std(z), out, cap);
+    } catch (const std::exception&) { return -1; }
+}
+// utils.DecodeBatchWitness on `in` (any valid stream), then serializeWorker again: what a decode -> encode round trip preserves
+long zkh_witness_reencode(const char* in, size_t in_len, int expand_assets, int s2_level, char* out, size_t cap, char* err, size_t err_len) {
+    try {
+        BatchCreateUserWitnessW w = DecodeBatchWitness(std::string(in, in_len), expand_assets != 0);
+        return put_out(EncodeBatchWitness(w, s2_level), out, cap);
+    } catch (const std::exception& e) {
+        if (err && err_len) { snprintf(err, err_len, "%s", e.what()); }
+        return -1;
+    }
+}
+long zkh_s2(const char* in, size_t in_len, int decode, int level, char* out, size_t cap, char* err, size_t err_len) {
+    try {
+        return put_out(decode ? s2::Decode(std::string(in, in_len)) : s2::Encode(std::string(in, in_len), level), out, cap);
+    } catch (const std::exception& e) {
+        if (err && err_len) { snprintf(err, err_len, "%s", e.what()); }
+        return -1;
+    }
+}
+// the worked example of the encoding/gob package documentation: type Point struct{ X, Y int }; Point{22, 33} (type id 65)
+long zkh_gob_point_example(char* out, size_t cap) {
+    gob::WireType t; t.kind = gob::WireType::Struct; t.id = 65; t.name = "Point"; t.fields = {{"X", gob::tInt}, {"Y", gob::tInt}};
+    Bytes o;
+    gob::put_message(o, gob::type_definition(t));
+    Bytes v;
+    gob::put_int(v, 65);
+    gob::put_uint(v, 1); gob::put_int(v, 22); gob::put_uint(v, 1); gob::put_int(v, 33); gob::put_uint(v, 0);
+    gob::put_message(o, v);
+    return put_out(o, out, cap);
 }
 }

@@ -26,7 +26,8 @@ enum Err { Ok = 0, DbErrNotFound = 1, DbErrDuplicate = 2, QueueNil = 3, ProveFai
 
 struct BatchWitness {  // witness_model.go:43-48
     int64_t Height = 0;
-    std::string WitnessData;  // base64(s2(gob(BatchCreateUserWitness))) in the reference; opaque here
+    std::string WitnessData;  // base64(s2(gob(BatchCreateUserWitness))): written by witness_host.hpp MakeWitnessRows, read by
+                              // witness_codec.hpp DecodeBatchWitness (= utils.DecodeBatchWitness, src/utils/utils.go:704-742)
     int Status = StatusPublished;
 };
 struct Proof {  // proof_model.go:29-39

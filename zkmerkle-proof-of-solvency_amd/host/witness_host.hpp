@@ -9,6 +9,9 @@
 //   2. ONE zkpor_cex_commitments call hashes all boundary states (After of batch i is Before of batch i+1, so
 //      nBatches + 1 states instead of 2 nBatches hashes), ONE zkpor_tree_get_proofs call fetches every user's proof,
 //      ONE zkpor_batch_commitments call hashes all batch commitments.
+//   3. every batch becomes a row of the witness table in the reference's own encoding — WitnessData =
+//      base64(s2(gob(utils.BatchCreateUserWitness))) (serializeWorker :215-232; host/witness_codec.hpp) — so the UNMODIFIED prover
+//      service (utils.DecodeBatchWitness, src/utils/utils.go:704-742) reads what this loop writes.
 // Field names follow utils.BatchCreateUserWitness (src/utils/types.go:50-60).  C++ because the build image has no Go.
 #pragma once
 #include <array>
@@ -17,6 +20,7 @@
 #include <string>
 #include <vector>
 #include "../../include/zkpor.h"
+#include "witness_codec.hpp"
 
 namespace zkpor_host {
 
@@ -115,5 +119,74 @@ private:
     std::vector<zkpor_cex_asset_const_t> consts_;
     std::vector<zkpor_cex_totals_t> totals_;
 };
+
+// ---- the witness table row (witness_model.go:43-48) ------------------------------------------------------------------
+struct WitnessRow { int64_t Height = 0; std::string WitnessData; int Status = 0; };  // Status 0 = StatusPublished
+
+// [TierCount]TierRatio of one list as the reference holds it: boundary and ratio from the (already padded) constant table,
+// PrecomputedValue by CalculatePrecomputedValue (src/utils/utils.go:420-432): running sum of (boundary_i - boundary_{i-1}) * ratio_i / 100
+inline std::array<TierRatioW, kTierCount> TierRatiosToWire(const zkpor_tier_ratio_t* t) {
+    std::array<TierRatioW, kTierCount> out;
+    unsigned __int128 prev = 0, pre = 0;
+    for (int i = 0; i < kTierCount; ++i) {
+        unsigned __int128 b = ((unsigned __int128)t[i].boundary[1] << 64) | t[i].boundary[0];
+        pre += (b - prev) * t[i].ratio / 100;
+        prev = b;
+        out[i].BoundaryValue = BigIntW::from_u128(b);
+        out[i].Ratio = t[i].ratio;
+        out[i].PrecomputedValue = BigIntW::from_u128(pre);
+    }
+    return out;
+}
+
+// one batch of Witness::Run as utils.BatchCreateUserWitness: hashes as 32-byte strings, the CEX asset list with the totals that
+// entered the batch, every operation with its stored (sparse) asset list and its 28 siblings.  symbols may be NULL.
+inline BatchCreateUserWitnessW ToWire(const BatchCreateUserWitness& b, const std::vector<CreateUserOperation>& ops, size_t userOpsPerBatch,
+                                      int depth, const std::vector<zkpor_cex_asset_const_t>& consts, const std::vector<std::string>* symbols = nullptr) {
+    if (depth != kAccountTreeDepth) throw std::invalid_argument("the witness row holds AccountTreeDepth = 28 siblings per user");
+    auto h = [](const WHash32& x) { return Bytes((const char*)x.data(), 32); };
+    BatchCreateUserWitnessW w;
+    w.BatchCommitment = h(b.BatchCommitment); w.AccountTreeRoot = h(b.AccountTreeRoot);
+    w.BeforeCEXAssetsCommitment = h(b.BeforeCEXAssetsCommitment); w.AfterCEXAssetsCommitment = h(b.AfterCEXAssetsCommitment);
+    w.MinAccountIndex = b.MinAccountIndex; w.MaxAccountIndex = b.MaxAccountIndex;
+    w.BeforeCexAssets.resize(consts.size());
+    for (size_t i = 0; i < consts.size(); ++i) {
+        CexAssetInfoW& c = w.BeforeCexAssets[i];
+        const zkpor_cex_totals_t& t = b.BeforeCexAssets[i];
+        c.TotalEquity = t.total_equity; c.TotalDebt = t.total_debt; c.BasePrice = consts[i].base_price;
+        if (symbols && i < symbols->size()) c.Symbol = (*symbols)[i];
+        c.Index = (uint32_t)i;
+        c.LoanCollateral = t.loan_collateral; c.MarginCollateral = t.margin_collateral; c.PortfolioMarginCollateral = t.portfolio_margin_collateral;
+        c.LoanRatios = TierRatiosToWire(consts[i].loan); c.MarginRatios = TierRatiosToWire(consts[i].margin);
+        c.PortfolioMarginRatios = TierRatiosToWire(consts[i].portfolio_margin);
+    }
+    w.CreateUserOps.resize(userOpsPerBatch);
+    for (size_t j = 0; j < userOpsPerBatch; ++j) {
+        const CreateUserOperation& op = ops[b.firstOp + j];
+        CreateUserOperationW& o = w.CreateUserOps[j];
+        o.Assets.resize(op.nAssets);
+        for (size_t p = 0; p < op.nAssets; ++p) {
+            const zkpor_asset_t& a = op.Assets[p];
+            o.Assets[p] = AccountAssetW{(uint16_t)a.index, a.equity, a.debt, a.loan, a.margin, a.portfolio_margin};
+        }
+        o.AccountIndex = op.AccountIndex;
+        o.AccountIdHash = h(op.AccountIdHash);
+        for (int k = 0; k < kAccountTreeDepth; ++k) o.AccountProof[k] = h(b.AccountProofs[j * (size_t)depth + k]);
+    }
+    return w;
+}
+
+// the rows Witness.Run hands to WriteBatchWitnessToDB (witness.go:199-203 / :215-232): height = batch number, Status = Published
+inline std::vector<WitnessRow> MakeWitnessRows(const std::vector<BatchCreateUserWitness>& batches, const std::vector<CreateUserOperation>& ops,
+                                               size_t userOpsPerBatch, int depth, const std::vector<zkpor_cex_asset_const_t>& consts,
+                                               int64_t firstHeight = 0, const std::vector<std::string>* symbols = nullptr) {
+    std::vector<WitnessRow> rows(batches.size());
+    for (size_t i = 0; i < batches.size(); ++i) {
+        rows[i].Height = firstHeight + (int64_t)i;
+        rows[i].WitnessData = EncodeBatchWitness(ToWire(batches[i], ops, userOpsPerBatch, depth, consts, symbols));
+        rows[i].Status = 0;
+    }
+    return rows;
+}
 
 }  // namespace zkpor_host
