@@ -4,6 +4,7 @@
 #include "proof_row.hpp"
 #include "r1cs_file.hpp"
 #include "witness_codec.hpp"
+#include "witness_assign.hpp"
 #include <atomic>
 #include <cstring>
 using namespace zkpor_host;
@@ -184,5 +185,23 @@ long zkh_gob_point_example(char* out, size_t cap) {
     gob::put_uint(v, 1); gob::put_int(v, 22); gob::put_uint(v, 1); gob::put_int(v, 33); gob::put_uint(v, 0);
     gob::put_message(o, v);
     return put_out(o, out, cap);
+}
+// decode a WitnessData column and assign the circuit witness (host/witness_assign.hpp): out = n x 32 bytes (4 x u64 LE canonical limbs),
+// counts = n_public, n_secret, tier.  Returns the number of values (negative: needed capacity in values), -1 on error
+long zkh_witness_assign(const char* column, size_t column_len, const int* tiers, int n_tiers, uint64_t* out, size_t cap_values, uint64_t counts[3],
+                        char* err, size_t err_len) {
+    try {
+        BatchCreateUserWitnessW w = DecodeBatchWitness(std::string(column, column_len), true);
+        AssignedWitness a;
+        std::string why;
+        if (!SetBatchCreateUserCircuitWitness(w, std::vector<int>(tiers, tiers + n_tiers), &a, &why)) { if (err && err_len) snprintf(err, err_len, "%s", why.c_str()); return -1; }
+        counts[0] = a.n_public; counts[1] = a.n_secret; counts[2] = (uint64_t)a.tier;
+        if (a.values.size() > cap_values) return -(long)a.values.size();
+        memcpy(out, a.values.data(), a.values.size() * 32);
+        return (long)a.values.size();
+    } catch (const std::exception& e) {
+        if (err && err_len) snprintf(err, err_len, "%s", e.what());
+        return -1;
+    }
 }
 }
