@@ -87,9 +87,10 @@ def cpu_baseline(log2_sample, log2_full, commit_frac):
     here (no Go toolchain); its published figure (62 s per proof INCLUDING the solver, 32 vCPU) is quoted as the anchor."""
     import numpy as np
     import oracle as O
-    cores = O.threads()
+    cores, why = O.usable_cpus()       # the cgroup quota, not the logical CPU count: threads beyond it are only throttled
+    O.set_threads(cores)
     if log2_sample <= 0:
-        log2_sample = 23 if cores >= 64 else (21 if cores >= 16 else 19)
+        log2_sample = 23 if cores >= 64 else (22 if cores >= 12 else 19)
     log2_sample = min(log2_sample, log2_full)
     n = 1 << log2_sample
     nc = max(1, int(n * commit_frac))
@@ -102,12 +103,12 @@ def cpu_baseline(log2_sample, log2_full, commit_frac):
     fft_s, g1_s, g2_s, com_s = O.fast_prove_tail_work(log2_sample, p1, p2, sc, a, b, c, nc)
     dt = fft_s + g1_s + g2_s + com_s
     scale = float(1 << (log2_full - log2_sample))
-    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cores, "kind": "port",
-            "seconds_per_proof_scaled": dt * scale,
+    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cores, "cores_source": why, "kind": "port",
+            "seconds_per_proof_scaled": dt * scale, "core_seconds_per_proof_scaled": dt * scale * cores,
             "sample": f"oracle/cpubase.hpp prove tail (computeH {fft_s:.2f}s + 4 G1 MultiExp {g1_s:.2f}s + G2 MultiExp {g2_s:.2f}s + "
                       f"2 commitment MultiExp {com_s:.2f}s = {dt:.2f}s) at D=2^{log2_sample} on {cores} threads, uniform scalars, "
                       f"scaled x{int(scale)} to D=2^{log2_full}; anchor: the reference publishes 62 s per proof INCLUDING the solver on "
-                      "32 vCPU for gnark (docs/updated_proof_of_solvency_to_mitigate_dummy_user_attack.md:201)"}
+                      "32 vCPU for gnark = 1984 vCPU-seconds (docs/updated_proof_of_solvency_to_mitigate_dummy_user_attack.md:201)"}
 
 
 def solver_budget(gpu_ms_per_proof, host_threads, gpus_per_node=8):
@@ -360,8 +361,14 @@ def main():
                     help="with --split: computeH on rank 0 + scatter of h, or sharded over all ranks with all-to-alls "
                          "(needs a power-of-two number of ranks >= 2; falls back to rank0 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="warm-up + the timed region and nothing else (no uniform region, check, boundary, CPU baseline, acceptance): the "
+                         "form to run under rocprofv3 so that its per-kernel averages cover exactly the launches `roofline` averages")
     ap.add_argument("--cpu-log2", type=int, default=0, help="log2 of the CPU baseline sample (0 = by core count: 2^23 from 64 threads up)")
     args = ap.parse_args()
+    if args.timed_only:
+        args.no_check = args.no_boundary = args.no_cpu_baseline = True
+        args.uniform_steps = 0
 
     import torch
     import zkpor
@@ -637,10 +644,11 @@ def main():
                 except Exception as e:  # the baseline is informational; never lose the GPU line over it
                     out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
             out["solver_budget"] = solver_budget(dt / args.steps * 1e3, os.cpu_count() or 1)
-            try:
-                out["acceptance"] = verifier_acceptance(ctx)
-            except Exception as e:
-                out["acceptance"] = {"proofs": 0, "accepted": 0, "verifier": f"failed: {e}"}
+            if not args.timed_only:
+                try:
+                    out["acceptance"] = verifier_acceptance(ctx)
+                except Exception as e:
+                    out["acceptance"] = {"proofs": 0, "accepted": 0, "verifier": f"failed: {e}"}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     for wk in workers[1:]:
         wk[0].close()

@@ -506,3 +506,39 @@ def fast_prove_tail_work(log2d, g1, g2, w, a, b, c, n_commit):
 
 def threads():
     return int(lib().orc_threads())
+
+
+def set_threads(n):
+    """OpenMP thread count of the baseline port (libgomp of this process)"""
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+
+
+def usable_cpus():
+    """CPUs this process can really use: min(logical CPUs, affinity mask, cgroup CPU quota) and where the number came from.
+    A container with cpu.max = "1600000 100000" gets 16 CPUs' worth of time however many it sees (more threads only get throttled)."""
+    import math
+    import os
+    n = os.cpu_count() or 1
+    why = f"{n} logical CPUs"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, f"affinity mask of {a} CPUs"
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:                                                                      # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, why = max(1, int(math.floor(quota + 1e-9))), f"cgroup CPU quota of {quota:g} CPUs (of {os.cpu_count()} logical)"
+    return n, why

@@ -1,5 +1,5 @@
 // fe52: a 254-bit Montgomery product on 5 x 52-bit limbs held in doubles, partial products split into exact high and low halves
-// by two v_fma_f64 in round-toward-zero mode (Emmart et al., "Faster Modular Exponentiation Using Double Precision Floating Point
+// by two v_fma_f64 (after Emmart et al., "Faster Modular Exponentiation Using Double Precision Floating Point
 // Arithmetic on the GPU"), column sums accumulated as 64-bit integers.  PROTOTYPE for one question: does a
 // DFMA formulation beat the 9 x 29-bit v_mad_i64_i32 product of fe29.cuh (206 VALU instructions, 1.74e11 products/s measured)?
 // v_fma_f64 issues at the same rate as v_mad_u64_u32 on gfx950 (profiles/r01_alu_microbench.txt), so the answer is the
@@ -20,67 +20,71 @@ __device__ __forceinline__ long long bits(double x) { return __double_as_longlon
 __device__ __constant__ double kP52[5] = {0xc16d87cfd47p0 * 1.0, 0, 0, 0, 0};  // filled by the host (see main)
 __device__ __constant__ double kNinv52;
 
-// one 52 x 52 -> 104 bit partial product as two exact halves, added into 64-bit column sums.
-// hi = fma_rz(a, b, 2^104) = 2^104 + floor(ab / 2^52) 2^52 (exact: ulp at 2^104 is 2^52, rounding toward zero = floor)
-// lo = fma_rz(a, b, (2^104 + 2^52) - hi) = 2^52 + (ab mod 2^52) (exact)
-// The exponent words the bit patterns carry are removed once per column (constants folded into the column's start value).
+// one 52 x 52 -> 104 bit partial product as two exact halves, added into 64-bit column sums — in the DEFAULT rounding mode
+// (round to nearest), so no MODE register games:
+//   hi = fma(a, b, 2^104)                   = 2^104 + H 2^52,  H = round(ab / 2^52)        (ulp at 2^104 is 2^52)
+//   lo = fma(a, b, 2^104 - hi) + 1.5 2^52   = 1.5 2^52 + L,    L = ab - H 2^52 in [-2^51, 2^51]   (both steps exact; the offset
+//        cannot be folded into the addend: 2^104 + 1.5 2^52 is not representable)
+// The bit patterns are added as integers: the mantissa of hi is H, of lo is 2^51 + L; the exponent words and the 2^51 are removed
+// once per column.  q of the reduction is the SIGNED residue L of t n' (|q| <= 2^51), its products with p use 1.5 2^104 so that
+// a negative product still lands in [2^104, 2^105).
 #define C1 0x1p104
-#define C3 (0x1p104 + 0x1p52)
+#define C1S 0x1.8p104
+template <bool SIGNED>
 __device__ __forceinline__ void pp(double a, double b, long long& col_lo, long long& col_hi) {
-    double hi = __builtin_fma(a, b, C1);
-    double lo = __builtin_fma(a, b, C3 - hi);
+    double hi = __builtin_fma(a, b, SIGNED ? C1S : C1);
+    double lo = __builtin_fma(a, b, (SIGNED ? C1S : C1) - hi) + 0x1.8p52;
     col_lo += bits(lo);
     col_hi += bits(hi);
 }
 
 __device__ __forceinline__ Fe52 mul52(const Fe52& a, const Fe52& b) {
-    // columns 0..9 of the 10-limb product, as integers (each < 10 x 2^52 + carries: fits easily)
     long long t[11];
-    const long long bias_lo = bits(0x1p52), bias_hi = bits(C1);   // removed per term below, in bulk
+    const long long bias_lo = bits(0x1.8p52), bias_hi = bits(C1), bias_his = bits(C1S);
 #pragma unroll
     for (int k = 0; k < 11; ++k) t[k] = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) pp(a.l[i], b.l[j], t[i + j], t[i + j + 1]);
-    // number of lo terms in column k: min(k, 8 - k) + 1 for k <= 8; hi terms: the same for column k - 1
+        for (int j = 0; j < 5; ++j) pp<false>(a.l[i], b.l[j], t[i + j], t[i + j + 1]);
+    // number of lo terms in column k: min(k, 8 - k) + 1 for k <= 8; hi terms: the same for column k - 1 (compile-time constants)
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         int nlo = k <= 8 ? (k < 4 ? k : 8 - k < 4 ? 8 - k : 4) + 1 : 0;
         int nhi = k >= 1 ? ((k - 1) < 4 ? (k - 1) : 8 - (k - 1) < 4 ? 8 - (k - 1) : 4) + 1 : 0;
         t[k] -= nlo * bias_lo + nhi * bias_hi;
     }
-    // Montgomery reduction, one limb per step: q = (t[i] n') mod 2^52, t += q p 2^(52 i)
+    // + p R: the signed q below can leave the quotient one p short; the result stays in (0, 3p)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) t[5 + j] += (long long)kP52[j];
+    // Montgomery reduction, one limb per step: q = signed residue of (t[i] n') mod 2^52, t += q p 2^(52 i)
     const long long M52 = (1LL << 52) - 1;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         double ti = __longlong_as_double((t[i] & M52) | bits(0x1p52)) - 0x1p52;   // low 52 bits of the column as a double
         double hq = __builtin_fma(ti, kNinv52, C1);
-        double q = __builtin_fma(ti, kNinv52, C3 - hq) - 0x1p52;                   // (ti n') mod 2^52
-        long long lo_acc = 0, hi_acc = 0;
+        double q = __builtin_fma(ti, kNinv52, C1 - hq);                            // in [-2^51, 2^51], = ti n' mod 2^52
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             long long l = 0, h = 0;
-            pp(q, kP52[j], l, h);
+            pp<true>(q, kP52[j], l, h);
             t[i + j] += l - bias_lo;
-            t[i + j + 1] += h - bias_hi;
+            t[i + j + 1] += h - bias_his;
         }
-        (void)lo_acc; (void)hi_acc;
-        t[i + 1] += t[i] >> 52;   // t[i] is now 0 mod 2^52: pass its carry on
+        t[i + 1] += t[i] >> 52;   // t[i] is now 0 mod 2^52: pass its (signed) carry on
     }
-    // limbs 5..9 hold the result (< 2p); normalise to 52-bit limbs and back to doubles
+    // limbs 5..9 hold the result; normalise to 52-bit limbs and back to doubles
     Fe52 r;
 #pragma unroll
     for (int k = 5; k < 10; ++k) {
         long long v = t[k];
-        if (k < 9) t[k + 1] += v >> 52;
-        r.l[k - 5] = __longlong_as_double((v & M52) | bits(0x1p52)) - 0x1p52;
+        if (k < 9) { t[k + 1] += v >> 52; v &= M52; }
+        r.l[k - 5] = __longlong_as_double(v | bits(0x1p52)) - 0x1p52;
     }
     return r;
 }
 
 __global__ __launch_bounds__(256) void k_mul52(double* x, int iters) {
-    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);   // MODE.fp_round[3:2] (f64 / f16) = round toward zero
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     Fe52 a, b;
 #pragma unroll
@@ -159,7 +163,29 @@ int main() {
         }
         u64 r[5];
         for (int k = 5; k < 10; ++k) { if (k < 9) col[k + 1] += col[k] >> 52; r[k - 5] = (u64)(col[k] & ((1ULL << 52) - 1)); }
-        for (int k = 0; k < 5; ++k) if ((u64)got[10 * t + k] != r[k]) { if (!bad) printf("fe52 MISMATCH thread %d limb %d: %llx vs %llx\n", t, k, (unsigned long long)got[10 * t + k], (unsigned long long)r[k]); ++bad; break; }
+        // both sides are a b R^-1 up to a small multiple of p (the device uses signed quotient digits and an offset of p): compare mod p
+        auto modp = [&](const u64* l52, u64 top_extra) {   // value = sum l52[k] 2^(52k) (+ top limb may exceed 52 bits), reduced below p
+            u128 acc[5];
+            for (int k = 0; k < 5; ++k) acc[k] = l52[k];
+            acc[4] += (u128)top_extra << 52;
+            std::vector<u64> v(5);
+            for (int rep = 0; rep < 8; ++rep) {
+                // compare acc with p52 limb-wise after normalising
+                for (int k = 0; k < 4; ++k) { acc[k + 1] += acc[k] >> 52; acc[k] &= ((1ULL << 52) - 1); }
+                bool ge = true;
+                for (int k = 4; k >= 0; --k) { if ((u64)acc[k] != p52[k]) { ge = (u64)acc[k] > p52[k]; break; } }
+                if (!ge) break;
+                // acc -= p (borrow through 52-bit limbs)
+                long long borrow = 0;
+                for (int k = 0; k < 5; ++k) { long long d = (long long)(u64)acc[k] - (long long)p52[k] - borrow; borrow = d < 0; if (d < 0 && k < 4) d += 1LL << 52; acc[k] = (u64)d; }
+            }
+            for (int k = 0; k < 5; ++k) v[k] = (u64)acc[k];
+            return v;
+        };
+        u64 g52[5];
+        for (int k = 0; k < 5; ++k) g52[k] = (u64)got[10 * t + k];
+        u64 gtop = g52[4] >> 52; g52[4] &= (1ULL << 52) - 1;
+        if (modp(g52, gtop) != modp(r, 0)) { if (!bad) printf("fe52 MISMATCH thread %d: device limb0 %llx host limb0 %llx\n", t, (unsigned long long)g52[0], (unsigned long long)r[0]); ++bad; }
     }
     printf("fe52 prototype vs host integers on 256 products: %s\n", bad ? "MISMATCH" : "ok");
 
