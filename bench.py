@@ -548,6 +548,8 @@ def main():
         t_chk = time.perf_counter()
         import oracle as O
         import trapdoor as T
+        if world > 1:   # every rank checks its own proofs: share the host's usable CPUs instead of oversubscribing them world-fold
+            O.set_threads(max(1, O.usable_cpus()[0] // world))
 
         def host(t, n):
             out = np.empty((n, 4), dtype=np.uint64)
@@ -563,7 +565,7 @@ def main():
             ok += int(td.check(proof, r, s) and np.array_equal(com, ec) and np.array_equal(pok, ek))
         total = len(proofs)
         if uproofs:
-            tdu = T.SynthKeyTrapdoor(seed, 3, host(wu, n_wires), h_host)
+            tdu = T.SynthKeyTrapdoor(seed, 3, host(wu, n_wires), None, dZ=td.dZ)      # same a, b, c => same h
             for i, proof, com, pok in uproofs:
                 r, s = blinding(i)
                 ok += int(tdu.check(proof, r, s) and np.array_equal(com, ec) and np.array_equal(pok, ek))

@@ -105,14 +105,14 @@ class SynthKeyTrapdoor:
     """the discrete logs of one synthetic key against one (w, h): the four dot products are taken once, any number of
     proofs with different blinding (r, s) are then checked with a handful of Fr operations and three fixed-base products"""
 
-    def __init__(self, seed, n_public, w_mont, h_mont):
+    def __init__(self, seed, n_public, w_mont, h_mont, dZ=None):
+        """h_mont: the first len(Z) = D - 1 scalars of h in the key's order; dZ: <sZ, h> from another instance over the same h"""
         w = O._u64(w_mont).reshape(-1, 4)
-        h = O._u64(h_mont).reshape(-1, 4)
         self.k_alpha = _fr(synth_k(seed, 100, 0)); self.k_beta = _fr(synth_k(seed, 101, 0)); self.k_delta = _fr(synth_k(seed, 102, 0))
         self.dA = synth_dot(seed, G1_A, w)
         self.dB = synth_dot(seed, G1_B, w)                       # B1 and B2 carry the same scalars
         self.dK = synth_dot(seed, G1_K, w, inf_below=n_public)
-        self.dZ = synth_dot(seed, G1_Z, h)                       # h in the order of the key's Z (memory order of both)
+        self.dZ = dZ if dZ is not None else synth_dot(seed, G1_Z, O._u64(h_mont).reshape(-1, 4))   # h in the order of the key's Z
 
     def expected(self, r_mont, s_mont):
         """(Ar, Bs, Krs) affine as uint64 limb arrays (8,), (16,), (8,) for blinding r, s (Montgomery limbs)"""
