@@ -234,6 +234,39 @@ def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vector
                     "buffers filled by copy threads, w first then a/b/c under the A/B1/K accumulations; two callers = two contexts on one GPU"}
 
 
+def poseidon_tree_leg(ctx, log2_leaves=27, depth=28):
+    """The second half of the north star in the driver's line: the Poseidon account tree at the reference's BenchmarkBuild size
+    (2^27 leaves, src/utils/merkletree/merkletree_test.go:287-298), leaves resident in HBM, built by zkpor_merkle_build_dev.
+    Algorithmic bytes: 32 N leaves read + 32 (N - 1) nodes written.  Checked through a size-independent property:
+    root(N leaves) = H(root(left half), root(right half)) lifted with nil hashes to the full depth (oracle Poseidon as the checker).
+    Untimed leg, rank 0, N = 1 only."""
+    import numpy as np
+    import oracle as O
+    n = 1 << log2_leaves
+    buf = ctx.alloc(32 * n)
+    try:
+        ctx.fill_fr(buf, n, 5, 0)
+        nil = O.poseidon_hash(O.fr_from_ints([0, 0, 0, 0, 0]))
+        ctx.merkle_build_dev(buf.ptr, 1 << 16, depth, nil)           # tables, workspace
+        ctx.sync()
+        ctx.phase_reset()
+        root = ctx.merkle_build_dev(buf.ptr, n, depth, nil)
+        ms, _ = ctx.phase_ms("poseidon_tree")
+        left = ctx.merkle_build_dev(buf.ptr, n // 2, log2_leaves - 1, nil)
+        right = ctx.merkle_build_dev(buf.ptr + 32 * (n // 2), n // 2, log2_leaves - 1, nil)
+        node = O.poseidon_hash(np.stack([left, right]))
+        _, nilh, _ = O.merkle_build(np.zeros((0, 4), np.uint64), depth, nil)
+        for l in range(log2_leaves, depth):
+            node = O.poseidon_hash(np.stack([node, nilh[l]]))
+        ok = bool(np.array_equal(root, node))
+    finally:
+        buf.free()
+    gbs = 64.0 * n / (ms * 1e-3) / 1e9
+    return {"leaves": n, "depth": depth, "build_ms": ms, "hashes_per_s": (n - 1) / (ms * 1e-3), "checked_root_split_property": ok,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "note": "width-3 Poseidon permutation per node (~370 field products): VALU-bound like the prove tail"}}
+
+
 def verifier_acceptance(ctx, n_proofs=4):
     """BASELINE.json's metric asks for 100 % verifier acceptance beside the rate.  The 2^26 key of the timed region is
     a random-point key (no R1CS behind it), so acceptance is measured on a real (small) circuit: the same library calls
@@ -646,6 +679,11 @@ def main():
                 except Exception as e:  # the baseline is informational; never lose the GPU line over it
                     out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
             out["solver_budget"] = solver_budget(dt / args.steps * 1e3, os.cpu_count() or 1)
+            if not args.timed_only and log2 >= 20:
+                try:
+                    out["poseidon_tree"] = poseidon_tree_leg(ctx)
+                except Exception as e:
+                    out["poseidon_tree"] = {"leaves": 0, "note": f"failed: {e}"}
             if not args.timed_only:
                 try:
                     out["acceptance"] = verifier_acceptance(ctx)

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""profiles/rNN_pmc_valu.json from one rocprofv3 pass (--pmc SQ_INSTS_VALU --kernel-trace, csv): VALU wave-instructions per
+kernel, the input of bench.py's `roofline.valu_issue` (issue-rate ceiling = instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)).
+usage: pmc_valu_summary.py counter_collection.csv out.json [round-tag]"""
+import collections
+import csv
+import json
+import sys
+
+KERNELS = ("k_acc_level1_fp29", "k_acc_level1_g2pair29", "k_ntt_pass29", "k_acc_levelN29", "k_reduce_level29", "k_h_pointwise", "k_decompose")
+
+
+def main():
+    agg = collections.defaultdict(lambda: [0.0, 0, 0.0])
+    for r in csv.DictReader(open(sys.argv[1])):
+        if r["Counter_Name"] != "SQ_INSTS_VALU":
+            continue
+        for k in KERNELS:
+            if k in r["Kernel_Name"]:
+                a = agg[k]
+                a[0] += float(r["Counter_Value"]); a[1] += 1
+                a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+                break
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    out = {"source": f"rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -- python bench.py --log2 26 --steps 1 --warmup 0 --timed-only ({tag})",
+           "simds": 1024, "issue_cycles_per_wave_instruction": 4, "nominal_clock_hz": 2.4e9, "kernels": {}}
+    for k, (v, n, ms) in agg.items():
+        bound_ms = v * 4 / (1024 * 2.4e9) * 1e3
+        out["kernels"][k] = {"launches": n, "valu_wave_insts_total": v, "time_ms_total_under_pmc": ms,
+                             "issue_bound_ms_total": bound_ms, "frac_of_issue_bound_under_pmc": bound_ms / ms if ms else None}
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
+    print(json.dumps(out["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
