@@ -268,8 +268,8 @@ void zkpor_destroy(zkpor_ctx* ctx) {
     pos_tables_free(ctx);
     ntt_domains_free(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
-    bounce_free(ctx);
+    bounce_free(ctx);  // drains the copy stream first: no DMA may still read the pinned buffers
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -1,6 +1,13 @@
 // MSM step 3, G1, level 1 — the dominant kernel of the prover: field products fully inlined.
 #include "msm_kernels.cuh"
 #include "msm_kernels29.cuh"
+// occupancy experiment hook (tools/r02_occupancy.sh): -DZK_L1_WAVES=n pins the level-1 kernels to n waves per SIMD; the default lets
+// the register allocator decide (149 VGPRs -> 3 waves per SIMD)
+#ifdef ZK_L1_WAVES
+#define ZK_L1_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ZK_L1_WAVES, ZK_L1_WAVES)))
+#else
+#define ZK_L1_OCCUPANCY
+#endif
 namespace zk {
 
 // 2 * (+/- P) for a key point, out of line and fed from memory (see xyzz29_madd)
@@ -13,7 +20,7 @@ __device__ __noinline__ XYZZ29 dbl_point_g1(const Affine<Fp>* p, bool neg) {
 // raw register image (raw29_store): finished buckets go to `braw`, the <= 2 runs cut by the chunk edge to `praw` (2 per
 // chunk) — the key-change path, taken by some lane of a wave in about half of all iterations, is 36 plain stores.  The
 // later stages (msm_kernels29.cuh) consume the images as they are.
-__global__ __launch_bounds__(256) void k_acc_level1_fp29(const u32* __restrict__ keys, const u32* __restrict__ vals,
+__global__ __launch_bounds__(256) ZK_L1_OCCUPANCY void k_acc_level1_fp29(const u32* __restrict__ keys, const u32* __restrict__ vals,
                                                          const Affine<Fp>* __restrict__ pts, u32 M, int L,
                                                          u32* __restrict__ braw, u32* __restrict__ out_keys, u32* __restrict__ praw) {
     __shared__ u32 sk[256 * ACC_PITCH];

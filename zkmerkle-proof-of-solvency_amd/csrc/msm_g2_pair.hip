@@ -4,6 +4,13 @@
 #include "msm_kernels29.cuh"
 #include "fp2_lanepair.cuh"
 
+// occupancy experiment hook (tools/r02_occupancy.sh): -DZK_L1_WAVES=n pins the level-1 kernels to n waves per SIMD; the default lets
+// the register allocator decide (149 VGPRs -> 3 waves per SIMD)
+#ifdef ZK_L1_WAVES
+#define ZK_L1_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ZK_L1_WAVES, ZK_L1_WAVES)))
+#else
+#define ZK_L1_OCCUPANCY
+#endif
 namespace zk {
 
 __device__ __forceinline__ void lp_store(XYZZ<Fp2>* dst, const XYZZ<Fp2L>& a, u32 par) {
@@ -104,7 +111,7 @@ struct Pol29G2 {
 };
 
 // see k_acc_level1_fp29 (msm_g1_hot.hip): raw images for buckets (braw) and the chunk's two partials (praw)
-__global__ __launch_bounds__(256) void k_acc_level1_g2pair29(const u32* __restrict__ keys, const u32* __restrict__ vals,
+__global__ __launch_bounds__(256) ZK_L1_OCCUPANCY void k_acc_level1_g2pair29(const u32* __restrict__ keys, const u32* __restrict__ vals,
                                                              const Affine<Fp2>* __restrict__ pts, u32 M, int L,
                                                              u32* __restrict__ braw, u32* __restrict__ out_keys, u32* __restrict__ praw) {
     __shared__ u32 sk[128 * ACC_PITCH];

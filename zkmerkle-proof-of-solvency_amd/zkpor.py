@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkpor.so")
+# ZKPOR_LIB: experiment hook (kernel build variants under tools/bin/variants); the product library is the in-tree one
+LIB_PATH = os.environ.get("ZKPOR_LIB") or os.path.join(_HERE, "libzkpor.so")
 
 G1_A, G1_B, G1_K, G1_Z, G1_COMMIT_BASIS, G1_COMMIT_BASIS_SIGMA = range(6)
 G2_B = 0
