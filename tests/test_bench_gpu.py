@@ -1,0 +1,48 @@
+"""-m gpu: bench.py end to end at a small domain (2^18) — the contract of its one JSON line: the metric fields, every timed proof
+verified against the trapdoor (both timed regions), the uniform rate, roofline, the host-pointer boundary leg with its own check,
+CPU baseline, solver budget, acceptance.  Guards the line the driver records against regressions of any leg."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line on stdout, whatever the native libraries print
+    return json.loads(lines[0])
+
+
+def test_bench_line_small_domain():
+    d = _bench("--log2", "18", "--steps", "3", "--warmup", "1", "--cpu-log2", "14")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "proofs/s" and d["higher_is_better"] and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "solver is NOT included" in d["config"]["workload"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["checked"]["proofs"] == 3 + d["uniform"]["steps"] and d["checked"]["ok"] == d["checked"]["proofs"]
+    assert d["value_uniform"] == d["uniform"]["value"] and d["value_uniform"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["avg_launch_ms"] > 0
+    b = d["boundary"]
+    assert b["callers"] == 2 and b["checked_ok"] == b["proofs"] and b["value"] > 0 and b["one_caller_ms_per_proof"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "2^14" in c["sample"]
+    assert d["acceptance"]["accepted"] == d["acceptance"]["proofs"] == 4
+    assert d["solver_budget"]["gpu_ms_per_proof"] == d["ms_per_step"]
+
+
+def test_bench_other_tier_and_timed_only():
+    d = _bench("--log2", "17", "--steps", "2", "--warmup", "1", "--config", "zkpor500_200", "--timed-only")
+    assert d["config"]["tier"] == "zkpor500_200" and d["config"]["users_per_batch"] == 200
+    assert d["checked"] is None and d["value_uniform"] is None and "boundary" not in d and "cpu_baseline" not in d and "acceptance" not in d
