@@ -161,7 +161,7 @@ def timed_region(dist, sync, run):
     return dt
 
 
-def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vectors, td, blinding, resident_ms, n_proofs=3):
+def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vectors, td, blinding, resident_ms, n_proofs=3, copy_threads=0):
     """The call a cgo caller actually makes (INTEGRATION.md `ProveTail` / `Commit`): the HOST-pointer entry points
     zkpor_commit + zkpor_prove_tail on PAGEABLE host memory (numpy heap arrays standing in for gnark's []fr.Element), 8.6 GB + 0.5 GB
     per proof across PCIe inside the call.  Two shapes: one caller (a proof's latency from host memory: w crosses first, a/b/c cross
@@ -192,6 +192,9 @@ def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vector
     other = zkpor.Context(device, None)
     try:
         ctxs = [ctx, other]
+        if copy_threads:
+            for c_ in ctxs:
+                c_.set_param("copy_threads", copy_threads)
         for k, wctx in enumerate(ctxs):       # warm-up: staging areas, bounce buffers, copy threads, workspaces
             prove(wctx, 9000 + k)
         t0 = time.perf_counter()
@@ -229,7 +232,7 @@ def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vector
     ok = sum(int(td.check(p, *blinding(i))) for i, p in results) if td is not None else None
     return {"value": 1e3 / two_ms, "unit": "proofs/s", "ms_per_proof": two_ms, "frac_of_resident_value": resident_ms / two_ms,
             "callers": 2, "one_caller_ms_per_proof": one_ms, "one_caller_value": 1e3 / one_ms,
-            "bytes_per_proof": int(bytes_per_proof), "proofs": len(results), "checked_ok": ok,
+            "bytes_per_proof": int(bytes_per_proof), "proofs": len(results), "checked_ok": ok, "copy_threads_per_context": copy_threads or 4,
             "note": "zkpor_commit + zkpor_prove_tail (host-pointer ABI) on pageable numpy memory; persistent HBM staging, pinned bounce "
                     "buffers filled by copy threads, w first then a/b/c under the A/B1/K accumulations; two callers = two contexts on one GPU"}
 
@@ -384,6 +387,8 @@ def main():
                     help="steps of the second, uniform-scalar timed region reported as value_uniform (-1 = max(2, steps/4); 0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the trapdoor verification of the timed proofs")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-pointer (cgo-shaped) boundary leg")
+    ap.add_argument("--copy-threads", type=int, default=0, help="host threads per context that fill the pinned bounce buffers in the "
+                    "boundary leg (0 = library default, 4)")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1, help="proofs in flight per GPU (in-process dispatcher workers, one HIP stream + workspace each)")
@@ -670,7 +675,7 @@ def main():
             if not args.no_boundary:
                 try:
                     out["boundary"] = boundary_leg(torch, zkpor, ctx, local_rank, pk, D, n_wires, n_commit, (w, a0, b0, c0, cv), td, blinding,
-                                                   resident_ms=dt / args.steps * 1e3)
+                                                   resident_ms=dt / args.steps * 1e3, copy_threads=args.copy_threads)
                 except Exception as e:
                     out["boundary"] = {"value": None, "note": f"failed: {e}"}
             if not args.no_cpu_baseline:
