@@ -387,6 +387,7 @@ def main():
                     help="steps of the second, uniform-scalar timed region reported as value_uniform (-1 = max(2, steps/4); 0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the trapdoor verification of the timed proofs")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-pointer (cgo-shaped) boundary leg")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="skip the informational region with two proofs in flight per GPU")
     ap.add_argument("--copy-threads", type=int, default=0, help="host threads per context that fill the pinned bounce buffers in the "
                     "boundary leg (0 = library default, 4)")
     ap.add_argument("--window", type=int, default=0)
@@ -577,6 +578,27 @@ def main():
         dtu = timed_region(dist, torch.cuda.synchronize, lambda: run_steps(usteps, wu, uproofs, first=5000))
         uni = {"value": world * usteps / dtu, "ms_per_step": dtu / usteps * 1e3, "steps": usteps}
 
+    # informational third region (N = 1): TWO proofs in flight on the GPU (a second context + stream, how host/prover_host.hpp keeps a
+    # GPU busy and how `boundary` hides the copies).  `value` stays the one-in-flight figure so that the kernel times `roofline`
+    # reports are those rocprofv3 sees for an undisturbed kernel; the proofs of this region are checked with the others.
+    two = None
+    if world == 1 and len(workers) == 1 and not args.timed_only and not args.no_two_in_flight:
+        extra = (zkpor.Context(local_rank, None), dev(32 * D), dev(32 * D), dev(32 * D))
+        workers.append(extra)
+        try:
+            tsteps = max(4, args.steps // 2)
+            run_steps(2, w)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(tsteps, w, proofs, first=7000)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            two = {"value": tsteps / dt2, "ms_per_step": dt2 / tsteps * 1e3, "steps": tsteps, "proofs_in_flight": 2}
+        finally:
+            workers.pop()
+            extra[0].close()
+            del extra
+
     # ---- every timed proof is verified, untimed: prove, then verify (prover.go:269-276).  The synthetic key is trapdoor-known, so
     # Ar / Bs / Krs and the two commitment sums are checked in the exponent at the exact size and mixture that was timed
     # (oracle/trapdoor.py: four dot products over Fr on the host + fixed-base products by the CPU oracle).
@@ -655,6 +677,7 @@ def main():
             "value_uniform": uni["value"] if uni else None,
             "uniform": ({**uni, "note": "same step with every witness scalar uniform in Fr (worst case; the witness mixture is an estimate)"}
                         if uni else None),
+            "two_in_flight": two,
             "checked": checked,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -30,7 +30,8 @@ def test_bench_line_small_domain():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "proofs/s" and d["higher_is_better"] and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "solver is NOT included" in d["config"]["workload"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
-    assert d["checked"]["proofs"] == 3 + d["uniform"]["steps"] and d["checked"]["ok"] == d["checked"]["proofs"]
+    assert d["two_in_flight"]["proofs_in_flight"] == 2 and d["two_in_flight"]["value"] > 0
+    assert d["checked"]["proofs"] == 3 + d["uniform"]["steps"] + d["two_in_flight"]["steps"] and d["checked"]["ok"] == d["checked"]["proofs"]
     assert d["value_uniform"] == d["uniform"]["value"] and d["value_uniform"] > 0
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["avg_launch_ms"] > 0
@@ -45,4 +46,4 @@ def test_bench_line_small_domain():
 def test_bench_other_tier_and_timed_only():
     d = _bench("--log2", "17", "--steps", "2", "--warmup", "1", "--config", "zkpor500_200", "--timed-only")
     assert d["config"]["tier"] == "zkpor500_200" and d["config"]["users_per_batch"] == 200
-    assert d["checked"] is None and d["value_uniform"] is None and "boundary" not in d and "cpu_baseline" not in d and "acceptance" not in d
+    assert d["checked"] is None and d["value_uniform"] is None and d["two_in_flight"] is None and "boundary" not in d and "cpu_baseline" not in d and "acceptance" not in d
