@@ -4,6 +4,7 @@
 // how two proofs are kept in flight per GPU).  Plays the role of the Go caller; loaded by tests/test_dispatcher_gpu.py.
 #include "../../zkmerkle-proof-of-solvency_amd/host/prover_host.hpp"
 #include "../../zkmerkle-proof-of-solvency_amd/host/r1cs_file.hpp"
+#include "../../zkmerkle-proof-of-solvency_amd/host/prove_batch.hpp"
 #include "../../include/zkpor.h"
 #include <atomic>
 #include <cstring>
@@ -83,5 +84,38 @@ int r1cs_file_eval(const uint8_t* data, size_t len, const uint64_t* w, uint64_t*
     if (r) zkpor_r1cs_destroy(r);
     zkpor_destroy(ctx);
     return rc;
+}
+
+// a1 end to end: a witness-table row -> decode -> assign -> solver (stub: the test's own solution of its own circuit, after checking
+// what it was handed) -> commitment -> prove tail -> raw proof -> proof-table row as a CSV line.  The key is loaded by the caller
+// (Python) into ctx/pk handles passed in as pointers.
+long prove_batch_row(void* ctx_h, void* pk_h, const char* column, size_t column_len, int64_t batch, const uint64_t* w, const uint64_t* a,
+                     const uint64_t* b, const uint64_t* c, size_t n_wires, size_t n_constraints, const uint64_t* committed, size_t n_committed,
+                     const uint64_t* r, const uint64_t* s, uint64_t expect_inputs, int fail_stage, char* out, size_t cap, int* tier,
+                     uint8_t* raw_out, size_t* raw_len, char* err, size_t err_len) {
+    zkpor_ctx* ctx = (zkpor_ctx*)ctx_h;
+    zkpor_pk* pk = (zkpor_pk*)pk_h;
+    std::string raw_seen;
+    SolveFn solve = [&](const AssignedWitness& in, const CommitFn& commit, SolvedWitness* sol) -> int {
+        if (in.values.size() != expect_inputs || in.n_public != 1) return 2;   // the assigned vector really reached the solver
+        if (fail_stage == PB_SOLVE) return 1;
+        sol->w.assign(w, w + 4 * n_wires); sol->a.assign(a, a + 4 * n_constraints);
+        sol->b.assign(b, b + 4 * n_constraints); sol->c.assign(c, c + 4 * n_constraints);
+        sol->n_constraints = n_constraints;
+        if (n_committed) { uint8_t cm[64], k[64]; if (commit(committed, n_committed, cm, k) != 0) return 3; }
+        return 0;
+    };
+    VerifyFn verify = [&](const std::string& raw, const BatchCreateUserWitnessW&) -> int { raw_seen = raw; return fail_stage == PB_VERIFY ? 1 : 0; };
+    ProofRow row;
+    std::string why;
+    int rc = GenerateAndVerifyProof(ctx, pk, std::string(column, column_len), batch, {50, 500}, solve, r, s, verify, &row, tier, &why);
+    if (rc != PB_OK) { snprintf(err, err_len, "%s", why.c_str()); return -rc; }
+    if (raw_seen.size() > 512) return -100;
+    memcpy(raw_out, raw_seen.data(), raw_seen.size());
+    *raw_len = raw_seen.size();
+    std::string line = std::string(ProofCsvHeader()) + ProofCsvLine(row);
+    if (line.size() > cap) return -101;
+    memcpy(out, line.data(), line.size());
+    return (long)line.size();
 }
 }
