@@ -271,30 +271,40 @@ def poseidon_tree_leg(ctx, log2_leaves=27, depth=28):
 
 
 def verifier_acceptance(ctx, n_proofs=4):
-    """BASELINE.json's metric asks for 100 % verifier acceptance beside the rate.  The 2^26 key of the timed region is
-    a random-point key (no R1CS behind it), so acceptance is measured on a real (small) circuit: the same library calls
-    prove a 500-constraint synthetic R1CS with fresh blinding each time and the oracle's pairing verifier
-    (oracle/algos.hpp groth16_verify_pairing = the equation of groth16.Verify, prover.go:276) must accept every proof.
-    Untimed, rank 0, N = 1 only."""
+    """BASELINE.json's metric asks for 100 % verifier acceptance beside the rate.  The 2^26 key of the timed region is a
+    random-point key (no R1CS behind it), so acceptance is measured on a real (small) circuit of the reference's SHAPE — one BSB22
+    commitment over a set of private wires that are therefore absent from pk.G1.K: the same library calls (zkpor_commit +
+    zkpor_prove_tail, fresh blinding each time) prove a 500-constraint synthetic R1CS and the oracle's pairing verifier must accept
+    every proof under the commitment-extended equation of groth16.Verify (prover.go:276; oracle/algos.hpp
+    groth16_verify_pairing_commit: D joins the public-input sum, the knowledge proof is checked).  Untimed, rank 0, N = 1 only."""
     import numpy as np
     import oracle as O
     import zkpor
     S = O.Synth(6, 500, n_public=2, seed=41)
+    rng = np.random.default_rng(5)
+    committed = np.sort(rng.choice(np.arange(S.n_public, S.n_wires), size=64, replace=False)).astype(np.uint32)
+    sigma = O.fr_random(77, 1)[0]
+    basis, basis_sigma = S.commitment_basis(committed, sigma)
+    g2s = O.g2_mul_gen(sigma)
+    keep = np.ones(S.n_wires, dtype=bool); keep[:S.n_public] = False; keep[committed] = False
     pk = zkpor.ProvingKey(ctx)
     try:
         z = np.zeros(S.n_wires, dtype=np.uint8)
         pk.set_g1(zkpor.G1_A, S.A); pk.set_g1(zkpor.G1_B, S.B1); pk.set_g2(zkpor.G2_B, S.B2)
-        pk.set_g1(zkpor.G1_K, S.K[S.n_public:]); pk.set_g1(zkpor.G1_Z, S.Z)
-        pk.set_consts(S.abd1[0], S.abd1[1], S.abd1[2], S.bd2[0], S.bd2[1], S.log2d, z, z, S.n_wires, S.n_public)
+        pk.set_g1(zkpor.G1_K, S.K[keep]); pk.set_g1(zkpor.G1_Z, S.Z)
+        pk.set_g1(zkpor.G1_COMMIT_BASIS, basis); pk.set_g1(zkpor.G1_COMMIT_BASIS_SIGMA, basis_sigma)
+        pk.set_consts(S.abd1[0], S.abd1[1], S.abd1[2], S.bd2[0], S.bd2[1], S.log2d, z, z, S.n_wires, S.n_public, committed)
         ok = 0
         for i in range(n_proofs):
             r = O.fr_random(100 + i, 1)[0]; s = O.fr_random(200 + i, 1)[0]
+            d, pok = ctx.commit(pk, S.w[committed])
             proof = ctx.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
-            ok += int(S.verify_pairing(proof))
+            ok += int(S.verify_pairing_commit(proof, d, pok, g2s))
     finally:
         pk.close()
     return {"proofs": n_proofs, "accepted": ok,
-            "verifier": "oracle pairing check of the Groth16 equation (stand-in for gnark groth16.Verify), 500-constraint synthetic R1CS"}
+            "verifier": "oracle pairing check of the Groth16 equation with one BSB22 commitment (stand-in for gnark groth16.Verify), "
+                        "500-constraint synthetic R1CS, 64 committed wires"}
 
 
 def split_main(args, torch, zkpor, ctx, dist, rank, world, json_fd):

@@ -337,6 +337,18 @@ int orc_synth_verify_pairing(void* p, const uint8_t* proof256) {
     SynthVK vk = synth_vk(h->key);
     return groth16_verify_pairing(vk, h->inst.w.data(), pr) ? 1 : 0;
 }
+// BSB22: the Pedersen key of the committed wires for this synthetic setup, and the commitment-extended verification equation
+void orc_synth_commitment_basis(void* p, const uint32_t* committed, size_t n, const Fr* sigma, G1A* basis, G1A* basis_sigma) {
+    auto* h = (SynthHandle*)p;
+    synth_commitment_basis(h->key, committed, n, *sigma, basis, basis_sigma);
+}
+int orc_synth_verify_pairing_commit(void* p, const uint8_t* proof256, const G1A* commitment, const G1A* pok, const G2A* g2_sigma) {
+    auto* h = (SynthHandle*)p;
+    ProofPts pr;
+    memcpy(&pr.ar, proof256, 64); memcpy(&pr.bs, proof256 + 64, 128); memcpy(&pr.krs, proof256 + 192, 64);
+    SynthVK vk = synth_vk(h->key);
+    return groth16_verify_pairing_commit(vk, h->inst.w.data(), pr, *commitment, *pok, *g2_sigma) ? 1 : 0;
+}
 // out: 6 Fp2 coefficients (12 Fp, Montgomery) of the reduced Tate pairing t(P, Q)
 void orc_pairing(const G1A* P, const G2A* Q, Fp* out12) {
     Fp12 f = pairing(*P, *Q);

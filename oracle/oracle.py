@@ -391,6 +391,18 @@ class Synth:
             out.append((row_ptr, inv[off:off + co.shape[0]].copy(), wid)); off += co.shape[0]
         return np.ascontiguousarray(table), out
 
+    def commitment_basis(self, committed_idx, sigma):
+        """(Basis, BasisExpSigma) of a BSB22 commitment over the wires `committed_idx` for this setup (gamma-divided K values)"""
+        ci = np.ascontiguousarray(committed_idx, dtype=np.uint32); sigma = _u64(sigma)
+        basis = np.empty((ci.size, 8), dtype=np.uint64); bs = np.empty((ci.size, 8), dtype=np.uint64)
+        lib().orc_synth_commitment_basis(self.h, _p(ci), ctypes.c_size_t(ci.size), _p(sigma), _p(basis), _p(bs))
+        return basis, bs
+
+    def verify_pairing_commit(self, proof256, commitment, pok, g2_sigma):
+        """groth16.Verify's equation with one commitment: D joins the public-input sum, and the knowledge proof must hold"""
+        proof256 = np.ascontiguousarray(proof256, dtype=np.uint8)
+        return bool(lib().orc_synth_verify_pairing_commit(self.h, _p(proof256), _p(_u64(commitment)), _p(_u64(pok)), _p(_u64(g2_sigma))))
+
     def verify_pairing(self, proof256):
         """groth16.Verify's equation with a real pairing; uses only the vk, the public wires and the proof"""
         proof256 = np.ascontiguousarray(proof256, dtype=np.uint8)

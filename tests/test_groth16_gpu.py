@@ -228,3 +228,47 @@ def test_blinding_must_be_canonical(zk):
         assert S.check(below, ok, zk.prove_tail(pk, S.w, S.a, S.b, S.c, below, ok))
     finally:
         pk.close()
+
+
+def test_commitment_extended_groth16_verifies(zk):
+    """Groth16 with one BSB22 commitment, the protocol algebra end to end on the device: the privately committed wires leave pk.G1.K
+    (zkpor_pk_set_consts committed_idx) and enter the Pedersen basis gamma-divided; zkpor_commit gives D and its knowledge proof,
+    zkpor_prove_tail sums K over the remaining wires; the verifier's equation with D added to the public-input sum accepts — and
+    rejects a proof whose Krs still contains the committed wires, a proof checked without D, a wrong D and a wrong knowledge proof."""
+    S = O.Synth(8, 400, n_public=2, seed=61)
+    rng = np.random.default_rng(3)
+    committed = np.sort(rng.choice(np.arange(S.n_public, S.n_wires), size=37, replace=False)).astype(np.uint32)
+    sigma = O.fr_random(9, 1)[0]
+    basis, basis_sigma = S.commitment_basis(committed, sigma)
+    g2s = O.g2_mul_gen(sigma)
+    z = np.zeros(S.n_wires, dtype=np.uint8)
+    keep = np.ones(S.n_wires, dtype=bool); keep[:S.n_public] = False; keep[committed] = False
+    r = O.fr_random(5, 1)[0]; s = O.fr_random(6, 1)[0]
+
+    def prove(with_exclusion):
+        pk = zkpor.ProvingKey(zk)
+        try:
+            pk.set_g1(zkpor.G1_A, S.A); pk.set_g1(zkpor.G1_B, S.B1); pk.set_g2(zkpor.G2_B, S.B2)
+            pk.set_g1(zkpor.G1_K, S.K[keep] if with_exclusion else S.K[S.n_public:]); pk.set_g1(zkpor.G1_Z, S.Z)
+            pk.set_g1(zkpor.G1_COMMIT_BASIS, basis); pk.set_g1(zkpor.G1_COMMIT_BASIS_SIGMA, basis_sigma)
+            pk.set_consts(S.abd1[0], S.abd1[1], S.abd1[2], S.bd2[0], S.bd2[1], S.log2d, z, z, S.n_wires, S.n_public,
+                          committed if with_exclusion else None)
+            d, pok = zk.commit(pk, S.w[committed])
+            return zk.prove_tail(pk, S.w, S.a, S.b, S.c, r, s), d, pok
+        finally:
+            pk.close()
+
+    proof, d, pok = prove(True)
+    assert np.array_equal(d, O.g1_msm(basis, S.w[committed]))
+    assert S.verify_pairing_commit(proof, d, pok, g2s)
+    assert not S.verify_pairing(proof)                                   # without D the committed wires' share is missing
+    full, d2, pok2 = prove(False)
+    assert np.array_equal(d2, d) and S.verify_pairing(full)              # the plain key still proves the plain statement ...
+    assert not S.verify_pairing_commit(full, d, pok, g2s)                # ... and counts the committed wires twice under the extended one
+    other = O.g1_msm(basis, O.fr_random(11, committed.size))
+    assert not S.verify_pairing_commit(proof, other, pok, g2s)
+    assert not S.verify_pairing_commit(proof, d, d, g2s)
+    # Krs of the two proofs differ by exactly the committed wires' delta-divided share
+    share = O.g1_msm(S.K[committed], S.w[committed])
+    krs_excl = proof.view(np.uint64)[24:32]; krs_full = full.view(np.uint64)[24:32]
+    assert np.array_equal(O.g1_add(krs_excl[None, :], share[None, :])[0], krs_full)

@@ -391,3 +391,24 @@ def test_product_field_and_curve_headers_match_oracle():
     assert np.array_equal(out2, O.g2_msm(p2, ones[:30], -1))
     jac2 = np.empty(24, np.uint64); L.hm_g2_sum_tree(p(p2), ctypes.c_size_t(30), p(jac2))
     assert np.array_equal(O.g2_jac_to_affine(jac2)[0], O.g2_msm(p2, ones[:30], -1))
+
+
+def test_commitment_extended_verification_equation():
+    """the BSB22-extended Groth16 equation of the oracle's verifier, on the oracle's own proof: moving the committed wires' share out
+    of Krs (delta-divided) into D (gamma-divided basis) keeps the equation; anything else breaks it"""
+    S = O.Synth(5, 60, n_public=2, seed=17)
+    committed = np.array([3, 7, 8, 20], dtype=np.uint32)
+    sigma = O.fr_random(4, 1)[0]
+    basis, basis_sigma = S.commitment_basis(committed, sigma)
+    d = O.g1_msm(basis, S.w[committed]); pok = O.g1_msm(basis_sigma, S.w[committed])
+    r = O.fr_random(1, 1)[0]; s = O.fr_random(2, 1)[0]
+    proof = S.prove_tail(r, s)
+    assert S.verify_pairing(proof)
+    share = O.g1_msm(S.K[committed], S.w[committed])
+    neg = share.copy(); neg[4:8] = O.fp_sub(O.fp_from_ints([0]), share[4:8].reshape(1, 4))[0]       # -P = (x, -y)
+    excl = proof.copy()
+    excl.view(np.uint64)[24:32] = O.g1_add(proof.view(np.uint64)[24:32][None, :], neg[None, :])[0]
+    g2s = O.g2_mul_gen(sigma)
+    assert S.verify_pairing_commit(excl, d, pok, g2s)
+    assert not S.verify_pairing_commit(proof, d, pok, g2s) and not S.verify_pairing(excl)
+    assert not S.verify_pairing_commit(excl, d, d, g2s)
