@@ -272,3 +272,43 @@ def test_commitment_extended_groth16_verifies(zk):
     share = O.g1_msm(S.K[committed], S.w[committed])
     krs_excl = proof.view(np.uint64)[24:32]; krs_full = full.view(np.uint64)[24:32]
     assert np.array_equal(O.g1_add(krs_excl[None, :], share[None, :])[0], krs_full)
+
+
+def test_host_pointer_staging_survives_regrowth_and_copy_thread_changes():
+    """one context, keys of different sizes one after the other (the staging area regrows, then is reused for a smaller key), the
+    bounce-buffer copier rebuilt with 1 and 7 threads in between, a commitment placed behind the prove tail's vectors — every proof
+    equals the resident form's; an invalid thread count is refused"""
+    import ctypes
+    ctx = zkpor.Context(0)
+    try:
+        with pytest.raises(zkpor.ZkporError):
+            ctx.set_param("copy_threads", 0)
+        for log2, threads in ((12, 1), (16, 7), (13, 4)):
+            ctx.set_param("copy_threads", threads)
+            n = 1 << log2
+            nc = 300
+            seed = 0xC0 + log2
+            pk = zkpor.ProvingKey(ctx)
+            bufs = [ctx.alloc(32 * n) for _ in range(4)]
+            try:
+                pk.synth(log2, n, 3, nc, seed)
+                w = O.fr_random(log2, n); a = O.fr_random(log2 + 100, n - 7); b = O.fr_random(log2 + 200, n - 7); c = O.fr_mul(a, b)
+                v = O.fr_random(log2 + 300, nc)
+                r = O.fr_random(1, 1)[0]; s = O.fr_random(2, 1)[0]
+                d1, k1 = ctx.commit(pk, v)
+                got = ctx.prove_tail(pk, w, a, b, c, r, s)
+                d2, k2 = ctx.commit(pk, v)
+                assert np.array_equal(d1, d2) and np.array_equal(k1, k2)
+                pad = lambda x: np.concatenate([x, np.zeros((n - x.shape[0], 4), np.uint64)])
+                for buf, x in zip(bufs, (w, pad(a), pad(b), pad(c))):
+                    buf.upload(x)
+                assert np.array_equal(got, ctx.prove_tail_dev(pk, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, r, s))
+                import trapdoor as T
+                ec, ek = T.expected_commitment(seed, v)
+                assert np.array_equal(d1, ec) and np.array_equal(k1, ek)
+            finally:
+                for b_ in bufs:
+                    b_.free()
+                pk.close()
+    finally:
+        ctx.close()
