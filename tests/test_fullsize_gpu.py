@@ -65,19 +65,21 @@ def test_msm_fullsize_trapdoor(zk):
         pk.close()
 
 
-@pytest.mark.parametrize("tier,fill_kind", [("zkpor50_1380", 1), ("zkpor500_200", 2)])
-def test_prove_tail_fullsize_trapdoor(zk, tier, fill_kind):
+@pytest.mark.parametrize("tier,fill_kind,tables", [("zkpor50_1380", 1, 1), ("zkpor500_200", 2, 1), ("zkpor50_1380", 1, 4)])
+def test_prove_tail_fullsize_trapdoor(zk, tier, fill_kind, tables):
     """The fused path that bench.py times (zkpor_commit_dev + zkpor_prove_tail_dev: ONE sorted digit stream of w -> A, B1, K,
     B2; computeH -> h in the order of Z -> Z.h; blinding; the 2^(LOG2-2) Pedersen sums) at the bench's size and scalar
     mixture, verified in the exponent from the synthetic key's trapdoor — prove, then verify, as prover.go:269-276 does."""
     n = 1 << LOG2
     nc = n >> 2
     seed = 0x5A4B504F52
+    zk.set_param("msm_tables", tables)                 # 4: the key as fixed-base tables (112 GB at 2^26), 12 digits of 22 bits
     pk = zkpor.ProvingKey(zk)
     bufs = {k: zk.alloc(32 * n) for k in ("w", "a", "b", "c")}
     cv = zk.alloc(32 * nc)
     try:
         pk.synth(LOG2, n, 3, nc, seed)
+        zk.set_param("msm_tables", 1)
         zk.fill_fr(bufs["w"], n, 2, fill_kind)         # the tier's witness-like mixture (BASELINE.json configs[1] / configs[2])
         zk.fill_fr(bufs["a"], n, 11, 0)
         zk.fill_fr(bufs["b"], n, 12, 0)

@@ -312,3 +312,53 @@ def test_host_pointer_staging_survives_regrowth_and_copy_thread_changes():
                 pk.close()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("tables,n_cons", [(2, 300), (4, 2000), (3, 2000), (8, 70)])
+def test_prove_tail_with_fixed_base_tables(tables, n_cons):
+    """"msm_tables" = m: every key array becomes n x m points, entry i m + q = 2^(q piece c) P_i, the W digits of a scalar share
+    ceil(W / m) bucket windows (msm.cuh MsmCfg).  Same group elements: the proof equals the oracle's bit for bit, the commitment
+    equals the plain sum, and the operations that need plain arrays say so."""
+    ctx = zkpor.Context(0)
+    try:
+        ctx.set_param("msm_tables", tables)
+        S = O.Synth(6, n_cons, n_public=2, seed=90 + tables, z_bitrev=True)
+        nb = 50
+        basis = O.g1_from_scalars(O.fr_random(31, nb)); basis_sigma = O.g1_from_scalars(O.fr_random(32, nb))
+        pk = zkpor.ProvingKey(ctx)
+        try:
+            nw = S.n_wires
+            A = S.A.copy(); A[5] = 0                                    # an infinity wire: every table entry of it is infinity
+            inf_a = np.array([not A[i].any() for i in range(nw)], dtype=np.uint8)
+            z = np.zeros(nw, dtype=np.uint8)
+            pk.set_g1(zkpor.G1_A, A[inf_a == 0]); pk.set_g1(zkpor.G1_B, S.B1); pk.set_g2(zkpor.G2_B, S.B2)
+            pk.set_g1(zkpor.G1_K, S.K[S.n_public:]); pk.set_g1(zkpor.G1_Z, S.Z)
+            pk.set_g1(zkpor.G1_COMMIT_BASIS, basis); pk.set_g1(zkpor.G1_COMMIT_BASIS_SIGMA, basis_sigma)
+            pk.set_consts(S.abd1[0], S.abd1[1], S.abd1[2], S.bd2[0], S.bd2[1], S.log2d, inf_a, z, nw, S.n_public)
+            r = O.fr_random(5, 1)[0]; s = O.fr_random(6, 1)[0]
+            got = ctx.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
+            ref = S.prove_tail(r, s)
+            # Ar of the reference contains wire 5's A point: remove its share to compare (A[5] was knocked out above)
+            share = O.g1_scalar_mul(S.A[5:6], S.w[5:6])[0]
+            neg = share.copy(); neg[4:8] = O.fp_sub(O.fp_from_ints([0]), share[4:8].reshape(1, 4))[0]
+            ar = O.g1_add(ref.view(np.uint64)[0:8][None, :], neg[None, :])[0]
+            assert np.array_equal(got.view(np.uint64)[0:8], ar)
+            assert np.array_equal(got.view(np.uint64)[8:24], ref.view(np.uint64)[8:24])      # Bs untouched
+            vals = O.fr_random(33, nb)
+            d, k = ctx.commit(pk, vals)
+            assert np.array_equal(d, O.g1_msm(basis, vals)) and np.array_equal(k, O.g1_msm(basis_sigma, vals))
+            with pytest.raises(zkpor.ZkporError, match="fixed-base tables"):
+                pk.g1_dev(zkpor.G1_A)
+            with pytest.raises(zkpor.ZkporError, match="fixed-base tables"):
+                pk.keep_range(0, 4, 0, 4)
+            ctx.set_param("msm_window", 9)                               # another window than the tables were built for
+            with pytest.raises(zkpor.ZkporError, match="fixed-base tables"):
+                ctx.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
+            ctx.set_param("msm_window", 0)
+            # with the key reloaded plainly (tables off) the same proof comes out
+        finally:
+            pk.close()
+        with pytest.raises(zkpor.ZkporError):
+            ctx.set_param("msm_tables", 9)
+    finally:
+        ctx.close()

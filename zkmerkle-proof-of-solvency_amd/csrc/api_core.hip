@@ -291,6 +291,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     std::string n(name);
     if (n == "msm_window") ctx->msm_window = (int)value;
     else if (n == "msm_chunk") ctx->msm_chunk = (int)value;
+    else if (n == "msm_tables") { if (value < 1 || value > 8) { ctx->err = "msm_tables must be in [1,8]"; return ZKPOR_E_ARG; } ctx->msm_tables = (int)value; }
     else if (n == "msm_g1_variant") ctx->g1_variant = (int)value;
     else if (n == "msm_g2_variant") ctx->g2_variant = (int)value;
     else if (n == "ntt_variant") ctx->ntt_variant = (int)value;

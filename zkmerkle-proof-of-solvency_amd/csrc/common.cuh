@@ -29,6 +29,7 @@ struct zkpor_ctx {
     size_t ws_cap = 0, ws_off = 0;
     // tuning
     int msm_window = 0;  // 0 = auto
+    int msm_tables = 1;  // fixed-base tables per key point, applied to keys loaded AFTER the parameter is set (msm.cuh MsmCfg)
     int msm_chunk = 32;
     int g1_variant = 1;  // level-1 G1 accumulation arithmetic: 0 = 8 x 32-bit limbs, 1 = 9 x 29-bit limbs (fe29.cuh)
     int g2_variant = 1;  // same for the G2 lane-pair kernel

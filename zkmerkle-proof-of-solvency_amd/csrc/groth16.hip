@@ -31,6 +31,9 @@ struct zkpor_pk {
     G2Affine beta2, delta2;
     bool ready = false;
     bool shard = false;  // holds only a contiguous range of every array (zkpor_pk_keep_range): sums only, no whole proof
+    int tab_shift_w = 0, tab_shift_z = 0, tab_shift_c = 0;  // bits between consecutive tables of the w-, h- and commitment-indexed arrays
+    int tab_m = 1;       // fixed-base tables per point (context parameter "msm_tables" at load time): every array then holds
+                         // n * tab_m points, entry i * tab_m + q = 2^(q * piece * c) P_i (msm.cuh MsmCfg)
 };
 
 zkpor_ctx* zk_pk_ctx(zkpor_pk* pk) { return pk->ctx; }  // for keyfile.hip
@@ -159,6 +162,68 @@ int32_t synth_array(zkpor_ctx* ctx, const Affine<F>& gen, u64 seed, int arr, siz
         ZK_KERNEL_CHECK(ctx);
     }
     *out = d;
+    return ZKPOR_OK;
+}
+
+// ---- fixed-base tables (msm.cuh MsmCfg): out[i * m + q] = 2^(q * shift_bits) src[i], affine -----------------------------------
+template <class F>
+__global__ __launch_bounds__(64) void k_build_tables(const Affine<F>* __restrict__ src, size_t n, int m, int shift_bits, Affine<F>* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = src[i];
+    out[i * (size_t)m] = p;
+    XYZZ<F> acc = xyzz_from_affine<F>(p);
+    for (int q = 1; q < m; ++q) {
+        for (int b = 0; b < shift_bits; ++b) acc = xyzz_dbl<F>(acc);
+        Affine<F> a;
+        if (acc.is_inf()) { a.x = F::zero(); a.y = F::zero(); }
+        else {  // one inversion: ZZ^3 = ZZZ^2  =>  1/ZZ = (ZZ / ZZZ)^2
+            F iz = F::inv(acc.zzz);
+            F t = F::mul(acc.zz, iz);
+            a.x = F::mul(acc.x, F::sqr(t));
+            a.y = F::mul(acc.y, iz);
+        }
+        out[i * (size_t)m + q] = a;
+    }
+}
+// replace a wire-indexed array by its table form (m > 1); the plain array is freed
+template <class F>
+int32_t make_tables(zkpor_ctx* ctx, Affine<F>** arr, size_t n, int m, int shift_bits) {
+    if (m <= 1 || !*arr || n == 0) return ZKPOR_OK;
+    Affine<F>* out = nullptr;
+    if (hipMalloc((void**)&out, n * (size_t)m * sizeof(Affine<F>) + 16) != hipSuccess) { (void)hipGetLastError(); ctx->err = "pk: out of device memory for the fixed-base tables"; return ZKPOR_E_OOM; }
+    hipLaunchKernelGGL(k_build_tables<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const Affine<F>*)*arr, n, m, shift_bits, out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(out); ctx->err = std::string("pk: table construction: ") + hipGetErrorString(e); return ZKPOR_E_HIP; }
+    (void)hipFree(*arr);
+    *arr = out;
+    return ZKPOR_OK;
+}
+
+// after the wire-indexed arrays are final: turn them into tables if the context asks for it.  The spacing of an array's tables is
+// the spacing its multi-exponentiation will use (piece * c of msm_cfg for the array's length); prove_sums / commit check it.
+int32_t pk_apply_tables(zkpor_pk* pk) {
+    zkpor_ctx* ctx = pk->ctx;
+    pk->tab_m = 1;
+    const int m = ctx->msm_tables;
+    if (m <= 1) return ZKPOR_OK;
+    MsmCfg cw = msm_cfg(ctx, pk->n_wires, m), cz = msm_cfg(ctx, pk->nZ ? pk->nZ : 1, m), cc = msm_cfg(ctx, pk->nC ? pk->nC : 1, m);
+    pk->tab_shift_w = cw.piece * cw.c; pk->tab_shift_z = cz.piece * cz.c; pk->tab_shift_c = cc.piece * cc.c;
+    pk->ready = false;  // a failure half-way leaves arrays of different shapes
+    ZK_TRY(make_tables<Fp>(ctx, &pk->A, pk->n_wires, m, pk->tab_shift_w));
+    ZK_TRY(make_tables<Fp>(ctx, &pk->B1, pk->n_wires, m, pk->tab_shift_w));
+    ZK_TRY(make_tables<Fp>(ctx, &pk->K, pk->n_wires, m, pk->tab_shift_w));
+    ZK_TRY(make_tables<Fp2>(ctx, &pk->B2, pk->n_wires, m, pk->tab_shift_w));
+    ZK_TRY(make_tables<Fp>(ctx, &pk->Z, pk->nZ, m, pk->tab_shift_z));
+    ZK_TRY(make_tables<Fp>(ctx, &pk->CB, pk->nC, m, pk->tab_shift_c));
+    ZK_TRY(make_tables<Fp>(ctx, &pk->CBS, pk->nC, m, pk->tab_shift_c));
+    pk->tab_m = m;
+    pk->ready = true;
+    return ZKPOR_OK;
+}
+int32_t check_tables(zkpor_ctx* ctx, zkpor_pk* pk, const MsmCfg& cfg, int shift) {
+    if (pk->tab_m > 1 && cfg.piece * cfg.c != shift) { ctx->err = "msm: the window in force differs from the one the key's fixed-base tables were built for (msm_window changed after the key was loaded)"; return ZKPOR_E_STATE; }
     return ZKPOR_OK;
 }
 
@@ -305,6 +370,8 @@ int32_t zk_pk_finalize(zkpor_pk* pk, const void* alpha, const void* beta, const 
     if (pk->g2_raw) { (void)hipFree(pk->g2_raw); pk->g2_raw = nullptr; pk->g2_raw_n = 0; }
     pk->ready = true;
     pk->shard = shard;
+    pk->tab_m = 1;
+    if (!shard) ZK_TRY(pk_apply_tables(pk));
     return ZKPOR_OK;
 }
 
@@ -353,13 +420,14 @@ int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_p
     pk->delta2 = xyzz_to_affine<Fp2>(xyzz_mul_u64<Fp2>(xyzz_from_affine<Fp2>(g2), synth_k(seed, 102, 0)));
     pk->ready = true;
     pk->shard = false;
-    return ZKPOR_OK;
+    return pk_apply_tables(pk);
 }
 
 int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !dev_ptr || !n) return ZKPOR_E_ARG;
     if (!pk->ready) return ZKPOR_E_STATE;
+    if (pk->tab_m > 1) { pk->ctx->err = "pk: the arrays are interleaved fixed-base tables (msm_tables > 1), not plain point arrays"; return ZKPOR_E_STATE; }
     switch (which) {
         case ZKPOR_G1_A: *dev_ptr = pk->A; *n = pk->n_wires; break;
         case ZKPOR_G1_B: *dev_ptr = pk->B1; *n = pk->n_wires; break;
@@ -375,6 +443,7 @@ int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !dev_ptr || !n || which != ZKPOR_G2_B) return ZKPOR_E_ARG;
     if (!pk->ready) return ZKPOR_E_STATE;
+    if (pk->tab_m > 1) { pk->ctx->err = "pk: the arrays are interleaved fixed-base tables (msm_tables > 1), not plain point arrays"; return ZKPOR_E_STATE; }
     *dev_ptr = pk->B2; *n = pk->n_wires;
     return ZKPOR_OK;
 }
@@ -407,8 +476,10 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     hipStream_t main_s = ctx->stream, aux_s = ctx->aux_stream;
     hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx), e_up = ev_get(ctx);
     struct EvGuard { zkpor_ctx* c; hipEvent_t e[5]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up}, main_s};
-    MsmCfg cfgw = msm_cfg(ctx, pk->n_wires);
-    MsmCfg cfgh = msm_cfg(ctx, nZ ? nZ : 1);
+    MsmCfg cfgw = msm_cfg(ctx, pk->n_wires, pk->tab_m);
+    MsmCfg cfgh = msm_cfg(ctx, nZ ? nZ : 1, pk->tab_m);
+    ZK_TRY(check_tables(ctx, pk, cfgw, pk->tab_shift_w));
+    if (nZ) ZK_TRY(check_tables(ctx, pk, cfgh, pk->tab_shift_z));
     size_t sortw = 0, sorth = 0;
     size_t need_dw = digits_ws_bytes(ctx, pk->n_wires, cfgw, &sortw);
     size_t need_dh = digits_ws_bytes(ctx, nZ ? nZ : 1, cfgh, &sorth);
@@ -593,6 +664,7 @@ int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t
     if (!pk) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
     if (!pk->ready) { ctx->err = "pk: key not loaded"; return ZKPOR_E_STATE; }
+    if (pk->tab_m > 1) { ctx->err = "pk: a key with fixed-base tables cannot be cut into a shard (load it with msm_tables = 1)"; return ZKPOR_E_STATE; }
     if (wire_lo >= wire_hi || wire_hi > pk->n_wires || z_lo > z_hi || z_hi > pk->nZ) { ctx->err = "pk: shard range outside the key"; return ZKPOR_E_ARG; }
     auto cut = [&](auto** arr, size_t lo, size_t hi) -> int32_t {
         using P = std::remove_pointer_t<std::remove_pointer_t<decltype(arr)>>;
@@ -718,7 +790,8 @@ int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, siz
     if (n != pk->nC) { ctx->err = "commit: value count differs from the commitment basis"; return ZKPOR_E_ARG; }
     G1XYZZ c1 = G1XYZZ::inf(), c2 = G1XYZZ::inf();
     if (n) {
-        MsmCfg cfg = msm_cfg(ctx, n);
+        MsmCfg cfg = msm_cfg(ctx, n, pk->tab_m);
+        ZK_TRY(check_tables(ctx, pk, cfg, pk->tab_shift_c));
         size_t st = 0;
         size_t need = digits_ws_bytes(ctx, n, cfg, &st) + accumulate_ws_bytes<Fp>(cfg, n * (size_t)cfg.W);
         DigitStream ds;

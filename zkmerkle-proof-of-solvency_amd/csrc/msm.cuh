@@ -27,9 +27,11 @@ static constexpr u32 NOKEY = 0xffffffffu;
 
 struct MsmCfg {
     int c;     // window bits
-    int W;     // windows = ceil(255 / c)
+    int W;     // signed digits per scalar = ceil(255 / c)
+    int m;     // fixed-base tables per point (1 = none): table q holds 2^(q * piece * c) P, so digit t of a scalar is an entry of
+    int piece; //   bucket window t % piece against point i * m + t / piece; piece = ceil(W / m) bucket windows remain
     u32 bpw;   // buckets per window = 2^(c-1)
-    u32 NB;    // total buckets
+    u32 NB;    // total buckets = bpw * piece
     int L;     // entries per accumulation thread
     int key_bits;
     u32 g1, n1, g2, n2;  // reduce group sizes: g1*n1 = bpw, g2*n2 = n1
@@ -40,20 +42,25 @@ inline int log2_ceil(size_t n) {
     while (((size_t)1 << k) < n) ++k;
     return k;
 }
-inline MsmCfg msm_cfg(zkpor_ctx* ctx, size_t n) {
+// Fixed-base tables (the key arrays never change): with m tables per point the W digits of a scalar share ceil(W / m) bucket
+// windows, so the window can grow — 22 bits and 12 digits instead of 20 bits and 13 at 2^26 — at the SAME number of buckets (the
+// bucket reduction does not grow), for m times the key memory: HBM capacity bought back as 8 % fewer bucket additions.
+inline MsmCfg msm_cfg(zkpor_ctx* ctx, size_t n, int tables = 1) {
     MsmCfg m;
     int c = ctx->msm_window;
     if (c <= 0) {
-        c = log2_ceil(n) - 6;
+        c = log2_ceil(n) - (tables > 1 ? 4 : 6);
         if (c < 4) c = 4;
-        if (c > 20) c = 20;
+        if (c > (tables > 1 ? 22 : 20)) c = tables > 1 ? 22 : 20;
     }
     if (c < 2) c = 2;
     if (c > 22) c = 22;
     m.c = c;
     m.W = (255 + c - 1) / c;
+    m.m = tables < 1 ? 1 : tables;
+    m.piece = (m.W + m.m - 1) / m.m;
     m.bpw = 1u << (c - 1);
-    m.NB = m.bpw * (u32)m.W;
+    m.NB = m.bpw * (u32)m.piece;
     m.L = ctx->msm_chunk < 4 ? 4 : ctx->msm_chunk;
     m.key_bits = log2_ceil(m.NB);
     if (m.key_bits < 1) m.key_bits = 1;
@@ -119,7 +126,7 @@ inline size_t digits_ws_bytes(zkpor_ctx* ctx, size_t n, const MsmCfg& cfg, size_
 inline int32_t msm_digits(zkpor_ctx* ctx, const Fr* d_scalars, size_t n, const MsmCfg& cfg, size_t sort_temp,
                           DigitStream* out) {
     size_t cap = n * (size_t)cfg.W;
-    if (cap >= 0xfffffff0ull || n >= (1ull << 31)) { ctx->err = "msm: too many digit entries for 32-bit indexing"; return ZKPOR_E_ARG; }
+    if (cap >= 0xfffffff0ull || n * (size_t)cfg.m >= (1ull << 31)) { ctx->err = "msm: too many digit entries for 32-bit indexing"; return ZKPOR_E_ARG; }
     u32* k0 = ws_alloc<u32>(ctx, cap); u32* k1 = ws_alloc<u32>(ctx, cap);
     u32* v0 = ws_alloc<u32>(ctx, cap); u32* v1 = ws_alloc<u32>(ctx, cap);
     u32* counter = ws_alloc<u32>(ctx, 64);
@@ -228,7 +235,7 @@ inline int32_t msm_accumulate_launch(zkpor_ctx* ctx, const DigitStream& ds, cons
         }
         fin_S = Sin; fin_Y = Yin;
     }
-    const size_t Wn = (size_t)cfg.W;
+    const size_t Wn = (size_t)cfg.piece;
     const size_t fin_bytes = Wn * (raw ? img : sizeof(XYZZ<F>));
     out->Kmul = Kmul;
     ZK_HIP(ctx, hipMemcpyAsync(pinned_S, fin_S, fin_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -268,7 +275,7 @@ inline void msm_accumulate_finish(const MsmPending& p, XYZZ<F>* result) {
         const XYZZ<F>* hS = (const XYZZ<F>*)p.hS;
         const XYZZ<F>* hY = (const XYZZ<F>*)p.hY;
         const size_t rw = raw_words<F>();
-        for (int w = p.cfg.W - 1; w >= 0; --w) {
+        for (int w = p.cfg.piece - 1; w >= 0; --w) {
             for (int k = 0; k < p.cfg.c; ++k) acc = xyzz_dbl<F>(acc);
             XYZZ<F> win = p.raw29 ? raw29_to_xyzz_host((const u32*)p.hY + (size_t)w * rw, (const F*)nullptr) : hY[w];
             XYZZ<F> sw = p.raw29 ? raw29_to_xyzz_host((const u32*)p.hS + (size_t)w * rw, (const F*)nullptr) : hS[w];

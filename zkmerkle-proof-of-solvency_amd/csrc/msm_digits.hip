@@ -14,7 +14,7 @@ ZK_D u32 take_digit(Fr& s, int c) {
 
 // One thread per scalar.  Two passes over the digits (count, then write) so nothing spills; entries of one
 // 256-thread block are appended with ONE global atomic.
-__global__ __launch_bounds__(256) void k_decompose(const Fr* __restrict__ scalars, u32 n, int c, int W, u32 bpw,
+__global__ __launch_bounds__(256) void k_decompose(const Fr* __restrict__ scalars, u32 n, int c, int W, int tables, int piece, u32 bpw,
                                                    u32* __restrict__ out_keys, u32* __restrict__ out_vals,
                                                    u32* __restrict__ counter) {
     __shared__ u32 wave_tot[4];
@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void k_decompose(const Fr* __restrict__ scalar
             carry = d > half ? 1u : 0u;
             d = carry ? (1u << c) - d : d;
             if (d) {
-                out_keys[pos] = (u32)w * bpw + (d - 1u);
-                out_vals[pos] = (i << 1) | carry;  // carry == 1 <=> the digit is negative
+                // digit w of the scalar = bucket window w % piece against table w / piece of point i (msm.cuh MsmCfg)
+                const u32 q = (u32)w / (u32)piece;
+                out_keys[pos] = ((u32)w - q * (u32)piece) * bpw + (d - 1u);
+                out_vals[pos] = ((i * (u32)tables + q) << 1) | carry;  // carry == 1 <=> the digit is negative
                 ++pos;
             }
         }
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void k_decompose(const Fr* __restrict__ scalar
 
 int32_t launch_decompose(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, u32* keys, u32* vals, u32* counter) {
     u32 blocks = (n + 255u) / 256u;
-    hipLaunchKernelGGL(k_decompose, dim3(blocks), dim3(256), 0, ctx->stream, d_scalars, n, cfg.c, cfg.W, cfg.bpw, keys, vals, counter);
+    hipLaunchKernelGGL(k_decompose, dim3(blocks), dim3(256), 0, ctx->stream, d_scalars, n, cfg.c, cfg.W, cfg.m, cfg.piece, cfg.bpw, keys, vals, counter);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
