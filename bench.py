@@ -663,7 +663,7 @@ def main():
         achieved = units_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         bproof = algorithmic_bytes_per_proof(log2, n_wires, n_commit)
         tb, tsrc = pmc_traffic_bytes_per_launch()
-        profiled_cfg = log2 == 26 and args.scalars == "witness" and args.config == "zkpor50_1380" and not args.window and not args.chunk
+        profiled_cfg = log2 == 26 and args.scalars == "witness" and args.config == "zkpor50_1380" and not args.window and not args.chunk and args.tables == 4
         traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and profiled_cfg) else None
         vb_ms, vsrc = pmc_valu_issue_bound_ms()
         valu = ({"issue_bound_ms_per_launch": vb_ms, "frac": vb_ms / (avg_launch_s * 1e3),

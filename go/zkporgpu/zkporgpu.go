@@ -38,6 +38,15 @@ func NewContext(device int) (*Context, error) {
 	return &Context{h}, nil
 }
 
+// SetParam sets a tuning knob of the context (zkpor_set_param).  A production prover on a 288 GB part sets "msm_tables" to 4 BEFORE
+// loading the key: the key is then held as four fixed-base tables per point (112 GB at 2^26) and every proof needs 6 % fewer
+// bucket additions.
+func (c *Context) SetParam(name string, value int64) error {
+	cname := C.CString(name)
+	defer C.free(unsafe.Pointer(cname))
+	return c.err(C.zkpor_set_param(c.h, cname, C.int64_t(value)))
+}
+
 func (c *Context) Close() {
 	if c.h != nil {
 		C.zkpor_destroy(c.h)

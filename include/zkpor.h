@@ -69,6 +69,11 @@ void zkpor_destroy(zkpor_ctx* ctx);
 const char* zkpor_last_error(zkpor_ctx* ctx);
 int32_t zkpor_sync(zkpor_ctx* ctx);
 /* tuning knobs: "msm_window" (bits, 0 = auto), "msm_chunk" (entries per accumulation thread),
+ * "msm_tables" (1..8, default 1; applies to keys loaded AFTER it is set): m > 1 stores every key array as m interleaved
+ * fixed-base tables, entry i*m + q = 2^(q * piece * c) P_i, so that the digits of a scalar share ceil(W / m) bucket windows: at
+ * 2^26, m = 4 costs 112 GB of HBM instead of 28 and buys 12 digits of 22 bits instead of 13 of 20 at the same number of buckets
+ * (6 % fewer bucket additions; built on the device at load time, ~14 s).  Such a key cannot be cut into shards, and "msm_window" must
+ * not change between the load and the proofs,
  * "copy_threads" (host threads that fill the pinned bounce buffers of the host-pointer entry points, default 4),
  * "poseidon_out_idx", "poseidon_carry_idx" (hash-wrapper convention) */
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);

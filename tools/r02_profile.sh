@@ -1,7 +1,7 @@
 # round-2 profiles of the default bench workload on one MI355X (run through gpurun; outputs under gpurun_out/r02d, summaries are
 # copied into profiles/ by hand).  PMC counters are collected in their own passes, with --kernel-trace only.
 set -u
-OUT=gpurun_out/r02d
+OUT=gpurun_out/r02l
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o timed -- python bench.py --steps 5 --warmup 2 --timed-only > $OUT/bench_timed_only.json 2> $OUT/bench_timed_only.err
