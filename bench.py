@@ -161,7 +161,7 @@ def timed_region(dist, sync, run):
     return dt
 
 
-def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vectors, td, blinding, resident_ms, n_proofs=3, copy_threads=0):
+def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vectors, td, blinding, resident_ms, n_proofs=3, copy_threads=0, copy_chunk_mb=0):
     """The call a cgo caller actually makes (INTEGRATION.md `ProveTail` / `Commit`): the HOST-pointer entry points
     zkpor_commit + zkpor_prove_tail on PAGEABLE host memory (numpy heap arrays standing in for gnark's []fr.Element), 8.6 GB + 0.5 GB
     per proof across PCIe inside the call.  Two shapes: one caller (a proof's latency from host memory: w crosses first, a/b/c cross
@@ -192,9 +192,11 @@ def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vector
     other = zkpor.Context(device, None)
     try:
         ctxs = [ctx, other]
-        if copy_threads:
-            for c_ in ctxs:
+        for c_ in ctxs:
+            if copy_threads:
                 c_.set_param("copy_threads", copy_threads)
+            if copy_chunk_mb:
+                c_.set_param("copy_chunk_mb", copy_chunk_mb)
         for k, wctx in enumerate(ctxs):       # warm-up: staging areas, bounce buffers, copy threads, workspaces
             prove(wctx, 9000 + k)
         t0 = time.perf_counter()
@@ -398,6 +400,7 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the trapdoor verification of the timed proofs")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-pointer (cgo-shaped) boundary leg")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the informational region with two proofs in flight per GPU")
+    ap.add_argument("--copy-chunk-mb", type=int, default=0, help="size of the pinned bounce buffers of the boundary leg (0 = library default, 32)")
     ap.add_argument("--copy-threads", type=int, default=0, help="host threads per context that fill the pinned bounce buffers in the "
                     "boundary leg (0 = library default, 4)")
     ap.add_argument("--tables", type=int, default=4, help="fixed-base tables per key point (msm_tables; 1 = plain arrays): the default "
@@ -470,7 +473,7 @@ def main():
         ctx.set_param("msm_chunk", args.chunk)
     if args.g1_variant >= 0:
         ctx.set_param("msm_g1_variant", args.g1_variant)
-    if args.tables > 1:
+    if args.tables > 1 and not args.split:   # a key with tables cannot be cut into the shards of the single-proof split
         ctx.set_param("msm_tables", args.tables)
     lib = ctx.lib
 
@@ -713,7 +716,7 @@ def main():
             if not args.no_boundary:
                 try:
                     out["boundary"] = boundary_leg(torch, zkpor, ctx, local_rank, pk, D, n_wires, n_commit, (w, a0, b0, c0, cv), td, blinding,
-                                                   resident_ms=dt / args.steps * 1e3, copy_threads=args.copy_threads)
+                                                   resident_ms=dt / args.steps * 1e3, copy_threads=args.copy_threads, copy_chunk_mb=args.copy_chunk_mb)
                 except Exception as e:
                     out["boundary"] = {"value": None, "note": f"failed: {e}"}
             if not args.no_cpu_baseline:

@@ -32,7 +32,7 @@ int32_t stage_reserve(zkpor_ctx* ctx, size_t bytes) {
 // Pinned bounce buffers + the host threads that fill them.  One per context, created on the first pageable upload.
 struct Bounce {
     static constexpr int SLOTS = 4;
-    static constexpr size_t CHUNK = (size_t)32 << 20;
+    size_t CHUNK = (size_t)32 << 20;   // context parameter "copy_chunk_mb"
     char* buf[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     bool used[SLOTS] = {false, false, false, false};
@@ -124,16 +124,17 @@ int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes
         b = new (std::nothrow) Bounce();
         if (!b) { ctx->err = "host_upload: out of host memory"; return ZKPOR_E_OOM; }
         ctx->bounce = b;
+        b->CHUNK = (size_t)ctx->copy_chunk_mb << 20;
         for (int i = 0; i < Bounce::SLOTS; ++i) {
-            ZK_HIP(ctx, hipHostMalloc((void**)&b->buf[i], Bounce::CHUNK, hipHostMallocDefault));
+            ZK_HIP(ctx, hipHostMalloc((void**)&b->buf[i], b->CHUNK, hipHostMallocDefault));
             ZK_HIP(ctx, hipEventCreateWithFlags(&b->ev[i], hipEventDisableTiming));
         }
         b->start(ctx->copy_threads);
     }
     const char* src = (const char*)h_src;
     char* dst = (char*)d_dst;
-    for (size_t off = 0; off < bytes; off += Bounce::CHUNK) {
-        size_t n = bytes - off < Bounce::CHUNK ? bytes - off : Bounce::CHUNK;
+    for (size_t off = 0; off < bytes; off += b->CHUNK) {
+        size_t n = bytes - off < b->CHUNK ? bytes - off : b->CHUNK;
         int s = b->next;
         b->next = (s + 1) % Bounce::SLOTS;
         if (b->used[s]) ZK_HIP(ctx, hipEventSynchronize(b->ev[s]));  // the DMA that last read this slot is done
@@ -296,6 +297,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     else if (n == "msm_g2_variant") ctx->g2_variant = (int)value;
     else if (n == "ntt_variant") ctx->ntt_variant = (int)value;
     else if (n == "ntt_tile_log") { if (value < 9 || value > 12) { ctx->err = "ntt_tile_log must be in [9,12]"; return ZKPOR_E_ARG; } ctx->ntt_tile_log = (int)value; }
+    else if (n == "copy_chunk_mb") { if (value < 1 || value > 1024) { ctx->err = "copy_chunk_mb must be in [1,1024]"; return ZKPOR_E_ARG; } if (ctx->bounce) bounce_free(ctx); ctx->copy_chunk_mb = (int)value; }
     else if (n == "copy_threads") { if (value < 1 || value > 64) { ctx->err = "copy_threads must be in [1,64]"; return ZKPOR_E_ARG; } if (ctx->bounce) bounce_free(ctx); ctx->copy_threads = (int)value; }
     else if (n == "poseidon_out_idx") ctx->pos_out = (int)value;
     else if (n == "poseidon_carry_idx") ctx->pos_carry = (int)value;

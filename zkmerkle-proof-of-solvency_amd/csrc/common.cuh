@@ -53,6 +53,7 @@ struct zkpor_ctx {
     hipStream_t copy_stream = nullptr;
     void* bounce = nullptr;          // zk::Bounce*
     int copy_threads = 4;
+    int copy_chunk_mb = 32;          // size of one of the four pinned bounce buffers
 };
 
 #define ZK_HIP(ctx, call)                                                                             \
