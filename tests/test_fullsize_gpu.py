@@ -78,8 +78,10 @@ def test_prove_tail_fullsize_trapdoor(zk, tier, fill_kind, tables):
     bufs = {k: zk.alloc(32 * n) for k in ("w", "a", "b", "c")}
     cv = zk.alloc(32 * nc)
     try:
-        pk.synth(LOG2, n, 3, nc, seed)
-        zk.set_param("msm_tables", 1)
+        try:
+            pk.synth(LOG2, n, 3, nc, seed)
+        finally:
+            zk.set_param("msm_tables", 1)              # the session context goes back to plain arrays whatever happens
         zk.fill_fr(bufs["w"], n, 2, fill_kind)         # the tier's witness-like mixture (BASELINE.json configs[1] / configs[2])
         zk.fill_fr(bufs["a"], n, 11, 0)
         zk.fill_fr(bufs["b"], n, 12, 0)
