@@ -87,3 +87,31 @@ def test_container_errors_are_reported(zk, tmp_path):
         assert S.verify_pairing(proof)
     finally:
         pk.close()
+
+
+def test_key_file_loaded_as_fixed_base_tables():
+    """the production shape: "msm_tables" = 4 set before zkpor_pk_load_gnark — the file's compacted, compressed arrays are decompressed,
+    re-laid out wire-indexed AND turned into tables on the device; the proof is the oracle's"""
+    ctx = zkpor.Context(0)
+    try:
+        ctx.set_param("msm_tables", 4)
+        S = O.Synth(6, 700, n_public=2, seed=33)
+        nb = 24
+        bs = O.fr_random(31, nb); sig = O.fr_random(32, 1)[0]
+        basis = O.g1_from_scalars(bs); basis_sigma = O.g1_from_scalars(O.fr_mul(bs, np.repeat(sig[None, :], nb, axis=0)))
+        data, _, _ = GK.pk_bytes_from_synth(S, [(basis, basis_sigma)])
+        pk = zkpor.ProvingKey(ctx)
+        try:
+            pk.load_gnark(data, S.n_public)
+            r = O.fr_random(5, 1)[0]; s = O.fr_random(6, 1)[0]
+            proof = ctx.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
+            assert np.array_equal(proof, S.prove_tail(r, s)) and S.verify_pairing(proof)
+            vals = O.fr_random(33, nb)
+            c, k = ctx.commit(pk, vals)
+            assert np.array_equal(c, O.g1_msm(basis, vals)) and O.pedersen_verify_pairing(c, k, O.g2_mul_gen(sig))
+            with pytest.raises(zkpor.ZkporError, match="fixed-base tables"):
+                pk.g1_dev(zkpor.G1_Z)
+        finally:
+            pk.close()
+    finally:
+        ctx.close()
