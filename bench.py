@@ -491,7 +491,18 @@ def main():
     cfg = CONFIGS[args.config]
     seed = SYNTH_SEED + rank
     pk = zkpor.ProvingKey(ctx)
-    pk.synth(log2, n_wires, 3, n_commit, seed=seed)
+    tables_used = args.tables
+    try:
+        pk.synth(log2, n_wires, 3, n_commit, seed=seed)
+    except zkpor.ZkporError as e:   # e.g. not enough free HBM for the table form of the key: measure the plain layout and say so
+        if args.tables <= 1:
+            raise
+        print(f"bench.py: key with {args.tables} tables per point failed ({e}); falling back to plain arrays", file=sys.stderr)
+        pk.close()
+        ctx.set_param("msm_tables", 1)
+        tables_used = 1
+        pk = zkpor.ProvingKey(ctx)
+        pk.synth(log2, n_wires, 3, n_commit, seed=seed)
 
     def dev(nbytes):
         return torch.empty(nbytes, dtype=torch.uint8, device="cuda")
@@ -666,7 +677,7 @@ def main():
         achieved = units_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         bproof = algorithmic_bytes_per_proof(log2, n_wires, n_commit)
         tb, tsrc = pmc_traffic_bytes_per_launch()
-        profiled_cfg = log2 == 26 and args.scalars == "witness" and args.config == "zkpor50_1380" and not args.window and not args.chunk and args.tables == 4
+        profiled_cfg = log2 == 26 and args.scalars == "witness" and args.config == "zkpor50_1380" and not args.window and not args.chunk and tables_used == 4
         traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and profiled_cfg) else None
         vb_ms, vsrc = pmc_valu_issue_bound_ms()
         valu = ({"issue_bound_ms_per_launch": vb_ms, "frac": vb_ms / (avg_launch_s * 1e3),
@@ -688,7 +699,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}-shaped Groth16 PROVE TAIL (everything in groth16.Prove after the R1CS solver: computeH, "
                                    f"A/B1/K/Z + B2 multi-exponentiations, blinding, + the 2 Pedersen commitment sums): D=2^{log2}, "
-                                   f"n_wires=2^{log2}, commit 2^{log2 - 2}, key as {args.tables} fixed-base table(s) per point, scalars={args.scalars}"
+                                   f"n_wires=2^{log2}, commit 2^{log2 - 2}, key as {tables_used} fixed-base table(s) per point, scalars={args.scalars}"
                                    + (f" ({cfg['mixture']})" if args.scalars == "witness" else "")
                                    + f", {len(workers)} proof(s) in flight per GPU, w/a/b/c resident in HBM; the solver is NOT included",
                        "tier": args.config, "users_per_batch": cfg["users"], "assets_per_user": cfg["assets"]},
