@@ -50,3 +50,33 @@ def test_damaged_streams_are_refused(host):
     for name, data in cases.items():
         rc, _, _, err = _parse(host, data)
         assert rc == 1 and err.startswith("r1cs file:"), name
+
+
+def test_random_damage_never_escapes_the_header_walk(host):
+    """the container is mapped from disk: random byte damage, truncation and growth must end in a refusal (or, when only payload
+    bytes changed, in the same counts) — the walk forms no pointer past the stream"""
+    import random
+    S = O.Synth(5, 120, n_public=2, seed=8)
+    good = RC.from_synth(S, commitments=[(9, [3, 4, 6], [1])])
+    rc0, c0, _, _ = _parse(host, good)
+    assert rc0 == 0
+    rng = random.Random(4)
+    refused = same = 0
+    for _ in range(1200):
+        b = bytearray(good)
+        mode = rng.randrange(3)
+        if mode == 0:
+            for _ in range(rng.choice((1, 2, 8))):
+                b[rng.randrange(min(len(b), 200))] = rng.randrange(256)      # the header and the commitment info
+        elif mode == 1:
+            del b[rng.randrange(len(b)):]
+        else:
+            b += bytes(rng.randrange(256) for _ in range(rng.choice((1, 8, 64))))
+        rc, c, _, err = _parse(host, bytes(b))
+        if rc == 0:
+            same += 1
+            assert c[1] < (1 << 32) and c[4] < (1 << 32)
+        else:
+            refused += 1
+            assert err.startswith("r1cs file:")
+    assert refused > 600

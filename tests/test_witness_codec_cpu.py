@@ -147,3 +147,49 @@ def test_s2_blocks(host):
             assert G.s2_decode(z) == src and s2(z, 1)[0] == src
         if len(src) > 1000 and src[:4] == b"0123":
             assert len(s2(src, 0, 1)[0]) < len(src) // 3
+
+
+def test_damaged_rows_are_refused_not_crashed_on(host):
+    """WitnessData comes out of a database: thousands of random single- and multi-byte mutations of a valid row (inside the base64,
+    the s2 block and the gob stream) must each end in an error or in a decoded witness — never in a crash or a runaway allocation"""
+    import random
+    col = _synth(host, 7, 3, 4, 6)
+    z = base64.b64decode(col)
+    g = G.s2_decode(z)
+    rng = random.Random(11)
+    err = ctypes.create_string_buffer(256)
+    out = ctypes.create_string_buffer(1 << 22)
+    host.zkh_witness_reencode.restype = ctypes.c_long
+    outcomes = {"ok": 0, "error": 0}
+
+    def feed(column):
+        n = host.zkh_witness_reencode(column, ctypes.c_size_t(len(column)), 1, 0, out, ctypes.c_size_t(1 << 22), err, ctypes.c_size_t(256))
+        outcomes["ok" if n >= 0 else "error"] += 1
+
+    for trial in range(1500):
+        layer = trial % 3
+        src = bytearray(col if layer == 0 else z if layer == 1 else g)
+        for _ in range(rng.choice((1, 1, 2, 5))):
+            pos = rng.randrange(len(src))
+            mode = rng.randrange(4)
+            if mode == 0:
+                src[pos] = rng.randrange(256)
+            elif mode == 1:
+                src[pos] ^= 1 << rng.randrange(8)
+            elif mode == 2:
+                del src[pos:pos + rng.choice((1, 3, 40))]
+            else:
+                src[pos:pos] = bytes(rng.randrange(256) for _ in range(rng.choice((1, 9))))
+            if not src:
+                src = bytearray(b"A")
+        if layer == 0:
+            feed(bytes(src))
+        elif layer == 1:
+            feed(base64.b64encode(bytes(src)))
+        else:
+            feed(base64.b64encode(G.s2_literal_block(bytes(src))))
+    # huge counts and lengths in front of nothing
+    for evil in (b"\xf8" + b"\xff" * 8, b"\x05\xff\x81" + b"\xf8" + b"\x7f" * 8, b"\x03\xff\x82\x00"):
+        feed(base64.b64encode(G.s2_literal_block(evil)))
+    feed(base64.b64encode(bytes([0xff, 0xff, 0xff, 0xff, 0x0f, 0x00]) + b"x"))      # s2 block claiming 4 GiB
+    assert outcomes["error"] > 500 and outcomes["ok"] + outcomes["error"] == 1504

@@ -278,7 +278,7 @@ private:
             case WireType::Array: case WireType::Slice: {
                 uint64_t cnt = m.uint();
                 if (t.kind == WireType::Array && (int64_t)cnt != t.len) throw std::runtime_error("gob: array length differs from its type");
-                if (cnt > m.n - m.off + 1 && cnt > (1u << 20)) throw std::runtime_error("gob: element count");
+                if (cnt > m.n - m.off) throw std::runtime_error("gob: element count beyond the message");  // every element is >= 1 byte
                 v.kind = Value::List;
                 v.list.reserve((size_t)cnt);
                 for (uint64_t k = 0; k < cnt; ++k) v.list.push_back(value(t.elem, m, depth + 1));
@@ -588,7 +588,7 @@ inline Bytes Decode(const Bytes& in) {
     }
     if (want > (1ull << 32)) throw std::runtime_error("s2: block too large");
     Bytes out;
-    out.reserve((size_t)want);
+    out.reserve((size_t)(want < 64 * (uint64_t)n + 64 ? want : 64 * (uint64_t)n + 64));  // a damaged length prefix must not reserve gigabytes
     size_t last_offset = 1;
     auto need = [&](size_t k) { if (n - i < k) throw std::runtime_error("s2: truncated element"); };
     while (i < n) {
