@@ -89,6 +89,9 @@ int r1cs_file_eval(const uint8_t* data, size_t len, const uint64_t* w, uint64_t*
 // a1 end to end: a witness-table row -> decode -> assign -> solver (stub: the test's own solution of its own circuit, after checking
 // what it was handed) -> commitment -> prove tail -> raw proof -> proof-table row as a CSV line.  The key is loaded by the caller
 // (Python) into ctx/pk handles passed in as pointers.
+static uint8_t g_last_challenge[32];
+// what the commit callback handed the (stub) solver as the BSB22 hint's output in the last prove_batch_row call
+void prove_batch_last_challenge(uint8_t out[32]) { memcpy(out, g_last_challenge, 32); }
 long prove_batch_row(void* ctx_h, void* pk_h, const char* column, size_t column_len, int64_t batch, const uint64_t* w, const uint64_t* a,
                      const uint64_t* b, const uint64_t* c, size_t n_wires, size_t n_constraints, const uint64_t* committed, size_t n_committed,
                      const uint64_t* r, const uint64_t* s, uint64_t expect_inputs, int fail_stage, char* out, size_t cap, int* tier,
@@ -102,7 +105,7 @@ long prove_batch_row(void* ctx_h, void* pk_h, const char* column, size_t column_
         sol->w.assign(w, w + 4 * n_wires); sol->a.assign(a, a + 4 * n_constraints);
         sol->b.assign(b, b + 4 * n_constraints); sol->c.assign(c, c + 4 * n_constraints);
         sol->n_constraints = n_constraints;
-        if (n_committed) { uint8_t cm[64], k[64]; if (commit(committed, n_committed, cm, k) != 0) return 3; }
+        if (n_committed) { uint8_t cm[64], k[64]; if (commit(committed, n_committed, cm, k, g_last_challenge) != 0) return 3; }
         return 0;
     };
     VerifyFn verify = [&](const std::string& raw, const BatchCreateUserWitnessW&) -> int { raw_seen = raw; return fail_stage == PB_VERIFY ? 1 : 0; };

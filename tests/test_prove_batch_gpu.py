@@ -67,6 +67,11 @@ def test_row_to_row(zk):
         cm, kp = zk.commit(pk, vals)
         assert raw[260:388] == zkpor.proof_write_raw(proof, cm[None, :], kp).tobytes()[260:388]
         assert O.pedersen_verify_pairing(cm, kp, O.g2_mul_gen(sig)) and S.verify_pairing(proof)
+        # the solver got the hint's output: hash_to_field(commitment), DST "bsb22-commitment" (host/bsb22_challenge.hpp)
+        from test_bsb22_challenge_cpu import fr_hash_py
+        ch = (ctypes.c_uint8 * 32)()
+        drv.prove_batch_last_challenge(ch)
+        assert int.from_bytes(bytes(ch), "big") == fr_hash_py(raw[260:324], b"bsb22-commitment", 1)[0]
         rows = list(csv.DictReader(io.StringIO(text)))
         assert len(rows) == 1
         row = rows[0]

@@ -5,6 +5,7 @@
 #include "r1cs_file.hpp"
 #include "witness_codec.hpp"
 #include "witness_assign.hpp"
+#include "bsb22_challenge.hpp"
 #include <atomic>
 #include <cstring>
 using namespace zkpor_host;
@@ -203,5 +204,33 @@ long zkh_witness_assign(const char* column, size_t column_len, const int* tiers,
         if (err && err_len) snprintf(err, err_len, "%s", e.what());
         return -1;
     }
+}
+// ---- bsb22_challenge.hpp ----
+void zkh_sha256(const uint8_t* msg, size_t len, uint8_t out[32]) { Sha256 h; h.Write(msg, len); h.Sum(out); }
+// 0 = ok, 1 = refused (RFC 9380 limits)
+int zkh_expand_msg_xmd(const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, uint8_t* out, size_t out_len) {
+    try {
+        std::string u = ExpandMsgXmd(std::string((const char*)msg, msg_len), std::string((const char*)dst, dst_len), out_len);
+        memcpy(out, u.data(), out_len);
+        return 0;
+    } catch (const std::exception&) { return 1; }
+}
+// fr.Hash: count elements of 32 bytes big-endian each
+int zkh_fr_hash(const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, size_t count, uint8_t* out) {
+    try {
+        auto v = FrHash(std::string((const char*)msg, msg_len), std::string((const char*)dst, dst_len), count);
+        for (size_t i = 0; i < count; ++i) memcpy(out + 32 * i, v[i].data(), 32);
+        return 0;
+    } catch (const std::exception&) { return 1; }
+}
+// the BSB22 hint's output for one commitment: n_public values of 32 bytes big-endian follow the 64-byte commitment in the hash input
+int zkh_bsb22_challenge(const uint8_t commitment[64], const uint8_t* public_be32, size_t n_public, uint8_t out[32]) {
+    try {
+        std::vector<std::string> pub;
+        for (size_t i = 0; i < n_public; ++i) pub.emplace_back((const char*)public_be32 + 32 * i, 32);
+        std::string c = Bsb22Challenge(commitment, pub);
+        memcpy(out, c.data(), 32);
+        return 0;
+    } catch (const std::exception&) { return 1; }
 }
 }

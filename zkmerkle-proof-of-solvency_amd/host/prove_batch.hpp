@@ -4,6 +4,7 @@
 //     --SetBatchCreateUserCircuitWitness--> the assigned circuit / NewWitness vector           (circuit/...:334-436; witness_assign.hpp)
 //     --SOLVER (gnark's r1cs.Solve + hints: NOT part of this repo, a callback)--> w, a, b, c    (prover.go:269, inside groth16.Prove)
 //          the BSB22 hint inside it calls back for the Pedersen commitment --zkpor_commit--> (commitment, knowledge proof)
+//          and gets the hint's output, the challenge hash_to_field(commitment) (bsb22_challenge.hpp), to carry on solving
 //     --zkpor_prove_tail--> Ar, Bs, Krs --zkpor_proof_write_raw--> proof.WriteRawTo bytes      (prover.go:201)
 //     --MakeProofRow--> the `proof` table row (prover.go:227-236; proof_row.hpp)
 //
@@ -15,6 +16,7 @@
 #include <string>
 #include <vector>
 #include "../../include/zkpor.h"
+#include "bsb22_challenge.hpp"
 #include "proof_row.hpp"
 #include "witness_assign.hpp"
 #include "witness_codec.hpp"
@@ -27,8 +29,10 @@ struct SolvedWitness {                    // what r1cs.Solve leaves behind (gnar
     bool has_commitment = false;
     uint8_t commitment[64] = {0}, pok[64] = {0};  // filled by the commit callback during the solve
 };
-// the Pedersen commitment the BSB22 hint asks for in the middle of the solve: values = the committed wires (Montgomery Fr)
-typedef std::function<int(const uint64_t* values, size_t n, uint8_t commitment[64], uint8_t pok[64])> CommitFn;
+// the Pedersen commitment the BSB22 hint asks for in the middle of the solve: values = the private committed wires (Montgomery Fr).
+// challenge = the value the hint returns to the solver (32 B big-endian, canonical): hash_to_field(commitment) — this circuit commits
+// to no public wire; a circuit that does calls Bsb22Challenge(commitment, public values) itself.
+typedef std::function<int(const uint64_t* values, size_t n, uint8_t commitment[64], uint8_t pok[64], uint8_t challenge[32])> CommitFn;
 // the solver: assigned inputs -> full solution; calls `commit` when the circuit has a commitment.  0 = ok
 typedef std::function<int(const AssignedWitness& in, const CommitFn& commit, SolvedWitness* out)> SolveFn;
 typedef std::function<int(const std::string& raw_proof, const BatchCreateUserWitnessW& w)> VerifyFn;  // groth16.Verify stand-in; may be empty
@@ -46,9 +50,12 @@ inline int GenerateAndVerifyProof(zkpor_ctx* ctx, zkpor_pk* pk, const std::strin
     std::string why;
     if (!SetBatchCreateUserCircuitWitness(w, asset_counts_tiers, &in, &why)) { if (err) *err = "assign: " + why; return PB_ASSIGN; }
     SolvedWitness sol;
-    CommitFn commit = [&](const uint64_t* values, size_t n, uint8_t c[64], uint8_t k[64]) -> int {
+    CommitFn commit = [&](const uint64_t* values, size_t n, uint8_t c[64], uint8_t k[64], uint8_t challenge[32]) -> int {
         int32_t rc = zkpor_commit(ctx, pk, values, n, c, k);
-        if (rc == ZKPOR_OK) { sol.has_commitment = true; memcpy(sol.commitment, c, 64); memcpy(sol.pok, k, 64); }
+        if (rc == ZKPOR_OK) {
+            sol.has_commitment = true; memcpy(sol.commitment, c, 64); memcpy(sol.pok, k, 64);
+            if (challenge) memcpy(challenge, Bsb22Challenge(c).data(), 32);
+        }
         return rc;
     };
     if (solve(in, commit, &sol) != 0) { if (err) *err = "solve: the solver reported an error"; return PB_SOLVE; }
