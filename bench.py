@@ -239,6 +239,103 @@ def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vector
                     "buffers filled by copy threads, w first then a/b/c under the A/B1/K accumulations; two callers = two contexts on one GPU"}
 
 
+def r1cs_leg(torch, zkpor, ctx, device, pk, D, log2, n_wires, w_dev, seed, blinding, resident_ms, terms, n_proofs=3):
+    """Opt-in leg (--r1cs-terms K): the host-pointer form with the constraint matrices RESIDENT (zkpor_prove_r1cs): only
+    w crosses PCIe per proof, a, b, c = L.w, R.w, O.w are evaluated in HBM.  Synthetic matrices: K terms per constraint over the three
+    matrices (the 12 GB .r1cs of the production tiers suggests ~20), uniform random wires, 256 distinct coefficients.  Same two shapes
+    as `boundary` (one caller, two callers on two contexts sharing ONE copy of the matrices); every proof verified against the
+    trapdoor with h = computeH of the evaluated a, b, c."""
+    import threading
+    import numpy as np
+    import oracle as O
+    import trapdoor as T
+    import zkpor as _z
+    lib = ctx.lib
+    t_setup = time.perf_counter()
+    rng = np.random.default_rng(20260927)
+    ncoef = 256
+    table = O.fr_random(91, ncoef)
+    table[:2] = O.fr_from_ints([1, O.R_MOD - 1])
+    ks = [max(1, (terms + 2) // 3), max(1, (terms + 1) // 3), max(1, terms // 3)]
+    r1 = zkpor.R1CS(ctx, D, n_wires, table)
+    other = None
+    try:
+        nnz = 0
+        for which, k in enumerate(ks):
+            row_ptr = np.arange(D + 1, dtype=np.uint64) * np.uint64(k)
+            cid = rng.integers(0, ncoef, size=D * k, dtype=np.uint32)
+            wid = rng.integers(0, n_wires, size=D * k, dtype=np.uint32)
+            r1.set_matrix(which, row_ptr, cid, wid)
+            nnz += D * k
+            del row_ptr, cid, wid
+        hw = np.empty((n_wires, 4), dtype=np.uint64)
+        ctx._ck(lib.zkpor_dev_download(ctx.h, _z._p(hw), ctypes.c_void_p(w_dev.data_ptr()), ctypes.c_size_t(hw.nbytes)))
+        bufs = [torch.empty(32 * D, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        ctx.sync(); ctx.phase_reset()
+        r1.eval_dev(w_dev.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), D)
+        ctx.sync()
+        eval_ms = ctx.phase_ms("r1cs_eval")[0]
+        ctx.compute_h_dev(log2, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+        hh = np.empty((D, 4), dtype=np.uint64)
+        ctx._ck(lib.zkpor_dev_download(ctx.h, _z._p(hh), ctypes.c_void_p(bufs[0].data_ptr()), ctypes.c_size_t(hh.nbytes)))
+        del bufs
+        torch.cuda.empty_cache()
+        td = T.SynthKeyTrapdoor(seed, 3, hw, hh[: D - 1])
+        del hh
+        setup_s = time.perf_counter() - t_setup
+        results = []
+
+        def prove(wctx, i):
+            r, s = blinding(i)
+            results.append((i, wctx.prove_r1cs(pk, r1, hw, r, s)))
+
+        other = zkpor.Context(device, None)
+        ctxs = [ctx, other]
+        for k, wctx in enumerate(ctxs):
+            prove(wctx, 9500 + k)
+        t0 = time.perf_counter()
+        for i in range(n_proofs):
+            prove(ctx, 9600 + i)
+        one_ms = (time.perf_counter() - t0) / n_proofs * 1e3
+        n2 = 2 * n_proofs
+        nxt = [0]
+        lock = threading.Lock()
+        errs = []
+
+        def loop(wctx):
+            torch.cuda.set_device(device)
+            try:
+                while True:
+                    with lock:
+                        if nxt[0] >= n2:
+                            return
+                        i = nxt[0]; nxt[0] += 1
+                    prove(wctx, 9700 + i)
+            except Exception as e:
+                errs.append(e)
+
+        th = [threading.Thread(target=loop, args=(c_,)) for c_ in ctxs]
+        t0 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        two_ms = (time.perf_counter() - t0) / n2 * 1e3
+        if errs:
+            raise errs[0]
+        ok = sum(int(td.check(p_, *blinding(i))) for i, p_ in results)
+    finally:
+        if other is not None:
+            other.close()
+        r1.close()
+    return {"value": 1e3 / two_ms, "unit": "proofs/s", "ms_per_proof": two_ms, "frac_of_resident_value": resident_ms / two_ms, "callers": 2,
+            "one_caller_ms_per_proof": one_ms, "bytes_per_proof": int(hw.nbytes), "terms_per_constraint": int(sum(ks)), "nnz": int(nnz),
+            "matrices_bytes": int(nnz * 8 + 3 * (D + 1) * 8), "r1cs_eval_kernel_ms": round(eval_ms, 2), "proofs": len(results), "checked_ok": ok,
+            "setup_seconds": round(setup_s, 1),
+            "note": "zkpor_prove_r1cs: w from pageable host memory, a, b, c evaluated in HBM from resident synthetic matrices (one copy "
+                    "shared by both contexts), then the resident order of the prove tail"}
+
+
 def poseidon_tree_leg(ctx, log2_leaves=27, depth=28):
     """The second half of the north star in the driver's line: the Poseidon account tree at the reference's BenchmarkBuild size
     (2^27 leaves, src/utils/merkletree/merkletree_test.go:287-298), leaves resident in HBM, built by zkpor_merkle_build_dev.
@@ -399,6 +496,8 @@ def main():
                     help="steps of the second, uniform-scalar timed region reported as value_uniform (-1 = max(2, steps/4); 0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the trapdoor verification of the timed proofs")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-pointer (cgo-shaped) boundary leg")
+    ap.add_argument("--r1cs-terms", type=int, default=0, help="opt-in leg: the host-pointer form with resident constraint matrices "
+                    "(zkpor_prove_r1cs) on synthetic matrices of this many terms per constraint (0 = off; ~20 mirrors the 12 GB .r1cs)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the informational region with two proofs in flight per GPU")
     ap.add_argument("--copy-chunk-mb", type=int, default=0, help="size of the pinned bounce buffers of the boundary leg (0 = library default, 32)")
     ap.add_argument("--copy-threads", type=int, default=0, help="host threads per context that fill the pinned bounce buffers in the "
@@ -730,6 +829,12 @@ def main():
                                                    resident_ms=dt / args.steps * 1e3, copy_threads=args.copy_threads, copy_chunk_mb=args.copy_chunk_mb)
                 except Exception as e:
                     out["boundary"] = {"value": None, "note": f"failed: {e}"}
+            if args.r1cs_terms > 0:
+                try:
+                    out["r1cs_resident"] = r1cs_leg(torch, zkpor, ctx, local_rank, pk, D, log2, n_wires, w, seed, blinding,
+                                                    resident_ms=dt / args.steps * 1e3, terms=args.r1cs_terms)
+                except Exception as e:
+                    out["r1cs_resident"] = {"value": None, "note": f"failed: {e}"}
             if not args.no_cpu_baseline:
                 try:
                     out["cpu_baseline"] = cpu_baseline(args.cpu_log2, log2, 0.25)

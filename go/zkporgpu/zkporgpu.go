@@ -206,6 +206,22 @@ func (c *Context) ProveTail(pk *ProvingKey, w, a, b, cc []fr.Element, r, s *fr.E
 	return
 }
 
+// ProveR1CS is ProveTail for a caller whose constraint matrices are resident (UploadR1CS): only w crosses PCIe (n_wires x 32 B per
+// proof instead of n_wires + 3 n_constraints); a, b, c = L.w, R.w, O.w are evaluated in HBM.  `m` may have been uploaded through any
+// Context of the same GPU.
+func (c *Context) ProveR1CS(pk *ProvingKey, m *R1CS, w []fr.Element, r, s *fr.Element) (ar curve.G1Affine, bs curve.G2Affine, krs curve.G1Affine, err error) {
+	var out [256]byte
+	err = c.err(C.zkpor_prove_r1cs(c.h, pk.dev, m.h, (*C.uint64_t)(unsafe.Pointer(&w[0])),
+		(*C.uint64_t)(unsafe.Pointer(r)), (*C.uint64_t)(unsafe.Pointer(s)), (*C.uint8_t)(unsafe.Pointer(&out[0]))))
+	if err != nil {
+		return
+	}
+	ar = *(*curve.G1Affine)(unsafe.Pointer(&out[0]))
+	bs = *(*curve.G2Affine)(unsafe.Pointer(&out[64]))
+	krs = *(*curve.G1Affine)(unsafe.Pointer(&out[192]))
+	return
+}
+
 // Commit replaces pedersen.ProvingKey.Commit and ProveKnowledge (two MultiExps over the committed values) in one call.
 func (c *Context) Commit(pk *ProvingKey, values []fr.Element) (commitment, pok curve.G1Affine, err error) {
 	var p *C.uint64_t

@@ -198,6 +198,14 @@ int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const 
 int32_t zkpor_prove_tail_rand(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                               const uint64_t* c, size_t n_constraints, uint64_t r_out[4], uint64_t s_out[4],
                               uint8_t proof_out[256]);
+/* HOST-POINTER FORM WITH THE CONSTRAINT MATRICES RESIDENT (zkpor_r1cs_* below): only the wire vector crosses PCIe —
+ * n_wires x 32 B per proof instead of (n_wires + 3 n_constraints) x 32 B (2.1 GB instead of 8.6 GB at 2^26) — and a, b, c =
+ * L.w, R.w, O.w are evaluated in the staging area before computeH.  Replaces the same call as zkpor_prove_tail (groth16.Prove,
+ * src/prover/prover/prover.go:269) for a caller that exported its constraint system once (go/export_r1cs).  `r1cs` may belong to
+ * any context of the same GPU (the matrices are only read): two callers share one copy. */
+typedef struct zkpor_r1cs zkpor_r1cs;
+int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const uint64_t* w, const uint64_t r[4], const uint64_t s[4],
+                         uint8_t proof_out[256]);
 /* device-resident inputs; d_a/d_b/d_c must hold 2^log2_domain elements (zero padded) and are overwritten */
 int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c,
                              const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]);

@@ -24,7 +24,7 @@ def _bench(*args):
 
 
 def test_bench_line_small_domain():
-    d = _bench("--log2", "18", "--steps", "3", "--warmup", "1", "--cpu-log2", "14")
+    d = _bench("--log2", "18", "--steps", "3", "--warmup", "1", "--cpu-log2", "14", "--r1cs-terms", "7")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "proofs/s" and d["higher_is_better"] and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -37,6 +37,8 @@ def test_bench_line_small_domain():
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["avg_launch_ms"] > 0
     b = d["boundary"]
     assert b["callers"] == 2 and b["checked_ok"] == b["proofs"] and b["value"] > 0 and b["one_caller_ms_per_proof"] > 0
+    q = d["r1cs_resident"]     # opt-in leg: host w + resident matrices (zkpor_prove_r1cs), its proofs checked as well
+    assert q["callers"] == 2 and q["checked_ok"] == q["proofs"] == 11 and q["terms_per_constraint"] == 7 and q["bytes_per_proof"] * 4 < b["bytes_per_proof"] + 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "2^14" in c["sample"]
     assert d["acceptance"]["accepted"] == d["acceptance"]["proofs"] == 4

@@ -101,6 +101,42 @@ def test_witness_to_proof_without_abc_on_the_host(zk):
             b.free()
 
 
+def test_prove_r1cs_host_pointer_form(zk):
+    """zkpor_prove_r1cs: w in host memory + matrices resident = the proof of the (w, a, b, c) host form = the oracle's; a second context
+    of the same GPU proves against the same matrices; mismatches are refused"""
+    S = O.Synth(6, 700, n_public=2, seed=35)
+    r, _, _ = _load(zk, S)
+    pk = zkpor.ProvingKey(zk)
+    zk2 = zkpor.Context(0)
+    try:
+        z = np.zeros(S.n_wires, dtype=np.uint8)
+        pk.set_g1(zkpor.G1_A, S.A); pk.set_g1(zkpor.G1_B, S.B1); pk.set_g2(zkpor.G2_B, S.B2)
+        pk.set_g1(zkpor.G1_K, S.K[S.n_public:]); pk.set_g1(zkpor.G1_Z, S.Z)
+        pk.set_consts(S.abd1[0], S.abd1[1], S.abd1[2], S.bd2[0], S.bd2[1], S.log2d, z, z, S.n_wires, S.n_public)
+        for i, ctx in enumerate((zk, zk2, zk)):
+            rr = O.fr_random(50 + i, 1)[0]; ss = O.fr_random(60 + i, 1)[0]
+            want = S.prove_tail(rr, ss)
+            got = ctx.prove_r1cs(pk, r, S.w, rr, ss)
+            assert np.array_equal(got, want)
+            assert np.array_equal(ctx.prove_tail(pk, S.w, S.a, S.b, S.c, rr, ss), want)
+        assert S.verify_pairing(got)
+        # a constraint system with another wire count than the key
+        S2 = O.Synth(6, 650, n_public=2, seed=36)
+        if S2.n_wires != S.n_wires:
+            r2, _, _ = _load(zk, S2)
+            try:
+                with pytest.raises(zkpor.ZkporError, match="number of wires"):
+                    zk.prove_r1cs(pk, r2, S2.w, rr, ss)
+            finally:
+                r2.close()
+        # non-canonical blinding is refused as in the other forms
+        bad = np.full(4, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+        with pytest.raises(zkpor.ZkporError, match="blinding"):
+            zk.prove_r1cs(pk, r, S.w, bad, ss)
+    finally:
+        zk2.close(); pk.close(); r.close()
+
+
 def test_exported_container_loads_and_evaluates(zk):
     """f1 ingestion end to end: the flat container go/export_r1cs writes (here: written by tests/r1cs_container.py from the oracle's
     instance) -> host/r1cs_file.hpp (C++: header walk on mapped bytes, zkpor_r1cs_create / set_matrix) -> a, b, c on the device"""

@@ -168,6 +168,9 @@ int32_t stage_reserve(zkpor_ctx* ctx, size_t bytes);
 // range is no longer needed afterwards unless it was page-locked (then: until the copy stream has drained).
 int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 void bounce_free(zkpor_ctx* ctx);
+// r1cs.hip: a, b, c = L.w, R.w, O.w queued on `ctx`'s stream (any context of the GPU the matrices live on: they are only read)
+int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size);
+void r1cs_dims(const zkpor_r1cs* r, size_t* n_constraints, size_t* n_wires, int* device);
 
 // sort.hip (rocPRIM radix sort of (key,value) u32 pairs, keys in [0, 2^end_bit))
 int32_t sort_pairs_temp_bytes(zkpor_ctx* ctx, size_t n, int end_bit, size_t* bytes);

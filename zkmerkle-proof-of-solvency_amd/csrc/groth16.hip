@@ -753,6 +753,49 @@ int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const 
     return ZKPOR_OK;
 }
 
+// Host-pointer form with the constraint matrices resident (zkpor_r1cs_*): only w crosses PCIe (n_wires x 32 B instead of
+// n_wires + 3 n_constraints); a, b, c are evaluated in the staging area, then the resident order of prove_sums runs
+// (computeH first, decompose + sort of w hidden under it).
+int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const uint64_t* w, const uint64_t r[4], const uint64_t s[4],
+                         uint8_t proof_out[256]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !pk || !r1cs || !w || !r || !s || !proof_out) return ZKPOR_E_ARG;
+    if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
+    if (pk->shard) { ctx->err = "prove: the key is a shard (zkpor_pk_keep_range): use zkpor_prove_sums_dev + zkpor_prove_assemble"; return ZKPOR_E_STATE; }
+    const size_t D = (size_t)1 << pk->log2_domain;
+    size_t nc = 0, nw = 0;
+    int dev = -1;
+    r1cs_dims(r1cs, &nc, &nw, &dev);
+    if (dev != ctx->device) { ctx->err = "prove: the constraint matrices live on another GPU than the context"; return ZKPOR_E_ARG; }
+    if (nw != pk->n_wires) { ctx->err = "prove: the constraint system and the key disagree on the number of wires"; return ZKPOR_E_ARG; }
+    if (nc > D) { ctx->err = "prove: more constraints than the domain"; return ZKPOR_E_ARG; }
+    ZK_TRY(check_same_gpu(ctx, pk));
+    ZK_TRY(check_blinding(ctx, r, s));
+    ZK_TRY(stage_reserve(ctx, (3 * D + pk->n_wires) * sizeof(Fr)));
+    Fr* d = (Fr*)ctx->stage;
+    Fr* d_w = d + 3 * D;
+    auto drain = [&] {  // nothing may still read the caller's memory or the staging area when the call returns
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+    };
+    int32_t rc = host_upload(ctx, d_w, w, pk->n_wires * sizeof(Fr));
+    hipEvent_t e_up = ev_get(ctx);
+    if (rc == ZKPOR_OK && (hipEventRecord(e_up, ctx->copy_stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, e_up, 0) != hipSuccess)) {
+        ctx->err = "prove: event on the copy stream failed"; rc = ZKPOR_E_HIP;
+    }
+    ctx->event_pool.push_back(e_up);
+    if (rc == ZKPOR_OK) rc = r1cs_eval_on(ctx, r1cs, d_w, d, d + D, d + 2 * D, D);
+    ProveSums m;
+    Blind bl;
+    const std::function<void()> prep = [&] { bl = blind_prepare(pk->delta, pk->delta2, r, s); };
+    if (rc == ZKPOR_OK) rc = prove_sums(ctx, pk, d_w, d, d + D, d + 2 * D, &m, true, true, &prep);
+    if (rc != ZKPOR_OK) { drain(); return rc; }
+    HostPhase hp(ctx, "host_assembly");
+    assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
+    return ZKPOR_OK;
+}
+
 // uniform Fr from the operating system's CSPRNG: 32 bytes from getrandom(2), top two bits cleared, rejected unless below the
 // modulus (acceptance ~ 0.76) — the construction of gnark-crypto's fr.Element.SetRandom.  The canonical limbs are used as the
 // Montgomery representation directly: x -> x R^-1 is a bijection of Fr, so the residue is uniform either way.

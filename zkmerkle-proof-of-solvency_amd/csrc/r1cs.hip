@@ -62,6 +62,27 @@ static void r1cs_free(zkpor_r1cs* r) {
 }  // namespace zk
 
 using namespace zk;
+namespace zk {
+int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
+    if (!ctx || !r || !d_w || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
+    if (ctx->device != r->ctx->device) { ctx->err = "r1cs: the matrices live on another GPU than the context"; return ZKPOR_E_ARG; }
+    if (domain_size < r->n_constraints) { ctx->err = "r1cs: domain smaller than the constraint count"; return ZKPOR_E_ARG; }
+    for (int m = 0; m < 3; ++m) if (!r->row_ptr[m]) { ctx->err = "r1cs: matrix " + std::to_string(m) + " not loaded"; return ZKPOR_E_STATE; }
+    if (domain_size == 0) return ZKPOR_OK;
+    R1csDev M;
+    M.coeff = r->coeff; M.kind = r->coeff_kind;
+    for (int m = 0; m < 3; ++m) { M.row_ptr[m] = r->row_ptr[m]; M.cid[m] = r->cid[m]; M.wid[m] = r->wid[m]; }
+    PhaseScope ps(ctx, "r1cs_eval");
+    hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((domain_size + 255) / 256), 3), dim3(256), 0, ctx->stream, M, (const Fr*)d_w,
+                       r->n_constraints, domain_size, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+void r1cs_dims(const zkpor_r1cs* r, size_t* n_constraints, size_t* n_wires, int* device) {
+    *n_constraints = r->n_constraints; *n_wires = r->n_wires; *device = r->ctx->device;
+}
+}  // namespace zk
+
 extern "C" {
 
 int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, const uint64_t* coeff_table, size_t n_coeff,
@@ -117,19 +138,8 @@ int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr,
 }
 int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
     ZK_ENTER(r ? r->ctx->device : -1);
-    if (!r || !d_w || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
-    zkpor_ctx* ctx = r->ctx;
-    if (domain_size < r->n_constraints) { ctx->err = "r1cs: domain smaller than the constraint count"; return ZKPOR_E_ARG; }
-    for (int m = 0; m < 3; ++m) if (!r->row_ptr[m]) { ctx->err = "r1cs: matrix " + std::to_string(m) + " not loaded"; return ZKPOR_E_STATE; }
-    if (domain_size == 0) return ZKPOR_OK;
-    R1csDev M;
-    M.coeff = r->coeff; M.kind = r->coeff_kind;
-    for (int m = 0; m < 3; ++m) { M.row_ptr[m] = r->row_ptr[m]; M.cid[m] = r->cid[m]; M.wid[m] = r->wid[m]; }
-    PhaseScope ps(ctx, "r1cs_eval");
-    hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((domain_size + 255) / 256), 3), dim3(256), 0, ctx->stream, M, (const Fr*)d_w,
-                       r->n_constraints, domain_size, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c);
-    ZK_KERNEL_CHECK(ctx);
-    return ZKPOR_OK;
+    if (!r) return ZKPOR_E_ARG;
+    return zk::r1cs_eval_on(r->ctx, r, d_w, d_a, d_b, d_c, domain_size);
 }
 /* host-buffer form for tests and small circuits: w in, a/b/c (n_constraints each) out */
 int32_t zkpor_r1cs_eval(zkpor_r1cs* r, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c) {

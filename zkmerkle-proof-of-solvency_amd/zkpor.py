@@ -167,6 +167,13 @@ class Context:
         self._ck(self.lib.zkpor_prove_tail(self.h, pk.h, _p(w), _p(a), _p(b), _p(c), ctypes.c_size_t(a.shape[0]), _p(r), _p(s), _p(out)))
         return out
 
+    def prove_r1cs(self, pk, r1cs, w, r, s):
+        """host-pointer form with the constraint matrices resident: only w crosses PCIe (zkpor_prove_r1cs)"""
+        w = _u64(w); r = _u64(r); s = _u64(s)
+        out = np.empty(256, dtype=np.uint8)
+        self._ck(self.lib.zkpor_prove_r1cs(self.h, pk.h, r1cs.h, _p(w), _p(r), _p(s), _p(out)))
+        return out
+
     def prove_tail_dev(self, pk, d_w, d_a, d_b, d_c, r, s):
         r = _u64(r); s = _u64(s)
         out = np.empty(256, dtype=np.uint8)
