@@ -13,6 +13,7 @@ Output: ONE JSON line (rank 0) with value = proofs/s over all ranks, plus
   checked      — every timed proof verified in the exponent from the synthetic key's trapdoor (untimed)
   value_uniform — the same step with uniform witness scalars (the worst case), timed in a second region
   boundary     — the host-pointer ABI a cgo caller binds, from pageable host memory (untimed leg, N = 1)
+  r1cs_resident — the same with the constraint matrices resident in HBM: only w crosses PCIe (zkpor_prove_r1cs; untimed leg, N = 1)
 """
 import argparse
 import ctypes
@@ -239,12 +240,12 @@ def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vector
                     "buffers filled by copy threads, w first then a/b/c under the A/B1/K accumulations; two callers = two contexts on one GPU"}
 
 
-def r1cs_leg(torch, zkpor, ctx, device, pk, D, log2, n_wires, w_dev, seed, blinding, resident_ms, terms, n_proofs=3):
-    """Opt-in leg (--r1cs-terms K): the host-pointer form with the constraint matrices RESIDENT (zkpor_prove_r1cs): only
+def r1cs_leg(torch, zkpor, ctx, device, pk, D, log2, n_wires, n_commit, w_dev, cv_dev, seed, blinding, resident_ms, terms, n_proofs=3):
+    """Untimed leg (--r1cs-terms K, 0 = off): the host-pointer form with the constraint matrices RESIDENT (zkpor_prove_r1cs): only
     w crosses PCIe per proof, a, b, c = L.w, R.w, O.w are evaluated in HBM.  Synthetic matrices: K terms per constraint over the three
     matrices (the 12 GB .r1cs of the production tiers suggests ~20), uniform random wires, 256 distinct coefficients.  Same two shapes
-    as `boundary` (one caller, two callers on two contexts sharing ONE copy of the matrices); every proof verified against the
-    trapdoor with h = computeH of the evaluated a, b, c."""
+    as `boundary` (one caller, two callers on two contexts sharing ONE copy of the matrices), zkpor_commit from host memory included
+    as there; every proof verified against the trapdoor with h = computeH of the evaluated a, b, c.  Rank 0, N = 1 only."""
     import threading
     import numpy as np
     import oracle as O
@@ -270,6 +271,9 @@ def r1cs_leg(torch, zkpor, ctx, device, pk, D, log2, n_wires, w_dev, seed, blind
             del row_ptr, cid, wid
         hw = np.empty((n_wires, 4), dtype=np.uint64)
         ctx._ck(lib.zkpor_dev_download(ctx.h, _z._p(hw), ctypes.c_void_p(w_dev.data_ptr()), ctypes.c_size_t(hw.nbytes)))
+        hcv = np.empty((n_commit, 4), dtype=np.uint64)
+        ctx._ck(lib.zkpor_dev_download(ctx.h, _z._p(hcv), ctypes.c_void_p(cv_dev.data_ptr()), ctypes.c_size_t(hcv.nbytes)))
+        ec, ek = T.expected_commitment(seed, hcv)
         bufs = [torch.empty(32 * D, dtype=torch.uint8, device="cuda") for _ in range(3)]
         ctx.sync(); ctx.phase_reset()
         r1.eval_dev(w_dev.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), D)
@@ -287,7 +291,8 @@ def r1cs_leg(torch, zkpor, ctx, device, pk, D, log2, n_wires, w_dev, seed, blind
 
         def prove(wctx, i):
             r, s = blinding(i)
-            results.append((i, wctx.prove_r1cs(pk, r1, hw, r, s)))
+            com, pok = wctx.commit(pk, hcv)
+            results.append((i, wctx.prove_r1cs(pk, r1, hw, r, s), com, pok))
 
         other = zkpor.Context(device, None)
         ctxs = [ctx, other]
@@ -323,16 +328,16 @@ def r1cs_leg(torch, zkpor, ctx, device, pk, D, log2, n_wires, w_dev, seed, blind
         two_ms = (time.perf_counter() - t0) / n2 * 1e3
         if errs:
             raise errs[0]
-        ok = sum(int(td.check(p_, *blinding(i))) for i, p_ in results)
+        ok = sum(int(td.check(p_, *blinding(i)) and np.array_equal(com, ec) and np.array_equal(pok, ek)) for i, p_, com, pok in results)
     finally:
         if other is not None:
             other.close()
         r1.close()
     return {"value": 1e3 / two_ms, "unit": "proofs/s", "ms_per_proof": two_ms, "frac_of_resident_value": resident_ms / two_ms, "callers": 2,
-            "one_caller_ms_per_proof": one_ms, "bytes_per_proof": int(hw.nbytes), "terms_per_constraint": int(sum(ks)), "nnz": int(nnz),
+            "one_caller_ms_per_proof": one_ms, "bytes_per_proof": int(hw.nbytes + hcv.nbytes), "terms_per_constraint": int(sum(ks)), "nnz": int(nnz),
             "matrices_bytes": int(nnz * 8 + 3 * (D + 1) * 8), "r1cs_eval_kernel_ms": round(eval_ms, 2), "proofs": len(results), "checked_ok": ok,
             "setup_seconds": round(setup_s, 1),
-            "note": "zkpor_prove_r1cs: w from pageable host memory, a, b, c evaluated in HBM from resident synthetic matrices (one copy "
+            "note": "zkpor_commit + zkpor_prove_r1cs: committed values and w from pageable host memory, a, b, c evaluated in HBM from resident synthetic matrices (one copy "
                     "shared by both contexts), then the resident order of the prove tail"}
 
 
@@ -496,8 +501,8 @@ def main():
                     help="steps of the second, uniform-scalar timed region reported as value_uniform (-1 = max(2, steps/4); 0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the trapdoor verification of the timed proofs")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-pointer (cgo-shaped) boundary leg")
-    ap.add_argument("--r1cs-terms", type=int, default=0, help="opt-in leg: the host-pointer form with resident constraint matrices "
-                    "(zkpor_prove_r1cs) on synthetic matrices of this many terms per constraint (0 = off; ~20 mirrors the 12 GB .r1cs)")
+    ap.add_argument("--r1cs-terms", type=int, default=20, help="untimed leg: the host-pointer form with resident constraint matrices "
+                    "(zkpor_prove_r1cs) on synthetic matrices of this many terms per constraint (0 = off; 20 mirrors the 12 GB .r1cs)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the informational region with two proofs in flight per GPU")
     ap.add_argument("--copy-chunk-mb", type=int, default=0, help="size of the pinned bounce buffers of the boundary leg (0 = library default, 32)")
     ap.add_argument("--copy-threads", type=int, default=0, help="host threads per context that fill the pinned bounce buffers in the "
@@ -522,6 +527,7 @@ def main():
     args = ap.parse_args()
     if args.timed_only:
         args.no_check = args.no_boundary = args.no_cpu_baseline = True
+        args.r1cs_terms = 0
         args.uniform_steps = 0
 
     import torch
@@ -831,7 +837,7 @@ def main():
                     out["boundary"] = {"value": None, "note": f"failed: {e}"}
             if args.r1cs_terms > 0:
                 try:
-                    out["r1cs_resident"] = r1cs_leg(torch, zkpor, ctx, local_rank, pk, D, log2, n_wires, w, seed, blinding,
+                    out["r1cs_resident"] = r1cs_leg(torch, zkpor, ctx, local_rank, pk, D, log2, n_wires, n_commit, w, cv, seed, blinding,
                                                     resident_ms=dt / args.steps * 1e3, terms=args.r1cs_terms)
                 except Exception as e:
                     out["r1cs_resident"] = {"value": None, "note": f"failed: {e}"}

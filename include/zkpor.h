@@ -260,6 +260,9 @@ int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_
                      uint8_t out_pok[64]);
 int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, size_t n, uint8_t out_commit[64],
                          uint8_t out_pok[64]);
+/* G1Affine.Marshal() (gnark-crypto: X | Y big-endian canonical, the identity as 0x40 then zeros) of one point this library returned
+ * as Montgomery limbs — the bytes gnark hashes into the BSB22 challenge (constraint.SerializeCommitment; host/bsb22_challenge.hpp). */
+int32_t zkpor_g1_marshal(const uint8_t affine_mont[64], uint8_t out_be[64]);
 /* gnark raw proof bytes (proof.WriteRawTo): big-endian Ar.X|Ar.Y|Bs.X.A1|Bs.X.A0|Bs.Y.A1|Bs.Y.A0|Krs.X|Krs.Y|
  * u32 n_commitments | commitments... | pok  (388 B for one commitment; 324 B... for none) */
 int32_t zkpor_proof_write_raw(const uint8_t proof[256], const uint8_t* commitments, uint32_t n_commitments,

@@ -888,6 +888,15 @@ static void g2_raw(const Fp* p, uint8_t* out) {  // p = X.A0, X.A1, Y.A0, Y.A1 -
     if (p[0].is_zero() && p[1].is_zero() && p[2].is_zero() && p[3].is_zero()) { memset(out, 0, 128); out[0] = 0x40; return; }
     fp_be(p[1], out); fp_be(p[0], out + 32); fp_be(p[3], out + 64); fp_be(p[2], out + 96);
 }
+// G1Affine.Marshal() of one point handed out by this library (Montgomery limbs): X | Y big-endian, the identity as 0x40 | zeros.
+// What gnark hashes into the BSB22 challenge (constraint.SerializeCommitment).  Host arithmetic only.
+int32_t zkpor_g1_marshal(const uint8_t affine[64], uint8_t out[64]) {
+    if (!affine || !out) return ZKPOR_E_ARG;
+    Fp xy[2];
+    memcpy(xy, affine, 64);
+    g1_raw(xy, out);
+    return ZKPOR_OK;
+}
 int32_t zkpor_proof_write_raw(const uint8_t proof[256], const uint8_t* commitments, uint32_t n_commitments,
                               const uint8_t pok[64], uint8_t* out, size_t out_cap, size_t* out_len) {
     if (!proof || !out || !out_len || (n_commitments && (!commitments || !pok))) return ZKPOR_E_ARG;

@@ -164,7 +164,7 @@ inline std::vector<std::string> FrHash(const std::string& msg, const std::string
 inline const char* CommitmentDst() { return "bsb22-commitment"; }  // gnark constraint.CommitmentDst
 
 // constraint.SerializeCommitment(privateCommitment, publicCommitted, 32) then HashToFieldFn.Write/Sum: the challenge as 32 B big-endian.
-// commitment_raw = proof.Commitments[i].Marshal() = X || Y big-endian (what zkpor_commit returns); public_committed = the public
+// commitment_raw = proof.Commitments[i].Marshal() = X || Y big-endian canonical (zkpor_g1_marshal of what zkpor_commit returns); public_committed = the public
 // wires among the committed ones ("hashed"), canonical, 32 B big-endian each (none in BatchCreateUserCircuit: its single public
 // input is not range-checked).
 inline std::string Bsb22Challenge(const uint8_t commitment_raw[64], const std::vector<std::string>& public_committed_be32 = {},

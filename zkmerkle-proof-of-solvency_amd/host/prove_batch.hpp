@@ -54,7 +54,11 @@ inline int GenerateAndVerifyProof(zkpor_ctx* ctx, zkpor_pk* pk, const std::strin
         int32_t rc = zkpor_commit(ctx, pk, values, n, c, k);
         if (rc == ZKPOR_OK) {
             sol.has_commitment = true; memcpy(sol.commitment, c, 64); memcpy(sol.pok, k, 64);
-            if (challenge) memcpy(challenge, Bsb22Challenge(c).data(), 32);
+            if (challenge) {   // gnark hashes commitment.Marshal(): big-endian canonical bytes, not the limbs
+                uint8_t be[64];
+                zkpor_g1_marshal(c, be);
+                memcpy(challenge, Bsb22Challenge(be).data(), 32);
+            }
         }
         return rc;
     };
