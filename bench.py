@@ -13,7 +13,7 @@ Output: ONE JSON line (rank 0) with value = proofs/s over all ranks, plus
   checked      — every timed proof verified in the exponent from the synthetic key's trapdoor (untimed)
   value_uniform — the same step with uniform witness scalars (the worst case), timed in a second region
   boundary     — the host-pointer ABI a cgo caller binds, from pageable host memory (untimed leg, N = 1)
-  r1cs_resident — the same with the constraint matrices resident in HBM: only w crosses PCIe (zkpor_prove_r1cs; untimed leg, N = 1)
+  r1cs_resident — the same with the constraint matrices resident in HBM: only w crosses PCIe (zkpor_prove_r1cs; opt-in: --r1cs-terms 20)
 """
 import argparse
 import ctypes
@@ -501,8 +501,9 @@ def main():
                     help="steps of the second, uniform-scalar timed region reported as value_uniform (-1 = max(2, steps/4); 0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the trapdoor verification of the timed proofs")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-pointer (cgo-shaped) boundary leg")
-    ap.add_argument("--r1cs-terms", type=int, default=20, help="untimed leg: the host-pointer form with resident constraint matrices "
-                    "(zkpor_prove_r1cs) on synthetic matrices of this many terms per constraint (0 = off; 20 mirrors the 12 GB .r1cs)")
+    ap.add_argument("--r1cs-terms", type=int, default=0, help="opt-in untimed leg: the host-pointer form with resident constraint matrices "
+                    "(zkpor_prove_r1cs) on synthetic matrices of this many terms per constraint (0 = off; 20 mirrors the 12 GB .r1cs; "
+                    "measured: profiles/r02_bench_with_r1cs_resident.json)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the informational region with two proofs in flight per GPU")
     ap.add_argument("--copy-chunk-mb", type=int, default=0, help="size of the pinned bounce buffers of the boundary leg (0 = library default, 32)")
     ap.add_argument("--copy-threads", type=int, default=0, help="host threads per context that fill the pinned bounce buffers in the "
