@@ -230,10 +230,54 @@ def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vector
         two_ms = (time.perf_counter() - t0) / n2 * 1e3
         if errs:
             raise errs[0]
+        # the same two callers with the host ranges page-locked (zkpor_host_register): host_upload then queues direct DMA instead of
+        # bouncing through pinned buffers — what a caller that owns its allocations (C memory, or slices it keeps across proofs) gets
+        reg_ms = None
+        reg_note = None
+        regd = []
+        try:
+            t_reg = time.perf_counter()
+            for v in (hw, ha, hb, hc, hcv):
+                ctx._ck(lib.zkpor_host_register(ctx.h, _z._p(v), ctypes.c_size_t(v.nbytes)))
+                regd.append(v)
+            reg_s = time.perf_counter() - t_reg
+            nxt[0] = 0
+            base = [9300]
+
+            def loop_reg(wctx):
+                torch.cuda.set_device(device)
+                try:
+                    while True:
+                        with lock:
+                            if nxt[0] >= n2:
+                                return
+                            i = nxt[0]; nxt[0] += 1
+                        prove(wctx, base[0] + i)
+                except Exception as e:
+                    errs.append(e)
+
+            th = [threading.Thread(target=loop_reg, args=(c_,)) for c_ in ctxs]
+            t0 = time.perf_counter()
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            reg_ms = (time.perf_counter() - t0) / n2 * 1e3
+            if errs:
+                raise errs[0]
+        except Exception as e:   # informational: never lose the pageable figures over it
+            reg_ms = None
+            errs.clear()
+            reg_note = f"registered-memory variant failed: {e}"
+        finally:
+            for v in regd:
+                lib.zkpor_host_unregister(ctx.h, _z._p(v))
     finally:
         other.close()
     ok = sum(int(td.check(p, *blinding(i))) for i, p in results) if td is not None else None
-    return {"value": 1e3 / two_ms, "unit": "proofs/s", "ms_per_proof": two_ms, "frac_of_resident_value": resident_ms / two_ms,
+    extra = ({"registered_note": reg_note} if reg_note else {}) if reg_ms is None else {"registered_ms_per_proof": reg_ms, "registered_frac_of_resident_value": resident_ms / reg_ms,
+                                       "register_seconds_once": round(reg_s, 2)}
+    return {**extra, "value": 1e3 / two_ms, "unit": "proofs/s", "ms_per_proof": two_ms, "frac_of_resident_value": resident_ms / two_ms,
             "callers": 2, "one_caller_ms_per_proof": one_ms, "one_caller_value": 1e3 / one_ms,
             "bytes_per_proof": int(bytes_per_proof), "proofs": len(results), "checked_ok": ok, "copy_threads_per_context": copy_threads or 4,
             "note": "zkpor_commit + zkpor_prove_tail (host-pointer ABI) on pageable numpy memory; persistent HBM staging, pinned bounce "
