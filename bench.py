@@ -162,7 +162,7 @@ def timed_region(dist, sync, run):
     return dt
 
 
-def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vectors, td, blinding, resident_ms, n_proofs=3, copy_threads=0, copy_chunk_mb=0):
+def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vectors, td, blinding, resident_ms, n_proofs=3, copy_threads=-1, copy_chunk_mb=0, host_order=0, gpu_token=1):
     """The call a cgo caller actually makes (INTEGRATION.md `ProveTail` / `Commit`): the HOST-pointer entry points
     zkpor_commit + zkpor_prove_tail on PAGEABLE host memory (numpy heap arrays standing in for gnark's []fr.Element), 8.6 GB + 0.5 GB
     per proof across PCIe inside the call.  Two shapes: one caller (a proof's latency from host memory: w crosses first, a/b/c cross
@@ -194,10 +194,13 @@ def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vector
     try:
         ctxs = [ctx, other]
         for c_ in ctxs:
-            if copy_threads:
+            if copy_threads >= 0:
                 c_.set_param("copy_threads", copy_threads)
             if copy_chunk_mb:
                 c_.set_param("copy_chunk_mb", copy_chunk_mb)
+            if host_order:
+                c_.set_param("host_order", host_order)
+            c_.set_param("gpu_token", 1 if gpu_token else 0)
         for k, wctx in enumerate(ctxs):       # warm-up: staging areas, bounce buffers, copy threads, workspaces
             prove(wctx, 9000 + k)
         t0 = time.perf_counter()
@@ -279,9 +282,12 @@ def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vector
                                        "register_seconds_once": round(reg_s, 2)}
     return {**extra, "value": 1e3 / two_ms, "unit": "proofs/s", "ms_per_proof": two_ms, "frac_of_resident_value": resident_ms / two_ms,
             "callers": 2, "one_caller_ms_per_proof": one_ms, "one_caller_value": 1e3 / one_ms,
-            "bytes_per_proof": int(bytes_per_proof), "proofs": len(results), "checked_ok": ok, "copy_threads_per_context": copy_threads or 4,
-            "note": "zkpor_commit + zkpor_prove_tail (host-pointer ABI) on pageable numpy memory; persistent HBM staging, pinned bounce "
-                    "buffers filled by copy threads, w first then a/b/c under the A/B1/K accumulations; two callers = two contexts on one GPU"}
+            "bytes_per_proof": int(bytes_per_proof), "proofs": len(results), "checked_ok": ok, "copy_threads_per_context": copy_threads if copy_threads >= 0 else "library default",
+            "gpu_token": int(bool(gpu_token)),
+            "note": "zkpor_commit + zkpor_prove_tail (host-pointer ABI) on pageable numpy memory; persistent HBM staging; the pageable ranges "
+                    "are page-locked on the fly by the HIP runtime (copy_threads 0) or bounced through pinned buffers (copy_threads n); two "
+                    "callers = two contexts on one GPU taking turns on the device (gpu_token 1): the waiting caller's vectors cross PCIe "
+                    "under the running proof; registered_* = the same from ranges page-locked once with zkpor_host_register"}
 
 
 def r1cs_leg(torch, zkpor, ctx, device, pk, D, log2, n_wires, n_commit, w_dev, cv_dev, seed, blinding, resident_ms, terms, n_proofs=3):
@@ -549,9 +555,15 @@ def main():
                     "(zkpor_prove_r1cs) on synthetic matrices of this many terms per constraint (0 = off; 20 mirrors the 12 GB .r1cs; "
                     "measured: profiles/r02_bench_with_r1cs_resident.json)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the informational region with two proofs in flight per GPU")
+    ap.add_argument("--boundary-sweep", type=int, default=0, help="experiment: repeat the boundary leg with this many proofs per caller shape for "
+                    "copy_threads in {4, 0} x gpu_token in {1, 0} (boundary_sweep in the line)")
+    ap.add_argument("--no-gpu-token", action="store_true", help="boundary leg: let the two callers' kernels share the GPU freely instead of "
+                    "taking turns on it (context parameter gpu_token 0; the behaviour before the turns existed)")
+    ap.add_argument("--host-order", type=int, default=0, help="boundary leg: 0 = w first and a/b/c under the witness sums (library default), "
+                    "1 = all four vectors first, then the resident order")
     ap.add_argument("--copy-chunk-mb", type=int, default=0, help="size of the pinned bounce buffers of the boundary leg (0 = library default, 32)")
-    ap.add_argument("--copy-threads", type=int, default=0, help="host threads per context that fill the pinned bounce buffers in the "
-                    "boundary leg (0 = library default, 4)")
+    ap.add_argument("--copy-threads", type=int, default=-1, help="host threads per context that fill the pinned bounce buffers in the "
+                    "boundary leg (-1 = library default; 0 = no bounce: the HIP runtime page-locks the caller's range on the fly)")
     ap.add_argument("--tables", type=int, default=4, help="fixed-base tables per key point (msm_tables; 1 = plain arrays): the default "
                     "4 holds the key as 4 interleaved tables (112 GB of the 288 GB at 2^26) and buys 12 digits of 22 bits instead of "
                     "13 of 20 at the same number of buckets — 6 %% fewer bucket additions (profiles/r02_tables.txt)")
@@ -877,9 +889,23 @@ def main():
             if not args.no_boundary:
                 try:
                     out["boundary"] = boundary_leg(torch, zkpor, ctx, local_rank, pk, D, n_wires, n_commit, (w, a0, b0, c0, cv), td, blinding,
-                                                   resident_ms=dt / args.steps * 1e3, copy_threads=args.copy_threads, copy_chunk_mb=args.copy_chunk_mb)
+                                                   resident_ms=dt / args.steps * 1e3, copy_threads=args.copy_threads, copy_chunk_mb=args.copy_chunk_mb, host_order=args.host_order, gpu_token=0 if args.no_gpu_token else 1)
                 except Exception as e:
                     out["boundary"] = {"value": None, "note": f"failed: {e}"}
+            if args.boundary_sweep and "value" in out.get("boundary", {}):
+                sweep = []
+                for ct, tok in ((4, 1), (4, 0), (0, 1), (0, 0)):
+                    try:
+                        b_ = boundary_leg(torch, zkpor, ctx, local_rank, pk, D, n_wires, n_commit, (w, a0, b0, c0, cv), td, blinding,
+                                          resident_ms=dt / args.steps * 1e3, n_proofs=args.boundary_sweep, copy_threads=ct, gpu_token=tok)
+                        sweep.append({"copy_threads": ct, "gpu_token": tok, "pageable_ms": round(b_["ms_per_proof"], 1),
+                                      "registered_ms": round(b_.get("registered_ms_per_proof", 0.0), 1), "one_caller_ms": round(b_["one_caller_ms_per_proof"], 1),
+                                      "proofs": b_["proofs"], "checked_ok": b_["checked_ok"]})
+                    except Exception as e:
+                        sweep.append({"copy_threads": ct, "gpu_token": tok, "note": f"failed: {e}"})
+                out["boundary_sweep"] = sweep
+                ctx.set_param("copy_threads", 0 if args.copy_threads < 0 else args.copy_threads)
+                ctx.set_param("gpu_token", 0 if args.no_gpu_token else 1)
             if args.r1cs_terms > 0:
                 try:
                     out["r1cs_resident"] = r1cs_leg(torch, zkpor, ctx, local_rank, pk, D, log2, n_wires, n_commit, w, cv, seed, blinding,

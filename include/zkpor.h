@@ -74,7 +74,12 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * 2^26, m = 4 costs 112 GB of HBM instead of 28 and buys 12 digits of 22 bits instead of 13 of 20 at the same number of buckets
  * (6 % fewer bucket additions; built on the device at load time, ~14 s).  Such a key cannot be cut into shards, and "msm_window" must
  * not change between the load and the proofs,
- * "copy_threads" (host threads that fill the pinned bounce buffers of the host-pointer entry points, default 4),
+ * "copy_threads" (how pageable host memory crosses PCIe in the host-pointer entry points: 0, the default, hands the range to the HIP
+ * runtime, which page-locks it on the fly and lets the DMA engine read the caller's pages — 56 GB/s measured; n > 0 copies through
+ * pinned bounce buffers with n host threads — 30 GB/s, for hosts where page-locking on the fly is not available),
+ * "gpu_token" (1, the default: host-pointer proofs of several contexts on one GPU take turns on the device, see zkpor_prove_tail;
+ * 0: their kernels share it freely), "host_order" (0, the default: a proof that finds the GPU free sends w first and a, b, c
+ * underneath its own witness sums; 1: always everything first),
  * "poseidon_out_idx", "poseidon_carry_idx" (hash-wrapper convention) */
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);
 /* per-phase GPU time in ms accumulated since the last reset (HIP events on the context's stream).
@@ -185,11 +190,15 @@ int32_t zkpor_fft_dev(zkpor_ctx* ctx, void* d_a, int log2n, int inverse, int dec
  * r and s itself from the operating system (getrandom) for callers without a CSPRNG at hand.
  *
  * HOST-POINTER FORM (what a cgo shim binds): w, a, b, c may be ordinary pageable memory (a Go slice).  The context keeps a
- * persistent staging area in HBM (no allocation per proof) and moves the vectors across PCIe itself — through pinned bounce
- * buffers filled by "copy_threads" host threads, or by direct DMA if the range was page-locked with zkpor_host_register —
- * w first, then a, b, c underneath the A, B1 and K accumulations.  Nothing of the caller's memory is read after the call
- * returns.  To hide the transfer completely keep two proofs in flight per GPU (two contexts, one caller each): one proof's
- * copies then run under the other's kernels (bench.py `boundary`; host/prover_host.hpp does this). */
+ * persistent staging area in HBM (no allocation per proof) and moves the vectors across PCIe itself ("copy_threads" above; direct
+ * DMA if the range was page-locked with zkpor_host_register).  Nothing of the caller's memory is read after the call returns.
+ * To hide the transfer keep two proofs in flight per GPU (two contexts, one caller each; host/prover_host.hpp does this).  The
+ * callers of one GPU then TAKE TURNS on the device ("gpu_token"): a call that finds the GPU free sends w first and a, b, c
+ * underneath its own A, B1, K sums (the shortest single proof); a call that finds another proof running moves all four vectors
+ * across underneath that proof's kernels, waits for it to finish, and runs with everything resident.  Without the turns two
+ * callers drift into lockstep — kernels sharing the GPU, finishing together, then both copying with the GPU idle.  Measured
+ * (bench.py `boundary`): 97 % of the resident rate from pageable memory with two callers.  The turn is process-wide state (one
+ * flag per GPU); zkpor_commit takes none. */
 int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                          const uint64_t* c, size_t n_constraints, const uint64_t r[4], const uint64_t s[4],
                          uint8_t proof_out[256]);

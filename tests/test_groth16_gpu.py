@@ -200,6 +200,14 @@ def test_prove_tail_host_pointer_form_equals_resident_form(zk, log2, ncons_short
         finally:
             for v in (w, a, b, c):
                 zk._ck(zk.lib.zkpor_host_unregister(zk.h, zkpor._p(v)))
+        # the other order of the same work (everything crosses first, then the resident order): same proof
+        zk.set_param("host_order", 1)
+        try:
+            assert np.array_equal(zk.prove_tail(pk, w, a, b, c, r, s), got)
+        finally:
+            zk.set_param("host_order", 0)
+        with pytest.raises(zkpor.ZkporError):
+            zk.set_param("host_order", 2)
         # the library draws its own blinding: two calls give two different proofs, each correct for the (r, s) it reports
         out = np.empty(256, np.uint8); ro = np.empty(4, np.uint64); so = np.empty(4, np.uint64)
         seen = []
@@ -274,16 +282,63 @@ def test_commitment_extended_groth16_verifies(zk):
     assert np.array_equal(O.g1_add(krs_excl[None, :], share[None, :])[0], krs_full)
 
 
+@pytest.mark.parametrize("gpu_token,copy_threads", [(1, 0), (1, 3), (0, 0)])
+def test_two_callers_take_turns_on_the_device(zk, gpu_token, copy_threads):
+    """two contexts of one GPU, one caller thread each, proving from host memory at the same time (what host/prover_host.hpp runs per
+    GPU): with gpu_token 1 a caller that finds the other's proof running sends all four vectors first and waits for its turn (the
+    resident order), otherwise it overlaps its own copies — every proof equals the one-caller proof for its blinding, in every mode"""
+    import threading
+    log2 = 17
+    n = 1 << log2
+    pk = zkpor.ProvingKey(zk)
+    other = zkpor.Context(0)
+    try:
+        pk.synth(log2, n, 3, 0, 0x7A11)
+        rng = np.random.default_rng(3)
+        def fr(m):
+            x = rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64)
+            x[:, 3] &= np.uint64((1 << 60) - 1)
+            return x
+        w, a, b, c = fr(n), fr(n - 5), fr(n - 5), fr(n - 5)
+        blind = [(O.fr_random(100 + i, 1)[0], O.fr_random(200 + i, 1)[0]) for i in range(12)]
+        zk.set_param("gpu_token", 1); zk.set_param("copy_threads", 0)
+        want = [zk.prove_tail(pk, w, a, b, c, r, s) for r, s in blind]
+        got = [None] * len(blind)
+        errs = []
+        ctxs = [zk, other]
+        for c_ in ctxs:
+            c_.set_param("gpu_token", gpu_token); c_.set_param("copy_threads", copy_threads)
+
+        def run(k):
+            try:
+                for i in range(k, len(blind), 2):
+                    got[i] = ctxs[k].prove_tail(pk, w, a, b, c, *blind[i])
+            except Exception as e:
+                errs.append(e)
+
+        th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for g, x in zip(got, want):
+            assert np.array_equal(g, x)
+    finally:
+        zk.set_param("gpu_token", 1); zk.set_param("copy_threads", 0)
+        other.close(); pk.close()
+
+
 def test_host_pointer_staging_survives_regrowth_and_copy_thread_changes():
     """one context, keys of different sizes one after the other (the staging area regrows, then is reused for a smaller key), the
-    bounce-buffer copier rebuilt with 1 and 7 threads in between, a commitment placed behind the prove tail's vectors — every proof
+    bounce-buffer copier rebuilt with 1, 7 and 0 (runtime path) threads in between, a commitment placed behind the prove tail's vectors — every proof
     equals the resident form's; an invalid thread count is refused"""
     import ctypes
     ctx = zkpor.Context(0)
     try:
         with pytest.raises(zkpor.ZkporError):
-            ctx.set_param("copy_threads", 0)
-        for log2, threads in ((12, 1), (16, 7), (13, 4)):
+            ctx.set_param("copy_threads", 65)
+        for log2, threads in ((12, 1), (16, 7), (14, 0), (13, 4)):   # 0 = no bounce buffers: the runtime moves the pageable range
             ctx.set_param("copy_threads", threads)
             n = 1 << log2
             nc = 300

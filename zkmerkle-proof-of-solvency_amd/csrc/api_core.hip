@@ -110,6 +110,38 @@ void bounce_free(zkpor_ctx* ctx) {
     ctx->bounce = nullptr;
 }
 
+// ---- turns on the device (common.cuh GpuTurn): one flag per GPU, shared by every context of the process ----
+namespace {
+struct TurnState { std::mutex mu; std::condition_variable cv; bool busy = false; };
+TurnState& turn_state(int dev) {
+    static TurnState st[64];
+    return st[dev < 0 ? 0 : dev % 64];
+}
+}  // namespace
+bool GpuTurn::try_acquire(zkpor_ctx* ctx) {
+    if (held) return false;
+    if (!ctx->gpu_token) { return true; }   // arbitration off: everybody always has the turn
+    TurnState& t = turn_state(ctx->device);
+    std::lock_guard<std::mutex> lk(t.mu);
+    if (t.busy) return false;
+    t.busy = true; held = true; dev = ctx->device;
+    return true;
+}
+void GpuTurn::acquire(zkpor_ctx* ctx) {
+    if (held || !ctx->gpu_token) return;
+    TurnState& t = turn_state(ctx->device);
+    std::unique_lock<std::mutex> lk(t.mu);
+    t.cv.wait(lk, [&] { return !t.busy; });
+    t.busy = true; held = true; dev = ctx->device;
+}
+void GpuTurn::release() {
+    if (!held) return;
+    TurnState& t = turn_state(dev);
+    { std::lock_guard<std::mutex> lk(t.mu); t.busy = false; }
+    t.cv.notify_one();
+    held = false;
+}
+
 int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     if (!bytes) return ZKPOR_OK;
     if (!ctx->copy_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -119,6 +151,12 @@ int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes
         return ZKPOR_OK;
     }
     (void)hipGetLastError();  // an unregistered pointer is the expected case, not an error
+    if (ctx->copy_threads == 0) {
+        // "copy_threads" 0: hand the pageable range to the HIP runtime, which page-locks it on the fly and lets the DMA engine read the
+        // caller's pages directly (no CPU copy at all; the call may block until the range has been read)
+        ZK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        return ZKPOR_OK;
+    }
     Bounce* b = (Bounce*)ctx->bounce;
     if (!b) {
         b = new (std::nothrow) Bounce();
@@ -297,8 +335,10 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     else if (n == "msm_g2_variant") ctx->g2_variant = (int)value;
     else if (n == "ntt_variant") ctx->ntt_variant = (int)value;
     else if (n == "ntt_tile_log") { if (value < 9 || value > 12) { ctx->err = "ntt_tile_log must be in [9,12]"; return ZKPOR_E_ARG; } ctx->ntt_tile_log = (int)value; }
+    else if (n == "gpu_token") { if (value < 0 || value > 1) { ctx->err = "gpu_token must be 0 or 1"; return ZKPOR_E_ARG; } ctx->gpu_token = (int)value; }
+    else if (n == "host_order") { if (value < 0 || value > 1) { ctx->err = "host_order must be 0 or 1"; return ZKPOR_E_ARG; } ctx->host_order = (int)value; }
     else if (n == "copy_chunk_mb") { if (value < 1 || value > 1024) { ctx->err = "copy_chunk_mb must be in [1,1024]"; return ZKPOR_E_ARG; } if (ctx->bounce) bounce_free(ctx); ctx->copy_chunk_mb = (int)value; }
-    else if (n == "copy_threads") { if (value < 1 || value > 64) { ctx->err = "copy_threads must be in [1,64]"; return ZKPOR_E_ARG; } if (ctx->bounce) bounce_free(ctx); ctx->copy_threads = (int)value; }
+    else if (n == "copy_threads") { if (value < 0 || value > 64) { ctx->err = "copy_threads must be in [0,64]"; return ZKPOR_E_ARG; } if (ctx->bounce) bounce_free(ctx); ctx->copy_threads = (int)value; }
     else if (n == "poseidon_out_idx") ctx->pos_out = (int)value;
     else if (n == "poseidon_carry_idx") ctx->pos_carry = (int)value;
     else { ctx->err = "unknown parameter " + n; return ZKPOR_E_ARG; }

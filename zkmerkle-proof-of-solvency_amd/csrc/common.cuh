@@ -52,8 +52,10 @@ struct zkpor_ctx {
     size_t stage_cap = 0;
     hipStream_t copy_stream = nullptr;
     void* bounce = nullptr;          // zk::Bounce*
-    int copy_threads = 4;
+    int copy_threads = 0;            // 0 = the HIP runtime moves pageable ranges (page-locks them on the fly: 56 GB/s measured); n > 0 = n host threads fill pinned bounce buffers (30 GB/s)
     int copy_chunk_mb = 32;          // size of one of the four pinned bounce buffers
+    int host_order = 0;              // zkpor_prove_tail from host memory: 0 = w first, a/b/c under the witness sums; 1 = everything first, then the resident order
+    int gpu_token = 1;               // host-pointer calls of several contexts on one GPU take turns on the device (api_core.hip GpuTurn)
 };
 
 #define ZK_HIP(ctx, call)                                                                             \
@@ -168,6 +170,21 @@ int32_t stage_reserve(zkpor_ctx* ctx, size_t bytes);
 // range is no longer needed afterwards unless it was page-locked (then: until the copy stream has drained).
 int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 void bounce_free(zkpor_ctx* ctx);
+// One caller at a time runs the GPU part of a host-pointer call on a device (the others keep moving their vectors across PCIe
+// meanwhile).  Without it two callers drift into lockstep: their kernels share the GPU, finish together, and then both copy at
+// the same time with the GPU idle (measured: profiles/r02_boundary_turns.txt).  A turn is held from "my vectors are across" to
+// "my last kernel is done"; RAII, released on every path.
+struct GpuTurn {
+    int dev = -1;
+    bool held = false;
+    GpuTurn() = default;
+    ~GpuTurn() { release(); }
+    GpuTurn(const GpuTurn&) = delete;
+    GpuTurn& operator=(const GpuTurn&) = delete;
+    bool try_acquire(zkpor_ctx* ctx);   // false = somebody else is on the device (or already held)
+    void acquire(zkpor_ctx* ctx);       // waits for the turn; no-op when the context's "gpu_token" parameter is 0
+    void release();
+};
 // r1cs.hip: a, b, c = L.w, R.w, O.w queued on `ctx`'s stream (any context of the GPU the matrices live on: they are only read)
 int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size);
 void r1cs_dims(const zkpor_r1cs* r, size_t* n_constraints, size_t* n_wires, int* device);

@@ -467,7 +467,8 @@ struct HostInputs { const void *w, *a, *b, *c; size_t n_constraints; };
 // w crosses PCIe first, its digit stream is built, A, B1 and K start — and a, b, c (3/4 of the bytes) cross on the copy stream
 // while those three accumulations run; then computeH, B2 (sort of h hidden under it) and Z.
 int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c, ProveSums* out, bool do_w = true,
-                   bool do_h = true, const std::function<void()>* while_gpu_runs = nullptr, const HostInputs* host = nullptr) {
+                   bool do_h = true, const std::function<void()>* while_gpu_runs = nullptr, const HostInputs* host = nullptr,
+                   GpuTurn* turn = nullptr) {
     const int n = pk->log2_domain;
     const size_t nZ = do_h ? pk->nZ : 0;
     // Two HIP streams: the ALU-bound work (NTTs, bucket accumulations) on the context's stream, the HBM-bound digit
@@ -555,6 +556,7 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     }
     if (while_gpu_runs) (*while_gpu_runs)();  // host work that needs no device result: everything is queued, nothing is waited for yet
     ZK_HIP(ctx, hipStreamSynchronize(main_s));
+    if (turn) turn->release();   // the device is free for the next caller while this one finishes on the host
     HostPhase hp(ctx, "host_assembly");
     if (do_w) {
         msm_accumulate_finish<Fp>(pA, &out->A);
@@ -741,7 +743,30 @@ int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const 
     ProveSums m;
     Blind bl;
     const std::function<void()> prep = [&] { bl = blind_prepare(pk->delta, pk->delta2, r, s); };
-    int32_t rc = prove_sums(ctx, pk, d + 3 * D, d, d + D, d + 2 * D, &m, true, true, &prep, &host);
+    int32_t rc = ZKPOR_OK;
+    GpuTurn turn;
+    if (ctx->host_order == 0 && turn.try_acquire(ctx)) {
+        // nobody else is on the device: w first, a, b, c underneath the witness sums (the shortest single proof)
+        rc = prove_sums(ctx, pk, d + 3 * D, d, d + D, d + 2 * D, &m, true, true, &prep, &host, &turn);
+    } else {
+        // another caller's proof is running (or "host_order" 1): everything crosses PCIe underneath it, then this proof takes its
+        // turn with all inputs resident, in the resident order (computeH first, the digit stream of w hidden under it)
+        const void* src[4] = {w, a, b, c};
+        Fr* dst[4] = {d + 3 * D, d, d + D, d + 2 * D};
+        for (int i = 0; i < 4 && rc == ZKPOR_OK; ++i) {
+            const size_t n = i ? n_constraints : pk->n_wires;
+            if (i && n < D && hipMemsetAsync(dst[i] + n, 0, (D - n) * sizeof(Fr), ctx->copy_stream) != hipSuccess) { ctx->err = "prove: memset failed"; rc = ZKPOR_E_HIP; break; }
+            rc = host_upload(ctx, dst[i], src[i], n * sizeof(Fr));
+        }
+        hipEvent_t e_up = ev_get(ctx);
+        if (rc == ZKPOR_OK && hipEventRecord(e_up, ctx->copy_stream) != hipSuccess) { ctx->err = "prove: event on the copy stream failed"; rc = ZKPOR_E_HIP; }
+        if (rc == ZKPOR_OK) {
+            turn.acquire(ctx);
+            if (hipStreamWaitEvent(ctx->stream, e_up, 0) != hipSuccess) { ctx->err = "prove: event on the copy stream failed"; rc = ZKPOR_E_HIP; }
+        }
+        ctx->event_pool.push_back(e_up);
+        if (rc == ZKPOR_OK) rc = prove_sums(ctx, pk, d + 3 * D, d, d + D, d + 2 * D, &m, true, true, &prep, nullptr, &turn);
+    }
     if (rc != ZKPOR_OK) {  // nothing may still read the caller's memory or the staging area when the call returns
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamSynchronize(ctx->stream);
@@ -779,17 +804,20 @@ int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const u
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     };
+    GpuTurn turn;
     int32_t rc = host_upload(ctx, d_w, w, pk->n_wires * sizeof(Fr));
     hipEvent_t e_up = ev_get(ctx);
-    if (rc == ZKPOR_OK && (hipEventRecord(e_up, ctx->copy_stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, e_up, 0) != hipSuccess)) {
-        ctx->err = "prove: event on the copy stream failed"; rc = ZKPOR_E_HIP;
+    if (rc == ZKPOR_OK && hipEventRecord(e_up, ctx->copy_stream) != hipSuccess) { ctx->err = "prove: event on the copy stream failed"; rc = ZKPOR_E_HIP; }
+    if (rc == ZKPOR_OK) {
+        turn.acquire(ctx);   // w crossed underneath whoever was on the device
+        if (hipStreamWaitEvent(ctx->stream, e_up, 0) != hipSuccess) { ctx->err = "prove: event on the copy stream failed"; rc = ZKPOR_E_HIP; }
     }
     ctx->event_pool.push_back(e_up);
     if (rc == ZKPOR_OK) rc = r1cs_eval_on(ctx, r1cs, d_w, d, d + D, d + 2 * D, D);
     ProveSums m;
     Blind bl;
     const std::function<void()> prep = [&] { bl = blind_prepare(pk->delta, pk->delta2, r, s); };
-    if (rc == ZKPOR_OK) rc = prove_sums(ctx, pk, d_w, d, d + D, d + 2 * D, &m, true, true, &prep);
+    if (rc == ZKPOR_OK) rc = prove_sums(ctx, pk, d_w, d, d + D, d + 2 * D, &m, true, true, &prep, nullptr, &turn);
     if (rc != ZKPOR_OK) { drain(); return rc; }
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
@@ -869,6 +897,8 @@ int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_
         ZK_TRY(host_upload(ctx, d, values, n * sizeof(Fr)));
         ZK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     }
+    // no turn on the device for these two short sums (common.cuh GpuTurn): they run next to whatever proof is on the GPU — waiting
+    // for it would keep this caller from moving its proof's vectors across PCIe in the meantime
     return zkpor_commit_dev(ctx, pk, d, n, out_commit, out_pok);
 }
 
