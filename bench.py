@@ -162,7 +162,7 @@ def timed_region(dist, sync, run):
     return dt
 
 
-def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vectors, td, blinding, resident_ms, n_proofs=3, copy_threads=-1, copy_chunk_mb=0, host_order=0, gpu_token=1):
+def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vectors, td, blinding, resident_ms, n_proofs=6, copy_threads=-1, copy_chunk_mb=0, host_order=0, gpu_token=1):
     """The call a cgo caller actually makes (INTEGRATION.md `ProveTail` / `Commit`): the HOST-pointer entry points
     zkpor_commit + zkpor_prove_tail on PAGEABLE host memory (numpy heap arrays standing in for gnark's []fr.Element), 8.6 GB + 0.5 GB
     per proof across PCIe inside the call.  Two shapes: one caller (a proof's latency from host memory: w crosses first, a/b/c cross
