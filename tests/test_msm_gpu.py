@@ -49,6 +49,26 @@ def test_g1_msm_windows_chunks(zk, window, chunk):
         zk.set_param("msm_chunk", 32)
 
 
+@pytest.mark.parametrize("window", [4, 9, 14, 0])
+def test_g1_msm_reduction_tail_both_forms(zk, window):
+    """the small levels of the bucket reduction as one lane per bucket (suffix scan + tree sums, the default) and as the serial walk
+    (msm_reduce_scan 0): same sums; points repeated so that equal operands (the doubling branch) meet inside the scan"""
+    n = 3000
+    base = O.g1_from_scalars(O.fr_random(61, 40))
+    pts = np.ascontiguousarray(base[np.arange(n) % 40])
+    sc = O.fr_random(62, n)
+    sc[::7] = sc[3]                      # equal scalars on equal points: equal bucket contents in neighbouring lanes
+    want = O.g1_msm(pts, sc)
+    zk.set_param("msm_window", window)
+    try:
+        for form in (1, 0):
+            zk.set_param("msm_reduce_scan", form)
+            assert _g1_eq(zk.msm_g1(pts, sc), want)
+    finally:
+        zk.set_param("msm_reduce_scan", 1)
+        zk.set_param("msm_window", 0)
+
+
 def test_g1_msm_edge_scalars(zk):
     n = 600
     pts = O.g1_from_scalars(O.fr_random(7, n))

@@ -110,8 +110,68 @@ int32_t launch_levelN29<Fp>(zkpor_ctx* ctx, const u32* keys, const u32* src, u32
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
+// The same level for SMALL inputs (the last three or four levels of every reduction: a few thousand buckets down to one per
+// window), one LANE per bucket instead of one thread per group.  k_reduce_level29 walks a group's g buckets with a serial chain
+// of 3 g additions — with fewer groups than the GPU has SIMDs that chain IS the kernel's duration (0.3 ms per level whatever its
+// size).  Here the g lanes of a group compute the same three sums as a suffix scan and two tree sums: 3 log2(g) additions deep.
+//     run  = sum_k S_k                 = T_0,  T_k = sum_{k' >= k} S_k'   (inclusive suffix scan)
+//     wacc = sum_k (k + 1) S_k         = sum_k T_k                          (tree sum of the scan)
+//     ysum = sum_k Y_k                                                       (tree sum)
+// One loop, one copy of the addition code (the step is wave-uniform); the operand of the other lane comes through 36 lane shuffles.
+ZK_D XYZZ29 shfl_down29(const XYZZ29& a, u32 d) {
+    XYZZ29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.x.l[i] = (u32)__shfl_down((int)a.x.l[i], d, 64); r.y.l[i] = (u32)__shfl_down((int)a.y.l[i], d, 64);
+        r.zz.l[i] = (u32)__shfl_down((int)a.zz.l[i], d, 64); r.zzz.l[i] = (u32)__shfl_down((int)a.zzz.l[i], d, 64);
+    }
+    return r;
+}
+template <bool HAS_Y>
+__global__ __launch_bounds__(256) void k_reduce_scan29_g1(const u32* __restrict__ Sin, const u32* __restrict__ Yin, u32 n_groups, int gl,
+                                                           int dbl, u32* __restrict__ Sout, u32* __restrict__ Yout) {
+    const u32 g = 1u << gl;                          // <= 16: a group never straddles a wave
+    const u32 gt = blockIdx.x * 256u + threadIdx.x;  // = j * g + k: the element's index
+    const u32 j = gt >> gl, k = gt & (g - 1u);
+    const bool live = j < n_groups;
+    XYZZ29 T = live ? raw29_load(Sin + (size_t)gt * RAW29_WORDS) : XYZZ29::inf();
+    XYZZ29 W = XYZZ29::inf(), Y = XYZZ29::inf();
+    if (HAS_Y && live) Y = raw29_load(Yin + (size_t)gt * RAW29_WORDS);
+    const int phases = HAS_Y ? 3 : 2;
+#pragma unroll 1
+    for (int it = 0; it < phases * gl; ++it) {
+        const int phase = it / gl, st = it - phase * gl;
+        const u32 d = 1u << st;
+        if (phase == 1 && st == 0) W = T;            // the scan is complete: T_k on every lane
+        XYZZ29 a = phase == 0 ? T : (phase == 1 ? W : Y);
+        const XYZZ29 b = shfl_down29(a, d);          // every lane takes part in the shuffle
+        const bool doit = phase == 0 ? (k + d < g) : ((k & (2u * d - 1u)) == 0u);
+        if (doit) xyzz29_add<Fp29>(a, b);
+        if (phase == 0) T = a; else if (phase == 1) W = a; else Y = a;
+    }
+    if (!live || k != 0) return;
+    raw29_store(Sout + (size_t)j * RAW29_WORDS, T);
+    if (HAS_Y) {
+        for (int q = 0; q < dbl; ++q) W = xyzz29_dbl<Fp29>(W);
+        xyzz29_add<Fp29>(Y, W);
+        raw29_store(Yout + (size_t)j * RAW29_WORDS, Y);
+    } else {
+        raw29_store(Yout + (size_t)j * RAW29_WORDS, W);
+    }
+}
+
 template <>
 int32_t launch_reduce29<Fp>(zkpor_ctx* ctx, const u32* Sin, const u32* Yin, u32 n_groups, u32 g, int dbl, u32* Sout, u32* Yout) {
+    // few buckets: one lane per bucket (above ~2^15 buckets the serial walk has enough threads to fill the GPU and does less work)
+    if (ctx->msm_reduce_scan && g <= 16u && (g & (g - 1u)) == 0u && g >= 2u && (size_t)n_groups * g <= ((size_t)1 << 15)) {
+        int gl = 0;
+        while ((1u << gl) < g) ++gl;
+        dim3 grid_s((unsigned)(((size_t)n_groups * g + 255u) / 256u));
+        if (Yin) hipLaunchKernelGGL((k_reduce_scan29_g1<true>), grid_s, dim3(256), 0, ctx->stream, Sin, Yin, n_groups, gl, dbl, Sout, Yout);
+        else hipLaunchKernelGGL((k_reduce_scan29_g1<false>), grid_s, dim3(256), 0, ctx->stream, Sin, Yin, n_groups, gl, dbl, Sout, Yout);
+        ZK_KERNEL_CHECK(ctx);
+        return ZKPOR_OK;
+    }
     dim3 grid((n_groups + 127u) / 128u);
     if (Yin) hipLaunchKernelGGL((k_reduce_level29<Pol29G1, true>), grid, dim3(128), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
     else hipLaunchKernelGGL((k_reduce_level29<Pol29G1, false>), grid, dim3(128), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
