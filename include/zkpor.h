@@ -77,6 +77,7 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * "copy_threads" (how pageable host memory crosses PCIe in the host-pointer entry points: 0, the default, hands the range to the HIP
  * runtime, which page-locks it on the fly and lets the DMA engine read the caller's pages — 56 GB/s measured; n > 0 copies through
  * pinned bounce buffers with n host threads — 30 GB/s, for hosts where page-locking on the fly is not available),
+ * "msm_reduce_scan" (1, the default: the small levels of the G1 bucket reduction run one lane per bucket; 0: the serial walk),
  * "gpu_token" (1, the default: host-pointer proofs of several contexts on one GPU take turns on the device, see zkpor_prove_tail;
  * 0: their kernels share it freely), "host_order" (0, the default: a proof that finds the GPU free sends w first and a, b, c
  * underneath its own witness sums; 1: always everything first),
