@@ -555,6 +555,7 @@ def main():
                     "(zkpor_prove_r1cs) on synthetic matrices of this many terms per constraint (0 = off; 20 mirrors the 12 GB .r1cs; "
                     "measured: profiles/r02_bench_with_r1cs_resident.json)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the informational region with two proofs in flight per GPU")
+    ap.add_argument("--aux-priority", action="store_true", help="experiment: the digit-stream HIP stream at the highest stream priority")
     ap.add_argument("--no-reduce-scan", action="store_true", help="experiment: the small bucket-reduction levels as the serial walk (msm_reduce_scan 0)")
     ap.add_argument("--boundary-sweep", type=int, default=0, help="experiment: repeat the boundary leg with this many proofs per caller shape for "
                     "copy_threads in {4, 0} x gpu_token in {1, 0} (boundary_sweep in the line)")
@@ -638,6 +639,8 @@ def main():
         ctx.set_param("msm_g1_variant", args.g1_variant)
     if args.no_reduce_scan:
         ctx.set_param("msm_reduce_scan", 0)
+    if args.aux_priority:
+        ctx.set_param("aux_priority", 1)
     if args.tables > 1 and not args.split:   # a key with tables cannot be cut into the shards of the single-proof split
         ctx.set_param("msm_tables", args.tables)
     lib = ctx.lib

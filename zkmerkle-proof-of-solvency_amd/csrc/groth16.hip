@@ -473,7 +473,15 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     const size_t nZ = do_h ? pk->nZ : 0;
     // Two HIP streams: the ALU-bound work (NTTs, bucket accumulations) on the context's stream, the HBM-bound digit
     // streams (decompose + radix sort) on an auxiliary one.  No host synchronisation on the main stream until all five sums are queued.
-    if (!ctx->aux_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->aux_stream) {
+        // the digit streams feed the accumulations that wait for them: "aux_priority" 1 puts the auxiliary stream on the highest
+        // stream priority so that its HBM-bound kernels are not starved by the VALU-bound ones of the main stream
+        int lo = 0, hi = 0;
+        if (ctx->aux_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+            ZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, hi));
+        else
+            ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    }
     hipStream_t main_s = ctx->stream, aux_s = ctx->aux_stream;
     hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx), e_up = ev_get(ctx);
     struct EvGuard { zkpor_ctx* c; hipEvent_t e[5]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up}, main_s};
