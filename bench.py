@@ -162,6 +162,18 @@ def timed_region(dist, sync, run):
     return dt
 
 
+def gather_per_rank(dist, values):
+    """one row of numbers per rank, on every rank (rank order); [values] without a process group"""
+    if dist is None:
+        return [list(values)]
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor(list(values), dtype=torch.float64, device=dev)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[float(x) for x in t.tolist()] for t in out]
+
+
 def boundary_leg(torch, zkpor, ctx, device, pk, D, n_wires, n_commit, dev_vectors, td, blinding, resident_ms, n_proofs=6, copy_threads=-1, copy_chunk_mb=0, host_order=0, gpu_token=1):
     """The call a cgo caller actually makes (INTEGRATION.md `ProveTail` / `Commit`): the HOST-pointer entry points
     zkpor_commit + zkpor_prove_tail on PAGEABLE host memory (numpy heap arrays standing in for gnark's []fr.Element), 8.6 GB + 0.5 GB
@@ -549,6 +561,9 @@ def main():
                     help="witness = the mixture of --config; uniform = the worst case (every scalar 254 bits)")
     ap.add_argument("--uniform-steps", type=int, default=-1,
                     help="steps of the second, uniform-scalar timed region reported as value_uniform (-1 = max(2, steps/4); 0 = skip)")
+    ap.add_argument("--other-config-steps", type=int, default=-1,
+                    help="steps of the timed region for the OTHER single-GPU config of BASELINE.json (zkpor500_200 when --config is the "
+                         "default), reported under `configs` (-1 = max(5, steps/4); 0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the trapdoor verification of the timed proofs")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-pointer (cgo-shaped) boundary leg")
     ap.add_argument("--r1cs-terms", type=int, default=0, help="opt-in untimed leg: the host-pointer form with resident constraint matrices "
@@ -588,6 +603,7 @@ def main():
         args.no_check = args.no_boundary = args.no_cpu_baseline = True
         args.r1cs_terms = 0
         args.uniform_steps = 0
+        args.other_config_steps = 0
 
     import torch
     import zkpor
@@ -702,13 +718,16 @@ def main():
     for _ in range(1, max(1, args.streams)):
         workers.append((zkpor.Context(local_rank, None), dev(32 * D), dev(32 * D), dev(32 * D)))
 
+    cv_of = {}  # witness buffer -> its committed-values buffer (default: cv)
+
     def one_proof(wk, w_buf, i, sink):
         wctx, wa, wb, wc = wk
+        cv_buf = cv_of.get(w_buf.data_ptr(), cv)
         wck = wctx._ck
         for dst, src in ((wa, a0), (wb, b0), (wc, c0)):
             wck(lib.zkpor_dev_copy(wctx.h, vp(dst.data_ptr()), vp(src.data_ptr()), ctypes.c_size_t(32 * D)))
         com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
-        wck(lib.zkpor_commit_dev(wctx.h, pk.h, vp(cv.data_ptr()), ctypes.c_size_t(n_commit), _z._p(com), _z._p(pok)))
+        wck(lib.zkpor_commit_dev(wctx.h, pk.h, vp(cv_buf.data_ptr()), ctypes.c_size_t(n_commit), _z._p(com), _z._p(pok)))
         r, s = blinding(i)
         proof = wctx.prove_tail_dev(pk, w_buf.data_ptr(), wa.data_ptr(), wb.data_ptr(), wc.data_ptr(), r, s)
         if sink is not None:
@@ -749,7 +768,16 @@ def main():
     for wk in workers:
         wk[0].phase_reset()
     proofs = []
-    dt = timed_region(dist, torch.cuda.synchronize, lambda: run_steps(args.steps, w, proofs, first=1000))
+    local_t = [0.0]
+
+    def timed_steps():
+        t0_ = time.perf_counter()
+        run_steps(args.steps, w, proofs, first=1000)
+        torch.cuda.synchronize()
+        local_t[0] = time.perf_counter() - t0_
+
+    dt = timed_region(dist, torch.cuda.synchronize, timed_steps)
+    per_rank_ms = [row[0] for row in gather_per_rank(dist, [local_t[0] / max(1, args.steps) * 1e3])]
 
     phases = {}
     for name in ("msm_decompose", "msm_sort", "msm_accumulate", "msm_reduce", "k_acc_level1_g1", "k_acc_level1_g2", "ntt", "pointwise", "host_assembly"):
@@ -774,6 +802,28 @@ def main():
         torch.cuda.synchronize()
         dtu = timed_region(dist, torch.cuda.synchronize, lambda: run_steps(usteps, wu, uproofs, first=5000))
         uni = {"value": world * usteps / dtu, "ms_per_step": dtu / usteps * 1e3, "steps": usteps}
+
+    # BASELINE.json configs[2] in the same line: the other production tier's scalar mixture at the same D and array sizes (the tiers
+    # differ in the witness only) — a short timed region under the same contract, its proofs checked like the others
+    other_cfg = None
+    oproofs = []
+    w_o = cv_o = None
+    other_name = "zkpor500_200" if args.config == "zkpor50_1380" else "zkpor50_1380"
+    osteps = args.other_config_steps if args.other_config_steps >= 0 else max(5, args.steps // 4)
+    if args.scalars == "witness" and osteps > 0 and not args.timed_only:
+        okind = CONFIGS[other_name]["fill_kind"]
+        w_o = dev(32 * n_wires); cv_o = dev(32 * n_commit)
+        ck(lib.zkpor_dev_fill_fr(ctx.h, vp(w_o.data_ptr()), ctypes.c_size_t(n_wires), ctypes.c_uint64(2 + rank), ctypes.c_int(okind)))
+        ck(lib.zkpor_dev_fill_fr(ctx.h, vp(cv_o.data_ptr()), ctypes.c_size_t(n_commit), ctypes.c_uint64(13 + rank), ctypes.c_int(okind)))
+        cv_of[w_o.data_ptr()] = cv_o
+        run_steps(len(workers), w_o)
+        torch.cuda.synchronize()
+        dto = timed_region(dist, torch.cuda.synchronize, lambda: run_steps(osteps, w_o, oproofs, first=3000))
+        other_cfg = {"value": world * osteps / dto, "unit": "proofs/s", "ms_per_step": dto / osteps * 1e3, "steps": osteps,
+                     "mixture": CONFIGS[other_name]["mixture"], "users_per_batch": CONFIGS[other_name]["users"],
+                     "assets_per_user": CONFIGS[other_name]["assets"],
+                     "note": "BASELINE.json configs[%d]: same D, key and array sizes, this tier's witness scalar mixture (w and the committed "
+                             "values); timed under the same barrier/sync contract" % (2 if other_name == "zkpor500_200" else 1)}
 
     # informational third region (N = 1): TWO proofs in flight on the GPU (a second context + stream, how host/prover_host.hpp keeps a
     # GPU busy and how `boundary` hides the copies).  `value` stays the one-in-flight figure so that the kernel times `roofline`
@@ -814,29 +864,56 @@ def main():
             return out
 
         ok = 0
-        h_host = host(workers[0][1], D)[: D - 1]       # prove_tail_dev leaves h in `a`, in the order of the key's Z
+        h_full = host(workers[0][1], D)                # prove_tail_dev leaves h in `a`, in the order of the key's Z
+        # h is device output: before the trapdoor check may use it, verify it against its DEFINITION from the inputs alone —
+        # H(tau)(tau^D - 1) = A(tau)B(tau) - C(tau) at a random tau, A, B, C by barycentric sums over a0, b0, c0 (oracle/quotient.hpp;
+        # no FFT, nothing shared with the device passes).  Every timed proof used the same a, b, c, hence the same h.
+        t_h = time.perf_counter()
+        tau = O.fr_random(0x7A0 + rank, 1)[0]
+        h_ok = bool(O.quotient_identity(log2, host(a0, D), host(b0, D), host(c0, D), h_full, tau))
+        h_seconds = time.perf_counter() - t_h
+        h_host = h_full[: D - 1]
         td = T.SynthKeyTrapdoor(seed, 3, host(w, n_wires), h_host)
         ec, ek = T.expected_commitment(seed, host(cv, n_commit))
         for i, proof, com, pok in proofs:
             r, s = blinding(i)
-            ok += int(td.check(proof, r, s) and np.array_equal(com, ec) and np.array_equal(pok, ek))
+            ok += int(h_ok and td.check(proof, r, s) and np.array_equal(com, ec) and np.array_equal(pok, ek))
         total = len(proofs)
         if uproofs:
             tdu = T.SynthKeyTrapdoor(seed, 3, host(wu, n_wires), None, dZ=td.dZ)      # same a, b, c => same h
             for i, proof, com, pok in uproofs:
                 r, s = blinding(i)
-                ok += int(tdu.check(proof, r, s) and np.array_equal(com, ec) and np.array_equal(pok, ek))
+                ok += int(h_ok and tdu.check(proof, r, s) and np.array_equal(com, ec) and np.array_equal(pok, ek))
             total += len(uproofs)
             del tdu
+        if oproofs:
+            tdo = T.SynthKeyTrapdoor(seed, 3, host(w_o, n_wires), None, dZ=td.dZ)     # same a, b, c => same h
+            eco, eko = T.expected_commitment(seed, host(cv_o, n_commit))
+            oko = 0
+            for i, proof, com, pok in oproofs:
+                r, s = blinding(i)
+                oko += int(h_ok and tdo.check(proof, r, s) and np.array_equal(com, eco) and np.array_equal(pok, eko))
+            ok += oko
+            total += len(oproofs)
+            other_cfg["checked"] = {"proofs": len(oproofs), "ok": oko}
+            del tdo
+        per_rank_checked = [[int(x) for x in row] for row in gather_per_rank(dist, [ok, total])]
+        if other_cfg is not None and "checked" in other_cfg and dist is not None:
+            rows = gather_per_rank(dist, [other_cfg["checked"]["ok"], other_cfg["checked"]["proofs"]])
+            other_cfg["checked"] = {"proofs": int(sum(r_[1] for r_ in rows)), "ok": int(sum(r_[0] for r_ in rows))}
         if dist is not None:
-            t = torch.tensor([ok, total], dtype=torch.int64, device="cuda")
+            t = torch.tensor([ok, total, int(h_ok), 1], dtype=torch.int64, device="cuda")
             dist.all_reduce(t)
             ok, total = int(t[0].item()), int(t[1].item())
-        checked = {"proofs": total, "ok": ok,
-                   "how": "Ar, Bs, Krs of every timed proof (own blinding each) and the two Pedersen sums equal the values predicted in the "
-                          "exponent from the synthetic key's trapdoor (oracle/trapdoor.py), at the timed size and scalar mixture",
+            h_ok = bool(int(t[2].item()) == int(t[3].item()))
+        checked = {"proofs": total, "ok": ok, "h_verified": h_ok, "per_rank_ok_of_total": per_rank_checked,
+                   "how": "(1) h = computeH(a, b, c) of the timed proofs is verified from the inputs alone by the quotient identity "
+                          "H(tau)(tau^D - 1) = A(tau)B(tau) - C(tau) at a random tau (oracle/quotient.hpp: barycentric sums, no FFT); (2) Ar, Bs, "
+                          "Krs of every timed proof (own blinding each) and the two Pedersen sums equal the values predicted in the "
+                          "exponent from the synthetic key's trapdoor with that h (oracle/trapdoor.py), at the timed size and scalar mixture",
+                   "h_check_seconds": round(h_seconds, 2),
                    "seconds": round(time.perf_counter() - t_chk, 2)}
-    del wu
+    del wu, w_o, cv_o
 
     if rank == 0:
         # launches of k_acc_level1_fp29 per proof: A, B1, K, Z (n ~ D points each) + 2 commitment MSMs (n/4 points)
@@ -860,6 +937,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -874,6 +952,7 @@ def main():
             "value_uniform": uni["value"] if uni else None,
             "uniform": ({**uni, "note": "same step with every witness scalar uniform in Fr (worst case; the witness mixture is an estimate)"}
                         if uni else None),
+            "configs": ({other_name: other_cfg} if other_cfg else None),
             "two_in_flight": two,
             "checked": checked,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -62,6 +62,14 @@ enum { ZKPOR_G2_B = 0, ZKPOR_G2_NUM = 1 };
 /* order of pk.G1.Z relative to the coefficient index of h: gnark >= 0.9 stores it bit-reversed at setup */
 enum { ZKPOR_Z_ORDER_BITREV = 0, ZKPOR_Z_ORDER_NATURAL = 1 };
 
+/* ---- ABI version -------------------------------------------------------------------------------------- */
+/* Bumped whenever an existing entry point changes its signature or meaning (3: z_order joined the zkpor_pk_load_gnark* family in
+ * the middle of their argument lists).  A binding compiled or written against another value must refuse to run: a stale ctypes /
+ * cgo caller would otherwise pass arguments in the old positions and nothing would notice at load time.  zkpor.py and
+ * go/zkporgpu check it when the library is loaded. */
+#define ZKPOR_ABI_VERSION 3u
+uint32_t zkpor_abi_version(void);
+
 /* ---- context ------------------------------------------------------------------------------------------- */
 /* stream: a hipStream_t (as void*) the context launches on, or NULL to create its own. */
 int32_t zkpor_init(int device, void* stream, zkpor_ctx** out);
@@ -152,6 +160,10 @@ int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, con
 int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, size_t n_committed,
                        uint64_t seed);
 /* device pointer + length of a loaded (wire-indexed) array, for tests */
+/* Shape of a loaded key: dims = { n_wires, n_public, n_committed, |Z|, log2_domain, msm_tables }.  What a host caller checks a
+ * solver's output against before handing it over (the reference reads the same numbers off r1cs.GetNbConstraints() / the pk,
+ * src/prover/prover/prover.go:317-349); works for keys held as fixed-base tables too. */
+int32_t zkpor_pk_dims(zkpor_pk* pk, uint64_t dims[6]);
 int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n);
 int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n);
 

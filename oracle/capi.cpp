@@ -5,6 +5,7 @@
 #include "poseidon.hpp"
 #include "marshal.hpp"
 #include "cpubase.hpp"
+#include "quotient.hpp"
 #include <memory>
 
 using namespace orc;
@@ -432,5 +433,17 @@ void orc_fast_prove_tail_work(int log2d, const G1A* g1, const G2A* g2, const Fr*
     times[0] = t.fft_s; times[1] = t.msm_g1_s; times[2] = t.msm_g2_s; times[3] = t.commit_s;
 }
 int orc_threads() { return fast::threads(); }
+
+// ---- FFT-free check of computeH's output (quotient.hpp): out6 = A(tau), B(tau), C(tau), H(tau), H(tau)(tau^D-1), A(tau)B(tau)-C(tau);
+// returns 1 when the last two agree, 0 when they differ, -1 when tau lies in the domain
+int orc_quotient_identity(int log2d, const Fr* a, const Fr* b, const Fr* c, size_t n_cons, const Fr* h, int h_bitrev, const Fr* tau, Fr* out6) {
+    Fr t = *tau;
+    Fr tD = t;
+    for (int i = 0; i < log2d; ++i) tD = Fr::sqr(tD);
+    if (Fr::sub(tD, Fr::one()).is_zero()) return -1;
+    orc_quot::Eval e = orc_quot::quotient_identity(log2d, a, b, c, n_cons, h, h_bitrev, t);
+    if (out6) { out6[0] = e.At; out6[1] = e.Bt; out6[2] = e.Ct; out6[3] = e.Ht; out6[4] = e.lhs; out6[5] = e.rhs; }
+    return Fr::sub(e.lhs, e.rhs).is_zero() ? 1 : 0;
+}
 
 }  // extern "C"

@@ -219,6 +219,21 @@ def compute_h(a, b, c, log2d):
     return out
 
 
+def quotient_identity(log2d, a, b, c, h, tau, h_bitrev=True, want_values=False):
+    """FFT-free check of computeH's output (oracle/quotient.hpp): H(tau) (tau^D - 1) == A(tau) B(tau) - C(tau) with A, B, C evaluated
+    from their values on the domain by barycentric Lagrange sums and H from its coefficient vector h (bit-reversed order = what
+    computeH returns).  a, b, c: n_cons <= D rows (zero padded); h: D rows; tau: one Fr (Montgomery limbs).  True iff it holds."""
+    a = _u64(a).reshape(-1, 4); b = _u64(b).reshape(-1, 4); c = _u64(c).reshape(-1, 4); h = _u64(h).reshape(-1, 4)
+    assert a.shape == b.shape == c.shape and a.shape[0] <= (1 << log2d) and h.shape[0] == (1 << log2d)
+    t = _u64(tau).reshape(4)
+    out = np.empty((6, 4), dtype=np.uint64)
+    rc = lib().orc_quotient_identity(ctypes.c_int(log2d), _p(a), _p(b), _p(c), ctypes.c_size_t(a.shape[0]), _p(h), ctypes.c_int(int(h_bitrev)),
+                                     _p(t), _p(out))
+    if rc < 0:
+        raise ValueError("tau lies in the evaluation domain")
+    return (bool(rc), out) if want_values else bool(rc)
+
+
 def poseidon_set_convention(out_idx, carry_idx):
     lib().orc_poseidon_set_convention(ctypes.c_int(out_idx), ctypes.c_int(carry_idx))
 

@@ -31,7 +31,12 @@ def test_bench_line_small_domain():
     assert "workload" in d["config"] and "solver is NOT included" in d["config"]["workload"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert d["two_in_flight"]["proofs_in_flight"] == 2 and d["two_in_flight"]["value"] > 0
-    assert d["checked"]["proofs"] == 3 + d["uniform"]["steps"] + d["two_in_flight"]["steps"] and d["checked"]["ok"] == d["checked"]["proofs"]
+    o = d["configs"]["zkpor500_200"]     # BASELINE.json configs[2] in the default line: its own timed region, its proofs checked
+    assert o["steps"] == 5 and o["value"] > 0 and abs(o["value"] - 1e3 / o["ms_per_step"]) < 1e-6 * o["value"] and o["checked"] == {"proofs": 5, "ok": 5}
+    assert d["checked"]["proofs"] == 3 + d["uniform"]["steps"] + d["two_in_flight"]["steps"] + o["steps"] and d["checked"]["ok"] == d["checked"]["proofs"]
+    assert d["checked"]["h_verified"] is True and "quotient identity" in d["checked"]["how"]      # h is verified from a, b, c, not trusted
+    assert d["checked"]["per_rank_ok_of_total"] == [[d["checked"]["ok"], d["checked"]["proofs"]]]
+    assert len(d["per_rank_ms_per_step"]) == 1 and abs(d["per_rank_ms_per_step"][0] - d["ms_per_step"]) < 0.2 * d["ms_per_step"]
     assert d["value_uniform"] == d["uniform"]["value"] and d["value_uniform"] > 0
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["avg_launch_ms"] > 0
@@ -48,4 +53,4 @@ def test_bench_line_small_domain():
 def test_bench_other_tier_and_timed_only():
     d = _bench("--log2", "17", "--steps", "2", "--warmup", "1", "--config", "zkpor500_200", "--timed-only")
     assert d["config"]["tier"] == "zkpor500_200" and d["config"]["users_per_batch"] == 200
-    assert d["checked"] is None and d["value_uniform"] is None and d["two_in_flight"] is None and "boundary" not in d and "cpu_baseline" not in d and "acceptance" not in d
+    assert d["checked"] is None and d["value_uniform"] is None and d["two_in_flight"] is None and d["configs"] is None and "boundary" not in d and "cpu_baseline" not in d and "acceptance" not in d

@@ -3,6 +3,9 @@ properties — the oracle cannot run 2^26-point MSMs in test time:
   * MSM: the synthetic key's points are s_i*G with a known s_i  =>  MSM(w) == (sum s_i w_i) * G   (G1 over A, G2 over B2)
   * NTT: inverse(forward(x)) == x on the coset at 2^26
   * computeH: for A = B = X^(D/2+1), C = X^2 the quotient is exactly H = X^2
+  * computeH on random a, b, c at 2^26: bit-exact with the CPU port (oracle/cpubase.hpp, itself checked against the plain oracle) AND
+    the FFT-free quotient identity H(tau)(tau^D - 1) = A(tau)B(tau) - C(tau) at a random tau (oracle/quotient.hpp); a twiddle
+    table with one flipped bit must fail both
   * prove tail: the fused path bench.py times (one digit stream -> A, B1, K, B2; h -> Z; blinding; commitment) gives
     exactly the proof the key's discrete logs predict (oracle/trapdoor.py)
   * Merkle: root(2^27 leaves) == H(H(root(left half), root(right half)), nil) one level up
@@ -87,6 +90,7 @@ def test_prove_tail_fullsize_trapdoor(zk, tier, fill_kind, tables):
         zk.fill_fr(bufs["b"], n, 12, 0)
         zk._ck(zk.lib.zkpor_dev_fr_mul(zk.h, _vp(bufs["c"].ptr), _vp(bufs["a"].ptr), _vp(bufs["b"].ptr), ctypes.c_size_t(n)))
         zk.fill_fr(cv, nc, 13, fill_kind)
+        abc = [bufs[k].download(np.uint64, (n, 4)) for k in ("a", "b", "c")]   # the prove tail works in place: keep the inputs
         com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
         zk._ck(zk.lib.zkpor_commit_dev(zk.h, pk.h, _vp(cv.ptr), ctypes.c_size_t(nc), zkpor._p(com), zkpor._p(pok)))
         r = O.fr_random(71, 1)[0]; s = O.fr_random(72, 1)[0]
@@ -94,6 +98,10 @@ def test_prove_tail_fullsize_trapdoor(zk, tier, fill_kind, tables):
         w = bufs["w"].download(np.uint64, (n, 4))
         h = bufs["a"].download(np.uint64, (n, 4))     # prove_tail_dev leaves h in a, in the order of the key's Z
         assert h.any()
+        # h is device output: verify it against its DEFINITION before the trapdoor check uses it (the trapdoor proves Z.h was
+        # summed correctly for whatever h it is given) — FFT-free, from the inputs alone
+        assert O.quotient_identity(LOG2, abc[0], abc[1], abc[2], h, O.fr_random(4242, 1)[0])
+        del abc
         td = T.SynthKeyTrapdoor(seed, 3, w, h[: n - 1])
         assert td.check(proof, r, s)
         # a second proof over the same sums with other blinding must check as well, and a tampered one must not
@@ -125,6 +133,52 @@ def test_ntt_fullsize_roundtrip(zk):
         assert np.array_equal(buf.download(np.uint64, (n, 4)), before)
     finally:
         buf.free()
+
+
+def test_compute_h_fullsize_random_inputs_vs_cpu_port_and_definition(zk):
+    """computeH of RANDOM a, b, c at the timed size (8 + 9 + 9 bit fields, 2 GiB inter-field twiddle tables): (1) bit-exact with
+    the CPU port's computeH on the same inputs, (2) the quotient identity at a random point, (3) with one bit of one tabulated
+    twiddle flipped on the device both checks must fail, and restoring the table restores h."""
+    n = 1 << LOG2
+    bufs = [zk.alloc(32 * n) for _ in range(3)]
+    try:
+        def fill():
+            zk.fill_fr(bufs[0], n, 21, 0)
+            zk.fill_fr(bufs[1], n, 22, 0)
+            zk._ck(zk.lib.zkpor_dev_fr_mul(zk.h, _vp(bufs[2].ptr), _vp(bufs[0].ptr), _vp(bufs[1].ptr), ctypes.c_size_t(n)))   # c = a.b
+        fill()
+        a, b, c = (x.download(np.uint64, (n, 4)) for x in bufs)
+        tail = n - 12345                                 # ragged: the last rows are padding zeros, as for a real constraint count
+        z = np.zeros((n - tail, 4), dtype=np.uint64)
+        for x, buf in zip((a, b, c), bufs):
+            x[tail:] = 0
+            zkpor.DevBuf.upload(_view(zk, buf, tail * 32, z.nbytes), z)
+        zk.compute_h_dev(LOG2, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)
+        h = bufs[0].download(np.uint64, (n, 4))
+        tau = O.fr_random(777, 1)[0]
+        assert O.quotient_identity(LOG2, a[:tail], b[:tail], c[:tail], h, tau)
+        ref = O.fast_compute_h(a[:tail], b[:tail], c[:tail], LOG2)
+        assert np.array_equal(h, ref)
+        del ref
+        # fault injection: one flipped bit in the highest field's inverse twiddle table
+        zk.set_param("debug_ntt_fault", LOG2)
+        try:
+            for x, buf in zip((a, b, c), bufs):
+                zkpor.DevBuf.upload(buf, x)
+            zk.compute_h_dev(LOG2, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)
+            bad = bufs[0].download(np.uint64, (n, 4))
+        finally:
+            zk.set_param("debug_ntt_fault", LOG2)      # flips the bit back
+        assert not np.array_equal(bad, h)
+        assert not O.quotient_identity(LOG2, a[:tail], b[:tail], c[:tail], bad, tau)
+        del bad
+        for x, buf in zip((a, b, c), bufs):
+            zkpor.DevBuf.upload(buf, x)
+        zk.compute_h_dev(LOG2, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)
+        assert np.array_equal(bufs[0].download(np.uint64, (n, 4)), h)
+    finally:
+        for x in bufs:
+            x.free()
 
 
 def _rev(x, bits):

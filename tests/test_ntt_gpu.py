@@ -39,6 +39,18 @@ def test_fft_matches_oracle(zkv, log2n, inverse, decimation, coset):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("log2n", [19, 20, 22])
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("decimation", [O.DIT, O.DIF])
+@pytest.mark.parametrize("coset", [False, True])
+def test_fft_matches_oracle_three_wide_fields(zk, log2n, inverse, decimation, coset):
+    """past 2^18 the plan has three fields with 9-bit upper fields (19 = 8+6+5 ... 22 = 8+7+7, 26 = 8+9+9): bit-exact with the
+    oracle's radix-2 FFT for every mode gnark-crypto's Domain offers (default 29-bit kernel)"""
+    a, ref = _fft_case(log2n, inverse, decimation, coset)
+    assert np.array_equal(zk.fft(a, log2n, inverse, decimation, coset), ref)
+    _CASES.pop((log2n, inverse, decimation, coset))      # 128 MiB per case at 2^22
+
+
 def test_fft_edge_values(zkv):
     """inputs at the ends of the canonical range and all-equal vectors (worst-case limb carries in the lazy form)"""
     zk = zkv
@@ -72,6 +84,45 @@ def test_compute_h_matches_oracle(zkv, log2d, ncons):
     a, b, c, ref = _CASES[key]
     got = zk.compute_h(a, b, c, log2d)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("log2d,short", [(19, 7), (20, 0), (22, 12345)])
+def test_compute_h_matches_oracle_large(zkv, log2d, short):
+    """computeH on random a, b, c past 2^18: bit-exact with the CPU port's computeH (oracle/cpubase.hpp, which
+    tests/test_cpubase_cpu.py pins to the plain oracle; at 2^19 the plain oracle is run as well) and consistent with the
+    FFT-free definition of the quotient (oracle/quotient.hpp)"""
+    zk = zkv
+    ncons = (1 << log2d) - short
+    key = ("hl", log2d, ncons)
+    if key not in _CASES:
+        a = O.fr_random(31, ncons); b = O.fr_random(32, ncons); c = O.fr_mul(a, b)   # c = a.b on the domain: the quotient is a polynomial
+        ref = O.fast_compute_h(a, b, c, log2d)
+        if log2d <= 19:
+            assert np.array_equal(ref, O.compute_h(a, b, c, log2d))
+        assert O.quotient_identity(log2d, a, b, c, ref, O.fr_random(5, 1)[0])
+        _CASES[key] = (a, b, c, ref)
+    a, b, c, ref = _CASES[key]
+    got = zk.compute_h(a, b, c, log2d)
+    assert np.array_equal(got, ref)
+
+
+def test_compute_h_fault_injection_detected(zk):
+    """the quotient identity is sensitive to a single wrong twiddle: one flipped bit in one entry of the tabulated inter-pass
+    twiddles (zkpor_set_param debug_ntt_fault) changes h and the identity fails; flipping it back restores h"""
+    log2d = 18
+    n = 1 << log2d
+    a = O.fr_random(41, n); b = O.fr_random(42, n); c = O.fr_mul(a, b)
+    tau = O.fr_random(6, 1)[0]
+    good = zk.compute_h(a, b, c, log2d)
+    assert O.quotient_identity(log2d, a, b, c, good, tau)
+    zk.set_param("debug_ntt_fault", log2d)
+    try:
+        bad = zk.compute_h(a, b, c, log2d)
+    finally:
+        zk.set_param("debug_ntt_fault", log2d)
+    assert not np.array_equal(bad, good)
+    assert not O.quotient_identity(log2d, a, b, c, bad, tau)
+    assert np.array_equal(zk.compute_h(a, b, c, log2d), good)
 
 
 def test_compute_h_zero_and_ragged(zk):

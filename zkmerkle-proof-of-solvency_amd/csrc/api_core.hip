@@ -3,6 +3,7 @@
 #include "msm.cuh"
 #include "ntt.cuh"
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -159,15 +160,18 @@ int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes
     }
     Bounce* b = (Bounce*)ctx->bounce;
     if (!b) {
-        b = new (std::nothrow) Bounce();
-        if (!b) { ctx->err = "host_upload: out of host memory"; return ZKPOR_E_OOM; }
-        ctx->bounce = b;
-        b->CHUNK = (size_t)ctx->copy_chunk_mb << 20;
+        // built completely in a local object and published only once it works: a pinned allocation that fails half way must not
+        // leave a half-initialised Bounce (null buffers, no workers) for the next upload to copy into
+        std::unique_ptr<Bounce> nb(new (std::nothrow) Bounce());
+        if (!nb) { ctx->err = "host_upload: out of host memory"; return ZKPOR_E_OOM; }
+        nb->CHUNK = (size_t)ctx->copy_chunk_mb << 20;
         for (int i = 0; i < Bounce::SLOTS; ++i) {
-            ZK_HIP(ctx, hipHostMalloc((void**)&b->buf[i], b->CHUNK, hipHostMallocDefault));
-            ZK_HIP(ctx, hipEventCreateWithFlags(&b->ev[i], hipEventDisableTiming));
+            ZK_HIP(ctx, hipHostMalloc((void**)&nb->buf[i], nb->CHUNK, hipHostMallocDefault));   // ~Bounce frees what exists on the way out
+            ZK_HIP(ctx, hipEventCreateWithFlags(&nb->ev[i], hipEventDisableTiming));
         }
-        b->start(ctx->copy_threads);
+        nb->start(ctx->copy_threads);
+        b = nb.release();
+        ctx->bounce = b;
     }
     const char* src = (const char*)h_src;
     char* dst = (char*)d_dst;
@@ -324,6 +328,8 @@ int32_t zkpor_sync(zkpor_ctx* ctx) {
     return ZKPOR_OK;
 }
 
+uint32_t zkpor_abi_version(void) { return ZKPOR_ABI_VERSION; }
+
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !name) return ZKPOR_E_ARG;
@@ -345,6 +351,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     else if (n == "host_order") { if (value < 0 || value > 1) { ctx->err = "host_order must be 0 or 1"; return ZKPOR_E_ARG; } ctx->host_order = (int)value; }
     else if (n == "copy_chunk_mb") { if (value < 1 || value > 1024) { ctx->err = "copy_chunk_mb must be in [1,1024]"; return ZKPOR_E_ARG; } if (ctx->bounce) bounce_free(ctx); ctx->copy_chunk_mb = (int)value; }
     else if (n == "copy_threads") { if (value < 0 || value > 64) { ctx->err = "copy_threads must be in [0,64]"; return ZKPOR_E_ARG; } if (ctx->bounce) bounce_free(ctx); ctx->copy_threads = (int)value; }
+    else if (n == "debug_ntt_fault") return ntt_debug_fault(ctx, (int)value);   // test-only fault injection (ntt.hip)
     else if (n == "poseidon_out_idx") ctx->pos_out = (int)value;
     else if (n == "poseidon_carry_idx") ctx->pos_carry = (int)value;
     else { ctx->err = "unknown parameter " + n; return ZKPOR_E_ARG; }

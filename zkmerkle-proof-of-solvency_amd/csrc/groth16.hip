@@ -423,6 +423,14 @@ int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_p
     return pk_apply_tables(pk);
 }
 
+int32_t zkpor_pk_dims(zkpor_pk* pk, uint64_t dims[6]) {
+    if (!pk || !dims) return ZKPOR_E_ARG;
+    if (!pk->ready) return ZKPOR_E_STATE;
+    dims[0] = pk->n_wires; dims[1] = pk->n_public; dims[2] = pk->nC; dims[3] = pk->nZ;
+    dims[4] = (uint64_t)pk->log2_domain; dims[5] = (uint64_t)pk->tab_m;
+    return ZKPOR_OK;
+}
+
 int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !dev_ptr || !n) return ZKPOR_E_ARG;
@@ -519,7 +527,10 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     };
     if (do_w) {
         ctx->stream = aux_s;
-        ZK_HIP(ctx, hipStreamWaitEvent(aux_s, host ? e_up : e_start, 0));
+        // e_start orders the digit kernels (they write the shared workspace) after whatever is already queued on the main stream —
+        // also on the host path, where e_up (the copy stream) alone would not; free when the main stream is idle
+        ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_start, 0));
+        if (host) ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_up, 0));
         ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw));
         ZK_HIP(ctx, hipEventRecord(e_w, aux_s));
         off_dh = ctx->ws_off;

@@ -465,6 +465,25 @@ int32_t ntt_domain_get(zkpor_ctx* ctx, int n, NttDomain** out) {
     return ZKPOR_OK;
 }
 
+// Fault injection for the tests of the h check (tests/test_fullsize_gpu.py): flips one bit of one tabulated inter-pass twiddle of
+// the highest field of the 2^n domain (inverse table of the 29-bit kernel when present, else of the 32-bit one).  Calling it a
+// second time restores the table.  Never called by the product path (zkpor_set_param "debug_ntt_fault").
+__global__ void k_flip_bit(u32* word) { *word ^= 4u; }
+int32_t ntt_debug_fault(zkpor_ctx* ctx, int n) {
+    NttDomain* d;
+    ZK_TRY(ntt_domain_get(ctx, n, &d));
+    Field f[8];
+    const int nf = plan_fields(n, f);
+    if (nf < 2) { ctx->err = "debug_ntt_fault: the domain has a single field (no inter-pass twiddles)"; return ZKPOR_E_ARG; }
+    Fr* t = (ctx->ntt_variant == 1 && d->have29) ? d->full_inv29[nf - 1] : d->full_inv[nf - 1];
+    if (!t) { ctx->err = "debug_ntt_fault: no tabulated twiddles for this domain"; return ZKPOR_E_STATE; }
+    const size_t cnt = (size_t)1 << (f[nf - 1].lo + f[nf - 1].kb);
+    hipLaunchKernelGGL(k_flip_bit, dim3(1), dim3(1), 0, ctx->stream, (u32*)(t + (cnt / 3)) + 1);
+    ZK_KERNEL_CHECK(ctx);
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+}
+
 void ntt_domains_free(zkpor_ctx* ctx) {
     for (auto& kv : ctx->ntt_domains) {
         NttDomain* d = (NttDomain*)kv.second;

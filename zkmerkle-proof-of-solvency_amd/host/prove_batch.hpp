@@ -64,6 +64,15 @@ inline int GenerateAndVerifyProof(zkpor_ctx* ctx, zkpor_pk* pk, const std::strin
     };
     if (solve(in, commit, &sol) != 0) { if (err) *err = "solve: the solver reported an error"; return PB_SOLVE; }
     if (sol.a.size() != 4 * sol.n_constraints || sol.b.size() != sol.a.size() || sol.c.size() != sol.a.size()) { if (err) *err = "solve: a, b, c sizes"; return PB_SOLVE; }
+    // zkpor_prove_tail reads n_wires x 32 bytes of w and n_constraints x 32 of a, b, c: a solver that returns another circuit's
+    // (e.g. the other tier's) vectors must end in PB_SOLVE, not in an out-of-bounds read
+    uint64_t dims[6];
+    if (zkpor_pk_dims(pk, dims) != ZKPOR_OK) { if (err) *err = "prove: the key is not loaded"; return PB_PROVE; }
+    if (sol.w.size() != 4 * dims[0]) {
+        if (err) *err = "solve: w has " + std::to_string(sol.w.size() / 4) + " wires, the key has " + std::to_string(dims[0]);
+        return PB_SOLVE;
+    }
+    if (sol.n_constraints > ((uint64_t)1 << dims[4])) { if (err) *err = "solve: more constraints than the key's domain"; return PB_SOLVE; }
     uint8_t proof[256];
     int32_t rc = zkpor_prove_tail(ctx, pk, sol.w.data(), sol.a.data(), sol.b.data(), sol.c.data(), sol.n_constraints, r, s, proof);
     if (rc != ZKPOR_OK) { if (err) *err = std::string("prove: ") + zkpor_last_error(ctx); return PB_PROVE; }

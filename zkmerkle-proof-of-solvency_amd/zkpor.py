@@ -22,12 +22,19 @@ class ZkporError(RuntimeError):
 _lib = None
 
 
+ABI_VERSION = 3   # include/zkpor.h ZKPOR_ABI_VERSION
+
+
 def load_library():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ZkporError(f"{LIB_PATH} is not built (run __graft_entry__.build()); there is no CPU fallback")
         lib = ctypes.CDLL(LIB_PATH)
+        lib.zkpor_abi_version.restype = ctypes.c_uint32
+        got = int(lib.zkpor_abi_version())
+        if got != ABI_VERSION:   # a stale binding would pass arguments in the old positions (include/zkpor.h ZKPOR_ABI_VERSION)
+            raise ZkporError(f"{LIB_PATH} speaks ABI version {got}, this binding was written against {ABI_VERSION}")
         lib.zkpor_last_error.restype = ctypes.c_char_p
         lib.zkpor_phase_ms.restype = ctypes.c_double
         _lib = lib
