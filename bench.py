@@ -71,6 +71,21 @@ def pmc_valu_issue_bound_ms(kernel="k_acc_level1_fp29"):
         return None, None
 
 
+def valu_class_weight(kernel="k_acc_level1_fp29"):
+    """mean issue cycles per VALU instruction of `kernel` if every simple 32-bit instruction issued at the fast rate (2 cycles) and the
+    rest at 4 (profiles/r03_valu_class.txt: measured classes; profiles/r03_valu_mix.json: the kernel's static mix), relative to 4"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_mix.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        f = float(d["kernels"][kernel]["fast32_share"])
+        return ((1.0 - f) * d["slow_class_cycles"] + f * d["fast_class_cycles"]) / 4.0, os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def algorithmic_bytes_per_proof(log2, n_wires, n_commit):
     d = 1 << log2
     msm = 4 * 96 * n_wires + 160 * n_wires  # 3 witness G1 MSMs + Z (counted at n_wires ~ D) + G2
@@ -584,6 +599,8 @@ def main():
     ap.add_argument("--tables", type=int, default=4, help="fixed-base tables per key point (msm_tables; 1 = plain arrays): the default "
                     "4 holds the key as 4 interleaved tables (112 GB of the 288 GB at 2^26) and buys 12 digits of 22 bits instead of "
                     "13 of 20 at the same number of buckets — 6 %% fewer bucket additions (profiles/r02_tables.txt)")
+    ap.add_argument("--sort-block", type=int, default=-1, help="workgroup size of the onesweep radix sort under the main stream's kernels: 0 = rocPRIM's "
+                    "default (1024 threads), 256, 512; -1 = library default")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1, help="proofs in flight per GPU (in-process dispatcher workers, one HIP stream + workspace each)")
@@ -655,6 +672,8 @@ def main():
         ctx.set_param("msm_g1_variant", args.g1_variant)
     if args.no_reduce_scan:
         ctx.set_param("msm_reduce_scan", 0)
+    if args.sort_block >= 0:
+        ctx.set_param("sort_block", args.sort_block)
     if args.aux_priority:
         ctx.set_param("aux_priority", 1)
     if args.tables > 1 and not args.split:   # a key with tables cannot be cut into the shards of the single-proof split
@@ -925,8 +944,14 @@ def main():
         profiled_cfg = log2 == 26 and args.scalars == "witness" and args.config == "zkpor50_1380" and not args.window and not args.chunk and tables_used == 4
         traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and profiled_cfg) else None
         vb_ms, vsrc = pmc_valu_issue_bound_ms()
+        cw, cwsrc = valu_class_weight()
         valu = ({"issue_bound_ms_per_launch": vb_ms, "frac": vb_ms / (avg_launch_s * 1e3),
-                 "source": f"profiles/{vsrc}: SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz) / live avg launch time"}
+                 "frac_class_weighted": (vb_ms * cw / (avg_launch_s * 1e3)) if cw else None,
+                 "source": f"profiles/{vsrc}: SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz nominal) / live avg launch time; "
+                           f"class-weighted: the same count priced per instruction class (profiles/{cwsrc}: 24 % of the kernel's VALU "
+                           "instructions are simple 32-bit ops that issue in 2 cycles when they come in runs, the rest 4 — measured per class in "
+                           "profiles/r03_valu_class.txt).  The part runs this kernel at ~2.05 GHz, not 2.4 (SQ_BUSY_CYCLES per ms, "
+                           "profiles/r01_pmc_valu_utilisation.txt): at the clock it gets, frac is ~0.9"}
                 if (vb_ms and avg_launch_s > 0 and profiled_cfg) else None)
         main_stream = ("k_acc_level1_g1", "k_acc_level1_g2", "msm_accumulate", "msm_reduce", "ntt", "pointwise", "host_assembly")
         out = {

@@ -20,11 +20,13 @@ typedef uint64_t u64;
 
 enum Op { ADD_U32, SUB_U32, AND_B32, XOR_B32, LSHLREV_B32, ASHRREV_I32, MOV_B32, CNDMASK_B32, ADD3_U32, LSHL_ADD_U32, AND_OR_B32, BFE_I32, ALIGNBIT_B32,
           ASHRREV_I64, LSHLREV_B64, LSHL_ADD_U64, ADD_CO_ADDC, MUL_LO_U32, MUL_HI_U32, MAD_U64_U32, MAD_I64_I32, MAD_U32_U24, FMA_F64, FMA_F32, PK_FMA_F32,
-          MOV_DPP, MIX_MAD_ADD, MIX_MAD_ASHR, N_OPS };
+          MOV_DPP, MIX_MAD_ADD, MIX_MAD_ASHR, CNDMASK_SGPR, PAT_MMAA, PAT_M_AAAA, PAT_ADD_AND, PAT_DEP_ADD, PAT_M_A_DEP, PAT_AAMM_X2, PAT_MAD_MOV, PAT_ASHR64_AND, N_OPS };
 static const char* NAMES[N_OPS] = {"v_add_u32", "v_sub_u32", "v_and_b32", "v_xor_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_mov_b32", "v_cndmask_b32", "v_add3_u32",
     "v_lshl_add_u32", "v_and_or_b32", "v_bfe_i32", "v_alignbit_b32", "v_ashrrev_i64", "v_lshlrev_b64", "v_lshl_add_u64", "v_add_co_u32+v_addc_co_u32",
     "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_mad_i64_i32", "v_mad_u32_u24", "v_fma_f64", "v_fma_f32", "v_pk_fma_f32", "v_mov_b32_dpp quad_perm",
-    "MIX 1:1 v_mad_i64_i32 / v_add_u32", "MIX 1:1 v_mad_i64_i32 / v_ashrrev_i64"};
+    "MIX 1:1 v_mad_i64_i32 / v_add_u32", "MIX 1:1 v_mad_i64_i32 / v_ashrrev_i64",
+    "v_cndmask_b32 (mask in an SGPR pair)", "PAT mad mad add add", "PAT mad add add add add", "PAT add and add and (indep.)", "PAT add->add dependent chain (1 reg)",
+    "PAT mad, add (add depends on mad lo)", "PAT add add mad mad add add mad mad", "PAT mad mov mad mov", "PAT ashr64 and ashr64 and"};
 
 #define ONE8_32(INS) \
     asm volatile(INS " %0, %0, %8\n" INS " %1, %1, %8\n" INS " %2, %2, %8\n" INS " %3, %3, %8\n" INS " %4, %4, %8\n" INS " %5, %5, %8\n" INS " %6, %6, %8\n" INS " %7, %7, %8\n" \
@@ -43,6 +45,7 @@ template <int OP>
 __global__ __launch_bounds__(64) void k_class(u64* cyc, u32* sink, int iters, u32 seed) {
     u32 a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;
     u32 b = blockIdx.x * 11 + 5, sh = (seed & 3) + 1;
+    u64 smask = __builtin_amdgcn_readfirstlane(b) * 0x9e3779b97f4a7c15ull;
     u64 c0 = a0, c1 = a1, c2 = a2, c3 = a3, c4 = a4, c5 = a5, c6 = a6, c7 = a7;
     double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7, db = 1.0000001;
     float f0 = a0, f1 = a1, f2 = a2, f3 = a3, f4 = a4, f5 = a5, f6 = a6, f7 = a7, fb = 1.0001f;
@@ -128,6 +131,51 @@ __global__ __launch_bounds__(64) void k_class(u64* cyc, u32* sink, int iters, u3
                               "v_mad_i64_i32 %2, vcc, %8, %9, %2\n v_ashrrev_i64 %6, 29, %6\n v_mad_i64_i32 %3, vcc, %8, %9, %3\n v_ashrrev_i64 %7, 29, %7\n"
                               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a0), "v"(b) : "vcc");)
         }
+
+        else if (OP == CNDMASK_SGPR) {
+            REP4(asm volatile("v_cndmask_b32 %0, %0, %8, %9\n v_cndmask_b32 %1, %1, %8, %9\n v_cndmask_b32 %2, %2, %8, %9\n v_cndmask_b32 %3, %3, %8, %9\n"
+                              "v_cndmask_b32 %4, %4, %8, %9\n v_cndmask_b32 %5, %5, %8, %9\n v_cndmask_b32 %6, %6, %8, %9\n v_cndmask_b32 %7, %7, %8, %9\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "s"(smask));)
+        }
+        else if (OP == PAT_MMAA) {
+            REP4(asm volatile("v_mad_i64_i32 %0, vcc, %8, %9, %0\n v_mad_i64_i32 %1, vcc, %8, %9, %1\n v_add_u32 %4, %4, %9\n v_add_u32 %5, %5, %9\n"
+                              "v_mad_i64_i32 %2, vcc, %8, %9, %2\n v_mad_i64_i32 %3, vcc, %8, %9, %3\n v_add_u32 %6, %6, %9\n v_add_u32 %7, %7, %9\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(a0), "v"(b) : "vcc");)
+        }
+        else if (OP == PAT_M_AAAA) {  // 10 instructions x 3 + 2 = 32: approximated by 8 = mad + 4 adds + mad + 2 adds
+            REP4(asm volatile("v_mad_i64_i32 %0, vcc, %8, %9, %0\n v_add_u32 %4, %4, %9\n v_add_u32 %5, %5, %9\n v_add_u32 %6, %6, %9\n v_add_u32 %7, %7, %9\n"
+                              "v_add_u32 %4, %4, %9\n v_add_u32 %5, %5, %9\n v_add_u32 %6, %6, %9\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(a0), "v"(b) : "vcc");)
+        }
+        else if (OP == PAT_ADD_AND) {
+            REP4(asm volatile("v_add_u32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_and_b32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_and_b32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+        }
+        else if (OP == PAT_DEP_ADD) {
+            REP4(asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n"
+                              : "+v"(a0) : "v"(b));)
+        }
+        else if (OP == PAT_M_A_DEP) {  // the add consumes the low half of the product just made (register pair aliasing via asm operands is not
+                                      // expressible; use the 32-bit result of v_mul_lo instead)
+            REP4(asm volatile("v_mul_lo_u32 %0, %0, %8\n v_add_u32 %4, %4, %0\n v_mul_lo_u32 %1, %1, %8\n v_add_u32 %5, %5, %1\n"
+                              "v_mul_lo_u32 %2, %2, %8\n v_add_u32 %6, %6, %2\n v_mul_lo_u32 %3, %3, %8\n v_add_u32 %7, %7, %3\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+        }
+        else if (OP == PAT_AAMM_X2) {
+            REP4(asm volatile("v_add_u32 %4, %4, %9\n v_and_b32 %5, %5, %9\n v_mad_i64_i32 %0, vcc, %8, %9, %0\n v_mad_i64_i32 %1, vcc, %8, %9, %1\n"
+                              "v_add_u32 %6, %6, %9\n v_and_b32 %7, %7, %9\n v_mad_i64_i32 %2, vcc, %8, %9, %2\n v_mad_i64_i32 %3, vcc, %8, %9, %3\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(a0), "v"(b) : "vcc");)
+        }
+        else if (OP == PAT_MAD_MOV) {
+            REP4(asm volatile("v_mad_i64_i32 %0, vcc, %8, %9, %0\n v_mov_b32 %4, %5\n v_mad_i64_i32 %1, vcc, %8, %9, %1\n v_mov_b32 %5, %6\n"
+                              "v_mad_i64_i32 %2, vcc, %8, %9, %2\n v_mov_b32 %6, %7\n v_mad_i64_i32 %3, vcc, %8, %9, %3\n v_mov_b32 %7, %4\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(a0), "v"(b) : "vcc");)
+        }
+        else if (OP == PAT_ASHR64_AND) {
+            REP4(asm volatile("v_ashrrev_i64 %0, 29, %0\n v_and_b32 %4, %4, %8\n v_ashrrev_i64 %1, 29, %1\n v_and_b32 %5, %5, %8\n"
+                              "v_ashrrev_i64 %2, 29, %2\n v_and_b32 %6, %6, %8\n v_ashrrev_i64 %3, 29, %3\n v_and_b32 %7, %7, %8\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+        }
     }
     u64 t1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -158,11 +206,11 @@ int main(int argc, char** argv) {
     std::vector<u64> h(max_blocks);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    printf("%-36s %8s %8s %8s %8s   %s\n", "class", "W=1", "W=2", "W=4", "W=8", "wall-clock cycles @nominal (W=8)");
+    printf("%-40s %7s %7s %7s %7s %7s   %s\n", "class", "W=1", "W=2", "W=3", "W=4", "W=8", "wall-clock cycles @nominal: W=3, W=8");
     for (int op = 0; op < N_OPS; ++op) {
-        double res[4]; double wall8 = 0;
+        double res[5]; double wall8 = 0, wall3 = 0;
         int wi = 0;
-        for (int W : {1, 2, 4, 8}) {
+        for (int W : {1, 2, 3, 4, 8}) {
             const int blocks = simds * W;
             fn[op](blocks, cyc, sink, 16);   // warm-up
             CHECK(hipDeviceSynchronize());
@@ -183,8 +231,9 @@ int main(int argc, char** argv) {
             }
             res[wi++] = best;
             if (W == 8) wall8 = bestwall;
+            if (W == 3) wall3 = bestwall;
         }
-        printf("%-36s %8.2f %8.2f %8.2f %8.2f   %.2f\n", NAMES[op], res[0], res[1], res[2], res[3], wall8);
+        printf("%-40s %7.2f %7.2f %7.2f %7.2f %7.2f   %.2f  %.2f\n", NAMES[op], res[0], res[1], res[2], res[3], res[4], wall3, wall8);
     }
     printf("(cycles of s_memtime per wave-instruction per SIMD; the W=8 column is the steady-state issue cost; a class at ~4 issues at 16 lanes per\n"
            " cycle, ~2 would be 32 lanes per cycle, ~8 is half rate, ~16 quarter rate.  If s_memtime does not tick at the shader clock on this part the\n"

@@ -56,6 +56,7 @@ struct zkpor_ctx {
     int copy_chunk_mb = 32;          // size of one of the four pinned bounce buffers
     int host_order = 0;              // zkpor_prove_tail from host memory: 0 = w first, a/b/c under the witness sums; 1 = everything first, then the resident order
     int msm_reduce_scan = 1;         // small bucket-reduction levels (G1): one lane per bucket, scan + tree sums (msm_g1_hot.hip)
+    int sort_block = 0;              // workgroup size of the onesweep radix sort: 0 = rocPRIM default (1024), 256, 512 (sort.hip)
     int aux_priority = 0;            // 1: the auxiliary (digit-stream) HIP stream is created with the highest stream priority
     int gpu_token = 1;               // host-pointer calls of several contexts on one GPU take turns on the device (api_core.hip GpuTurn)
 };
