@@ -397,6 +397,32 @@ int32_t zkpor_tree_set_accounts(zkpor_tree* tree, uint64_t first_key, zkpor_acco
 /* poseidon.Poseidon(inputs...) for `count` independent inputs of `len` elements each (Montgomery Fr in/out) */
 int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, size_t count, uint64_t* out);
 
+/* ---- structured witness generation on the device ------------------------------------------------------------
+ * r1cs.Solve (inside groth16.Prove, src/prover/prover/prover.go:269; hints registered at :68) fills the wire vector of
+ * BatchCreateUserCircuit one instruction at a time on the host.  Two families of its wires are plain data-parallel functions of the
+ * witness inputs and make up about half of the vector: the S-box wires of the in-circuit Poseidon gadget
+ * (circuit/utils.go:12-21, 28-49; circuit/batch_create_user_circuit.go:104,129,181,270,281,320) and the 16-bit range-check limbs with
+ * the multiplicities and inverse wires of the log-derivative lookup argument (circuit/batch_create_user_circuit.go:201-213,
+ * circuit/utils.go:85-100,115-177).  These entry points compute them in HBM into "semantic slots"; the wire map that assigns a slot
+ * to gnark's wire id comes from the one-off solver export (go/export_solver) and is applied by zkpor_witgen_scatter_dev.  The
+ * remaining wires are solved by the levelized host executor (host/solver_exec.hpp).  All pointers are device pointers, all calls
+ * asynchronous on the context's stream. */
+/* S-boxes per permutation of width t: 8 t + R_P(t) (0 for widths the circuit does not use: anything but 3, 5, 6, 13) */
+size_t zkpor_witgen_poseidon_sboxes(int t);
+/* d_states: count x t Montgomery Fr, the initial states (state[0] = the capacity element), replaced by the final states.
+ * d_trace: 3 * sboxes(t) * count Fr: trace[(s * 3 + c) * count + i] = for permutation i, S-box s in round order (full rounds: lanes
+ * 0..t-1; partial rounds: lane 0), c = 0,1,2 -> x^2, x^4, x^5 — the three multiplication wires the gadget spends per S-box. */
+int32_t zkpor_witgen_poseidon_trace_dev(zkpor_ctx* ctx, int t, void* d_states, size_t count, void* d_trace);
+/* d_values: n Montgomery Fr below 2^(16 nb_limbs), nb_limbs in [1, 15].  d_limbs: nb_limbs * n Fr, limbs[l * n + i] = limb l of value i.
+ * d_multiplicity: 65536 x u32 counters, incremented (not cleared) — the multiplicities of the 2^16-entry table.  d_bad: one u32,
+ * incremented per value out of range. */
+int32_t zkpor_witgen_limbs_dev(zkpor_ctx* ctx, const void* d_values, size_t n, int nb_limbs, void* d_limbs, void* d_multiplicity, void* d_bad);
+/* d_out[i] = 1 / (challenge - d_values[i]) (the inverse wires of the log-derivative argument); a zero denominator gives 0 and
+ * increments *d_bad */
+int32_t zkpor_witgen_inverse_dev(zkpor_ctx* ctx, const void* d_values, size_t n, const uint64_t challenge[4], void* d_out, void* d_bad);
+/* d_w[d_wire_ids[i]] = d_src[i], i < n */
+int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, const uint32_t* d_wire_ids, size_t n);
+
 /* ---- device memory helpers for host languages without a HIP binding ------------------------------------ */
 int32_t zkpor_dev_alloc(zkpor_ctx* ctx, size_t bytes, void** out);
 int32_t zkpor_dev_free(zkpor_ctx* ctx, void* p);

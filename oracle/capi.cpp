@@ -169,6 +169,16 @@ void orc_poseidon_params(int t, Fr* rc_out, Fr* mds_out) {
 }
 void orc_poseidon_permute(Fr* state, int t) { poseidon_permute(state, t); }
 void orc_poseidon_hash(const Fr* in, size_t n, Fr* out) { *out = poseidon_hash(in, n); }
+// count permutations of width t: states count x t (in place), trace in the DEVICE's slot order [(s * 3 + c) * count + i]
+void orc_poseidon_permute_trace(Fr* states, int t, size_t count, Fr* trace) {
+    const size_t ns = (size_t)POSEIDON_RF * t + poseidon_rp(t);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < count; ++i) {
+        std::vector<Fr> tr(3 * ns);
+        poseidon_permute_trace(states + i * t, t, tr.data());
+        for (size_t k = 0; k < 3 * ns; ++k) trace[k * count + i] = tr[k];
+    }
+}
 // batched 2->1 hashing: out[i] = H(in[2i], in[2i+1])
 void orc_poseidon_hash2_batch(const Fr* in, size_t n_pairs, Fr* out) {
 #pragma omp parallel for schedule(static)

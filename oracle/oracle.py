@@ -252,6 +252,17 @@ def poseidon_permute(state):
     return s
 
 
+def poseidon_permute_trace(states, t):
+    """(final states, trace) of len(states) permutations of width t; trace[(s * 3 + c), i] = x^2 / x^4 / x^5 of S-box s of permutation i
+    (the slot order of zkpor_witgen_poseidon_trace_dev)"""
+    st = _u64(states).reshape(-1, t, 4).copy()
+    n = st.shape[0]
+    ns = 8 * t + int(lib().orc_poseidon_rp(ctypes.c_int(t)))
+    tr = np.empty((3 * ns, n, 4), dtype=np.uint64)
+    lib().orc_poseidon_permute_trace(_p(st), ctypes.c_int(t), ctypes.c_size_t(n), _p(tr))
+    return st, tr
+
+
 def poseidon_hash(inp):
     inp = _u64(inp); out = np.empty((4,), dtype=np.uint64)
     lib().orc_poseidon_hash(_p(inp), ctypes.c_size_t(inp.shape[0]), _p(out))

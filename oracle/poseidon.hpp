@@ -139,6 +139,35 @@ static inline void poseidon_permute(Fr* st, int t) {
     }
 }
 
+// the same permutation, recording what the in-circuit gadget allocates: per S-box the wires x^2, x^4, x^5 (three multiplications;
+// round constants and the MDS layer are linear and cost no wire).  trace[(s * 3 + c)]: S-box s in round order, lanes 0..t-1 within a
+// full round.  Checker of zkpor_witgen_poseidon_trace_dev (the device runs the OPTIMISED partial rounds; the S-box inputs coincide).
+static inline void poseidon_permute_trace(Fr* st, int t, Fr* trace) {
+    const PoseidonParams& p = poseidon_params(t);
+    std::vector<Fr> tmp(t);
+    int k = 0;
+    size_t s = 0;
+    auto sbox = [&](const Fr& x) {
+        Fr x2 = Fr::sqr(x), x4 = Fr::sqr(x2), x5 = Fr::mul(x4, x);
+        trace[3 * s] = x2; trace[3 * s + 1] = x4; trace[3 * s + 2] = x5;
+        ++s;
+        return x5;
+    };
+    for (int r = 0; r < POSEIDON_RF + p.rp; ++r) {
+        for (int i = 0; i < t; ++i) st[i] = Fr::add(st[i], p.rc[k++]);
+        if (r < POSEIDON_RF / 2 || r >= POSEIDON_RF / 2 + p.rp)
+            for (int i = 0; i < t; ++i) st[i] = sbox(st[i]);
+        else
+            st[0] = sbox(st[0]);
+        for (int i = 0; i < t; ++i) {
+            Fr acc = Fr::zero();
+            for (int j = 0; j < t; ++j) acc = Fr::add(acc, Fr::mul(p.mds[i * t + j], st[j]));
+            tmp[i] = acc;
+        }
+        for (int i = 0; i < t; ++i) st[i] = tmp[i];
+    }
+}
+
 struct PoseidonConv { int out_idx, carry_idx; };
 static inline PoseidonConv& poseidon_conv() {
     static PoseidonConv c = {1, 0};

@@ -107,6 +107,33 @@ def test_account_leaves_match_oracle(zk, tier, max_assets, n):
     assert np.array_equal(got, ref)
 
 
+def test_account_leaves_tier500_at_scale(zk):
+    """tier 500 (83 full sponge blocks + a ragged one + the leaf hash per account: a chain of 85 permutations per thread) on more accounts
+    than one wave holds, with asset counts from 0 to the full tier: every leaf equals the oracle's"""
+    rng = np.random.default_rng(500)
+    n = 1100
+    acc = np.zeros(n, dtype=zkpor.ACCOUNT_DTYPE)
+    k = rng.integers(0, 501, size=n)
+    k[0] = 0; k[1] = 500; k[2] = 1
+    off = np.concatenate([[0], np.cumsum(k)[:-1]])
+    acc["n_assets"] = k; acc["asset_off"] = off
+    acc["id_be"][:, 20:] = rng.integers(0, 256, size=(n, 12), dtype=np.uint8)
+    for f in ("equity", "debt", "collateral"):
+        acc[f][:, 0] = rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
+        acc[f][:, 1] = rng.integers(0, 1 << 30, size=n, dtype=np.uint64)
+    tot = int(k.sum())
+    assets = np.zeros(tot, dtype=zkpor.ASSET_DTYPE)
+    for name in ("equity", "debt", "loan", "margin", "portfolio_margin"):
+        assets[name] = rng.integers(0, 1 << 63, size=tot, dtype=np.uint64)
+    idx = np.empty(tot, dtype=np.uint32)
+    for i in range(n):
+        idx[off[i]:off[i] + k[i]] = np.sort(rng.choice(500, size=k[i], replace=False))
+    assets["index"] = idx
+    got = zk.poseidon_leaves(acc, assets, 500)
+    ref = O.fr_to_be(O.account_leaves(acc, assets, 500))
+    assert np.array_equal(got, ref)
+
+
 def test_account_leaves_padding_edge_cases(zk):
     # utils_test.go:43-136 cases: assets at the very end of the index range, contiguous from 0, exactly `tier` assets
     tier = 50

@@ -334,9 +334,34 @@ ZK_D Fr29 pow5_29(const Fr29& x) {
     Fr29 x2 = Fr29::sqr(x);
     return Fr29::mul(Fr29::sqr(x2), x);
 }
+// S-box trace of the structured witness generator: the in-circuit Poseidon gadget (circuit/utils.go:12-21,
+// 28-49 -> std/hash/poseidon) spends three multiplication wires per S-box — x^2, x^4, x^5 — and nothing else (round constants and
+// the MDS layer are linear).  The sink stores them as trace[(s * 3 + c) * count + perm]: S-box s in round order (full rounds: lanes
+// 0..T-1), component c, consecutive permutations adjacent (coalesced stores); a wire map scatters the slots to gnark's wire ids.
+struct TraceSink {
+    Fr* base;
+    size_t count, perm;
+    u32 s;
+};
+ZK_D Fr29 pow5_29_tr(const Fr29& x, TraceSink& ts) {
+    Fr29 x2 = Fr29::sqr(x);
+    Fr29 x4 = Fr29::sqr(x2);
+    Fr29 x5 = Fr29::mul(x4, x);
+    Fr* o = ts.base + (size_t)ts.s * 3u * ts.count + ts.perm;
+    o[0] = Fr29::to32_div32(x2);
+    o[ts.count] = Fr29::to32_div32(x4);
+    o[2 * ts.count] = Fr29::to32_div32(x5);
+    ++ts.s;
+    return x5;
+}
+template <bool TR>
+ZK_D Fr29 sbox29(const Fr29& x, TraceSink* ts) {
+    if (TR) return pow5_29_tr(x, *ts);
+    return pow5_29(x);
+}
 // st: tight limbs, any magnitude below ~60 r on entry; all tables as 9-limb rows at the same element offsets as PermTab
-template <int T>
-ZK_D void permute29(Fr29 (&st)[T], const u32* rc, const u32* m, const u32* prc, const u32* sp, const u32* post, int rp) {
+template <int T, bool TR = false>
+ZK_D void permute29(Fr29 (&st)[T], const u32* rc, const u32* m, const u32* prc, const u32* sp, const u32* post, int rp, TraceSink* ts = nullptr) {
     for (int half = 0; half < 2; ++half) {
 #pragma unroll 1
         for (int rr = 0; rr < POS_RF / 2; ++rr) {
@@ -346,7 +371,7 @@ ZK_D void permute29(Fr29 (&st)[T], const u32* rc, const u32* m, const u32* prc, 
             if (T <= 4) {  // narrow states (the 2-to-1 node hash): everything unrolled, everything in registers
                 Fr29 tmp[T];
 #pragma unroll
-                for (int i = 0; i < T; ++i) st[i] = pow5_29(Fr29::reduce32(Fr29::add_l(st[i], k29(c, i))));
+                for (int i = 0; i < T; ++i) st[i] = sbox29<TR>(Fr29::reduce32(Fr29::add_l(st[i], k29(c, i))), ts);
 #pragma unroll
                 for (int i = 0; i < T; ++i) tmp[i] = dot29<T>(m + 9 * i * T, st);
 #pragma unroll
@@ -357,7 +382,7 @@ ZK_D void permute29(Fr29 (&st)[T], const u32* rc, const u32* m, const u32* prc, 
 #pragma unroll
             for (int i = 0; i < T; ++i) sb[i] = st[i];
 #pragma unroll 1
-            for (int i = 0; i < T; ++i) sb[i] = pow5_29(Fr29::reduce32(Fr29::add_l(sb[i], k29(c, i))));
+            for (int i = 0; i < T; ++i) sb[i] = sbox29<TR>(Fr29::reduce32(Fr29::add_l(sb[i], k29(c, i))), ts);
 #pragma unroll 1
             for (int i = 0; i < T; ++i) tmp[i] = dot29<T>(m + 9 * i * T, sb);
 #pragma unroll
@@ -368,7 +393,7 @@ ZK_D void permute29(Fr29 (&st)[T], const u32* rc, const u32* m, const u32* prc, 
         for (int i = 0; i < rp; ++i) {
             const u32* k = prc + 9 * T * i;
             const u32* s = sp + 9 * (2 * T - 1) * i;
-            st[0] = pow5_29(Fr29::reduce32(Fr29::add_l(st[0], k29(k, 0))));  // x0
+            st[0] = sbox29<TR>(Fr29::reduce32(Fr29::add_l(st[0], k29(k, 0))), ts);  // x0
 #pragma unroll
             for (int j = 1; j < T; ++j) st[j] = Fr29::reduce32(Fr29::add_l(st[j], k29(k, j)));
             Fr29 acc = dot29<T>(s, st);
@@ -497,6 +522,91 @@ __global__ __launch_bounds__(64, 2) void k_hash_many(const Fr* __restrict__ in, 
     const Fr* x = in + (size_t)i * len;
     for (u32 k = 0; k < len; ++k) sp.push(P, x[k]);
     out[i] = sp.finish(P);
+}
+
+// ---- structured witness generation: wire families of BatchCreateUserCircuit that are data-parallel ----------
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int T>
+__device__ __noinline__ void trace_block29(Fr* st, const PosDev& P, TraceSink* ts) {
+    Fr29 s29[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) s29[i] = Fr29::from32<5>(st[i]);
+    auto uni = [](const u32* p) {
+        u64 v = (u64)(uintptr_t)p;
+        u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+        return (const u32*)(uintptr_t)(((u64)hi << 32) | lo);
+    };
+    const u32* b = P.tab29;
+    const int rp = __builtin_amdgcn_readfirstlane(P.rp[T]);
+    permute29<T, true>(s29, uni(b + 9 * (size_t)P.rc_off[T]), uni(b + 9 * (size_t)P.mds_off[T]), uni(b + 9 * (size_t)P.prc_off[T]),
+                       uni(b + 9 * (size_t)P.sp_off[T]), uni(b + 9 * (size_t)P.post_off[T]), rp, ts);
+#pragma unroll
+    for (int i = 0; i < T; ++i) st[i] = Fr29::to32_div32(s29[i]);
+}
+#endif
+// one permutation per thread: states[perm * T + i] in, final state out (in place), the S-box wires to trace
+template <int T>
+__global__ __launch_bounds__(64, 2) void k_poseidon_trace(Fr* __restrict__ states, size_t count, Fr* __restrict__ trace, PosDev P) {
+    size_t i = (size_t)blockIdx.x * 64u + threadIdx.x;
+    if (i >= count) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fr st[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) st[k] = states[i * T + k];
+    TraceSink ts{trace, count, i, 0u};
+    trace_block29<T>(st, P, &ts);
+#pragma unroll
+    for (int k = 0; k < T; ++k) states[i * T + k] = st[k];
+#endif
+}
+
+// range-check limbs (gnark std/rangecheck with a commitment: every checked value is cut into 16-bit limbs, each limb is a committed
+// wire and one query of the 2^16-entry table of the log-derivative argument): limbs[l * n + i] = limb l of value i as a Montgomery Fr,
+// multiplicity[limb] += 1 (the m_i wires of the argument).  Values at or above 2^(16 nb_limbs) are counted in *bad.
+__global__ __launch_bounds__(256) void k_witgen_limbs(const Fr* __restrict__ values, size_t n, int nb_limbs, Fr* __restrict__ limbs, u32* __restrict__ mult, u32* __restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    Fr c = Fr::from_mont(values[i]);
+    bool over = false;
+    for (int l = 0; l < 16; ++l) {
+        u32 d = (c.v[l >> 1] >> ((l & 1) * 16)) & 0xffffu;
+        if (l < nb_limbs) {
+            Fr x = Fr::zero();
+            x.v[0] = d;
+            limbs[(size_t)l * n + i] = Fr::to_mont(x);
+            atomicAdd(mult + d, 1u);
+        } else if (d) over = true;
+    }
+    if (over) atomicAdd(bad, 1u);
+}
+// log-derivative inverse wires: out[i] = 1 / (challenge - v[i]); chunks of 8 per thread share one inversion (Montgomery's trick).
+// A zero denominator (a value equal to the challenge: probability 2^-254 for an honest challenge) gives 0 and is counted.
+__global__ __launch_bounds__(128) void k_witgen_inverse(const Fr* __restrict__ values, size_t n, Fr challenge, Fr* __restrict__ out, u32* __restrict__ bad) {
+    const size_t t = (size_t)blockIdx.x * 128u + threadIdx.x;
+    const size_t lo = t * 8u;
+    if (lo >= n) return;
+    const int m = (int)((n - lo) < 8 ? (n - lo) : 8);
+    Fr d[8], pre[8];
+    Fr run = Fr::one();
+    u32 zeros = 0;
+    for (int j = 0; j < m; ++j) {
+        d[j] = Fr::sub(challenge, values[lo + j]);
+        if (d[j].is_zero()) { d[j] = Fr::one(); zeros |= 1u << j; }
+        pre[j] = run;
+        run = Fr::mul(run, d[j]);
+    }
+    Fr inv = Fr::inv(run);
+    for (int j = m - 1; j >= 0; --j) {
+        Fr r = Fr::mul(inv, pre[j]);
+        inv = Fr::mul(inv, d[j]);
+        out[lo + j] = ((zeros >> j) & 1u) ? Fr::zero() : r;
+    }
+    if (zeros) atomicAdd(bad, (u32)__popc(zeros));
+}
+// w[wire_ids[i]] = src[i]: the slots of a generator land on the wire ids of the compiled circuit (the map is part of the solver export)
+__global__ __launch_bounds__(256) void k_witgen_scatter(Fr* __restrict__ w, const Fr* __restrict__ src, const u32* __restrict__ wire_ids, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) w[wire_ids[i]] = src[i];
 }
 
 struct AccountHdr {
@@ -974,6 +1084,60 @@ int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, 
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(din); (void)hipFree(dout);
     return rc;
+}
+
+size_t zkpor_witgen_poseidon_sboxes(int t) {
+    if (t != 3 && t != 5 && t != 6 && t != 13) return 0;
+    return (size_t)POS_RF * t + (size_t)pos_rp(t);
+}
+
+int32_t zkpor_witgen_poseidon_trace_dev(zkpor_ctx* ctx, int t, void* d_states, size_t count, void* d_trace) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !d_states || !d_trace || count == 0) return ZKPOR_E_ARG;
+    if (t != 3 && t != 5 && t != 6 && t != 13) { ctx->err = "witgen: the circuit's Poseidon widths are 3, 5, 6 and 13"; return ZKPOR_E_ARG; }
+    PosDev P;
+    ZK_TRY(pos_dev(ctx, &P));
+    if (!P.tab29) { ctx->err = "witgen: the 29-bit Poseidon tables are not available"; return ZKPOR_E_STATE; }
+    PhaseScope ps(ctx, "witgen_poseidon");
+    dim3 grid((unsigned)((count + 63) / 64)), block(64);
+    if (t == 3) hipLaunchKernelGGL(k_poseidon_trace<3>, grid, block, 0, ctx->stream, (Fr*)d_states, count, (Fr*)d_trace, P);
+    else if (t == 5) hipLaunchKernelGGL(k_poseidon_trace<5>, grid, block, 0, ctx->stream, (Fr*)d_states, count, (Fr*)d_trace, P);
+    else if (t == 6) hipLaunchKernelGGL(k_poseidon_trace<6>, grid, block, 0, ctx->stream, (Fr*)d_states, count, (Fr*)d_trace, P);
+    else hipLaunchKernelGGL(k_poseidon_trace<13>, grid, block, 0, ctx->stream, (Fr*)d_states, count, (Fr*)d_trace, P);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_witgen_limbs_dev(zkpor_ctx* ctx, const void* d_values, size_t n, int nb_limbs, void* d_limbs, void* d_multiplicity, void* d_bad) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !d_values || !d_limbs || !d_multiplicity || !d_bad || n == 0 || nb_limbs < 1 || nb_limbs > 15) return ZKPOR_E_ARG;
+    PhaseScope ps(ctx, "witgen_limbs");
+    hipLaunchKernelGGL(k_witgen_limbs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_values, n, nb_limbs, (Fr*)d_limbs,
+                       (u32*)d_multiplicity, (u32*)d_bad);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_witgen_inverse_dev(zkpor_ctx* ctx, const void* d_values, size_t n, const uint64_t challenge[4], void* d_out, void* d_bad) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !d_values || !d_out || !d_bad || !challenge || n == 0) return ZKPOR_E_ARG;
+    Fr c;
+    memcpy(&c, challenge, sizeof c);
+    PhaseScope ps(ctx, "witgen_inverse");
+    const size_t threads = (n + 7) / 8;
+    hipLaunchKernelGGL(k_witgen_inverse, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, ctx->stream, (const Fr*)d_values, n, c, (Fr*)d_out, (u32*)d_bad);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, const uint32_t* d_wire_ids, size_t n) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !d_w || !d_src || !d_wire_ids) return ZKPOR_E_ARG;
+    if (n == 0) return ZKPOR_OK;
+    PhaseScope ps(ctx, "witgen_scatter");
+    hipLaunchKernelGGL(k_witgen_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_w, (const Fr*)d_src, d_wire_ids, n);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
 }
 
 int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, const zkpor_asset_t* assets,

@@ -117,6 +117,66 @@ class Context:
     def fill_fr(self, buf, n, seed, kind=0):
         self._ck(self.lib.zkpor_dev_fill_fr(self.h, ctypes.c_void_p(buf.ptr), ctypes.c_size_t(n), ctypes.c_uint64(seed), ctypes.c_int(kind)))
 
+    # ---- structured witness generation (include/zkpor.h zkpor_witgen_*) ----
+    def witgen_poseidon_sboxes(self, t):
+        self.lib.zkpor_witgen_poseidon_sboxes.restype = ctypes.c_size_t
+        return int(self.lib.zkpor_witgen_poseidon_sboxes(ctypes.c_int(t)))
+
+    def witgen_poseidon_trace_dev(self, t, d_states, count, d_trace):
+        self._ck(self.lib.zkpor_witgen_poseidon_trace_dev(self.h, ctypes.c_int(t), ctypes.c_void_p(d_states), ctypes.c_size_t(count), ctypes.c_void_p(d_trace)))
+
+    def witgen_poseidon_trace(self, states, t):
+        """host convenience (tests): (final states, trace[(s * 3 + c), i]) of len(states) permutations of width t"""
+        st = _u64(states).reshape(-1, t, 4)
+        n = st.shape[0]
+        ns = self.witgen_poseidon_sboxes(t)
+        ds = self.alloc(st.nbytes).upload(st)
+        dt = self.alloc(3 * ns * n * 32)
+        try:
+            self.witgen_poseidon_trace_dev(t, ds.ptr, n, dt.ptr)
+            return ds.download(np.uint64, (n, t, 4)), dt.download(np.uint64, (3 * ns, n, 4))
+        finally:
+            ds.free(); dt.free()
+
+    def witgen_limbs_dev(self, d_values, n, nb_limbs, d_limbs, d_mult, d_bad):
+        self._ck(self.lib.zkpor_witgen_limbs_dev(self.h, ctypes.c_void_p(d_values), ctypes.c_size_t(n), ctypes.c_int(nb_limbs), ctypes.c_void_p(d_limbs),
+                                                 ctypes.c_void_p(d_mult), ctypes.c_void_p(d_bad)))
+
+    def witgen_limbs(self, values, nb_limbs):
+        """host convenience (tests): (limbs[l, i] as Montgomery Fr, multiplicities of the 2^16 table, number of values out of range)"""
+        v = _u64(values).reshape(-1, 4)
+        n = v.shape[0]
+        dv = self.alloc(v.nbytes).upload(v)
+        dl = self.alloc(nb_limbs * n * 32)
+        dm = self.alloc(65536 * 4).upload(np.zeros(65536, np.uint32))
+        db = self.alloc(4).upload(np.zeros(1, np.uint32))
+        try:
+            self.witgen_limbs_dev(dv.ptr, n, nb_limbs, dl.ptr, dm.ptr, db.ptr)
+            return dl.download(np.uint64, (nb_limbs, n, 4)), dm.download(np.uint32, (65536,)), int(db.download(np.uint32, (1,))[0])
+        finally:
+            for b in (dv, dl, dm, db):
+                b.free()
+
+    def witgen_inverse_dev(self, d_values, n, challenge, d_out, d_bad):
+        c = _u64(challenge).reshape(4)
+        self._ck(self.lib.zkpor_witgen_inverse_dev(self.h, ctypes.c_void_p(d_values), ctypes.c_size_t(n), _p(c), ctypes.c_void_p(d_out), ctypes.c_void_p(d_bad)))
+
+    def witgen_inverse(self, values, challenge):
+        v = _u64(values).reshape(-1, 4)
+        n = v.shape[0]
+        dv = self.alloc(v.nbytes).upload(v)
+        do = self.alloc(v.nbytes)
+        db = self.alloc(4).upload(np.zeros(1, np.uint32))
+        try:
+            self.witgen_inverse_dev(dv.ptr, n, challenge, do.ptr, db.ptr)
+            return do.download(np.uint64, (n, 4)), int(db.download(np.uint32, (1,))[0])
+        finally:
+            for b in (dv, do, db):
+                b.free()
+
+    def witgen_scatter_dev(self, d_w, d_src, d_wire_ids, n):
+        self._ck(self.lib.zkpor_witgen_scatter_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_src), ctypes.c_void_p(d_wire_ids), ctypes.c_size_t(n)))
+
     # ---- MSM ----
     def msm_g1(self, points, scalars):
         points = _u64(points); scalars = _u64(scalars)
