@@ -1,0 +1,172 @@
+// export_solver: one-off exporter of the SOLVER PROGRAM of a compiled gnark constraint system — what r1cs.Solve walks inside
+// groth16.Prove (src/prover/prover/prover.go:269) — to the flat container zkmerkle-proof-of-solvency_amd/host/solver_exec.hpp executes
+// on all host threads (SURVEY.md §8 f4).  Companion of export_r1cs (the matrices).  NOT COMPILED in the authoring image (no Go
+// toolchain; written against bnb-chain/gnark v0.10.1-0.20240910145009-4b5261061f04, go.mod:57) — go/README.md.
+//
+//	go run ./export_solver zkpor50_1380.r1cs zkpor50_1380.zksolv
+//
+// gnark (constraint/core.go, 3P) stores a compiled system as
+//	Instructions []PackedInstruction{BlueprintID, ConstraintOffset, WireOffset, StartCallData}, CallData []uint32,
+//	Blueprints []Blueprint, Levels [][]int (instruction ids that are mutually independent)
+// and the solver dispatches per blueprint: BlueprintGenericR1C -> solve the instruction's ONE constraint for its single unknown wire;
+// BlueprintGenericHint -> decode a HintMapping{HintID, Inputs []LinearExpression, OutputRange} from the call data and call the hint;
+// every other blueprint of the R1CS builder (e.g. the lookup blueprint of the bnb fork) is either a solver (BlueprintSolvable: it fills
+// wires itself) or a hint carrier (BlueprintHint).  This exporter flattens that into:
+//
+//	magic "ZKPSOLV\x01"
+//	u64 nInstructions, nLevels, nHintNames, nCallData
+//	hint names: u32 length + bytes each; pad to 8
+//	u32 kind[nInstructions]   0 = solve constraint arg; 1 = hint, call data at arg; 2 = skipped (wires produced by a device generator)
+//	u32 arg[nInstructions]
+//	u64 levelPtr[nLevels+1]; u32 levelInstr[...]; pad to 8
+//	u32 callData[]: per hint  nameId, nIn, nOut, outWire[nOut], then per input  nTerms, (coeffId, wireId)[nTerms]
+//
+// Hint names are the registered function names (solver.GetHintName), e.g. "…/circuit.IntegerDivision", "…/std/math/bits.nBits",
+// "…/constraint/solver.InvZeroHint", "…/std/rangecheck.DecomposeHint", "…/frontend/cs.Bsb22CommitmentComputePlaceholder"; the executor
+// binds its native implementations by the LAST path element (host/solver_exec.hpp HintRegistry) and refuses a program that calls a hint it
+// does not implement.  The wire families a device generator produces are marked with -skip (a file of instruction ids, one per line, written
+// by the wire-map tool from the same compiled system); without it everything runs on the host.
+package main
+
+import (
+	"bufio"
+	"encoding/binary"
+	"fmt"
+	"os"
+	"strconv"
+	"strings"
+
+	"github.com/consensys/gnark-crypto/ecc"
+	"github.com/consensys/gnark/backend/groth16"
+	"github.com/consensys/gnark/constraint"
+	cs_bn254 "github.com/consensys/gnark/constraint/bn254"
+	"github.com/consensys/gnark/constraint/solver"
+)
+
+func main() {
+	if len(os.Args) < 3 {
+		fmt.Println("usage: export_solver <in.r1cs> <out.zksolv> [-skip ids.txt]")
+		os.Exit(2)
+	}
+	in, err := os.Open(os.Args[1])
+	if err != nil {
+		panic(err)
+	}
+	defer in.Close()
+	ccs := groth16.NewCS(ecc.BN254)
+	if _, err = ccs.ReadFrom(bufio.NewReaderSize(in, 1<<26)); err != nil {
+		panic(err)
+	}
+	r1cs := ccs.(*cs_bn254.R1CS)
+	skip := map[int]bool{}
+	if len(os.Args) == 5 && os.Args[3] == "-skip" {
+		f, err := os.Open(os.Args[4])
+		if err != nil {
+			panic(err)
+		}
+		sc := bufio.NewScanner(f)
+		for sc.Scan() {
+			if id, err := strconv.Atoi(strings.TrimSpace(sc.Text())); err == nil {
+				skip[id] = true
+			}
+		}
+		f.Close()
+	}
+
+	var names []string
+	nameID := map[string]uint32{}
+	intern := func(n string) uint32 {
+		if i := strings.LastIndexAny(n, "./"); i >= 0 {
+			n = n[i+1:]
+		}
+		if id, ok := nameID[n]; ok {
+			return id
+		}
+		nameID[n] = uint32(len(names))
+		names = append(names, n)
+		return nameID[n]
+	}
+
+	nIns := len(r1cs.Instructions)
+	kind := make([]uint32, nIns)
+	arg := make([]uint32, nIns)
+	var callData []uint32
+	for i, pi := range r1cs.Instructions {
+		ins := pi.Unpack(&r1cs.System)
+		bp := r1cs.Blueprints[pi.BlueprintID]
+		switch b := bp.(type) {
+		case constraint.BlueprintR1C: // BlueprintGenericR1C: exactly one constraint
+			_ = b
+			kind[i], arg[i] = 0, uint32(ins.ConstraintOffset)
+		case constraint.BlueprintHint: // BlueprintGenericHint and the hint-carrying blueprints of the std gadgets
+			var hm constraint.HintMapping
+			b.DecompressHint(&hm, ins)
+			kind[i], arg[i] = 1, uint32(len(callData))
+			nOut := hm.OutputRange.End - hm.OutputRange.Start
+			callData = append(callData, intern(solver.GetHintName(hm.HintID)), uint32(len(hm.Inputs)), nOut)
+			for w := hm.OutputRange.Start; w < hm.OutputRange.End; w++ {
+				callData = append(callData, w)
+			}
+			for _, le := range hm.Inputs {
+				callData = append(callData, uint32(len(le)))
+				for _, t := range le {
+					callData = append(callData, uint32(t.CoeffID()), uint32(t.WireID()))
+				}
+			}
+		default:
+			panic(fmt.Sprintf("instruction %d: blueprint %T is neither an R1C nor a hint carrier — extend the exporter", i, bp))
+		}
+		if skip[i] {
+			kind[i] = 2
+		}
+	}
+
+	out, err := os.Create(os.Args[2])
+	if err != nil {
+		panic(err)
+	}
+	defer out.Close()
+	w := bufio.NewWriterSize(out, 1<<26)
+	defer w.Flush()
+	n := 0
+	put := func(v interface{}) {
+		if err := binary.Write(w, binary.LittleEndian, v); err != nil {
+			panic(err)
+		}
+		n += binary.Size(v)
+	}
+	pad := func() {
+		for n%8 != 0 {
+			put(uint8(0))
+		}
+	}
+	nLevelEntries := 0
+	for _, l := range r1cs.Levels {
+		nLevelEntries += len(l)
+	}
+	w.WriteString("ZKPSOLV\x01")
+	n += 8
+	put([]uint64{uint64(nIns), uint64(len(r1cs.Levels)), uint64(len(names)), uint64(len(callData))})
+	for _, s := range names {
+		put(uint32(len(s)))
+		w.WriteString(s)
+		n += len(s)
+	}
+	pad()
+	put(kind)
+	put(arg)
+	pad()
+	ptr := make([]uint64, len(r1cs.Levels)+1)
+	flat := make([]uint32, 0, nLevelEntries)
+	for i, l := range r1cs.Levels {
+		for _, id := range l {
+			flat = append(flat, uint32(id))
+		}
+		ptr[i+1] = uint64(len(flat))
+	}
+	put(ptr)
+	put(flat)
+	pad()
+	put(callData)
+	fmt.Printf("%d instructions (%d skipped), %d levels, %d hint names %v, %d words of call data\n", nIns, len(skip), len(r1cs.Levels), len(names), names, len(callData))
+}

@@ -1,0 +1,143 @@
+"""CPU: the levelized solver executor (host/solver_exec.hpp, SURVEY.md §8 f4 — the host side of r1cs.Solve, prover.go:269) on a synthetic circuit
+with the gadget shapes of BatchCreateUserCircuit (tests/solver_circuit.py): the wire vector must equal the builder's Python-integer values bit for
+bit, a . b = c must hold on every row, any thread count must give the same result, wires pre-filled by another producer (the device generators)
+must be taken as they are, and every failure mode must be reported as an error, never as a wrong vector."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import solver_circuit as SC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = ctypes.CDLL(os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd", "libzkpor_host.so"))
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def solve(b, solver=None, threads=4, inputs=None, prefilled=None):
+    r1 = b.r1cs_bytes()
+    sv = b.solver_bytes() if solver is None else solver
+    n_in = b.n_public + b.n_secret
+    inp = SC.to_mont_limbs(b.val[:n_in]) if inputs is None else inputs
+    n_in = inp.shape[0]
+    nw, nc = len(b.val), len(b.rows)
+    w = np.zeros((nw, 4), np.uint64); a = np.zeros((nc, 4), np.uint64); bb = np.zeros((nc, 4), np.uint64); c = np.zeros((nc, 4), np.uint64)
+    stats = np.zeros(3, np.uint64)
+    err = ctypes.create_string_buffer(256)
+    ids = np.array([i for i, _ in (prefilled or [])], dtype=np.uint32)
+    vals = SC.to_mont_limbs([v for _, v in (prefilled or [])]) if prefilled else np.zeros((0, 4), np.uint64)
+    rc = LIB.zkh_solve(r1, ctypes.c_size_t(len(r1)), sv, ctypes.c_size_t(len(sv)), _p(inp), ctypes.c_size_t(n_in), _p(ids), _p(vals),
+                       ctypes.c_size_t(len(ids)), ctypes.c_int(threads), _p(w), _p(a), _p(bb), _p(c), _p(stats), err, ctypes.c_size_t(256))
+    return rc, w, a, bb, c, [int(x) for x in stats], err.value.decode()
+
+
+def test_host_field_arithmetic_against_python_integers():
+    rng = np.random.default_rng(1)
+    vals = [int.from_bytes(rng.bytes(32), "big") % SC.R for _ in range(50)] + [0, 1, SC.R - 1]
+    a = SC.to_mont_limbs(vals); b = SC.to_mont_limbs(vals[::-1])
+    out = np.zeros_like(a)
+    LIB.zkh_fr_mul(_p(a), _p(b), _p(out), ctypes.c_size_t(len(vals)))
+    assert np.array_equal(out, SC.to_mont_limbs([x * y % SC.R for x, y in zip(vals, vals[::-1])]))
+    LIB.zkh_fr_inv(_p(a), _p(out), ctypes.c_size_t(len(vals)))
+    assert np.array_equal(out, SC.to_mont_limbs([pow(x, SC.R - 2, SC.R) for x in vals]))
+    canon = np.zeros_like(a)
+    LIB.zkh_fr_to_canon(_p(a), _p(canon), ctypes.c_size_t(len(vals)))
+    assert [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in canon] == vals
+    LIB.zkh_fr_from_canon(_p(canon), _p(out), ctypes.c_size_t(len(vals)))
+    assert np.array_equal(out, a)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 16])
+@pytest.mark.parametrize("seed,users", [(1, 1), (2, 6), (3, 40)])
+def test_wire_vector_equals_the_builders(seed, users, threads):
+    b = SC.demo_circuit(seed, users)
+    rc, w, a, bb, c, stats, err = solve(b, threads=threads)
+    assert rc == 0, err
+    assert np.array_equal(w, SC.to_mont_limbs(b.val))
+    prod = np.zeros_like(a)
+    LIB.zkh_fr_mul(_p(a), _p(bb), _p(prod), ctypes.c_size_t(a.shape[0]))
+    assert np.array_equal(prod, c)                      # the evaluations the prove tail consumes satisfy a . b = c row by row
+    n_hint = sum(1 for k, _, _, _ in b.instr if k == 1)
+    assert stats == [len(b.instr) - n_hint, n_hint, 0]
+    # a, b, c are L.w, R.w, O.w
+    for row in (0, len(b.rows) // 2, len(b.rows) - 1):
+        for side, arr in enumerate((a, bb, c)):
+            exp = sum(b.val[wid] * next(v for v, i in b.coeffs.items() if i == cid) for cid, wid in b.rows[row][side]) % SC.R
+            assert np.array_equal(arr[row], SC.to_mont_limbs([exp])[0])
+
+
+def test_levels_are_real_parallel_structure():
+    b = SC.demo_circuit(5, 30)
+    lv = b.levels()
+    assert len(lv) > 10 and max(len(x) for x in lv) >= 30       # wide levels (users side by side), deep chains (S-boxes, accumulation)
+
+
+def test_prefilled_wires_from_another_producer_are_skipped():
+    """the S-box wires arrive from the device generators: their instructions are marked skipped, the values are taken as known"""
+    b = SC.demo_circuit(7, 8)
+    wires = b.wires_of_tag("sbox")
+    assert len(wires) == 8 * 2 * 3 * 3
+    sv = b.solver_bytes(skip_tags=("sbox",))
+    rc, w, *_rest, stats, err = solve(b, solver=sv, prefilled=[(i, b.val[i]) for i in wires])
+    assert rc == 0, err
+    assert np.array_equal(w, SC.to_mont_limbs(b.val)) and stats[2] == len(wires)
+    # without the values the dependants cannot be solved: an error, not a vector
+    rc, *_ = solve(b, solver=sv)
+    assert rc != 0
+    # a WRONG pre-filled value is caught by the final constraint check
+    bad = [(i, b.val[i]) for i in wires]
+    bad[5] = (bad[5][0], bad[5][1] ^ 1)
+    rc, *_x, err = solve(b, solver=sv, prefilled=bad)
+    assert rc != 0 and ("constraint" in err)
+
+
+def test_failures_are_errors():
+    b = SC.demo_circuit(9, 4)
+    n_in = b.n_public + b.n_secret
+    # 1. an input that violates a range check: the decomposition hint refuses
+    vals = list(b.val[:n_in]); vals[b.n_public] = 1 << 70
+    rc, *_x, err = solve(b, inputs=SC.to_mont_limbs(vals))
+    assert rc != 0 and "hint" in err
+    # 2. an assertion that does not hold (the zero-test input is not zero and the circuit asserts nothing about it... use the public tail)
+    vals = list(b.val[:n_in]); vals[b.n_public + 4] = 0          # a zero price: IntegerDivision refuses like big.Int.DivMod panics
+    rc, *_x, err = solve(b, inputs=SC.to_mont_limbs(vals))
+    assert rc != 0
+    # 3. levels in the wrong order: an instruction meets two unknown wires or an unsolved hint input
+    lv = b.levels()
+    rc, *_x, err = solve(b, solver=b.solver_bytes(levels=lv[::-1]))
+    assert rc != 0 and ("unknown" in err or "not solved" in err)
+    # 4. an instruction missing from the levels: a wire is never assigned
+    short = [l[:] for l in lv]; short[-2] = short[-2][:-1]
+    rc, *_x, err = solve(b, solver=b.solver_bytes(levels=short))
+    assert rc != 0
+    # 5. a hint without a native implementation
+    b2 = SC.demo_circuit(9, 2)
+    b2.hint_names[b2.hint_names.index("InvZero")] = "SomeHintOfAnotherCircuit"
+    rc, *_x, err = solve(b2)
+    assert rc != 0 and "no native implementation" in err
+    # 6. wrong number of inputs
+    rc, *_x, err = solve(b, inputs=SC.to_mont_limbs(b.val[:n_in - 1]))
+    assert rc != 0
+
+
+def test_solver_container_is_validated():
+    b = SC.demo_circuit(4, 3)
+    sv = b.solver_bytes()
+    counts = (ctypes.c_uint64 * 4)()
+    err = ctypes.create_string_buffer(200)
+    assert LIB.zkh_solver_parse(sv, ctypes.c_size_t(len(sv)), counts, err, ctypes.c_size_t(200)) == 0
+    assert list(counts) == [len(b.instr), len(b.levels()), len(b.hint_names), len(b.calldata)]
+    for cut in (4, 20, 41, len(sv) // 2, len(sv) - 3):
+        assert LIB.zkh_solver_parse(sv[:cut], ctypes.c_size_t(cut), counts, err, ctypes.c_size_t(200)) != 0
+    bad = bytearray(sv); bad[0] = ord("X")
+    assert LIB.zkh_solver_parse(bytes(bad), ctypes.c_size_t(len(bad)), counts, err, ctypes.c_size_t(200)) != 0
+    rng = np.random.default_rng(0)
+    for _ in range(300):                     # mutated containers end in an error or a parse, never in a crash
+        m = bytearray(sv)
+        for _k in range(int(rng.integers(1, 4))):
+            m[int(rng.integers(8, len(m)))] = int(rng.integers(0, 256))
+        LIB.zkh_solver_parse(bytes(m), ctypes.c_size_t(len(m)), counts, err, ctypes.c_size_t(200))

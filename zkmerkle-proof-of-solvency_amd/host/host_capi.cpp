@@ -6,6 +6,7 @@
 #include "witness_codec.hpp"
 #include "witness_assign.hpp"
 #include "bsb22_challenge.hpp"
+#include "solver_exec.hpp"
 #include <atomic>
 #include <cstring>
 using namespace zkpor_host;
@@ -232,5 +233,48 @@ int zkh_bsb22_challenge(const uint8_t commitment[64], const uint8_t* public_be32
         memcpy(out, c.data(), 32);
         return 0;
     } catch (const std::exception&) { return 1; }
+}
+
+// ---- the levelized solver executor (host/solver_exec.hpp): no device involved ----
+// field helpers for the tests: out = a * b, out = a^-1 (Montgomery limbs), canonical <-> Montgomery
+void zkh_fr_mul(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    for (size_t i = 0; i < n; ++i) { FrH x, y; memcpy(x.v, a + 4 * i, 32); memcpy(y.v, b + 4 * i, 32); FrH r = FrH::mul(x, y); memcpy(out + 4 * i, r.v, 32); }
+}
+void zkh_fr_inv(const uint64_t* a, uint64_t* out, size_t n) {
+    for (size_t i = 0; i < n; ++i) { FrH x; memcpy(x.v, a + 4 * i, 32); FrH r = FrH::inv(x); memcpy(out + 4 * i, r.v, 32); }
+}
+void zkh_fr_from_canon(const uint64_t* c, uint64_t* out, size_t n) { for (size_t i = 0; i < n; ++i) { FrH r = FrH::from_canon(c + 4 * i); memcpy(out + 4 * i, r.v, 32); } }
+void zkh_fr_to_canon(const uint64_t* a, uint64_t* out, size_t n) { for (size_t i = 0; i < n; ++i) { FrH x; memcpy(x.v, a + 4 * i, 32); x.to_canon(out + 4 * i); } }
+// header walk of the solver container: counts = nInstructions, nLevels, nHintNames, nCallData
+int zkh_solver_parse(const uint8_t* data, size_t len, uint64_t counts[4], char* err, size_t err_len) {
+    SolverView v;
+    std::string why;
+    if (ParseSolverFile(data, len, &v, &why) != 0) {
+        if (err && err_len) { size_t n = why.size() < err_len - 1 ? why.size() : err_len - 1; memcpy(err, why.data(), n); err[n] = 0; }
+        return 1;
+    }
+    counts[0] = v.n_instructions; counts[1] = v.n_levels; counts[2] = v.hint_names.size(); counts[3] = v.n_calldata;
+    return 0;
+}
+// solve: inputs = nPublic + nSecret elements; pre_ids / pre_vals = wires filled elsewhere (the device generators); w_out nWires x 4,
+// a/b/c_out nConstraints x 4; stats = solved constraints, hint calls, skipped instructions.  0 = ok, else the executor's code + err text
+int zkh_solve(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* solv, size_t solv_len, const uint64_t* inputs, size_t n_inputs,
+              const uint32_t* pre_ids, const uint64_t* pre_vals, size_t n_pre, int threads, uint64_t* w_out, uint64_t* a_out, uint64_t* b_out,
+              uint64_t* c_out, uint64_t stats[3], char* err, size_t err_len) {
+    auto put = [&](const std::string& why) { if (err && err_len) { size_t n = why.size() < err_len - 1 ? why.size() : err_len - 1; memcpy(err, why.data(), n); err[n] = 0; } };
+    R1csFileView rv;
+    SolverView sv;
+    std::string why;
+    if (ParseR1csFile(r1cs, r1cs_len, &rv, &why) != 0) { put(why); return 1; }
+    if (ParseSolverFile(solv, solv_len, &sv, &why) != 0) { put(why); return 1; }
+    std::vector<std::pair<uint32_t, FrH>> pre(n_pre);
+    for (size_t i = 0; i < n_pre; ++i) { pre[i].first = pre_ids[i]; memcpy(pre[i].second.v, pre_vals + 4 * i, 32); }
+    SolveResult res;
+    int rc = SolveLevelized(rv, sv, inputs, n_inputs, HintRegistry::Standard(), pre, threads, &res, &why);
+    if (rc != 0) { put(why); return rc; }
+    memcpy(w_out, res.w.data(), res.w.size() * 8);
+    memcpy(a_out, res.a.data(), res.a.size() * 8); memcpy(b_out, res.b.data(), res.b.size() * 8); memcpy(c_out, res.c.data(), res.c.size() * 8);
+    stats[0] = res.solved_constraints; stats[1] = res.hint_calls; stats[2] = res.skipped;
+    return 0;
 }
 }

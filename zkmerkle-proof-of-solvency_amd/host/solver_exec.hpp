@@ -1,0 +1,286 @@
+// Levelized executor of a compiled R1CS's solver program — the host side of SURVEY.md §8 f4.
+//
+// What it replaces: r1cs.Solve inside groth16.Prove (src/prover/prover/prover.go:269; gnark constraint/bn254/solver.go, 3P): gnark's
+// solver walks `Levels [][]int` — sets of mutually independent instructions — and, per instruction, either solves ONE constraint for its
+// single unknown wire or calls a hint (circuit.IntegerDivision registered at prover.go:68, the std hints behind ToBinary / IsZero / range
+// checks / lookups, and the BSB22 commitment placeholder).  go/export_solver (source; needs a box with Go) flattens that program — levels,
+// instruction kinds, hint names, hint inputs as linear expressions, output wires — into the container read here; the matrices come from
+// the r1cs container (host/r1cs_file.hpp).  The executor runs the levels on all host threads, leaves out the wires the DEVICE generators
+// produce (zkpor_witgen_*: their instructions are marked `skip`, their wires arrive pre-filled) and returns the full wire vector
+// w and the evaluations a, b, c that zkpor_prove_tail consumes.
+//
+// Container "ZKPSOLV\x01" (little-endian):
+//   u64 nInstructions, nLevels, nHintNames, nCallData
+//   hint names: per name u32 length + bytes, then padding to 8
+//   u32 kind[nInstructions]            0 = solve constraint `arg`; 1 = hint with call data at `arg`; 2 = same as 0/1 but skipped (pre-filled)
+//   u32 arg[nInstructions]
+//   u64 levelPtr[nLevels + 1]; u32 levelInstr[levelPtr[nLevels]]; pad to 8
+//   u32 callData[nCallData]: per hint  nameId, nIn, nOut, out wire ids[nOut], then per input: nTerms, (coeffId, wireId)[nTerms]
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fr_host.hpp"
+#include "r1cs_file.hpp"
+
+namespace zkpor_host {
+
+struct SolverView {
+    uint64_t n_instructions = 0, n_levels = 0, n_calldata = 0;
+    std::vector<std::string> hint_names;
+    const uint32_t* kind = nullptr;
+    const uint32_t* arg = nullptr;
+    const uint64_t* level_ptr = nullptr;
+    const uint32_t* level_instr = nullptr;
+    const uint32_t* calldata = nullptr;
+};
+enum { INSTR_R1C = 0, INSTR_HINT = 1, INSTR_SKIP = 2 };
+
+inline int ParseSolverFile(const uint8_t* data, size_t len, SolverView* out, std::string* err) {
+    auto fail = [&](const char* m) { if (err) *err = std::string("solver file: ") + m; return 1; };
+    size_t off = 0;
+    auto need = [&](uint64_t n) { return n <= len && off <= len - n; };
+    if (!data || !need(8) || memcmp(data, "ZKPSOLV\x01", 8) != 0) return fail("bad magic");
+    off = 8;
+    uint64_t h[4];
+    if (!need(sizeof h)) return fail("truncated header");
+    memcpy(h, data + off, sizeof h); off += sizeof h;
+    SolverView v;
+    v.n_instructions = h[0]; v.n_levels = h[1]; v.n_calldata = h[3];
+    const uint64_t n_names = h[2];
+    if (v.n_instructions >= (1ull << 32) || v.n_levels > v.n_instructions + 1 || n_names > 4096 || v.n_calldata >= (1ull << 40)) return fail("bad counts");
+    for (uint64_t i = 0; i < n_names; ++i) {
+        uint32_t l;
+        if (!need(4)) return fail("truncated names");
+        memcpy(&l, data + off, 4); off += 4;
+        if (l > 256 || !need(l)) return fail("bad name");
+        v.hint_names.emplace_back((const char*)data + off, l); off += l;
+    }
+    off += (8 - off % 8) % 8;
+    auto take32 = [&](uint64_t n, const uint32_t** p) { if (!need(n * 4)) return false; *p = (const uint32_t*)(data + off); off += n * 4; return true; };
+    if (!take32(v.n_instructions, &v.kind) || !take32(v.n_instructions, &v.arg)) return fail("truncated instruction table");
+    off += (8 - off % 8) % 8;
+    if (!need((v.n_levels + 1) * 8)) return fail("truncated levels");
+    v.level_ptr = (const uint64_t*)(data + off); off += (v.n_levels + 1) * 8;
+    if (v.level_ptr[0] != 0) return fail("levels must start at 0");
+    for (uint64_t l = 0; l < v.n_levels; ++l) if (v.level_ptr[l + 1] < v.level_ptr[l]) return fail("levels not monotone");
+    const uint64_t n_li = v.level_ptr[v.n_levels];
+    if (n_li > v.n_instructions) return fail("more level entries than instructions");
+    if (!take32(n_li, &v.level_instr)) return fail("truncated level entries");
+    off += (8 - off % 8) % 8;
+    if (!take32(v.n_calldata, &v.calldata)) return fail("truncated call data");
+    for (uint64_t i = 0; i < n_li; ++i) if (v.level_instr[i] >= v.n_instructions) return fail("level entry out of range");
+    for (uint64_t i = 0; i < v.n_instructions; ++i) if (v.kind[i] > 3) return fail("unknown instruction kind");
+    *out = std::move(v);
+    return 0;
+}
+
+// A hint works on field elements; integer-valued ones convert through U256 (gnark hands *big.Int in [0, r)).  Return non-zero to fail.
+typedef std::function<int(const std::vector<FrH>& in, std::vector<FrH>& out)> HintFn;
+
+struct HintRegistry {
+    std::map<std::string, HintFn> by_name;
+    // the hints whose semantics are fixed by their source text and that BatchCreateUserCircuit reaches:
+    static HintRegistry Standard() {
+        HintRegistry r;
+        // circuit.IntegerDivision (circuit/utils.go:103-110): out[0], out[1] = DivMod(in[0], in[1])
+        r.by_name["IntegerDivision"] = [](const std::vector<FrH>& in, std::vector<FrH>& out) {
+            if (in.size() != 2 || out.size() != 2) return 1;
+            U256 a = U256::of(in[0]), b = U256::of(in[1]);
+            if (b.is_zero()) return 2;                    // big.Int.DivMod panics on a zero divisor
+            U256 q, m;
+            U256::divmod(a, b, &q, &m);
+            out[0] = q.fr(); out[1] = m.fr();
+            return 0;
+        };
+        // gnark std/math/bits NBits (behind api.ToBinary): out[i] = bit i of in[0]
+        r.by_name["NBits"] = [](const std::vector<FrH>& in, std::vector<FrH>& out) {
+            if (in.size() != 1) return 1;
+            U256 a = U256::of(in[0]);
+            for (size_t i = 0; i < out.size(); ++i) out[i] = a.bit((int)i) ? FrH::one() : FrH::zero();
+            return 0;
+        };
+        // gnark solver.InvZeroHint (behind api.IsZero / api.Inverse): 1 / in[0], or 0
+        r.by_name["InvZero"] = [](const std::vector<FrH>& in, std::vector<FrH>& out) {
+            if (in.size() != 1 || out.size() != 1) return 1;
+            out[0] = FrH::inv(in[0]);
+            return 0;
+        };
+        // gnark std/rangecheck DecomposeHint: in = (varSize, limbSize, value) -> out = limbs of limbSize bits, little-endian
+        r.by_name["DecomposeHint"] = [](const std::vector<FrH>& in, std::vector<FrH>& out) {
+            if (in.size() != 3) return 1;
+            U256 vs = U256::of(in[0]), ls = U256::of(in[1]), v = U256::of(in[2]);
+            if (ls.w[0] == 0 || ls.w[0] > 64 || (ls.w[1] | ls.w[2] | ls.w[3]) || vs.w[0] > 256) return 2;
+            const int limb = (int)ls.w[0];
+            if ((int)out.size() * limb < v.bitlen()) return 3;   // the value does not fit the requested limbs: the range check must fail
+            for (size_t i = 0; i < out.size(); ++i) {
+                uint64_t x = 0;
+                for (int b = 0; b < limb; ++b) if (v.bit((int)i * limb + b)) x |= (uint64_t)1 << b;
+                out[i] = FrH::from_u64(x);
+            }
+            return 0;
+        };
+        // gnark registers its hints under their Go function names; the exporter keeps the last path element
+        r.by_name["nBits"] = r.by_name["NBits"];
+        r.by_name["InvZeroHint"] = r.by_name["InvZero"];
+        return r;
+    }
+};
+
+struct SolveResult {
+    std::vector<uint64_t> w, a, b, c;   // n_wires / n_constraints x 4 limbs (Montgomery), the form zkpor_prove_tail takes
+    uint64_t solved_constraints = 0, hint_calls = 0, skipped = 0;
+};
+
+namespace detail {
+inline FrH coeff(const R1csFileView& r, uint32_t id) { FrH c; memcpy(c.v, r.coeff + 4 * (size_t)id, 32); return c; }
+// value of one side with at most one unknown wire: returns sum of known terms; *unk / *unk_coeff describe the unknown term (if any);
+// a second unknown wire sets *two
+inline FrH side(const R1csFileView& r, int which, size_t row, const FrH* w, const std::vector<uint8_t>& known, int64_t* unk, FrH* unk_coeff, bool* two) {
+    FrH acc = FrH::zero();
+    for (uint64_t k = r.row_ptr[which][row]; k < r.row_ptr[which][row + 1]; ++k) {
+        const uint32_t wid = r.wire_ids[which][k];
+        const FrH c = coeff(r, r.coeff_ids[which][k]);
+        if (known[wid]) acc = FrH::add(acc, FrH::mul(c, w[wid]));
+        else if (*unk < 0 || *unk == (int64_t)wid) { *unk_coeff = (*unk < 0) ? c : FrH::add(*unk_coeff, c); *unk = wid; }
+        else *two = true;
+    }
+    return acc;
+}
+}  // namespace detail
+
+// inputs: the assigned part of the wire vector in gnark's order (wire 0 = ONE, then public, then secret): n_public + n_secret elements.
+// prefilled: optional (wire id, value) pairs produced elsewhere (the device generators), taken as known from the start.
+// Returns 0, or a non-zero code with `err` set; on success every wire is assigned and every constraint holds (checked).
+inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint64_t* inputs, size_t n_inputs, const HintRegistry& hints,
+                          const std::vector<std::pair<uint32_t, FrH>>& prefilled, int threads, SolveResult* out, std::string* err) {
+    auto fail = [&](int code, const std::string& m) { if (err) *err = "solver: " + m; return code; };
+    if (n_inputs != r.n_public + r.n_secret) return fail(1, "the assignment must hold nPublic + nSecret elements");
+    const size_t nw = r.n_wires, nc = r.n_constraints;
+    std::vector<FrH> w(nw, FrH::zero());
+    std::vector<uint8_t> known(nw, 0);
+    memcpy(w.data(), inputs, n_inputs * 32);
+    for (size_t i = 0; i < n_inputs; ++i) known[i] = 1;
+    for (auto& pv : prefilled) { if (pv.first >= nw) return fail(1, "prefilled wire out of range"); w[pv.first] = pv.second; known[pv.first] = 1; }
+    std::vector<HintFn> fn(s.hint_names.size());
+    for (size_t i = 0; i < fn.size(); ++i) {
+        auto it = hints.by_name.find(s.hint_names[i]);
+        if (it != hints.by_name.end()) fn[i] = it->second;   // a missing one only matters if an instruction calls it
+    }
+    if (threads < 1) threads = 1;
+    std::atomic<int> bad{0};
+    std::string bad_msg;
+    std::atomic<uint64_t> n_r1c{0}, n_hint{0}, n_skip{0};
+    auto run_instr = [&](uint32_t ins) -> int {
+        const uint32_t kind = s.kind[ins], arg = s.arg[ins];
+        if (kind >= INSTR_SKIP) { ++n_skip; return 0; }
+        if (kind == INSTR_R1C) {
+            if (arg >= nc) return 10;
+            int64_t unk[3] = {-1, -1, -1};
+            FrH uc[3];
+            bool two = false;
+            FrH v[3];
+            for (int m = 0; m < 3; ++m) v[m] = detail::side(r, m, arg, w.data(), known, &unk[m], &uc[m], &two);
+            const int n_unk = (unk[0] >= 0) + (unk[1] >= 0) + (unk[2] >= 0);
+            if (two || n_unk > 1) return 11;                     // not solvable at this level: the export's levels are wrong
+            ++n_r1c;
+            if (n_unk == 0) return FrH::mul(v[0], v[1]) == v[2] ? 0 : 12;   // an assertion
+            FrH val;
+            int which = unk[0] >= 0 ? 0 : (unk[1] >= 0 ? 1 : 2);
+            if (uc[which].is_zero()) return 13;
+            if (which == 2) val = FrH::sub(FrH::mul(v[0], v[1]), v[2]);      // O_known + c x = L R
+            else {
+                const FrH& other = v[1 - which];
+                if (other.is_zero()) return 14;                              // gnark: "division by zero" — the wire is not determined
+                val = FrH::sub(FrH::mul(v[2], FrH::inv(other)), v[which]);   // (L_known + c x) R = O
+            }
+            val = FrH::mul(val, FrH::inv(uc[which]));
+            w[unk[which]] = val;
+            known[unk[which]] = 1;
+            return 0;
+        }
+        // hint
+        const uint32_t* cd = s.calldata + arg;
+        if (arg + 3 > s.n_calldata) return 20;
+        const uint32_t name = cd[0], n_in = cd[1], n_out = cd[2];
+        if (name >= fn.size() || !fn[name]) return 21;
+        size_t p = 3 + n_out;
+        std::vector<FrH> in(n_in), o(n_out);
+        for (uint32_t i = 0; i < n_in; ++i) {
+            if (arg + p >= s.n_calldata) return 20;
+            const uint32_t nt = cd[p++];
+            FrH acc = FrH::zero();
+            for (uint32_t k = 0; k < nt; ++k) {
+                const uint32_t cid = cd[p++], wid = cd[p++];
+                if (wid >= nw || cid >= r.n_coeff) return 22;
+                if (!known[wid]) return 23;
+                acc = FrH::add(acc, FrH::mul(detail::coeff(r, cid), w[wid]));
+            }
+            in[i] = acc;
+        }
+        if (fn[name](in, o) != 0) return 24;
+        for (uint32_t i = 0; i < n_out; ++i) { const uint32_t wid = cd[3 + i]; if (wid >= nw) return 22; w[wid] = o[i]; known[wid] = 1; }
+        ++n_hint;
+        return 0;
+    };
+    for (uint64_t l = 0; l < s.n_levels && !bad; ++l) {
+        const uint64_t lo = s.level_ptr[l], hi = s.level_ptr[l + 1];
+        const uint64_t n = hi - lo;
+        auto work = [&](uint64_t a0, uint64_t a1) {
+            for (uint64_t i = a0; i < a1 && !bad; ++i) {
+                int rc = run_instr(s.level_instr[i]);
+                if (rc) { int exp = 0; if (bad.compare_exchange_strong(exp, rc)) bad_msg = "instruction " + std::to_string(s.level_instr[i]) + " of level " + std::to_string(l); }
+            }
+        };
+        const int nt = (int)std::min<uint64_t>((uint64_t)threads, (n + 255) / 256);   // small levels are not worth a thread each
+        if (nt <= 1) { work(lo, hi); continue; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, lo + n * t / nt, lo + n * (t + 1) / nt);
+        for (auto& t : th) t.join();
+    }
+    if (bad) {
+        static const std::map<int, const char*> why = {{10, "constraint index out of range"}, {11, "more than one unknown wire (wrong level order)"},
+            {12, "constraint not satisfied"}, {13, "unknown wire with a zero coefficient"}, {14, "division by zero"}, {20, "call data out of range"},
+            {21, "no native implementation for this hint"}, {22, "wire or coefficient id out of range"}, {23, "hint input not solved yet"}, {24, "hint failed"}};
+        auto it = why.find(bad.load());
+        return fail(bad.load(), std::string(it != why.end() ? it->second : "error") + " at " + bad_msg);
+    }
+    for (size_t i = 0; i < nw; ++i) if (!known[i]) return fail(30, "wire " + std::to_string(i) + " was never assigned");
+    // a, b, c and the final check of every constraint (parallel over constraints)
+    out->w.resize(nw * 4); out->a.resize(nc * 4); out->b.resize(nc * 4); out->c.resize(nc * 4);
+    memcpy(out->w.data(), w.data(), nw * 32);
+    std::atomic<int64_t> first_bad{-1};
+    auto eval = [&](size_t a0, size_t a1) {
+        for (size_t row = a0; row < a1; ++row) {
+            FrH v[3];
+            for (int m = 0; m < 3; ++m) {
+                FrH acc = FrH::zero();
+                for (uint64_t k = r.row_ptr[m][row]; k < r.row_ptr[m][row + 1]; ++k)
+                    acc = FrH::add(acc, FrH::mul(detail::coeff(r, r.coeff_ids[m][k]), w[r.wire_ids[m][k]]));
+                v[m] = acc;
+            }
+            memcpy(&out->a[4 * row], v[0].v, 32); memcpy(&out->b[4 * row], v[1].v, 32); memcpy(&out->c[4 * row], v[2].v, 32);
+            if (!(FrH::mul(v[0], v[1]) == v[2])) { int64_t e = -1; first_bad.compare_exchange_strong(e, (int64_t)row); }
+        }
+    };
+    {
+        const int nt = (int)std::min<size_t>((size_t)threads, (nc + 1023) / 1024);
+        if (nt <= 1) eval(0, nc);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(eval, nc * t / nt, nc * (t + 1) / nt);
+            for (auto& t : th) t.join();
+        }
+    }
+    if (first_bad >= 0) return fail(31, "constraint " + std::to_string(first_bad.load()) + " does not hold for the solved wires");
+    out->solved_constraints = n_r1c; out->hint_calls = n_hint; out->skipped = n_skip;
+    return 0;
+}
+
+}  // namespace zkpor_host
