@@ -148,6 +148,59 @@ def solver_budget(gpu_ms_per_proof, host_threads, gpus_per_node=8):
                     "(a, b, c evaluated in HBM, zkpor_r1cs_*) already built"}
 
 
+def usable_cpus():
+    """CPUs this process may really use: min(logical, affinity mask, cgroup v2 quota)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def host_executor_leg(threads):
+    """SURVEY.md §8 f4, host side, measured: host/solver_exec.hpp (the levelized executor of a compiled circuit's solver program — the generic
+    fallback for every wire the device generators do not produce) on a synthetic circuit with the gadget shapes of BatchCreateUserCircuit
+    (tests/solver_circuit.py: range checks, bit decompositions, the IntegerDivision hint, zero tests, S-box chains, inverses; users side by
+    side = wide levels).  The wire vector is compared with the builder's Python-integer values.  No device, no oracle."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import solver_circuit as SC
+    lib = ctypes.CDLL(os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd", "libzkpor_host.so"))
+    b = SC.demo_circuit(11, 1500, chain=False)
+    r1, sv = b.r1cs_bytes(), b.solver_bytes()
+    n_in = b.n_public + b.n_secret
+    inp = SC.to_mont_limbs(b.val[:n_in])
+    nw, nc = len(b.val), len(b.rows)
+    w = np.zeros((nw, 4), np.uint64); a = np.zeros((nc, 4), np.uint64); bb = np.zeros((nc, 4), np.uint64); c = np.zeros((nc, 4), np.uint64)
+    st = np.zeros(3, np.uint64); err = ctypes.create_string_buffer(256)
+    ids = np.zeros(1, np.uint32); vals = np.zeros((1, 4), np.uint64)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    rates = {}
+    ok = True
+    for th in sorted({1, max(1, threads)}):
+        best = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = lib.zkh_solve(r1, ctypes.c_size_t(len(r1)), sv, ctypes.c_size_t(len(sv)), p(inp), ctypes.c_size_t(n_in), p(ids), p(vals), ctypes.c_size_t(0),
+                               ctypes.c_int(th), p(w), p(a), p(bb), p(c), p(st), err, ctypes.c_size_t(256))
+            best = min(best, time.perf_counter() - t0)
+            ok = ok and rc == 0
+        rates[th] = len(b.instr) / best
+    ok = ok and bool(np.array_equal(w, SC.to_mont_limbs(b.val)))
+    levels = b.levels()
+    return {"instructions": len(b.instr), "constraints": nc, "wires": nw, "levels": len(levels), "hint_calls": int(st[1]),
+            "instructions_per_s": {f"threads_{k}": v for k, v in rates.items()}, "wire_vector_equals_builder": ok,
+            "note": "synthetic circuit of the real one's gadget shapes, 1500 independent users; ~4 field inversions per 52 instructions (the real "
+                    "circuit's inverse wires are the device generators')"}
+
+
 def shard_heights(n_batches, rank, world):
     """contiguous shard of batch heights for this rank: every height exactly once (host/prover_host.hpp shard_range)"""
     base, extra = divmod(n_batches, world)
@@ -1149,6 +1202,11 @@ def main():
                 except Exception as e:  # the baseline is informational; never lose the GPU line over it
                     out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
             out["solver_budget"] = solver_budget(dt / args.steps * 1e3, os.cpu_count() or 1)
+            if not args.timed_only:
+                try:
+                    out["solver_budget"]["host_executor_measured"] = host_executor_leg(usable_cpus())
+                except Exception as e:
+                    out["solver_budget"]["host_executor_measured"] = {"note": f"failed: {e}"}
             if not args.timed_only and log2 >= 20:
                 try:
                     out["poseidon_tree"] = poseidon_tree_leg(ctx)

@@ -206,9 +206,11 @@ class Builder:
         return out
 
 
-def demo_circuit(seed=1, n_users=6):
+def demo_circuit(seed=1, n_users=6, chain=True):
     """a miniature of the real circuit's structure: per "user" a 64-bit balance range-checked and bit-decomposed, an integer division by a price,
-    a zero test, two rounds of a width-3 S-box permutation with linear mixing, an inverse, a division"""
+    a zero test, two rounds of a width-3 S-box permutation with linear mixing, an inverse, a division.  chain=True threads one accumulator
+    through the users (deep levels, as the running CEX totals do); chain=False leaves the users independent (wide levels, as the per-user
+    Merkle / commitment gadgets are)"""
     rng = np.random.default_rng(seed)
     balances = [int(rng.integers(1, 1 << 62)) for _ in range(n_users)]
     prices = [int(rng.integers(1, 1 << 20)) for _ in range(n_users)]
@@ -230,6 +232,10 @@ def demo_circuit(seed=1, n_users=6):
             st = [b.add(b.scale(st[0], 2 + i), b.scale(st[1], 3 + i), b.scale(st[2], 5 + i)) for i in range(3)]
         inv = b.inverse(b.add(st[0], b.const(1)))
         d = b.div_left(st[1], b.add(b.wire(inv), b.const(2)))
-        acc = b.add(b.wire(d), st[2])
+        nxt = b.add(b.wire(d), st[2])
+        if chain:
+            acc = nxt
+        else:
+            b.assert_mul(nxt, b.const(1), nxt, "tail")
     b.assert_mul(acc, b.const(1), acc, "tail")
     return b

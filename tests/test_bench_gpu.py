@@ -50,6 +50,8 @@ def test_bench_line_small_domain():
     assert g["checked_against_oracle"] is True and g["users_per_batch"] == 40 and g["accounts_per_s"] > 0 and g["wire_slots_generated"] > 40 * 20000
     assert d["acceptance"]["accepted"] == d["acceptance"]["proofs"] == 4
     assert d["solver_budget"]["gpu_ms_per_proof"] == d["ms_per_step"]
+    he = d["solver_budget"]["host_executor_measured"]
+    assert he["wire_vector_equals_builder"] is True and he["instructions_per_s"]["threads_1"] > 0 and he["hint_calls"] == 1500 * 5
 
 
 def test_bench_other_tier_and_timed_only():

@@ -177,9 +177,9 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
     std::atomic<int> bad{0};
     std::string bad_msg;
     std::atomic<uint64_t> n_r1c{0}, n_hint{0}, n_skip{0};
-    auto run_instr = [&](uint32_t ins) -> int {
+    auto run_instr = [&](uint32_t ins, uint64_t* cnt) -> int {
         const uint32_t kind = s.kind[ins], arg = s.arg[ins];
-        if (kind >= INSTR_SKIP) { ++n_skip; return 0; }
+        if (kind >= INSTR_SKIP) { ++cnt[2]; return 0; }
         if (kind == INSTR_R1C) {
             if (arg >= nc) return 10;
             int64_t unk[3] = {-1, -1, -1};
@@ -189,7 +189,7 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
             for (int m = 0; m < 3; ++m) v[m] = detail::side(r, m, arg, w.data(), known, &unk[m], &uc[m], &two);
             const int n_unk = (unk[0] >= 0) + (unk[1] >= 0) + (unk[2] >= 0);
             if (two || n_unk > 1) return 11;                     // not solvable at this level: the export's levels are wrong
-            ++n_r1c;
+            ++cnt[0];
             if (n_unk == 0) return FrH::mul(v[0], v[1]) == v[2] ? 0 : 12;   // an assertion
             FrH val;
             int which = unk[0] >= 0 ? 0 : (unk[1] >= 0 ? 1 : 2);
@@ -200,7 +200,10 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
                 if (other.is_zero()) return 14;                              // gnark: "division by zero" — the wire is not determined
                 val = FrH::sub(FrH::mul(v[2], FrH::inv(other)), v[which]);   // (L_known + c x) R = O
             }
-            val = FrH::mul(val, FrH::inv(uc[which]));
+            // the unknown's coefficient is 1 or -1 in almost every constraint gnark emits: no inversion for those
+            if (uc[which] == FrH::one()) {}
+            else if (FrH::neg(uc[which]) == FrH::one()) val = FrH::neg(val);
+            else val = FrH::mul(val, FrH::inv(uc[which]));
             w[unk[which]] = val;
             known[unk[which]] = 1;
             return 0;
@@ -226,17 +229,19 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
         }
         if (fn[name](in, o) != 0) return 24;
         for (uint32_t i = 0; i < n_out; ++i) { const uint32_t wid = cd[3 + i]; if (wid >= nw) return 22; w[wid] = o[i]; known[wid] = 1; }
-        ++n_hint;
+        ++cnt[1];
         return 0;
     };
     for (uint64_t l = 0; l < s.n_levels && !bad; ++l) {
         const uint64_t lo = s.level_ptr[l], hi = s.level_ptr[l + 1];
         const uint64_t n = hi - lo;
         auto work = [&](uint64_t a0, uint64_t a1) {
+            uint64_t cnt[3] = {0, 0, 0};
             for (uint64_t i = a0; i < a1 && !bad; ++i) {
-                int rc = run_instr(s.level_instr[i]);
+                int rc = run_instr(s.level_instr[i], cnt);
                 if (rc) { int exp = 0; if (bad.compare_exchange_strong(exp, rc)) bad_msg = "instruction " + std::to_string(s.level_instr[i]) + " of level " + std::to_string(l); }
             }
+            n_r1c += cnt[0]; n_hint += cnt[1]; n_skip += cnt[2];
         };
         const int nt = (int)std::min<uint64_t>((uint64_t)threads, (n + 255) / 256);   // small levels are not worth a thread each
         if (nt <= 1) { work(lo, hi); continue; }
