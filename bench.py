@@ -775,6 +775,10 @@ def main():
                     "13 of 20 at the same number of buckets — 6 %% fewer bucket additions (profiles/r02_tables.txt)")
     ap.add_argument("--sort-block", type=int, default=-1, help="workgroup size of the onesweep radix sort under the main stream's kernels: 0 = rocPRIM's "
                     "default (1024 threads), 256, 512; -1 = library default")
+    ap.add_argument("--no-filter", action="store_true", help="experiment: accumulate B1 / B2 / K from the shared digit stream of w instead of the "
+                    "per-array streams without the entries of absent points (context parameter msm_filter 0)")
+    ap.add_argument("--filter-mode", type=int, default=-1, help="experiment: msm_filter 0 / 1 (filter beside A) / 2 (A waits for the filter)")
+    ap.add_argument("--filter-grid", type=int, default=0, help="experiment: workgroups of the per-array stream filter kernels (0 = library default)")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1, help="proofs in flight per GPU (in-process dispatcher workers, one HIP stream + workspace each)")
@@ -848,6 +852,12 @@ def main():
         ctx.set_param("msm_reduce_scan", 0)
     if args.sort_block >= 0:
         ctx.set_param("sort_block", args.sort_block)
+    if args.no_filter:
+        ctx.set_param("msm_filter", 0)
+    if args.filter_grid:
+        ctx.set_param("msm_filter_grid", args.filter_grid)
+    if args.filter_mode >= 0:
+        ctx.set_param("msm_filter", args.filter_mode)
     if args.aux_priority:
         ctx.set_param("aux_priority", 1)
     if args.tables > 1 and not args.split:   # a key with tables cannot be cut into the shards of the single-proof split

@@ -417,3 +417,48 @@ def test_prove_tail_with_fixed_base_tables(tables, n_cons):
             ctx.set_param("msm_tables", 9)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("tables", [1, 4])
+def test_per_array_digit_streams_equal_the_shared_stream(tables):
+    """B1 / B2 and K are accumulated from the shared digit stream of w MINUS the entries of their absent points (pk.InfinityB; the
+    committed wires K leaves out) — msm_digits.hip k_filter_write, context parameter "msm_filter".  With a quarter of the B wires at infinity
+    and a third of the wires committed: the filter pass runs (one per proof, both groups), the proof is bit-identical to the one from the shared stream,
+    and its B and K parts equal the oracle's multi-exponentiations over the knocked-out arrays."""
+    ctx = zkpor.Context(0)
+    try:
+        ctx.set_param("msm_tables", tables)
+        S = O.Synth(8, 3000, n_public=2, seed=333, z_bitrev=True)
+        nw = S.n_wires
+        rng = np.random.default_rng(tables)
+        inf_b = (rng.random(nw) < 0.25).astype(np.uint8)
+        inf_b[:4] = [0, 1, 0, 1]
+        committed = np.sort(rng.choice(np.arange(S.n_public, nw), size=nw // 3, replace=False)).astype(np.uint32)
+        keep = np.ones(nw, dtype=bool); keep[:S.n_public] = False; keep[committed] = False
+        basis = O.g1_from_scalars(O.fr_random(41, committed.size)); basis_sigma = O.g1_from_scalars(O.fr_random(42, committed.size))
+        z = np.zeros(nw, dtype=np.uint8)
+        pk = zkpor.ProvingKey(ctx)
+        try:
+            pk.set_g1(zkpor.G1_A, S.A); pk.set_g1(zkpor.G1_B, S.B1[inf_b == 0]); pk.set_g2(zkpor.G2_B, S.B2[inf_b == 0])
+            pk.set_g1(zkpor.G1_K, S.K[keep]); pk.set_g1(zkpor.G1_Z, S.Z)
+            pk.set_g1(zkpor.G1_COMMIT_BASIS, basis); pk.set_g1(zkpor.G1_COMMIT_BASIS_SIGMA, basis_sigma)
+            pk.set_consts(S.abd1[0], S.abd1[1], S.abd1[2], S.bd2[0], S.bd2[1], S.log2d, z, inf_b, nw, S.n_public, committed)
+            r = O.fr_random(5, 1)[0]; s = O.fr_random(6, 1)[0]
+            ctx.phase_reset()
+            with_filter = ctx.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
+            assert ctx.phase_ms("msm_filter")[1] == 1
+            ctx.set_param("msm_filter", 0)
+            ctx.phase_reset()
+            shared = ctx.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
+            assert ctx.phase_ms("msm_filter")[1] == 0
+            ctx.set_param("msm_filter", 1)
+            assert np.array_equal(with_filter, shared)
+            # Bs (G2) = beta2 + sum over the wires that HAVE a B point + s delta2, against the oracle
+            B2k = S.B2.copy(); B2k[inf_b == 1] = 0
+            sums = O.g2_msm(B2k, S.w)
+            bs = O.g2_add(O.g2_add(sums[None, :], S.bd2[0][None, :]), O.g2_msm(S.bd2[1][None, :], s[None, :])[None, :])[0]
+            assert np.array_equal(with_filter.view(np.uint64)[8:24], bs)
+        finally:
+            pk.close()
+    finally:
+        ctx.close()

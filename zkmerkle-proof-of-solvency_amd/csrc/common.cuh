@@ -56,6 +56,8 @@ struct zkpor_ctx {
     int copy_chunk_mb = 32;          // size of one of the four pinned bounce buffers
     int host_order = 0;              // zkpor_prove_tail from host memory: 0 = w first, a/b/c under the witness sums; 1 = everything first, then the resident order
     int msm_reduce_scan = 1;         // small bucket-reduction levels (G1): one lane per bucket, scan + tree sums (msm_g1_hot.hip)
+    int msm_filter = 1;              // per-array digit streams: drop the entries of absent points before B1 / B2 and K (msm_digits.hip)
+    int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 512: two per CU — bandwidth, not wave slots)
     int sort_block = 0;              // workgroup size of the onesweep radix sort: 0 = rocPRIM default (1024), 256, 512 (sort.hip)
     int aux_priority = 0;            // 1: the auxiliary (digit-stream) HIP stream is created with the highest stream priority
     int gpu_token = 1;               // host-pointer calls of several contexts on one GPU take turns on the device (api_core.hip GpuTurn)
@@ -194,6 +196,7 @@ void r1cs_dims(const zkpor_r1cs* r, size_t* n_constraints, size_t* n_wires, int*
 
 // sort.hip (rocPRIM radix sort of (key,value) u32 pairs, keys in [0, 2^end_bit))
 int32_t sort_pairs_temp_bytes(zkpor_ctx* ctx, size_t n, int end_bit, size_t* bytes);
+
 // sorts (k0,v0); the sorted data ends up in (k_out, v_out) which alias one of the two buffers
 int32_t sort_pairs(zkpor_ctx* ctx, void* temp, size_t temp_bytes, u32* k0, u32* k1, u32* v0, u32* v1, size_t n,
                    int end_bit, u32** k_out, u32** v_out);

@@ -32,6 +32,10 @@ struct zkpor_pk {
     bool ready = false;
     bool shard = false;  // holds only a contiguous range of every array (zkpor_pk_keep_range): sums only, no whole proof
     int tab_shift_w = 0, tab_shift_z = 0, tab_shift_c = 0;  // bits between consecutive tables of the w-, h- and commitment-indexed arrays
+    // per-array digit streams (msm_digits.hip k_filter_write): bit w set = wire w has no point in B1 / B2 (pk.InfinityB) resp. in K (the
+    // public and committed wires); built from the wire-indexed arrays when the key is finalised; nullptr = nothing worth filtering
+    u32 *absentB = nullptr, *absentK = nullptr;
+    double fracB = 0.0, fracK = 0.0;
     int tab_m = 1;       // fixed-base tables per point (context parameter "msm_tables" at load time): every array then holds
                          // n * tab_m points, entry i * tab_m + q = 2^(q * piece * c) P_i (msm.cuh MsmCfg)
 };
@@ -201,11 +205,56 @@ int32_t make_tables(zkpor_ctx* ctx, Affine<F>** arr, size_t n, int m, int shift_
     return ZKPOR_OK;
 }
 
+// bit i of bits = point i of the (plain, wire-indexed) array is infinity; *count = how many
+template <class P>
+__global__ void k_absent_bits(const P* __restrict__ pts, size_t n, u32* __restrict__ bits, u32* __restrict__ count) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const bool inf = i < n && pts[i].is_inf();
+    const u64 b = __ballot(inf);
+    const u32 lane = threadIdx.x & 63u;
+    if (lane == 0) { bits[2 * (i >> 6)] = (u32)b; bits[2 * (i >> 6) + 1] = (u32)(b >> 32); if (b) atomicAdd(count, (u32)__popcll(b)); }
+}
+void pk_free_masks(zkpor_pk* pk) {
+    if (pk->absentB) (void)hipFree(pk->absentB);
+    if (pk->absentK) (void)hipFree(pk->absentK);
+    pk->absentB = pk->absentK = nullptr;
+    pk->fracB = pk->fracK = 0.0;
+}
+// the masks of the per-array digit streams, from the final wire-indexed arrays themselves (so every load path — set_consts, the
+// .pk container, the synthetic key — gets them the same way).  A group is filtered only when >= 3 % of its wires are absent.
+int32_t pk_build_masks(zkpor_pk* pk) {
+    zkpor_ctx* ctx = pk->ctx;
+    pk_free_masks(pk);
+    if (pk->shard || pk->n_wires == 0 || !pk->B1 || !pk->K) return ZKPOR_OK;
+    const size_t n = pk->n_wires, words = 2 * ((n + 63) / 64) + 2;
+    u32 *bB = nullptr, *bK = nullptr, *cnt = nullptr;
+    if (hipMalloc((void**)&bB, words * 4) != hipSuccess || hipMalloc((void**)&bK, words * 4) != hipSuccess || hipMalloc((void**)&cnt, 8) != hipSuccess) {
+        (void)hipGetLastError();
+        if (bB) (void)hipFree(bB); if (bK) (void)hipFree(bK); if (cnt) (void)hipFree(cnt);
+        return ZKPOR_OK;   // no memory for the masks: prove with the shared stream
+    }
+    ZK_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_absent_bits<G1Affine>, dim3(blocks), dim3(256), 0, ctx->stream, (const G1Affine*)pk->B1, n, bB, cnt);
+    hipLaunchKernelGGL(k_absent_bits<G1Affine>, dim3(blocks), dim3(256), 0, ctx->stream, (const G1Affine*)pk->K, n, bK, cnt + 1);
+    u32 h[2] = {0, 0};
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(cnt);
+    if (e != hipSuccess) { (void)hipFree(bB); (void)hipFree(bK); ctx->err = std::string("pk: mask construction: ") + hipGetErrorString(e); return ZKPOR_E_HIP; }
+    pk->fracB = (double)h[0] / (double)n; pk->fracK = (double)h[1] / (double)n;
+    if (pk->fracB >= 0.03) pk->absentB = bB; else (void)hipFree(bB);
+    if (pk->fracK >= 0.03) pk->absentK = bK; else (void)hipFree(bK);
+    return ZKPOR_OK;
+}
+
 // after the wire-indexed arrays are final: turn them into tables if the context asks for it.  The spacing of an array's tables is
 // the spacing its multi-exponentiation will use (piece * c of msm_cfg for the array's length); prove_sums / commit check it.
 int32_t pk_apply_tables(zkpor_pk* pk) {
     zkpor_ctx* ctx = pk->ctx;
     pk->tab_m = 1;
+    ZK_TRY(pk_build_masks(pk));
     const int m = ctx->msm_tables;
     if (m <= 1) return ZKPOR_OK;
     MsmCfg cw = msm_cfg(ctx, pk->n_wires, m), cz = msm_cfg(ctx, pk->nZ ? pk->nZ : 1, m), cc = msm_cfg(ctx, pk->nC ? pk->nC : 1, m);
@@ -234,6 +283,7 @@ void pk_free_arrays(zkpor_pk* pk) {
     for (void* p : arrs) if (p) (void)hipFree(p);
     pk->A = pk->B1 = pk->K = pk->Z = pk->CB = pk->CBS = nullptr;
     pk->B2 = nullptr;
+    pk_free_masks(pk);
     pk->ready = false;
 }
 
@@ -491,14 +541,18 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
             ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     }
     hipStream_t main_s = ctx->stream, aux_s = ctx->aux_stream;
-    hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx), e_up = ev_get(ctx);
-    struct EvGuard { zkpor_ctx* c; hipEvent_t e[5]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up}, main_s};
+    hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx), e_up = ev_get(ctx), e_wB = ev_get(ctx), e_wK = ev_get(ctx);
+    struct EvGuard { zkpor_ctx* c; hipEvent_t e[7]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up, e_wB, e_wK}, main_s};
+    // per-array digit streams: B1 / B2 and K get the shared stream of w minus the entries of their absent points
+    StreamFilter filt;
+    if (ctx->msm_filter && do_w) { filt.absent[0] = pk->absentB; filt.absent[1] = pk->absentK; }
+    const int n_filters = (filt.absent[0] ? 1 : 0) + (filt.absent[1] ? 1 : 0);
     MsmCfg cfgw = msm_cfg(ctx, pk->n_wires, pk->tab_m);
     MsmCfg cfgh = msm_cfg(ctx, nZ ? nZ : 1, pk->tab_m);
     ZK_TRY(check_tables(ctx, pk, cfgw, pk->tab_shift_w));
     if (nZ) ZK_TRY(check_tables(ctx, pk, cfgh, pk->tab_shift_z));
     size_t sortw = 0, sorth = 0;
-    size_t need_dw = digits_ws_bytes(ctx, pk->n_wires, cfgw, &sortw);
+    size_t need_dw = digits_ws_bytes(ctx, pk->n_wires, cfgw, &sortw, n_filters);
     size_t need_dh = digits_ws_bytes(ctx, nZ ? nZ : 1, cfgh, &sorth);
     size_t need_aw = accumulate_ws_bytes<Fp2>(cfgw, pk->n_wires * (size_t)cfgw.W);
     size_t need_ah = accumulate_ws_bytes<Fp>(cfgh, (nZ ? nZ : 1) * (size_t)cfgh.W);
@@ -517,13 +571,13 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     }
     if (!host) ZK_HIP(ctx, hipEventRecord(e_h, main_s));
     // 2. digit stream of the witness on the auxiliary stream (serves A, B1, B2, K)
-    DigitStream dsw, dsh;
+    DigitStream dsw, dsh, dswB, dswK;
     size_t off_dh = need_dw;
     const size_t mark = need_dw + need_dh;
     MsmPending pA, pB1, pK, pB2, pZ;
     auto queue_b2 = [&]() -> int32_t {
         ctx->ws_off = mark;
-        return msm_accumulate_launch<Fp2>(ctx, dsw, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2);
+        return msm_accumulate_launch<Fp2>(ctx, dswB, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2);
     };
     if (do_w) {
         ctx->stream = aux_s;
@@ -531,18 +585,23 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         // also on the host path, where e_up (the copy stream) alone would not; free when the main stream is idle
         ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_start, 0));
         if (host) ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_up, 0));
-        ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw));
-        ZK_HIP(ctx, hipEventRecord(e_w, aux_s));
+        // e_w: the sorted shared stream (A starts on it); e_wB: + the B filter; e_wK: + the K filter (the filters hide under A)
+        ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw, n_filters ? &filt : nullptr, &dswB, &dswK, e_w, e_wB));
+        ZK_HIP(ctx, hipEventRecord(e_wK, aux_s));
         off_dh = ctx->ws_off;
         ctx->stream = main_s;
         // 3. queue the witness accumulations (they reuse one workspace region in stream order)
         ctx->ws_off = mark;
-        ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_w, 0));
+        // "msm_filter" 2: A waits for the filter as well, so that the filter runs on an otherwise idle GPU (with a full-size grid) instead of
+        // beside A's VALU-bound kernel, where it is starved and starves (profiles/r03_filter.txt)
+        ZK_HIP(ctx, hipStreamWaitEvent(main_s, (n_filters && ctx->msm_filter == 2) ? e_wK : e_w, 0));
         ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->A, pin + 0 * MSM_SLOT_BYTES, pin + 1 * MSM_SLOT_BYTES, &pA));
         ctx->ws_off = mark;
-        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->B1, pin + 2 * MSM_SLOT_BYTES, pin + 3 * MSM_SLOT_BYTES, &pB1));
+        ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_wB, 0));
+        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dswB, pk->B1, pin + 2 * MSM_SLOT_BYTES, pin + 3 * MSM_SLOT_BYTES, &pB1));
         ctx->ws_off = mark;
-        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->K, pin + 4 * MSM_SLOT_BYTES, pin + 5 * MSM_SLOT_BYTES, &pK));
+        ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_wK, 0));
+        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dswK, pk->K, pin + 4 * MSM_SLOT_BYTES, pin + 5 * MSM_SLOT_BYTES, &pK));
         if (!host) ZK_TRY(queue_b2());
     }
     if (host) {
@@ -707,6 +766,7 @@ int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t
     pk->n_wires = wire_hi - wire_lo;
     pk->nZ = z_hi - z_lo;
     pk->shard = true;
+    pk_free_masks(pk);   // a shard's arrays were cut: it proves with the shared stream
     pk->ready = true;
     return ZKPOR_OK;
 }

@@ -73,7 +73,12 @@ inline MsmCfg msm_cfg(zkpor_ctx* ctx, size_t n, int tables = 1) {
 
 // ------------------------------------------------------------------------------------------------ launchers
 // defined next to the kernel instantiations (one translation unit per field / inlining policy)
-int32_t launch_decompose(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, u32* keys, u32* vals, u32* counter);
+int32_t launch_decompose(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, u32* keys, u32* vals, u32* counter, const u32* absent0 = nullptr,
+                         const u32* absent1 = nullptr);
+int32_t launch_filter(zkpor_ctx* ctx, const u32* keys, const u32* vals, u32 M, u32* seg_counts, u32 grid, u32* k0, u32* v0, u32* k1, u32* v1);
+constexpr u32 FILTER_MAX_GRID = 2048;
+// a digit-stream value = (point index << 1 | sign) in bits 0..29; bit 30 / 31 = the point is absent from array group 0 / 1
+constexpr u32 VAL_MASK = 0x3fffffffu, VAL_ABSENT0 = 1u << 30, VAL_ABSENT1 = 1u << 31;
 int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp>* pts, u32 M, int L, u32 NB,
                       XYZZ<Fp>* buckets, u32* out_keys, XYZZ<Fp>* out_part);
 int32_t launch_level1(zkpor_ctx* ctx, const u32* keys, const u32* vals, const Affine<Fp2>* pts, u32 M, int L, u32 NB,
@@ -111,20 +116,29 @@ struct DigitStream {  // sorted digits of one scalar vector, reusable across poi
     u32 M = 0;
 };
 
-inline size_t digits_ws_bytes(zkpor_ctx* ctx, size_t n, const MsmCfg& cfg, size_t* sort_temp) {
+// per-array streams (msm_digits.hip k_filter_write): up to two groups of arrays whose absent points are dropped from the shared stream
+struct StreamFilter {
+    const u32* absent[2] = {nullptr, nullptr};   // device bitmaps over the scalars' indices; nullptr = group not filtered
+};
+
+inline size_t digits_ws_bytes(zkpor_ctx* ctx, size_t n, const MsmCfg& cfg, size_t* sort_temp, int n_filters = 0) {
     size_t cap = n * (size_t)cfg.W;
     WsPlan p;
     p.add<u32>(cap); p.add<u32>(cap); p.add<u32>(cap); p.add<u32>(cap); p.add<u32>(64);
     size_t tb = 0;
     sort_pairs_temp_bytes(ctx, cap, cfg.key_bits, &tb);
+    if (n_filters > 0 && tb < 2 * FILTER_MAX_GRID * sizeof(u32)) tb = 2 * FILTER_MAX_GRID * sizeof(u32);   // the filter's segment counts reuse the sort's scratch
     *sort_temp = tb;
     p.add<char>(tb + 256);
+    // the first filtered stream lands in the sort's spare buffer pair, every further one needs its own
+    for (int f = 1; f < n_filters; ++f) { p.add<u32>(cap); p.add<u32>(cap); }
     return p.total;
 }
 
 // decompose + sort.  Workspace must already be reserved; allocates from it.
 inline int32_t msm_digits(zkpor_ctx* ctx, const Fr* d_scalars, size_t n, const MsmCfg& cfg, size_t sort_temp,
-                          DigitStream* out) {
+                          DigitStream* out, const StreamFilter* filt = nullptr, DigitStream* out_f0 = nullptr, DigitStream* out_f1 = nullptr,
+                          hipEvent_t ev_sorted = nullptr, hipEvent_t ev_f0 = nullptr) {
     size_t cap = n * (size_t)cfg.W;
     if (cap >= 0xfffffff0ull || n * (size_t)cfg.m >= (1ull << 31)) { ctx->err = "msm: too many digit entries for 32-bit indexing"; return ZKPOR_E_ARG; }
     u32* k0 = ws_alloc<u32>(ctx, cap); u32* k1 = ws_alloc<u32>(ctx, cap);
@@ -133,20 +147,43 @@ inline int32_t msm_digits(zkpor_ctx* ctx, const Fr* d_scalars, size_t n, const M
     char* temp = ws_alloc<char>(ctx, sort_temp + 256);
     if (!k0 || !k1 || !v0 || !v1 || !counter || !temp) { ctx->err = "msm: workspace too small"; return ZKPOR_E_OOM; }
     out->cfg = cfg;
+    const bool flags_fit = n * (size_t)cfg.m < (1ull << 29);   // the absence flags live in bits 30 / 31 of a value
     {
         PhaseScope ps(ctx, "msm_decompose");
-        ZK_HIP(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
-        ZK_TRY(launch_decompose(ctx, d_scalars, (u32)n, cfg, k0, v0, counter));
+        ZK_HIP(ctx, hipMemsetAsync(counter, 0, 64, ctx->stream));
+        ZK_TRY(launch_decompose(ctx, d_scalars, (u32)n, cfg, k0, v0, counter, (filt && flags_fit) ? filt->absent[0] : nullptr, (filt && flags_fit) ? filt->absent[1] : nullptr));
     }
-    u32 M = 0;
-    ZK_HIP(ctx, hipMemcpyAsync(&M, counter, 4, hipMemcpyDeviceToHost, ctx->stream));
+    u32 Ms[3] = {0, 0, 0};
+    ZK_HIP(ctx, hipMemcpyAsync(Ms, counter, 12, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const u32 M = Ms[0];
     out->M = M;
     out->keys = k0; out->vals = v0;
     if (M > 1) {
         PhaseScope ps(ctx, "msm_sort");
         ZK_TRY(sort_pairs(ctx, temp, sort_temp, k0, k1, v0, v1, M, cfg.key_bits, &out->keys, &out->vals));
     }
+    if (ev_sorted) ZK_HIP(ctx, hipEventRecord(ev_sorted, ctx->stream));
+    // per-array streams: ONE stable filter pass pair over the sorted stream produces both groups; their sizes were counted by the decomposition
+    if (out_f0) *out_f0 = *out;                            // not filtered: the shared stream itself
+    if (out_f1) *out_f1 = *out;
+    const bool g0 = flags_fit && filt && filt->absent[0] && out_f0 && M, g1 = flags_fit && filt && filt->absent[1] && out_f1 && M;
+    if (g0 || g1) {
+        u32 *fk[2] = {nullptr, nullptr}, *fv[2] = {nullptr, nullptr};
+        bool spare_used = false;
+        for (int f = 0; f < 2; ++f) {
+            if (!(f == 0 ? g0 : g1)) continue;
+            if (!spare_used) { fk[f] = (out->keys == k0) ? k1 : k0; fv[f] = (out->vals == v0) ? v1 : v0; spare_used = true; }   // the sort's spare pair
+            else { fk[f] = ws_alloc<u32>(ctx, cap); fv[f] = ws_alloc<u32>(ctx, cap); if (!fk[f] || !fv[f]) { ctx->err = "msm: workspace too small"; return ZKPOR_E_OOM; } }
+        }
+        PhaseScope ps(ctx, "msm_filter");
+        int grid = ctx->msm_filter_grid > 0 ? ctx->msm_filter_grid : 512;
+        if (grid > (int)FILTER_MAX_GRID) grid = FILTER_MAX_GRID;
+        ZK_TRY(launch_filter(ctx, out->keys, out->vals, M, (u32*)temp, (u32)grid, fk[0], fv[0], fk[1], fv[1]));
+        if (g0) { out_f0->keys = fk[0]; out_f0->vals = fv[0]; out_f0->M = Ms[1]; }
+        if (g1) { out_f1->keys = fk[1]; out_f1->vals = fv[1]; out_f1->M = Ms[2]; }
+    }
+    if (ev_f0) ZK_HIP(ctx, hipEventRecord(ev_f0, ctx->stream));
     return ZKPOR_OK;
 }
 

@@ -30,7 +30,7 @@ ZK_D void acc_stage(const u32* __restrict__ keys, const u32* __restrict__ vals, 
         u64 g = (u64)(row0 + r) * (u32)L + col;
         if (col < (u32)L && g < M) {
             sk[r * ACC_PITCH + c] = keys[g];
-            sv[r * ACC_PITCH + c] = vals[g];
+            sv[r * ACC_PITCH + c] = vals[g] & VAL_MASK;   // bits 30 / 31 carry the per-array absence flags of the filter (msm_digits.hip)
         }
     }
 }
