@@ -753,6 +753,8 @@ def main():
     ap.add_argument("--other-config-steps", type=int, default=-1,
                     help="steps of the timed region for the OTHER single-GPU config of BASELINE.json (zkpor500_200 when --config is the "
                          "default), reported under `configs` (-1 = max(5, steps/4); 0 = skip)")
+    ap.add_argument("--copy-inputs", action="store_true", help="restore a, b, c by device copies inside every step and prove in place "
+                    "(zkpor_prove_tail_dev; the form of rounds 1-2) instead of the input-preserving zkpor_prove_tail_dev_keep")
     ap.add_argument("--no-check", action="store_true", help="skip the trapdoor verification of the timed proofs")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-pointer (cgo-shaped) boundary leg")
     ap.add_argument("--r1cs-terms", type=int, default=0, help="opt-in untimed leg: the host-pointer form with resident constraint matrices "
@@ -927,12 +929,15 @@ def main():
         wctx, wa, wb, wc = wk
         cv_buf = cv_of.get(w_buf.data_ptr(), cv)
         wck = wctx._ck
-        for dst, src in ((wa, a0), (wb, b0), (wc, c0)):
-            wck(lib.zkpor_dev_copy(wctx.h, vp(dst.data_ptr()), vp(src.data_ptr()), ctypes.c_size_t(32 * D)))
         com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
         wck(lib.zkpor_commit_dev(wctx.h, pk.h, vp(cv_buf.data_ptr()), ctypes.c_size_t(n_commit), _z._p(com), _z._p(pok)))
         r, s = blinding(i)
-        proof = wctx.prove_tail_dev(pk, w_buf.data_ptr(), wa.data_ptr(), wb.data_ptr(), wc.data_ptr(), r, s)
+        if args.copy_inputs:   # the round-1/2 form: restore the in-place form's inputs by three device copies inside the step (12.9 GB, 2.6 ms)
+            for dst, src in ((wa, a0), (wb, b0), (wc, c0)):
+                wck(lib.zkpor_dev_copy(wctx.h, vp(dst.data_ptr()), vp(src.data_ptr()), ctypes.c_size_t(32 * D)))
+            proof = wctx.prove_tail_dev(pk, w_buf.data_ptr(), wa.data_ptr(), wb.data_ptr(), wc.data_ptr(), r, s)
+        else:                  # inputs preserved: computeH's first pass reads a0, b0, c0 and writes this worker's buffers (h ends up in wa)
+            proof = wctx.prove_tail_dev_keep(pk, w_buf.data_ptr(), a0.data_ptr(), b0.data_ptr(), c0.data_ptr(), wa.data_ptr(), wb.data_ptr(), wc.data_ptr(), r, s)
         if sink is not None:
             sink.append((i, proof, com, pok))
 

@@ -231,6 +231,12 @@ int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const u
 /* device-resident inputs; d_a/d_b/d_c must hold 2^log2_domain elements (zero padded) and are overwritten */
 int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c,
                              const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]);
+/* the same with the inputs PRESERVED: d_a / d_b / d_c are only read (computeH's first pass reads them and writes the work buffers), d_wa / d_wb /
+ * d_wc (2^log2_domain elements each, distinct from the inputs) are overwritten and d_wa holds h on return.  For a caller that proves
+ * again from the same evaluations (another blinding, a retry) or keeps them for checking — gnark's computeH destroys its inputs as
+ * zkpor_prove_tail_dev does, so this form has no counterpart there. */
+int32_t zkpor_prove_tail_dev_keep(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_a, const void* d_b, const void* d_c, void* d_wa,
+                                  void* d_wb, void* d_wc, const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]);
 /* ---- single-proof split over several GPUs (BASELINE.json configs[4]: one 2^28 proof, 8 MI355X) ----------
  * Every GPU keeps one contiguous range of each key array and of the matching scalars, computes the five partial
  * multi-exponentiations, the partial sums (576 B per GPU) are all-gathered (RCCL; the only collective of the path besides

@@ -462,3 +462,38 @@ def test_per_array_digit_streams_equal_the_shared_stream(tables):
             pk.close()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("variant", [1, 0], ids=["limbs29", "limbs32"])
+def test_prove_tail_dev_keep_preserves_its_inputs(zk, variant):
+    """zkpor_prove_tail_dev_keep: computeH's first pass reads the caller's a, b, c and writes the work buffers — same proof as the in-place
+    form, bit for bit, inputs untouched, h left in the first work buffer (both NTT kernel variants: the 32-bit one copies first)"""
+    S = O.Synth(6, 1500, n_public=2, seed=77, z_bitrev=True)
+    pk = _load_pk(zk, S, zkpor.Z_ORDER_BITREV)
+    D = 1 << S.log2d
+    pad = lambda v: np.concatenate([v, np.zeros((D - v.shape[0], 4), np.uint64)])
+    a, b, c = pad(S.a), pad(S.b), pad(S.c)
+    bufs = [zk.alloc(32 * D) for _ in range(6)]
+    dw = zk.alloc(S.w.nbytes).upload(S.w)
+    zk.set_param("ntt_variant", variant)
+    try:
+        for buf, v in zip(bufs[:3], (a, b, c)):
+            buf.upload(v)
+        r = O.fr_random(5, 1)[0]; s = O.fr_random(6, 1)[0]
+        got = zk.prove_tail_dev_keep(pk, dw.ptr, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, bufs[4].ptr, bufs[5].ptr, r, s)
+        assert np.array_equal(got, S.prove_tail(r, s))
+        for buf, v in zip(bufs[:3], (a, b, c)):
+            assert np.array_equal(buf.download(np.uint64, (D, 4)), v)          # inputs untouched
+        h = bufs[3].download(np.uint64, (D, 4))
+        assert np.array_equal(h, O.compute_h(S.a, S.b, S.c, S.log2d))           # h where the in-place form leaves it: the first work buffer
+        again = zk.prove_tail_dev_keep(pk, dw.ptr, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, bufs[4].ptr, bufs[5].ptr, r, s)
+        assert np.array_equal(again, got)                                        # provable again from the same inputs
+        inplace = zk.prove_tail_dev(pk, dw.ptr, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, r, s)
+        assert np.array_equal(inplace, got)
+        with pytest.raises(zkpor.ZkporError):
+            zk.prove_tail_dev_keep(pk, dw.ptr, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[0].ptr, bufs[4].ptr, bufs[5].ptr, r, s)
+    finally:
+        zk.set_param("ntt_variant", 1)
+        for x in bufs + [dw]:
+            x.free()
+        pk.close()

@@ -515,6 +515,8 @@ struct ProveSums { G1XYZZ A, B1, K, Z; G2XYZZ B2; };  // the five multi-exponent
 // the caller's vectors when they are still in HOST memory (zkpor_prove_tail): prove_sums then carries them across PCIe itself,
 // in the order the GPU needs them, under its own kernels
 struct HostInputs { const void *w, *a, *b, *c; size_t n_constraints; };
+// device-resident a, b, c the caller wants back untouched (zkpor_prove_tail_dev_keep): computeH's first pass reads them
+struct KeptInputs { const void *a, *b, *c; };
 
 // Queue everything in groth16.Prove between the solver and the blinding: h = computeH(a, b, c) when d_b is given (else d_a
 // already holds the h scalars matching pk->Z), then A.w, B1.w, B2.w, K.w over one sorted digit stream of w and Z.h.
@@ -526,7 +528,7 @@ struct HostInputs { const void *w, *a, *b, *c; size_t n_constraints; };
 // while those three accumulations run; then computeH, B2 (sort of h hidden under it) and Z.
 int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c, ProveSums* out, bool do_w = true,
                    bool do_h = true, const std::function<void()>* while_gpu_runs = nullptr, const HostInputs* host = nullptr,
-                   GpuTurn* turn = nullptr) {
+                   GpuTurn* turn = nullptr, const KeptInputs* kept = nullptr) {
     const int n = pk->log2_domain;
     const size_t nZ = do_h ? pk->nZ : 0;
     // Two HIP streams: the ALU-bound work (NTTs, bucket accumulations) on the context's stream, the HBM-bound digit
@@ -567,7 +569,8 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         ZK_HIP(ctx, hipEventRecord(e_up, ctx->copy_stream));
     } else if (d_b) {
         // 1. h = computeH(a,b,c) on the main stream, left in d_a (bit-reversed = the order of pk->Z)
-        ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
+        if (kept) ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, (const Fr*)kept->a, (const Fr*)kept->b, (const Fr*)kept->c));
+        else ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
     }
     if (!host) ZK_HIP(ctx, hipEventRecord(e_h, main_s));
     // 2. digit stream of the witness on the auxiliary stream (serves A, B1, B2, K)
@@ -733,6 +736,25 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
     Blind bl;
     const std::function<void()> prep = [&] { bl = blind_prepare(pk->delta, pk->delta2, r, s); };
     ZK_TRY(prove_sums(ctx, pk, d_w, d_a, d_b, d_c, &m, true, true, &prep));
+    HostPhase hp(ctx, "host_assembly");
+    assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_prove_tail_dev_keep(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_a, const void* d_b, const void* d_c, void* d_wa,
+                                  void* d_wb, void* d_wc, const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !pk || !d_w || !d_a || !d_b || !d_c || !d_wa || !d_wb || !d_wc || !r || !s || !proof_out) return ZKPOR_E_ARG;
+    if (d_wa == d_a || d_wb == d_b || d_wc == d_c) { ctx->err = "prove: the work buffers must differ from the inputs (use zkpor_prove_tail_dev to work in place)"; return ZKPOR_E_ARG; }
+    if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
+    if (pk->shard) { ctx->err = "prove: the key is a shard (zkpor_pk_keep_range): use zkpor_prove_sums_dev + zkpor_prove_assemble"; return ZKPOR_E_STATE; }
+    ZK_TRY(check_same_gpu(ctx, pk));
+    ZK_TRY(check_blinding(ctx, r, s));
+    ProveSums m;
+    Blind bl;
+    const std::function<void()> prep = [&] { bl = blind_prepare(pk->delta, pk->delta2, r, s); };
+    const KeptInputs kept{d_a, d_b, d_c};
+    ZK_TRY(prove_sums(ctx, pk, d_w, d_wa, d_wb, d_wc, &m, true, true, &prep, nullptr, nullptr, &kept));
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;

@@ -25,5 +25,5 @@ int32_t ntt_domain_get(zkpor_ctx* ctx, int n, NttDomain** out);
 void ntt_domains_free(zkpor_ctx* ctx);
 int32_t ntt_debug_fault(zkpor_ctx* ctx, int n);
 int32_t ntt_dev(zkpor_ctx* ctx, Fr* d_x, int n, bool inverse, bool dif, bool on_coset);
-int32_t compute_h_dev(zkpor_ctx* ctx, int n, Fr* a, Fr* b, Fr* c);
+int32_t compute_h_dev(zkpor_ctx* ctx, int n, Fr* a, Fr* b, Fr* c, const Fr* a_in = nullptr, const Fr* b_in = nullptr, const Fr* c_in = nullptr);
 }  // namespace zk

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass(PassArgs A) {
 // (to32_div32).  All constants come from tables already in the 2^261 form.
 struct PassArgs29 {
     Fr* x;
+    const Fr* src;               // where this pass LOADS from (x unless the transform's first pass reads the caller's untouched input)
     int n, lo, kb, clog;
     const u32* small29;          // w_512^j, 9 limbs each
     const Fr* tw_full;           // [k_m << lo | l], packed 2^261 form
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
         u32 m, c, p, li;
         if (lo > 0) { c = idx & (C - 1u); m = idx >> clog; p = (hi << (lo + kb)) + (m << lo) + l0 + c; li = m * C + c; }
         else { m = idx & (F - 1u); c = idx >> kb; p = ((hi + c) << kb) + m; li = c * F + m; }
-        const Fr raw = A.x[p];
+        const Fr raw = A.src[p];
         Fr29 v = A.in_gnark ? Fr29::from32<5>(raw) : Fr29::from32<0>(raw);
         if (A.scale_load) v = scale29(A, A.scale_load, v, ((p << A.p_shift) | A.p_or) + A.p_add);
         if (!DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << (lo + A.p_shift)) | (((l0 + c) << A.p_shift) | A.p_or)]));
@@ -500,12 +501,14 @@ void ntt_domains_free(zkpor_ctx* ctx) {
 struct ScaleSpec { int mode = 0; const Fr* g_lo = nullptr; const Fr* g_hi = nullptr; Fr konst; };
 
 static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
-                            const ScaleSpec& last_store);
+                            const ScaleSpec& last_store, const Fr* src);
+// src (optional): the transform reads its input from there and leaves it untouched; x receives every pass's output
 static int32_t run_passes(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
-                          const ScaleSpec& last_store) {
+                          const ScaleSpec& last_store, const Fr* src = nullptr) {
     Field f[8];
     int nf = plan_fields(d->n, f);
-    if (ctx->ntt_variant == 1 && d->have29 && !(first_load.mode && last_store.mode && nf == 1)) return run_passes29(ctx, d, x, inverse, dif, first_load, last_store);
+    if (ctx->ntt_variant == 1 && d->have29 && !(first_load.mode && last_store.mode && nf == 1)) return run_passes29(ctx, d, x, inverse, dif, first_load, last_store, src);
+    if (src && src != x) ZK_HIP(ctx, hipMemcpyAsync(x, src, sizeof(Fr) << d->n, hipMemcpyDeviceToDevice, ctx->stream));   // the 32-bit kernel works in place only
     for (int step = 0; step < nf; ++step) {
         const Field& fl = dif ? f[nf - 1 - step] : f[step];
         PassArgs A;
@@ -548,7 +551,7 @@ static const Fr* table29(const NttDomain* d, const Fr* t) {
     return nullptr;
 }
 static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
-                            const ScaleSpec& last_store) {
+                            const ScaleSpec& last_store, const Fr* src) {
     Field f[8];
     int nf = plan_fields(d->n, f);
     Fr c32 = Fr::one();
@@ -557,7 +560,7 @@ static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, b
         const int fi = dif ? nf - 1 - step : step;
         const Field& fl = f[fi];
         PassArgs29 A;
-        A.x = x; A.n = d->n; A.lo = fl.lo; A.kb = fl.kb;
+        A.x = x; A.src = (step == 0 && src) ? src : x; A.n = d->n; A.lo = fl.lo; A.kb = fl.kb;
         int cmax = ctx->ntt_tile_log - fl.kb;  // default: tile of <= 1024 elements x 36 B, four blocks (16 waves) per CU
         if (cmax < 0) cmax = 0;
         int avail = fl.lo > 0 ? fl.lo : d->n - fl.kb;
@@ -617,7 +620,7 @@ static int32_t ntt_shard_stage(zkpor_ctx* ctx, NttDomain* d, Fr* x, int wlog, in
         if (st != stage) continue;
         const Field& fl = f[fi];
         PassArgs29 A;
-        A.x = x; A.n = nl; A.kb = fl.kb;
+        A.x = x; A.src = x; A.n = nl; A.kb = fl.kb;
         A.lo = high ? 0 : fl.lo - wlog;
         A.n_glob = d->n;
         A.p_shift = high ? 0 : wlog; A.p_or = high ? 0u : (u32)rank; A.p_add = high ? ((u32)rank << nl) : 0u;
@@ -731,7 +734,7 @@ int32_t ntt_dev(zkpor_ctx* ctx, Fr* d_x, int n, bool inverse, bool dif, bool on_
 
 // computeH in place: a,b,c hold 2^n evaluations (zero padded); on return a = h in BIT-REVERSED order.
 // The 1/N of the three inverse transforms is folded into the coset pre-scale of the forward ones.
-int32_t compute_h_dev(zkpor_ctx* ctx, int n, Fr* a, Fr* b, Fr* c) {
+int32_t compute_h_dev(zkpor_ctx* ctx, int n, Fr* a, Fr* b, Fr* c, const Fr* a_in, const Fr* b_in, const Fr* c_in) {
     NttDomain* d;
     ZK_TRY(ntt_domain_get(ctx, n, &d));
     ScaleSpec none, pre, post;
@@ -740,8 +743,9 @@ int32_t compute_h_dev(zkpor_ctx* ctx, int n, Fr* a, Fr* b, Fr* c) {
     {
         PhaseScope ps(ctx, "ntt");
         Fr* v[3] = {a, b, c};
+        const Fr* in[3] = {a_in, b_in, c_in};     // inputs the caller wants preserved: the first pass reads them, a / b / c are the work buffers
         for (int i = 0; i < 3; ++i) {
-            ZK_TRY(run_passes(ctx, d, v[i], true, true, none, none));
+            ZK_TRY(run_passes(ctx, d, v[i], true, true, none, none, in[i]));
             ZK_TRY(run_passes(ctx, d, v[i], false, false, pre, none));
         }
     }

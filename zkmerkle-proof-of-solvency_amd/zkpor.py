@@ -247,6 +247,14 @@ class Context:
         self._ck(self.lib.zkpor_prove_tail_dev(self.h, pk.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c), _p(r), _p(s), _p(out)))
         return out
 
+    def prove_tail_dev_keep(self, pk, d_w, d_a, d_b, d_c, d_wa, d_wb, d_wc, r, s):
+        """zkpor_prove_tail_dev_keep: a, b, c are only read; the work buffers are overwritten (h is left in d_wa)"""
+        r = _u64(r); s = _u64(s)
+        out = np.empty(256, dtype=np.uint8)
+        vp = ctypes.c_void_p
+        self._ck(self.lib.zkpor_prove_tail_dev_keep(self.h, pk.h, vp(d_w), vp(d_a), vp(d_b), vp(d_c), vp(d_wa), vp(d_wb), vp(d_wc), _p(r), _p(s), _p(out)))
+        return out
+
     def prove_sums_dev(self, pk, d_w, d_h):
         """the five multi-exponentiations over the key's (or shard's) arrays: 576 B of Jacobian points A.w | B1.w | B2.w | K.w | Z.h"""
         out = np.empty(576, dtype=np.uint8)
