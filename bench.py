@@ -781,6 +781,7 @@ def main():
                     "per-array streams without the entries of absent points (context parameter msm_filter 0)")
     ap.add_argument("--filter-mode", type=int, default=-1, help="experiment: msm_filter 0 / 1 (filter beside A) / 2 (A waits for the filter)")
     ap.add_argument("--filter-grid", type=int, default=0, help="experiment: workgroups of the per-array stream filter kernels (0 = library default)")
+    ap.add_argument("--no-ntt-fuse", action="store_true", help="experiment: computeH's two lowest-field passes as separate kernels (ntt_fuse 0)")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1, help="proofs in flight per GPU (in-process dispatcher workers, one HIP stream + workspace each)")
@@ -856,6 +857,8 @@ def main():
         ctx.set_param("sort_block", args.sort_block)
     if args.no_filter:
         ctx.set_param("msm_filter", 0)
+    if args.no_ntt_fuse:
+        ctx.set_param("ntt_fuse", 0)
     if args.filter_grid:
         ctx.set_param("msm_filter_grid", args.filter_grid)
     if args.filter_mode >= 0:

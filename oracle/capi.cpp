@@ -444,6 +444,32 @@ void orc_fast_prove_tail_work(int log2d, const G1A* g1, const G2A* g2, const Fr*
 }
 int orc_threads() { return fast::threads(); }
 
+// <s, x> over Fr for the first n points of one synthetic key array (trapdoor.py synth_dot in one fused, OpenMP pass — the numpy form
+// stays as its cross-check in tests/test_trapdoor_cpu.py): s_i = k(i / 32) + (i % 32) q with the 64-bit mixer of zkpor_pk_synth,
+// zero where the synthetic point is infinity (hash test mod inf_mod, or i < inf_below)
+void orc_synth_dot(u64 seed, int arr, const Fr* x, size_t n, u64 inf_mod, size_t inf_below, Fr* out) {
+    auto smix = [](u64 v) { v += 0x9e3779b97f4a7c15ULL; v = (v ^ (v >> 30)) * 0xbf58476d1ce4e5b9ULL; v = (v ^ (v >> 27)) * 0x94d049bb133111ebULL; return v ^ (v >> 31); };
+    const u64 q = 0x9e3779b97f4a7c15ULL;
+    Fr acc = Fr::zero();
+#pragma omp parallel
+    {
+        Fr loc = Fr::zero();
+#pragma omp for schedule(static) nowait
+        for (size_t i = 0; i < n; ++i) {
+            if (i < inf_below) continue;
+            if (inf_mod) { u64 h = (u64)i * 0xd6e8feb86659fd93ULL; h ^= h >> 32; if (h % inf_mod == 0) continue; }
+            const u64 run = i / 32, j = i % 32;
+            const u64 k = smix(seed ^ ((u64)(arr + 1) * 0xa0761d6478bd642fULL) ^ (run * 0xe7037ed1a0b428dbULL)) | 1;
+            const unsigned __int128 sv = (unsigned __int128)k + (unsigned __int128)j * q;
+            u64 c[4] = {(u64)sv, (u64)(sv >> 64), 0, 0};
+            loc = Fr::add(loc, Fr::mul(Fr::from_canon(c), x[i]));
+        }
+#pragma omp critical
+        acc = Fr::add(acc, loc);
+    }
+    *out = acc;
+}
+
 // ---- FFT-free check of computeH's output (quotient.hpp): out6 = A(tau), B(tau), C(tau), H(tau), H(tau)(tau^D-1), A(tau)B(tau)-C(tau);
 // returns 1 when the last two agree, 0 when they differ, -1 when tau lies in the domain
 int orc_quotient_identity(int log2d, const Fr* a, const Fr* b, const Fr* c, size_t n_cons, const Fr* h, int h_bitrev, const Fr* tau, Fr* out6) {

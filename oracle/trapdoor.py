@@ -69,11 +69,18 @@ def synth_scalars_canon(seed, arr, lo, hi, inf_mod=None, inf_below=0):
     return out
 
 
-def synth_dot(seed, arr, scalars_mont, inf_mod=None, inf_below=0, chunk=1 << 22):
-    """<s, x> over Fr (Montgomery limbs, shape (4,)) for the first len(x) points of synthetic array `arr`, in chunks so that
-    2^26 elements need no multi-GB temporaries"""
+def synth_dot(seed, arr, scalars_mont, inf_mod=None, inf_below=0, chunk=1 << 22, fused=True):
+    """<s, x> over Fr (Montgomery limbs, shape (4,)) for the first len(x) points of synthetic array `arr`.  fused: one OpenMP pass in the
+    oracle library (orc_synth_dot: generator and dot product restated in C); otherwise the numpy generator in chunks — the two are
+    compared in tests/test_trapdoor_cpu.py, the fused one is what the 2^26 checks use (4 x 2^26 elements in ~1 s instead of ~12 s)"""
     x = O._u64(scalars_mont).reshape(-1, 4)
     n = x.shape[0]
+    if fused:
+        import ctypes
+        out = np.empty(4, dtype=np.uint64)
+        O.lib().orc_synth_dot(ctypes.c_uint64(seed & _M64), ctypes.c_int(arr), O._p(x), ctypes.c_size_t(n),
+                              ctypes.c_uint64(INF_MOD[arr] if inf_mod is None else inf_mod), ctypes.c_size_t(inf_below), O._p(out))
+        return out
     acc = O.fr_from_ints([0])[0]
     buf = np.empty((min(chunk, n), 4), dtype=np.uint64)
     for lo in range(0, n, chunk):

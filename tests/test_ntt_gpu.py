@@ -125,6 +125,24 @@ def test_compute_h_fault_injection_detected(zk):
     assert np.array_equal(zk.compute_h(a, b, c, log2d), good)
 
 
+@pytest.mark.parametrize("log2d", [9, 13, 17, 20])
+def test_compute_h_fused_passes_equal_separate_passes(zk, log2d):
+    """computeH's fused kernels ("ntt_fuse" 1, the default) — k_ntt_mid29: the two passes over the lowest field (inverse DIF last, coset
+    DIT first) on one tile; k_ntt_top29: the last DIT pass of a, b and c, the pointwise quotient and the first DIF pass of h on one tile of
+    the highest field — are bit-identical to the 21 separate passes + pointwise kernel, which the tests above pin to the oracle"""
+    n = (1 << log2d) - 3
+    a = O.fr_random(61, n); b = O.fr_random(62, n); c = O.fr_mul(a, b)
+    fused = zk.compute_h(a, b, c, log2d)
+    zk.set_param("ntt_fuse", 0)
+    try:
+        separate = zk.compute_h(a, b, c, log2d)
+    finally:
+        zk.set_param("ntt_fuse", 1)
+    assert np.array_equal(fused, separate)
+    if log2d <= 17:
+        assert np.array_equal(fused, O.compute_h(a, b, c, log2d))
+
+
 def test_compute_h_zero_and_ragged(zk):
     # n_constraints = 0..1: zero padding path; h of the zero polynomial is zero
     z = np.zeros((1, 4), np.uint64)

@@ -35,6 +35,19 @@ def test_dot_equals_msm_over_generated_points():
         assert np.array_equal(O.g1_msm(pts, w), O.g1_from_scalars(d.reshape(1, 4))[0])
 
 
+def test_fused_dot_equals_the_numpy_generator():
+    """orc_synth_dot (generator + dot product in one OpenMP pass, what the 2^26 checks use) against the numpy restatement, array by array,
+    with and without the infinity patterns, across run boundaries and chunk edges"""
+    n, seed = 100_000, 0x5A4B504F52 + 3
+    x = O.fr_random(11, n)
+    for arr, below in ((T.G1_A, 0), (T.G1_B, 0), (T.G1_K, 3), (T.G1_Z, 0), (T.G1_COMMIT_BASIS, 0), (T.G1_COMMIT_BASIS_SIGMA, 0)):
+        for m in (n, 33, 1):
+            a = T.synth_dot(seed, arr, x[:m], inf_below=below, fused=True)
+            b = T.synth_dot(seed, arr, x[:m], inf_below=below, fused=False, chunk=4096)
+            assert np.array_equal(a, b)
+    assert np.array_equal(T.synth_dot(seed, T.G1_A, x, inf_mod=7, fused=True), T.synth_dot(seed, T.G1_A, x, inf_mod=7, fused=False))
+
+
 def test_proof_prediction_matches_group_formulas():
     n, seed, npub = 256, 77, 3
     w = O.fr_random(5, n); h = O.fr_random(6, n - 1)

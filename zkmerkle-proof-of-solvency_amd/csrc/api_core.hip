@@ -343,6 +343,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     else if (n == "ntt_tile_log") { if (value < 9 || value > 12) { ctx->err = "ntt_tile_log must be in [9,12]"; return ZKPOR_E_ARG; } ctx->ntt_tile_log = (int)value; }
     else if (n == "msm_filter") { if (value < 0 || value > 2) { ctx->err = "msm_filter must be 0, 1 or 2"; return ZKPOR_E_ARG; } ctx->msm_filter = (int)value; }
     else if (n == "msm_filter_grid") { if (value < 0 || value > 2048) { ctx->err = "msm_filter_grid must be in [0,2048]"; return ZKPOR_E_ARG; } ctx->msm_filter_grid = (int)value; }
+    else if (n == "ntt_fuse") { if (value < 0 || value > 1) { ctx->err = "ntt_fuse must be 0 or 1"; return ZKPOR_E_ARG; } ctx->ntt_fuse = (int)value; }
     else if (n == "sort_block") { if (value != 0 && value != 256 && value != 512) { ctx->err = "sort_block must be 0 (rocPRIM default), 256 or 512"; return ZKPOR_E_ARG; } ctx->sort_block = (int)value; }
     else if (n == "msm_reduce_scan") { if (value < 0 || value > 1) { ctx->err = "msm_reduce_scan must be 0 or 1"; return ZKPOR_E_ARG; } ctx->msm_reduce_scan = (int)value; }
     else if (n == "aux_priority") {

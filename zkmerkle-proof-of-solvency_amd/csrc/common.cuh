@@ -57,7 +57,8 @@ struct zkpor_ctx {
     int host_order = 0;              // zkpor_prove_tail from host memory: 0 = w first, a/b/c under the witness sums; 1 = everything first, then the resident order
     int msm_reduce_scan = 1;         // small bucket-reduction levels (G1): one lane per bucket, scan + tree sums (msm_g1_hot.hip)
     int msm_filter = 1;              // per-array digit streams: drop the entries of absent points before B1 / B2 and K (msm_digits.hip)
-    int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 512: two per CU — bandwidth, not wave slots)
+    int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 256: one per CU — bandwidth, not wave slots)
+    int ntt_fuse = 1;                // computeH: the two passes over the lowest field (inverse DIF last, coset DIT first) in one kernel (ntt.hip k_ntt_mid29)
     int sort_block = 0;              // workgroup size of the onesweep radix sort: 0 = rocPRIM default (1024), 256, 512 (sort.hip)
     int aux_priority = 0;            // 1: the auxiliary (digit-stream) HIP stream is created with the highest stream priority
     int gpu_token = 1;               // host-pointer calls of several contexts on one GPU take turns on the device (api_core.hip GpuTurn)

@@ -177,7 +177,7 @@ inline int32_t msm_digits(zkpor_ctx* ctx, const Fr* d_scalars, size_t n, const M
             else { fk[f] = ws_alloc<u32>(ctx, cap); fv[f] = ws_alloc<u32>(ctx, cap); if (!fk[f] || !fv[f]) { ctx->err = "msm: workspace too small"; return ZKPOR_E_OOM; } }
         }
         PhaseScope ps(ctx, "msm_filter");
-        int grid = ctx->msm_filter_grid > 0 ? ctx->msm_filter_grid : 512;
+        int grid = ctx->msm_filter_grid > 0 ? ctx->msm_filter_grid : 256;
         if (grid > (int)FILTER_MAX_GRID) grid = FILTER_MAX_GRID;
         ZK_TRY(launch_filter(ctx, out->keys, out->vals, M, (u32*)temp, (u32)grid, fk[0], fv[0], fk[1], fv[1]));
         if (g0) { out_f0->keys = fk[0]; out_f0->vals = fv[0]; out_f0->M = Ms[1]; }

@@ -186,6 +186,99 @@ ZK_D Fr29 scale29(const PassArgs29& A, int mode, const Fr29& v, u32 p) {
     return Fr29::mul(v, g);
 }
 
+// all radix-2 stages of one field on an LDS tile of (2^kb x 2^clog) elements (element i at tile + 9 i); ends with a barrier
+template <bool DIF>
+ZK_D void ntt_stages29(u32* tile, const u32* __restrict__ small29, const int kb, const int lo, const int clog) {
+    const u32 F = 1u << kb, C = 1u << clog;
+    const u32 total = F << clog;
+    // stages two at a time: a thread takes the four elements that differ in the two index bits of stages j and j+1,
+    // does both stages in registers (4 products, as two radix-2 stages would) and touches LDS once instead of twice
+    int j = 0;
+    for (; j + 1 < kb; j += 2) {
+        const int hA = DIF ? (kb - 1 - j) : j;          // bit of the first stage of the pair
+        const int hB = DIF ? hA - 1 : hA + 1;           // bit of the second
+        const int hl = DIF ? hB : hA;                   // the lower of the two
+        const int tsA = (DIF ? j : (kb - 1 - j)) + (9 - kb);
+        const int tsB = (DIF ? j + 1 : (kb - 2 - j)) + (9 - kb);
+        const u32 ngrp = total >> 2;
+        for (u32 t = threadIdx.x; t < ngrp; t += 256u) {
+            u32 q, c;
+            if (lo > 0) { c = t & (C - 1u); q = t >> clog; }
+            else { q = t & ((F >> 2) - 1u); c = t >> (kb - 2); }
+            const u32 low = q & ((1u << hl) - 1u);
+            const u32 base = ((q >> hl) << (hl + 2)) + low;
+            const u32 s1 = 1u << hl, s2 = 2u << hl;
+            // x0..x3 = base + {0, s1, s2, s1+s2}
+            u32* p0 = tile + 9u * (lo > 0 ? base * C + c : c * F + base);
+            const u32 estep = 9u * (lo > 0 ? C : 1u);
+            u32* p1 = p0 + estep * s1; u32* p2 = p0 + estep * s2; u32* p3 = p2 + estep * s1;
+            Fr29 x0 = ld29(p0), x1 = ld29(p1), x2 = ld29(p2), x3 = ld29(p3);
+            if (DIF) {
+                // stage A pairs elements 2^hA apart (x0,x2),(x1,x3): twiddle position = index below bit hA
+                const u32 posA0 = low, posA1 = low + s1;
+                Fr29 wa0 = ld29(small29 + 9u * (posA0 << tsA)), wa1 = ld29(small29 + 9u * (posA1 << tsA));
+                Fr29 a0 = Fr29::reduce32(Fr29::add_l(x0, x2)), a2 = Fr29::mul(wa0, Fr29::sub_l(x0, x2));
+                Fr29 a1 = Fr29::reduce32(Fr29::add_l(x1, x3)), a3 = Fr29::mul(wa1, Fr29::sub_l(x1, x3));
+                // stage B pairs elements 2^hB apart (a0,a1),(a2,a3): position = index below bit hB = low
+                st29(p0, Fr29::reduce32(Fr29::add_l(a0, a1)));
+                st29(p2, Fr29::reduce32(Fr29::add_l(a2, a3)));
+                if (hl == 0) {  // the field's last stage: every twiddle is w^0 = 1, a product-free reduction replaces the product
+                    st29(p1, Fr29::reduce32(Fr29::sub_l(a0, a1)));
+                    st29(p3, Fr29::reduce32(Fr29::sub_l(a2, a3)));
+                } else {
+                    Fr29 wb = ld29(small29 + 9u * (low << tsB));
+                    st29(p1, Fr29::mul(wb, Fr29::sub_l(a0, a1)));
+                    st29(p3, Fr29::mul(wb, Fr29::sub_l(a2, a3)));
+                }
+            } else {
+                // stage A pairs (x0,x1),(x2,x3) (distance 2^hA), position = low
+                Fr29 t1 = x1, t3 = x3;
+                if (hl != 0) {  // (the field's first stage has twiddle w^0 = 1 throughout: no product)
+                    Fr29 wa = ld29(small29 + 9u * (low << tsA));
+                    t1 = Fr29::mul(x1, wa); t3 = Fr29::mul(x3, wa);
+                }
+                Fr29 a0 = Fr29::reduce32(Fr29::add_l(x0, t1)), a1 = Fr29::reduce32(Fr29::sub_l(x0, t1));
+                Fr29 a2 = Fr29::reduce32(Fr29::add_l(x2, t3)), a3 = Fr29::reduce32(Fr29::sub_l(x2, t3));
+                // stage B pairs (a0,a2),(a1,a3) (distance 2^hB), positions low and low + 2^hA
+                Fr29 wb0 = ld29(small29 + 9u * (low << tsB)), wb1 = ld29(small29 + 9u * ((low + s1) << tsB));
+                Fr29 u2 = Fr29::mul(a2, wb0), u3 = Fr29::mul(a3, wb1);
+                st29(p0, Fr29::reduce32(Fr29::add_l(a0, u2)));
+                st29(p2, Fr29::reduce32(Fr29::sub_l(a0, u2)));
+                st29(p1, Fr29::reduce32(Fr29::add_l(a1, u3)));
+                st29(p3, Fr29::reduce32(Fr29::sub_l(a1, u3)));
+            }
+        }
+        __syncthreads();
+    }
+    const u32 nbf = total >> 1;
+    for (; j < kb; ++j) {
+        const int hlog = DIF ? (kb - 1 - j) : j;
+        const u32 half = 1u << hlog;
+        const int tshift = (DIF ? j : (kb - 1 - j)) + (9 - kb);
+        for (u32 t = threadIdx.x; t < nbf; t += 256u) {
+            u32 q, c;
+            if (lo > 0) { c = t & (C - 1u); q = t >> clog; }
+            else { q = t & ((F >> 1) - 1u); c = t >> (kb - 1); }
+            u32 pos = q & (half - 1u);
+            u32 i0 = ((q >> hlog) << (hlog + 1)) + pos;
+            u32 i1 = i0 + half;
+            u32* p0 = tile + 9u * (lo > 0 ? i0 * C + c : c * F + i0);
+            u32* p1 = tile + 9u * (lo > 0 ? i1 * C + c : c * F + i1);
+            Fr29 a = ld29(p0), b = ld29(p1);
+            if (DIF) {
+                st29(p0, Fr29::reduce32(Fr29::add_l(a, b)));
+                if (half == 1u) st29(p1, Fr29::reduce32(Fr29::sub_l(a, b)));      // last stage: twiddle 1
+                else st29(p1, Fr29::mul(ld29(small29 + 9u * (pos << tshift)), Fr29::sub_l(a, b)));
+            } else {
+                Fr29 tb_ = half == 1u ? b : Fr29::mul(b, ld29(small29 + 9u * (pos << tshift)));
+                st29(p0, Fr29::reduce32(Fr29::add_l(a, tb_)));
+                st29(p1, Fr29::reduce32(Fr29::sub_l(a, tb_)));
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <bool DIF>
 __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -214,92 +307,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
         st29(tile + 9u * li, v);
     }
     __syncthreads();
-    // stages two at a time: a thread takes the four elements that differ in the two index bits of stages j and j+1,
-    // does both stages in registers (4 products, as two radix-2 stages would) and touches LDS once instead of twice
-    int j = 0;
-    for (; j + 1 < kb; j += 2) {
-        const int hA = DIF ? (kb - 1 - j) : j;          // bit of the first stage of the pair
-        const int hB = DIF ? hA - 1 : hA + 1;           // bit of the second
-        const int hl = DIF ? hB : hA;                   // the lower of the two
-        const int tsA = (DIF ? j : (kb - 1 - j)) + (9 - kb);
-        const int tsB = (DIF ? j + 1 : (kb - 2 - j)) + (9 - kb);
-        const u32 ngrp = total >> 2;
-        for (u32 t = threadIdx.x; t < ngrp; t += 256u) {
-            u32 q, c;
-            if (lo > 0) { c = t & (C - 1u); q = t >> clog; }
-            else { q = t & ((F >> 2) - 1u); c = t >> (kb - 2); }
-            const u32 low = q & ((1u << hl) - 1u);
-            const u32 base = ((q >> hl) << (hl + 2)) + low;
-            const u32 s1 = 1u << hl, s2 = 2u << hl;
-            // x0..x3 = base + {0, s1, s2, s1+s2}
-            u32* p0 = tile + 9u * (lo > 0 ? base * C + c : c * F + base);
-            const u32 estep = 9u * (lo > 0 ? C : 1u);
-            u32* p1 = p0 + estep * s1; u32* p2 = p0 + estep * s2; u32* p3 = p2 + estep * s1;
-            Fr29 x0 = ld29(p0), x1 = ld29(p1), x2 = ld29(p2), x3 = ld29(p3);
-            if (DIF) {
-                // stage A pairs elements 2^hA apart (x0,x2),(x1,x3): twiddle position = index below bit hA
-                const u32 posA0 = low, posA1 = low + s1;
-                Fr29 wa0 = ld29(A.small29 + 9u * (posA0 << tsA)), wa1 = ld29(A.small29 + 9u * (posA1 << tsA));
-                Fr29 a0 = Fr29::reduce32(Fr29::add_l(x0, x2)), a2 = Fr29::mul(wa0, Fr29::sub_l(x0, x2));
-                Fr29 a1 = Fr29::reduce32(Fr29::add_l(x1, x3)), a3 = Fr29::mul(wa1, Fr29::sub_l(x1, x3));
-                // stage B pairs elements 2^hB apart (a0,a1),(a2,a3): position = index below bit hB = low
-                st29(p0, Fr29::reduce32(Fr29::add_l(a0, a1)));
-                st29(p2, Fr29::reduce32(Fr29::add_l(a2, a3)));
-                if (hl == 0) {  // the field's last stage: every twiddle is w^0 = 1, a product-free reduction replaces the product
-                    st29(p1, Fr29::reduce32(Fr29::sub_l(a0, a1)));
-                    st29(p3, Fr29::reduce32(Fr29::sub_l(a2, a3)));
-                } else {
-                    Fr29 wb = ld29(A.small29 + 9u * (low << tsB));
-                    st29(p1, Fr29::mul(wb, Fr29::sub_l(a0, a1)));
-                    st29(p3, Fr29::mul(wb, Fr29::sub_l(a2, a3)));
-                }
-            } else {
-                // stage A pairs (x0,x1),(x2,x3) (distance 2^hA), position = low
-                Fr29 t1 = x1, t3 = x3;
-                if (hl != 0) {  // (the field's first stage has twiddle w^0 = 1 throughout: no product)
-                    Fr29 wa = ld29(A.small29 + 9u * (low << tsA));
-                    t1 = Fr29::mul(x1, wa); t3 = Fr29::mul(x3, wa);
-                }
-                Fr29 a0 = Fr29::reduce32(Fr29::add_l(x0, t1)), a1 = Fr29::reduce32(Fr29::sub_l(x0, t1));
-                Fr29 a2 = Fr29::reduce32(Fr29::add_l(x2, t3)), a3 = Fr29::reduce32(Fr29::sub_l(x2, t3));
-                // stage B pairs (a0,a2),(a1,a3) (distance 2^hB), positions low and low + 2^hA
-                Fr29 wb0 = ld29(A.small29 + 9u * (low << tsB)), wb1 = ld29(A.small29 + 9u * ((low + s1) << tsB));
-                Fr29 u2 = Fr29::mul(a2, wb0), u3 = Fr29::mul(a3, wb1);
-                st29(p0, Fr29::reduce32(Fr29::add_l(a0, u2)));
-                st29(p2, Fr29::reduce32(Fr29::sub_l(a0, u2)));
-                st29(p1, Fr29::reduce32(Fr29::add_l(a1, u3)));
-                st29(p3, Fr29::reduce32(Fr29::sub_l(a1, u3)));
-            }
-        }
-        __syncthreads();
-    }
-    const u32 nbf = total >> 1;
-    for (; j < kb; ++j) {
-        const int hlog = DIF ? (kb - 1 - j) : j;
-        const u32 half = 1u << hlog;
-        const int tshift = (DIF ? j : (kb - 1 - j)) + (9 - kb);
-        for (u32 t = threadIdx.x; t < nbf; t += 256u) {
-            u32 q, c;
-            if (lo > 0) { c = t & (C - 1u); q = t >> clog; }
-            else { q = t & ((F >> 1) - 1u); c = t >> (kb - 1); }
-            u32 pos = q & (half - 1u);
-            u32 i0 = ((q >> hlog) << (hlog + 1)) + pos;
-            u32 i1 = i0 + half;
-            u32* p0 = tile + 9u * (lo > 0 ? i0 * C + c : c * F + i0);
-            u32* p1 = tile + 9u * (lo > 0 ? i1 * C + c : c * F + i1);
-            Fr29 a = ld29(p0), b = ld29(p1);
-            if (DIF) {
-                st29(p0, Fr29::reduce32(Fr29::add_l(a, b)));
-                if (half == 1u) st29(p1, Fr29::reduce32(Fr29::sub_l(a, b)));      // last stage: twiddle 1
-                else st29(p1, Fr29::mul(ld29(A.small29 + 9u * (pos << tshift)), Fr29::sub_l(a, b)));
-            } else {
-                Fr29 tb_ = half == 1u ? b : Fr29::mul(b, ld29(A.small29 + 9u * (pos << tshift)));
-                st29(p0, Fr29::reduce32(Fr29::add_l(a, tb_)));
-                st29(p1, Fr29::reduce32(Fr29::sub_l(a, tb_)));
-            }
-        }
-        __syncthreads();
-    }
+    ntt_stages29<DIF>(tile, A.small29, kb, lo, clog);
     for (u32 idx = threadIdx.x; idx < total; idx += 256u) {
         u32 m, c, p, li;
         if (lo > 0) { c = idx & (C - 1u); m = idx >> clog; p = (hi << (lo + kb)) + (m << lo) + l0 + c; li = m * C + c; }
@@ -308,6 +316,91 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
         if (DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << (lo + A.p_shift)) | (((l0 + c) << A.p_shift) | A.p_or)]));
         if (A.scale_store) v = scale29(A, A.scale_store, v, ((p << A.p_shift) | A.p_or) + A.p_add);
         A.x[p] = A.out_gnark ? Fr29::to32_div32(v) : Fr29::reduce32_pos(v).pack32();
+    }
+}
+
+// computeH runs, per vector, an inverse DIF transform (fields high -> low) and then a forward coset DIT transform (fields low -> high): the
+// last pass of the first and the first pass of the second work on the SAME tiles of the lowest field (lo == 0: contiguous groups of 2^kb
+// elements).  This kernel does both on one tile — DIF stages with the inverse table, the coset scale g^rev(p) / N, DIT stages with the
+// forward table: one load and one store instead of two of each, no round trip through gnark's form in between (21 -> 18 launches and
+// 6 x 2 GiB less traffic per computeH at 2^26).  A = the DIF pass's arguments (its x / src, small29 = inverse table), B = the DIT pass's
+// (scale tables, small29 = forward table, out_gnark).  Bit-identical to the two passes: only a canonicalisation in between is skipped.
+__global__ __launch_bounds__(256) void k_ntt_mid29(PassArgs29 A, PassArgs29 B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32* tile = (u32*)smem_raw;
+    const int kb = A.kb, clog = A.clog;
+    const u32 F = 1u << kb;
+    const u32 hi = blockIdx.x << clog;
+    const u32 total = F << clog;
+    for (u32 idx = threadIdx.x; idx < total; idx += 256u) {
+        const u32 m = idx & (F - 1u), c = idx >> kb, p = ((hi + c) << kb) + m, li = c * F + m;
+        const Fr raw = A.src[p];
+        st29(tile + 9u * li, A.in_gnark ? Fr29::from32<5>(raw) : Fr29::from32<0>(raw));
+    }
+    __syncthreads();
+    ntt_stages29<true>(tile, A.small29, kb, 0, clog);
+    for (u32 idx = threadIdx.x; idx < total; idx += 256u) {
+        const u32 m = idx & (F - 1u), c = idx >> kb, p = ((hi + c) << kb) + m, li = c * F + m;
+        st29(tile + 9u * li, scale29(B, B.scale_load, ld29(tile + 9u * li), p));
+    }
+    __syncthreads();
+    ntt_stages29<false>(tile, B.small29, kb, 0, clog);
+    for (u32 idx = threadIdx.x; idx < total; idx += 256u) {
+        const u32 m = idx & (F - 1u), c = idx >> kb, p = ((hi + c) << kb) + m, li = c * F + m;
+        const Fr29 v = ld29(tile + 9u * li);
+        B.x[p] = B.out_gnark ? Fr29::to32_div32(v) : Fr29::reduce32_pos(v).pack32();
+    }
+}
+
+// The other fusable place of computeH: the LAST pass of the three forward coset transforms (DIT, highest field), the pointwise step
+// h = (a b - c) / (g^D - 1) and the FIRST pass of the inverse coset transform of h (DIF, highest field) all work on the same tiles of the
+// highest field.  One kernel: for a, then b, then c — load with the DIT pre-twiddle, DIT stages — with the running product kept in
+// registers (a thread reads back exactly the LDS slots it loaded, so no barrier separates the vectors), then h into the tile, DIF stages,
+// store with the DIF post-twiddle.  Saves the three stores, the pointwise kernel (two 32-bit products per element become two 29-bit
+// ones), one load, and three launches; with k_ntt_mid29: 21 + 1 -> 15 launches and 14 x 2 GiB less traffic per computeH at 2^26.
+// T = the DIT pass's arguments for a (xb, xc: the other two vectors); I = the DIF pass's arguments for a; den29 = 32 / (g^D - 1).
+template <int PER>   // tile elements per thread: 2 or 4
+__global__ __launch_bounds__(256) void k_ntt_top29(PassArgs29 T, Fr* xb, Fr* xc, PassArgs29 I, Fr den29) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32* tile = (u32*)smem_raw;
+    const int kb = T.kb, lo = T.lo, clog = T.clog;
+    const u32 C = 1u << clog;
+    const u32 lgroups = (1u << lo) >> clog;
+    const u32 hi = blockIdx.x / lgroups, l0 = (blockIdx.x % lgroups) << clog;
+    Fr29 acc[PER];
+    Fr* const xs[3] = {T.x, xb, xc};
+#pragma unroll 1
+    for (int v = 0; v < 3; ++v) {
+        const Fr* x = xs[v];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const u32 idx = threadIdx.x + 256u * k;
+            const u32 c = idx & (C - 1u), m = idx >> clog, p = (hi << (lo + kb)) + (m << lo) + l0 + c;
+            Fr29 e = Fr29::from32<0>(x[p]);
+            e = Fr29::mul(e, Fr29::from32<0>(T.tw_full[((size_t)brev(m, kb) << lo) | (l0 + c)]));
+            st29(tile + 9u * idx, e);
+        }
+        __syncthreads();
+        ntt_stages29<false>(tile, T.small29, kb, lo, clog);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const Fr29 e = ld29(tile + 9u * (threadIdx.x + 256u * k));
+            if (v == 0) acc[k] = e;
+            else if (v == 1) acc[k] = Fr29::mul(acc[k], e);
+            else acc[k] = Fr29::mul(Fr29::from32<0>(den29), Fr29::sub_l(acc[k], e));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) st29(tile + 9u * (threadIdx.x + 256u * k), acc[k]);
+    __syncthreads();
+    ntt_stages29<true>(tile, I.small29, kb, lo, clog);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const u32 idx = threadIdx.x + 256u * k;
+        const u32 c = idx & (C - 1u), m = idx >> clog, p = (hi << (lo + kb)) + (m << lo) + l0 + c;
+        Fr29 e = ld29(tile + 9u * idx);
+        e = Fr29::mul(e, Fr29::from32<0>(I.tw_full[((size_t)brev(m, kb) << lo) | (l0 + c)]));
+        I.x[p] = Fr29::reduce32_pos(e).pack32();
     }
 }
 
@@ -501,7 +594,7 @@ void ntt_domains_free(zkpor_ctx* ctx) {
 struct ScaleSpec { int mode = 0; const Fr* g_lo = nullptr; const Fr* g_hi = nullptr; Fr konst; };
 
 static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
-                            const ScaleSpec& last_store, const Fr* src);
+                            const ScaleSpec& last_store, const Fr* src, int step_lo = 0, int step_hi = 99, PassArgs29* only_args = nullptr);
 // src (optional): the transform reads its input from there and leaves it untouched; x receives every pass's output
 static int32_t run_passes(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
                           const ScaleSpec& last_store, const Fr* src = nullptr) {
@@ -551,12 +644,13 @@ static const Fr* table29(const NttDomain* d, const Fr* t) {
     return nullptr;
 }
 static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
-                            const ScaleSpec& last_store, const Fr* src) {
+                            const ScaleSpec& last_store, const Fr* src, int step_lo, int step_hi, PassArgs29* only_args) {
     Field f[8];
     int nf = plan_fields(d->n, f);
     Fr c32 = Fr::one();
     for (int i = 0; i < 5; ++i) c32 = Fr::add(c32, c32);
-    for (int step = 0; step < nf; ++step) {
+    if (step_hi > nf) step_hi = nf;
+    for (int step = step_lo; step < step_hi; ++step) {
         const int fi = dif ? nf - 1 - step : step;
         const Field& fl = f[fi];
         PassArgs29 A;
@@ -583,6 +677,7 @@ static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, b
             else { A.g_lo = table29(d, last_store.g_lo); A.g_hi = table29(d, last_store.g_hi); }
         }
         if ((A.scale_load > 1 || A.scale_store > 1) && (!A.g_lo || !A.g_hi)) { ctx->err = "ntt: no 2^261-form table for this scale"; return ZKPOR_E_ARG; }
+        if (only_args) { *only_args = A; return ZKPOR_OK; }   // the caller launches a fused kernel with these arguments
         u32 blocks = (u32)(((size_t)1 << d->n) >> (fl.kb + A.clog));
         size_t smem = ((size_t)36 << fl.kb) << A.clog;
         if (smem > 64 * 1024) {  // beyond the default dynamic-LDS limit (gfx950 has 160 KiB per CU); per device, so no caching here
@@ -594,6 +689,44 @@ static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, b
         ZK_KERNEL_CHECK(ctx);
     }
     return ZKPOR_OK;
+}
+
+// inverse DIF transform followed by forward coset DIT transform of one vector, as computeH needs them, with the two passes over the lowest
+// field fused (k_ntt_mid29).  Falls back to the two plain transforms when the fusion does not apply.
+static bool ntt_fusable(zkpor_ctx* ctx, NttDomain* d) {
+    Field f[8];
+    const int nf = plan_fields(d->n, f);
+    if (!(ctx->ntt_variant == 1 && d->have29 && ctx->ntt_fuse && nf >= 2)) return false;
+    const int top = nf - 1;
+    int cmax = ctx->ntt_tile_log - f[top].kb;
+    if (cmax < 0) cmax = 0;
+    const int clog = f[top].lo < cmax ? f[top].lo : cmax;
+    const int tl = f[top].kb + clog;             // log2 of the top field's tile: the fused top kernel keeps 2 or 4 elements per thread
+    return tl == 9 || tl == 10;
+}
+// skip_top: leave out the DIT pass of the highest field (the caller runs k_ntt_top29 over all three vectors instead)
+static int32_t run_inverse_then_coset_forward(zkpor_ctx* ctx, NttDomain* d, Fr* x, const ScaleSpec& pre, const Fr* src, bool skip_top) {
+    Field f[8];
+    const int nf = plan_fields(d->n, f);
+    ScaleSpec none;
+    if (!ntt_fusable(ctx, d)) {
+        ZK_TRY(run_passes(ctx, d, x, true, true, none, none, src));
+        return run_passes(ctx, d, x, false, false, pre, none);
+    }
+    PassArgs29 A, B;
+    ZK_TRY(run_passes29(ctx, d, x, true, true, none, none, src, 0, nf - 1));                   // DIF: every field but the lowest
+    ZK_TRY(run_passes29(ctx, d, x, true, true, none, none, src, nf - 1, nf, &A));             // the lowest field's DIF pass: arguments only
+    ZK_TRY(run_passes29(ctx, d, x, false, false, pre, none, nullptr, 0, 1, &B));              // the lowest field's DIT pass: arguments only
+    A.in_gnark = 0; A.out_gnark = 0;                                                            // nf >= 2: the DIF pass is not the first, the DIT pass not the last
+    if (A.kb != B.kb || A.clog != B.clog || A.lo != 0 || B.lo != 0) { ctx->err = "ntt: fused pass geometry mismatch"; return ZKPOR_E_STATE; }
+    {
+        const u32 blocks = (u32)(((size_t)1 << d->n) >> (A.kb + A.clog));
+        const size_t smem = ((size_t)36 << A.kb) << A.clog;
+        if (smem > 64 * 1024) ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_mid29, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(k_ntt_mid29, dim3(blocks), dim3(256), smem, ctx->stream, A, B);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    return run_passes29(ctx, d, x, false, false, pre, none, nullptr, 1, skip_top ? nf - 1 : nf);   // DIT: the fields above the lowest
 }
 
 // ---- one transform spread over W = 2^wlog GPUs (index algebra modelled in tools/ntt_model.py fft_sharded) ----
@@ -744,9 +877,26 @@ int32_t compute_h_dev(zkpor_ctx* ctx, int n, Fr* a, Fr* b, Fr* c, const Fr* a_in
         PhaseScope ps(ctx, "ntt");
         Fr* v[3] = {a, b, c};
         const Fr* in[3] = {a_in, b_in, c_in};     // inputs the caller wants preserved: the first pass reads them, a / b / c are the work buffers
-        for (int i = 0; i < 3; ++i) {
-            ZK_TRY(run_passes(ctx, d, v[i], true, true, none, none, in[i]));
-            ZK_TRY(run_passes(ctx, d, v[i], false, false, pre, none));
+        const bool fuse = ntt_fusable(ctx, d);
+        for (int i = 0; i < 3; ++i) ZK_TRY(run_inverse_then_coset_forward(ctx, d, v[i], pre, in[i], fuse));
+        if (fuse) {
+            Field f[8];
+            const int nf = plan_fields(n, f);
+            PassArgs29 T, I;
+            ZK_TRY(run_passes29(ctx, d, a, false, false, pre, none, nullptr, nf - 1, nf, &T));   // DIT, highest field: arguments only
+            ZK_TRY(run_passes29(ctx, d, a, true, true, none, post, nullptr, 0, 1, &I));          // DIF of the inverse coset transform, highest field
+            if (T.kb != I.kb || T.clog != I.clog || T.lo != I.lo || T.lo == 0) { ctx->err = "ntt: fused top pass geometry mismatch"; return ZKPOR_E_STATE; }
+            Fr c32 = Fr::one();
+            for (int i = 0; i < 5; ++i) c32 = Fr::add(c32, c32);
+            const Fr den29 = Fr::mul(d->den, c32);
+            const int tl = T.kb + T.clog;
+            const u32 blocks = (u32)(((size_t)1 << n) >> tl);
+            const size_t smem = (size_t)36 << tl;
+            if (tl == 10) hipLaunchKernelGGL(k_ntt_top29<4>, dim3(blocks), dim3(256), smem, ctx->stream, T, b, c, I, den29);
+            else hipLaunchKernelGGL(k_ntt_top29<2>, dim3(blocks), dim3(256), smem, ctx->stream, T, b, c, I, den29);
+            ZK_KERNEL_CHECK(ctx);
+            ZK_TRY(run_passes29(ctx, d, a, true, true, none, post, nullptr, 1, nf));              // the remaining DIF passes of h
+            return ZKPOR_OK;
         }
     }
     {
