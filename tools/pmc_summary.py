@@ -10,7 +10,11 @@ import sys
 KERNELS = {  # substring of the kernel name -> (label, FETCH_SIZE correction)
     "k_acc_level1_fp29": ("k_acc_level1_fp29", 1.0),        # 64-byte random gathers are counted 1:1
     "k_acc_level1_g2pair29": ("k_acc_level1_g2pair29", 2.0),
-    "k_ntt_pass29": ("k_ntt_pass29", 2.0),                  # wide coalesced streams read back at 1/2
+    "k_ntt_pass29": ("k_ntt_pass29", 2.0),                  # wide coalesced streams read back at 1/2 (per launch: see ntt_per_launch below)
+    "k_ntt_mid29": ("k_ntt_mid29", 2.0),                    # lowest field: contiguous 8 KiB tiles
+    "k_ntt_top29": ("k_ntt_top29", 1.0),                    # highest field: 64-128 B segments, counted 1:1
+    "k_filter_write": ("k_filter_write", 2.0),
+    "k_filter_count": ("k_filter_count", 2.0),
     "k_h_pointwise": ("k_h_pointwise", 2.0),
     "k_acc_levelN29": ("k_acc_levelN29", 2.0),
     "k_reduce_level29": ("k_reduce_level29", 2.0),
@@ -32,7 +36,7 @@ def load(path, counter):
 def main():
     fetch = load(sys.argv[1], "FETCH_SIZE"); write = load(sys.argv[2], "WRITE_SIZE")
     out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --log2 26 --steps 1 "
-                      "--warmup 0 --timed-only (two separate passes, tools/r02_profile.sh)",
+                      "--warmup 0 --timed-only (two separate passes, tools/r03_profile.sh)",
            "calibration": "FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 wide coalesced read streams report exactly 1/2 of the true bytes "
                           "(calibrated in round 1 on k_fr_mul: 4.29 GB true reads -> 2.147 GB reported, k_h_pointwise 6.44 -> 3.22; WRITE_SIZE exact), "
                           "as MI355X_MICROARCH.md says; the 64-byte random point gathers of the G1 level-1 kernel are counted 1:1 "
@@ -45,6 +49,28 @@ def main():
         fpl = fb * 1024 / max(fn, 1); wpl = wb * 1024 / max(wn, 1)
         out["kernels"][label] = {"launches": fn, "fetch_raw_bytes_per_launch": fpl, "fetch_correction": corr,
                                  "write_bytes_per_launch": wpl, "hbm_bytes_per_launch": fpl * corr + wpl}
+    # the NTT launches one by one: a launch that reads contiguous tiles (lowest field) reports half of its reads, the others 1:1 —
+    # told apart by the raw figure (half an array or less = a halved contiguous stream); total per computeH = the sum over one proof
+    arr = float(32 << 26)
+    per = collections.defaultdict(lambda: [0.0, 0])
+    wr = collections.defaultdict(lambda: [0.0, 0])
+    rows = []
+    for r in csv.DictReader(open(sys.argv[1])):
+        if r["Counter_Name"] == "FETCH_SIZE" and "k_ntt_" in r["Kernel_Name"]:
+            rows.append((r["Dispatch_Id"], r["Kernel_Name"], float(r["Counter_Value"]) * 1024))
+    wmap = {}
+    for r in csv.DictReader(open(sys.argv[2])):
+        if r["Counter_Name"] == "WRITE_SIZE" and "k_ntt_" in r["Kernel_Name"]:
+            wmap[r["Dispatch_Id"]] = float(r["Counter_Value"]) * 1024
+    total = 0.0
+    for did, name, raw in rows:
+        corr = 2.0 if raw < 0.75 * arr else 1.0
+        total += raw * corr + wmap.get(did, 0.0)
+    if rows:
+        out["ntt_hbm_bytes_per_computeH"] = total
+        out["ntt_launches_per_computeH"] = len(rows)
+        out["ntt_note"] = ("per launch: FETCH_SIZE x 2 when the raw figure is below 3/4 of the array (contiguous tiles of the lowest field are "
+                           "read back at 1/2), x 1 otherwise (strided 64-128 B segments + tabulated twiddles), + WRITE_SIZE; one proof in the trace")
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 

@@ -7,7 +7,8 @@ import csv
 import json
 import sys
 
-KERNELS = ("k_acc_level1_fp29", "k_acc_level1_g2pair29", "k_ntt_pass29", "k_acc_levelN29", "k_reduce_level29", "k_h_pointwise", "k_decompose")
+KERNELS = ("k_acc_level1_fp29", "k_acc_level1_g2pair29", "k_ntt_pass29", "k_ntt_mid29", "k_ntt_top29", "k_acc_levelN29", "k_reduce_level29", "k_reduce_scan29", "k_h_pointwise",
+           "k_decompose", "k_filter_write", "k_filter_count")
 
 
 def main():

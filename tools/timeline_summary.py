@@ -23,7 +23,7 @@ def main():
     rows.sort()
     # a proof starts with the three k_ntt_pass29 launches... robust marker: the first k_h_pointwise of each proof; take windows between
     # consecutive copies that precede a proof: bench.py copies a0,b0,c0 -> a,b,c (memcpy, not a kernel), so use k_h_pointwise as anchor
-    anchors = [i for i, r in enumerate(rows) if "k_h_pointwise" in r[3]]
+    anchors = [i for i, r in enumerate(rows) if "k_h_pointwise" in r[3] or "k_ntt_top29" in r[3]]   # one per proof (the fused top pass since round 3)
     if len(anchors) < 2:
         print("need at least two proofs in the trace"); return
     # proof window: from the first kernel after the previous proof's last kernel... approximate by anchor-to-anchor period
@@ -31,7 +31,7 @@ def main():
     t0, t1 = rows[a0][0], rows[a1][0]
     period = (t1 - t0) / 1e6
     win = [r for r in rows if t0 <= r[0] < t1]
-    print(f"one proof period (k_h_pointwise to k_h_pointwise): {period:.2f} ms, {len(win)} kernel launches")
+    print(f"one proof period (pointwise step to pointwise step): {period:.2f} ms, {len(win)} kernel launches")
     per_stream = defaultdict(float)
     fam = defaultdict(lambda: [0.0, 0])
     for s, e, st, n in win:

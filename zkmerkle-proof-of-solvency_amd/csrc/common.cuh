@@ -30,7 +30,7 @@ struct zkpor_ctx {
     // tuning
     int msm_window = 0;  // 0 = auto
     int msm_tables = 1;  // fixed-base tables per key point, applied to keys loaded AFTER the parameter is set (msm.cuh MsmCfg)
-    int msm_chunk = 32;
+    int msm_chunk = 0;               // sorted entries per level-1 thread: 0 = 64 from 2^22 scalars up (fewer partial sums: -5 ms per 2^26 proof), else 32
     int g1_variant = 1;  // level-1 G1 accumulation arithmetic: 0 = 8 x 32-bit limbs, 1 = 9 x 29-bit limbs (fe29.cuh)
     int g2_variant = 1;  // same for the G2 lane-pair kernel
     int ntt_tile_log = 10;  // log2 of the elements per LDS tile of k_ntt_pass29 (36 B each)

@@ -61,7 +61,7 @@ inline MsmCfg msm_cfg(zkpor_ctx* ctx, size_t n, int tables = 1) {
     m.piece = (m.W + m.m - 1) / m.m;
     m.bpw = 1u << (c - 1);
     m.NB = m.bpw * (u32)m.piece;
-    m.L = ctx->msm_chunk < 4 ? 4 : ctx->msm_chunk;
+    m.L = ctx->msm_chunk >= 4 ? ctx->msm_chunk : (n >= ((size_t)1 << 22) ? 64 : 32);
     m.key_bits = log2_ceil(m.NB);
     if (m.key_bits < 1) m.key_bits = 1;
     m.g1 = m.bpw < 128 ? m.bpw : 128;
