@@ -17,7 +17,10 @@ struct AccOut {
 // The (key,val) words of a block's chunks are staged through LDS in sub-phases of ACC_SUB entries per thread with
 // coalesced global loads: read one-by-one they cost a 64-byte fabric request per 4-byte word (measured with
 // rocprofv3 FETCH_SIZE: 185 B/entry instead of ~72), which made this kernel HBM-bound.
-static constexpr int ACC_SUB = 16;
+#ifndef ZK_ACC_SUB   // experiment hook (tools/r03_accsub.sh): entries per thread and staging phase; LDS per workgroup = 2 x 256 x (ZK_ACC_SUB + 1) x 4 B
+#define ZK_ACC_SUB 16
+#endif
+static constexpr int ACC_SUB = ZK_ACC_SUB;
 static constexpr int ACC_PITCH = ACC_SUB + 1;  // odd pitch: conflict-free column reads
 
 // cooperative load of phase `ph`: row r of the tile = the ACC_SUB entries [ (row0+r)*L + ph*ACC_SUB, ... ) of thread r
