@@ -562,6 +562,9 @@ def witness_gen_leg(ctx, users=1380, tier=50, n_wires=1 << 26):
     n_values = users * 32 * tier                           # ~128 sixteen-bit limbs per asset (Appendix B) = 32 64-bit values
     nb_limbs = 4
     n_inv = n_values * nb_limbs + users * (29 * tier + 2500) + 65536
+    n_lookup = users * 29 * tier                           # lookup results: one per query (asset table, price, challenge powers, 18 tier queries per asset)
+    n_div = users * 3 * tier                               # circuit.IntegerDivision: one per (asset slot, collateral type)
+    n_bits_vals, nbits = 4_900_000 // 128, 128             # the shared base's ~4.9 M comparison bits (Appendix B), as 128-bit decompositions
     bufs = []
 
     def alloc(nbytes):
@@ -586,6 +589,16 @@ def witness_gen_leg(ctx, users=1380, tier=50, n_wires=1 << 26):
         inv_in = alloc(n_inv * 32); inv_out = alloc(n_inv * 32)
         ctx.fill_fr(inv_in, n_inv, 78, 0)
         slots += nb_limbs * n_values + n_inv
+        table = alloc(2500 * 32); ctx.fill_fr(table, 2500, 79, 0)
+        lk_idx = alloc(n_lookup * 32); lk_out = alloc(n_lookup * 32)
+        idx_host = np.zeros((n_lookup, 4), dtype=np.uint64); idx_host[:, 0] = np.random.default_rng(2).integers(0, 2500, size=n_lookup, dtype=np.uint64)
+        idx_m = np.empty_like(idx_host); O.lib().orc_fr_from_canon(O._p(idx_host), O._p(idx_m), n_lookup); lk_idx.upload(idx_m)
+        div_in = alloc(n_div * 32); div_q = alloc(n_div * 32); div_r = alloc(n_div * 32)
+        ctx.fill_fr(div_in, n_div, 80, 0)
+        bit_in = alloc(n_bits_vals * 32); bit_out = alloc(n_bits_vals * nbits * 32)
+        bv = np.zeros((n_bits_vals, 4), dtype=np.uint64); bv[:, :2] = np.random.default_rng(3).integers(0, 1 << 63, size=(n_bits_vals, 2), dtype=np.uint64)
+        bm = np.empty_like(bv); O.lib().orc_fr_from_canon(O._p(bv), O._p(bm), n_bits_vals); bit_in.upload(bm)
+        slots += n_lookup + 2 * n_div + n_bits_vals * nbits
         ids = alloc(slots * 4).upload(np.random.default_rng(1).integers(0, n_wires, size=slots, dtype=np.uint32))
         w = alloc(n_wires * 32)
         ch = O.fr_random(4, 1)[0]
@@ -597,15 +610,20 @@ def witness_gen_leg(ctx, users=1380, tier=50, n_wires=1 << 26):
             ctx.witgen_poseidon_trace_dev(t, st[t].ptr, cnt, tr[t].ptr)
         ctx.witgen_limbs_dev(vals.ptr, n_values, nb_limbs, limbs.ptr, mult.ptr, bad.ptr)
         ctx.witgen_inverse_dev(inv_in.ptr, n_inv, ch, inv_out.ptr, bad.ptr)
+        ctx.witgen_gather_dev(table.ptr, 2500, lk_idx.ptr, n_lookup, lk_out.ptr, bad.ptr)
+        ctx.witgen_divmod_small_dev(div_in.ptr, n_div, 100, div_q.ptr, div_r.ptr)
+        ctx.witgen_bits_dev(bit_in.ptr, n_bits_vals, nbits, bit_out.ptr, bad.ptr)
         off = 0
         for t, cnt in perms.items():
             k = 3 * ctx.witgen_poseidon_sboxes(t) * cnt
             ctx.witgen_scatter_dev(w.ptr, tr[t].ptr, ids.ptr + 4 * off, k); off += k
         ctx.witgen_scatter_dev(w.ptr, limbs.ptr, ids.ptr + 4 * off, nb_limbs * n_values); off += nb_limbs * n_values
         ctx.witgen_scatter_dev(w.ptr, inv_out.ptr, ids.ptr + 4 * off, n_inv); off += n_inv
+        for src, k in ((lk_out, n_lookup), (div_q, n_div), (div_r, n_div), (bit_out, n_bits_vals * nbits)):
+            ctx.witgen_scatter_dev(w.ptr, src.ptr, ids.ptr + 4 * off, k); off += k
         ctx.sync()
         total_ms = (time.perf_counter() - t0) * 1e3
-        ph = {k: round(ctx.phase_ms(k)[0], 3) for k in ("witgen_poseidon", "witgen_limbs", "witgen_inverse", "witgen_scatter")}
+        ph = {k: round(ctx.phase_ms(k)[0], 3) for k in ("witgen_poseidon", "witgen_limbs", "witgen_inverse", "witgen_gather", "witgen_divmod", "witgen_bits", "witgen_scatter")}
         # spot check against the oracle: the first 64 width-3 permutations are recomputed from the (overwritten) states is not possible —
         # re-run a fresh slice instead
         chk = O.fr_random(5, 64 * 3).reshape(64, 3, 4)
@@ -618,10 +636,11 @@ def witness_gen_leg(ctx, users=1380, tier=50, n_wires=1 << 26):
             b.free()
     return {"users_per_batch": users, "tier": tier, "ms_per_batch": total_ms, "accounts_per_s": users / (total_ms * 1e-3), "phases_ms": ph,
             "wire_slots_generated": int(slots), "share_of_2p26_wires": slots / float(n_wires),
-            "permutations": {f"width_{t}": c for t, c in perms.items()}, "limbs": nb_limbs * n_values, "inverse_wires": n_inv, "checked_against_oracle": ok,
+            "permutations": {f"width_{t}": c for t, c in perms.items()}, "limbs": nb_limbs * n_values, "inverse_wires": n_inv, "lookup_results": n_lookup, "integer_divisions": n_div,
+            "comparison_bits": n_bits_vals * nbits, "checked_against_oracle": ok,
             "note": "device generators of SURVEY.md §8 f4 (Poseidon S-box wires for widths 3/5/6/13, 16-bit range-check limbs + table multiplicities, "
-                    "log-derivative inverse wires, slot -> wire scatter), one zkpor50_1380 batch, counts from the static count of Define (Appendix B, "
-                    "estimates), inputs resident; the wires NOT covered (comparison bits, lookup results, RLC products, the hint outputs) are the "
+                    "log-derivative inverse wires, lookup results, IntegerDivision quotients / remainders, comparison bits, slot -> wire scatter), one batch, counts from the static count of Define (Appendix B, "
+                    "estimates), inputs resident; the wires NOT covered (RLC products, selects, the glue between the gadgets) are the "
                     "host executor's (host/solver_exec.hpp); gnark's wire map cannot be produced in this image (go/export_solver is source only)"}
 
 

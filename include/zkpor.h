@@ -426,6 +426,15 @@ int32_t zkpor_witgen_limbs_dev(zkpor_ctx* ctx, const void* d_values, size_t n, i
 /* d_out[i] = 1 / (challenge - d_values[i]) (the inverse wires of the log-derivative argument); a zero denominator gives 0 and
  * increments *d_bad */
 int32_t zkpor_witgen_inverse_dev(zkpor_ctx* ctx, const void* d_values, size_t n, const uint64_t challenge[4], void* d_out, void* d_bad);
+/* bit decompositions (api.ToBinary and the comparison gadgets; std/math/bits NBits): d_bits[b * n + i] = bit b of value i (Fr one / zero),
+ * b < nbits <= 254; a value at or above 2^nbits increments *d_bad */
+int32_t zkpor_witgen_bits_dev(zkpor_ctx* ctx, const void* d_values, size_t n, int nbits, void* d_bits, void* d_bad);
+/* lookup results (logderivlookup.Table.Lookup: circuit/utils.go:137, circuit/batch_create_user_circuit.go:184-195,292): d_out[i] =
+ * d_table[index_i], the index given as a field element (the query wire); an index outside the table yields 0 and increments *d_bad */
+int32_t zkpor_witgen_gather_dev(zkpor_ctx* ctx, const void* d_table, size_t table_len, const void* d_indices, size_t n, void* d_out, void* d_bad);
+/* circuit.IntegerDivision as checkAndGetIntegerDivisionRes calls it (circuit/utils.go:103-110,166-177; divisor = utils.PercentageMultiplier):
+ * d_quotient[i], d_remainder[i] = DivMod(d_values[i], divisor) */
+int32_t zkpor_witgen_divmod_small_dev(zkpor_ctx* ctx, const void* d_values, size_t n, uint32_t divisor, void* d_quotient, void* d_remainder);
 /* d_w[d_wire_ids[i]] = d_src[i], i < n */
 int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, const uint32_t* d_wire_ids, size_t n);
 

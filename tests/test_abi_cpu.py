@@ -24,6 +24,26 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_abi_version_is_exported_and_checked_by_the_binding(monkeypatch):
+    """include/zkpor.h ZKPOR_ABI_VERSION = the library's zkpor_abi_version() = the value zkpor.py was written against; a binding written
+    against another value refuses to load the library (signatures changed in the middle of an argument list)"""
+    import zkpor
+    hdr = open(os.path.join(ROOT, "include", "zkpor.h")).read()
+    declared = int(re.search(r"#define\s+ZKPOR_ABI_VERSION\s+(\d+)u", hdr).group(1))
+    lib = ctypes.CDLL(LIB)
+    lib.zkpor_abi_version.restype = ctypes.c_uint32
+    assert lib.zkpor_abi_version() == declared == zkpor.ABI_VERSION
+    go = open(os.path.join(ROOT, "go", "zkporgpu", "abi.go")).read()
+    assert int(re.search(r"const abiVersion = (\d+)", go).group(1)) == declared
+    monkeypatch.setattr(zkpor, "_lib", None)
+    monkeypatch.setattr(zkpor, "ABI_VERSION", declared + 1)
+    with pytest.raises(zkpor.ZkporError, match="ABI version"):
+        zkpor.load_library()
+    monkeypatch.setattr(zkpor, "ABI_VERSION", declared)
+    monkeypatch.setattr(zkpor, "_lib", None)
+    zkpor.load_library()
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():

@@ -95,3 +95,43 @@ def test_scatter_to_wire_ids(zk):
         dw.free(); ds.free(); di.free()
     exp = w0.copy(); exp[ids] = src
     assert np.array_equal(w, exp)
+
+
+@pytest.mark.parametrize("nbits,n", [(1, 5), (8, 1000), (64, 300), (128, 257), (254, 10)])
+def test_bit_decompositions(zk, nbits, n):
+    rng = np.random.default_rng(nbits)
+    vals = [int.from_bytes(rng.bytes(32), "big") % min(1 << nbits, O.R_MOD) for _ in range(n)]
+    vals[0] = 0
+    vals[-1] = min((1 << nbits) - 1, O.R_MOD - 1)
+    bits, bad = zk.witgen_bits(O.fr_from_ints(vals), nbits)
+    assert bad == 0
+    for b in range(nbits):
+        assert O.fr_to_ints(bits[b]) == [(v >> b) & 1 for v in vals]
+    if nbits < 254:
+        _, bad = zk.witgen_bits(O.fr_from_ints([1 << nbits, 1, (1 << nbits) + 5]), nbits)
+        assert bad == 2
+
+
+def test_lookup_results(zk):
+    table = O.fr_random(21, 2500)                       # one user's 2500-entry asset table (circuit/batch_create_user_circuit.go:154-161)
+    rng = np.random.default_rng(4)
+    idx = [int(x) for x in rng.integers(0, 2500, size=4000)]
+    idx[0] = 0; idx[1] = 2499
+    out, bad = zk.witgen_gather(table, O.fr_from_ints(idx))
+    assert bad == 0 and np.array_equal(out, table[idx])
+    out, bad = zk.witgen_gather(table, O.fr_from_ints([5, 2500, O.R_MOD - 1, 1 << 40]))
+    assert bad == 3 and np.array_equal(out[0], table[5]) and not out[1:].any()
+
+
+def test_integer_division_by_the_percentage_multiplier(zk):
+    """circuit.IntegerDivision(dividend, utils.PercentageMultiplier) over 136-bit dividends: quotient and remainder as big.Int.DivMod gives them,
+    and the identity the circuit asserts (circuit/utils.go:175): q * 100 + rem == dividend"""
+    rng = np.random.default_rng(8)
+    vals = [int.from_bytes(rng.bytes(17), "big") for _ in range(3000)] + [0, 99, 100, 101, (1 << 136) - 1, O.R_MOD - 1]
+    q, rem = zk.witgen_divmod_small(O.fr_from_ints(vals), 100)
+    assert O.fr_to_ints(q) == [v // 100 for v in vals] and O.fr_to_ints(rem) == [v % 100 for v in vals]
+    q7, r7 = zk.witgen_divmod_small(O.fr_from_ints(vals), 4294967295)
+    assert O.fr_to_ints(q7) == [v // 4294967295 for v in vals] and O.fr_to_ints(r7) == [v % 4294967295 for v in vals]
+    import zkpor
+    with pytest.raises(zkpor.ZkporError):
+        zk.witgen_divmod_small(O.fr_from_ints([1]), 0)

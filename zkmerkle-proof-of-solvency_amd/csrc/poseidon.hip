@@ -603,6 +603,50 @@ __global__ __launch_bounds__(128) void k_witgen_inverse(const Fr* __restrict__ v
     }
     if (zeros) atomicAdd(bad, (u32)__popc(zeros));
 }
+// bit decompositions (api.ToBinary / the comparison gadgets: std/math/bits NBits hint): bits[b * n + i] = bit b of value i as a Montgomery Fr
+// (one or zero); a value at or above 2^nbits is counted in *bad (its recomposition constraint could not hold)
+__global__ __launch_bounds__(256) void k_witgen_bits(const Fr* __restrict__ values, size_t n, int nbits, Fr* __restrict__ bits, u32* __restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const Fr c = Fr::from_mont(values[i]);
+    const Fr one = Fr::one(), zero = Fr::zero();
+    bool over = false;
+    for (int b = 0; b < 256; ++b) {
+        const bool set = (c.v[b >> 5] >> (b & 31)) & 1u;
+        if (b < nbits) bits[(size_t)b * n + i] = set ? one : zero;
+        else over |= set;
+    }
+    if (over) atomicAdd(bad, 1u);
+}
+// lookup results (logderivlookup.Table.Lookup: circuit/utils.go:137, circuit/batch_create_user_circuit.go:184-195,292): out[i] = table[index_i],
+// the index a field element (the query wire); an index outside the table is counted in *bad and yields zero
+__global__ __launch_bounds__(256) void k_witgen_gather(const Fr* __restrict__ table, u32 table_len, const Fr* __restrict__ indices, size_t n,
+                                                       Fr* __restrict__ out, u32* __restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const Fr c = Fr::from_mont(indices[i]);
+    const bool ok = !(c.v[1] | c.v[2] | c.v[3] | c.v[4] | c.v[5] | c.v[6] | c.v[7]) && c.v[0] < table_len;
+    out[i] = ok ? table[c.v[0]] : Fr::zero();
+    if (!ok) atomicAdd(bad, 1u);
+}
+// circuit.IntegerDivision (circuit/utils.go:103-110) as the circuit calls it (checkAndGetIntegerDivisionRes, :166-177): the divisor is a small
+// constant (utils.PercentageMultiplier = 100): q[i], rem[i] = DivMod(value_i, divisor) by long division over the eight 32-bit words
+__global__ __launch_bounds__(256) void k_witgen_divmod_small(const Fr* __restrict__ values, size_t n, u32 divisor, Fr* __restrict__ q, Fr* __restrict__ rem) {
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const Fr c = Fr::from_mont(values[i]);
+    Fr quo = Fr::zero(), r = Fr::zero();
+    u64 carry = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        const u64 cur = (carry << 32) | c.v[k];
+        quo.v[k] = (u32)(cur / divisor);
+        carry = cur % divisor;
+    }
+    r.v[0] = (u32)carry;
+    q[i] = Fr::to_mont(quo);
+    rem[i] = Fr::to_mont(r);
+}
 // w[wire_ids[i]] = src[i]: the slots of a generator land on the wire ids of the compiled circuit (the map is part of the solver export)
 __global__ __launch_bounds__(256) void k_witgen_scatter(Fr* __restrict__ w, const Fr* __restrict__ src, const u32* __restrict__ wire_ids, size_t n) {
     size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
@@ -1126,6 +1170,35 @@ int32_t zkpor_witgen_inverse_dev(zkpor_ctx* ctx, const void* d_values, size_t n,
     PhaseScope ps(ctx, "witgen_inverse");
     const size_t threads = (n + 7) / 8;
     hipLaunchKernelGGL(k_witgen_inverse, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, ctx->stream, (const Fr*)d_values, n, c, (Fr*)d_out, (u32*)d_bad);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_witgen_bits_dev(zkpor_ctx* ctx, const void* d_values, size_t n, int nbits, void* d_bits, void* d_bad) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !d_values || !d_bits || !d_bad || n == 0 || nbits < 1 || nbits > 254) return ZKPOR_E_ARG;
+    PhaseScope ps(ctx, "witgen_bits");
+    hipLaunchKernelGGL(k_witgen_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_values, n, nbits, (Fr*)d_bits, (u32*)d_bad);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_witgen_gather_dev(zkpor_ctx* ctx, const void* d_table, size_t table_len, const void* d_indices, size_t n, void* d_out, void* d_bad) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !d_table || !d_indices || !d_out || !d_bad || n == 0 || table_len == 0 || table_len > 0xffffffffull) return ZKPOR_E_ARG;
+    PhaseScope ps(ctx, "witgen_gather");
+    hipLaunchKernelGGL(k_witgen_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_table, (u32)table_len, (const Fr*)d_indices, n,
+                       (Fr*)d_out, (u32*)d_bad);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_witgen_divmod_small_dev(zkpor_ctx* ctx, const void* d_values, size_t n, uint32_t divisor, void* d_quotient, void* d_remainder) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !d_values || !d_quotient || !d_remainder || n == 0) return ZKPOR_E_ARG;
+    if (divisor == 0) { ctx->err = "witgen: division by zero (big.Int.DivMod panics)"; return ZKPOR_E_ARG; }
+    PhaseScope ps(ctx, "witgen_divmod");
+    hipLaunchKernelGGL(k_witgen_divmod_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_values, n, divisor, (Fr*)d_quotient, (Fr*)d_remainder);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

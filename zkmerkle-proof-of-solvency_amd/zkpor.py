@@ -174,6 +174,49 @@ class Context:
             for b in (dv, do, db):
                 b.free()
 
+    def witgen_bits_dev(self, d_values, n, nbits, d_bits, d_bad):
+        self._ck(self.lib.zkpor_witgen_bits_dev(self.h, ctypes.c_void_p(d_values), ctypes.c_size_t(n), ctypes.c_int(nbits), ctypes.c_void_p(d_bits), ctypes.c_void_p(d_bad)))
+
+    def witgen_bits(self, values, nbits):
+        v = _u64(values).reshape(-1, 4)
+        n = v.shape[0]
+        dv = self.alloc(v.nbytes).upload(v); do = self.alloc(nbits * n * 32); db = self.alloc(4).upload(np.zeros(1, np.uint32))
+        try:
+            self.witgen_bits_dev(dv.ptr, n, nbits, do.ptr, db.ptr)
+            return do.download(np.uint64, (nbits, n, 4)), int(db.download(np.uint32, (1,))[0])
+        finally:
+            for b in (dv, do, db):
+                b.free()
+
+    def witgen_gather_dev(self, d_table, table_len, d_indices, n, d_out, d_bad):
+        self._ck(self.lib.zkpor_witgen_gather_dev(self.h, ctypes.c_void_p(d_table), ctypes.c_size_t(table_len), ctypes.c_void_p(d_indices), ctypes.c_size_t(n),
+                                                  ctypes.c_void_p(d_out), ctypes.c_void_p(d_bad)))
+
+    def witgen_gather(self, table, indices):
+        t = _u64(table).reshape(-1, 4); ix = _u64(indices).reshape(-1, 4)
+        n = ix.shape[0]
+        dt = self.alloc(t.nbytes).upload(t); di = self.alloc(ix.nbytes).upload(ix); do = self.alloc(ix.nbytes); db = self.alloc(4).upload(np.zeros(1, np.uint32))
+        try:
+            self.witgen_gather_dev(dt.ptr, t.shape[0], di.ptr, n, do.ptr, db.ptr)
+            return do.download(np.uint64, (n, 4)), int(db.download(np.uint32, (1,))[0])
+        finally:
+            for b in (dt, di, do, db):
+                b.free()
+
+    def witgen_divmod_small_dev(self, d_values, n, divisor, d_q, d_rem):
+        self._ck(self.lib.zkpor_witgen_divmod_small_dev(self.h, ctypes.c_void_p(d_values), ctypes.c_size_t(n), ctypes.c_uint32(divisor), ctypes.c_void_p(d_q), ctypes.c_void_p(d_rem)))
+
+    def witgen_divmod_small(self, values, divisor):
+        v = _u64(values).reshape(-1, 4)
+        n = v.shape[0]
+        dv = self.alloc(v.nbytes).upload(v); dq = self.alloc(v.nbytes); dr = self.alloc(v.nbytes)
+        try:
+            self.witgen_divmod_small_dev(dv.ptr, n, divisor, dq.ptr, dr.ptr)
+            return dq.download(np.uint64, (n, 4)), dr.download(np.uint64, (n, 4))
+        finally:
+            for b in (dv, dq, dr):
+                b.free()
+
     def witgen_scatter_dev(self, d_w, d_src, d_wire_ids, n):
         self._ck(self.lib.zkpor_witgen_scatter_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_src), ctypes.c_void_p(d_wire_ids), ctypes.c_size_t(n)))
 
