@@ -212,7 +212,7 @@ __global__ void k_absent_bits(const P* __restrict__ pts, size_t n, u32* __restri
     const bool inf = i < n && pts[i].is_inf();
     const u64 b = __ballot(inf);
     const u32 lane = threadIdx.x & 63u;
-    if (lane == 0) { bits[2 * (i >> 6)] = (u32)b; bits[2 * (i >> 6) + 1] = (u32)(b >> 32); if (b) atomicAdd(count, (u32)__popcll(b)); }
+    if (lane == 0 && i < n) { bits[2 * (i >> 6)] = (u32)b; bits[2 * (i >> 6) + 1] = (u32)(b >> 32); if (b) atomicAdd(count, (u32)__popcll(b)); }   // a wave wholly past n writes nothing
 }
 void pk_free_masks(zkpor_pk* pk) {
     if (pk->absentB) (void)hipFree(pk->absentB);
