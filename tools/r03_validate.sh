@@ -1,14 +1,11 @@
+# final validation of round 3: the whole -m gpu suite, smoke(), and a timeline of the final code
 set -u
-OUT=gpurun_out/r03i
+OUT=gpurun_out/r03u
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 1200 python -m pytest tests -m gpu -x -q --durations=6 > $OUT/pytest_full.txt 2>&1
-tail -12 $OUT/pytest_full.txt
-for F in "--filter-grid 256" "--filter-grid 384" "--filter-grid 512" "--filter-grid 768" "--copy-inputs"; do
-  T=$(echo $F | tr -d ' -')
-  timeout 300 python bench.py --steps 6 --warmup 2 --timed-only $F > $OUT/bench_$T.json 2> $OUT/bench_$T.err
-  python - "$OUT/bench_$T.json" "$F" <<'PY'
-import json,sys
-d=json.load(open(sys.argv[1])); print(sys.argv[2],"ms_per_step",round(d["ms_per_step"],2),d["phases_ms_per_proof"])
-PY
-done
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 > $OUT/pytest_full.txt 2>&1
+tail -10 $OUT/pytest_full.txt
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o tl -- python bench.py --steps 2 --warmup 1 --timed-only > /dev/null 2> $OUT/trace.err
+python tools/timeline_summary.py $OUT/trace/tl_kernel_trace.csv > $OUT/timeline.txt; head -40 $OUT/timeline.txt
+rm -rf $OUT/trace
