@@ -782,6 +782,8 @@ def main():
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the informational region with two proofs in flight per GPU")
     ap.add_argument("--aux-priority", action="store_true", help="experiment: the digit-stream HIP stream at the highest stream priority")
     ap.add_argument("--no-reduce-scan", action="store_true", help="experiment: the small bucket-reduction levels as the serial walk (msm_reduce_scan 0)")
+    ap.add_argument("--reduce-scan", type=int, default=-1, help="experiment: msm_reduce_scan (1 = lane-parallel small levels for G1 and G2, 2 = G1 only, 0 = serial walk)")
+    ap.add_argument("--tail-chunk", type=int, default=-1, help="experiment: msm_tail_chunk, entries per thread of the small partial-sum levels (0 = the level-1 chunk)")
     ap.add_argument("--boundary-sweep", type=int, default=0, help="experiment: repeat the boundary leg with this many proofs per caller shape for "
                     "copy_threads in {4, 0} x gpu_token in {1, 0} (boundary_sweep in the line)")
     ap.add_argument("--no-gpu-token", action="store_true", help="boundary leg: let the two callers' kernels share the GPU freely instead of "
@@ -870,6 +872,10 @@ def main():
         ctx.set_param("msm_chunk", args.chunk)
     if args.g1_variant >= 0:
         ctx.set_param("msm_g1_variant", args.g1_variant)
+    if args.reduce_scan >= 0:
+        ctx.set_param("msm_reduce_scan", args.reduce_scan)
+    if args.tail_chunk >= 0:
+        ctx.set_param("msm_tail_chunk", args.tail_chunk)
     if args.no_reduce_scan:
         ctx.set_param("msm_reduce_scan", 0)
     if args.sort_block >= 0:

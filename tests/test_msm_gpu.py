@@ -46,7 +46,7 @@ def test_g1_msm_windows_chunks(zk, window, chunk):
         assert _g1_eq(zk.msm_g1(pts, sc), O.g1_msm(pts, sc))
     finally:
         zk.set_param("msm_window", 0)
-        zk.set_param("msm_chunk", 32)
+        zk.set_param("msm_chunk", 0)
 
 
 @pytest.mark.parametrize("window", [4, 9, 14, 0])
@@ -67,6 +67,60 @@ def test_g1_msm_reduction_tail_both_forms(zk, window):
     finally:
         zk.set_param("msm_reduce_scan", 1)
         zk.set_param("msm_window", 0)
+
+
+@pytest.mark.parametrize("window", [4, 9, 14, 0])
+def test_g2_msm_reduction_tail_all_forms(zk, window):
+    """G2: the small reduction levels as one lane PAIR per bucket (k_reduce_scan29_g2, the default), with the round-2 setting (scan for G1
+    only: msm_reduce_scan 2) and as the serial walk (0): same sums; repeated points so that equal operands meet inside the scan"""
+    n = 1500
+    base = O.g2_from_scalars(O.fr_random(63, 24))
+    pts = np.ascontiguousarray(base[np.arange(n) % 24])
+    sc = O.fr_random(64, n)
+    sc[::5] = sc[2]
+    want = O.g2_msm(pts, sc)
+    zk.set_param("msm_window", window)
+    try:
+        for form in (1, 2, 0):
+            zk.set_param("msm_reduce_scan", form)
+            assert _g2_eq(zk.msm_g2(pts, sc), want)
+    finally:
+        zk.set_param("msm_reduce_scan", 1)
+        zk.set_param("msm_window", 0)
+
+
+@pytest.mark.parametrize("tail", [0, 4, 5, 8, 16])
+def test_msm_tail_chunk_values(zk, tail):
+    """the small partial-sum levels with short chunks (msm_tail_chunk; 0 = the level-1 chunk everywhere): one heavy bucket spanning hundreds
+    of chunks forces several recursion levels, random scalars give the many-small-segments case; G1 and G2"""
+    n = 6000
+    pts1 = O.g1_from_scalars(O.fr_random(65, n))
+    pts2 = O.g2_from_scalars(O.fr_random(66, 1200))
+    heavy = np.repeat(O.fr_random(67, 1), n, axis=0)
+    mixed = O.fr_random(68, n)
+    mixed[: n // 2] = mixed[0]
+    zk.set_param("msm_tail_chunk", tail)
+    try:
+        for chunk in (32, 8):
+            zk.set_param("msm_chunk", chunk)
+            for sc in (heavy, mixed):
+                assert _g1_eq(zk.msm_g1(pts1, sc), O.g1_msm(pts1, sc))
+            assert _g2_eq(zk.msm_g2(pts2, mixed[:1200]), O.g2_msm(pts2, mixed[:1200]))
+            assert _g2_eq(zk.msm_g2(pts2, heavy[:1200]), O.g2_msm(pts2, heavy[:1200]))
+    finally:
+        zk.set_param("msm_tail_chunk", 8)
+        zk.set_param("msm_chunk", 0)
+
+
+def test_chunk_parameters_below_four_are_refused(zk):
+    """a level of the partial-sum recursion turns T threads into 2 T / chunk: below 4 entries per thread it would never reach one thread"""
+    import zkpor
+    for name in ("msm_chunk", "msm_tail_chunk"):
+        for bad in (1, 2, 3, -1):
+            with pytest.raises(zkpor.ZkporError):
+                zk.set_param(name, bad)
+    zk.set_param("msm_chunk", 0)
+    zk.set_param("msm_tail_chunk", 8)
 
 
 def test_g1_msm_edge_scalars(zk):
@@ -91,7 +145,7 @@ def test_g1_msm_skew_heavy_bucket(zk):
     try:
         assert _g1_eq(zk.msm_g1(pts, sc), O.g1_msm(pts, sc))
     finally:
-        zk.set_param("msm_chunk", 32)
+        zk.set_param("msm_chunk", 0)
 
 
 def test_g1_msm_repeated_negated_infinity_points(zk):

@@ -335,7 +335,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return ZKPOR_E_ARG;
     std::string n(name);
     if (n == "msm_window") ctx->msm_window = (int)value;
-    else if (n == "msm_chunk") ctx->msm_chunk = (int)value;
+    else if (n == "msm_chunk") { if (value != 0 && (value < 4 || value > 4096)) { ctx->err = "msm_chunk must be 0 (automatic) or 4..4096 (a level of the partial-sum recursion turns T threads into 2 T / chunk)"; return ZKPOR_E_ARG; } ctx->msm_chunk = (int)value; }
     else if (n == "msm_tables") { if (value < 1 || value > 8) { ctx->err = "msm_tables must be in [1,8]"; return ZKPOR_E_ARG; } ctx->msm_tables = (int)value; }
     else if (n == "msm_g1_variant") ctx->g1_variant = (int)value;
     else if (n == "msm_g2_variant") ctx->g2_variant = (int)value;
@@ -345,7 +345,8 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     else if (n == "msm_filter_grid") { if (value < 0 || value > 2048) { ctx->err = "msm_filter_grid must be in [0,2048]"; return ZKPOR_E_ARG; } ctx->msm_filter_grid = (int)value; }
     else if (n == "ntt_fuse") { if (value < 0 || value > 1) { ctx->err = "ntt_fuse must be 0 or 1"; return ZKPOR_E_ARG; } ctx->ntt_fuse = (int)value; }
     else if (n == "sort_block") { if (value != 0 && value != 256 && value != 512) { ctx->err = "sort_block must be 0 (rocPRIM default), 256 or 512"; return ZKPOR_E_ARG; } ctx->sort_block = (int)value; }
-    else if (n == "msm_reduce_scan") { if (value < 0 || value > 1) { ctx->err = "msm_reduce_scan must be 0 or 1"; return ZKPOR_E_ARG; } ctx->msm_reduce_scan = (int)value; }
+    else if (n == "msm_reduce_scan") { if (value < 0 || value > 2) { ctx->err = "msm_reduce_scan must be 0, 1 or 2"; return ZKPOR_E_ARG; } ctx->msm_reduce_scan = (int)value; }
+    else if (n == "msm_tail_chunk") { if (value != 0 && (value < 4 || value > 64)) { ctx->err = "msm_tail_chunk must be 0 or 4..64"; return ZKPOR_E_ARG; } ctx->msm_tail_chunk = (int)value; }
     else if (n == "aux_priority") {
         if (value < 0 || value > 1) { ctx->err = "aux_priority must be 0 or 1"; return ZKPOR_E_ARG; }
         if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); ctx->aux_stream = nullptr; }

@@ -55,7 +55,8 @@ struct zkpor_ctx {
     int copy_threads = 0;            // 0 = the HIP runtime moves pageable ranges (page-locks them on the fly: 56 GB/s measured); n > 0 = n host threads fill pinned bounce buffers (30 GB/s)
     int copy_chunk_mb = 32;          // size of one of the four pinned bounce buffers
     int host_order = 0;              // zkpor_prove_tail from host memory: 0 = w first, a/b/c under the witness sums; 1 = everything first, then the resident order
-    int msm_reduce_scan = 1;         // small bucket-reduction levels (G1): one lane per bucket, scan + tree sums (msm_g1_hot.hip)
+    int msm_reduce_scan = 1;         // small bucket-reduction levels: one lane (G2: lane pair) per bucket, scan + tree sums; 2 = G1 only (round 2), 0 = serial walk
+    int msm_tail_chunk = 8;          // entries per thread of the SMALL partial-sum levels (< 2^21 entries): their duration is the serial chain, not the work; 0 = msm_chunk
     int msm_filter = 1;              // per-array digit streams: drop the entries of absent points before B1 / B2 and K (msm_digits.hip)
     int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 256: one per CU — bandwidth, not wave slots)
     int ntt_fuse = 1;                // computeH: the two passes over the lowest field (inverse DIF last, coset DIT first) in one kernel (ntt.hip k_ntt_mid29)

@@ -187,11 +187,20 @@ inline int32_t msm_digits(zkpor_ctx* ctx, const Fr* d_scalars, size_t n, const M
     return ZKPOR_OK;
 }
 
+// threads of the second partial-sum level for T1 level-1 threads (its 2 T2 outputs size the second partials buffer): chunks of L, or the
+// short chunks of a small level (msm_tail_chunk >= 4, levels below 2^21 entries); monotonic in T1, so a bound for every smaller stream
+inline size_t level2_threads(size_t T1, int L) {
+    size_t by_l = (2 * T1 + L - 1) / L;
+    size_t small = 2 * T1 < ((size_t)1 << 21) ? 2 * T1 : ((size_t)1 << 21);
+    size_t by_tail = (small + 3) / 4;
+    return by_l > by_tail ? by_l : by_tail;
+}
+
 template <class F>
 inline size_t accumulate_ws_bytes(const MsmCfg& cfg, size_t max_entries) {
     WsPlan p;
     size_t T1 = (max_entries + cfg.L - 1) / cfg.L;
-    size_t T2 = (2 * T1 + cfg.L - 1) / cfg.L;
+    size_t T2 = level2_threads(T1, cfg.L);
     const size_t img = raw_words<F>() * 4;  // the raw 29-bit image is the larger of the two element formats
     p.add<char>(cfg.NB * img);
     p.add<char>((2 * T1 + 2) * img); p.add<u32>(2 * T1 + 2);
@@ -223,7 +232,7 @@ inline int32_t msm_accumulate_launch(zkpor_ctx* ctx, const DigitStream& ds, cons
     const u32 M = ds.M;
     const int L = cfg.L;
     size_t T1 = ((size_t)M + L - 1) / L;
-    size_t T2 = (2 * T1 + L - 1) / L;
+    size_t T2 = level2_threads(T1, L);
     const bool raw = std::is_same<F, Fp>::value ? ctx->g1_variant == 1 : ctx->g2_variant == 1;
     const size_t img = raw_words<F>() * 4;
     char* buckets = ws_alloc<char>(ctx, cfg.NB * img);
@@ -244,9 +253,11 @@ inline int32_t msm_accumulate_launch(zkpor_ctx* ctx, const DigitStream& ds, cons
         char* src = pa; u32* srck = ka; char* dst = pb; u32* dstk = kb;
         while (T > 1) {
             u32 Mn = (u32)(2 * T);
-            size_t Tn = ((size_t)Mn + L - 1) / L;
-            if (raw) ZK_TRY(launch_levelN29<F>(ctx, srck, (const u32*)src, Mn, L, (u32*)buckets, dstk, (u32*)dst));
-            else ZK_TRY(launch_levelN(ctx, srck, (const XYZZ<F>*)src, Mn, L, (XYZZ<F>*)buckets, dstk, (XYZZ<F>*)dst));
+            // a small level is as long as one thread's serial chain of additions: short chunks there (chunks of >= 4: every level turns T threads into at most T / 2 + 1, down to one)
+            const int Ln = (ctx->msm_tail_chunk && Mn < (1u << 21) && ctx->msm_tail_chunk < L) ? ctx->msm_tail_chunk : L;
+            size_t Tn = ((size_t)Mn + Ln - 1) / Ln;
+            if (raw) ZK_TRY(launch_levelN29<F>(ctx, srck, (const u32*)src, Mn, Ln, (u32*)buckets, dstk, (u32*)dst));
+            else ZK_TRY(launch_levelN(ctx, srck, (const XYZZ<F>*)src, Mn, Ln, (XYZZ<F>*)buckets, dstk, (XYZZ<F>*)dst));
             std::swap(src, dst); std::swap(srck, dstk);
             T = Tn;
         }

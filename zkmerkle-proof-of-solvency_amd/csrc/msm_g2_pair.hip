@@ -303,8 +303,64 @@ int32_t launch_levelN29<Fp2>(zkpor_ctx* ctx, const u32* keys, const u32* src, u3
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
+// Lane-parallel form of a SMALL reduction level, as k_reduce_scan29_g1 (msm_g1_hot.hip) but one bucket per lane PAIR: the g <= 16 pairs of
+// a group lie in one wave, the other pair's operand comes through 36 lane shuffles over 2 d lanes, the additions are the lane-pair ones.
+// 3 log2(g) additions deep instead of 3 g: the last four levels of the G2 reduction were 0.5 ms each whatever their size.
+__device__ __forceinline__ XYZZ29T<Fp2L29> lp_shfl_down29(const XYZZ29T<Fp2L29>& a, u32 lanes) {
+    XYZZ29T<Fp2L29> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.x.c.l[i] = (u32)__shfl_down((int)a.x.c.l[i], lanes, 64); r.y.c.l[i] = (u32)__shfl_down((int)a.y.c.l[i], lanes, 64);
+        r.zz.c.l[i] = (u32)__shfl_down((int)a.zz.c.l[i], lanes, 64); r.zzz.c.l[i] = (u32)__shfl_down((int)a.zzz.c.l[i], lanes, 64);
+    }
+    return r;
+}
+template <bool HAS_Y>
+__global__ __launch_bounds__(256) void k_reduce_scan29_g2(const u32* __restrict__ Sin, const u32* __restrict__ Yin, u32 n_groups, int gl,
+                                                           int dbl, u32* __restrict__ Sout, u32* __restrict__ Yout) {
+    typedef XYZZ29T<Fp2L29> Acc;
+    const u32 g = 1u << gl;                          // <= 16: a group's 2 g lanes never straddle a wave
+    const u32 gt = blockIdx.x * 256u + threadIdx.x;
+    const u32 e = gt >> 1, par = gt & 1u;            // e = j * g + k: the element's index
+    const u32 j = e >> gl, k = e & (g - 1u);
+    const bool live = j < n_groups;
+    Acc T = live ? Pol29G2::load(Sin, e, par) : Acc::inf();
+    Acc W = Acc::inf(), Y = Acc::inf();
+    if (HAS_Y && live) Y = Pol29G2::load(Yin, e, par);
+    const int phases = HAS_Y ? 3 : 2;
+#pragma unroll 1
+    for (int it = 0; it < phases * gl; ++it) {
+        const int phase = it / gl, st = it - phase * gl;
+        const u32 d = 1u << st;
+        if (phase == 1 && st == 0) W = T;
+        Acc a = phase == 0 ? T : (phase == 1 ? W : Y);
+        const Acc b = lp_shfl_down29(a, 2u * d);
+        const bool doit = phase == 0 ? (k + d < g) : ((k & (2u * d - 1u)) == 0u);   // the same for both lanes of a pair
+        if (doit) xyzz29_add<Fp2L29>(a, b);
+        if (phase == 0) T = a; else if (phase == 1) W = a; else Y = a;
+    }
+    if (!live || k != 0) return;
+    Pol29G2::store(Sout, j, T, par);
+    if (HAS_Y) {
+        for (int q = 0; q < dbl; ++q) W = xyzz29_dbl<Fp2L29>(W);
+        xyzz29_add<Fp2L29>(Y, W);
+        Pol29G2::store(Yout, j, Y, par);
+    } else {
+        Pol29G2::store(Yout, j, W, par);
+    }
+}
+
 template <>
 int32_t launch_reduce29<Fp2>(zkpor_ctx* ctx, const u32* Sin, const u32* Yin, u32 n_groups, u32 g, int dbl, u32* Sout, u32* Yout) {
+    if (ctx->msm_reduce_scan == 1 && g <= 16u && (g & (g - 1u)) == 0u && g >= 2u && (size_t)n_groups * g <= ((size_t)1 << 15)) {
+        int gl = 0;
+        while ((1u << gl) < g) ++gl;
+        dim3 grid_s((unsigned)((2u * (size_t)n_groups * g + 255u) / 256u));
+        if (Yin) hipLaunchKernelGGL((k_reduce_scan29_g2<true>), grid_s, dim3(256), 0, ctx->stream, Sin, Yin, n_groups, gl, dbl, Sout, Yout);
+        else hipLaunchKernelGGL((k_reduce_scan29_g2<false>), grid_s, dim3(256), 0, ctx->stream, Sin, Yin, n_groups, gl, dbl, Sout, Yout);
+        ZK_KERNEL_CHECK(ctx);
+        return ZKPOR_OK;
+    }
     dim3 grid((2u * n_groups + 127u) / 128u);
     if (Yin) hipLaunchKernelGGL((k_reduce_level29<Pol29G2, true>), grid, dim3(128), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
     else hipLaunchKernelGGL((k_reduce_level29<Pol29G2, false>), grid, dim3(128), 0, ctx->stream, Sin, Yin, n_groups, g, dbl, Sout, Yout);
