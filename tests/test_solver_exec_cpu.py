@@ -141,3 +141,69 @@ def test_solver_container_is_validated():
         for _k in range(int(rng.integers(1, 4))):
             m[int(rng.integers(8, len(m)))] = int(rng.integers(0, 256))
         LIB.zkh_solver_parse(bytes(m), ctypes.c_size_t(len(m)), counts, err, ctypes.c_size_t(200))
+
+
+def test_integer_division_and_limb_hints_at_every_operand_width():
+    """the IntegerDivision hint with one-word divisors (word-wise long division) and multi-word ones (shift-subtract), the limb decomposition with
+    limbs that straddle 64-bit words, NBits up to the field's width: outputs against Python integers through a circuit that constrains them"""
+    rng = np.random.default_rng(21)
+    cases = []
+    for abits, bbits in [(20, 7), (64, 64), (130, 63), (200, 64), (253, 1), (253, 65), (253, 128), (250, 200), (100, 250), (0, 9)]:
+        for _ in range(3):
+            a = int.from_bytes(rng.bytes(32), "big") >> (256 - abits) if abits else 0
+            d = (int.from_bytes(rng.bytes(32), "big") >> (256 - bbits)) | 1
+            cases.append((a % SC.R, d % SC.R or 1))
+    secret = [x for ab in cases for x in ab]
+    b = SC.Builder([5], secret)
+    base = b.n_public
+    for i in range(len(cases)):
+        b.integer_division(b.wire(base + 2 * i), b.wire(base + 2 * i + 1))
+    for i, (bits, limb) in enumerate([(16, 16), (64, 16), (70, 7), (250, 60), (253, 64), (128, 13), (1, 1)]):
+        v = cases[i][0] & ((1 << bits) - 1)
+        x = b.mul(b.const(v), b.const(1), "val")
+        b.range_check(b.wire(x), bits, limb)
+    for i, n in enumerate([1, 8, 64, 65, 128, 253]):
+        v = cases[3 + i][0] & ((1 << n) - 1)
+        x = b.mul(b.const(v), b.const(1), "val")
+        b.to_binary(b.wire(x), n)
+    for th in (1, 5):
+        rc, w, *_rest, err = solve(b, threads=th)
+        assert rc == 0, err
+        assert np.array_equal(w, SC.to_mont_limbs(b.val))
+
+
+def test_w_only_mode_and_thread_counts_beyond_the_level_widths():
+    """a, b, c left to the device (NULL outputs): the same wire vector, no row evaluation; more threads than any level has instructions"""
+    b = SC.demo_circuit(12, 3)
+    r1, sv = b.r1cs_bytes(), b.solver_bytes()
+    n_in = b.n_public + b.n_secret
+    inp = SC.to_mont_limbs(b.val[:n_in])
+    for th in (1, 2, 64):
+        w = np.zeros((len(b.val), 4), np.uint64)
+        stats = np.zeros(3, np.uint64); err = ctypes.create_string_buffer(256)
+        ids = np.zeros(0, np.uint32); vals = np.zeros((0, 4), np.uint64)
+        rc = LIB.zkh_solve(r1, ctypes.c_size_t(len(r1)), sv, ctypes.c_size_t(len(sv)), _p(inp), ctypes.c_size_t(n_in), _p(ids), _p(vals), ctypes.c_size_t(0),
+                           ctypes.c_int(th), _p(w), None, None, None, _p(stats), err, ctypes.c_size_t(256))
+        assert rc == 0, err.value
+        assert np.array_equal(w, SC.to_mont_limbs(b.val))
+
+
+def test_quotients_of_a_level_share_one_inversion_and_zero_denominators_are_errors():
+    """inverses, scaled left divisions and the InvZero hint (zero and non-zero inputs) side by side in one level — they are resolved together;
+    a zero denominator must stay the error it is in gnark (division by zero), not poison the shared product"""
+    rng = np.random.default_rng(33)
+    vals = [int.from_bytes(rng.bytes(32), "big") % SC.R for _ in range(40)] + [0, 0]
+    b = SC.Builder([1], vals)
+    base = b.n_public
+    for i in range(0, 40, 2):
+        b.inverse(b.wire(base + i))
+        b.div_left(b.wire(base + i), b.wire(base + i + 1))
+        b.is_zero(b.wire(base + i))
+    b.is_zero(b.wire(base + 40))                       # zero input: InvZero gives 0, not an inversion
+    rc, w, *_rest, err = solve(b, threads=3)
+    assert rc == 0, err
+    assert np.array_equal(w, SC.to_mont_limbs(b.val))
+    assert len(b.levels()[0]) >= 60                    # they do sit in one level
+    b.inverse(b.wire(base + 41))                       # 1 / 0
+    rc, *_x, err = solve(b, threads=3)
+    assert rc != 0 and "division by zero" in err

@@ -65,6 +65,7 @@ struct FrH {
     void to_canon(uint64_t out[4]) const { FrH o{{1, 0, 0, 0}}; FrH r = mul(*this, o); memcpy(out, r.v, 32); }
     // a^(r-2); inv(0) = 0 (what gnark's field does as well)
     static FrH inv(const FrH& a) {
+        if (a.is_zero()) return a;
         const uint64_t* m = mod();
         uint64_t e[4] = {m[0] - 2, m[1], m[2], m[3]};
         FrH r = one(), b = a;
@@ -92,7 +93,23 @@ struct U256 {
     }
     U256 shl1() const { U256 r; uint64_t c = 0; for (int i = 0; i < 4; ++i) { r.w[i] = (w[i] << 1) | c; c = w[i] >> 63; } return r; }
     // big.Int.DivMod for non-negative operands: q = a / b, rem = a mod b (b != 0); schoolbook shift-subtract
+    // bits [lo, lo + n) of the value, n <= 64
+    uint64_t bits(int lo, int n) const {
+        if (lo >= 256 || n <= 0) return 0;
+        const int wi = lo >> 6, sh = lo & 63;
+        uint64_t x = w[wi] >> sh;
+        if (sh && wi + 1 < 4) x |= w[wi + 1] << (64 - sh);
+        return n >= 64 ? x : (x & (((uint64_t)1 << n) - 1));
+    }
     static void divmod(const U256& a, const U256& b, U256* q, U256* rem) {
+        if ((b.w[1] | b.w[2] | b.w[3]) == 0) {   // a one-word divisor (every division the circuit makes: prices, the base 100): word-wise long division
+            const uint64_t d = b.w[0];
+            U256 qq;
+            unsigned __int128 r = 0;
+            for (int i = 3; i >= 0; --i) { unsigned __int128 cur = (r << 64) | a.w[i]; qq.w[i] = (uint64_t)(cur / d); r = cur % d; }
+            *q = qq; *rem = U256{{(uint64_t)r, 0, 0, 0}};
+            return;
+        }
         U256 qq{{0, 0, 0, 0}}, r{{0, 0, 0, 0}};
         for (int i = a.bitlen() - 1; i >= 0; --i) {
             r = r.shl1();

@@ -257,7 +257,7 @@ int zkh_solver_parse(const uint8_t* data, size_t len, uint64_t counts[4], char* 
     return 0;
 }
 // solve: inputs = nPublic + nSecret elements; pre_ids / pre_vals = wires filled elsewhere (the device generators); w_out nWires x 4,
-// a/b/c_out nConstraints x 4; stats = solved constraints, hint calls, skipped instructions.  0 = ok, else the executor's code + err text
+// a/b/c_out nConstraints x 4 (all three NULL: w only, no row check); stats = solved constraints, hint calls, skipped instructions.  0 = ok, else the executor's code + err text
 int zkh_solve(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* solv, size_t solv_len, const uint64_t* inputs, size_t n_inputs,
               const uint32_t* pre_ids, const uint64_t* pre_vals, size_t n_pre, int threads, uint64_t* w_out, uint64_t* a_out, uint64_t* b_out,
               uint64_t* c_out, uint64_t stats[3], char* err, size_t err_len) {
@@ -270,10 +270,11 @@ int zkh_solve(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* solv, size_t 
     std::vector<std::pair<uint32_t, FrH>> pre(n_pre);
     for (size_t i = 0; i < n_pre; ++i) { pre[i].first = pre_ids[i]; memcpy(pre[i].second.v, pre_vals + 4 * i, 32); }
     SolveResult res;
-    int rc = SolveLevelized(rv, sv, inputs, n_inputs, HintRegistry::Standard(), pre, threads, &res, &why);
+    const bool want_abc = a_out && b_out && c_out;   // all three or none: without them only w is produced (a, b, c on the device: zkpor_prove_r1cs)
+    int rc = SolveLevelized(rv, sv, inputs, n_inputs, HintRegistry::Standard(), pre, threads, &res, &why, want_abc);
     if (rc != 0) { put(why); return rc; }
     memcpy(w_out, res.w.data(), res.w.size() * 8);
-    memcpy(a_out, res.a.data(), res.a.size() * 8); memcpy(b_out, res.b.data(), res.b.size() * 8); memcpy(c_out, res.c.data(), res.c.size() * 8);
+    if (want_abc) { memcpy(a_out, res.a.data(), res.a.size() * 8); memcpy(b_out, res.b.data(), res.b.size() * 8); memcpy(c_out, res.c.data(), res.c.size() * 8); }
     stats[0] = res.solved_constraints; stats[1] = res.hint_calls; stats[2] = res.skipped;
     return 0;
 }
