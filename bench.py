@@ -174,7 +174,7 @@ def host_executor_leg(threads):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import solver_circuit as SC
     lib = ctypes.CDLL(os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd", "libzkpor_host.so"))
-    b = SC.demo_circuit(11, 6000, chain=False)
+    b = _demo_circuit(SC, 11, 6000, False)
     r1, sv = b.r1cs_bytes(), b.solver_bytes()
     n_in = b.n_public + b.n_secret
     inp = SC.to_mont_limbs(b.val[:n_in])
@@ -202,6 +202,59 @@ def host_executor_leg(threads):
             "instructions_per_s": rates["w_only"], "instructions_per_s_with_a_b_c": rates["w_a_b_c_checked"], "wire_vector_equals_builder": ok,
             "note": "synthetic circuit of the real one's gadget shapes, 6000 independent users; w-only is the mode of the GPU path (a, b, c on the device); the "
                     "divisions of a level (inverse wires, IsZero hints) share one field inversion per thread, coefficients 1 / -1 cost an addition"}
+
+
+_DEMO = {}
+
+
+def _demo_circuit(SC, seed, users, chain):
+    key = (seed, users, chain)
+    if key not in _DEMO:
+        _DEMO[key] = SC.demo_circuit(seed, users, chain=chain)
+    return _DEMO[key]
+
+
+def device_executor_leg(ctx):
+    """SURVEY.md §8 f4, the generic half on the DEVICE, measured: csrc/solver.hip (zkpor_solver_*) runs the same solver program the host executor
+    runs — one launch per wide level with a GPU thread per instruction, one workgroup stepping through every run of narrow levels — with the
+    inputs resident in HBM.  Two shapes of the synthetic gadget circuit: users side by side (12 wide levels: the throughput case) and users
+    chained through a running accumulator (thousands of narrow levels: the latency case).  Wire vectors compared with the builder's."""
+    import numpy as np
+    import zkpor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import solver_circuit as SC
+    out = {}
+    for name, users, chain in (("users_side_by_side", 6000, False), ("users_chained", 600, True)):
+        b = _demo_circuit(SC, 11, users, chain)
+        table, mats = b.tables()
+        r = zkpor.R1CS(ctx, len(b.rows), len(b.val), table)
+        s = None
+        d_w = ctx.alloc(len(b.val) * 32)
+        try:
+            for m in range(3):
+                r.set_matrix(m, *mats[m])
+            s = zkpor.Solver(r, b.solver_bytes())
+            n_in = b.n_public + b.n_secret
+            host_w = np.zeros((len(b.val), 4), np.uint64)
+            host_w[:n_in] = SC.to_mont_limbs(b.val[:n_in])
+            best = 1e30
+            for _ in range(3):
+                d_w.upload(host_w)
+                ctx.sync()
+                t0 = time.perf_counter()
+                paused = s.start_dev(d_w.ptr, n_in)
+                best = min(best, time.perf_counter() - t0)
+            ok = paused == zkpor.NOT_PAUSED and bool(np.array_equal(d_w.download(np.uint64, (len(b.val), 4)), SC.to_mont_limbs(b.val)))
+            d = s.dims()
+            out[name] = {"users": users, "instructions": d["instructions"], "levels": d["levels"], "launches": d["launches_last_run"], "seconds": best,
+                         "instructions_per_s": d["instructions"] / best, "levels_per_s": d["levels"] / best, "wire_vector_equals_builder": ok}
+        finally:
+            if s is not None:
+                s.close()
+            d_w.free(); r.close()
+    out["note"] = ("inputs resident, the call returns when every wire is assigned; one field inversion per division and thread (no batching across the "
+                   "threads of a level yet); the same instruction semantics are unit-tested on the CPU (tests/test_solver_logic_cpu.py)")
+    return out
 
 
 def shard_heights(n_batches, rank, world):
@@ -1253,6 +1306,10 @@ def main():
                     out["solver_budget"]["host_executor_measured"] = host_executor_leg(usable_cpus())
                 except Exception as e:
                     out["solver_budget"]["host_executor_measured"] = {"note": f"failed: {e}"}
+                try:
+                    out["solver_budget"]["device_executor_measured"] = device_executor_leg(ctx)
+                except Exception as e:
+                    out["solver_budget"]["device_executor_measured"] = {"note": f"failed: {e}"}
             if not args.timed_only and log2 >= 20:
                 try:
                     out["poseidon_tree"] = poseidon_tree_leg(ctx)

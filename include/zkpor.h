@@ -438,6 +438,39 @@ int32_t zkpor_witgen_divmod_small_dev(zkpor_ctx* ctx, const void* d_values, size
 /* d_w[d_wire_ids[i]] = d_src[i], i < n */
 int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, const uint32_t* d_wire_ids, size_t n);
 
+/* ---- the solver program on the device (the generic half) --------------------------------------------------------
+ * r1cs.Solve inside groth16.Prove (src/prover/prover/prover.go:269; gnark constraint/bn254/solver.go, 3P) walks the compiled system's
+ * levels — sets of mutually independent instructions: solve one constraint for its single unknown wire, or call a hint — with the host's
+ * cores.  Here the exported program (go/export_solver -> the "ZKPSOLV" container, host/solver_file.hpp) sits in HBM next to the
+ * constraint matrices (zkpor_r1cs_*) and a level is one launch with one GPU thread per instruction; runs of narrow levels are stepped
+ * through by one workgroup.  Native hints: circuit.IntegerDivision (circuit/utils.go:103-110, registered at prover.go:68), NBits, InvZero,
+ * DecomposeHint.  Any other hint (gnark's BSB22 commitment placeholder) is EXTERNAL: the run pauses in front of it and the caller serves it.
+ * The wire vector never leaves the device: wires the structured generators (zkpor_witgen_*) produced are passed in as already known,
+ * and the result feeds zkpor_r1cs_eval_dev / zkpor_commit_dev / zkpor_prove_tail_dev. */
+typedef struct zkpor_solver zkpor_solver;
+/* `r1cs` (all three matrices loaded) must outlive the solver; the container is copied and validated (ZKPOR_E_ARG) */
+int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* solver_container, size_t len, zkpor_solver** out);
+void zkpor_solver_destroy(zkpor_solver* solver);
+/* dims = {instructions, levels, constraint instructions, hint instructions, skipped instructions, levels holding an external hint,
+ * kernel launches of the last run} */
+int32_t zkpor_solver_dims(const zkpor_solver* solver, uint64_t dims[7]);
+/* d_w: n_wires Montgomery Fr on the device, the first n_inputs (1 + nPublic + nSecret, gnark's order, wire 0 = ONE) filled.
+ * d_known_or_null: n_wires bytes on the device, non-zero = this wire is already assigned (pre-filled by a generator); NULL = only the inputs.
+ * Runs until the program ends (*paused_instr = 0xffffffff; every wire of d_w is then assigned, else ZKPOR_E_STATE) or until an external
+ * hint is met (*paused_instr = its instruction index): read its inputs, provide its outputs, call zkpor_solver_resume_dev.  Synchronous.
+ * Errors (ZKPOR_E_STATE, text in zkpor_last_error): the reference solver's — unsatisfied assertion, division by zero, a hint that
+ * refuses its input (range check violated, zero divisor), an instruction with two unknown wires (wrong level order). */
+int32_t zkpor_solver_start_dev(zkpor_solver* solver, void* d_w, size_t n_inputs, uint8_t* d_known_or_null, uint32_t* paused_instr);
+int32_t zkpor_solver_resume_dev(zkpor_solver* solver, uint32_t* paused_instr);
+/* the external hint the run is paused at: its evaluated input expressions (n_in x 4 limbs into in_values when not NULL) and its shape */
+int32_t zkpor_solver_external_inputs(zkpor_solver* solver, uint32_t instr, uint64_t* in_values, size_t capacity, size_t* n_in, size_t* n_out);
+/* its output wires (n_out x 4 limbs, Montgomery), written into d_w and marked assigned */
+int32_t zkpor_solver_external_outputs(zkpor_solver* solver, uint32_t instr, const uint64_t* out_values, size_t n_out);
+/* host-buffer form for tests and small circuits: inputs in, w_out receives n_wires elements; (pre_ids, pre_vals) = wires assigned
+ * elsewhere; stats = {constraint instructions, hint instructions, skipped instructions, kernel launches}.  External hints are refused. */
+int32_t zkpor_solver_run(zkpor_solver* solver, const uint64_t* inputs, size_t n_inputs, const uint32_t* pre_ids, const uint64_t* pre_vals,
+                         size_t n_pre, uint64_t* w_out, uint64_t stats[4]);
+
 /* ---- device memory helpers for host languages without a HIP binding ------------------------------------ */
 int32_t zkpor_dev_alloc(zkpor_ctx* ctx, size_t bytes, void** out);
 int32_t zkpor_dev_free(zkpor_ctx* ctx, void* p);

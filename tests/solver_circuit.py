@@ -21,6 +21,12 @@ def to_mont_limbs(vals):
     return out
 
 
+def from_mont_limbs(arr):
+    """python integers of Montgomery limb rows"""
+    inv = pow(MONT, R - 2, R)
+    return [sum(int(x) << (64 * k) for k, x in enumerate(row)) * inv % R for row in np.asarray(arr, dtype=np.uint64).reshape(-1, 4)]
+
+
 class Builder:
     def __init__(self, public, secret):
         """wire 0 = ONE, then the public inputs, then the secret ones (gnark's order)"""
@@ -162,8 +168,8 @@ class Builder:
             by.setdefault(lvl, []).append(i)
         return [by[k] for k in sorted(by)]
 
-    def r1cs_bytes(self):
-        import r1cs_container
+    def tables(self):
+        """(coefficient table as Montgomery limbs, [(row_ptr, coeff ids, wire ids) for L, R, O]) — the arguments of zkpor_r1cs_create / set_matrix"""
         table = [0] * len(self.coeffs)
         for v, i in self.coeffs.items():
             table[i] = v
@@ -175,7 +181,12 @@ class Builder:
                     cids.append(cid); wids.append(w)
                 ptr.append(len(cids))
             mats.append((np.array(ptr, dtype=np.uint64), np.array(cids, dtype=np.uint32), np.array(wids, dtype=np.uint32)))
-        return r1cs_container.write(len(self.rows), len(self.val), self.n_public, self.n_secret, to_mont_limbs(table), mats)
+        return to_mont_limbs(table), mats
+
+    def r1cs_bytes(self):
+        import r1cs_container
+        table, mats = self.tables()
+        return r1cs_container.write(len(self.rows), len(self.val), self.n_public, self.n_secret, table, mats)
 
     def solver_bytes(self, levels=None, skip_tags=()):
         levels = self.levels() if levels is None else levels

@@ -1,0 +1,199 @@
+"""-m gpu: the solver program executed on the device (csrc/solver.hip, include/zkpor.h zkpor_solver_*; SURVEY.md §8 f4 — r1cs.Solve inside
+groth16.Prove, prover.go:269) through the C ABI: the wire vector must equal the builder's Python-integer values bit for bit (wide levels =
+one thread per instruction, narrow levels = one workgroup stepping through a run), a . b = c must hold on the device's own evaluation of the
+result, pre-filled wires must be taken as they are, external hints must pause the run and resume it, and every failure mode of the
+reference solver must come back as an error."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import solver_circuit as SC
+import zkpor
+
+pytestmark = pytest.mark.gpu
+
+
+def device_system(zk, b, solver=None):
+    table, mats = b.tables()
+    r = zkpor.R1CS(zk, len(b.rows), len(b.val), table)
+    for m in range(3):
+        r.set_matrix(m, *mats[m])
+    return r, zkpor.Solver(r, b.solver_bytes() if solver is None else solver)
+
+
+def inputs_of(b, vals=None):
+    return SC.to_mont_limbs((b.val if vals is None else vals)[:b.n_public + b.n_secret])
+
+
+@pytest.mark.parametrize("seed,users,chain", [(1, 1, True), (2, 7, True), (3, 40, False), (4, 700, False)])
+def test_wire_vector_equals_the_builders(zk, seed, users, chain):
+    b = SC.demo_circuit(seed, users, chain=chain)
+    r, s = device_system(zk, b)
+    try:
+        d = s.dims()
+        assert d["instructions"] == len(b.instr) and d["levels"] == len(b.levels()) and d["external_levels"] == 0
+        w, st = s.run(inputs_of(b))
+        assert np.array_equal(w, SC.to_mont_limbs(b.val))
+        n_hint = sum(1 for k, _, _, _ in b.instr if k == 1)
+        assert (st["constraint_instructions"], st["hint_instructions"], st["skipped"]) == (len(b.instr) - n_hint, n_hint, 0)
+        widths = [len(l) for l in b.levels()]
+        runs = sum(1 for i, n in enumerate(widths) if n > 512 or i == 0 or widths[i - 1] > 512)    # a launch per wide level, one per run of narrow ones
+        assert st["launches"] == runs
+        a, bb, c = r.eval(w)                         # the device's own a, b, c of the solved vector
+        dw = [zk.alloc(a.nbytes).upload(x) for x in (a, bb)]
+        out = zk.alloc(a.nbytes)
+        zk._ck(zk.lib.zkpor_dev_fr_mul(zk.h, ctypes.c_void_p(out.ptr), ctypes.c_void_p(dw[0].ptr), ctypes.c_void_p(dw[1].ptr), ctypes.c_size_t(a.shape[0])))
+        prod = out.download(np.uint64, a.shape)
+        for x in dw + [out]:
+            x.free()
+        assert np.array_equal(prod, c)
+        w2, _ = s.run(inputs_of(b))                  # the handle is reusable
+        assert np.array_equal(w2, w)
+    finally:
+        s.close(); r.close()
+
+
+def test_hints_at_every_operand_width(zk):
+    rng = np.random.default_rng(21)
+    cases = []
+    for abits, bbits in [(20, 7), (64, 64), (130, 63), (200, 64), (253, 1), (253, 65), (253, 128), (250, 200), (100, 250), (0, 9), (33, 32), (64, 33)]:
+        for _ in range(3):
+            a = int.from_bytes(rng.bytes(32), "big") >> (256 - abits) if abits else 0
+            d = (int.from_bytes(rng.bytes(32), "big") >> (256 - bbits)) | 1
+            cases.append((a % SC.R, d % SC.R or 1))
+    b = SC.Builder([5], [x for ab in cases for x in ab])
+    base = b.n_public
+    for i in range(len(cases)):
+        b.integer_division(b.wire(base + 2 * i), b.wire(base + 2 * i + 1))
+    for i, (bits, limb) in enumerate([(16, 16), (64, 16), (70, 7), (250, 60), (253, 64), (128, 13), (1, 1), (96, 32), (99, 33), (64, 31)]):
+        v = cases[i][0] & ((1 << bits) - 1)
+        b.range_check(b.wire(b.mul(b.const(v), b.const(1), "val")), bits, limb)
+    for i, n in enumerate([1, 8, 31, 32, 33, 64, 65, 128, 253]):
+        v = cases[3 + i][0] & ((1 << n) - 1)
+        b.to_binary(b.wire(b.mul(b.const(v), b.const(1), "val")), n)
+    vals = [int.from_bytes(rng.bytes(32), "big") % SC.R for _ in range(6)] + [0]
+    b2 = SC.Builder([1], vals)
+    for i in range(7):
+        b2.is_zero(b2.wire(b2.n_public + i))
+    for i in range(0, 6, 2):
+        b2.inverse(b2.wire(b2.n_public + i))
+        b2.div_left(b2.wire(b2.n_public + i), b2.wire(b2.n_public + i + 1))
+    for bb in (b, b2):
+        r, s = device_system(zk, bb)
+        try:
+            w, _ = s.run(inputs_of(bb))
+            assert np.array_equal(w, SC.to_mont_limbs(bb.val))
+        finally:
+            s.close(); r.close()
+
+
+def test_prefilled_wires_and_skipped_instructions(zk):
+    """the S-box wires arrive from the device generators: their instructions are marked skipped, the values are taken as known"""
+    b = SC.demo_circuit(7, 8)
+    wires = b.wires_of_tag("sbox")
+    r, s = device_system(zk, b, solver=b.solver_bytes(skip_tags=("sbox",)))
+    try:
+        pre = [(i, SC.to_mont_limbs([b.val[i]])[0]) for i in wires]
+        w, st = s.run(inputs_of(b), prefilled=pre)
+        assert np.array_equal(w, SC.to_mont_limbs(b.val)) and st["skipped"] == len(wires)
+        with pytest.raises(zkpor.ZkporError):        # without the values the dependants cannot be solved: an error, not a vector
+            s.run(inputs_of(b))
+    finally:
+        s.close(); r.close()
+
+
+def test_external_hints_pause_and_resume(zk):
+    """a hint without a native implementation (gnark's BSB22 commitment placeholder in the real circuit) stops the run in front of it: the caller
+    reads the evaluated inputs, provides the outputs and resumes — two of them in one level, a third one later, wires in between depend on them"""
+    rng = np.random.default_rng(5)
+    vals = [int.from_bytes(rng.bytes(32), "big") % SC.R for _ in range(6)]
+    b = SC.Builder([9], vals)
+    base = b.n_public
+    x = b.mul(b.wire(base), b.wire(base + 1))
+    ext = lambda ins: ((sum(ins) * 7 + 3) % SC.R, (ins[0] * ins[0]) % SC.R)        # what the "caller" computes: two outputs
+    e1_in = [b.add(b.wire(x), b.wire(base + 2, 5)), b.wire(base + 3)]
+    o1 = b.hint("bsb22CommitmentComputePlaceholder", e1_in, list(ext([b.eval(e) for e in e1_in])))
+    e2_in = [b.add(b.wire(x), b.wire(base + 4)), b.const(11)]                     # same level as the first one
+    o2 = b.hint("bsb22CommitmentComputePlaceholder", e2_in, list(ext([b.eval(e) for e in e2_in])))
+    y = b.mul(b.wire(o1[0]), b.wire(o2[1]))                                           # depends on both
+    b.is_zero(b.sub(b.wire(y), b.wire(y)))
+    e3_in = [b.wire(y), b.wire(o1[1])]
+    o3 = b.hint("AnotherHintOfTheCaller", e3_in, list(ext([b.eval(e) for e in e3_in])))
+    b.inverse(b.add(b.wire(o3[0]), b.const(1)))
+    r, s = device_system(zk, b)
+    d_w = zk.alloc(len(b.val) * 32)
+    try:
+        assert s.dims()["external_levels"] == 2
+        with pytest.raises(zkpor.ZkporError):        # the host-buffer form does not serve external hints
+            s.run(inputs_of(b))
+        host_w = np.zeros((len(b.val), 4), np.uint64)
+        n_in = b.n_public + b.n_secret
+        host_w[:n_in] = inputs_of(b)
+        d_w.upload(host_w)
+        served = []
+        paused = s.start_dev(d_w.ptr, n_in)
+        while paused != zkpor.NOT_PAUSED:
+            ins_vals, n_out = s.external_inputs(paused)
+            ints = SC.from_mont_limbs(ins_vals)
+            assert n_out == 2
+            with pytest.raises(zkpor.ZkporError):    # wrong instruction / wrong output count are refused, the pause stays
+                s.external_outputs(paused + 1, SC.to_mont_limbs([1, 2]))
+            with pytest.raises(zkpor.ZkporError):
+                s.external_outputs(paused, SC.to_mont_limbs([1]))
+            s.external_outputs(paused, SC.to_mont_limbs(list(ext(ints))))
+            served.append((paused, ints))
+            paused = s.resume_dev()
+        assert len(served) == 3 and served[0][0] < served[1][0]
+        assert served[0][1] == [b.eval(e) for e in e1_in] and served[1][1] == [b.eval(e) for e in e2_in] and served[2][1] == [b.eval(e) for e in e3_in]
+        w = d_w.download(np.uint64, (len(b.val), 4))
+        assert np.array_equal(w, SC.to_mont_limbs(b.val))
+        with pytest.raises(zkpor.ZkporError):        # nothing left to resume
+            s.resume_dev()
+    finally:
+        d_w.free(); s.close(); r.close()
+
+
+def test_failures_are_errors(zk):
+    def fails(b, text, vals=None, solver=None):
+        r, s = device_system(zk, b, solver=solver)
+        try:
+            with pytest.raises(zkpor.ZkporError) as e:
+                s.run(inputs_of(b, vals))
+            assert text in str(e.value), str(e.value)
+        finally:
+            s.close(); r.close()
+    b = SC.demo_circuit(9, 4)
+    n_in = b.n_public + b.n_secret
+    vals = list(b.val[:n_in]); vals[b.n_public] = 1 << 70           # violates a range check: the decomposition hint refuses
+    fails(b, "hint failed", vals=vals)
+    vals = list(b.val[:n_in]); vals[b.n_public + 4] = 0             # a zero price: IntegerDivision refuses like big.Int.DivMod panics
+    fails(b, "hint failed", vals=vals)
+    lv = b.levels()
+    fails(b, "solver:", solver=b.solver_bytes(levels=lv[::-1]))     # wrong level order: two unknown wires or an unsolved hint input
+    short = [l[:] for l in lv]; short[-2] = short[-2][:-1]
+    fails(b, "solver:", solver=b.solver_bytes(levels=short))        # an instruction missing from the levels: a wire is never assigned
+    b3 = SC.Builder([1], [0])
+    b3.inverse(b3.wire(b3.n_public))
+    fails(b3, "division by zero")
+    b4 = SC.Builder([1], [3, 4])
+    b4.assert_mul(b4.wire(b4.n_public), b4.wire(b4.n_public + 1), b4.const(13))
+    fails(b4, "constraint not satisfied")
+    # a malformed container is refused when the solver is created
+    table, mats = b.tables()
+    r = zkpor.R1CS(zk, len(b.rows), len(b.val), table)
+    for m in range(3):
+        r.set_matrix(m, *mats[m])
+    try:
+        sv = bytearray(b.solver_bytes())
+        with pytest.raises(zkpor.ZkporError):
+            zkpor.Solver(r, sv[:len(sv) // 2])
+        bad = bytearray(sv); bad[0] = ord("X")
+        with pytest.raises(zkpor.ZkporError):
+            zkpor.Solver(r, bad)
+        b5 = SC.demo_circuit(9, 4)
+        b5.instr[3] = (0, len(b5.rows) + 5, b5.instr[3][2], b5.instr[3][3])     # names a constraint outside the system
+        with pytest.raises(zkpor.ZkporError):
+            zkpor.Solver(r, b5.solver_bytes())
+    finally:
+        r.close()

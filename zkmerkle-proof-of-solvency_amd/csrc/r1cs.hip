@@ -6,17 +6,7 @@
 // Layout follows gnark's compiled constraint system: a linear expression is a list of terms (coefficient id, wire id),
 // coefficients live in a small shared table (most terms use 1 or -1); three CSR matrices share the table.
 #include "common.cuh"
-
-struct zkpor_r1cs {
-    zkpor_ctx* ctx = nullptr;
-    size_t n_constraints = 0, n_wires = 0, n_coeff = 0;
-    zk::Fr* coeff = nullptr;       // Montgomery
-    uint8_t* coeff_kind = nullptr;  // 0 generic, 1 = one, 2 = minus one, 3 = zero
-    uint64_t* row_ptr[3] = {nullptr, nullptr, nullptr};
-    uint32_t* cid[3] = {nullptr, nullptr, nullptr};
-    uint32_t* wid[3] = {nullptr, nullptr, nullptr};
-    size_t nnz[3] = {0, 0, 0};
-};
+#include "r1cs.cuh"
 
 namespace zk {
 

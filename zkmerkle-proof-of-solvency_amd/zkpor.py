@@ -758,3 +758,59 @@ class R1CS:
         if self.h:
             self.ctx.lib.zkpor_r1cs_destroy(self.h)
             self.h = None
+
+
+NOT_PAUSED = 0xffffffff
+
+
+class Solver:
+    """the solver program of a compiled circuit on the device (include/zkpor.h zkpor_solver_*): r1cs.Solve of groth16.Prove
+    (prover.go:269) as one launch per level over the matrices of `r1cs`"""
+
+    def __init__(self, r1cs, container):
+        self.ctx = r1cs.ctx; self.r1cs = r1cs
+        buf = bytes(container)
+        h = ctypes.c_void_p()
+        self.ctx._ck(self.ctx.lib.zkpor_solver_create(r1cs.h, buf, ctypes.c_size_t(len(buf)), ctypes.byref(h)))
+        self.h = h
+
+    def dims(self):
+        d = (ctypes.c_uint64 * 7)()
+        self.ctx._ck(self.ctx.lib.zkpor_solver_dims(self.h, d))
+        return dict(zip(("instructions", "levels", "constraint_instructions", "hint_instructions", "skipped", "external_levels", "launches_last_run"), [int(x) for x in d]))
+
+    def run(self, inputs, prefilled=None):
+        """host-buffer form: (w, stats)"""
+        inputs = _u64(inputs).reshape(-1, 4)
+        ids = np.ascontiguousarray([i for i, _ in (prefilled or [])], dtype=np.uint32)
+        vals = _u64(np.array([v for _, v in prefilled])).reshape(-1, 4) if prefilled else np.zeros((0, 4), np.uint64)
+        w = np.zeros((self.r1cs.n_wires, 4), np.uint64)
+        st = (ctypes.c_uint64 * 4)()
+        self.ctx._ck(self.ctx.lib.zkpor_solver_run(self.h, _p(inputs), ctypes.c_size_t(inputs.shape[0]), _p(ids), _p(vals), ctypes.c_size_t(ids.shape[0]), _p(w), st))
+        return w, dict(zip(("constraint_instructions", "hint_instructions", "skipped", "launches"), [int(x) for x in st]))
+
+    def start_dev(self, d_w, n_inputs, d_known=None):
+        paused = ctypes.c_uint32()
+        self.ctx._ck(self.ctx.lib.zkpor_solver_start_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_size_t(n_inputs), ctypes.c_void_p(d_known) if d_known else None, ctypes.byref(paused)))
+        return paused.value
+
+    def resume_dev(self):
+        paused = ctypes.c_uint32()
+        self.ctx._ck(self.ctx.lib.zkpor_solver_resume_dev(self.h, ctypes.byref(paused)))
+        return paused.value
+
+    def external_inputs(self, instr):
+        n_in = ctypes.c_size_t(); n_out = ctypes.c_size_t()
+        self.ctx._ck(self.ctx.lib.zkpor_solver_external_inputs(self.h, ctypes.c_uint32(instr), None, ctypes.c_size_t(0), ctypes.byref(n_in), ctypes.byref(n_out)))
+        vals = np.zeros((n_in.value, 4), np.uint64)
+        self.ctx._ck(self.ctx.lib.zkpor_solver_external_inputs(self.h, ctypes.c_uint32(instr), _p(vals), ctypes.c_size_t(n_in.value), ctypes.byref(n_in), ctypes.byref(n_out)))
+        return vals, n_out.value
+
+    def external_outputs(self, instr, values):
+        values = _u64(values).reshape(-1, 4)
+        self.ctx._ck(self.ctx.lib.zkpor_solver_external_outputs(self.h, ctypes.c_uint32(instr), _p(values), ctypes.c_size_t(values.shape[0])))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.zkpor_solver_destroy(self.h)
+            self.h = None
