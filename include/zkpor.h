@@ -464,8 +464,15 @@ int32_t zkpor_solver_start_dev(zkpor_solver* solver, void* d_w, size_t n_inputs,
 int32_t zkpor_solver_resume_dev(zkpor_solver* solver, uint32_t* paused_instr);
 /* the external hint the run is paused at: its evaluated input expressions (n_in x 4 limbs into in_values when not NULL) and its shape */
 int32_t zkpor_solver_external_inputs(zkpor_solver* solver, uint32_t instr, uint64_t* in_values, size_t capacity, size_t* n_in, size_t* n_out);
+/* the same into device memory (capacity >= n_in elements): the committed wires of a BSB22 commitment go straight to zkpor_commit_dev */
+int32_t zkpor_solver_external_inputs_dev(zkpor_solver* solver, uint32_t instr, void* d_out, size_t capacity);
 /* its output wires (n_out x 4 limbs, Montgomery), written into d_w and marked assigned */
 int32_t zkpor_solver_external_outputs(zkpor_solver* solver, uint32_t instr, const uint64_t* out_values, size_t n_out);
+/* groth16.Prove from the assigned inputs (prover.go:269 as one call): inputs cross PCIe, solver program -> w, r1cs -> a, b, c, prove tail,
+ * all on the device.  For programs without external hints (else ZKPOR_E_STATE: drive the steps with the calls above + zkpor_commit_dev +
+ * zkpor_r1cs_eval_dev + zkpor_prove_tail_dev).  `solver` must have been created on `r1cs`; any context of that GPU may call. */
+int32_t zkpor_prove_inputs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, zkpor_solver* solver, const uint64_t* inputs, size_t n_inputs,
+                           const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]);
 /* host-buffer form for tests and small circuits: inputs in, w_out receives n_wires elements; (pre_ids, pre_vals) = wires assigned
  * elsewhere; stats = {constraint instructions, hint instructions, skipped instructions, kernel launches}.  External hints are refused. */
 int32_t zkpor_solver_run(zkpor_solver* solver, const uint64_t* inputs, size_t n_inputs, const uint32_t* pre_ids, const uint64_t* pre_vals,

@@ -135,6 +135,10 @@ def test_external_hints_pause_and_resume(zk):
         paused = s.start_dev(d_w.ptr, n_in)
         while paused != zkpor.NOT_PAUSED:
             ins_vals, n_out = s.external_inputs(paused)
+            d_in = zk.alloc(ins_vals.nbytes)                                             # the device form gives the same values
+            s.external_inputs_dev(paused, d_in.ptr, ins_vals.shape[0])
+            assert np.array_equal(d_in.download(np.uint64, ins_vals.shape), ins_vals)
+            d_in.free()
             ints = SC.from_mont_limbs(ins_vals)
             assert n_out == 2
             with pytest.raises(zkpor.ZkporError):    # wrong instruction / wrong output count are refused, the pause stays
@@ -197,3 +201,63 @@ def test_failures_are_errors(zk):
             zkpor.Solver(r, b5.solver_bytes())
     finally:
         r.close()
+
+
+def synth_solver_bytes(S, mats):
+    """the solver program of the oracle's synthetic instance (oracle/algos.hpp synth_instance): constraint k is a multiplication gate that
+    defines wire 1 + n_inputs + k from earlier wires — one instruction per constraint, levels from the wire dependencies"""
+    import struct
+    n_in = S.n_wires - S.n_cons
+    level_of = np.zeros(S.n_wires, dtype=np.int64)
+    levels = {}
+    for k in range(S.n_cons):
+        deps = [int(w) for m in (0, 1) for w in mats[m][2][int(mats[m][0][k]):int(mats[m][0][k + 1])]]
+        lvl = 1 + max([int(level_of[w]) for w in deps] + [0])
+        level_of[n_in + k] = lvl
+        levels.setdefault(lvl, []).append(k)
+    order = [levels[l] for l in sorted(levels)]
+    out = bytearray(b"ZKPSOLV\x01") + struct.pack("<4Q", S.n_cons, len(order), 0, 0)
+    out += np.zeros(S.n_cons, dtype="<u4").tobytes() + np.arange(S.n_cons, dtype="<u4").tobytes()
+    out += b"\0" * (-len(out) % 8)
+    ptr = np.cumsum([0] + [len(l) for l in order]).astype("<u8")
+    out += ptr.tobytes() + np.array([i for l in order for i in l], dtype="<u4").tobytes()
+    out += b"\0" * (-len(out) % 8)
+    return bytes(out), len(order)
+
+
+@pytest.mark.parametrize("n_inputs,n_cons", [(6, 700), (40, 5000)])
+def test_prove_from_the_assigned_inputs_on_the_device(zk, n_inputs, n_cons):
+    """groth16.Prove (prover.go:269) as ONE call from the assigned inputs: solver program -> w, constraint matrices -> a, b, c, prove tail, all in
+    HBM (zkpor_prove_inputs) — the proof equals the oracle's proof of its own solved instance bit for bit and passes the pairing check; a second
+    context of the GPU proves against the same resident program; an input that breaks nothing still proves, one of the wrong length is refused"""
+    import oracle as O
+    S = O.Synth(n_inputs, n_cons, n_public=2, seed=77 + n_cons)
+    table, mats = S.r1cs()
+    r = zkpor.R1CS(zk, S.n_cons, S.n_wires, table)
+    for which, (row_ptr, cid, wid) in enumerate(mats):
+        r.set_matrix(which, row_ptr, cid, wid)
+    prog, n_levels = synth_solver_bytes(S, mats)
+    s = zkpor.Solver(r, prog)
+    pk = zkpor.ProvingKey(zk)
+    zk2 = zkpor.Context(0)
+    try:
+        assert s.dims()["levels"] == n_levels and n_levels > 3
+        n_in = S.n_wires - S.n_cons
+        w, _ = s.run(S.w[:n_in])
+        assert np.array_equal(w, S.w)                                   # the program reproduces the oracle's wire vector
+        z = np.zeros(S.n_wires, dtype=np.uint8)
+        pk.set_g1(zkpor.G1_A, S.A); pk.set_g1(zkpor.G1_B, S.B1); pk.set_g2(zkpor.G2_B, S.B2)
+        pk.set_g1(zkpor.G1_K, S.K[S.n_public:]); pk.set_g1(zkpor.G1_Z, S.Z)
+        pk.set_consts(S.abd1[0], S.abd1[1], S.abd1[2], S.bd2[0], S.bd2[1], S.log2d, z, z, S.n_wires, S.n_public)
+        for i, ctx in enumerate((zk, zk2, zk)):
+            rr = O.fr_random(150 + i, 1)[0]; ss = O.fr_random(160 + i, 1)[0]
+            got = ctx.prove_inputs(pk, r, s, S.w[:n_in], rr, ss)
+            assert np.array_equal(got, S.prove_tail(rr, ss))
+        assert S.verify_pairing(got)
+        with pytest.raises(zkpor.ZkporError):
+            zk.prove_inputs(pk, r, s, S.w[:n_in - 1], rr, ss)           # one input short: wires stay unassigned
+        bad = np.full(4, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+        with pytest.raises(zkpor.ZkporError, match="blinding"):
+            zk.prove_inputs(pk, r, s, S.w[:n_in], bad, ss)
+    finally:
+        zk2.close(); pk.close(); s.close(); r.close()

@@ -196,6 +196,10 @@ struct GpuTurn {
 int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size);
 void r1cs_dims(const zkpor_r1cs* r, size_t* n_constraints, size_t* n_wires, int* device);
 
+// solver.hip: the context and the constraint system a solver program was created on
+zkpor_ctx* solver_ctx(zkpor_solver* s);
+zkpor_r1cs* solver_r1cs(zkpor_solver* s);
+
 // sort.hip (rocPRIM radix sort of (key,value) u32 pairs, keys in [0, 2^end_bit))
 int32_t sort_pairs_temp_bytes(zkpor_ctx* ctx, size_t n, int end_bit, size_t* bytes);
 

@@ -925,6 +925,60 @@ int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const u
     return ZKPOR_OK;
 }
 
+// groth16.Prove from the ASSIGNED INPUTS, everything after them on the device (SURVEY §8 f4 + f1 + a6): the inputs (1 + nPublic + nSecret
+// elements, gnark's order) cross PCIe, the solver program fills the wire vector in HBM (csrc/solver.hip), a, b, c are evaluated from it
+// (csrc/r1cs.hip) and the prove tail runs in its resident order.  For circuits whose solver program holds no external hint; a circuit with a
+// BSB22 commitment drives the same steps itself (zkpor_solver_start_dev / _external_* / _resume_dev, zkpor_commit_dev, zkpor_r1cs_eval_dev,
+// zkpor_prove_tail_dev — INTEGRATION.md §1c).
+int32_t zkpor_prove_inputs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, zkpor_solver* solver, const uint64_t* inputs, size_t n_inputs,
+                           const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !pk || !r1cs || !solver || !inputs || !r || !s || !proof_out) return ZKPOR_E_ARG;
+    if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
+    if (pk->shard) { ctx->err = "prove: the key is a shard (zkpor_pk_keep_range): use zkpor_prove_sums_dev + zkpor_prove_assemble"; return ZKPOR_E_STATE; }
+    if (solver_r1cs(solver) != r1cs) { ctx->err = "prove: the solver program was created on another constraint system"; return ZKPOR_E_ARG; }
+    const size_t D = (size_t)1 << pk->log2_domain;
+    size_t nc = 0, nw = 0;
+    int dev = -1;
+    r1cs_dims(r1cs, &nc, &nw, &dev);
+    if (dev != ctx->device) { ctx->err = "prove: the constraint matrices live on another GPU than the context"; return ZKPOR_E_ARG; }
+    if (nw != pk->n_wires) { ctx->err = "prove: the constraint system and the key disagree on the number of wires"; return ZKPOR_E_ARG; }
+    if (nc > D) { ctx->err = "prove: more constraints than the domain"; return ZKPOR_E_ARG; }
+    if (n_inputs == 0 || n_inputs > nw) { ctx->err = "prove: the assignment must hold 1 + nPublic + nSecret elements"; return ZKPOR_E_ARG; }
+    ZK_TRY(check_same_gpu(ctx, pk));
+    ZK_TRY(check_blinding(ctx, r, s));
+    ZK_TRY(stage_reserve(ctx, (3 * D + pk->n_wires) * sizeof(Fr)));
+    Fr* d = (Fr*)ctx->stage;
+    Fr* d_w = d + 3 * D;
+    auto drain = [&] {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+    };
+    GpuTurn turn;
+    int32_t rc = host_upload(ctx, d_w, inputs, n_inputs * sizeof(Fr));
+    if (rc == ZKPOR_OK && hipStreamSynchronize(ctx->copy_stream) != hipSuccess) { ctx->err = "prove: the upload of the inputs failed"; rc = ZKPOR_E_HIP; }
+    if (rc == ZKPOR_OK) {
+        turn.acquire(ctx);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "prove: stream"; rc = ZKPOR_E_HIP; }   // the solver runs on its own context's stream
+    }
+    if (rc == ZKPOR_OK) {
+        uint32_t paused = 0xffffffffu;
+        rc = zkpor_solver_start_dev(solver, d_w, n_inputs, nullptr, &paused);
+        if (rc != ZKPOR_OK) ctx->err = solver_ctx(solver)->err;
+        else if (paused != 0xffffffffu) { ctx->err = "prove: the solver program holds an external hint (instruction " + std::to_string(paused) + "): drive the steps yourself"; rc = ZKPOR_E_STATE; }
+    }
+    if (rc == ZKPOR_OK) rc = r1cs_eval_on(ctx, r1cs, d_w, d, d + D, d + 2 * D, D);
+    ProveSums m;
+    Blind bl;
+    const std::function<void()> prep = [&] { bl = blind_prepare(pk->delta, pk->delta2, r, s); };
+    if (rc == ZKPOR_OK) rc = prove_sums(ctx, pk, d_w, d, d + D, d + 2 * D, &m, true, true, &prep, nullptr, &turn);
+    if (rc != ZKPOR_OK) { drain(); return rc; }
+    HostPhase hp(ctx, "host_assembly");
+    assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
+    return ZKPOR_OK;
+}
+
 // uniform Fr from the operating system's CSPRNG: 32 bytes from getrandom(2), top two bits cleared, rejected unless below the
 // modulus (acceptance ~ 0.76) — the construction of gnark-crypto's fr.Element.SetRandom.  The canonical limbs are used as the
 // Montgomery representation directly: x -> x R^-1 is a bijection of Fr, so the residue is uniform either way.

@@ -87,23 +87,22 @@ __global__ __launch_bounds__(256) void k_count_unknown(const uint8_t* __restrict
     if ((threadIdx.x & 63u) == 0 && b) atomicAdd(&err[2], (u32)__popcll(b));
 }
 
-// the input expressions of a hint, evaluated for the caller: out[i] = sum coeff * w over input i
-__global__ void k_hint_inputs(SolverProg P, u32 ins, const Fr* __restrict__ w, const uint8_t* __restrict__ known, Fr* out, u32* err) {
-    const u32 arg = P.arg[ins];
-    const u32* cd = P.calldata + arg;
-    const u32 n_in = cd[1], n_out = cd[2];
-    u64 p = 3 + (u64)n_out;
-    for (u32 i = 0; i < n_in; ++i) {
-        const u32 nterms = cd[p++];
-        Fr acc = Fr::zero();
-        for (u32 k = 0; k < nterms; ++k) {
-            const u32 ci = cd[p++], wi = cd[p++];
-            if (wi >= P.n_wires || ci >= P.n_coeff) { err[0] = SE_ID_RANGE; err[1] = ins; return; }
-            if (!known[wi]) { err[0] = SE_INPUT_UNSOLVED; err[1] = ins; return; }
-            si_add_term(acc, P.ckind[ci], P.coeff, ci, w[wi]);
-        }
-        out[i] = acc;
+// the input expressions of a hint, evaluated for the caller: out[i] = sum coeff * w over input i (one thread per input; the BSB22
+// placeholder's inputs are the committed wires, thousands to millions of one-term expressions)
+__global__ __launch_bounds__(256) void k_hint_inputs(SolverProg P, u32 ins, const u64* __restrict__ offs, u32 n_in, const Fr* __restrict__ w,
+                                                     const uint8_t* __restrict__ known, Fr* out, u32* err) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_in) return;
+    const u32* cd = P.calldata + P.arg[ins];
+    u64 p = offs[i];
+    const u32 nterms = cd[p++];
+    Fr acc = Fr::zero();
+    for (u32 k = 0; k < nterms; ++k) {
+        const u32 ci = cd[p++], wi = cd[p++];
+        if (!known[wi]) { if (atomicCAS(&err[0], 0u, (u32)SE_INPUT_UNSOLVED) == 0u) err[1] = ins; return; }
+        si_add_term(acc, P.ckind[ci], P.coeff, ci, w[wi]);
     }
+    out[i] = acc;
 }
 __global__ void k_hint_outputs(SolverProg P, u32 ins, const Fr* __restrict__ vals, Fr* w, uint8_t* known) {
     const u32* cd = P.calldata + P.arg[ins];
@@ -199,6 +198,8 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
     }
     return ZKPOR_OK;
 }
+zkpor_ctx* solver_ctx(zkpor_solver* s) { return s->ctx; }
+zkpor_r1cs* solver_r1cs(zkpor_solver* s) { return s->r1cs; }
 }  // namespace zk
 
 using namespace zk;
@@ -299,6 +300,30 @@ int32_t zkpor_solver_resume_dev(zkpor_solver* s, uint32_t* paused_instr) {
     return solver_advance(s, paused_instr);
 }
 
+// evaluates the inputs of the external hint the run is paused at into d_out (device, n_in elements); synchronous
+static int32_t hint_inputs_to(zkpor_solver* s, uint32_t instr, Fr* d_out) {
+    zkpor_ctx* ctx = s->ctx;
+    const uint32_t* cd = s->view.calldata + s->view.arg[instr];
+    const uint32_t n_in = cd[1];
+    if (n_in == 0) return ZKPOR_OK;
+    std::vector<uint64_t> offs(n_in);
+    uint64_t p = 3 + (uint64_t)cd[2];
+    for (uint32_t i = 0; i < n_in; ++i) { offs[i] = p; p += 1 + 2ull * cd[p]; }   // shapes were validated by zkpor_solver_create
+    uint64_t* d_offs = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&d_offs, n_in * sizeof(uint64_t)));
+    int32_t rc = ZKPOR_OK;
+    u32 h[2] = {0, 0};
+    if (hipMemcpyAsync(d_offs, offs.data(), n_in * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "solver: H2D failed"; rc = ZKPOR_E_HIP; }
+    if (rc == ZKPOR_OK) {
+        hipLaunchKernelGGL(k_hint_inputs, dim3((n_in + 255u) / 256u), dim3(256), 0, ctx->stream, prog_of(s), instr, d_offs, n_in, (const Fr*)s->d_w, s->known, d_out, s->d_err);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h, s->d_err, sizeof h, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "solver: launch failed"; rc = ZKPOR_E_HIP; }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_offs);
+    if (rc == ZKPOR_OK && h[0]) { s->running = false; ctx->err = std::string("solver: ") + solver_error_text(h[0]) + " at instruction " + std::to_string(h[1]); rc = ZKPOR_E_STATE; }
+    return rc;
+}
+
 int32_t zkpor_solver_external_inputs(zkpor_solver* s, uint32_t instr, uint64_t* in_values, size_t capacity, size_t* n_in, size_t* n_out) {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || !n_in || !n_out) return ZKPOR_E_ARG;
@@ -309,15 +334,23 @@ int32_t zkpor_solver_external_inputs(zkpor_solver* s, uint32_t instr, uint64_t* 
     if (!in_values) return ZKPOR_OK;              // sizes only
     if (capacity < cd[1]) { ctx->err = "solver: the buffer holds fewer elements than the hint has inputs"; return ZKPOR_E_ARG; }
     if (cd[1] == 0) return ZKPOR_OK;
-    ZK_TRY(stage_reserve(ctx, (size_t)cd[1] * sizeof(Fr)));
-    hipLaunchKernelGGL(k_hint_inputs, dim3(1), dim3(1), 0, ctx->stream, prog_of(s), instr, (const Fr*)s->d_w, s->known, (Fr*)ctx->stage, s->d_err);
-    ZK_KERNEL_CHECK(ctx);
-    u32 h[2];
-    ZK_HIP(ctx, hipMemcpyAsync(in_values, ctx->stage, (size_t)cd[1] * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipMemcpyAsync(h, s->d_err, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (h[0]) { s->running = false; ctx->err = std::string("solver: ") + solver_error_text(h[0]) + " at instruction " + std::to_string(h[1]); return ZKPOR_E_STATE; }
-    return ZKPOR_OK;
+    Fr* d_tmp = nullptr;                          // not the staging area: the caller's d_w may live there (zkpor_prove_inputs)
+    ZK_HIP(ctx, hipMalloc((void**)&d_tmp, (size_t)cd[1] * sizeof(Fr)));
+    int32_t rc = hint_inputs_to(s, instr, d_tmp);
+    if (rc == ZKPOR_OK && hipMemcpy(in_values, d_tmp, (size_t)cd[1] * sizeof(Fr), hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "solver: D2H failed"; rc = ZKPOR_E_HIP; }
+    (void)hipFree(d_tmp);
+    return rc;
+}
+
+/* the same into device memory (d_out: capacity elements): the committed wires of a BSB22 commitment go straight to zkpor_commit_dev */
+int32_t zkpor_solver_external_inputs_dev(zkpor_solver* s, uint32_t instr, void* d_out, size_t capacity) {
+    ZK_ENTER(s ? s->ctx->device : -1);
+    if (!s || !d_out) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = s->ctx;
+    if (!s->running || s->pending.empty() || s->pending.front() != instr) { ctx->err = "solver: not paused at this instruction"; return ZKPOR_E_STATE; }
+    const uint32_t* cd = s->view.calldata + s->view.arg[instr];
+    if (capacity < cd[1]) { ctx->err = "solver: the buffer holds fewer elements than the hint has inputs"; return ZKPOR_E_ARG; }
+    return hint_inputs_to(s, instr, (Fr*)d_out);
 }
 
 int32_t zkpor_solver_external_outputs(zkpor_solver* s, uint32_t instr, const uint64_t* out_values, size_t n_out) {
@@ -328,11 +361,17 @@ int32_t zkpor_solver_external_outputs(zkpor_solver* s, uint32_t instr, const uin
     const uint32_t* cd = s->view.calldata + s->view.arg[instr];
     if (n_out != cd[2]) { ctx->err = "solver: the hint has " + std::to_string(cd[2]) + " outputs"; return ZKPOR_E_ARG; }
     if (n_out) {
-        ZK_TRY(stage_reserve(ctx, n_out * sizeof(Fr)));
-        ZK_HIP(ctx, hipMemcpyAsync(ctx->stage, out_values, n_out * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_hint_outputs, dim3(1), dim3(256), 0, ctx->stream, prog_of(s), instr, (const Fr*)ctx->stage, (Fr*)s->d_w, s->known);
-        ZK_KERNEL_CHECK(ctx);
-        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // out_values may be pageable: the copy must have read it before the call returns
+        Fr* d_tmp = nullptr;
+        ZK_HIP(ctx, hipMalloc((void**)&d_tmp, n_out * sizeof(Fr)));
+        int32_t rc = ZKPOR_OK;
+        if (hipMemcpy(d_tmp, out_values, n_out * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "solver: H2D failed"; rc = ZKPOR_E_HIP; }
+        if (rc == ZKPOR_OK) {
+            hipLaunchKernelGGL(k_hint_outputs, dim3(1), dim3(256), 0, ctx->stream, prog_of(s), instr, (const Fr*)d_tmp, (Fr*)s->d_w, s->known);
+            if (hipGetLastError() != hipSuccess) { ctx->err = "solver: launch failed"; rc = ZKPOR_E_HIP; }
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_tmp);
+        if (rc != ZKPOR_OK) return rc;
     }
     s->pending.erase(s->pending.begin());
     return ZKPOR_OK;

@@ -284,6 +284,13 @@ class Context:
         self._ck(self.lib.zkpor_prove_r1cs(self.h, pk.h, r1cs.h, _p(w), _p(r), _p(s), _p(out)))
         return out
 
+    def prove_inputs(self, pk, r1cs, solver, inputs, r, s):
+        """groth16.Prove from the assigned inputs: solver program, a / b / c and the prove tail on the device (zkpor_prove_inputs)"""
+        inputs = _u64(inputs).reshape(-1, 4); r = _u64(r); s = _u64(s)
+        out = np.empty(256, dtype=np.uint8)
+        self._ck(self.lib.zkpor_prove_inputs(self.h, pk.h, r1cs.h, solver.h, _p(inputs), ctypes.c_size_t(inputs.shape[0]), _p(r), _p(s), _p(out)))
+        return out
+
     def prove_tail_dev(self, pk, d_w, d_a, d_b, d_c, r, s):
         r = _u64(r); s = _u64(s)
         out = np.empty(256, dtype=np.uint8)
@@ -805,6 +812,9 @@ class Solver:
         vals = np.zeros((n_in.value, 4), np.uint64)
         self.ctx._ck(self.ctx.lib.zkpor_solver_external_inputs(self.h, ctypes.c_uint32(instr), _p(vals), ctypes.c_size_t(n_in.value), ctypes.byref(n_in), ctypes.byref(n_out)))
         return vals, n_out.value
+
+    def external_inputs_dev(self, instr, d_out, capacity):
+        self.ctx._ck(self.ctx.lib.zkpor_solver_external_inputs_dev(self.h, ctypes.c_uint32(instr), ctypes.c_void_p(d_out), ctypes.c_size_t(capacity)))
 
     def external_outputs(self, instr, values):
         values = _u64(values).reshape(-1, 4)
