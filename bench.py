@@ -252,8 +252,8 @@ def device_executor_leg(ctx):
             if s is not None:
                 s.close()
             d_w.free(); r.close()
-    out["note"] = ("inputs resident, the call returns when every wire is assigned; one field inversion per division and thread (no batching across the "
-                   "threads of a level yet); the same instruction semantics are unit-tested on the CPU (tests/test_solver_logic_cpu.py)")
+    out["note"] = ("inputs resident, the call returns when every wire is assigned; one field inversion (binary extended Euclid) per division and thread, no "
+                   "batching across the threads of a level yet; the same instruction semantics are unit-tested on the CPU (tests/test_solver_logic_cpu.py)")
     return out
 
 

@@ -6,6 +6,7 @@ package zkporgpu
 
 import (
 	"errors"
+	"hash"
 	"math/big"
 
 	"github.com/consensys/gnark-crypto/ecc"
@@ -19,6 +20,21 @@ import (
 	"github.com/consensys/gnark/constraint/solver"
 	fcs "github.com/consensys/gnark/frontend/cs"
 )
+
+// bsb22ChallengeWith is the output of gnark's commitment hint (backend/groth16/bn254/prove.go): hash_to_field over the serialized
+// commitment and the public / commitment wires committed next to it.  Shared by Prove and ProveOnDevice (solver.go).
+func bsb22ChallengeWith(h hash.Hash, commitment *curve.G1Affine, hashed []*big.Int) fr.Element {
+	h.Write(constraint.SerializeCommitment(commitment.Marshal(), hashed, (fr.Bits-1)/8+1))
+	hashBts := h.Sum(nil)
+	h.Reset()
+	nbBuf := fr.Bytes
+	if h.Size() < fr.Bytes {
+		nbBuf = h.Size()
+	}
+	var res fr.Element
+	res.SetBytes(hashBts[:nbBuf])
+	return res
+}
 
 // Prove = groth16.Prove(r1cs, pk, fullWitness) on the GPU behind ctx.
 func Prove(ctx *Context, r1cs *cs_bn254.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...backend.ProverOption) (*groth16_bn254.Proof, error) {
@@ -52,15 +68,7 @@ func Prove(ctx *Context, r1cs *cs_bn254.R1CS, pk *ProvingKey, fullWitness witnes
 		if proof.Commitments[i], poks[i], e = ctx.Commit(pk, values); e != nil {
 			return e
 		}
-		opt.HashToFieldFn.Write(constraint.SerializeCommitment(proof.Commitments[i].Marshal(), hashed, (fr.Bits-1)/8+1))
-		hashBts := opt.HashToFieldFn.Sum(nil)
-		opt.HashToFieldFn.Reset()
-		nbBuf := fr.Bytes
-		if opt.HashToFieldFn.Size() < fr.Bytes {
-			nbBuf = opt.HashToFieldFn.Size()
-		}
-		var res fr.Element
-		res.SetBytes(hashBts[:nbBuf])
+		res := bsb22ChallengeWith(opt.HashToFieldFn, &proof.Commitments[i], hashed)
 		res.BigInt(out[0])
 		return nil
 	}))

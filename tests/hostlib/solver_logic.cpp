@@ -10,6 +10,9 @@
 using namespace zk;
 using namespace zkpor_host;
 
+extern "C" void sl_fr_inverse(const Fr* a, Fr* o, size_t n) { for (size_t i = 0; i < n; ++i) o[i] = fr_inverse(a[i]); }
+extern "C" void sl_fr_inv_fermat(const Fr* a, Fr* o, size_t n) { for (size_t i = 0; i < n; ++i) o[i] = Fr::inv(a[i]); }
+
 extern "C" int sl_run(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* solv, size_t solv_len, const uint64_t* inputs, size_t n_inputs,
                       const uint32_t* pre_ids, const uint64_t* pre_vals, size_t n_pre, int back_to_front, uint64_t* w_out, uint64_t info[2]) {
     R1csFileView r; SolverView s; std::string why;

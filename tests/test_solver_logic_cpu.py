@@ -118,3 +118,18 @@ def test_failures_carry_the_host_executors_codes():
     b4 = SC.Builder([1], [3, 4])
     b4.assert_mul(b4.wire(b4.n_public), b4.wire(b4.n_public + 1), b4.const(13))    # 3 * 4 = 13
     assert run_logic(b4)[0] == 12
+
+
+def test_binary_gcd_inverse_equals_the_fermat_power():
+    """fr_inverse (binary extended Euclid, what a GPU thread runs for a division) against Fr::inv (a^(r-2)) and Python: random residues, the
+    small and the large ones, powers of two, 0 -> 0"""
+    rng = np.random.default_rng(8)
+    vals = [int.from_bytes(rng.bytes(32), "big") % SC.R for _ in range(400)]
+    vals += [0, 1, 2, 3, SC.R - 1, SC.R - 2, (SC.R + 1) // 2, 1 << 32, (1 << 64) - 1, 1 << 253, SC.MONT, pow(SC.MONT, SC.R - 2, SC.R)]
+    vals += [1 << k for k in range(0, 254, 7)] + [(SC.R - (1 << k)) % SC.R for k in range(0, 254, 11)]
+    a = SC.to_mont_limbs(vals)
+    got = np.zeros_like(a); fermat = np.zeros_like(a)
+    LOGIC.sl_fr_inverse(_p(a), _p(got), ctypes.c_size_t(len(vals)))
+    LOGIC.sl_fr_inv_fermat(_p(a), _p(fermat), ctypes.c_size_t(len(vals)))
+    assert np.array_equal(got, fermat)
+    assert np.array_equal(got, SC.to_mont_limbs([pow(v, SC.R - 2, SC.R) if v else 0 for v in vals]))

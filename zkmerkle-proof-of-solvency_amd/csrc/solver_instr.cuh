@@ -35,6 +35,50 @@ ZK_HD void si_add_term(Fr& acc, uint8_t k, const Fr* coeff, u32 cid, const Fr& x
     else if (k == 0) acc = Fr::add(acc, Fr::mul(coeff[cid], x));
 }
 
+// 1 / a for a Montgomery residue (0 for 0) by the binary extended Euclidean algorithm: ~760 shift / add / subtract steps on 8 limbs, about a
+// third of the instructions of the Fermat power Fr::inv (254 squarings + 127 products).  The executor's levels are latency-bound — a level lasts
+// as long as its slowest instruction, and that is a division (IsZero, inverse wires) — so the single-thread cost of an inversion is what
+// a deep program's run time is made of.  Invariants: u x1^-1 = v x2^-1 = a (mod r) up to the tracked factors, u and v odd after the halvings.
+ZK_HD Fr fr_inverse(const Fr& a) {
+    if (a.is_zero()) return a;
+    u32 u[8], v[8], x1[8], x2[8];
+    for (int i = 0; i < 8; ++i) { u[i] = a.v[i]; v[i] = FrParams::mod(i); x1[i] = 0; x2[i] = 0; }
+    x1[0] = 1;
+    auto is_one = [](const u32* t) { u32 o = t[0] ^ 1u; for (int i = 1; i < 8; ++i) o |= t[i]; return o == 0; };
+    auto halve = [](u32* t, u32* x) {            // t even: t /= 2, x = x / 2 mod r
+        for (int i = 0; i < 7; ++i) t[i] = (t[i] >> 1) | (t[i + 1] << 31);
+        t[7] >>= 1;
+        u32 top = 0;
+        if (x[0] & 1u) {                          // x + r < 2^255: no carry out of the 8 limbs
+            u64 c = 0;
+            for (int i = 0; i < 8; ++i) { c += (u64)x[i] + FrParams::mod(i); x[i] = (u32)c; c >>= 32; }
+            top = (u32)c;
+        }
+        for (int i = 0; i < 7; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[7] = (x[7] >> 1) | (top << 31);
+    };
+    auto sub_into = [](u32* t, const u32* s) {   // t -= s, t >= s
+        u32 bw = 0;
+        for (int i = 0; i < 8; ++i) { const u64 d = (u64)t[i] - s[i] - bw; t[i] = (u32)d; bw = (u32)(d >> 32) & 1u; }
+    };
+    auto sub_mod = [](u32* x, const u32* y) {    // x = x - y mod r, both below r
+        u32 bw = 0;
+        for (int i = 0; i < 8; ++i) { const u64 d = (u64)x[i] - y[i] - bw; x[i] = (u32)d; bw = (u32)(d >> 32) & 1u; }
+        if (bw) { u64 c = 0; for (int i = 0; i < 8; ++i) { c += (u64)x[i] + FrParams::mod(i); x[i] = (u32)c; c >>= 32; } }
+    };
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u[0] & 1u)) halve(u, x1);
+        while (!(v[0] & 1u)) halve(v, x2);
+        bool ge = true;
+        for (int i = 7; i >= 0; --i) if (u[i] != v[i]) { ge = u[i] > v[i]; break; }
+        if (ge) { sub_into(u, v); sub_mod(x1, x2); } else { sub_into(v, u); sub_mod(x2, x1); }
+    }
+    Fr t;                                         // = (a R)^-1 as an integer = a^-1 R^-1
+    const u32* res = is_one(u) ? x1 : x2;
+    for (int i = 0; i < 8; ++i) t.v[i] = res[i];
+    return Fr::mul(Fr::mul(t, Fr::r2()), Fr::r2());   // two Montgomery products by R^2: a^-1 R^-1 -> a^-1 -> a^-1 R
+}
+
 // canonical 256-bit integers on 8 x 32-bit limbs (what gnark hands a hint as *big.Int)
 struct U256L {
     u32 l[8];
@@ -103,7 +147,7 @@ ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known) {
             val = Fr::sub(Fr::mul(v[0], v[1]), v[2]);                     // O_known + c x = L R
             if (uc == Fr::one()) {}
             else if (Fr::neg(uc) == Fr::one()) val = Fr::neg(val);
-            else val = Fr::mul(val, Fr::inv(uc));
+            else val = Fr::mul(val, fr_inverse(uc));
         } else {
             const Fr& other = v[1 - which];
             if (other.is_zero()) return SE_DIV_ZERO;                      // gnark: "division by zero" — the wire is not determined
@@ -112,7 +156,7 @@ ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known) {
             if (uc == Fr::one()) {}
             else if (Fr::neg(uc) == Fr::one()) den = Fr::neg(den);
             else den = Fr::mul(den, uc);
-            val = Fr::mul(num, Fr::inv(den));
+            val = Fr::mul(num, fr_inverse(den));
         }
         w[x] = val;
         known[x] = 1;
@@ -160,7 +204,7 @@ ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known) {
     }
     case HK_INVZERO: {                                                     // 1 / in[0], or 0
         if (n_in != 1 || n_out != 1) return SE_HINT_FAILED;
-        w[outw[0]] = Fr::inv(in[0]);
+        w[outw[0]] = fr_inverse(in[0]);
         break;
     }
     case HK_DECOMPOSE: {                                                   // in = (varSize, limbSize, value) -> limbs of limbSize bits, little-endian
