@@ -51,7 +51,12 @@ def test_bench_line_small_domain():
     assert d["acceptance"]["accepted"] == d["acceptance"]["proofs"] == 4
     assert d["solver_budget"]["gpu_ms_per_proof"] == d["ms_per_step"]
     he = d["solver_budget"]["host_executor_measured"]
-    assert he["wire_vector_equals_builder"] is True and he["instructions_per_s"]["threads_1"] > 0 and he["hint_calls"] == 1500 * 5
+    assert he["wire_vector_equals_builder"] is True and he["instructions_per_s"]["threads_1"] > 0 and he["hint_calls"] == 6000 * 5
+    assert he["instructions_per_s_with_a_b_c"]["threads_1"] > 0
+    de = d["solver_budget"]["device_executor_measured"]     # the same program on the device (zkpor_solver_*), a wide and a deep shape
+    for shape in ("users_side_by_side", "users_chained"):
+        assert de[shape]["wire_vector_equals_builder"] is True and de[shape]["instructions_per_s"] > 0 and de[shape]["launches"] <= de[shape]["levels"]
+    assert de["users_side_by_side"]["launches"] == 12 and de["users_chained"]["levels"] > 4000 and de["users_chained"]["launches"] < 20
 
 
 def test_bench_other_tier_and_timed_only():
