@@ -95,12 +95,32 @@ def algorithmic_bytes_per_proof(log2, n_wires, n_commit):
     return msm + ntt + pointwise + commit
 
 
-def cpu_baseline(log2_sample, log2_full, commit_frac):
+def mixture_scalars(seed, n, fill_kind):
+    """host copy of the witness scalar mixture of zkpor_dev_fill_fr (csrc/api_core.hip k_fill_fr): the same proportions, numpy's generator"""
+    import numpy as np
+    import oracle as O
+    rng = np.random.default_rng(seed)
+    sel = rng.integers(0, 100, n)
+    cuts = {1: (25, 45, 50), 2: (35, 65, 70)}.get(fill_kind, (0, 0, 0))
+    canon = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    canon[:, 3] &= np.uint64(0x0fffffffffffffff)                  # < 2^252 < r: canonical
+    small = sel < cuts[2]
+    canon[small, 1:] = 0
+    canon[sel < cuts[1], 0] &= np.uint64(0xffff)
+    canon[sel < cuts[0], 0] &= np.uint64(1)
+    out = np.empty_like(canon)
+    O.lib().orc_fr_from_canon(O._p(np.ascontiguousarray(canon)), O._p(out), n)
+    return out
+
+
+def cpu_baseline(log2_sample, log2_full, commit_frac, fill_kind=1, mixture="25% {0,1}, 20% <2^16, 5% <2^64, 50% uniform"):
     """The CPU baseline, kind "port": oracle/cpubase.hpp — what groth16.Prove does after the solver, organised as gnark /
     gnark-crypto organise it (no-carry Montgomery on 4 x 64-bit limbs, signed-digit c = 16 Pippenger with extended-Jacobian
-    buckets split over (window, chunk) tasks, cache-blocked radix-2 FFT), on ALL host cores, at a bounded sample of the bench's
-    own shape (D = n_wires = 2^log2_sample, commitment n/4), scaled by the size ratio to 2^log2_full.  gnark itself cannot run
-    here (no Go toolchain); its published figure (62 s per proof INCLUDING the solver, 32 vCPU) is quoted as the anchor."""
+    buckets split over (window, chunk) tasks, zero digits skipped, cache-blocked radix-2 FFT), on ALL host cores, at a bounded sample of
+    the bench's own shape (D = n_wires = 2^log2_sample, commitment n/4), scaled by the size ratio to 2^log2_full.  Run twice: with the
+    witness scalar mixture of the GPU headline (`value`, beside the line's `value`) and with uniform scalars (`value_uniform_scalars`,
+    beside `value_uniform`).  gnark itself cannot run here (no Go toolchain); its published figure (62 s per proof INCLUDING the
+    solver, 32 vCPU) is quoted as the anchor."""
     import numpy as np
     import oracle as O
     cores, why = O.usable_cpus()       # the cgroup quota, not the logical CPU count: threads beyond it are only throttled
@@ -110,19 +130,24 @@ def cpu_baseline(log2_sample, log2_full, commit_frac):
     log2_sample = min(log2_sample, log2_full)
     n = 1 << log2_sample
     nc = max(1, int(n * commit_frac))
-    sc = O.fr_random(1, n)
     base = O.fr_random(2, 4096)
     p1 = np.tile(O.g1_from_scalars(base), (n // 4096 + 1, 1))[:n].copy()
     p2 = np.tile(O.g2_from_scalars(base[:1024]), (n // 1024 + 1, 1))[:n].copy()
-    a = O.fr_random(3, n); b = O.fr_random(4, n); c = O.fr_mul(a, b)
-    O.fast_prove_tail_work(10, p1, p2, sc, a[:1024].copy(), b[:1024].copy(), c[:1024].copy(), 256)   # thread pool, constants
-    fft_s, g1_s, g2_s, com_s = O.fast_prove_tail_work(log2_sample, p1, p2, sc, a, b, c, nc)
+    a0 = O.fr_random(3, n); b0 = O.fr_random(4, n); c0 = O.fr_mul(a0, b0)
+    O.fast_prove_tail_work(10, p1, p2, O.fr_random(1, 1024), a0[:1024].copy(), b0[:1024].copy(), c0[:1024].copy(), 256)   # thread pool, constants
+    runs = {}
+    for name, sc in (("witness", mixture_scalars(7, n, fill_kind)), ("uniform", O.fr_random(1, n))):
+        runs[name] = O.fast_prove_tail_work(log2_sample, p1, p2, sc, a0.copy(), b0.copy(), c0.copy(), nc)
+    fft_s, g1_s, g2_s, com_s = runs["witness"]
     dt = fft_s + g1_s + g2_s + com_s
+    dt_u = sum(runs["uniform"])
     scale = float(1 << (log2_full - log2_sample))
     return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cores, "cores_source": why, "kind": "port",
             "seconds_per_proof_scaled": dt * scale, "core_seconds_per_proof_scaled": dt * scale * cores,
+            "value_uniform_scalars": 1.0 / (dt_u * scale), "core_seconds_per_proof_scaled_uniform_scalars": dt_u * scale * cores,
             "sample": f"oracle/cpubase.hpp prove tail (computeH {fft_s:.2f}s + 4 G1 MultiExp {g1_s:.2f}s + G2 MultiExp {g2_s:.2f}s + "
-                      f"2 commitment MultiExp {com_s:.2f}s = {dt:.2f}s) at D=2^{log2_sample} on {cores} threads, uniform scalars, "
+                      f"2 commitment MultiExp {com_s:.2f}s = {dt:.2f}s) at D=2^{log2_sample} on {cores} threads with the witness scalar mixture of the "
+                      f"headline ({mixture}; Z.h over the computed h), {dt_u:.2f}s with uniform scalars, "
                       f"scaled x{int(scale)} to D=2^{log2_full}; anchor: the reference publishes 62 s per proof INCLUDING the solver on "
                       "32 vCPU for gnark = 1984 vCPU-seconds (docs/updated_proof_of_solvency_to_mitigate_dummy_user_attack.md:201)"}
 
@@ -1297,7 +1322,7 @@ def main():
                     out["r1cs_resident"] = {"value": None, "note": f"failed: {e}"}
             if not args.no_cpu_baseline:
                 try:
-                    out["cpu_baseline"] = cpu_baseline(args.cpu_log2, log2, 0.25)
+                    out["cpu_baseline"] = cpu_baseline(args.cpu_log2, log2, 0.25, cfg["fill_kind"], cfg["mixture"])
                 except Exception as e:  # the baseline is informational; never lose the GPU line over it
                     out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
             out["solver_budget"] = solver_budget(dt / args.steps * 1e3, os.cpu_count() or 1)
