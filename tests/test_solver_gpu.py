@@ -4,6 +4,7 @@ one thread per instruction, narrow levels = one workgroup stepping through a run
 result, pre-filled wires must be taken as they are, external hints must pause the run and resume it, and every failure mode of the
 reference solver must come back as an error."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -261,3 +262,90 @@ def test_prove_from_the_assigned_inputs_on_the_device(zk, n_inputs, n_cons):
             zk.prove_inputs(pk, r, s, S.w[:n_in], bad, ss)
     finally:
         zk2.close(); pk.close(); s.close(); r.close()
+
+
+def _commitment_circuit(users, challenge):
+    """U users with two 32-bit balances each: range checks (their 16-bit limbs are the COMMITTED wires), gnark's commitment placeholder hint
+    over (index, limbs...) returning `challenge`, then the log-derivative shape: one inverse wire 1 / (challenge - limb) per limb and a
+    running product that ties everything after the hint to the challenge.  Returns (builder, limb wire ids, hint instruction index)."""
+    rng = np.random.default_rng(91)
+    vals = [int(x) for x in rng.integers(1, 1 << 32, size=2 * users)]
+    b = SC.Builder([7, 11], vals)
+    base = b.n_public
+    limbs = []
+    for i in range(2 * users):
+        limbs += b.range_check(b.wire(base + i), 32, 16)
+    hint_at = len(b.instr)
+    (ch,) = b.hint("bsb22CommitmentComputePlaceholder", [b.const(0)] + [b.wire(l) for l in limbs], [challenge])
+    acc = b.mul(b.wire(ch), b.wire(ch))
+    for i, l in enumerate(limbs):
+        inv = b.inverse(b.sub(b.wire(ch), b.wire(l)))
+        if i % 8 == 0:
+            acc = b.mul(b.wire(acc), b.wire(inv))
+    b.is_zero(b.sub(b.wire(acc), b.wire(ch)))
+    return b, limbs, hint_at
+
+
+def test_groth16_prove_with_a_commitment_entirely_on_the_device(zk):
+    """What go/zkporgpu/solver.go ProveOnDevice does, step by step through the C ABI: inputs up, the solver program runs until gnark's BSB22
+    placeholder, the committed wires go from the device straight into zkpor_commit_dev, the challenge is hashed on the host
+    (host/bsb22_challenge.hpp — gnark's hash_to_field over the marshalled commitment), handed back, the run resumes; a, b, c are evaluated in
+    HBM and the prove tail follows.  Checked: the commitment and its knowledge proof against the synthetic key's trapdoor, the challenge
+    against an independent restatement, the whole wire vector against the builder's integers, a . b = c, and the proof in the exponent."""
+    import ctypes
+    import oracle as O
+    import trapdoor as T
+    from test_bsb22_challenge_cpu import fr_hash_py
+    users, seed, log2 = 300, 0x5A4B504F52, 13
+    b0, limbs, hint_at = _commitment_circuit(users, 0)            # pass 1: the committed values do not depend on the challenge
+    committed = SC.to_mont_limbs([b0.val[l] for l in limbs])
+    want_com, want_pok = T.expected_commitment(seed, committed)
+    be = np.zeros(64, np.uint8)
+    zk._ck(zk.lib.zkpor_g1_marshal(zkpor._p(want_com), zkpor._p(be)))
+    challenge = fr_hash_py(bytes(be), b"bsb22-commitment", 1)[0]  # independent restatement of the hint's output
+    b, limbs, hint_at = _commitment_circuit(users, challenge)     # pass 2: every wire value known to the builder
+    n_wires, n_cons = len(b.val), len(b.rows)
+    D = 1 << log2
+    assert n_cons <= D and len(limbs) == 4 * users
+    r, s = device_system(zk, b)
+    pk = zkpor.ProvingKey(zk)
+    bufs = [zk.alloc(32 * n) for n in (n_wires, D, D, D)]
+    d_in = zk.alloc(32 * (1 + len(limbs)))
+    vp = ctypes.c_void_p
+    try:
+        pk.synth(log2, n_wires, b.n_public, len(limbs), seed)
+        n_in = b.n_public + b.n_secret
+        host_w = np.zeros((n_wires, 4), np.uint64)
+        host_w[:n_in] = inputs_of(b)
+        bufs[0].upload(host_w)
+        paused = s.start_dev(bufs[0].ptr, n_in)
+        assert paused == hint_at
+        s.external_inputs_dev(paused, d_in.ptr, 1 + len(limbs))
+        got_in = d_in.download(np.uint64, (1 + len(limbs), 4))
+        assert np.array_equal(got_in[1:], committed) and not got_in[0].any()      # (index 0, the committed wires in order)
+        com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
+        zk._ck(zk.lib.zkpor_commit_dev(zk.h, pk.h, vp(d_in.ptr + 32), ctypes.c_size_t(len(limbs)), zkpor._p(com), zkpor._p(pok)))
+        assert np.array_equal(com, want_com) and np.array_equal(pok, want_pok)
+        host = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zkmerkle-proof-of-solvency_amd", "libzkpor_host.so"))
+        zk._ck(zk.lib.zkpor_g1_marshal(zkpor._p(com), zkpor._p(be)))
+        out = (ctypes.c_uint8 * 32)()
+        assert host.zkh_bsb22_challenge(bytes(be), None, ctypes.c_size_t(0), out) == 0
+        assert int.from_bytes(bytes(out), "big") == challenge
+        s.external_outputs(paused, SC.to_mont_limbs([int.from_bytes(bytes(out), "big")]))
+        assert s.resume_dev() == zkpor.NOT_PAUSED
+        w = bufs[0].download(np.uint64, (n_wires, 4))
+        assert np.array_equal(w, SC.to_mont_limbs(b.val))
+        r.eval_dev(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, D)
+        abc = [x.download(np.uint64, (D, 4)) for x in bufs[1:]]
+        assert np.array_equal(O.fr_mul(abc[0], abc[1]), abc[2]) and not abc[0][n_cons:].any()
+        rr = O.fr_random(171, 1)[0]; ss = O.fr_random(172, 1)[0]
+        proof = zk.prove_tail_dev(pk, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, rr, ss)
+        h = bufs[1].download(np.uint64, (D, 4))                   # prove_tail_dev leaves h in a, in the order of the key's Z
+        assert O.quotient_identity(log2, abc[0], abc[1], abc[2], h, O.fr_random(4243, 1)[0])
+        td = T.SynthKeyTrapdoor(seed, b.n_public, w, h[: D - 1])
+        assert td.check(proof, rr, ss) and not td.check(proof, ss, rr)
+    finally:
+        d_in.free()
+        for x in bufs:
+            x.free()
+        pk.close(); s.close(); r.close()
