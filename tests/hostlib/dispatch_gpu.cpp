@@ -5,6 +5,7 @@
 #include "../../zkmerkle-proof-of-solvency_amd/host/prover_host.hpp"
 #include "../../zkmerkle-proof-of-solvency_amd/host/r1cs_file.hpp"
 #include "../../zkmerkle-proof-of-solvency_amd/host/prove_batch.hpp"
+#include "../../zkmerkle-proof-of-solvency_amd/host/prove_on_device.hpp"
 #include "../../include/zkpor.h"
 #include <atomic>
 #include <cstring>
@@ -116,6 +117,34 @@ long prove_batch_row(void* ctx_h, void* pk_h, const char* column, size_t column_
     if (raw_seen.size() > 512) return -100;
     memcpy(raw_out, raw_seen.data(), raw_seen.size());
     *raw_len = raw_seen.size();
+    std::string line = std::string(ProofCsvHeader()) + ProofCsvLine(row);
+    if (line.size() > cap) return -101;
+    memcpy(out, line.data(), line.size());
+    return (long)line.size();
+}
+// a1 end to end WITHOUT a host solver (host/prove_on_device.hpp): a witness-table row -> decode -> assign -> the inputs cross PCIe -> the solver
+// program, the BSB22 commitment, a / b / c and the prove tail on the device -> raw proof -> proof-table row as a CSV line.  For the test the
+// solved wire vector and h are copied back as well (w_out: n_wires x 4, h_out: domain x 4; NULL = not wanted).
+long prove_row_on_device(void* ctx_h, void* pk_h, void* r1cs_h, void* solver_h, const char* column, size_t column_len, int64_t batch, const uint64_t* r,
+                         const uint64_t* s, int fail_verify, char* out, size_t cap, int* tier, uint8_t* raw_out, size_t* raw_len, uint8_t* proof256,
+                         uint8_t* challenge32, uint64_t* w_out, uint64_t* h_out, char* err, size_t err_len) {
+    zkpor_ctx* ctx = (zkpor_ctx*)ctx_h;
+    DeviceProofBuffers bufs;
+    std::string raw_seen;
+    VerifyOnDeviceFn verify = [&](const std::string& raw, const BatchCreateUserWitnessW&) -> int { raw_seen = raw; return fail_verify ? 1 : 0; };
+    ProofRow row;
+    DeviceProof p;
+    std::string why;
+    int rc = GenerateAndVerifyProofOnDevice(ctx, (zkpor_pk*)pk_h, (zkpor_r1cs*)r1cs_h, (zkpor_solver*)solver_h, &bufs, std::string(column, column_len), batch,
+                                            {50, 500}, r, s, verify, &row, tier, &p, &why);
+    if (rc != POD_OK) { snprintf(err, err_len, "%s", why.c_str()); return -rc; }
+    if (raw_seen.size() > 512) return -100;
+    memcpy(raw_out, raw_seen.data(), raw_seen.size());
+    *raw_len = raw_seen.size();
+    memcpy(proof256, p.proof, 256);
+    memcpy(challenge32, p.challenge, 32);
+    if (w_out && zkpor_dev_download(ctx, w_out, bufs.w, bufs.n_wires * 32) != ZKPOR_OK) return -102;
+    if (h_out && zkpor_dev_download(ctx, h_out, bufs.abc[0], bufs.domain * 32) != ZKPOR_OK) return -102;   // prove_tail_dev leaves h in a
     std::string line = std::string(ProofCsvHeader()) + ProofCsvLine(row);
     if (line.size() > cap) return -101;
     memcpy(out, line.data(), line.size());
