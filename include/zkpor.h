@@ -437,6 +437,9 @@ int32_t zkpor_witgen_gather_dev(zkpor_ctx* ctx, const void* d_table, size_t tabl
 int32_t zkpor_witgen_divmod_small_dev(zkpor_ctx* ctx, const void* d_values, size_t n, uint32_t divisor, void* d_quotient, void* d_remainder);
 /* d_w[d_wire_ids[i]] = d_src[i], i < n */
 int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, const uint32_t* d_wire_ids, size_t n);
+/* the same, and d_known[d_wire_ids[i]] = 1: the generator's wires are handed to the solver program as already assigned (the d_known of
+ * zkpor_solver_start_dev; n_wires bytes, cleared by the caller before the first scatter of a proof) */
+int32_t zkpor_witgen_scatter_known_dev(zkpor_ctx* ctx, void* d_w, uint8_t* d_known, const void* d_src, const uint32_t* d_wire_ids, size_t n);
 
 /* ---- the solver program on the device (the generic half) --------------------------------------------------------
  * r1cs.Solve inside groth16.Prove (src/prover/prover/prover.go:269; gnark constraint/bn254/solver.go, 3P) walks the compiled system's

@@ -104,6 +104,39 @@ def test_prefilled_wires_and_skipped_instructions(zk):
         s.close(); r.close()
 
 
+def test_generator_wires_are_handed_over_on_the_device(zk):
+    """the device form of the hand-over: a generator's slots are scattered onto their wire ids AND marked assigned in one pass
+    (zkpor_witgen_scatter_known_dev), the solver program then starts with those flags (d_known) — nothing of it touches the host"""
+    b = SC.demo_circuit(17, 60, chain=False)
+    wires = b.wires_of_tag("sbox")
+    r, s = device_system(zk, b, solver=b.solver_bytes(skip_tags=("sbox",)))
+    n_wires = len(b.val)
+    n_in = b.n_public + b.n_secret
+    d_w = zk.alloc(32 * n_wires); d_known = zk.alloc(n_wires)
+    d_src = zk.alloc(32 * len(wires)); d_ids = zk.alloc(4 * len(wires))
+    try:
+        host_w = np.zeros((n_wires, 4), np.uint64)
+        host_w[:n_in] = inputs_of(b)
+        d_w.upload(host_w)
+        d_known.upload(np.zeros(n_wires, np.uint8))
+        order = np.random.default_rng(3).permutation(len(wires))                          # slots in any order
+        d_src.upload(SC.to_mont_limbs([b.val[wires[i]] for i in order]))
+        d_ids.upload(np.array([wires[i] for i in order], dtype=np.uint32))
+        zk.witgen_scatter_known_dev(d_w.ptr, d_known.ptr, d_src.ptr, d_ids.ptr, len(wires))
+        assert s.start_dev(d_w.ptr, n_in, d_known.ptr) == zkpor.NOT_PAUSED
+        assert np.array_equal(d_w.download(np.uint64, (n_wires, 4)), SC.to_mont_limbs(b.val))
+        known = d_known.download(np.uint8, (n_wires,))
+        assert known.all()                                                                # inputs, generator wires and solved wires alike
+        d_known.upload(np.zeros(n_wires, np.uint8))                                       # without the hand-over the program cannot finish
+        d_w.upload(host_w)
+        with pytest.raises(zkpor.ZkporError):
+            s.start_dev(d_w.ptr, n_in, d_known.ptr)
+    finally:
+        for x in (d_w, d_known, d_src, d_ids):
+            x.free()
+        s.close(); r.close()
+
+
 def test_external_hints_pause_and_resume(zk):
     """a hint without a native implementation (gnark's BSB22 commitment placeholder in the real circuit) stops the run in front of it: the caller
     reads the evaluated inputs, provides the outputs and resumes — two of them in one level, a third one later, wires in between depend on them"""

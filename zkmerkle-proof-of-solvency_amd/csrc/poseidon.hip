@@ -653,6 +653,13 @@ __global__ __launch_bounds__(256) void k_witgen_scatter(Fr* __restrict__ w, cons
     if (i < n) w[wire_ids[i]] = src[i];
 }
 
+// the same, and the wires are marked assigned for the solver program that runs next (zkpor_solver_start_dev's d_known)
+__global__ __launch_bounds__(256) void k_witgen_scatter_known(Fr* __restrict__ w, uint8_t* __restrict__ known, const Fr* __restrict__ src,
+                                                              const u32* __restrict__ wire_ids, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) { const u32 id = wire_ids[i]; w[id] = src[i]; known[id] = 1; }
+}
+
 struct AccountHdr {
     uint8_t id_be[32];
     u64 equity[2], debt[2], collateral[2];
@@ -1209,6 +1216,16 @@ int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, c
     if (n == 0) return ZKPOR_OK;
     PhaseScope ps(ctx, "witgen_scatter");
     hipLaunchKernelGGL(k_witgen_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_w, (const Fr*)d_src, d_wire_ids, n);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
+
+int32_t zkpor_witgen_scatter_known_dev(zkpor_ctx* ctx, void* d_w, uint8_t* d_known, const void* d_src, const uint32_t* d_wire_ids, size_t n) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || ((!d_w || !d_known || !d_src || !d_wire_ids) && n)) return ZKPOR_E_ARG;
+    if (n == 0) return ZKPOR_OK;
+    PhaseScope ps(ctx, "witgen_scatter");
+    hipLaunchKernelGGL(k_witgen_scatter_known, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_w, d_known, (const Fr*)d_src, d_wire_ids, n);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

@@ -220,6 +220,9 @@ class Context:
     def witgen_scatter_dev(self, d_w, d_src, d_wire_ids, n):
         self._ck(self.lib.zkpor_witgen_scatter_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_src), ctypes.c_void_p(d_wire_ids), ctypes.c_size_t(n)))
 
+    def witgen_scatter_known_dev(self, d_w, d_known, d_src, d_wire_ids, n):
+        self._ck(self.lib.zkpor_witgen_scatter_known_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_known), ctypes.c_void_p(d_src), ctypes.c_void_p(d_wire_ids), ctypes.c_size_t(n)))
+
     # ---- MSM ----
     def msm_g1(self, points, scalars):
         points = _u64(points); scalars = _u64(scalars)
