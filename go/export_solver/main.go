@@ -1,6 +1,6 @@
 // export_solver: one-off exporter of the SOLVER PROGRAM of a compiled gnark constraint system — what r1cs.Solve walks inside
-// groth16.Prove (src/prover/prover/prover.go:269) — to the flat container zkmerkle-proof-of-solvency_amd/host/solver_exec.hpp executes
-// on all host threads (SURVEY.md §8 f4).  Companion of export_r1cs (the matrices).  NOT COMPILED in the authoring image (no Go
+// groth16.Prove (src/prover/prover/prover.go:269) — to the flat container (host/solver_file.hpp) that csrc/solver.hip executes ON THE
+// DEVICE (zkpor_solver_*) and host/solver_exec.hpp on all host threads (SURVEY.md §8 f4).  Companion of export_r1cs (the matrices).  NOT COMPILED in the authoring image (no Go
 // toolchain; written against bnb-chain/gnark v0.10.1-0.20240910145009-4b5261061f04, go.mod:57) — go/README.md.
 //
 //	go run ./export_solver zkpor50_1380.r1cs zkpor50_1380.zksolv
@@ -22,9 +22,9 @@
 //	u32 callData[]: per hint  nameId, nIn, nOut, outWire[nOut], then per input  nTerms, (coeffId, wireId)[nTerms]
 //
 // Hint names are the registered function names (solver.GetHintName), e.g. "…/circuit.IntegerDivision", "…/std/math/bits.nBits",
-// "…/constraint/solver.InvZeroHint", "…/std/rangecheck.DecomposeHint", "…/frontend/cs.Bsb22CommitmentComputePlaceholder"; the executor
-// binds its native implementations by the LAST path element (host/solver_exec.hpp HintRegistry) and refuses a program that calls a hint it
-// does not implement.  The wire families a device generator produces are marked with -skip (a file of instruction ids, one per line, written
+// "…/constraint/solver.InvZeroHint", "…/std/rangecheck.DecomposeHint", "…/frontend/cs.Bsb22CommitmentComputePlaceholder"; the executors
+// bind their native implementations by the LAST path element (csrc/solver_instr.cuh hint_kind_of_name, host/solver_exec.hpp HintRegistry).  A hint
+// without one — the BSB22 placeholder — pauses the device run for the caller to serve (zkpor_solver_external_*); the host executor refuses it.  The wire families a device generator produces are marked with -skip (a file of instruction ids, one per line, written
 // by the wire-map tool from the same compiled system); without it everything runs on the host.
 package main
 
