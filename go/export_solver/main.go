@@ -24,7 +24,8 @@
 // Hint names are the registered function names (solver.GetHintName), e.g. "…/circuit.IntegerDivision", "…/std/math/bits.nBits",
 // "…/constraint/solver.InvZeroHint", "…/std/rangecheck.DecomposeHint", "…/frontend/cs.Bsb22CommitmentComputePlaceholder"; the executors
 // bind their native implementations by the LAST path element (csrc/solver_instr.cuh hint_kind_of_name, host/solver_exec.hpp HintRegistry).  A hint
-// without one — the BSB22 placeholder — pauses the device run for the caller to serve (zkpor_solver_external_*); the host executor refuses it.  The wire families a device generator produces are marked with -skip (a file of instruction ids, one per line, written
+// without one — the BSB22 placeholder — pauses the device run for the caller to serve (zkpor_solver_external_*); the host executor takes it as a closure the caller
+// registers under that name (HintRegistry.by_name).  The wire families a device generator produces are marked with -skip (a file of instruction ids, one per line, written
 // by the wire-map tool from the same compiled system); without it everything runs on the host.
 package main
 
