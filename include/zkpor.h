@@ -336,6 +336,10 @@ int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r1cs, int which, const uint64_t* row_p
 /* device buffers: w (n_wires Fr) in; a, b, c (domain_size Fr each) out, rows >= n_constraints written as zero (the
  * padding zkpor_compute_h_dev / zkpor_prove_tail_dev expect); asynchronous on the context's stream */
 int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r1cs, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size);
+/* the solver's final check on the device: counts[0] = constraints with L.w * R.w != O.w for the wire vector d_w, counts[1] = the lowest
+ * such row (2^64 - 1 when none).  What gnark's solver guarantees by construction has to be CHECKED when wires come from elsewhere (the
+ * structured generators): a skipped instruction's constraint is only ever seen here.  Synchronous. */
+int32_t zkpor_r1cs_check_dev(zkpor_r1cs* r1cs, const void* d_w, uint64_t counts[2]);
 /* host buffers: a, b, c receive n_constraints elements each */
 int32_t zkpor_r1cs_eval(zkpor_r1cs* r1cs, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c);
 

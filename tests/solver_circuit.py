@@ -250,3 +250,59 @@ def demo_circuit(seed=1, n_users=6, chain=True):
             b.assert_mul(nxt, b.const(1), nxt, "tail")
     b.assert_mul(acc, b.const(1), acc, "tail")
     return b
+
+
+def poseidon_gadget(b, state, rp, rc, mds, record):
+    """the in-circuit Poseidon permutation over len(state) lanes (plain HADES as oracle/poseidon.hpp poseidon_permute: round constants, S-box
+    x^5 on every lane in the 4 + 4 full rounds and on lane 0 in the rp partial ones, MDS): three multiplication wires per S-box (x^2, x^4,
+    x^5, tagged "sbox"), everything else linear.  `record` receives (input state values, [wire ids of the S-boxes in round order, 3 each]) —
+    the slot order of zkpor_witgen_poseidon_trace_dev.  Returns the output state as linear expressions."""
+    t = len(state)
+    inputs = [b.eval(e) for e in state]
+    wires = []
+    k = 0
+    for r in range(8 + rp):
+        state = [b.add(state[i], b.const(rc[k + i])) for i in range(t)]
+        k += t
+        for i in (range(t) if (r < 4 or r >= 4 + rp) else [0]):
+            x = state[i]
+            x2 = b.mul(x, x, "sbox"); x4 = b.mul(b.wire(x2), b.wire(x2), "sbox"); x5 = b.mul(b.wire(x4), x, "sbox")
+            wires += [x2, x4, x5]
+            state[i] = b.wire(x5)
+        state = [b.add(*[b.scale(state[j], mds[i * t + j]) for j in range(t)]) for i in range(t)]
+    record.append((inputs, wires))
+    return state
+
+
+def poseidon_circuit(params, seed=1, paths=3, depth=4, wide=2):
+    """`paths` Merkle paths of `depth` width-3 hashes each (the leaf and the siblings are secret inputs, the root is asserted against a public
+    input: a chain of permutations — deep) and `wide` independent width-13 permutations of secret inputs (one block of the account sponge),
+    their lane-1 outputs asserted against public inputs.  params = {t: (rp, rc ints, mds ints)} (oracle.poseidon_params).  Returns
+    (builder, {t: [(input state values, sbox wire ids)]}): the public inputs ARE the expected outputs, computed with the gadget's own values —
+    the caller checks them against the oracle's permutation."""
+    rng = np.random.default_rng(seed)
+    rnd = lambda: int.from_bytes(rng.bytes(32), "big") % R
+    leaves = [rnd() for _ in range(paths)]
+    sibs = [[rnd() for _ in range(depth)] for _ in range(paths)]
+    blocks = [[rnd() for _ in range(12)] for _ in range(wide)]
+    # pass 1 with placeholder public inputs to learn the outputs, pass 2 with them in place (the builder computes every value as it goes)
+    pub = [0] * (paths + wide)
+    for _ in range(2):
+        b = Builder(pub, leaves + [s for p in sibs for s in p] + [x for blk in blocks for x in blk])
+        base = b.n_public
+        rec = {3: [], 13: []}
+        outs = []
+        for p in range(paths):
+            cur = b.wire(base + p)
+            for d in range(depth):
+                sib = b.wire(base + paths + p * depth + d)
+                st = poseidon_gadget(b, [b.const(0), cur, sib] if (leaves[p] >> d) & 1 else [b.const(0), sib, cur], *params[3], rec[3])
+                cur = st[1]
+            outs.append(cur)
+        for w in range(wide):
+            st = poseidon_gadget(b, [b.const(0)] + [b.wire(base + paths + paths * depth + 12 * w + i) for i in range(12)], *params[13], rec[13])
+            outs.append(st[1])
+        for i, o in enumerate(outs):
+            b.assert_mul(o, b.const(1), b.wire(1 + i), "root")
+        pub = [b.eval(o) for o in outs]
+    return b, rec

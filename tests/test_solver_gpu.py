@@ -382,3 +382,57 @@ def test_groth16_prove_with_a_commitment_entirely_on_the_device(zk):
         for x in bufs:
             x.free()
         pk.close(); s.close(); r.close()
+
+
+def test_poseidon_generator_feeds_the_solver_program_on_the_device(zk):
+    """f4 (c) + (d) together, with the real Poseidon parameters: the in-circuit gadget's S-box wires (Merkle paths of width-3 hashes, width-13 sponge
+    blocks) come from the device generator (zkpor_witgen_poseidon_trace_dev), are scattered onto their wire ids and marked assigned
+    (zkpor_witgen_scatter_known_dev), and the solver program — their instructions skipped — runs on what is left: the root / output assertions.
+    The wire vector equals the builder's; a corrupted generator slot makes the program fail."""
+    import oracle as O
+    params = {}
+    for t in (3, 13):
+        rp, rc, mds = O.poseidon_params(t)
+        params[t] = (rp, O.fr_to_ints(rc), O.fr_to_ints(mds))
+    b, rec = SC.poseidon_circuit(params, seed=5, paths=6, depth=5, wide=3)
+    r, s = device_system(zk, b, solver=b.solver_bytes(skip_tags=("sbox",)))
+    n_wires, n_in = len(b.val), b.n_public + b.n_secret
+    d_w = zk.alloc(32 * n_wires); d_known = zk.alloc(n_wires)
+    held = []
+    try:
+        host_w = np.zeros((n_wires, 4), np.uint64)
+        host_w[:n_in] = inputs_of(b)
+
+        def generate(corrupt=False):
+            d_w.upload(host_w)
+            d_known.upload(np.zeros(n_wires, np.uint8))
+            for t, perms in rec.items():
+                n = len(perms)
+                ns = zk.witgen_poseidon_sboxes(t)
+                states = SC.to_mont_limbs([v for inputs, _ in perms for v in inputs])
+                ids = np.zeros(3 * ns * n, np.uint32)
+                for i, (_, wires) in enumerate(perms):
+                    ids[np.arange(3 * ns) * n + i] = wires                    # slot (s * 3 + c) of permutation i -> its wire
+                d_st = zk.alloc(states.nbytes).upload(states); d_tr = zk.alloc(3 * ns * n * 32); d_ids = zk.alloc(ids.nbytes).upload(ids)
+                held.extend([d_st, d_tr, d_ids])
+                zk.witgen_poseidon_trace_dev(t, d_st.ptr, n, d_tr.ptr)
+                if corrupt and t == 3:
+                    tr = d_tr.download(np.uint64, (3 * ns * n, 4)); tr[11, 0] ^= np.uint64(1); d_tr.upload(tr)
+                zk.witgen_scatter_known_dev(d_w.ptr, d_known.ptr, d_tr.ptr, d_ids.ptr, 3 * ns * n)
+
+        generate()
+        assert s.start_dev(d_w.ptr, n_in, d_known.ptr) == zkpor.NOT_PAUSED
+        assert np.array_equal(d_w.download(np.uint64, (n_wires, 4)), SC.to_mont_limbs(b.val))
+        assert s.dims()["skipped"] == sum(len(w) for perms in rec.values() for _, w in perms)
+        assert r.check_dev(d_w.ptr) == (0, None)                                   # the final check of every constraint, on the device
+        # a corrupted generator slot (row 11 of the trace = slot 0 of permutation 11: x^2 of its first S-box): the skipped instruction's
+        # constraint is seen by nobody but the final check
+        generate(corrupt=True)
+        assert s.start_dev(d_w.ptr, n_in, d_known.ptr) == zkpor.NOT_PAUSED
+        n_bad, first = r.check_dev(d_w.ptr)
+        bad_wire = rec[3][11][1][0]
+        assert n_bad >= 1 and first == next(i for i, row in enumerate(b.rows) if row[2] == [(b.cid(1), bad_wire)])
+    finally:
+        for x in held + [d_w, d_known]:
+            x.free()
+        s.close(); r.close()

@@ -38,6 +38,28 @@ __global__ __launch_bounds__(256) void k_r1cs_eval(R1csDev M, const Fr* __restri
     out[row] = acc;
 }
 
+// the final check of a solved wire vector: L.w * R.w = O.w on every row; out[0] = rows that fail, out[1] = the lowest failing row
+__global__ __launch_bounds__(256) void k_r1cs_check(R1csDev M, const Fr* __restrict__ w, size_t n_constraints, unsigned long long* out) {
+    const size_t row = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (row >= n_constraints) return;
+    Fr v[3];
+    for (int m = 0; m < 3; ++m) {
+        Fr acc = Fr::zero();
+        const uint64_t t0 = M.row_ptr[m][row], t1 = M.row_ptr[m][row + 1];
+        for (uint64_t t = t0; t < t1; ++t) {
+            const u32 ci = M.cid[m][t];
+            const uint8_t kind = M.kind[ci];
+            if (kind == 3) continue;
+            const Fr x = w[M.wid[m][t]];
+            if (kind == 1) acc = Fr::add(acc, x);
+            else if (kind == 2) acc = Fr::sub(acc, x);
+            else acc = Fr::add(acc, Fr::mul(M.coeff[ci], x));
+        }
+        v[m] = acc;
+    }
+    if (Fr::mul(v[0], v[1]) != v[2]) { atomicAdd(&out[0], 1ull); atomicMin(&out[1], (unsigned long long)row); }
+}
+
 static void r1cs_free(zkpor_r1cs* r) {
     if (r->coeff) (void)hipFree(r->coeff);
     if (r->coeff_kind) (void)hipFree(r->coeff_kind);
@@ -130,6 +152,29 @@ int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b
     ZK_ENTER(r ? r->ctx->device : -1);
     if (!r) return ZKPOR_E_ARG;
     return zk::r1cs_eval_on(r->ctx, r, d_w, d_a, d_b, d_c, domain_size);
+}
+/* every constraint against a wire vector on the device: counts[0] = rows with L.w * R.w != O.w, counts[1] = the lowest such row */
+int32_t zkpor_r1cs_check_dev(zkpor_r1cs* r, const void* d_w, uint64_t counts[2]) {
+    ZK_ENTER(r ? r->ctx->device : -1);
+    if (!r || !d_w || !counts) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = r->ctx;
+    for (int m = 0; m < 3; ++m) if (!r->row_ptr[m]) { ctx->err = "r1cs: matrix " + std::to_string(m) + " not loaded"; return ZKPOR_E_STATE; }
+    counts[0] = 0; counts[1] = ~0ull;
+    if (r->n_constraints == 0) return ZKPOR_OK;
+    unsigned long long* d_out = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&d_out, 16));
+    int32_t rc = ZKPOR_OK;
+    R1csDev M;
+    M.coeff = r->coeff; M.kind = r->coeff_kind;
+    for (int m = 0; m < 3; ++m) { M.row_ptr[m] = r->row_ptr[m]; M.cid[m] = r->cid[m]; M.wid[m] = r->wid[m]; }
+    if (hipMemcpyAsync(d_out, counts, 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "r1cs: H2D failed"; rc = ZKPOR_E_HIP; }
+    if (rc == ZKPOR_OK) {
+        hipLaunchKernelGGL(k_r1cs_check, dim3((unsigned)((r->n_constraints + 255) / 256)), dim3(256), 0, ctx->stream, M, (const Fr*)d_w, r->n_constraints, d_out);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(counts, d_out, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "r1cs: check failed to launch"; rc = ZKPOR_E_HIP; }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_out);
+    return rc;
 }
 /* host-buffer form for tests and small circuits: w in, a/b/c (n_constraints each) out */
 int32_t zkpor_r1cs_eval(zkpor_r1cs* r, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c) {

@@ -761,6 +761,12 @@ class R1CS:
         self.ctx._ck(self.ctx.lib.zkpor_r1cs_eval(self.h, _p(w), _p(a), _p(b), _p(c)))
         return a, b, c
 
+    def check_dev(self, d_w):
+        """(number of constraints that do not hold for the wire vector on the device, lowest failing row or None)"""
+        c = (ctypes.c_uint64 * 2)()
+        self.ctx._ck(self.ctx.lib.zkpor_r1cs_check_dev(self.h, ctypes.c_void_p(d_w), c))
+        return int(c[0]), (int(c[1]) if c[0] else None)
+
     def eval_dev(self, d_w, d_a, d_b, d_c, domain_size):
         self.ctx._ck(self.ctx.lib.zkpor_r1cs_eval_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c), ctypes.c_size_t(domain_size)))
 
