@@ -207,3 +207,34 @@ def test_quotients_of_a_level_share_one_inversion_and_zero_denominators_are_erro
     b.inverse(b.wire(base + 41))                       # 1 / 0
     rc, *_x, err = solve(b, threads=3)
     assert rc != 0 and "division by zero" in err
+
+
+def test_hint_shape_words_are_checked_before_they_size_anything():
+    """the nIn / nOut / nTerms words of a hint's call data come from a file: a container whose words promise more than the call data holds must be
+    refused with an error (found by tools/fuzz_solver_exec.cpp: such a word used to size a vector — 120 GB asked for), and mutated containers in
+    general must end in an error or a solved vector"""
+    import struct
+    b = SC.demo_circuit(6, 3)
+    sv = bytearray(b.solver_bytes())
+    # locate the call data: it is the tail of the container
+    n_cd = len(b.calldata)
+    cd_off = len(sv) - 4 * n_cd
+    first_hint = next(a for k, a, _, _ in b.instr if k == 1)
+    for word, value in ((1, 0xFFFFFFFF), (2, 0xFFFFFFFF), (1, n_cd), (2, n_cd - 2)):
+        m = bytearray(sv)
+        struct.pack_into("<I", m, cd_off + 4 * (first_hint + word), value)
+        rc, *_x, err = solve(b, solver=bytes(m))
+        assert rc != 0 and "solver" in err
+    # nTerms of the first input promises more terms than the call data holds
+    n_out = b.calldata[first_hint + 2]
+    m = bytearray(sv)
+    struct.pack_into("<I", m, cd_off + 4 * (first_hint + 3 + n_out), 0x7FFFFFFF)
+    rc, *_x, err = solve(b, solver=bytes(m))
+    assert rc != 0
+    rng = np.random.default_rng(4)
+    for _ in range(300):
+        m = bytearray(sv)
+        for _k in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(cd_off - 8 * len(b.instr), len(m)))      # instruction table and call data: what passes the parser
+            m[pos] = int(rng.integers(0, 256))
+        solve(b, solver=bytes(m), threads=2)                                 # any outcome but a crash

@@ -255,11 +255,15 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
         if (arg + 3 > s.n_calldata) return 20;
         const uint32_t name = cd[0], n_in = cd[1], n_out = cd[2];
         if (name >= fn.size() || !fn[name]) return 21;
-        size_t p = 3 + n_out;
+        // the shape words come from a file: they are checked against the call data's length before anything is sized or read by them
+        const uint64_t room = s.n_calldata - arg - 3;
+        if (n_out > room || n_in > room - n_out) return 20;     // every input takes at least its term count
+        size_t p = 3 + (size_t)n_out;
         sc.in.resize(n_in); sc.o.resize(n_out);
         for (uint32_t i = 0; i < n_in; ++i) {
             if (arg + p >= s.n_calldata) return 20;
             const uint32_t nterms = cd[p++];
+            if (2ull * nterms > s.n_calldata - arg - p) return 20;
             FrH acc = FrH::zero();
             for (uint32_t k = 0; k < nterms; ++k) {
                 const uint32_t cid = cd[p++], wid = cd[p++];
