@@ -229,6 +229,43 @@ def host_executor_leg(threads):
                     "divisions of a level (inverse wires, IsZero hints) share one field inversion per thread, coefficients 1 / -1 cost an addition"}
 
 
+def host_row_leg(users, tier, gpu_proofs_per_s):
+    """What is left on the HOST per proof once the solver program is resident on the device (host/prove_on_device.hpp): the witness-table row of
+    one full batch (synthetic, the reference's encoding: base64(s2(gob))) decoded (utils.DecodeBatchWitness, utils.go:704-742), assigned to the
+    circuit's input vector (SetBatchCreateUserCircuitWitness, batch_create_user_circuit.go:334-436) and converted to Montgomery form — timed on one
+    thread; the upload is the boundary leg's business.  No device, no oracle."""
+    import numpy as np
+    lib = ctypes.CDLL(os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd", "libzkpor_host.so"))
+    lib.zkh_witness_synth_encode.restype = ctypes.c_long
+    lib.zkh_witness_assign.restype = ctypes.c_long
+    cex = 500
+    assets = tier if tier <= 50 else 500
+    buf = ctypes.create_string_buffer(1 << 28)
+    n = lib.zkh_witness_synth_encode(ctypes.c_uint64(5), users, assets, cex, 1, 2, buf, ctypes.c_size_t(1 << 28))
+    if n <= 0:
+        raise RuntimeError("witness row synthesis failed")
+    column = buf.raw[:n]
+    cap = 1 + 5 + 114 * cex + users * (7 * (50 if assets <= 50 else 500) + 5 * cex + 30)
+    vals = np.zeros((cap, 4), np.uint64); mont = np.zeros_like(vals)
+    counts = (ctypes.c_uint64 * 3)(); err = ctypes.create_string_buffer(256)
+    tiers = (ctypes.c_int * 2)(50, 500)
+    t_assign = t_mont = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got = lib.zkh_witness_assign(column, ctypes.c_size_t(len(column)), tiers, 2, vals.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cap), counts, err, ctypes.c_size_t(256))
+        t1 = time.perf_counter()
+        lib.zkh_fr_from_canon(vals.ctypes.data_as(ctypes.c_void_p), mont.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cap))
+        t2 = time.perf_counter()
+        if got != cap:
+            raise RuntimeError(f"assignment returned {got} values, expected {cap}: {err.value.decode()}")
+        t_assign = min(t_assign, t1 - t0); t_mont = min(t_mont, t2 - t1)
+    per_proof = t_assign + t_mont
+    return {"users_per_batch": users, "row_bytes": n, "input_values": cap, "decode_and_assign_s": t_assign, "to_montgomery_s": t_mont,
+            "host_core_seconds_per_proof": per_proof, "host_cores_per_gpu_at_this_rate": per_proof * gpu_proofs_per_s,
+            "note": "one thread; a GPU proving at `value` proofs/s needs this many host cores for the rows it consumes (8 GPUs: 8x), next to the upload of "
+                    f"{cap * 32 / 1e6:.0f} MB of inputs per proof instead of w, a, b, c ({(1 << 26) * 4 * 32 / 1e9:.1f} GB)"}
+
+
 _DEMO = {}
 
 
@@ -1331,6 +1368,10 @@ def main():
                     out["solver_budget"]["host_executor_measured"] = host_executor_leg(usable_cpus())
                 except Exception as e:
                     out["solver_budget"]["host_executor_measured"] = {"note": f"failed: {e}"}
+                try:
+                    out["solver_budget"]["host_row_measured"] = host_row_leg(cfg["users"], cfg["assets"], world * args.steps / dt)
+                except Exception as e:
+                    out["solver_budget"]["host_row_measured"] = {"note": f"failed: {e}"}
                 try:
                     out["solver_budget"]["device_executor_measured"] = device_executor_leg(ctx)
                 except Exception as e:

@@ -54,6 +54,8 @@ def test_bench_line_small_domain():
     he = d["solver_budget"]["host_executor_measured"]
     assert he["wire_vector_equals_builder"] is True and he["instructions_per_s"]["threads_1"] > 0 and he["hint_calls"] == 6000 * 5
     assert he["instructions_per_s_with_a_b_c"]["threads_1"] > 0
+    hr = d["solver_budget"]["host_row_measured"]       # what stays on the host per proof with the solver program on the device
+    assert hr["input_values"] == 1 + 5 + 114 * 500 + 1380 * (7 * 50 + 5 * 500 + 30) and hr["host_core_seconds_per_proof"] > 0 and hr["host_cores_per_gpu_at_this_rate"] > 0
     de = d["solver_budget"]["device_executor_measured"]     # the same program on the device (zkpor_solver_*), a wide and a deep shape
     for shape in ("users_side_by_side", "users_chained"):
         assert de[shape]["wire_vector_equals_builder"] is True and de[shape]["instructions_per_s"] > 0 and de[shape]["launches"] <= de[shape]["levels"]
