@@ -640,26 +640,40 @@ inline Bytes Decode(const Bytes& in) {
 }  // namespace s2
 
 inline Bytes base64_std_decode(const std::string& in) {
-    auto val = [](char c) -> int {
-        if (c >= 'A' && c <= 'Z') return c - 'A';
-        if (c >= 'a' && c <= 'z') return c - 'a' + 26;
-        if (c >= '0' && c <= '9') return c - '0' + 52;
-        if (c == '+') return 62;
-        if (c == '/') return 63;
-        return -1;
-    };
-    if (in.size() % 4) throw std::runtime_error("base64: length is not a multiple of 4");
-    Bytes out;
-    for (size_t i = 0; i < in.size(); i += 4) {
-        int pad = (in[i + 2] == '=') + (in[i + 3] == '=');
-        if (pad && i + 4 != in.size()) throw std::runtime_error("base64: padding inside the data");
-        if (in[i + 2] == '=' && in[i + 3] != '=') throw std::runtime_error("base64: bad padding");
-        int v[4];
-        for (int k = 0; k < 4; ++k) { v[k] = (k >= 4 - pad) ? 0 : val(in[i + k]); if (v[k] < 0) throw std::runtime_error("base64: bad character"); }
-        uint32_t w = (uint32_t)v[0] << 18 | (uint32_t)v[1] << 12 | (uint32_t)v[2] << 6 | (uint32_t)v[3];
-        out.push_back((char)(uint8_t)(w >> 16));
-        if (pad < 2) out.push_back((char)(uint8_t)(w >> 8));
-        if (pad < 1) out.push_back((char)(uint8_t)w);
+    // one table lookup per character and a sized output: a 5 MB witness column decodes in a few milliseconds
+    static const std::array<int8_t, 256> T = [] {
+        std::array<int8_t, 256> t;
+        t.fill(-1);
+        for (int i = 0; i < 26; ++i) { t['A' + i] = (int8_t)i; t['a' + i] = (int8_t)(26 + i); }
+        for (int i = 0; i < 10; ++i) t['0' + i] = (int8_t)(52 + i);
+        t[(unsigned char)'+'] = 62; t[(unsigned char)'/'] = 63;
+        return t;
+    }();
+    const size_t n = in.size();
+    if (n % 4) throw std::runtime_error("base64: length is not a multiple of 4");
+    if (n == 0) return Bytes();
+    const unsigned char* p = (const unsigned char*)in.data();
+    const int pad = (p[n - 2] == '=') + (p[n - 1] == '=');
+    if (p[n - 2] == '=' && p[n - 1] != '=') throw std::runtime_error("base64: bad padding");
+    Bytes out(n / 4 * 3 - (size_t)pad, '\0');
+    char* o = &out[0];
+    const size_t full = n - (pad ? 4 : 0);                      // quads without padding
+    for (size_t i = 0; i < full; i += 4) {
+        const int a = T[p[i]], b = T[p[i + 1]], c = T[p[i + 2]], d = T[p[i + 3]];
+        if ((a | b | c | d) < 0) {
+            if (p[i] == '=' || p[i + 1] == '=' || p[i + 2] == '=' || p[i + 3] == '=') throw std::runtime_error("base64: padding inside the data");
+            throw std::runtime_error("base64: bad character");
+        }
+        const uint32_t w = (uint32_t)a << 18 | (uint32_t)b << 12 | (uint32_t)c << 6 | (uint32_t)d;
+        *o++ = (char)(uint8_t)(w >> 16); *o++ = (char)(uint8_t)(w >> 8); *o++ = (char)(uint8_t)w;
+    }
+    if (pad) {
+        const size_t i = n - 4;
+        const int a = T[p[i]], b = T[p[i + 1]], c = pad == 2 ? 0 : T[p[i + 2]];
+        if ((a | b | c) < 0) throw std::runtime_error("base64: bad character");
+        const uint32_t w = (uint32_t)a << 18 | (uint32_t)b << 12 | (uint32_t)c << 6;
+        *o++ = (char)(uint8_t)(w >> 16);
+        if (pad < 2) *o++ = (char)(uint8_t)(w >> 8);
     }
     return out;
 }
