@@ -13,7 +13,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); runs through the C ABI of libzkpor.so")
     # a fresh checkout has no built artefacts (they are git-ignored): build them once (hipcc cross-compiles without a GPU)
     lib = os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd", "libzkpor.so")
-    drivers = [os.path.join(ROOT, "tests", "hostlib", n) for n in ("tree_driver", "witness_driver", "libhostmath.so", "libsolverlogic.so")]
+    drivers = [os.path.join(ROOT, "tests", "hostlib", n) for n in ("tree_driver", "witness_driver", "libhostmath.so", "libsolverlogic.so", "libdispatch_gpu.so")]
     if not os.path.exists(lib) or not all(os.path.exists(d) for d in drivers):
         import __graft_entry__
         __graft_entry__.build()

@@ -193,3 +193,26 @@ def test_damaged_rows_are_refused_not_crashed_on(host):
         feed(base64.b64encode(G.s2_literal_block(evil)))
     feed(base64.b64encode(bytes([0xff, 0xff, 0xff, 0xff, 0x0f, 0x00]) + b"x"))      # s2 block claiming 4 GiB
     assert outcomes["error"] > 500 and outcomes["ok"] + outcomes["error"] == 1504
+
+
+def test_device_path_of_generate_and_verify_proof_refuses_a_bad_row_before_any_gpu_work():
+    """host/prove_on_device.hpp GenerateAndVerifyProofOnDevice: a row that does not decode ends in stage 1 (decode) — checked here without a GPU,
+    with null handles: nothing of the device path may have been touched when the row is bad"""
+    import ctypes
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = ctypes.CDLL(os.path.join(root, "tests", "hostlib", "libdispatch_gpu.so"))
+    host = ctypes.CDLL(os.path.join(root, "zkmerkle-proof-of-solvency_amd", "libzkpor_host.so"))
+    host.zkh_witness_synth_encode.restype = ctypes.c_long
+    buf = ctypes.create_string_buffer(1 << 22)
+    n = host.zkh_witness_synth_encode(ctypes.c_uint64(3), 2, 3, 500, 1, 2, buf, ctypes.c_size_t(1 << 22))
+    assert n > 0
+    column = buf.raw[:n]
+    drv.prove_row_on_device.restype = ctypes.c_long
+    r = (ctypes.c_uint64 * 4)(1, 0, 0, 0); s = (ctypes.c_uint64 * 4)(2, 0, 0, 0)
+    for bad in (column[: (len(column) // 2) & ~3], b"!!!!" + column[4:], column[:-3]):
+        err = ctypes.create_string_buffer(256)
+        rc = drv.prove_row_on_device(None, None, None, None, bad, ctypes.c_size_t(len(bad)), ctypes.c_int64(1), r, s, 0, ctypes.create_string_buffer(64), ctypes.c_size_t(64),
+                                     ctypes.byref(ctypes.c_int()), (ctypes.c_uint8 * 512)(), ctypes.byref(ctypes.c_size_t()), (ctypes.c_uint8 * 256)(), (ctypes.c_uint8 * 32)(),
+                                     None, None, err, ctypes.c_size_t(256))
+        assert rc == -1 and err.value.startswith(b"decode:")
