@@ -154,11 +154,13 @@ def test_external_hints_pause_and_resume(zk):
     b.is_zero(b.sub(b.wire(y), b.wire(y)))
     e3_in = [b.wire(y), b.wire(o1[1])]
     o3 = b.hint("AnotherHintOfTheCaller", e3_in, list(ext([b.eval(e) for e in e3_in])))
-    b.inverse(b.add(b.wire(o3[0]), b.const(1)))
+    inv = b.inverse(b.add(b.wire(o3[0]), b.const(1)))
+    e4_in = [b.wire(inv), b.const(5)]
+    b.hint("AnotherHintOfTheCaller", e4_in, list(ext([b.eval(e) for e in e4_in])))      # an external hint in the LAST level of the program
     r, s = device_system(zk, b)
     d_w = zk.alloc(len(b.val) * 32)
     try:
-        assert s.dims()["external_levels"] == 2
+        assert s.dims()["external_levels"] == 3
         with pytest.raises(zkpor.ZkporError):        # the host-buffer form does not serve external hints
             s.run(inputs_of(b))
         host_w = np.zeros((len(b.val), 4), np.uint64)
@@ -182,8 +184,8 @@ def test_external_hints_pause_and_resume(zk):
             s.external_outputs(paused, SC.to_mont_limbs(list(ext(ints))))
             served.append((paused, ints))
             paused = s.resume_dev()
-        assert len(served) == 3 and served[0][0] < served[1][0]
-        assert served[0][1] == [b.eval(e) for e in e1_in] and served[1][1] == [b.eval(e) for e in e2_in] and served[2][1] == [b.eval(e) for e in e3_in]
+        assert len(served) == 4 and served[0][0] < served[1][0]
+        assert [x[1] for x in served] == [[b.eval(e) for e in ins] for ins in (e1_in, e2_in, e3_in, e4_in)]
         w = d_w.download(np.uint64, (len(b.val), 4))
         assert np.array_equal(w, SC.to_mont_limbs(b.val))
         with pytest.raises(zkpor.ZkporError):        # nothing left to resume

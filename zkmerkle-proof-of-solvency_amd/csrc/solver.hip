@@ -173,6 +173,8 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
     }
     const bool finished = s->next_level >= v.n_levels;
     if (finished) {
+        // counted afresh every time the end is reached: a run that paused in its LAST level has been here before, with the hint's outputs still open
+        ZK_HIP(ctx, hipMemsetAsync(s->d_err + 2, 0, sizeof(u32), ctx->stream));
         hipLaunchKernelGGL(k_count_unknown, dim3((unsigned)((s->r1cs->n_wires + 255) / 256)), dim3(256), 0, ctx->stream, s->known, s->r1cs->n_wires, s->d_err);
         ZK_KERNEL_CHECK(ctx);
     }
