@@ -455,7 +455,10 @@ int32_t zkpor_witgen_scatter_known_dev(zkpor_ctx* ctx, void* d_w, uint8_t* d_kno
  * The wire vector never leaves the device: wires the structured generators (zkpor_witgen_*) produced are passed in as already known,
  * and the result feeds zkpor_r1cs_eval_dev / zkpor_commit_dev / zkpor_prove_tail_dev. */
 typedef struct zkpor_solver zkpor_solver;
-/* `r1cs` (all three matrices loaded) must outlive the solver; the container is copied and validated (ZKPOR_E_ARG) */
+/* `r1cs` (all three matrices loaded) must outlive the solver; the container is copied and validated (ZKPOR_E_ARG).
+ * THREADING: a solver's launches, phase timers and error text belong to the context its R1CS was created on — solvers of one R1CS
+ * context must not RUN concurrently from several threads (the matrices themselves are only read: zkpor_r1cs_eval_dev on any context of
+ * the GPU is fine).  A prover with two workers per GPU serialises its solver runs or gives each worker's context its own zkpor_r1cs. */
 int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* solver_container, size_t len, zkpor_solver** out);
 void zkpor_solver_destroy(zkpor_solver* solver);
 /* dims = {instructions, levels, constraint instructions, hint instructions, skipped instructions, levels holding an external hint,
