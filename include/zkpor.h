@@ -85,7 +85,13 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * "copy_threads" (how pageable host memory crosses PCIe in the host-pointer entry points: 0, the default, hands the range to the HIP
  * runtime, which page-locks it on the fly and lets the DMA engine read the caller's pages — 56 GB/s measured; n > 0 copies through
  * pinned bounce buffers with n host threads — 30 GB/s, for hosts where page-locking on the fly is not available),
- * "msm_reduce_scan" (1, the default: the small levels of the G1 bucket reduction run one lane per bucket; 0: the serial walk),
+ * "msm_chunk" 0 = automatic (64 from 2^22 scalars up, else 32), otherwise 4..4096 (below 4 the partial-sum recursion does not shrink),
+ * "msm_tail_chunk" (8, the default: entries per thread of the partial-sum levels below 2^21 entries — their duration is one thread's
+ * chain of additions; 0 = "msm_chunk" everywhere; 4..64),
+ * "msm_reduce_scan" (1, the default: the small levels of the bucket reduction run one lane — G2: one lane pair — per bucket; 2: G1
+ * only; 0: the serial walk),
+ * "msm_filter" (1, the default: B1 / B2 and K accumulate from the witness digit stream minus the entries of their absent points),
+ * "ntt_fuse" (1, the default: computeH's neighbouring passes over one index field run as one kernel),
  * "gpu_token" (1, the default: host-pointer proofs of several contexts on one GPU take turns on the device, see zkpor_prove_tail;
  * 0: their kernels share it freely), "host_order" (0, the default: a proof that finds the GPU free sends w first and a, b, c
  * underneath its own witness sums; 1: always everything first),
@@ -93,7 +99,8 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);
 /* per-phase GPU time in ms accumulated since the last reset (HIP events on the context's stream).
  * names: "msm_decompose","msm_sort","msm_accumulate","msm_reduce","k_acc_level1_g1","k_acc_level1_g2" (the
- * bucket-accumulation kernel alone, one launch per call),"ntt","pointwise","poseidon_leaf","poseidon_tree";
+ * bucket-accumulation kernel alone, one launch per call),"msm_filter","ntt","pointwise","poseidon_leaf","poseidon_tree","r1cs_eval",
+ * "solver_levels","witgen_scatter";
  * unknown names return 0.  calls = number of timed regions. */
 double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls);
 void zkpor_phase_reset(zkpor_ctx* ctx);
