@@ -279,3 +279,96 @@ int zkh_solve(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* solv, size_t 
     return 0;
 }
 }
+
+// ---- the circuit compiler (host/circuit/*.hpp): BatchCreateUserCircuit.Define restated, compiled to matrices + solver program ----
+#include "circuit/synth_batch.hpp"
+extern "C" {
+struct zkc_circuit {
+    zkpor_circuit::Compiled c;
+    zkpor_circuit::CircuitShape shape;
+    std::vector<uint8_t> solver_container;
+    std::string census_json;
+};
+static void zkc_put_err(char* err, size_t err_len, const std::string& why) { if (err && err_len) snprintf(err, err_len, "%s", why.c_str()); }
+// inputs_mont (may be NULL = compile only): n_public - 1 + n_secret Montgomery elements — then the compile also INTERPRETS the circuit
+// (every wire's value, every assertion checked; an assertion that fails is an error).  commitment_mont (may be NULL): the value of the
+// BSB22 commitment wire in that interpretation.  poseidon_native 0: gnark's own form (three constraint instructions per S-box).
+zkc_circuit* zkc_compile_batch_create_user(uint32_t user_assets, uint32_t all_assets, uint32_t users, const uint64_t* inputs_mont,
+                                           const uint64_t* commitment_mont, int poseidon_native, char* err, size_t err_len) {
+    try {
+        auto* z = new zkc_circuit();
+        z->shape.userAssetCounts = user_assets; z->shape.allAssetCounts = all_assets; z->shape.batchCounts = users;
+        if (user_assets == 0 || users == 0 || user_assets > all_assets) { delete z; zkc_put_err(err, err_len, "bad shape"); return nullptr; }
+        zkpor_circuit::Builder b(z->shape.n_public(), z->shape.n_secret(), (const FrH*)inputs_mont, poseidon_native != 0);
+        if (commitment_mont) { FrH v; memcpy(v.v, commitment_mont, 32); b.set_commitment_value(v); }
+        zkpor_circuit::DefineBatchCreateUser(b, z->shape);
+        z->c = b.finish();
+        z->solver_container = zkpor_circuit::SolverContainer(z->c);
+        std::string j = "{";
+        for (auto& kv : z->c.census) { if (j.size() > 1) j += ", "; j += "\"" + kv.first + "\": " + std::to_string(kv.second); }
+        z->census_json = j + "}";
+        return z;
+    } catch (const std::exception& e) { zkc_put_err(err, err_len, e.what()); return nullptr; }
+}
+void zkc_free(zkc_circuit* z) { delete z; }
+// dims: n_wires, n_public, n_secret, n_constraints, n_coeff, nnzL, nnzR, nnzO, n_instructions, n_levels, n_calldata, n_committed, commitment wire,
+// wires without an L term, wires without an R term, solver container bytes
+void zkc_dims(const zkc_circuit* z, uint64_t dims[16]) {
+    const auto& c = z->c;
+    uint64_t no_l = 0, no_r = 0;
+    for (uint8_t f : c.in_l) no_l += !f;
+    for (uint8_t f : c.in_r) no_r += !f;
+    const uint64_t d[16] = {c.n_wires, c.n_public, c.n_secret, c.n_constraints, c.coeff.size(), c.cid[0].size(), c.cid[1].size(), c.cid[2].size(),
+                            c.kind.size(), c.level_ptr.size() - 1, c.calldata.size(), c.committed.size(), c.commitment_wire, no_l, no_r, z->solver_container.size()};
+    memcpy(dims, d, sizeof d);
+}
+const uint64_t* zkc_coeff(const zkc_circuit* z) { return (const uint64_t*)z->c.coeff.data(); }
+const uint64_t* zkc_row_ptr(const zkc_circuit* z, int m) { return z->c.row_ptr[m].data(); }
+const uint32_t* zkc_cid(const zkc_circuit* z, int m) { return z->c.cid[m].data(); }
+const uint32_t* zkc_wid(const zkc_circuit* z, int m) { return z->c.wid[m].data(); }
+const uint32_t* zkc_committed(const zkc_circuit* z) { return z->c.committed.data(); }
+const uint8_t* zkc_in_l(const zkc_circuit* z) { return z->c.in_l.data(); }
+const uint8_t* zkc_in_r(const zkc_circuit* z) { return z->c.in_r.data(); }
+const uint64_t* zkc_values(const zkc_circuit* z) { return z->c.values.empty() ? nullptr : (const uint64_t*)z->c.values.data(); }
+const uint8_t* zkc_solver_container(const zkc_circuit* z) { return z->solver_container.data(); }
+const uint64_t* zkc_level_ptr(const zkc_circuit* z) { return z->c.level_ptr.data(); }
+const char* zkc_census(const zkc_circuit* z) { return z->census_json.c_str(); }
+// a valid synthetic batch of that shape (host/circuit/synth_batch.hpp): the assignment in Montgomery form (out: n_public - 1 + n_secret
+// elements); returns the element count, or -1
+long zkc_synth_inputs(uint32_t user_assets, uint32_t all_assets, uint32_t users, uint64_t seed, uint32_t first_index, uint64_t* out, size_t cap, char* err, size_t err_len) {
+    try {
+        zkpor_circuit::CircuitShape S; S.userAssetCounts = user_assets; S.allAssetCounts = all_assets; S.batchCounts = users;
+        const auto w = zkpor_circuit::SynthBatchWitness(S, seed, first_index);
+        const std::vector<FrH> a = zkpor_circuit::AssignMont(w, user_assets);
+        if (a.size() != S.n_public() - 1 + S.n_secret()) { zkc_put_err(err, err_len, "assignment length differs from the circuit's input count"); return -1; }
+        if (a.size() > cap) { zkc_put_err(err, err_len, "buffer too small"); return -1; }
+        memcpy(out, a.data(), a.size() * 32);
+        return (long)a.size();
+    } catch (const std::exception& e) { zkc_put_err(err, err_len, e.what()); return -1; }
+}
+// the compiled program on the host executor (host/solver_exec.hpp) — commitment_mont: what the BSB22 placeholder returns.
+// w_out: n_wires x 4.  0 = ok.
+int zkc_solve_host(const zkc_circuit* z, const uint64_t* inputs_mont, const uint64_t* commitment_mont, int threads, uint64_t* w_out, int check_rows,
+                   char* err, size_t err_len) {
+    const auto& c = z->c;
+    R1csFileView rv;
+    rv.n_constraints = c.n_constraints; rv.n_wires = c.n_wires; rv.n_public = c.n_public; rv.n_secret = c.n_secret; rv.n_coeff = c.coeff.size();
+    rv.coeff = (const uint64_t*)c.coeff.data();
+    for (int m = 0; m < 3; ++m) { rv.nnz[m] = c.cid[m].size(); rv.row_ptr[m] = c.row_ptr[m].data(); rv.coeff_ids[m] = c.cid[m].data(); rv.wire_ids[m] = c.wid[m].data(); }
+    SolverView sv;
+    std::string why;
+    if (ParseSolverFile(z->solver_container.data(), z->solver_container.size(), &sv, &why) != 0) { zkc_put_err(err, err_len, why); return 1; }
+    HintRegistry reg = HintRegistry::Standard();
+    FrH cm; memcpy(cm.v, commitment_mont, 32);
+    reg.by_name["bsb22CommitmentComputePlaceholder"] = [cm](const std::vector<FrH>&, std::vector<FrH>& out) { if (out.size() != 1) return 1; out[0] = cm; return 0; };
+    std::vector<uint64_t> in(4 * (c.n_public + c.n_secret));
+    const FrH one = FrH::one();
+    memcpy(in.data(), one.v, 32);
+    memcpy(in.data() + 4, inputs_mont, 32 * (c.n_public + c.n_secret - 1));
+    SolveResult res;
+    int rc = SolveLevelized(rv, sv, in.data(), c.n_public + c.n_secret, reg, {}, threads, &res, &why, check_rows != 0);
+    if (rc != 0) { zkc_put_err(err, err_len, why); return rc; }
+    memcpy(w_out, res.w.data(), res.w.size() * 8);
+    return 0;
+}
+}

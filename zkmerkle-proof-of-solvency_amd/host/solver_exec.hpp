@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "fr_host.hpp"
+#include "poseidon_host.hpp"
 #include "r1cs_file.hpp"
 #include "solver_file.hpp"
 
@@ -71,6 +72,29 @@ struct HintRegistry {
             const int limb = (int)ls.w[0];
             if ((int)out.size() * limb < v.bitlen()) return 3;   // the value does not fit the requested limbs: the range check must fail
             for (size_t i = 0; i < out.size(); ++i) out[i] = FrH::from_u64(v.bits((int)i * limb, limb));
+            return 0;
+        };
+        // gnark std/internal/logderivarg countHint (behind every range check and lookup table): in = (nbTable, nbCols, the table's rows,
+        // the queries' rows) -> per table row how many queries equal it; a query that matches no row fails the hint
+        r.by_name["countHint"] = [](const std::vector<FrH>& in, std::vector<FrH>& out) {
+            if (in.size() < 2) return 1;
+            const U256 nt = U256::of(in[0]), nc = U256::of(in[1]);
+            if ((nt.w[1] | nt.w[2] | nt.w[3] | nc.w[1] | nc.w[2] | nc.w[3]) || nc.w[0] == 0 || nt.w[0] != out.size()) return 2;
+            const size_t nb_table = nt.w[0], nb_col = nc.w[0];
+            if (in.size() < 2 + nb_table * nb_col || (in.size() - 2 - nb_table * nb_col) % nb_col) return 3;
+            const size_t nb_q = (in.size() - 2 - nb_table * nb_col) / nb_col;
+            std::map<std::vector<uint64_t>, size_t> row_of;
+            std::vector<uint64_t> key(4 * nb_col);
+            auto key_at = [&](size_t base) { for (size_t c = 0; c < nb_col; ++c) memcpy(&key[4 * c], in[base + c].v, 32); };
+            for (size_t i = 0; i < nb_table; ++i) { key_at(2 + i * nb_col); row_of.emplace(key, i); }   // the first of equal rows counts (gnark: map by row bytes)
+            std::vector<uint64_t> cnt(nb_table, 0);
+            for (size_t q = 0; q < nb_q; ++q) {
+                key_at(2 + (nb_table + q) * nb_col);
+                auto it = row_of.find(key);
+                if (it == row_of.end()) return 4;                                                      // "query element not in table"
+                ++cnt[it->second];
+            }
+            for (size_t i = 0; i < nb_table; ++i) out[i] = FrH::from_u64(cnt[i]);
             return 0;
         };
         // gnark registers its hints under their Go function names; the exporter keeps the last path element
@@ -215,8 +239,48 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
 
     struct Scratch { std::vector<detail::Quotient> q; std::vector<FrH> prod, in, o; uint64_t cnt[3] = {0, 0, 0}; };
     auto run_instr = [&](uint32_t ins, Scratch& sc) -> int {
-        const uint32_t kind = s.kind[ins], arg = s.arg[ins];
-        if (kind >= INSTR_SKIP) { ++sc.cnt[2]; return 0; }
+        const uint32_t kind = InstrKind(s, ins), arg = s.arg[ins];
+        if (kind == INSTR_SKIP) { ++sc.cnt[2]; return 0; }
+        auto eval_le = [&](const uint32_t* cd, uint64_t& p, FrH* out) -> int {   // nTerms, (coeffId, wireId)...; shapes were checked up front
+            const uint32_t nterms = cd[p++];
+            FrH acc = FrH::zero();
+            for (uint32_t k = 0; k < nterms; ++k) {
+                const uint32_t cid = cd[p++], wid = cd[p++];
+                if (!known[wid]) return 23;
+                detail::add_term(acc, cls[cid], r, cid, w[wid]);
+            }
+            *out = acc;
+            return 0;
+        };
+        if (kind == INSTR_LOOKUP) {              // outputs = entry[index] (gnark BlueprintLookupHint.Solve)
+            if (!CheckLookupShape(s, arg, nw, r.n_coeff)) return 20;
+            const uint32_t* cd = s.calldata + arg;
+            const uint32_t* tb = s.calldata + cd[0];
+            uint64_t p = 4;
+            for (uint32_t q = 0; q < cd[2]; ++q) {
+                FrH ix;
+                if (int rc = eval_le(cd, p, &ix)) return rc;
+                const U256 i = U256::of(ix);
+                if ((i.w[1] | i.w[2] | i.w[3]) || i.w[0] >= cd[1]) return 24;   // "lookup query too large"
+                uint64_t pe = tb[1 + i.w[0]];
+                FrH v;
+                if (int rc = eval_le(tb, pe, &v)) return rc;
+                w[cd[3] + q] = v; known[cd[3] + q] = 1;
+            }
+            ++sc.cnt[1];
+            return 0;
+        }
+        if (kind == INSTR_POSEIDON) {            // the whole sponge: every S-box's three product wires
+            if (!CheckPoseidonShape(s, arg, nw, r.n_coeff)) return 20;
+            const uint32_t* cd = s.calldata + arg;
+            sc.in.resize(cd[0]); sc.o.resize(cd[2]);
+            uint64_t p = 4;
+            for (uint32_t i = 0; i < cd[0]; ++i) if (int rc = eval_le(cd, p, &sc.in[i])) return rc;
+            PosSponge(sc.in.data(), cd[0], sc.o.data(), (int)(cd[3] & 0xff), (int)((cd[3] >> 8) & 0xff));
+            for (uint32_t i = 0; i < cd[2]; ++i) { w[cd[1] + i] = sc.o[i]; known[cd[1] + i] = 1; }
+            ++sc.cnt[1];
+            return 0;
+        }
         if (kind == INSTR_R1C) {
             if (arg >= nc) return 10;
             int64_t unk[3] = {-1, -1, -1};
@@ -243,7 +307,11 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
             }
             // (L_known + c x) R = O  =>  x = (O - L_known R) / (c R)
             const FrH& other = v[1 - which];
-            if (other.is_zero()) return 14;                      // gnark: "division by zero" — the wire is not determined
+            if (other.is_zero()) {                               // gnark solveR1C: nothing to divide by — the constraint must already hold
+                if (!v[2].is_zero()) return 12;                  // (L_known + c x) * 0 = O needs O = 0 ...
+                w[x] = FrH::zero(); known[x] = 1;                // ... and then the wire is left at 0: api.DivUnchecked(0, 0) = 0
+                return 0;
+            }
             FrH num = FrH::sub(v[2], FrH::mul(v[which], other));
             if (c_one) sc.q.push_back({x, num, other});
             else if (c_mone) sc.q.push_back({x, FrH::neg(num), other});

@@ -6,10 +6,18 @@
 // Container "ZKPSOLV\x01" (little-endian):
 //   u64 nInstructions, nLevels, nHintNames, nCallData
 //   hint names: per name u32 length + bytes, then padding to 8
-//   u32 kind[nInstructions]            0 = solve constraint `arg`; 1 = hint with call data at `arg`; 2 = same as 0/1 but skipped (pre-filled)
+//   u32 kind[nInstructions]            0 = solve constraint `arg`; 1 = hint with call data at `arg`; 2 = same as 0/1 but skipped (pre-filled);
+//                                      version 2 ("ZKPSOLV\x02") adds the two gadget instructions a gadget-aware export emits:
+//                                      3 = table lookup (gnark BlueprintLookupHint), 4 = a whole poseidon.Poseidon(...) call
 //   u32 arg[nInstructions]
 //   u64 levelPtr[nLevels + 1]; u32 levelInstr[levelPtr[nLevels]]; pad to 8
 //   u32 callData[nCallData]: per hint  nameId, nIn, nOut, out wire ids[nOut], then per input: nTerms, (coeffId, wireId)[nTerms]
+//     kind 3 (lookup):   blockOff, nbEntries, nQ, firstOutWire, then nQ index expressions; outputs = wires firstOutWire .. +nQ-1 =
+//                        entry[index].  Entry block at blockOff (shared by all lookups of one table, gnark stores it once per blueprint):
+//                        nEntries, entryOff[nEntries] (word offsets from blockOff), the entry expressions; nbEntries <= nEntries
+//     kind 4 (poseidon): nIn, firstOutWire, nOutWires, flags (bits 0-7 digest lane, 8-15 carry lane, bit 16 = ASYNC: the outputs are read
+//                        by the last level only), then nIn input expressions; outputs = the three product wires (x^2, x^4, x^5) of
+//                        every S-box of the sponge over the inputs, permutation after permutation in round order
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -20,6 +28,7 @@ namespace zkpor_host {
 
 struct SolverView {
     uint64_t n_instructions = 0, n_levels = 0, n_calldata = 0;
+    int version = 1;
     std::vector<std::string> hint_names;
     const uint32_t* kind = nullptr;
     const uint32_t* arg = nullptr;
@@ -27,13 +36,69 @@ struct SolverView {
     const uint32_t* level_instr = nullptr;
     const uint32_t* calldata = nullptr;
 };
-enum { INSTR_R1C = 0, INSTR_HINT = 1, INSTR_SKIP = 2 };
+enum { INSTR_R1C = 0, INSTR_HINT = 1, INSTR_SKIP = 2, INSTR_LOOKUP = 3, INSTR_POSEIDON = 4 };
+enum : uint32_t { POSEIDON_ASYNC = 1u << 16 };
+
+// shape checks of the two gadget instructions against the call data (both executors call this before they trust an offset).
+// A version-1 stream's kind 3 is the old "skipped" alias: callers map it to INSTR_SKIP.
+inline bool CheckLookupShape(const SolverView& v, uint64_t arg, uint64_t n_wires, uint64_t n_coeff) {
+    if (arg + 4 > v.n_calldata) return false;
+    const uint32_t* cd = v.calldata + arg;
+    const uint64_t block = cd[0], nb = cd[1], nq = cd[2], first = cd[3];
+    if (block + 1 > v.n_calldata) return false;
+    const uint32_t* tb = v.calldata + block;
+    const uint64_t ne = tb[0];
+    if (nb == 0 || nb > ne || block + 1 + ne > v.n_calldata || first + nq > n_wires) return false;
+    for (uint64_t i = 0; i < nb; ++i) {
+        const uint64_t o = block + tb[1 + i];
+        if (o >= v.n_calldata) return false;
+        const uint64_t nt = v.calldata[o];
+        if (o + 1 + 2 * nt > v.n_calldata) return false;
+        for (uint64_t t = 0; t < nt; ++t) if (v.calldata[o + 1 + 2 * t] >= n_coeff || v.calldata[o + 2 + 2 * t] >= n_wires) return false;
+    }
+    uint64_t p = arg + 4;
+    for (uint64_t i = 0; i < nq; ++i) {
+        if (p >= v.n_calldata) return false;
+        const uint64_t nt = v.calldata[p++];
+        if (p + 2 * nt > v.n_calldata) return false;
+        for (uint64_t t = 0; t < nt; ++t) if (v.calldata[p + 2 * t] >= n_coeff || v.calldata[p + 1 + 2 * t] >= n_wires) return false;
+        p += 2 * nt;
+    }
+    return true;
+}
+inline uint64_t PoseidonSboxCount(uint64_t n_in) {   // S-boxes of the sponge over n_in inputs (blocks of 12 + one ragged block)
+    static const int rp[] = {56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65};
+    const uint64_t full = n_in / 12, rem = n_in % 12;
+    return full * (8 * 13 + 65) + (rem ? 8 * (rem + 1) + rp[rem + 1 - 2] : 0);
+}
+inline bool CheckPoseidonShape(const SolverView& v, uint64_t arg, uint64_t n_wires, uint64_t n_coeff) {
+    if (arg + 4 > v.n_calldata) return false;
+    const uint32_t* cd = v.calldata + arg;
+    const uint64_t n_in = cd[0], first = cd[1], n_out = cd[2];
+    const uint32_t flags = cd[3];
+    if (n_in == 0 || n_out != 3 * PoseidonSboxCount(n_in) || first + n_out > n_wires) return false;
+    const uint32_t last_t = (uint32_t)(n_in % 12 ? n_in % 12 + 1 : 13);
+    if ((flags & 0xff) >= last_t || (n_in > 12 && ((flags >> 8) & 0xff) >= 13u)) return false;   // digest lane of the last block, carry lane of the full ones
+    uint64_t p = arg + 4;
+    for (uint64_t i = 0; i < n_in; ++i) {
+        if (p >= v.n_calldata) return false;
+        const uint64_t nt = v.calldata[p++];
+        if (p + 2 * nt > v.n_calldata) return false;
+        for (uint64_t t = 0; t < nt; ++t) if (v.calldata[p + 2 * t] >= n_coeff || v.calldata[p + 1 + 2 * t] >= n_wires) return false;
+        p += 2 * nt;
+    }
+    return true;
+}
+
+// the kind an executor acts on: a version-1 stream used 3 as a second spelling of "skipped"
+inline uint32_t InstrKind(const SolverView& v, uint64_t i) { const uint32_t k = v.kind[i]; return (v.version == 1 && k == 3) ? (uint32_t)INSTR_SKIP : k; }
 
 inline int ParseSolverFile(const uint8_t* data, size_t len, SolverView* out, std::string* err) {
     auto fail = [&](const char* m) { if (err) *err = std::string("solver file: ") + m; return 1; };
     size_t off = 0;
     auto need = [&](uint64_t n) { return n <= len && off <= len - n; };
-    if (!data || !need(8) || memcmp(data, "ZKPSOLV\x01", 8) != 0) return fail("bad magic");
+    if (!data || !need(8) || memcmp(data, "ZKPSOLV", 7) != 0 || (data[7] != 1 && data[7] != 2)) return fail("bad magic");
+    const uint32_t max_kind = data[7] == 1 ? 3 : 4;
     off = 8;
     uint64_t h[4];
     if (!need(sizeof h)) return fail("truncated header");
@@ -63,7 +128,8 @@ inline int ParseSolverFile(const uint8_t* data, size_t len, SolverView* out, std
     off += (8 - off % 8) % 8;
     if (!take32(v.n_calldata, &v.calldata)) return fail("truncated call data");
     for (uint64_t i = 0; i < n_li; ++i) if (v.level_instr[i] >= v.n_instructions) return fail("level entry out of range");
-    for (uint64_t i = 0; i < v.n_instructions; ++i) if (v.kind[i] > 3) return fail("unknown instruction kind");
+    for (uint64_t i = 0; i < v.n_instructions; ++i) if (v.kind[i] > max_kind) return fail("unknown instruction kind");
+    v.version = data[7];
     *out = std::move(v);
     return 0;
 }
