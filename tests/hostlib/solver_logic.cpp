@@ -27,7 +27,9 @@ extern "C" int sl_run(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* solv,
     P.coeff = tab; P.ckind = ckind.data();
     for (int m = 0; m < 3; ++m) { P.row_ptr[m] = r.row_ptr[m]; P.cid[m] = r.coeff_ids[m]; P.wid[m] = r.wire_ids[m]; }
     P.n_constraints = (u32)r.n_constraints; P.n_wires = (u32)r.n_wires; P.n_coeff = (u32)r.n_coeff;
-    P.kind = s.kind; P.arg = s.arg; P.calldata = s.calldata; P.n_calldata = s.n_calldata;
+    std::vector<uint32_t> kinds(s.n_instructions);
+    for (uint64_t i = 0; i < s.n_instructions; ++i) kinds[i] = InstrKind(s, i);      // what csrc/solver.hip uploads
+    P.kind = kinds.data(); P.arg = s.arg; P.calldata = s.calldata; P.n_calldata = s.n_calldata;
     P.hint_kind = hk.data(); P.n_hint_names = (u32)hk.size();
     Fr* w = (Fr*)w_out;
     memset(w_out, 0, r.n_wires * 32);

@@ -133,6 +133,16 @@ __global__ __launch_bounds__(64) void k_synth_points(Affine<F> gen, Affine<F> qp
     }
 }
 
+// zero (= infinity) every point whose mask byte is set
+template <class P>
+__global__ __launch_bounds__(256) void k_mask_points(P* __restrict__ pts, const uint8_t* __restrict__ mask, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || !mask[i]) return;
+    P z;
+    memset(&z, 0, sizeof z);
+    pts[i] = z;
+}
+
 G1Affine g1_generator() {
     G1Affine g;
     g.x = Fp::from_u32(1);
@@ -463,6 +473,54 @@ int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_p
     ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_COMMIT_BASIS_SIGMA, n_committed, 0, 0, &pk->CBS));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // alpha, beta, delta: fixed small multiples of the generators (host)
+    pk->alpha = xyzz_to_affine<Fp>(xyzz_mul_u64<Fp>(g1x(g1), synth_k(seed, 100, 0)));
+    pk->beta = xyzz_to_affine<Fp>(xyzz_mul_u64<Fp>(g1x(g1), synth_k(seed, 101, 0)));
+    pk->delta = xyzz_to_affine<Fp>(xyzz_mul_u64<Fp>(g1x(g1), synth_k(seed, 102, 0)));
+    pk->beta2 = xyzz_to_affine<Fp2>(xyzz_mul_u64<Fp2>(xyzz_from_affine<Fp2>(g2), synth_k(seed, 101, 0)));
+    pk->delta2 = xyzz_to_affine<Fp2>(xyzz_mul_u64<Fp2>(xyzz_from_affine<Fp2>(g2), synth_k(seed, 102, 0)));
+    pk->ready = true;
+    pk->shard = false;
+    return pk_apply_tables(pk);
+}
+
+/* the synthetic key with a CIRCUIT's sparsity instead of the seeded one: A / B1 / B2 are infinity exactly where inf_a / inf_b say
+ * (gnark: a wire that appears in no L / R row), K exactly at the public wires and at removed_idx (the committed wires + the commitment
+ * wire); the Pedersen bases hold n_basis points.  Same point generator, so oracle/trapdoor.py predicts every sum once it is given the masks. */
+int32_t zkpor_pk_synth_masked(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, const uint8_t* inf_a, const uint8_t* inf_b,
+                              const uint32_t* removed_idx, size_t n_removed, size_t n_basis, uint64_t seed) {
+    ZK_ENTER(pk ? pk->ctx->device : -1);
+    if (!pk || log2_domain < 1 || log2_domain > 28 || n_wires == 0 || n_public > n_wires || (n_removed && !removed_idx)) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = pk->ctx;
+    std::vector<uint8_t> mk(n_wires, 0);
+    for (size_t j = 0; j < n_removed; ++j) { if (removed_idx[j] >= n_wires) { ctx->err = "pk: removed wire out of range"; return ZKPOR_E_ARG; } mk[removed_idx[j]] = 1; }
+    pk_free_arrays(pk);
+    const size_t D = (size_t)1 << log2_domain;
+    G1Affine g1 = g1_generator();
+    G2Affine g2 = g2_generator();
+    pk->log2_domain = log2_domain; pk->n_wires = n_wires; pk->n_public = n_public; pk->nZ = D - 1; pk->nC = n_basis;
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_A, n_wires, 0, 0, &pk->A));
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_B, n_wires, 0, 0, &pk->B1));
+    ZK_TRY(synth_array<Fp2>(ctx, g2, seed, ZKPOR_G1_B, n_wires, 0, 0, &pk->B2));
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_K, n_wires, 0, n_public, &pk->K));
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_Z, D - 1, 0, 0, &pk->Z));
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_COMMIT_BASIS, n_basis, 0, 0, &pk->CB));
+    ZK_TRY(synth_array<Fp>(ctx, g1, seed, ZKPOR_G1_COMMIT_BASIS_SIGMA, n_basis, 0, 0, &pk->CBS));
+    uint8_t* d_mask = nullptr;
+    ZK_HIP(ctx, hipMalloc((void**)&d_mask, n_wires));
+    const unsigned grid = (unsigned)((n_wires + 255) / 256);
+    int32_t rc = ZKPOR_OK;
+    auto apply = [&](const uint8_t* h, int which) {
+        if (!h || rc != ZKPOR_OK) return;
+        if (hipMemcpyAsync(d_mask, h, n_wires, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "pk: H2D failed"; rc = ZKPOR_E_HIP; return; }
+        if (which == 0) hipLaunchKernelGGL(k_mask_points<G1Affine>, dim3(grid), dim3(256), 0, ctx->stream, pk->A, d_mask, n_wires);
+        if (which == 1) { hipLaunchKernelGGL(k_mask_points<G1Affine>, dim3(grid), dim3(256), 0, ctx->stream, pk->B1, d_mask, n_wires);
+                          hipLaunchKernelGGL(k_mask_points<G2Affine>, dim3(grid), dim3(256), 0, ctx->stream, pk->B2, d_mask, n_wires); }
+        if (which == 2) hipLaunchKernelGGL(k_mask_points<G1Affine>, dim3(grid), dim3(256), 0, ctx->stream, pk->K, d_mask, n_wires);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pk: mask kernel failed"; rc = ZKPOR_E_HIP; }   // the host mask is reused
+    };
+    apply(inf_a, 0); apply(inf_b, 1); apply(mk.data(), 2);
+    (void)hipFree(d_mask);
+    if (rc != ZKPOR_OK) return rc;
     pk->alpha = xyzz_to_affine<Fp>(xyzz_mul_u64<Fp>(g1x(g1), synth_k(seed, 100, 0)));
     pk->beta = xyzz_to_affine<Fp>(xyzz_mul_u64<Fp>(g1x(g1), synth_k(seed, 101, 0)));
     pk->delta = xyzz_to_affine<Fp>(xyzz_mul_u64<Fp>(g1x(g1), synth_k(seed, 102, 0)));

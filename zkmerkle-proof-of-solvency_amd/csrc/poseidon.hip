@@ -10,6 +10,7 @@
 // an independent restatement of the one in oracle/poseidon.hpp; tests compare the two and the iden3 KATs).
 #include "common.cuh"
 #include "fe29.cuh"
+#include "solver_instr.cuh"
 #include <vector>
 
 namespace zk {
@@ -560,6 +561,68 @@ __global__ __launch_bounds__(64, 2) void k_poseidon_trace(Fr* __restrict__ state
 #endif
 }
 
+// ---- the solver program's Poseidon instruction (host/solver_file.hpp kind 4; csrc/solver.hip launches it) -----------------------------
+// One poseidon.Poseidon(api, inputs...) call of the circuit (circuit/utils.go:17,47; circuit/batch_create_user_circuit.go:104,129,181,270,281,
+// 320) = ONE instruction: the thread evaluates the call's input expressions over the solved wires, runs the sponge and writes the three
+// product wires of every S-box (x^2, x^4, x^5, permutation after permutation in round order) straight to their wire ids — what gnark's
+// solver reaches by solving 3 x 169 constraints per full block one after the other.  Widths 3 / 5 / 6 / 13 run on the 29-bit register path,
+// the other ragged widths (a sponge over n inputs ends in a block of width n mod 12 + 1) on the plain permutation below.
+#if defined(__HIP_DEVICE_COMPILE__)
+ZK_D void permute_plain_trace(Fr* st, int t, const PermTab& T, int rp, TraceSink& ts) {
+    Fr tmp[POS_MAX_T];
+    const int rounds = POS_RF + rp;
+    for (int r = 0; r < rounds; ++r) {
+        const Fr* c = T.rc + (size_t)t * r;
+        const bool full = r < POS_RF / 2 || r >= POS_RF / 2 + rp;
+        for (int i = 0; i < t; ++i) st[i] = Fr::add(st[i], c[i]);
+        for (int i = 0; i < (full ? t : 1); ++i) {
+            const Fr x2 = Fr::sqr(st[i]), x4 = Fr::sqr(x2), x5 = Fr::mul(x4, st[i]);
+            Fr* o = ts.base + (size_t)ts.s * 3u * ts.count + ts.perm;
+            o[0] = x2; o[ts.count] = x4; o[2 * ts.count] = x5;
+            ++ts.s;
+            st[i] = x5;
+        }
+        for (int i = 0; i < t; ++i) {
+            Fr acc = Fr::mul(T.m[i * t], st[0]);
+            for (int j = 1; j < t; ++j) acc = Fr::add(acc, Fr::mul(T.m[i * t + j], st[j]));
+            tmp[i] = acc;
+        }
+        for (int i = 0; i < t; ++i) st[i] = tmp[i];
+    }
+}
+#endif
+__global__ __launch_bounds__(64, 2) void k_gadget_poseidon(SolverProg P, const u32* __restrict__ instr, u32 n, Fr* w, uint8_t* known, u32* err, PosDev D) {
+    const u32 i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n || err[0]) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 ins = instr[i];
+    const u32* cd = P.calldata + P.arg[ins];
+    const u32 n_in = cd[0], first = cd[1], n_out = cd[2], out_carry = (cd[3] >> 8) & 0xffu;
+    u64 p = 4;
+    Fr st[POS_MAX_T];
+    Fr cap = Fr::zero();
+    TraceSink ts{w + first, 1, 0, 0u};
+    u32 done = 0;
+    while (done < n_in) {
+        const u32 k = n_in - done < 12u ? n_in - done : 12u;
+        const int t = (int)k + 1;
+        st[0] = cap;
+        for (u32 j = 0; j < k; ++j) {
+            const int rc = si_eval_le(P, cd, p, w, known, &st[1 + j]);
+            if (rc) { if (atomicCAS(&err[0], 0u, (u32)rc) == 0u) err[1] = ins; return; }
+        }
+        if (t == 13) trace_block29<13>(st, D, &ts);
+        else if (t == 3) trace_block29<3>(st, D, &ts);
+        else if (t == 5) trace_block29<5>(st, D, &ts);
+        else if (t == 6) trace_block29<6>(st, D, &ts);
+        else permute_plain_trace(st, t, D.tabs(t), D.rp[t], ts);
+        cap = st[out_carry];
+        done += k;
+    }
+    for (u32 j = 0; j < n_out; ++j) known[first + j] = 1;
+#endif
+}
+
 // range-check limbs (gnark std/rangecheck with a commitment: every checked value is cut into 16-bit limbs, each limb is a committed
 // wire and one query of the 2^16-entry table of the log-derivative argument): limbs[l * n + i] = limb l of value i as a Montgomery Fr,
 // multiplicity[limb] += 1 (the m_i wires of the argument).  Values at or above 2^(16 nb_limbs) are counted in *bad.
@@ -760,6 +823,16 @@ static int32_t pos_dev(zkpor_ctx* ctx, PosDev* P) {
     }
     if (ctx->pos_out < 0 || ctx->pos_out > 1 || ctx->pos_carry < 0 || ctx->pos_carry > 1) { ctx->err = "poseidon: convention indices must be 0 or 1"; return ZKPOR_E_ARG; }
     P->out_idx = ctx->pos_out; P->carry_idx = ctx->pos_carry;
+    return ZKPOR_OK;
+}
+
+// csrc/solver.hip: n Poseidon instructions (ids in d_instr) of one level, one thread each, on `stream`
+int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverProg& P, const u32* d_instr, u32 n, Fr* w, uint8_t* known, u32* d_err) {
+    if (n == 0) return ZKPOR_OK;
+    PosDev D;
+    ZK_TRY(pos_dev(ctx, &D));
+    hipLaunchKernelGGL(k_gadget_poseidon, dim3((n + 63u) / 64u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D);
+    ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
 

@@ -12,5 +12,6 @@ struct zkpor_r1cs {
     uint32_t* cid[3] = {nullptr, nullptr, nullptr};
     uint32_t* wid[3] = {nullptr, nullptr, nullptr};
     size_t nnz[3] = {0, 0, 0};
+    std::vector<zk::Fr> h_coeff;    // host copy of the table (the solver reads constant hint inputs — table sizes — when a program is loaded)
 };
 

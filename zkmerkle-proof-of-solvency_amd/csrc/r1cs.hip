@@ -105,6 +105,7 @@ int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, 
     r->ctx = ctx; r->n_constraints = n_constraints; r->n_wires = n_wires; r->n_coeff = n_coeff;
     std::vector<uint8_t> kind(n_coeff, 0);
     const Fr* tab = (const Fr*)coeff_table;
+    r->h_coeff.assign(tab, tab + n_coeff);
     const Fr one = Fr::one(), mone = Fr::neg(one);
     for (size_t i = 0; i < n_coeff; ++i) {
         if (tab[i].is_zero()) kind[i] = 3;

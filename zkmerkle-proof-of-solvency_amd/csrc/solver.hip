@@ -1,22 +1,43 @@
-// The solver program of a compiled circuit executed on the device — SURVEY.md §8 row f4, the generic half: what the structured generators
-// (zkpor_witgen_*) do not produce is solved here, in HBM, instead of on the host.
+// The solver program of a compiled circuit executed on the device — SURVEY.md §8 row f4: r1cs.Solve without the host.
 //
 // What it replaces: r1cs.Solve inside groth16.Prove (src/prover/prover/prover.go:269; gnark constraint/bn254/solver.go, 3P).  gnark walks
-// `Levels [][]int`, sets of mutually independent instructions, with one goroutine per chunk of a level; here a level is ONE launch with one
-// GPU thread per instruction (csrc/solver_instr.cuh holds what a thread does — the same header is unit-tested on the CPU).  The levels of
-// BatchCreateUserCircuit are wide where the users sit side by side (hundreds to thousands of instructions) and narrow along the hash chains;
-// runs of consecutive narrow levels (<= 512 instructions each) are executed by ONE workgroup that steps through them with a workgroup
-// barrier per level, so a run of k narrow levels costs one launch instead of k.
-//
-// Hints: the native ones run on the device (IntegerDivision, NBits, InvZero, DecomposeHint).  Any other hint (gnark's BSB22 commitment
-// placeholder: the challenge wire depends on a multi-exponentiation over the committed wires and a hash-to-field) is EXTERNAL: the run
-// pauses in front of it, the caller reads the hint's inputs (zkpor_solver_external_inputs), computes the outputs by whatever means
-// (zkpor_commit_dev + the challenge of host/bsb22_challenge.hpp), hands them in (zkpor_solver_external_outputs) and resumes.
+// `Levels [][]int`, sets of mutually independent instructions, with one goroutine per chunk of a level.  Here the program sits in HBM next to
+// the constraint matrices and a level runs as a handful of launches, one per CLASS of instruction:
+//   generic    one GPU thread per instruction — solve one constraint for its single unknown wire, a native hint (circuit.IntegerDivision,
+//              NBits, InvZero, DecomposeHint) or a table lookup (gnark BlueprintLookupHint): csrc/solver_instr.cuh, the header the CPU suite
+//              also compiles.  Runs of consecutive narrow levels (<= 512 generic instructions, nothing else) are stepped through by ONE
+//              workgroup with a barrier per level, so k narrow levels cost one launch instead of k;
+//   poseidon   a whole poseidon.Poseidon(...) call per thread (csrc/poseidon.hip k_gadget_poseidon).  A call flagged ASYNC — the two
+//              10 000-element CEX commitments: 834 chained permutations whose digest only feeds an assertion — runs on a side stream
+//              beside all other levels and is joined in front of the last level;
+//   count      gnark's logderivarg countHint (one hint over EVERY query of a table — 10^7 inputs for the range checker): three kernels,
+//              one thread per table row / query / output, atomics into a histogram.
+// The BSB22 commitment placeholder (and any other hint without native semantics) is EXTERNAL: the run pauses in front of it, the caller
+// reads its inputs (zkpor_solver_external_inputs[_dev] — the committed wires go straight to zkpor_commit_dev), provides the output
+// (the challenge of host/bsb22_challenge.hpp) and resumes.
 #include <algorithm>
+#include <set>
 #include "common.cuh"
 #include "r1cs.cuh"
 #include "solver_instr.cuh"
 #include "../host/solver_file.hpp"
+
+namespace zk {
+int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverProg& P, const u32* d_instr, u32 n, Fr* w, uint8_t* known, u32* d_err);   // poseidon.hip
+}
+
+namespace {
+struct LevelPlan {          // one level of the reordered instruction list: [generic | poseidon | poseidon async | count]
+    uint64_t lo = 0;
+    uint32_t n_gen = 0, n_pos = 0, n_posa = 0, n_cnt = 0, cnt_first = 0;   // the level's count hints are counts[cnt_first .. + n_cnt)
+    bool external = false;
+};
+struct BigHint {            // a hint whose inputs are addressed through a persisted offset table (count hints, external hints)
+    uint32_t ins = 0, n_in = 0, n_out = 0, nb_table = 0, nb_col = 0;
+    uint64_t offs_base = 0; // first entry in d_offs: word offset of input i's expression from the instruction's call data
+    uint64_t nb_q = 0;
+};
+}  // namespace
 
 struct zkpor_solver {
     zkpor_ctx* ctx = nullptr;
@@ -24,15 +45,22 @@ struct zkpor_solver {
     zkpor_host::SolverView view;                // points into `container`
     std::vector<uint8_t> container;
     std::vector<uint8_t> hint_kind;             // per hint name id
-    std::vector<uint8_t> level_external;        // per level: holds at least one external hint
-    uint32_t *d_kind = nullptr, *d_arg = nullptr, *d_level_instr = nullptr, *d_calldata = nullptr;
-    uint64_t* d_level_ptr = nullptr;
+    std::vector<LevelPlan> plan;
+    std::vector<BigHint> counts;                // in level order (the order the levels meet them)
+    std::map<uint32_t, BigHint> externals;      // by instruction
+    uint32_t *d_kind = nullptr, *d_arg = nullptr, *d_level_instr = nullptr, *d_calldata = nullptr, *d_gen_cnt = nullptr, *d_offs = nullptr;
+    uint64_t* d_gen_lo = nullptr;
     uint8_t *d_hint_kind = nullptr, *d_known = nullptr;
     uint32_t* d_err = nullptr;                  // [0] first error code, [1] its instruction, [2] wires never assigned, [3] externals met in the level just run
     uint32_t* d_ext = nullptr;                  // external hint instructions of the level just run (capacity EXT_CAP)
-    uint64_t n_r1c = 0, n_hint = 0, n_skip = 0;
+    uint32_t* d_cnt = nullptr;                  // histogram of the count hint being served (max nb_table entries)
+    zk::Fr* d_tmp = nullptr;                    // scratch for external hint values (grow-only)
+    size_t tmp_cap = 0;
+    hipStream_t side = nullptr;                 // ASYNC instructions
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint64_t n_r1c = 0, n_hint = 0, n_skip = 0, n_lookup = 0, n_poseidon = 0;
     // run state (pause / resume)
-    bool running = false;
+    bool running = false, side_busy = false;
     uint64_t next_level = 0;
     std::vector<uint32_t> pending;              // external instructions of the level just run, still to be served
     uint64_t launches = 0;
@@ -46,14 +74,11 @@ static constexpr u32 NARROW = 512, EXT_CAP = 4096;
 ZK_D void solver_step(const SolverProg& P, u32 ins, Fr* w, uint8_t* known, u32* err, u32* ext) {
     // an external hint is not executed: it is reported, its outputs stay unknown until the caller provides them
     if (P.kind[ins] == SI_HINT) {
-        const u32 arg = P.arg[ins];
-        if ((u64)arg + 3 <= P.n_calldata) {
-            const u32 name = P.calldata[arg];
-            if (name < P.n_hint_names && P.hint_kind[name] == HK_NONE) {
-                const u32 slot = atomicAdd(&err[3], 1u);
-                if (slot < EXT_CAP) ext[slot] = ins;
-                return;
-            }
+        const u32 name = P.calldata[P.arg[ins]];
+        if (P.hint_kind[name] == HK_NONE) {
+            const u32 slot = atomicAdd(&err[3], 1u);
+            if (slot < EXT_CAP) ext[slot] = ins;
+            return;
         }
     }
     const int rc = solve_instr(P, ins, w, known);
@@ -69,11 +94,11 @@ __global__ __launch_bounds__(256) void k_solve_level(SolverProg P, const u32* __
 }
 
 // a run of narrow levels [l0, l1): one workgroup, a barrier per level (the writes of a level are visible to the workgroup after it)
-__global__ __launch_bounds__(NARROW) void k_solve_narrow(SolverProg P, const u32* __restrict__ level_instr, const u64* __restrict__ level_ptr, u64 l0,
-                                                         u64 l1, Fr* w, uint8_t* known, u32* err, u32* ext) {
+__global__ __launch_bounds__(NARROW) void k_solve_narrow(SolverProg P, const u32* __restrict__ level_instr, const u64* __restrict__ gen_lo,
+                                                         const u32* __restrict__ gen_cnt, u64 l0, u64 l1, Fr* w, uint8_t* known, u32* err, u32* ext) {
     for (u64 l = l0; l < l1; ++l) {
-        const u64 lo = level_ptr[l];
-        const u32 n = (u32)(level_ptr[l + 1] - lo);
+        const u64 lo = gen_lo[l];
+        const u32 n = gen_cnt[l];
         if (threadIdx.x < n && !err[0]) solver_step(P, level_instr[lo + threadIdx.x], w, known, err, ext);
         __threadfence_block();
         __syncthreads();
@@ -87,22 +112,69 @@ __global__ __launch_bounds__(256) void k_count_unknown(const uint8_t* __restrict
     if ((threadIdx.x & 63u) == 0 && b) atomicAdd(&err[2], (u32)__popcll(b));
 }
 
-// the input expressions of a hint, evaluated for the caller: out[i] = sum coeff * w over input i (one thread per input; the BSB22
-// placeholder's inputs are the committed wires, thousands to millions of one-term expressions)
-__global__ __launch_bounds__(256) void k_hint_inputs(SolverProg P, u32 ins, const u64* __restrict__ offs, u32 n_in, const Fr* __restrict__ w,
+ZK_D void report(u32* err, u32 code, u32 ins) { if (atomicCAS(&err[0], 0u, code) == 0u) err[1] = ins; }
+
+// ---- gnark logderivarg countHint: inputs = nbTable, nbCols, the table's rows, the queries' rows -> per row how many queries equal it.
+// The tables of this circuit carry their own index in column 0 (the range checker: the constants 0 .. 2^w - 1; a lookup table: rows
+// (i, entry_i)), so a query finds its row by that column; the remaining columns are compared.  A table whose column 0 is not 0..n-1, a
+// query outside the table or one that differs from its row fails the hint — as gnark's does ("query element not in table").
+__global__ __launch_bounds__(256) void k_count_table(SolverProg P, u32 ins, const u32* __restrict__ offs, u32 nb_table, u32 nb_col, const Fr* w,
+                                                     const uint8_t* known, u32* err) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nb_table) return;
+    const u32* cd = P.calldata + P.arg[ins];
+    u64 p = offs[2 + (u64)i * nb_col];
+    Fr v;
+    const int rc = si_eval_le(P, cd, p, w, known, &v);
+    if (rc) { report(err, (u32)rc, ins); return; }
+    u32 idx;
+    if (!si_index(v, nb_table, &idx) || idx != i) report(err, SE_COUNT_TABLE, ins);
+}
+__global__ __launch_bounds__(256) void k_count_queries(SolverProg P, u32 ins, const u32* __restrict__ offs, u32 nb_table, u32 nb_col, u64 nb_q,
+                                                       const Fr* w, const uint8_t* known, u32* cnt, u32* err) {
+    const u64 q = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (q >= nb_q) return;
+    const u32* cd = P.calldata + P.arg[ins];
+    const u32* qo = offs + 2 + ((u64)nb_table + q) * nb_col;
+    u64 p = qo[0];
+    Fr v;
+    int rc = si_eval_le(P, cd, p, w, known, &v);
+    if (rc) { report(err, (u32)rc, ins); return; }
+    u32 idx;
+    if (!si_index(v, nb_table, &idx)) { report(err, SE_COUNT_QUERY, ins); return; }
+    const u32* to = offs + 2 + (u64)idx * nb_col;
+    for (u32 c = 1; c < nb_col; ++c) {
+        Fr a, b;
+        u64 pa = qo[c], pb = to[c];
+        rc = si_eval_le(P, cd, pa, w, known, &a);
+        if (!rc) rc = si_eval_le(P, cd, pb, w, known, &b);
+        if (rc) { report(err, (u32)rc, ins); return; }
+        if (a != b) { report(err, SE_COUNT_QUERY, ins); return; }
+    }
+    atomicAdd(&cnt[idx], 1u);
+}
+__global__ __launch_bounds__(256) void k_count_out(SolverProg P, u32 ins, u32 nb_table, const u32* __restrict__ cnt, Fr* w, uint8_t* known) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nb_table) return;
+    const u32 out = P.calldata[P.arg[ins] + 3 + i];
+    Fr c = Fr::zero();
+    c.v[0] = cnt[i];
+    w[out] = Fr::to_mont(c);
+    known[out] = 1;
+}
+
+// the input expressions of a hint, evaluated for the caller: out[i] = value of input i (one thread per input; the BSB22 placeholder's
+// inputs are the committed wires, thousands to millions of one-term expressions)
+__global__ __launch_bounds__(256) void k_hint_inputs(SolverProg P, u32 ins, const u32* __restrict__ offs, u32 n_in, const Fr* __restrict__ w,
                                                      const uint8_t* __restrict__ known, Fr* out, u32* err) {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_in) return;
     const u32* cd = P.calldata + P.arg[ins];
     u64 p = offs[i];
-    const u32 nterms = cd[p++];
-    Fr acc = Fr::zero();
-    for (u32 k = 0; k < nterms; ++k) {
-        const u32 ci = cd[p++], wi = cd[p++];
-        if (!known[wi]) { if (atomicCAS(&err[0], 0u, (u32)SE_INPUT_UNSOLVED) == 0u) err[1] = ins; return; }
-        si_add_term(acc, P.ckind[ci], P.coeff, ci, w[wi]);
-    }
-    out[i] = acc;
+    Fr v;
+    const int rc = si_eval_le(P, cd, p, w, known, &v);
+    if (rc) { report(err, (u32)rc, ins); return; }
+    out[i] = v;
 }
 __global__ void k_hint_outputs(SolverProg P, u32 ins, const Fr* __restrict__ vals, Fr* w, uint8_t* known) {
     const u32* cd = P.calldata + P.arg[ins];
@@ -121,8 +193,12 @@ static SolverProg prog_of(const zkpor_solver* s) {
     return P;
 }
 static void solver_free(zkpor_solver* s) {
-    void* ptrs[] = {s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_level_ptr, s->d_hint_kind, s->d_known, s->d_err, s->d_ext};
+    void* ptrs[] = {s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
+                    s->d_cnt, s->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     delete s;
 }
 static const char* solver_error_text(u32 code) {
@@ -137,42 +213,90 @@ static const char* solver_error_text(u32 code) {
     case SE_ID_RANGE: return "wire or coefficient id out of range";
     case SE_INPUT_UNSOLVED: return "hint input not solved yet";
     case SE_HINT_FAILED: return "hint failed";
+    case SE_LOOKUP_RANGE: return "lookup query too large";
+    case SE_COUNT_TABLE: return "count hint: the table's first column is not 0 .. n-1 (no native semantics for such a table)";
+    case SE_COUNT_QUERY: return "count hint: query element not in table";
     default: return "error";
     }
+}
+static int32_t tmp_reserve(zkpor_solver* s, size_t elems) {
+    if (elems <= s->tmp_cap) return ZKPOR_OK;
+    zkpor_ctx* ctx = s->ctx;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (s->d_tmp) { (void)hipFree(s->d_tmp); s->d_tmp = nullptr; s->tmp_cap = 0; }
+    ZK_HIP(ctx, hipMalloc((void**)&s->d_tmp, elems * sizeof(Fr)));
+    s->tmp_cap = elems;
+    return ZKPOR_OK;
+}
+
+static int32_t join_side(zkpor_solver* s) {
+    if (!s->side_busy) return ZKPOR_OK;
+    ZK_HIP(s->ctx, hipEventRecord(s->ev_join, s->side));
+    ZK_HIP(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_join, 0));
+    s->side_busy = false;
+    return ZKPOR_OK;
 }
 
 // queue levels from s->next_level on until the program ends or a level with external hints has run; then look at the flags
 static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
     zkpor_ctx* ctx = s->ctx;
-    const auto& v = s->view;
     const SolverProg P = prog_of(s);
     Fr* w = (Fr*)s->d_w;
+    const u64 n_levels = s->plan.size();
     *paused_instr = 0xffffffffu;
     if (!s->pending.empty()) { *paused_instr = s->pending.front(); return ZKPOR_OK; }
     u32 h[4] = {0, 0, 0, 0};
-    while (s->next_level < v.n_levels) {
+    {
         PhaseScope ps(ctx, "solver_levels");
         bool stop = false;
-        while (s->next_level < v.n_levels && !stop) {
+        while (s->next_level < n_levels && !stop) {
             const u64 l = s->next_level;
-            const u64 lo = v.level_ptr[l], n = v.level_ptr[l + 1] - lo;
-            if (n > NARROW) {
-                hipLaunchKernelGGL(k_solve_level, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P, s->d_level_instr, lo, (u32)n, w, s->known, s->d_err, s->d_ext);
-                s->next_level = l + 1;
-                stop = s->level_external[l];
-            } else {
-                u64 l1 = l;                      // the run of narrow levels starting here, ended by (and including) a level with external hints
-                while (l1 < v.n_levels && v.level_ptr[l1 + 1] - v.level_ptr[l1] <= NARROW) { ++l1; if (s->level_external[l1 - 1]) { stop = true; break; } }
-                hipLaunchKernelGGL(k_solve_narrow, dim3(1), dim3(NARROW), 0, ctx->stream, P, s->d_level_instr, s->d_level_ptr, l, l1, w, s->known, s->d_err, s->d_ext);
+            const LevelPlan& L = s->plan[l];
+            if (l + 1 == n_levels) ZK_TRY(join_side(s));          // ASYNC outputs are read by the last level only (the container's promise)
+            const bool only_narrow = L.n_pos == 0 && L.n_posa == 0 && L.n_cnt == 0 && L.n_gen <= NARROW;
+            if (only_narrow) {
+                u64 l1 = l;                       // the run of narrow levels starting here, ended by (and including) a level with external hints
+                while (l1 < n_levels) {
+                    const LevelPlan& M = s->plan[l1];
+                    if (M.n_pos || M.n_posa || M.n_cnt || M.n_gen > NARROW) break;
+                    if (l1 + 1 == n_levels && l1 != l && s->side_busy) break;   // the last level starts its own launch, behind the join
+                    ++l1;
+                    if (M.external) { stop = true; break; }
+                }
+                hipLaunchKernelGGL(k_solve_narrow, dim3(1), dim3(NARROW), 0, ctx->stream, P, s->d_level_instr, s->d_gen_lo, s->d_gen_cnt, l, l1, w, s->known, s->d_err, s->d_ext);
+                ++s->launches;
                 s->next_level = l1;
+                continue;
             }
-            ++s->launches;
+            if (L.n_posa) {                       // fork: everything queued so far is visible to the side stream
+                ZK_HIP(ctx, hipEventRecord(s->ev_fork, ctx->stream));
+                ZK_HIP(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
+                ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_pos, L.n_posa, w, s->known, s->d_err));
+                s->side_busy = true;
+                ++s->launches;
+            }
+            if (L.n_gen) {
+                hipLaunchKernelGGL(k_solve_level, dim3((L.n_gen + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, w, s->known, s->d_err, s->d_ext);
+                ++s->launches;
+            }
+            if (L.n_pos) { ZK_TRY(gadget_poseidon_launch(ctx, ctx->stream, P, s->d_level_instr + L.lo + L.n_gen, L.n_pos, w, s->known, s->d_err)); ++s->launches; }
+            for (u32 k = 0; k < L.n_cnt; ++k) {   // one after the other: they share the histogram
+                const BigHint& c = s->counts[L.cnt_first + k];
+                const u32* offs = s->d_offs + c.offs_base;
+                ZK_HIP(ctx, hipMemsetAsync(s->d_cnt, 0, (size_t)c.nb_table * sizeof(u32), ctx->stream));
+                hipLaunchKernelGGL(k_count_table, dim3((c.nb_table + 255u) / 256u), dim3(256), 0, ctx->stream, P, c.ins, offs, c.nb_table, c.nb_col, w, s->known, s->d_err);
+                if (c.nb_q) hipLaunchKernelGGL(k_count_queries, dim3((unsigned)((c.nb_q + 255) / 256)), dim3(256), 0, ctx->stream, P, c.ins, offs, c.nb_table, c.nb_col, c.nb_q, w, s->known, s->d_cnt, s->d_err);
+                hipLaunchKernelGGL(k_count_out, dim3((c.nb_table + 255u) / 256u), dim3(256), 0, ctx->stream, P, c.ins, c.nb_table, s->d_cnt, w, s->known);
+                s->launches += 3;
+            }
+            s->next_level = l + 1;
+            stop = L.external;
         }
         ZK_KERNEL_CHECK(ctx);
-        if (stop) break;
     }
-    const bool finished = s->next_level >= v.n_levels;
+    const bool finished = s->next_level >= n_levels;
     if (finished) {
+        ZK_TRY(join_side(s));
         // counted afresh every time the end is reached: a run that paused in its LAST level has been here before, with the hint's outputs still open
         ZK_HIP(ctx, hipMemsetAsync(s->d_err + 2, 0, sizeof(u32), ctx->stream));
         hipLaunchKernelGGL(k_count_unknown, dim3((unsigned)((s->r1cs->n_wires + 255) / 256)), dim3(256), 0, ctx->stream, s->known, s->r1cs->n_wires, s->d_err);
@@ -182,6 +306,7 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h[0]) {
         s->running = false;
+        if (s->side_busy) { (void)hipStreamSynchronize(s->side); s->side_busy = false; }
         ctx->err = std::string("solver: ") + solver_error_text(h[0]) + " at instruction " + std::to_string(h[1]);
         return ZKPOR_E_STATE;
     }
@@ -218,47 +343,124 @@ int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t l
     std::string why;
     if (zkpor_host::ParseSolverFile(s->container.data(), len, &s->view, &why) != 0) { ctx->err = why; delete s; return ZKPOR_E_ARG; }
     const auto& v = s->view;
-    // validate what the kernels index with: constraint ids, call-data offsets and shapes, wire / coefficient ids inside the call data
+    auto bad = [&](const std::string& m) { ctx->err = "solver: " + m; delete s; return ZKPOR_E_ARG; };
+    if (v.n_calldata >= (1ull << 32)) return bad("call data beyond 2^32 words");
+    const uint64_t nw = r1cs->n_wires, ncoef = r1cs->n_coeff;
+    // validate what the kernels index with — constraint ids, call-data offsets and shapes, wire / coefficient ids inside the call data —
+    // and sort every instruction into its class
     s->hint_kind.resize(v.hint_names.size());
     for (size_t i = 0; i < v.hint_names.size(); ++i) s->hint_kind[i] = hint_kind_of_name(v.hint_names[i].c_str());
-    std::vector<uint8_t> instr_external(v.n_instructions, 0);
+    enum : uint8_t { CL_GEN = 0, CL_POS = 1, CL_POSA = 2, CL_CNT = 3 };
+    std::vector<uint8_t> cls(v.n_instructions, CL_GEN), external(v.n_instructions, 0);
+    std::vector<uint32_t> kinds(v.n_instructions);
+    std::set<std::pair<uint32_t, uint32_t>> tables_ok;   // (block, nbEntries) already validated: a table's entries are checked once, not per lookup
+    std::vector<uint32_t> offs;                          // the offset pool of count / external hints
+    std::map<uint32_t, BigHint> big;                     // by instruction
+    uint64_t max_table = 1;
+    auto const_u32 = [&](const uint32_t* cd, uint64_t p, uint32_t* out_v) {   // a constant expression's value (nbTable, nbCols)
+        if (cd[p] == 0) { *out_v = 0; return true; }
+        if (cd[p] != 1 || cd[p + 2] != 0) return false;
+        const Fr c = Fr::from_mont(r1cs->h_coeff[cd[p + 1]]);
+        for (int k = 1; k < 8; ++k) if (c.v[k]) return false;
+        *out_v = c.v[0];
+        return true;
+    };
     for (uint64_t i = 0; i < v.n_instructions; ++i) {
-        const uint32_t kind = v.kind[i], arg = v.arg[i];
-        if (kind == SI_R1C) { if (arg >= r1cs->n_constraints) { ctx->err = "solver: instruction " + std::to_string(i) + " names a constraint outside the system"; delete s; return ZKPOR_E_ARG; } ++s->n_r1c; }
-        else if (kind == SI_HINT) {
+        const uint32_t kind = zkpor_host::InstrKind(v, i), arg = v.arg[i];
+        kinds[i] = kind;
+        if (kind == SI_R1C) { if (arg >= r1cs->n_constraints) return bad("instruction " + std::to_string(i) + " names a constraint outside the system"); ++s->n_r1c; }
+        else if (kind == SI_LOOKUP) {
+            if ((uint64_t)arg + 4 > v.n_calldata) return bad("the call data of lookup " + std::to_string(i) + " is malformed");
+            const uint32_t* cd = v.calldata + arg;
+            const bool known_table = tables_ok.count({cd[0], cd[1]}) != 0;
+            if (known_table) {   // only the queries
+                uint64_t p = (uint64_t)arg + 4;
+                bool ok = (uint64_t)cd[3] + cd[2] <= nw;
+                for (uint32_t q = 0; ok && q < cd[2]; ++q) {
+                    ok = p < v.n_calldata;
+                    if (!ok) break;
+                    const uint64_t nt = v.calldata[p++];
+                    ok = p + 2 * nt <= v.n_calldata;
+                    for (uint64_t t = 0; ok && t < nt; ++t) ok = v.calldata[p + 2 * t] < ncoef && v.calldata[p + 1 + 2 * t] < nw;
+                    p += 2 * nt;
+                }
+                if (!ok) return bad("the call data of lookup " + std::to_string(i) + " is malformed");
+            } else {
+                if (!zkpor_host::CheckLookupShape(v, arg, nw, ncoef)) return bad("the call data of lookup " + std::to_string(i) + " is malformed");
+                tables_ok.insert({cd[0], cd[1]});
+            }
+            ++s->n_lookup;
+        } else if (kind == SI_POSEIDON) {
+            if (!zkpor_host::CheckPoseidonShape(v, arg, nw, ncoef)) return bad("the call data of Poseidon instruction " + std::to_string(i) + " is malformed");
+            cls[i] = (v.calldata[arg + 3] & zkpor_host::POSEIDON_ASYNC) ? CL_POSA : CL_POS;
+            ++s->n_poseidon;
+        } else if (kind == SI_HINT) {
             bool ok = (uint64_t)arg + 3 <= v.n_calldata;
-            uint64_t p = 0;
             if (ok) {
                 const uint32_t* cd = v.calldata + arg;
                 ok = cd[0] < v.hint_names.size() && (uint64_t)arg + 3 + cd[2] <= v.n_calldata;
-                p = 3 + (uint64_t)(ok ? cd[2] : 0);
-                for (uint32_t k = 0; ok && k < cd[2]; ++k) ok = cd[3 + k] < r1cs->n_wires;
+                uint64_t p = 3 + (uint64_t)(ok ? cd[2] : 0);
+                for (uint32_t k = 0; ok && k < cd[2]; ++k) ok = cd[3 + k] < nw;
+                const uint8_t hk = ok ? s->hint_kind[cd[0]] : 0;
+                const bool keep_offs = ok && (hk == HK_NONE || hk == HK_COUNT);
+                BigHint b;
+                if (keep_offs) { b.ins = (uint32_t)i; b.n_in = cd[1]; b.n_out = cd[2]; b.offs_base = offs.size(); offs.reserve(offs.size() + cd[1]); }
                 for (uint32_t k = 0; ok && k < cd[1]; ++k) {
                     ok = arg + p < v.n_calldata;
                     if (!ok) break;
+                    if (keep_offs) offs.push_back((uint32_t)p);
                     const uint32_t nt = cd[p++];
                     ok = arg + p + 2ull * nt <= v.n_calldata;
-                    for (uint32_t t = 0; ok && t < nt; ++t) { ok = cd[p] < r1cs->n_coeff && cd[p + 1] < r1cs->n_wires; p += 2; }
+                    for (uint32_t t = 0; ok && t < nt; ++t) { ok = cd[p] < ncoef && cd[p + 1] < nw; p += 2; }
                 }
-                if (ok && s->hint_kind[cd[0]] == HK_NONE) instr_external[i] = 1;
+                if (ok && hk == HK_NONE) { external[i] = 1; big[(uint32_t)i] = b; }
+                if (ok && hk == HK_COUNT) {
+                    ok = cd[1] >= 2 && const_u32(cd, offs[b.offs_base], &b.nb_table) && const_u32(cd, offs[b.offs_base + 1], &b.nb_col) && b.nb_col >= 1 &&
+                         b.nb_table >= 1 && b.nb_table == cd[2] && (uint64_t)cd[1] >= 2 + (uint64_t)b.nb_table * b.nb_col &&
+                         ((uint64_t)cd[1] - 2 - (uint64_t)b.nb_table * b.nb_col) % b.nb_col == 0;
+                    if (ok) { b.nb_q = ((uint64_t)cd[1] - 2 - (uint64_t)b.nb_table * b.nb_col) / b.nb_col; big[(uint32_t)i] = b; cls[i] = CL_CNT; max_table = std::max<uint64_t>(max_table, b.nb_table); }
+                }
             }
-            if (!ok) { ctx->err = "solver: the call data of instruction " + std::to_string(i) + " is malformed"; delete s; return ZKPOR_E_ARG; }
+            if (!ok) return bad("the call data of instruction " + std::to_string(i) + " is malformed");
             ++s->n_hint;
         } else ++s->n_skip;
     }
-    s->level_external.assign(v.n_levels, 0);
-    for (uint64_t l = 0; l < v.n_levels; ++l)
-        for (uint64_t k = v.level_ptr[l]; k < v.level_ptr[l + 1]; ++k) if (instr_external[v.level_instr[k]]) s->level_external[l] = 1;
+    // the level lists, every level reordered by class; count hints collected in level order
     const uint64_t n_li = v.level_ptr[v.n_levels];
+    std::vector<uint32_t> li(n_li), gen_cnt(v.n_levels);
+    std::vector<uint64_t> gen_lo(v.n_levels);
+    s->plan.resize(v.n_levels);
+    for (uint64_t l = 0; l < v.n_levels; ++l) {
+        LevelPlan& L = s->plan[l];
+        L.lo = v.level_ptr[l];
+        uint64_t o = L.lo;
+        for (uint8_t c = CL_GEN; c <= CL_CNT; ++c) {
+            uint32_t n = 0;
+            for (uint64_t k = v.level_ptr[l]; k < v.level_ptr[l + 1]; ++k) {
+                const uint32_t ins = v.level_instr[k];
+                if (cls[ins] != c) continue;
+                li[o++] = ins; ++n;
+                if (external[ins]) L.external = true;
+                if (c == CL_CNT) s->counts.push_back(big[ins]);
+            }
+            if (c == CL_GEN) L.n_gen = n; else if (c == CL_POS) L.n_pos = n; else if (c == CL_POSA) L.n_posa = n; else { L.n_cnt = n; L.cnt_first = (uint32_t)(s->counts.size() - n); }
+        }
+        gen_lo[l] = L.lo; gen_cnt[l] = L.n_gen;
+        if (L.n_posa && l + 1 >= v.n_levels) return bad("an ASYNC instruction in the last level");
+    }
+    for (auto& kv : big) if (external[kv.first]) s->externals[kv.first] = kv.second;
     auto up = [&](void** d, const void* h, size_t bytes) {
         if (hipMalloc(d, bytes ? bytes : 4) != hipSuccess) { (void)hipGetLastError(); return false; }
         return bytes == 0 || hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
-    bool ok = up((void**)&s->d_kind, v.kind, v.n_instructions * 4) && up((void**)&s->d_arg, v.arg, v.n_instructions * 4) &&
-              up((void**)&s->d_level_instr, v.level_instr, n_li * 4) && up((void**)&s->d_calldata, v.calldata, v.n_calldata * 4) &&
-              up((void**)&s->d_level_ptr, v.level_ptr, (v.n_levels + 1) * 8) && up((void**)&s->d_hint_kind, s->hint_kind.data(), s->hint_kind.size()) &&
-              hipMalloc((void**)&s->d_known, r1cs->n_wires) == hipSuccess && hipMalloc((void**)&s->d_err, 16) == hipSuccess &&
-              hipMalloc((void**)&s->d_ext, EXT_CAP * sizeof(u32)) == hipSuccess;
+    bool ok = up((void**)&s->d_kind, kinds.data(), v.n_instructions * 4) && up((void**)&s->d_arg, v.arg, v.n_instructions * 4) &&
+              up((void**)&s->d_level_instr, li.data(), n_li * 4) && up((void**)&s->d_calldata, v.calldata, v.n_calldata * 4) &&
+              up((void**)&s->d_gen_lo, gen_lo.data(), v.n_levels * 8) && up((void**)&s->d_gen_cnt, gen_cnt.data(), v.n_levels * 4) &&
+              up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up((void**)&s->d_hint_kind, s->hint_kind.data(), s->hint_kind.size()) &&
+              hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 16) == hipSuccess &&
+              hipMalloc((void**)&s->d_ext, EXT_CAP * sizeof(u32)) == hipSuccess && hipMalloc((void**)&s->d_cnt, max_table * sizeof(u32)) == hipSuccess &&
+              hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); solver_free(s); ctx->err = "solver: out of device memory"; return ZKPOR_E_OOM; }
     *out = s;
     return ZKPOR_OK;
@@ -268,14 +470,15 @@ void zkpor_solver_destroy(zkpor_solver* s) {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s) return;
     (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->side) (void)hipStreamSynchronize(s->side);
     solver_free(s);
 }
 
 int32_t zkpor_solver_dims(const zkpor_solver* s, uint64_t dims[7]) {
     if (!s || !dims) return ZKPOR_E_ARG;
-    dims[0] = s->view.n_instructions; dims[1] = s->view.n_levels; dims[2] = s->n_r1c; dims[3] = s->n_hint; dims[4] = s->n_skip;
+    dims[0] = s->view.n_instructions; dims[1] = s->view.n_levels; dims[2] = s->n_r1c; dims[3] = s->n_hint + s->n_lookup + s->n_poseidon; dims[4] = s->n_skip;
     uint64_t ext = 0;
-    for (uint8_t e : s->level_external) ext += e;
+    for (const LevelPlan& L : s->plan) ext += L.external;
     dims[5] = ext;
     dims[6] = s->launches;
     return ZKPOR_OK;
@@ -286,6 +489,7 @@ int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint
     if (!s || !d_w || !paused_instr) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
     if (n_inputs == 0 || n_inputs > s->r1cs->n_wires) { ctx->err = "solver: the assignment must hold 1 + nPublic + nSecret elements"; return ZKPOR_E_ARG; }
+    if (s->side_busy) { (void)hipStreamSynchronize(s->side); s->side_busy = false; }   // an abandoned run
     s->d_w = d_w;
     s->known = d_known_or_null ? d_known_or_null : s->d_known;
     if (!d_known_or_null) ZK_HIP(ctx, hipMemsetAsync(s->d_known, 0, s->r1cs->n_wires, ctx->stream));
@@ -305,25 +509,15 @@ int32_t zkpor_solver_resume_dev(zkpor_solver* s, uint32_t* paused_instr) {
 // evaluates the inputs of the external hint the run is paused at into d_out (device, n_in elements); synchronous
 static int32_t hint_inputs_to(zkpor_solver* s, uint32_t instr, Fr* d_out) {
     zkpor_ctx* ctx = s->ctx;
-    const uint32_t* cd = s->view.calldata + s->view.arg[instr];
-    const uint32_t n_in = cd[1];
-    if (n_in == 0) return ZKPOR_OK;
-    std::vector<uint64_t> offs(n_in);
-    uint64_t p = 3 + (uint64_t)cd[2];
-    for (uint32_t i = 0; i < n_in; ++i) { offs[i] = p; p += 1 + 2ull * cd[p]; }   // shapes were validated by zkpor_solver_create
-    uint64_t* d_offs = nullptr;
-    ZK_HIP(ctx, hipMalloc((void**)&d_offs, n_in * sizeof(uint64_t)));
-    int32_t rc = ZKPOR_OK;
+    const BigHint& b = s->externals.at(instr);
+    if (b.n_in == 0) return ZKPOR_OK;
     u32 h[2] = {0, 0};
-    if (hipMemcpyAsync(d_offs, offs.data(), n_in * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "solver: H2D failed"; rc = ZKPOR_E_HIP; }
-    if (rc == ZKPOR_OK) {
-        hipLaunchKernelGGL(k_hint_inputs, dim3((n_in + 255u) / 256u), dim3(256), 0, ctx->stream, prog_of(s), instr, d_offs, n_in, (const Fr*)s->d_w, s->known, d_out, s->d_err);
-        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h, s->d_err, sizeof h, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "solver: launch failed"; rc = ZKPOR_E_HIP; }
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_offs);
-    if (rc == ZKPOR_OK && h[0]) { s->running = false; ctx->err = std::string("solver: ") + solver_error_text(h[0]) + " at instruction " + std::to_string(h[1]); rc = ZKPOR_E_STATE; }
-    return rc;
+    hipLaunchKernelGGL(k_hint_inputs, dim3((b.n_in + 255u) / 256u), dim3(256), 0, ctx->stream, prog_of(s), instr, s->d_offs + b.offs_base, b.n_in, (const Fr*)s->d_w, s->known, d_out, s->d_err);
+    ZK_KERNEL_CHECK(ctx);
+    ZK_HIP(ctx, hipMemcpyAsync(h, s->d_err, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[0]) { s->running = false; ctx->err = std::string("solver: ") + solver_error_text(h[0]) + " at instruction " + std::to_string(h[1]); return ZKPOR_E_STATE; }
+    return ZKPOR_OK;
 }
 
 int32_t zkpor_solver_external_inputs(zkpor_solver* s, uint32_t instr, uint64_t* in_values, size_t capacity, size_t* n_in, size_t* n_out) {
@@ -336,12 +530,10 @@ int32_t zkpor_solver_external_inputs(zkpor_solver* s, uint32_t instr, uint64_t* 
     if (!in_values) return ZKPOR_OK;              // sizes only
     if (capacity < cd[1]) { ctx->err = "solver: the buffer holds fewer elements than the hint has inputs"; return ZKPOR_E_ARG; }
     if (cd[1] == 0) return ZKPOR_OK;
-    Fr* d_tmp = nullptr;                          // not the staging area: the caller's d_w may live there (zkpor_prove_inputs)
-    ZK_HIP(ctx, hipMalloc((void**)&d_tmp, (size_t)cd[1] * sizeof(Fr)));
-    int32_t rc = hint_inputs_to(s, instr, d_tmp);
-    if (rc == ZKPOR_OK && hipMemcpy(in_values, d_tmp, (size_t)cd[1] * sizeof(Fr), hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "solver: D2H failed"; rc = ZKPOR_E_HIP; }
-    (void)hipFree(d_tmp);
-    return rc;
+    ZK_TRY(tmp_reserve(s, cd[1]));                // not the staging area: the caller's d_w may live there (zkpor_prove_inputs)
+    ZK_TRY(hint_inputs_to(s, instr, s->d_tmp));
+    ZK_HIP(ctx, hipMemcpy(in_values, s->d_tmp, (size_t)cd[1] * sizeof(Fr), hipMemcpyDeviceToHost));
+    return ZKPOR_OK;
 }
 
 /* the same into device memory (d_out: capacity elements): the committed wires of a BSB22 commitment go straight to zkpor_commit_dev */
@@ -363,17 +555,11 @@ int32_t zkpor_solver_external_outputs(zkpor_solver* s, uint32_t instr, const uin
     const uint32_t* cd = s->view.calldata + s->view.arg[instr];
     if (n_out != cd[2]) { ctx->err = "solver: the hint has " + std::to_string(cd[2]) + " outputs"; return ZKPOR_E_ARG; }
     if (n_out) {
-        Fr* d_tmp = nullptr;
-        ZK_HIP(ctx, hipMalloc((void**)&d_tmp, n_out * sizeof(Fr)));
-        int32_t rc = ZKPOR_OK;
-        if (hipMemcpy(d_tmp, out_values, n_out * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "solver: H2D failed"; rc = ZKPOR_E_HIP; }
-        if (rc == ZKPOR_OK) {
-            hipLaunchKernelGGL(k_hint_outputs, dim3(1), dim3(256), 0, ctx->stream, prog_of(s), instr, (const Fr*)d_tmp, (Fr*)s->d_w, s->known);
-            if (hipGetLastError() != hipSuccess) { ctx->err = "solver: launch failed"; rc = ZKPOR_E_HIP; }
-        }
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_tmp);
-        if (rc != ZKPOR_OK) return rc;
+        ZK_TRY(tmp_reserve(s, n_out));
+        ZK_HIP(ctx, hipMemcpyAsync(s->d_tmp, out_values, n_out * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_hint_outputs, dim3(1), dim3(256), 0, ctx->stream, prog_of(s), instr, (const Fr*)s->d_tmp, (Fr*)s->d_w, s->known);
+        ZK_KERNEL_CHECK(ctx);
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // out_values is the caller's memory
     }
     s->pending.erase(s->pending.begin());
     return ZKPOR_OK;
@@ -395,17 +581,17 @@ int32_t zkpor_solver_run(zkpor_solver* s, const uint64_t* inputs, size_t n_input
         if (pre_ids[i] >= nw) { ctx->err = "solver: prefilled wire out of range"; return ZKPOR_E_ARG; }
         memcpy(&hw[4 * (size_t)pre_ids[i]], pre_vals + 4 * i, 32); hk[pre_ids[i]] = 1;
     }
-    Fr* d_w = nullptr; uint8_t* d_k = nullptr;
-    ZK_HIP(ctx, hipMalloc((void**)&d_w, nw * sizeof(Fr)));
-    if (hipMalloc((void**)&d_k, nw) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_w); ctx->err = "solver: out of device memory"; return ZKPOR_E_OOM; }
-    int32_t rc = ZKPOR_OK;
+    struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } tw, tk;   // freed on every path
+    ZK_HIP(ctx, hipMalloc(&tw.p, nw * sizeof(Fr)));
+    ZK_HIP(ctx, hipMalloc(&tk.p, nw));
+    ZK_HIP(ctx, hipMemcpy(tw.p, hw.data(), nw * sizeof(Fr), hipMemcpyHostToDevice));
+    ZK_HIP(ctx, hipMemcpy(tk.p, hk.data(), nw, hipMemcpyHostToDevice));
     uint32_t paused = 0xffffffffu;
-    if (hipMemcpy(d_w, hw.data(), nw * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_k, hk.data(), nw, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "solver: H2D failed"; rc = ZKPOR_E_HIP; }
-    if (rc == ZKPOR_OK) rc = zkpor_solver_start_dev(s, d_w, n_inputs, d_k, &paused);
+    int32_t rc = zkpor_solver_start_dev(s, tw.p, n_inputs, (uint8_t*)tk.p, &paused);
     if (rc == ZKPOR_OK && paused != 0xffffffffu) { s->running = false; ctx->err = "solver: external hint at instruction " + std::to_string(paused) + " (serve it through zkpor_solver_start_dev / _external_* / _resume_dev)"; rc = ZKPOR_E_STATE; }
-    if (rc == ZKPOR_OK && hipMemcpy(w_out, d_w, nw * sizeof(Fr), hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "solver: D2H failed"; rc = ZKPOR_E_HIP; }
-    if (stats) { stats[0] = s->n_r1c; stats[1] = s->n_hint; stats[2] = s->n_skip; stats[3] = s->launches; }
-    (void)hipFree(d_w); (void)hipFree(d_k);
+    if (s->side_busy) { (void)hipStreamSynchronize(s->side); s->side_busy = false; }
+    if (rc == ZKPOR_OK) ZK_HIP(ctx, hipMemcpy(w_out, tw.p, nw * sizeof(Fr), hipMemcpyDeviceToHost));
+    if (stats) { stats[0] = s->n_r1c; stats[1] = s->n_hint + s->n_lookup + s->n_poseidon; stats[2] = s->n_skip; stats[3] = s->launches; }
     return rc;
 }
 

@@ -12,11 +12,14 @@
 
 namespace zk {
 
-enum : uint8_t { HK_NONE = 0, HK_INTDIV = 1, HK_NBITS = 2, HK_INVZERO = 3, HK_DECOMPOSE = 4 };
-enum : u32 { SI_R1C = 0, SI_HINT = 1, SI_SKIP = 2 };
+enum : uint8_t { HK_NONE = 0, HK_INTDIV = 1, HK_NBITS = 2, HK_INVZERO = 3, HK_DECOMPOSE = 4, HK_COUNT = 5 };
+// 3, 4: the gadget instructions of a version-2 container (host/solver_file.hpp): a table lookup (gnark BlueprintLookupHint), a whole
+// poseidon.Poseidon(...) call.  HK_COUNT (gnark logderivarg countHint: millions of inputs) and kind 4 have their own kernels
+// (csrc/solver.hip, csrc/poseidon.hip); solve_instr refuses them.
+enum : u32 { SI_R1C = 0, SI_HINT = 1, SI_SKIP = 2, SI_LOOKUP = 3, SI_POSEIDON = 4 };
 enum : int {
     SE_OK = 0, SE_ROW_RANGE = 10, SE_TWO_UNKNOWN = 11, SE_NOT_SATISFIED = 12, SE_ZERO_COEFF = 13, SE_DIV_ZERO = 14, SE_CALLDATA = 20,
-    SE_NO_HINT = 21, SE_ID_RANGE = 22, SE_INPUT_UNSOLVED = 23, SE_HINT_FAILED = 24
+    SE_NO_HINT = 21, SE_ID_RANGE = 22, SE_INPUT_UNSOLVED = 23, SE_HINT_FAILED = 24, SE_LOOKUP_RANGE = 25, SE_COUNT_TABLE = 26, SE_COUNT_QUERY = 27
 };
 
 // the program and its constraint system, as pointers the executing side can read (device memory for the kernels, host memory for the CPU tests)
@@ -117,11 +120,54 @@ struct U256L {
     }
 };
 
+// a linear expression of the call data at word p (nTerms, (coeffId, wireId)...): its value over the solved wires; p moves behind it.
+// Ids were validated when the program was loaded.
+ZK_HD int si_eval_le(const SolverProg& P, const u32* cd, u64& p, const Fr* w, const uint8_t* known, Fr* out) {
+    const u32 nterms = cd[p++];
+    Fr acc = Fr::zero();
+    for (u32 k = 0; k < nterms; ++k) {
+        const u32 ci = cd[p++], wi = cd[p++];
+        if (!known[wi]) return SE_INPUT_UNSOLVED;
+        si_add_term(acc, P.ckind[ci], P.coeff, ci, w[wi]);
+    }
+    *out = acc;
+    return SE_OK;
+}
+// a field element as an index below `bound` (gnark: Uint64() of the canonical value)
+ZK_HD bool si_index(const Fr& x, u32 bound, u32* out) {
+    const Fr c = Fr::from_mont(x);
+    u32 hi = 0;
+    for (int i = 1; i < 8; ++i) hi |= c.v[i];
+    if (hi || c.v[0] >= bound) return false;
+    *out = c.v[0];
+    return true;
+}
+
 // Executes instruction `ins`: assigns its output wire(s) in w and marks them known.  The instructions of one level are independent: no
 // instruction reads a wire another instruction of the same level assigns, so a level may run in any order or all at once.
 ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known) {
     const u32 kind = P.kind[ins], arg = P.arg[ins];
-    if (kind >= SI_SKIP) return SE_OK;
+    if (kind == SI_SKIP) return SE_OK;
+    if (kind == SI_LOOKUP) {   // outputs = entry[index]: call data blockOff, nbEntries, nQ, firstOut, the index expressions (shapes validated at load)
+        const u32* cd = P.calldata + arg;
+        const u32* tb = P.calldata + cd[0];
+        const u32 nb = cd[1], nq = cd[2], first = cd[3];
+        u64 p = 4;
+        for (u32 q = 0; q < nq; ++q) {
+            Fr ix, v;
+            int rc = si_eval_le(P, cd, p, w, known, &ix);
+            if (rc) return rc;
+            u32 i;
+            if (!si_index(ix, nb, &i)) return SE_LOOKUP_RANGE;            // gnark: "lookup query too large"
+            u64 pe = tb[1 + i];
+            rc = si_eval_le(P, tb, pe, w, known, &v);
+            if (rc) return rc;
+            w[first + q] = v;
+            known[first + q] = 1;
+        }
+        return SE_OK;
+    }
+    if (kind != SI_R1C && kind != SI_HINT) return SE_NO_HINT;             // kind 4 runs in its own kernel
     if (kind == SI_R1C) {
         if (arg >= P.n_constraints) return SE_ROW_RANGE;
         Fr v[3], uc = Fr::zero();
@@ -150,7 +196,12 @@ ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known) {
             else val = Fr::mul(val, fr_inverse(uc));
         } else {
             const Fr& other = v[1 - which];
-            if (other.is_zero()) return SE_DIV_ZERO;                      // gnark: "division by zero" — the wire is not determined
+            if (other.is_zero()) {                                        // gnark solveR1C: nothing to divide by — the constraint must hold as it is,
+                if (!v[2].is_zero()) return SE_DIV_ZERO;                  // (L_known + c x) * 0 = O needs O = 0 (else: "division by zero") ...
+                w[x] = Fr::zero();                                        // ... and the wire stays 0: api.DivUnchecked(0, 0) = 0 (std logderivarg relies on it)
+                known[x] = 1;
+                return SE_OK;
+            }
             const Fr num = Fr::sub(v[2], Fr::mul(v[which], other));       // (L_known + c x) R = O  =>  x = (O - L_known R) / (c R)
             Fr den = other;
             if (uc == Fr::one()) {}
@@ -239,6 +290,7 @@ inline uint8_t hint_kind_of_name(const char* n) {
     if (eq("NBits") || eq("nBits")) return HK_NBITS;
     if (eq("InvZero") || eq("InvZeroHint")) return HK_INVZERO;
     if (eq("DecomposeHint")) return HK_DECOMPOSE;
+    if (eq("countHint")) return HK_COUNT;
     return HK_NONE;
 }
 

@@ -308,7 +308,7 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
             // (L_known + c x) R = O  =>  x = (O - L_known R) / (c R)
             const FrH& other = v[1 - which];
             if (other.is_zero()) {                               // gnark solveR1C: nothing to divide by — the constraint must already hold
-                if (!v[2].is_zero()) return 12;                  // (L_known + c x) * 0 = O needs O = 0 ...
+                if (!v[2].is_zero()) return 14;                  // (L_known + c x) * 0 = O needs O = 0 (else: "division by zero") ...
                 w[x] = FrH::zero(); known[x] = 1;                // ... and then the wire is left at 0: api.DivUnchecked(0, 0) = 0
                 return 0;
             }
