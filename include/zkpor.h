@@ -166,6 +166,12 @@ int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, con
  * n_wires = 2^log2_domain.  The key is NOT a sound Groth16 key; it exercises the prover's data path at scale. */
 int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, size_t n_committed,
                        uint64_t seed);
+/* TEST/BENCH utility: the same generator with a CIRCUIT's sparsity instead of the seeded one — A / B1 / B2 are infinity exactly where
+ * inf_a / inf_b are non-zero (pk.InfinityA / InfinityB: a wire that appears in no L / R row of the constraint system), K at the public
+ * wires and at removed_idx (the committed wires and the commitment wire: gnark r1cs.CommitmentInfo), the Pedersen bases hold n_basis points
+ * (one per committed wire).  What the end-to-end runs of a compiled circuit prove against (bench.py `end_to_end`, tests/test_circuit_gpu.py). */
+int32_t zkpor_pk_synth_masked(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, const uint8_t* inf_a, const uint8_t* inf_b,
+                              const uint32_t* removed_idx, size_t n_removed, size_t n_basis, uint64_t seed);
 /* device pointer + length of a loaded (wire-indexed) array, for tests */
 /* Shape of a loaded key: dims = { n_wires, n_public, n_committed, |Z|, log2_domain, msm_tables }.  What a host caller checks a
  * solver's output against before handing it over (the reference reads the same numbers off r1cs.GetNbConstraints() / the pk,

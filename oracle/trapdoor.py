@@ -112,13 +112,25 @@ class SynthKeyTrapdoor:
     """the discrete logs of one synthetic key against one (w, h): the four dot products are taken once, any number of
     proofs with different blinding (r, s) are then checked with a handful of Fr operations and three fixed-base products"""
 
-    def __init__(self, seed, n_public, w_mont, h_mont, dZ=None):
-        """h_mont: the first len(Z) = D - 1 scalars of h in the key's order; dZ: <sZ, h> from another instance over the same h"""
+    def __init__(self, seed, n_public, w_mont, h_mont, dZ=None, masks=None):
+        """h_mont: the first len(Z) = D - 1 scalars of h in the key's order; dZ: <sZ, h> from another instance over the same h.
+        masks = (inf_a, inf_b, removed_from_k) for a key made by zkpor_pk_synth_masked: byte masks / wire ids instead of the seeded infinity pattern"""
         w = O._u64(w_mont).reshape(-1, 4)
         self.k_alpha = _fr(synth_k(seed, 100, 0)); self.k_beta = _fr(synth_k(seed, 101, 0)); self.k_delta = _fr(synth_k(seed, 102, 0))
-        self.dA = synth_dot(seed, G1_A, w)
-        self.dB = synth_dot(seed, G1_B, w)                       # B1 and B2 carry the same scalars
-        self.dK = synth_dot(seed, G1_K, w, inf_below=n_public)
+        if masks is not None:
+            inf_a, inf_b, removed = masks
+
+            def masked(m):
+                x = w.copy(); x[np.asarray(m, dtype=bool)] = 0
+                return x
+            km = np.zeros(w.shape[0], dtype=bool); km[np.asarray(removed, dtype=np.int64)] = True
+            self.dA = synth_dot(seed, G1_A, masked(inf_a), inf_mod=0)
+            self.dB = synth_dot(seed, G1_B, masked(inf_b), inf_mod=0)
+            self.dK = synth_dot(seed, G1_K, masked(km), inf_mod=0, inf_below=n_public)
+        else:
+            self.dA = synth_dot(seed, G1_A, w)
+            self.dB = synth_dot(seed, G1_B, w)                       # B1 and B2 carry the same scalars
+            self.dK = synth_dot(seed, G1_K, w, inf_below=n_public)
         self.dZ = dZ if dZ is not None else synth_dot(seed, G1_Z, O._u64(h_mont).reshape(-1, 4))   # h in the order of the key's Z
 
     def expected(self, r_mont, s_mont):

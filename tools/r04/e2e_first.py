@@ -7,7 +7,7 @@ for p in (os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd"), os.path.join(ROO
 import zkpor, circuit as C
 import oracle as O, trapdoor as T
 
-def run(shape, compare, seed=0x5A4B504F52):
+def run(shape, compare, seed=0x5A4B504F52, variant=1):
     t0 = time.time()
     inp = C.synth_inputs(*shape)
     t1 = time.time()
@@ -15,6 +15,8 @@ def run(shape, compare, seed=0x5A4B504F52):
     t2 = time.time()
     print(shape, "synth %.2fs compile %.2fs" % (t1 - t0, t2 - t1), {k: cir.dims[k] for k in ("n_wires", "n_constraints", "n_instructions", "n_levels", "n_committed")}, flush=True)
     ctx = zkpor.Context(0)
+    ctx.set_param("solver_poseidon", variant)
+    print("  solver_poseidon =", variant)
     log2 = max(4, int(np.ceil(np.log2(max(cir.n_constraints, 2)))))
     D = 1 << log2
     pk = zkpor.ProvingKey(ctx)
@@ -63,8 +65,8 @@ def run(shape, compare, seed=0x5A4B504F52):
         dc.close(); pk.close(); ctx.close(); cir.close()
 
 if __name__ == "__main__":
-    shapes = [((3, 6, 3), True), ((5, 20, 6), True), ((50, 500, 8), True)]
+    shapes = [((3, 6, 3), True, 1), ((3, 6, 3), True, 0), ((5, 20, 6), True, 1), ((50, 500, 8), True, 1), ((50, 500, 8), False, 0), ((500, 500, 2), True, 1)]
     if len(sys.argv) > 1:
-        shapes = [(tuple(int(x) for x in sys.argv[1:4]), len(sys.argv) > 4)]
-    for sh, cmp_ in shapes:
-        run(sh, cmp_)
+        shapes = [(tuple(int(x) for x in sys.argv[1:4]), len(sys.argv) > 5, int(sys.argv[4]) if len(sys.argv) > 4 else 1)]
+    for sh, cmp_, var in shapes:
+        run(sh, cmp_, variant=var)

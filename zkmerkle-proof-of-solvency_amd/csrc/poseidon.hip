@@ -591,7 +591,170 @@ ZK_D void permute_plain_trace(Fr* st, int t, const PermTab& T, int rp, TraceSink
     }
 }
 #endif
-__global__ __launch_bounds__(64, 2) void k_gadget_poseidon(SolverProg P, const u32* __restrict__ instr, u32 n, Fr* w, uint8_t* known, u32* err, PosDev D) {
+// ---- the same instruction, GROUP-COOPERATIVE (one state spread over lanes): 16 lanes own one call, lane j holds state
+// element j.  Why: a call is a serial chain — 834 permutations for a CEX commitment, 9 for a user's asset commitment, 1 per Merkle level —
+// and a batch has at most a few thousand of them side by side, so the duration of the level is the LATENCY of one call, not throughput.
+// Per permutation one lane runs ~420 dependent products (t^2 + 3t per full round, 3 + 2t - 1 per sparse partial round); spread over the lanes
+// a full round is 3 + t products deep (S-boxes side by side, one matrix row per lane), a partial round 4 (the other lanes' share of the
+// dot product rides in the S-box's first product slot, the cross-lane sum is four DPP row shifts).  The three product wires of every S-box
+// go out through an LDS stash, sixteen conversions to the 8 x 32-bit memory form at a time, one per lane — alone they would double a
+// partial round.  Same tables, same optimised partial rounds, bit-identical wires to k_gadget_poseidon (tests/test_circuit_gpu.py).
+#if defined(__HIP_DEVICE_COMPILE__)
+namespace coop {
+constexpr int G = 16, XS = 152;                    // lanes per call; words per group in the exchange areas (16 x 9 + padding: four groups on distinct banks)
+ZK_D Fr29 ld29(const u32* p) { Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = p[i];
+    return r; }
+template <int N> ZK_D u32 row_shl(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, true); }   // lane i <- lane i + N of its row of 16, else 0
+template <int N> ZK_D Fr29 fold(const Fr29& v) { Fr29 t;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) t.l[i] = row_shl<N>(v.l[i]);
+    return Fr29::normed(Fr29::add_l(v, t)); }
+ZK_D Fr29 row_sum(Fr29 v) { v = fold<8>(v); v = fold<4>(v); v = fold<2>(v); return fold<1>(v); }   // lane 0 of the row: sum of its 16 lanes (tight limbs)
+ZK_D Fr29 from_lane(const Fr29& v, int src_lane) { Fr29 r;                                      // every lane: the value lane src_lane holds
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (u32)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v.l[i]);
+    return r; }
+ZK_D void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+ZK_D void put(u32* row, const Fr29& v) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) row[i] = v.l[i]; }
+// sum_c k[c] * x[c], c < n: constants from this lane's table row (global), operands from the group's exchange area (LDS)
+ZK_D Fr29 dot(const u32* krow, const u32* xs, int n) {
+    Fr29 acc = Fr29::zero();
+    int c = 0;
+    for (; c + 1 < n; c += 2) acc = Fr29::reduce32(Fr29::add_l(acc, Fr29::mul2(ld29(krow + 9 * c), ld29(xs + 9 * c), ld29(krow + 9 * (c + 1)), ld29(xs + 9 * (c + 1)))));
+    if (c < n) acc = Fr29::reduce32(Fr29::add_l(acc, Fr29::mul(ld29(krow + 9 * c), ld29(xs + 9 * c))));
+    return acc;
+}
+}  // namespace coop
+#endif
+// one wave per workgroup, four calls per wave
+__global__ __launch_bounds__(64) void k_gadget_poseidon_coop(SolverProg P, const u32* __restrict__ instr, u32 n, Fr* w, uint8_t* known, u32* err, PosDev D,
+                                                            const Fr* __restrict__ pre, const u32* __restrict__ pre_off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace coop;
+    __shared__ u32 xch[4 * XS], stash[4 * XS];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, base_lane = lane & ~15;
+    const u32 call = blockIdx.x * 4u + g;
+    const bool live = call < n && !err[0];
+    u32* xs = xch + g * XS;
+    u32* ts = stash + g * XS;
+    const u32 ins = live ? instr[call] : 0u;
+    const u32* cd = P.calldata + (live ? P.arg[ins] : 0u);
+    const u32 n_in = live ? cd[0] : 0u, first = live ? cd[1] : 0u, n_out = live ? cd[2] : 0u, carry_lane = live ? ((cd[3] >> 8) & 0xffu) : 0u;
+    const u32 pre_at = (live && pre_off) ? pre_off[call] : 0xffffffffu;   // first element of this call's inputs in `pre`, or none
+    u64 p = 4;                                   // every lane walks the call data (the expressions have no index)
+    Fr29 st = Fr29::zero();                      // lane 0: the capacity element carried from block to block
+    u32 done = 0, sbase = 0;                     // inputs absorbed, S-boxes written so far
+    u32 n_stash = 0, stash_first = 0;            // partial-round wires waiting in the stash: values, first S-box
+    auto flush = [&](u32 count) {                // `count` stashed values -> their wires, one conversion per lane
+        wave_sync();
+        if ((u32)j < count) {
+            const Fr v = Fr29::to32_div32(ld29(ts + 9 * j));
+            w[first + 3u * stash_first + (u32)j] = v;
+        }
+        wave_sync();
+    };
+    // lanes of dead groups run along with n_in = 0 (no loop trips) — the wave stays converged for the DPP / LDS steps of the live ones
+    u32 max_in = n_in;                            // loop bound shared by the wave: the longest call of its four groups
+    max_in = max(max_in, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)max_in));
+    max_in = max(max_in, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)max_in));
+    for (u32 blk = 0; blk * 12u < max_in; ++blk) {
+        const bool act = done < n_in;             // this group still has a block to absorb
+        const u32 k = act ? (n_in - done < 12u ? n_in - done : 12u) : 0u;
+        const int t = (int)k + 1;
+        // absorb: lane 1 + i takes input done + i — from the pre-evaluated inputs of a long call, else the lane evaluates its own expression
+        // (every lane walks the term counts: the expressions carry no index)
+        int bad = 0;
+        if (pre_at != 0xffffffffu) {
+            if (j >= 1 && (u32)j <= k) st = Fr29::from32<5>(pre[pre_at + done + (u32)j - 1u]);
+        } else {
+            for (u32 i = 0; i < k; ++i) {
+                if ((u32)j == i + 1u) {
+                    Fr v;
+                    u64 q = p;
+                    bad = si_eval_le(P, cd, q, w, known, &v);
+                    st = Fr29::from32<5>(v);
+                }
+                p += 1u + 2u * (u64)cd[p];
+            }
+        }
+        if (bad) { if (atomicCAS(&err[0], 0u, (u32)bad) == 0u) err[1] = ins; }
+        if (!act) { if (j) st = Fr29::zero(); }
+        const bool mine = act && j < t;           // this lane holds a state element
+        const int tt = act ? t : 2;               // table width of idle groups: anything valid
+        const u32* b29 = D.tab29;
+        const u32* rc = b29 + 9 * (size_t)D.rc_off[tt];
+        const u32* mm = b29 + 9 * (size_t)D.mds_off[tt];
+        const u32* prc = b29 + 9 * (size_t)D.prc_off[tt];
+        const u32* sp = b29 + 9 * (size_t)D.sp_off[tt];
+        const u32* post = b29 + 9 * (size_t)D.post_off[tt];
+        const int rp = D.rp[tt], jj = j < tt ? j : 0;
+        for (int half = 0; half < 2; ++half) {
+            for (int rr = 0; rr < POS_RF / 2; ++rr) {          // full round: S-boxes side by side, one matrix row per lane
+                const int r = half ? POS_RF / 2 + rp + rr : rr;
+                const Fr29 u = Fr29::reduce32(Fr29::add_l(st, ld29(rc + 9 * (r * tt + jj))));
+                const Fr29 x2 = Fr29::sqr(u), x4 = Fr29::sqr(x2), x5 = Fr29::mul(x4, u);
+                if (mine) {
+                    Fr* o = w + first + 3u * (sbase + (u32)j);
+                    o[0] = Fr29::to32_div32(x2); o[1] = Fr29::to32_div32(x4); o[2] = Fr29::to32_div32(x5);
+                }
+                put(xs + 9 * j, x5);
+                wave_sync();
+                st = dot(mm + 9 * (jj * tt), xs, tt);
+                wave_sync();
+                if (act) sbase += (u32)t;
+            }
+            if (half) break;
+            for (int i = 0; i < rp; ++i) {                       // sparse partial round: 4 products deep
+                const Fr29 s_j = Fr29::reduce32(Fr29::add_l(st, ld29(prc + 9 * (i * tt + jj))));   // lane 0: u = st0 + k0
+                const u32* srow = sp + 9 * (size_t)(i * (2 * tt - 1));
+                const Fr29 ka = ld29(srow + 9 * jj);                                            // lane 0: sp[0] (used in P4), lane j: v_j
+                const Fr29 p1 = Fr29::mul(j == 0 ? s_j : ka, s_j);                               // lane 0: x^2; lane j: v_j * s_j
+                const Fr29 x4 = Fr29::sqr(p1);
+                const Fr29 x5 = Fr29::mul(x4, s_j);                                              // lane 0 only is meaningful
+                if (j == 0 && act) { put(ts + 9 * (3 * n_stash), p1); put(ts + 9 * (3 * n_stash + 1), x4); put(ts + 9 * (3 * n_stash + 2), x5); }
+                const Fr29 X = from_lane(x5, base_lane);
+                const Fr29 kb = j == 0 ? ka : ld29(srow + 9 * (tt + jj - 1));                    // lane 0: m00; lane j: what_j
+                const Fr29 e = Fr29::mul(kb, X);
+                Fr29 dterm = p1;
+                if (j == 0 || j >= tt) dterm = Fr29::zero();
+                const Fr29 Dsum = row_sum(dterm);                                                // lane 0: sum_j v_j s_j
+                st = j == 0 ? Fr29::reduce32(Fr29::add_l(e, Dsum)) : Fr29::add_l(s_j, e);          // loose on lanes j: reduced at the next constant add
+                if (n_stash == 0) stash_first = sbase;
+                if (act) { ++n_stash; ++sbase; }
+                // the wave's groups stash in lockstep only when they run the same width; flush on the fullest
+                u32 fill = n_stash;
+                fill = max(fill, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)fill));
+                fill = max(fill, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)fill));
+                if (fill == 5u) { flush(3u * n_stash); n_stash = 0; }
+            }
+            {   // the dense block left over by the optimised rounds: st[1..t-1] = post * st[1..t-1]
+                u32 fill = n_stash;
+                fill = max(fill, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)fill));
+                fill = max(fill, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)fill));
+                if (fill) { flush(3u * n_stash); n_stash = 0; }
+                const Fr29 sj = Fr29::reduce32(st);
+                put(xs + 9 * j, sj);
+                wave_sync();
+                const Fr29 nv = dot(post + 9 * ((jj ? jj - 1 : 0) * (tt - 1)), xs + 9, tt - 1);
+                if (j) st = nv;
+                wave_sync();
+            }
+        }
+        // the next block's capacity element sits on lane 0
+        const Fr29 cap = from_lane(st, base_lane + (int)carry_lane);
+        if (j == 0) st = cap;
+        if (act) done += k;
+    }
+    if (live) for (u32 q = (u32)j; q < n_out; q += (u32)G) known[first + q] = 1;
+#endif
+}
+
+__global__ __launch_bounds__(64, 2) void k_gadget_poseidon(SolverProg P, const u32* __restrict__ instr, u32 n, Fr* w, uint8_t* known, u32* err, PosDev D,
+                                                          const Fr* __restrict__ pre, const u32* __restrict__ pre_off) {
     const u32 i = blockIdx.x * 64u + threadIdx.x;
     if (i >= n || err[0]) return;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -607,7 +770,9 @@ __global__ __launch_bounds__(64, 2) void k_gadget_poseidon(SolverProg P, const u
         const u32 k = n_in - done < 12u ? n_in - done : 12u;
         const int t = (int)k + 1;
         st[0] = cap;
+        const u32 pre_at = pre_off ? pre_off[i] : 0xffffffffu;
         for (u32 j = 0; j < k; ++j) {
+            if (pre_at != 0xffffffffu) { st[1 + j] = pre[pre_at + done + j]; continue; }
             const int rc = si_eval_le(P, cd, p, w, known, &st[1 + j]);
             if (rc) { if (atomicCAS(&err[0], 0u, (u32)rc) == 0u) err[1] = ins; return; }
         }
@@ -827,11 +992,14 @@ static int32_t pos_dev(zkpor_ctx* ctx, PosDev* P) {
 }
 
 // csrc/solver.hip: n Poseidon instructions (ids in d_instr) of one level, one thread each, on `stream`
-int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverProg& P, const u32* d_instr, u32 n, Fr* w, uint8_t* known, u32* d_err) {
+// d_pre / d_pre_off (may be NULL): inputs evaluated beforehand, pre_off[i] = first element of call i's inputs (0xffffffff: evaluate in the kernel)
+int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverProg& P, const u32* d_instr, u32 n, Fr* w, uint8_t* known, u32* d_err,
+                               const Fr* d_pre, const u32* d_pre_off) {
     if (n == 0) return ZKPOR_OK;
     PosDev D;
     ZK_TRY(pos_dev(ctx, &D));
-    hipLaunchKernelGGL(k_gadget_poseidon, dim3((n + 63u) / 64u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D);
+    if (ctx->solver_poseidon == 0) hipLaunchKernelGGL(k_gadget_poseidon, dim3((n + 63u) / 64u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off);
+    else hipLaunchKernelGGL(k_gadget_poseidon_coop, dim3((n + 3u) / 4u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

@@ -23,13 +23,15 @@
 #include "../host/solver_file.hpp"
 
 namespace zk {
-int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverProg& P, const u32* d_instr, u32 n, Fr* w, uint8_t* known, u32* d_err);   // poseidon.hip
+int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverProg& P, const u32* d_instr, u32 n, Fr* w, uint8_t* known, u32* d_err,
+                               const Fr* d_pre, const u32* d_pre_off);   // poseidon.hip
 }
 
 namespace {
 struct LevelPlan {          // one level of the reordered instruction list: [generic | poseidon | poseidon async | count]
     uint64_t lo = 0;
     uint32_t n_gen = 0, n_pos = 0, n_posa = 0, n_cnt = 0, cnt_first = 0;   // the level's count hints are counts[cnt_first .. + n_cnt)
+    uint32_t posa_first = 0;                                               // its ASYNC calls are asyncs[posa_first .. + n_posa), in list order
     bool external = false;
 };
 struct BigHint {            // a hint whose inputs are addressed through a persisted offset table (count hints, external hints)
@@ -47,6 +49,9 @@ struct zkpor_solver {
     std::vector<uint8_t> hint_kind;             // per hint name id
     std::vector<LevelPlan> plan;
     std::vector<BigHint> counts;                // in level order (the order the levels meet them)
+    std::vector<BigHint> asyncs;                // the ASYNC Poseidon calls, in level order; nb_q = first element of the call's inputs in d_pre
+    uint32_t* d_pre_off = nullptr;              // per ASYNC call (same order): that first element
+    zk::Fr* d_pre = nullptr;                    // their inputs, evaluated all at once in front of the (serial) sponge
     std::map<uint32_t, BigHint> externals;      // by instruction
     uint32_t *d_kind = nullptr, *d_arg = nullptr, *d_level_instr = nullptr, *d_calldata = nullptr, *d_gen_cnt = nullptr, *d_offs = nullptr;
     uint64_t* d_gen_lo = nullptr;
@@ -193,7 +198,7 @@ static SolverProg prog_of(const zkpor_solver* s) {
     return P;
 }
 static void solver_free(zkpor_solver* s) {
-    void* ptrs[] = {s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
+    void* ptrs[] = {s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
                     s->d_cnt, s->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (s->side) (void)hipStreamDestroy(s->side);
@@ -271,7 +276,12 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
             if (L.n_posa) {                       // fork: everything queued so far is visible to the side stream
                 ZK_HIP(ctx, hipEventRecord(s->ev_fork, ctx->stream));
                 ZK_HIP(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
-                ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_pos, L.n_posa, w, s->known, s->d_err));
+                for (u32 k = 0; k < L.n_posa; ++k) {   // the inputs of a long call (10 000 expressions, some a thousand terms long) side by side first
+                    const BigHint& a = s->asyncs[L.posa_first + k];
+                    hipLaunchKernelGGL(k_hint_inputs, dim3((a.n_in + 255u) / 256u), dim3(256), 0, s->side, P, a.ins, s->d_offs + a.offs_base, a.n_in, (const Fr*)w, s->known,
+                                       s->d_pre + a.nb_q, s->d_err);
+                }
+                ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_pos, L.n_posa, w, s->known, s->d_err, s->d_pre, s->d_pre_off + L.posa_first));
                 s->side_busy = true;
                 ++s->launches;
             }
@@ -279,7 +289,7 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                 hipLaunchKernelGGL(k_solve_level, dim3((L.n_gen + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, w, s->known, s->d_err, s->d_ext);
                 ++s->launches;
             }
-            if (L.n_pos) { ZK_TRY(gadget_poseidon_launch(ctx, ctx->stream, P, s->d_level_instr + L.lo + L.n_gen, L.n_pos, w, s->known, s->d_err)); ++s->launches; }
+            if (L.n_pos) { ZK_TRY(gadget_poseidon_launch(ctx, ctx->stream, P, s->d_level_instr + L.lo + L.n_gen, L.n_pos, w, s->known, s->d_err, nullptr, nullptr)); ++s->launches; }
             for (u32 k = 0; k < L.n_cnt; ++k) {   // one after the other: they share the histogram
                 const BigHint& c = s->counts[L.cnt_first + k];
                 const u32* offs = s->d_offs + c.offs_base;
@@ -356,7 +366,7 @@ int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t l
     std::set<std::pair<uint32_t, uint32_t>> tables_ok;   // (block, nbEntries) already validated: a table's entries are checked once, not per lookup
     std::vector<uint32_t> offs;                          // the offset pool of count / external hints
     std::map<uint32_t, BigHint> big;                     // by instruction
-    uint64_t max_table = 1;
+    uint64_t max_table = 1, pre_total = 0;
     auto const_u32 = [&](const uint32_t* cd, uint64_t p, uint32_t* out_v) {   // a constant expression's value (nbTable, nbCols)
         if (cd[p] == 0) { *out_v = 0; return true; }
         if (cd[p] != 1 || cd[p + 2] != 0) return false;
@@ -393,6 +403,14 @@ int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t l
         } else if (kind == SI_POSEIDON) {
             if (!zkpor_host::CheckPoseidonShape(v, arg, nw, ncoef)) return bad("the call data of Poseidon instruction " + std::to_string(i) + " is malformed");
             cls[i] = (v.calldata[arg + 3] & zkpor_host::POSEIDON_ASYNC) ? CL_POSA : CL_POS;
+            if (cls[i] == CL_POSA) {
+                BigHint b;
+                b.ins = (uint32_t)i; b.n_in = v.calldata[arg]; b.offs_base = offs.size(); b.nb_q = pre_total;
+                uint64_t p = 4;
+                for (uint32_t k = 0; k < b.n_in; ++k) { offs.push_back((uint32_t)p); p += 1 + 2ull * v.calldata[arg + p]; }
+                pre_total += b.n_in;
+                big[(uint32_t)i] = b;
+            }
             ++s->n_poseidon;
         } else if (kind == SI_HINT) {
             bool ok = (uint64_t)arg + 3 <= v.n_calldata;
@@ -429,6 +447,7 @@ int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t l
     const uint64_t n_li = v.level_ptr[v.n_levels];
     std::vector<uint32_t> li(n_li), gen_cnt(v.n_levels);
     std::vector<uint64_t> gen_lo(v.n_levels);
+    std::vector<uint32_t> pre_off_host;
     s->plan.resize(v.n_levels);
     for (uint64_t l = 0; l < v.n_levels; ++l) {
         LevelPlan& L = s->plan[l];
@@ -442,8 +461,9 @@ int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t l
                 li[o++] = ins; ++n;
                 if (external[ins]) L.external = true;
                 if (c == CL_CNT) s->counts.push_back(big[ins]);
+                if (c == CL_POSA) { s->asyncs.push_back(big[ins]); pre_off_host.push_back((uint32_t)big[ins].nb_q); }
             }
-            if (c == CL_GEN) L.n_gen = n; else if (c == CL_POS) L.n_pos = n; else if (c == CL_POSA) L.n_posa = n; else { L.n_cnt = n; L.cnt_first = (uint32_t)(s->counts.size() - n); }
+            if (c == CL_GEN) L.n_gen = n; else if (c == CL_POS) L.n_pos = n; else if (c == CL_POSA) { L.n_posa = n; L.posa_first = (uint32_t)(s->asyncs.size() - n); } else { L.n_cnt = n; L.cnt_first = (uint32_t)(s->counts.size() - n); }
         }
         gen_lo[l] = L.lo; gen_cnt[l] = L.n_gen;
         if (L.n_posa && l + 1 >= v.n_levels) return bad("an ASYNC instruction in the last level");
@@ -456,7 +476,8 @@ int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t l
     bool ok = up((void**)&s->d_kind, kinds.data(), v.n_instructions * 4) && up((void**)&s->d_arg, v.arg, v.n_instructions * 4) &&
               up((void**)&s->d_level_instr, li.data(), n_li * 4) && up((void**)&s->d_calldata, v.calldata, v.n_calldata * 4) &&
               up((void**)&s->d_gen_lo, gen_lo.data(), v.n_levels * 8) && up((void**)&s->d_gen_cnt, gen_cnt.data(), v.n_levels * 4) &&
-              up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up((void**)&s->d_hint_kind, s->hint_kind.data(), s->hint_kind.size()) &&
+              up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up((void**)&s->d_pre_off, pre_off_host.data(), pre_off_host.size() * 4) &&
+              hipMalloc((void**)&s->d_pre, (pre_total ? pre_total : 1) * sizeof(Fr)) == hipSuccess && up((void**)&s->d_hint_kind, s->hint_kind.data(), s->hint_kind.size()) &&
               hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 16) == hipSuccess &&
               hipMalloc((void**)&s->d_ext, EXT_CAP * sizeof(u32)) == hipSuccess && hipMalloc((void**)&s->d_cnt, max_table * sizeof(u32)) == hipSuccess &&
               hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&

@@ -750,14 +750,22 @@ inline void Builder::finalize_commitments() {
         for (u32 i = 1; i < nb_col; ++i) coef.push_back(mul(coef[i - 1], cmt));
         const LE challenge = nb_col == 1 ? cmt : mul(coef[nb_col - 1], cmt);
         auto combine = [&](const LE* row) { LE r; for (u32 i = 0; i < nb_col; ++i) r = add(r, mul(coef[i], row[i])); return r; };
-        // a running sum is folded into a fresh wire every kSumChunk terms (gnark adds term by term; one expression of 10^7 terms is
-        // one constraint row nobody can evaluate in parallel)
-        LE lp, rp;
-        auto fold = [&](LE& s) { if (s.size() >= kSumChunk) s = to_wire(s); };
-        for (u32 i = 0; i < a.nb_table; ++i) { add_assign(lp, div_unchecked(wire(a.first_exp + i), sub(challenge, combine(&a.table[(size_t)i * nb_col])))); fold(lp); }
+        // gnark adds term by term into ONE expression; a sum of 10^7 terms is one constraint row nobody can evaluate in parallel, so the
+        // sums are built as trees here: every kSumChunk terms become one wire, the chunk wires are summed the same way (depth log_1024 n)
+        struct SumTree {
+            Builder& b; std::vector<LE> lv;
+            void add(const LE& x, size_t depth = 0) {
+                if (lv.size() <= depth) lv.resize(depth + 1);
+                b.add_assign(lv[depth], x);
+                if (lv[depth].size() >= kSumChunk) { const LE wv = b.to_wire(lv[depth]); lv[depth].clear(); add(wv, depth + 1); }
+            }
+            LE total() { LE r; for (auto& e : lv) r = b.add(r, e); return r; }
+        };
+        SumTree lp{*this, {}}, rp{*this, {}};
+        for (u32 i = 0; i < a.nb_table; ++i) lp.add(div_unchecked(wire(a.first_exp + i), sub(challenge, combine(&a.table[(size_t)i * nb_col]))));
         const size_t nb_q = a.queries.size() / nb_col;
-        for (size_t i = 0; i < nb_q; ++i) { add_assign(rp, inverse(sub(challenge, combine(&a.queries[i * nb_col])))); fold(rp); }
-        assert_eq(lp, rp, "log-derivative sums");
+        for (size_t i = 0; i < nb_q; ++i) rp.add(inverse(sub(challenge, combine(&a.queries[i * nb_col]))));
+        assert_eq(lp.total(), rp.total(), "log-derivative sums");
         a = Arg();
     }
 }

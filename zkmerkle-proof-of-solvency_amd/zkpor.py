@@ -494,6 +494,14 @@ class ProvingKey:
         self.ctx._ck(self.ctx.lib.zkpor_pk_synth(self.h, ctypes.c_int(log2_domain), ctypes.c_size_t(n_wires), ctypes.c_size_t(n_public),
                                                  ctypes.c_size_t(n_committed), ctypes.c_uint64(seed)))
 
+    def synth_masked(self, log2_domain, n_wires, n_public, inf_a, inf_b, removed_idx, n_basis, seed):
+        """the synthetic key with a circuit's sparsity: A / B infinity masks (bytes per wire), the wires K leaves out besides the public ones"""
+        inf_a = np.ascontiguousarray(inf_a, dtype=np.uint8); inf_b = np.ascontiguousarray(inf_b, dtype=np.uint8)
+        removed_idx = np.ascontiguousarray(removed_idx, dtype=np.uint32)
+        assert inf_a.shape[0] == n_wires and inf_b.shape[0] == n_wires
+        self.ctx._ck(self.ctx.lib.zkpor_pk_synth_masked(self.h, ctypes.c_int(log2_domain), ctypes.c_size_t(n_wires), ctypes.c_size_t(n_public), _p(inf_a), _p(inf_b),
+                                                        _p(removed_idx), ctypes.c_size_t(removed_idx.shape[0]), ctypes.c_size_t(n_basis), ctypes.c_uint64(seed)))
+
     def g1_dev(self, which):
         p = ctypes.c_void_p(); n = ctypes.c_size_t()
         self.ctx._ck(self.ctx.lib.zkpor_pk_g1_dev(self.h, ctypes.c_int(which), ctypes.byref(p), ctypes.byref(n)))
