@@ -13,16 +13,25 @@
 // every other blueprint of the R1CS builder (e.g. the lookup blueprint of the bnb fork) is either a solver (BlueprintSolvable: it fills
 // wires itself) or a hint carrier (BlueprintHint).  This exporter flattens that into:
 //
-//	magic "ZKPSOLV\x01"
+//	magic "ZKPSOLV\x02"
 //	u64 nInstructions, nLevels, nHintNames, nCallData
 //	hint names: u32 length + bytes each; pad to 8
-//	u32 kind[nInstructions]   0 = solve constraint arg; 1 = hint, call data at arg; 2 = skipped (wires produced by a device generator)
+//	u32 kind[nInstructions]   0 = solve constraint arg; 1 = hint, call data at arg; 2 = skipped (wires produced by a device generator);
+//	                          3 = table lookup (gnark's BlueprintLookupHint: std/lookup/logderivlookup): call data blockOff, nbEntries, nQ,
+//	                              firstOutWire, the nQ index expressions — the table's entries are written ONCE per table (block at blockOff:
+//	                              nEntries, entryOff[nEntries], the entry expressions), as gnark keeps them once per blueprint;
+//	                          4 = a whole poseidon.Poseidon(...) gadget call (host/solver_file.hpp) — NOT produced here: the gadget leaves no
+//	                              trace in a compiled system (its S-boxes are plain R1C instructions).  A gadget-aware export needs the
+//	                              frontend's cooperation (a marker around std/hash/poseidon calls recording input expressions + the first S-box
+//	                              wire; -skip then covers the constraint instructions and one kind-4 instruction per call takes their place).
+//	                              This repo's own compiler (host/circuit/frontend.hpp) emits kind 4 directly; without the marker the S-boxes run
+//	                              as ~3 x 169 constraint instructions per permutation on the generic executor (correct, deep).
 //	u32 arg[nInstructions]
 //	u64 levelPtr[nLevels+1]; u32 levelInstr[...]; pad to 8
 //	u32 callData[]: per hint  nameId, nIn, nOut, outWire[nOut], then per input  nTerms, (coeffId, wireId)[nTerms]
 //
 // Hint names are the registered function names (solver.GetHintName), e.g. "…/circuit.IntegerDivision", "…/std/math/bits.nBits",
-// "…/constraint/solver.InvZeroHint", "…/std/rangecheck.DecomposeHint", "…/frontend/cs.Bsb22CommitmentComputePlaceholder"; the executors
+// "…/constraint/solver.InvZeroHint", "…/std/rangecheck.DecomposeHint", "…/std/internal/logderivarg.countHint", "…/frontend/cs.Bsb22CommitmentComputePlaceholder"; the executors
 // bind their native implementations by the LAST path element (csrc/solver_instr.cuh hint_kind_of_name, host/solver_exec.hpp HintRegistry).  A hint
 // without one — the BSB22 placeholder — pauses the device run for the caller to serve (zkpor_solver_external_*); the host executor takes it as a closure the caller
 // registers under that name (HintRegistry.by_name).  The wire families a device generator produces are marked with -skip (a file of instruction ids, one per line, written
@@ -92,6 +101,7 @@ func main() {
 	kind := make([]uint32, nIns)
 	arg := make([]uint32, nIns)
 	var callData []uint32
+	tableBlock := map[constraint.BlueprintID]uint32{} // lookup blueprint -> offset of its entry block in callData
 	for i, pi := range r1cs.Instructions {
 		ins := pi.Unpack(&r1cs.System)
 		bp := r1cs.Blueprints[pi.BlueprintID]
@@ -114,8 +124,29 @@ func main() {
 					callData = append(callData, uint32(t.CoeffID()), uint32(t.WireID()))
 				}
 			}
+		case *constraint.BlueprintLookupHint: // a BlueprintSolvable, not a hint carrier: Solve reads the entries + the queries and sets the outputs
+			// ins.Calldata = [len, nbEntries visible to this lookup, nbQueries, the query expressions as (n, (cID, vID) x n)...]
+			block, ok := tableBlock[pi.BlueprintID]
+			if !ok {
+				// the entries once per table: nEntries, entryOff[nEntries] (from the block's first word), then the expressions as gnark compressed them
+				block = uint32(len(callData))
+				tableBlock[pi.BlueprintID] = block
+				ec := b.EntriesCalldata
+				var offs []uint32
+				for p := 0; p < len(ec); p += 1 + 2*int(ec[p]) {
+					offs = append(offs, uint32(p))
+				}
+				callData = append(callData, uint32(len(offs)))
+				for _, o := range offs {
+					callData = append(callData, uint32(1+len(offs))+o)
+				}
+				callData = append(callData, ec...)
+			}
+			kind[i], arg[i] = 3, uint32(len(callData))
+			callData = append(callData, block, ins.Calldata[1], ins.Calldata[2], ins.WireOffset)
+			callData = append(callData, ins.Calldata[3:]...)
 		default:
-			panic(fmt.Sprintf("instruction %d: blueprint %T is neither an R1C nor a hint carrier — extend the exporter", i, bp))
+			panic(fmt.Sprintf("instruction %d: blueprint %T is neither an R1C, a hint carrier nor the lookup blueprint — extend the exporter", i, bp))
 		}
 		if skip[i] {
 			kind[i] = 2
@@ -145,7 +176,7 @@ func main() {
 	for _, l := range r1cs.Levels {
 		nLevelEntries += len(l)
 	}
-	w.WriteString("ZKPSOLV\x01")
+	w.WriteString("ZKPSOLV\x02")
 	n += 8
 	put([]uint64{uint64(nIns), uint64(len(r1cs.Levels)), uint64(len(names)), uint64(len(callData))})
 	for _, s := range names {

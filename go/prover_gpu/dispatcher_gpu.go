@@ -11,7 +11,8 @@
 // tests/test_dispatcher_gpu.py): exactly-once hand-out (status CAS Published -> Received, witness_model.go:129-152), the
 // duplicate-proof guard (prover.go:208-225; a lost CreateProof race reads as "already proved"), Finished after the row is written,
 // rerun = Received first, then Published, with an in-process claim so that N workers do not all take the latest row, and the
-// process ends when no Published row is left.  A tier change (LoadSnarkParamsOnce) stops the world: every worker finishes its
+// process ends when no Published row is left.  Rows of another tier than the loaded one are parked until the feed is drained and then
+// proved tier by tier (one key reload per tier instead of one per interleaving).  A tier change (LoadSnarkParamsOnce) stops the world: every worker finishes its
 // proof, the keys of all GPUs are swapped, proving resumes.
 package prover
 
@@ -45,6 +46,12 @@ type dispatcher struct {
 	claimMu sync.Mutex
 	claimed map[int64]bool // heights held by a worker of this process during a rerun
 	failed  chan error
+	// batches of ANOTHER tier than the loaded one are parked while the feed still hands out work (a tier switch reloads a multi-GB key
+	// on every GPU; with tiers interleaved in the feed several workers would take turns reloading).  The reference never meets the case:
+	// its single loop proves in height order and the witness service writes the tiers one after the other (witness.go:138-206).
+	parkMu  sync.Mutex
+	parked  map[int][]*witness.BatchWitness // by tier; rows already CASed to Received by this process
+	drained bool                            // the feed has ended: parked tiers are proved now, one switch per tier
 }
 
 // RunInProcess is Prover.Run for one process that drives `gpus` with `workersPerGPU` workers each.
@@ -54,7 +61,7 @@ func (p *Prover) RunInProcess(rerun bool, gpus []int, workersPerGPU int) error {
 	}
 	p.proofModel.CreateProofTable()
 	p.GPUs = gpus
-	d := &dispatcher{p: p, claimed: map[int64]bool{}, failed: make(chan error, len(gpus)*workersPerGPU)}
+	d := &dispatcher{p: p, claimed: map[int64]bool{}, parked: map[int][]*witness.BatchWitness{}, failed: make(chan error, len(gpus)*workersPerGPU)}
 	var workers []*gpuWorker
 	for _, g := range gpus {
 		for k := 0; k < workersPerGPU; k++ {
@@ -152,12 +159,74 @@ func (d *dispatcher) runLoop(w *gpuWorker, heights <-chan int64) error {
 			return err
 		}
 		for _, bw := range rows {
+			if d.park(bw) {
+				continue
+			}
 			if err := d.proveAndStore(w, bw); err != nil {
 				return err
 			}
 		}
 	}
-	return nil
+	// the feed is drained: the parked tiers, lowest first; every worker helps, the tier lock makes the switch happen once per tier
+	d.parkMu.Lock()
+	d.drained = true
+	d.parkMu.Unlock()
+	for {
+		bw := d.unpark()
+		if bw == nil {
+			return nil
+		}
+		if err := d.proveAndStore(w, bw); err != nil {
+			return err
+		}
+	}
+}
+
+// tierOfRow: the tier the prover would load for this row (decided by the first user: circuit.SetBatchCreateUserCircuitWitness :363-366)
+func tierOfRow(bw *witness.BatchWitness) int {
+	wc := utils.DecodeBatchWitness(bw.WitnessData)
+	return utils.GetNonEmptyAssetsCountOfUser(wc.CreateUserOps[0].Assets)
+}
+
+// park keeps a row of another tier for later while the feed is still running; false = prove it now
+func (d *dispatcher) park(bw *witness.BatchWitness) bool {
+	cur := d.p.CurrentSnarkParamsInUse
+	if cur == 0 { // nothing loaded yet: the first row decides
+		return false
+	}
+	t := tierOfRow(bw)
+	if t == cur {
+		return false
+	}
+	d.parkMu.Lock()
+	defer d.parkMu.Unlock()
+	if d.drained {
+		return false
+	}
+	d.parked[t] = append(d.parked[t], bw)
+	return true
+}
+
+// unpark hands out the parked rows tier by tier (ascending), nil when none is left
+func (d *dispatcher) unpark() *witness.BatchWitness {
+	d.parkMu.Lock()
+	defer d.parkMu.Unlock()
+	best := -1
+	for t, rows := range d.parked {
+		if len(rows) > 0 && (best < 0 || t < best) {
+			best = t
+		}
+	}
+	if best < 0 {
+		return nil
+	}
+	// rows of the tier that is loaded go first: the other workers are still proving them
+	if rows := d.parked[d.p.CurrentSnarkParamsInUse]; len(rows) > 0 {
+		best = d.p.CurrentSnarkParamsInUse
+	}
+	bw := d.parked[best][0]
+	d.parked[best] = d.parked[best][1:]
+	return bw
 }
 
 func (d *dispatcher) rerunLoop(w *gpuWorker) error {

@@ -10,6 +10,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "zkmerkle-proof
 
 
 def pytest_configure(config):
+    os.environ.setdefault("ZKPOR_TESTING", "1")   # enables the library's test-only hooks (zkpor_set_param "debug_ntt_fault")
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); runs through the C ABI of libzkpor.so")
     # a fresh checkout has no built artefacts (they are git-ignored): build them once (hipcc cross-compiles without a GPU)
     lib = os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd", "libzkpor.so")

@@ -31,7 +31,7 @@ def prove_once(zk, shape, variant, seed=7, compare=True, reps=1):
     try:
         pk.synth_masked(log2, cir.n_wires, cir.n_public, inf_a, inf_b, removed, cir.n_committed, SEED)
         dc = C.DeviceCircuit(zk, cir)
-        bufs = [zk.alloc(32 * n) for n in (cir.n_wires, D, D, D, cir.n_committed)]
+        bufs = [zk.alloc(32 * n) for n in (cir.n_wires, D, D, D, cir.n_committed + 1)]
         for rep in range(reps):
             com, pok, ch = C.solve_on_device(zk, dc, pk, bufs[0].ptr, bufs[4].ptr, inp)
             assert dc.r1cs.check_dev(bufs[0].ptr) == (0, None)
@@ -40,7 +40,7 @@ def prove_once(zk, shape, variant, seed=7, compare=True, reps=1):
             proof = zk.prove_tail_dev(pk, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, rr, ss)
         w = bufs[0].download(np.uint64, (cir.n_wires, 4))
         h = bufs[1].download(np.uint64, (D, 4))
-        cv = bufs[4].download(np.uint64, (cir.n_committed, 4))
+        cv = bufs[4].download(np.uint64, (cir.n_committed + 1, 4))[1:]
         assert np.array_equal(cv, w[cir.committed()])                     # the hint's inputs are the committed wires, in basis order
         ec, ek = T.expected_commitment(SEED, cv)
         assert np.array_equal(com, ec) and np.array_equal(pok, ek)
@@ -90,7 +90,7 @@ def test_a_witness_the_circuit_rejects_is_an_error_not_a_proof(zk):
     pk = zkpor.ProvingKey(zk)
     dc = C.DeviceCircuit(zk, cir)
     log2 = int(np.ceil(np.log2(cir.n_constraints)))
-    bufs = [zk.alloc(32 * cir.n_wires), zk.alloc(32 * cir.n_committed)]
+    bufs = [zk.alloc(32 * cir.n_wires), zk.alloc(32 * (cir.n_committed + 1))]
     try:
         pk.synth(log2, cir.n_wires, cir.n_public, cir.n_committed, SEED)
         meta = 6 + 114 * 6 + 7 * 3

@@ -36,7 +36,7 @@ def load(path, counter):
 def main():
     fetch = load(sys.argv[1], "FETCH_SIZE"); write = load(sys.argv[2], "WRITE_SIZE")
     out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --log2 26 --steps 1 "
-                      "--warmup 0 --timed-only (two separate passes, tools/r03_profile.sh)",
+                      "--warmup 0 --timed-only (two separate passes, tools/rounds/r03_profile.sh)",
            "calibration": "FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 wide coalesced read streams report exactly 1/2 of the true bytes "
                           "(calibrated in round 1 on k_fr_mul: 4.29 GB true reads -> 2.147 GB reported, k_h_pointwise 6.44 -> 3.22; WRITE_SIZE exact), "
                           "as MI355X_MICROARCH.md says; the 64-byte random point gathers of the G1 level-1 kernel are counted 1:1 "

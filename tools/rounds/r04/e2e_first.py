@@ -1,7 +1,7 @@
 """round 4: the compiled BatchCreateUserCircuit solved and proved on the device, first contact (run through gpurun)."""
 import ctypes, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 for p in (os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd"), os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 import zkpor, circuit as C
@@ -25,7 +25,7 @@ def run(shape, compare, seed=0x5A4B504F52, variant=1):
     dc = C.DeviceCircuit(ctx, cir)
     t4 = time.time()
     print("  key %.2fs upload+create %.2fs" % (t3 - t2, t4 - t3), dc.solver.dims(), flush=True)
-    bufs = [ctx.alloc(32 * n) for n in (cir.n_wires, D, D, D, max(1, cir.n_committed))]
+    bufs = [ctx.alloc(32 * n) for n in (cir.n_wires, D, D, D, cir.n_committed + 1)]
     try:
         for rep in range(3):
             tm = {}
@@ -45,7 +45,7 @@ def run(shape, compare, seed=0x5A4B504F52, variant=1):
         print("  constraints failing on the device-solved wires:", bad, flush=True)
         w = bufs[0].download(np.uint64, (cir.n_wires, 4))
         h = bufs[1].download(np.uint64, (D, 4))
-        cv = bufs[4].download(np.uint64, (cir.n_committed, 4))
+        cv = bufs[4].download(np.uint64, (cir.n_committed + 1, 4))[1:]
         assert np.array_equal(cv, w[cir.committed()]), "committed values are not the committed wires"
         ec, ek = T.expected_commitment(seed, cv)
         print("  commitment / pok vs trapdoor:", bool(np.array_equal(com, ec)), bool(np.array_equal(pok, ek)))

@@ -159,7 +159,8 @@ def bsb22_challenge(ctx, commitment_affine):
 
 def solve_on_device(ctx, dc, pk, d_w, d_cv, d_inputs_or_host, timings=None):
     """inputs -> the full wire vector in d_w, serving the BSB22 commitment: returns (commitment, pok, challenge).  d_inputs_or_host: a device
-    pointer (int) to n_inputs Montgomery elements, or a host array (uploaded here).  d_w: n_wires x 32 B, d_cv: n_committed x 32 B."""
+    pointer (int) to n_inputs Montgomery elements, or a host array (uploaded here).  d_w: n_wires x 32 B, d_cv: (1 + n_committed) x 32 B — the
+    placeholder's inputs: the commitment index, then the committed wires (the values zkpor_commit_dev sums start at d_cv + 32)."""
     import time
     c = dc.circuit
     n_in = c.n_public + c.n_secret
@@ -178,9 +179,9 @@ def solve_on_device(ctx, dc, pk, d_w, d_cv, d_inputs_or_host, timings=None):
     t1 = time.perf_counter()
     com = pok = ch = None
     while paused != zkpor.NOT_PAUSED:
-        s.external_inputs_dev(paused, d_cv, c.n_committed)
+        s.external_inputs_dev(paused, d_cv, c.n_committed + 1)
         com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
-        ctx._ck(lib.zkpor_commit_dev(ctx.h, pk.h, vp(d_cv), ctypes.c_size_t(c.n_committed), zkpor._p(com), zkpor._p(pok)))
+        ctx._ck(lib.zkpor_commit_dev(ctx.h, pk.h, vp(d_cv + 32), ctypes.c_size_t(c.n_committed), zkpor._p(com), zkpor._p(pok)))
         ch = bsb22_challenge(ctx, com)
         t2 = time.perf_counter()
         s.external_outputs(paused, ch.reshape(1, 4))

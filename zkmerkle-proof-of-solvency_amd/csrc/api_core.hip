@@ -357,7 +357,11 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
     else if (n == "host_order") { if (value < 0 || value > 1) { ctx->err = "host_order must be 0 or 1"; return ZKPOR_E_ARG; } ctx->host_order = (int)value; }
     else if (n == "copy_chunk_mb") { if (value < 1 || value > 1024) { ctx->err = "copy_chunk_mb must be in [1,1024]"; return ZKPOR_E_ARG; } if (ctx->bounce) bounce_free(ctx); ctx->copy_chunk_mb = (int)value; }
     else if (n == "copy_threads") { if (value < 0 || value > 64) { ctx->err = "copy_threads must be in [0,64]"; return ZKPOR_E_ARG; } if (ctx->bounce) bounce_free(ctx); ctx->copy_threads = (int)value; }
-    else if (n == "debug_ntt_fault") return ntt_debug_fault(ctx, (int)value);   // test-only fault injection (ntt.hip)
+    else if (n == "debug_ntt_fault") {   // test-only fault injection (ntt.hip): flips a bit of a twiddle table — every later proof of the context is wrong
+        const char* t = getenv("ZKPOR_TESTING");
+        if (!t || strcmp(t, "1") != 0) { ctx->err = "debug_ntt_fault is a test hook: set ZKPOR_TESTING=1 in the environment to enable it"; return ZKPOR_E_ARG; }
+        return ntt_debug_fault(ctx, (int)value);
+    }
     else if (n == "poseidon_out_idx") ctx->pos_out = (int)value;
     else if (n == "poseidon_carry_idx") ctx->pos_carry = (int)value;
     else { ctx->err = "unknown parameter " + n; return ZKPOR_E_ARG; }

@@ -32,6 +32,7 @@ struct LevelPlan {          // one level of the reordered instruction list: [gen
     uint64_t lo = 0;
     uint32_t n_gen = 0, n_pos = 0, n_posa = 0, n_cnt = 0, cnt_first = 0;   // the level's count hints are counts[cnt_first .. + n_cnt)
     uint32_t posa_first = 0;                                               // its ASYNC calls are asyncs[posa_first .. + n_posa), in list order
+    uint64_t cnt_rows = 0, cnt_queries = 0;                                // table rows / queries of all its count hints
     bool external = false;
 };
 struct BigHint {            // a hint whose inputs are addressed through a persisted offset table (count hints, external hints)
@@ -58,7 +59,8 @@ struct zkpor_solver {
     uint8_t *d_hint_kind = nullptr, *d_known = nullptr;
     uint32_t* d_err = nullptr;                  // [0] first error code, [1] its instruction, [2] wires never assigned, [3] externals met in the level just run
     uint32_t* d_ext = nullptr;                  // external hint instructions of the level just run (capacity EXT_CAP)
-    uint32_t* d_cnt = nullptr;                  // histogram of the count hint being served (max nb_table entries)
+    uint32_t* d_cnt = nullptr;                  // histograms of the count hints of the level being served (the largest level's table rows)
+    void* d_cmeta = nullptr;                    // zk::CountDev per count hint, level order
     zk::Fr* d_tmp = nullptr;                    // scratch for external hint values (grow-only)
     size_t tmp_cap = 0;
     hipStream_t side = nullptr;                 // ASYNC instructions
@@ -123,48 +125,85 @@ ZK_D void report(u32* err, u32 code, u32 ins) { if (atomicCAS(&err[0], 0u, code)
 // The tables of this circuit carry their own index in column 0 (the range checker: the constants 0 .. 2^w - 1; a lookup table: rows
 // (i, entry_i)), so a query finds its row by that column; the remaining columns are compared.  A table whose column 0 is not 0..n-1, a
 // query outside the table or one that differs from its row fails the hint — as gnark's does ("query element not in table").
-__global__ __launch_bounds__(256) void k_count_table(SolverProg P, u32 ins, const u32* __restrict__ offs, u32 nb_table, u32 nb_col, const Fr* w,
-                                                     const uint8_t* known, u32* err) {
-    const u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= nb_table) return;
-    const u32* cd = P.calldata + P.arg[ins];
-    u64 p = offs[2 + (u64)i * nb_col];
+struct CountDev {            // one count hint of a level, as the kernels see it
+    u32 ins, nb_table, nb_col, cnt_base;   // cnt_base: its histogram inside the level's
+    u64 offs_base, nb_q, row_prefix, q_prefix;   // table rows / queries of the level's hints in front of this one
+};
+// the hint a flat row / query index of the level belongs to (m hints, prefixes ascending)
+ZK_D u32 count_find(const CountDev* __restrict__ cm, u32 m, u64 i, bool queries) {
+    u32 lo = 0, hi = m;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if ((queries ? cm[mid].q_prefix : cm[mid].row_prefix) <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+// all count hints of a level in three launches: one thread per table row, per query, per output
+__global__ __launch_bounds__(256) void k_count_table(SolverProg P, const CountDev* __restrict__ cm, u32 m, u64 total_rows, const u32* __restrict__ offs_pool,
+                                                     const Fr* w, const uint8_t* known, u32* err) {
+    const u64 g = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (g >= total_rows) return;
+    const CountDev c = cm[count_find(cm, m, g, false)];
+    const u32 i = (u32)(g - c.row_prefix);
+    const u32* cd = P.calldata + P.arg[c.ins];
+    const u32* offs = offs_pool + c.offs_base;
+    u64 p = offs[2 + (u64)i * c.nb_col];
     Fr v;
     const int rc = si_eval_le(P, cd, p, w, known, &v);
-    if (rc) { report(err, (u32)rc, ins); return; }
+    if (rc) { report(err, (u32)rc, c.ins); return; }
     u32 idx;
-    if (!si_index(v, nb_table, &idx) || idx != i) report(err, SE_COUNT_TABLE, ins);
+    if (!si_index(v, c.nb_table, &idx) || idx != i) report(err, SE_COUNT_TABLE, c.ins);
 }
-__global__ __launch_bounds__(256) void k_count_queries(SolverProg P, u32 ins, const u32* __restrict__ offs, u32 nb_table, u32 nb_col, u64 nb_q,
+__global__ __launch_bounds__(256) void k_count_queries(SolverProg P, const CountDev* __restrict__ cm, u32 m, u64 total_q, const u32* __restrict__ offs_pool,
                                                        const Fr* w, const uint8_t* known, u32* cnt, u32* err) {
-    const u64 q = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (q >= nb_q) return;
-    const u32* cd = P.calldata + P.arg[ins];
-    const u32* qo = offs + 2 + ((u64)nb_table + q) * nb_col;
-    u64 p = qo[0];
-    Fr v;
-    int rc = si_eval_le(P, cd, p, w, known, &v);
-    if (rc) { report(err, (u32)rc, ins); return; }
-    u32 idx;
-    if (!si_index(v, nb_table, &idx)) { report(err, SE_COUNT_QUERY, ins); return; }
-    const u32* to = offs + 2 + (u64)idx * nb_col;
-    for (u32 c = 1; c < nb_col; ++c) {
-        Fr a, b;
-        u64 pa = qo[c], pb = to[c];
-        rc = si_eval_le(P, cd, pa, w, known, &a);
-        if (!rc) rc = si_eval_le(P, cd, pb, w, known, &b);
-        if (rc) { report(err, (u32)rc, ins); return; }
-        if (a != b) { report(err, SE_COUNT_QUERY, ins); return; }
+    const u64 g = (u64)blockIdx.x * 256u + threadIdx.x;
+    bool pending = false;
+    u32 key = 0;                                  // index of this query's counter in the level's histogram
+    if (g < total_q) {
+        const CountDev c = cm[count_find(cm, m, g, true)];
+        const u64 q = g - c.q_prefix;
+        const u32* cd = P.calldata + P.arg[c.ins];
+        const u32* offs = offs_pool + c.offs_base;
+        const u32* qo = offs + 2 + ((u64)c.nb_table + q) * c.nb_col;
+        u64 p = qo[0];
+        Fr v;
+        int rc = si_eval_le(P, cd, p, w, known, &v);
+        u32 idx = 0;
+        if (!rc && !si_index(v, c.nb_table, &idx)) rc = SE_COUNT_QUERY;
+        if (!rc) {
+            const u32* to = offs + 2 + (u64)idx * c.nb_col;
+            for (u32 k = 1; k < c.nb_col && !rc; ++k) {
+                Fr a, b;
+                u64 pa = qo[k], pb = to[k];
+                rc = si_eval_le(P, cd, pa, w, known, &a);
+                if (!rc) rc = si_eval_le(P, cd, pb, w, known, &b);
+                if (!rc && a != b) rc = SE_COUNT_QUERY;
+            }
+        }
+        if (rc) report(err, (u32)rc, c.ins);
+        else { pending = true; key = c.cnt_base + idx; }
     }
-    atomicAdd(&cnt[idx], 1u);
+    // range-check limbs are mostly 0 (balances far below 2^64, 128-bit checks of small values): millions of increments of ONE counter.  The
+    // lanes of a wave that hit the same counter go through one atomic: a few rounds of leader election catch the frequent values, the rest
+    // increment on their own (a wave of 64 distinct limbs would need 64 rounds).
+    const u32 lane = threadIdx.x & 63u;
+    for (int round = 0; round < 3; ++round) {
+        const u64 act = __ballot(pending);
+        if (!act) break;
+        const int leader = __ffsll((long long)act) - 1;
+        const u32 lkey = (u32)__shfl((int)key, leader, 64);
+        const u64 same = __ballot(pending && key == lkey);
+        if ((int)lane == leader) atomicAdd(&cnt[lkey], (u32)__popcll(same));
+        if (key == lkey) pending = false;
+    }
+    if (pending) atomicAdd(&cnt[key], 1u);
 }
-__global__ __launch_bounds__(256) void k_count_out(SolverProg P, u32 ins, u32 nb_table, const u32* __restrict__ cnt, Fr* w, uint8_t* known) {
-    const u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= nb_table) return;
-    const u32 out = P.calldata[P.arg[ins] + 3 + i];
-    Fr c = Fr::zero();
-    c.v[0] = cnt[i];
-    w[out] = Fr::to_mont(c);
+__global__ __launch_bounds__(256) void k_count_out(SolverProg P, const CountDev* __restrict__ cm, u32 m, u64 total_rows, const u32* __restrict__ cnt, Fr* w, uint8_t* known) {
+    const u64 g = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (g >= total_rows) return;
+    const CountDev c = cm[count_find(cm, m, g, false)];
+    const u32 i = (u32)(g - c.row_prefix);
+    const u32 out = P.calldata[P.arg[c.ins] + 3 + i];
+    Fr v = Fr::zero();
+    v.v[0] = cnt[c.cnt_base + i];
+    w[out] = Fr::to_mont(v);
     known[out] = 1;
 }
 
@@ -198,7 +237,7 @@ static SolverProg prog_of(const zkpor_solver* s) {
     return P;
 }
 static void solver_free(zkpor_solver* s) {
-    void* ptrs[] = {s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
+    void* ptrs[] = {s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
                     s->d_cnt, s->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (s->side) (void)hipStreamDestroy(s->side);
@@ -290,13 +329,12 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                 ++s->launches;
             }
             if (L.n_pos) { ZK_TRY(gadget_poseidon_launch(ctx, ctx->stream, P, s->d_level_instr + L.lo + L.n_gen, L.n_pos, w, s->known, s->d_err, nullptr, nullptr)); ++s->launches; }
-            for (u32 k = 0; k < L.n_cnt; ++k) {   // one after the other: they share the histogram
-                const BigHint& c = s->counts[L.cnt_first + k];
-                const u32* offs = s->d_offs + c.offs_base;
-                ZK_HIP(ctx, hipMemsetAsync(s->d_cnt, 0, (size_t)c.nb_table * sizeof(u32), ctx->stream));
-                hipLaunchKernelGGL(k_count_table, dim3((c.nb_table + 255u) / 256u), dim3(256), 0, ctx->stream, P, c.ins, offs, c.nb_table, c.nb_col, w, s->known, s->d_err);
-                if (c.nb_q) hipLaunchKernelGGL(k_count_queries, dim3((unsigned)((c.nb_q + 255) / 256)), dim3(256), 0, ctx->stream, P, c.ins, offs, c.nb_table, c.nb_col, c.nb_q, w, s->known, s->d_cnt, s->d_err);
-                hipLaunchKernelGGL(k_count_out, dim3((c.nb_table + 255u) / 256u), dim3(256), 0, ctx->stream, P, c.ins, c.nb_table, s->d_cnt, w, s->known);
+            if (L.n_cnt) {                        // every count hint of the level together: rows, queries, outputs
+                const CountDev* cm = (const CountDev*)s->d_cmeta + L.cnt_first;
+                ZK_HIP(ctx, hipMemsetAsync(s->d_cnt, 0, (size_t)L.cnt_rows * sizeof(u32), ctx->stream));
+                hipLaunchKernelGGL(k_count_table, dim3((unsigned)((L.cnt_rows + 255) / 256)), dim3(256), 0, ctx->stream, P, cm, L.n_cnt, L.cnt_rows, s->d_offs, w, s->known, s->d_err);
+                if (L.cnt_queries) hipLaunchKernelGGL(k_count_queries, dim3((unsigned)((L.cnt_queries + 255) / 256)), dim3(256), 0, ctx->stream, P, cm, L.n_cnt, L.cnt_queries, s->d_offs, w, s->known, s->d_cnt, s->d_err);
+                hipLaunchKernelGGL(k_count_out, dim3((unsigned)((L.cnt_rows + 255) / 256)), dim3(256), 0, ctx->stream, P, cm, L.n_cnt, L.cnt_rows, s->d_cnt, w, s->known);
                 s->launches += 3;
             }
             s->next_level = l + 1;
@@ -448,6 +486,7 @@ int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t l
     std::vector<uint32_t> li(n_li), gen_cnt(v.n_levels);
     std::vector<uint64_t> gen_lo(v.n_levels);
     std::vector<uint32_t> pre_off_host;
+    std::vector<CountDev> cmeta;
     s->plan.resize(v.n_levels);
     for (uint64_t l = 0; l < v.n_levels; ++l) {
         LevelPlan& L = s->plan[l];
@@ -465,6 +504,16 @@ int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t l
             }
             if (c == CL_GEN) L.n_gen = n; else if (c == CL_POS) L.n_pos = n; else if (c == CL_POSA) { L.n_posa = n; L.posa_first = (uint32_t)(s->asyncs.size() - n); } else { L.n_cnt = n; L.cnt_first = (uint32_t)(s->counts.size() - n); }
         }
+        for (uint32_t k = 0; k < L.n_cnt; ++k) {
+            const BigHint& c = s->counts[L.cnt_first + k];
+            CountDev d;
+            d.ins = c.ins; d.nb_table = c.nb_table; d.nb_col = c.nb_col; d.cnt_base = (uint32_t)L.cnt_rows;
+            d.offs_base = c.offs_base; d.nb_q = c.nb_q; d.row_prefix = L.cnt_rows; d.q_prefix = L.cnt_queries;
+            cmeta.push_back(d);
+            L.cnt_rows += c.nb_table; L.cnt_queries += c.nb_q;
+        }
+        if (L.cnt_rows >= (1ull << 32)) return bad("count hints of one level cover more than 2^32 table rows");
+        max_table = std::max<uint64_t>(max_table, L.cnt_rows);
         gen_lo[l] = L.lo; gen_cnt[l] = L.n_gen;
         if (L.n_posa && l + 1 >= v.n_levels) return bad("an ASYNC instruction in the last level");
     }
@@ -476,7 +525,7 @@ int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t l
     bool ok = up((void**)&s->d_kind, kinds.data(), v.n_instructions * 4) && up((void**)&s->d_arg, v.arg, v.n_instructions * 4) &&
               up((void**)&s->d_level_instr, li.data(), n_li * 4) && up((void**)&s->d_calldata, v.calldata, v.n_calldata * 4) &&
               up((void**)&s->d_gen_lo, gen_lo.data(), v.n_levels * 8) && up((void**)&s->d_gen_cnt, gen_cnt.data(), v.n_levels * 4) &&
-              up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up((void**)&s->d_pre_off, pre_off_host.data(), pre_off_host.size() * 4) &&
+              up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up(&s->d_cmeta, cmeta.data(), cmeta.size() * sizeof(CountDev)) && up((void**)&s->d_pre_off, pre_off_host.data(), pre_off_host.size() * 4) &&
               hipMalloc((void**)&s->d_pre, (pre_total ? pre_total : 1) * sizeof(Fr)) == hipSuccess && up((void**)&s->d_hint_kind, s->hint_kind.data(), s->hint_kind.size()) &&
               hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 16) == hipSuccess &&
               hipMalloc((void**)&s->d_ext, EXT_CAP * sizeof(u32)) == hipSuccess && hipMalloc((void**)&s->d_cnt, max_table * sizeof(u32)) == hipSuccess &&

@@ -113,6 +113,7 @@ public:
         for (auto& x : pow2_cid_) x = NO_WIRE;
         n_wires_ = n_public + n_secret;
         wire_level_.assign(n_wires_, 0);
+        producer_.assign(n_wires_, NO_WIRE);
         is_bool_.assign(n_wires_, 0);
         if (witness_) {
             val_.resize(n_wires_);
@@ -259,6 +260,7 @@ public:
         calldata_.push_back(name_id); calldata_.push_back((u32)inputs.size()); calldata_.push_back(n_out);
         for (u32 i = 0; i < n_out; ++i) calldata_.push_back(first + i);
         for (auto& e : inputs) push_le(e);
+        for (u32 i = 0; i < n_out; ++i) producer_[first + i] = (u32)kind_.size();
         push_instr(K_HINT, off, lvl);
         std::vector<LE> out;
         for (u32 i = 0; i < n_out; ++i) out.push_back(wire(first + i));
@@ -278,6 +280,7 @@ public:
         const u32 lvl = h.lvl + 1, first = new_wires(h.n_out, lvl);
         for (u32 i = 0; i < h.n_out; ++i) calldata_[h.off + 3 + i] = first + i;
         if (witness_) for (u32 i = 0; i < h.n_out; ++i) val_[first + i] = out_values[i];
+        for (u32 i = 0; i < h.n_out; ++i) producer_[first + i] = (u32)kind_.size();
         push_instr(K_HINT, h.off, lvl);
         return first;
     }
@@ -291,7 +294,7 @@ public:
         for (int m = 0; m < 3; ++m) row_ptr_[m].reserve(constraints + 1);
         cid_[0].reserve(terms * 2 / 5); wid_[0].reserve(terms * 2 / 5); cid_[1].reserve(terms / 2); wid_[1].reserve(terms / 2); cid_[2].reserve(terms / 10); wid_[2].reserve(terms / 10);
         kind_.reserve(constraints); arg_.reserve(constraints); level_.reserve(constraints);
-        wire_level_.reserve(wires); is_bool_.reserve(wires); calldata_.reserve(calldata);
+        wire_level_.reserve(wires); producer_.reserve(wires); is_bool_.reserve(wires); calldata_.reserve(calldata);
     }
     LE is_zero(const LE& a) {   // gnark r1cs IsZero: x = InvZero(a); m = 1 - a x; a m = 0
         FrH k;
@@ -376,6 +379,8 @@ public:
     // witness mode: the value the commitment wire takes (the BSB22 challenge is computed outside the circuit: a multi-exponentiation
     // over the committed wires + a hash to the field, host/bsb22_challenge.hpp; any value satisfies the circuit)
     void set_commitment_value(const FrH& v) { commitment_value_ = v; }
+    // level assignment of finish(): true (default) = as late as possible, false = gnark's as-soon-as-possible levels
+    void set_alap(bool on) { alap_ = on; }
     void finalize_commitments();
     Compiled finish();
 
@@ -393,6 +398,7 @@ private:
     std::unordered_map<FrH, u32, FrKeyHash> coeff_id_;
     std::vector<FrH> val_;
     std::vector<u32> wire_level_;
+    std::vector<u32> producer_;          // per wire: the instruction that assigns it (NO_WIRE: an input)
     std::vector<uint8_t> is_bool_;
     std::vector<u64> row_ptr_[3];
     std::vector<u32> cid_[3], wid_[3];
@@ -408,6 +414,7 @@ private:
     std::vector<u32> committed_;
     u32 commitment_wire_ = NO_WIRE;
     u32 max_level_ = 0;
+    bool alap_ = true;
     u32 pow2_cid_[256];
     std::vector<u32> small_cid_;
     int rc_width_ = 0;
@@ -425,6 +432,7 @@ private:
         if (n_wires_ + n >= 0xfffffff0ull) throw std::runtime_error("circuit: too many wires");
         n_wires_ += n;
         wire_level_.resize(n_wires_, lvl);
+        producer_.resize(n_wires_, NO_WIRE);
         is_bool_.resize(n_wires_, 0);
         if (witness_) val_.resize(n_wires_);
         return first;
@@ -464,7 +472,7 @@ private:
         const LE* sides[3] = {&l, &r, &o};
         for (auto* e : sides) for (u32 i = 0; i < e->size(); ++i) if ((*e)[i].wire != out) lvl = std::max(lvl, wire_level_[(*e)[i].wire]);
         ++lvl;
-        if (out != NO_WIRE) wire_level_[out] = lvl;
+        if (out != NO_WIRE) { wire_level_[out] = lvl; producer_[out] = (u32)kind_.size(); }
         push_row(0, l); push_row(1, r); push_row(2, o);
         const u64 row = row_ptr_[0].size() - 2;
         push_instr(K_R1C, row, lvl);
@@ -550,6 +558,7 @@ inline LE Builder::poseidon(const std::vector<LE>& inputs, bool async, int out_i
         calldata_.push_back((u32)n); calldata_.push_back(base); calldata_.push_back((u32)(3 * total_sbox));
         calldata_.push_back((u32)out_idx | ((u32)carry_idx << 8) | ((async ? 1u : 0u) << 16));
         for (auto& e : inputs) push_le(e);
+        for (size_t i = 0; i < 3 * total_sbox; ++i) producer_[base + i] = (u32)kind_.size();
         push_instr(K_POSEIDON, off, lvl);
     }
     // the constraints, permutation after permutation
@@ -632,6 +641,7 @@ inline std::vector<LE> Builder::table_lookup(int ti, const std::vector<LE>& inds
     calldata_.push_back((u32)T.block_off); calldata_.push_back((u32)T.block_entries); calldata_.push_back(nq); calldata_.push_back(first);
     if (T.block_off >= 0xffffffffull) throw std::runtime_error("circuit: call data beyond 2^32 words");
     for (auto& e : inds) push_le(e);
+    for (u32 i = 0; i < nq; ++i) producer_[first + i] = (u32)kind_.size();
     push_instr(K_LOOKUP, off, lvl);
     std::vector<LE> out;
     for (u32 i = 0; i < nq; ++i) { out.push_back(wire(first + i)); T.q_ind.push_back(inds[i]); T.q_val.push_back(wire(first + i)); }
@@ -738,7 +748,10 @@ inline void Builder::finalize_commitments() {
         std::sort(commit_wires.begin(), commit_wires.end());
         commit_wires.erase(std::unique(commit_wires.begin(), commit_wires.end()), commit_wires.end());
         committed_ = std::move(commit_wires);
-        HintOpen h = hint_open("bsb22CommitmentComputePlaceholder", (u32)committed_.size(), 1);
+        // inputs: the commitment's index, then the committed wires (no public / commitment wire is committed in this circuit) — the layout
+        // host/prove_on_device.hpp and go/zkporgpu/solver.go serve
+        HintOpen h = hint_open("bsb22CommitmentComputePlaceholder", (u32)committed_.size() + 1, 1);
+        hint_input(h, LE());
         for (u32 w : committed_) hint_input(h, wire(w));
         commitment_wire_ = hint_close(h, &commitment_value_);
     }
@@ -773,6 +786,39 @@ inline void Builder::finalize_commitments() {
 inline Compiled Builder::finish() {
     Compiled c;
     c.n_wires = n_wires_; c.n_public = n_public_; c.n_secret = n_secret_; c.n_constraints = n_constraints();
+    // ALAP: the levels recorded so far are gnark's (as soon as possible).  Nothing obliges an executor to them: any order that respects the
+    // dependencies is a valid run, and AS LATE AS POSSIBLE is the better one for a machine that pays per level — the 2 500 sequential
+    // products of the challenge powers (batch_create_user_circuit.go:286-289) each feed one product per user (:304-308), which ASAP spreads
+    // over the 2 500 levels of the chain (1 + U instructions each: 2 500 launches), ALAP collects in one level behind it (the chain itself
+    // becomes a run of one-instruction levels: one launch).  One reverse sweep: an instruction sits one level below its earliest consumer.
+    if (alap_) {
+        std::vector<u32> alap(kind_.size(), max_level_);
+        auto need = [&](u32 wire_id, u32 me, u32 my_level) {
+            const u32 p = producer_[wire_id];
+            if (p != NO_WIRE && p != me && alap[p] >= my_level) alap[p] = my_level - 1;
+        };
+        auto need_le = [&](const u32* cd, u64& p, u32 me, u32 my_level) { const u32 nt = cd[p++]; for (u32 k = 0; k < nt; ++k) { need(cd[p + 1], me, my_level); p += 2; } };
+        for (size_t ii = kind_.size(); ii-- > 0;) {
+            const u32 i = (u32)ii, lv = alap[i];
+            const u32* cd = calldata_.data() + arg_[i];
+            if (kind_[i] == K_R1C) {
+                for (int m = 0; m < 3; ++m) for (u64 t = row_ptr_[m][arg_[i]]; t < row_ptr_[m][arg_[i] + 1]; ++t) need(wid_[m][t], i, lv);
+            } else if (kind_[i] == K_HINT) {
+                u64 p = 3 + (u64)cd[2];
+                for (u32 k = 0; k < cd[1]; ++k) need_le(cd, p, i, lv);
+            } else if (kind_[i] == K_LOOKUP) {
+                const u32* tb = calldata_.data() + cd[0];
+                for (u32 e = 0; e < cd[1]; ++e) { u64 p = tb[1 + e]; need_le(tb, p, i, lv); }
+                u64 p = 4;
+                for (u32 q = 0; q < cd[2]; ++q) need_le(cd, p, i, lv);
+            } else if (kind_[i] == K_POSEIDON) {
+                u64 p = 4;
+                for (u32 k = 0; k < cd[0]; ++k) need_le(cd, p, i, lv);
+            }
+        }
+        for (size_t i = 0; i < kind_.size(); ++i) level_[i] = alap[i];
+        producer_.clear(); producer_.shrink_to_fit();
+    }
     // levels: counting sort of the instructions by level; deferred assertions go behind everything else
     const u32 last = max_level_ + 1;
     for (u32 i : deferred_asserts_) level_[i] = last;
