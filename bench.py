@@ -874,6 +874,155 @@ def split_main(args, torch, zkpor, ctx, dist, rank, world, json_fd):
     pk.close()
 
 
+def circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, shape, tier_name, seed, steps, e2e_steps, blinding, tables_used):
+    """One production tier as the COMPILED circuit, start to finish and then freed: synthetic valid batch -> compile -> key with the circuit's
+    sparsity -> matrices + program on the device -> one solve for the generated w / a / b / c / committed values -> a timed region of prove
+    tails (same contract as the headline) -> a timed end-to-end region -> every proof checked (r1cs check on the device, h by the quotient
+    identity, Ar / Bs / Krs / commitment against the trapdoor).  Used for the tier the headline is NOT measured on (BASELINE.json configs[1] /
+    configs[2] both in one line); the headline tier's code in main() is the same sequence spread over its regions."""
+    import numpy as np
+    import circuit as C
+    import oracle as O
+    import trapdoor as T
+    lib = ctx.lib
+    vp = ctypes.c_void_p
+    ck = ctx._ck
+    t0 = time.perf_counter()
+    inp = C.synth_inputs(*shape, seed=17 + rank)
+    cir = C.Circuit(*shape)
+    t1 = time.perf_counter()
+    log2 = max(10, int(np.ceil(np.log2(cir.n_constraints))))
+    D = 1 << log2
+    n_wires, n_commit, n_public = cir.n_wires, cir.n_committed, cir.n_public
+    inf_a, inf_b = cir.infinity_masks()
+    removed = np.concatenate([cir.committed(), np.array([cir.commitment_wire], dtype=np.uint32)])
+    pk = zkpor.ProvingKey(ctx)
+    dc = None
+    try:
+        pk.synth_masked(log2, n_wires, n_public, inf_a, inf_b, removed, n_commit, seed)
+        t2 = time.perf_counter()
+        dc = C.DeviceCircuit(ctx, cir)
+
+        def dev(nbytes):
+            return torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+
+        ws = [dev(32 * n_wires), dev(32 * n_wires)]
+        a0 = dev(32 * D); b0 = dev(32 * D); c0 = dev(32 * D); a = dev(32 * D); b = dev(32 * D); c = dev(32 * D)
+        cv_in = dev(32 * (n_commit + 1)); cv2 = dev(32 * (n_commit + 1))
+        d_in = dev(inp.nbytes)
+        ck(lib.zkpor_dev_upload(ctx.h, vp(d_in.data_ptr()), zkpor._p(inp), ctypes.c_size_t(inp.nbytes)))
+        w = ws[0]
+        C.solve_on_device(ctx, dc, pk, w.data_ptr(), cv_in.data_ptr(), d_in.data_ptr())
+        bad = dc.r1cs.check_dev(w.data_ptr())[0]
+        dc.r1cs.eval_dev(w.data_ptr(), a0.data_ptr(), b0.data_ptr(), c0.data_ptr(), D)
+        ctx.sync()
+        t3 = time.perf_counter()
+        proofs = []
+
+        def tail(i, sink):
+            com = np.empty(8, np.uint64); pok = np.empty(8, np.uint64)
+            ck(lib.zkpor_commit_dev(ctx.h, pk.h, vp(cv_in.data_ptr() + 32), ctypes.c_size_t(n_commit), zkpor._p(com), zkpor._p(pok)))
+            r, s_ = blinding(i)
+            proof = ctx.prove_tail_dev_keep(pk, w.data_ptr(), a0.data_ptr(), b0.data_ptr(), c0.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), r, s_)
+            if sink is not None:
+                sink.append((i, proof, com, pok))
+
+        tail(20000, None)
+        torch.cuda.synchronize()
+
+        def region():
+            for i in range(steps):
+                tail(20001 + i, proofs)
+            torch.cuda.synchronize()
+
+        dt = timed_region(dist, torch.cuda.synchronize, region)
+        # end to end, the next proof's hash chains prefetched (as in the headline's region)
+        n_in_wires = n_public + cir.n_secret
+        wx = ws[1]
+        eproofs = []
+        state = {"k": 0}
+        bufs2 = [w, wx]
+
+        def e2e(i, sink):
+            cur = bufs2[1 - state["k"] % 2]; nxt = bufs2[state["k"] % 2]      # starts on wx: w stays the headline vector until the checks are done
+            state["k"] += 1
+            com, pok, _ = C.solve_on_device(ctx, dc, pk, cur.data_ptr(), cv2.data_ptr(), d_in.data_ptr(), None, staged=True)
+            C.stage_inputs(ctx, dc, nxt.data_ptr(), d_in.data_ptr())
+            dc.solver.prefetch_dev(nxt.data_ptr(), n_in_wires)
+            dc.r1cs.eval_dev(cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), D)
+            r, s_ = blinding(i)
+            proof = ctx.prove_tail_dev(pk, cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), r, s_)
+            state["last"] = cur
+            if sink is not None:
+                sink.append((i, proof, com, pok))
+
+        e2e_res = None
+        h_src = a          # prove_tail_dev_keep left h in a; the e2e region overwrites it with the same h (same a, b, c)
+        w_host = np.empty((n_wires, 4), np.uint64)
+        ck(lib.zkpor_dev_download(ctx.h, zkpor._p(w_host), vp(w.data_ptr()), ctypes.c_size_t(w_host.nbytes)))      # before the e2e region reuses w
+        if e2e_steps > 0:
+            C.stage_inputs(ctx, dc, wx.data_ptr(), d_in.data_ptr())
+            dc.solver.prefetch_dev(wx.data_ptr(), n_in_wires)
+            e2e(30000, None)
+            torch.cuda.synchronize()
+
+            def eregion():
+                for i in range(e2e_steps):
+                    e2e(30001 + i, eproofs)
+                torch.cuda.synchronize()
+
+            dte = timed_region(dist, torch.cuda.synchronize, eregion)
+            last = state["last"]
+            w_last = np.empty((n_wires, 4), np.uint64)
+            ck(lib.zkpor_dev_download(ctx.h, zkpor._p(w_last), vp(last.data_ptr()), ctypes.c_size_t(w_last.nbytes)))
+            e2e_res = {"value": world * e2e_steps / dte, "ms_per_proof": dte / e2e_steps * 1e3, "steps": e2e_steps,
+                       "same_wires_as_tail_region": bool(np.array_equal(w_last, w_host)), "constraints_failing_on_device": dc.r1cs.check_dev(last.data_ptr())[0]}
+            del w_last
+            ctx.sync()
+        # checks
+        def host(t, n):
+            out = np.empty((n, 4), dtype=np.uint64)
+            ck(lib.zkpor_dev_download(ctx.h, zkpor._p(out), vp(t.data_ptr()), ctypes.c_size_t(out.nbytes)))
+            return out
+        h_full = host(h_src, D)
+        tau = O.fr_random(0x7B0 + rank, 1)[0]
+        h_ok = bool(O.quotient_identity(log2, host(a0, D), host(b0, D), host(c0, D), h_full, tau))
+        td = T.SynthKeyTrapdoor(seed, n_public, w_host, h_full[: D - 1], masks=(inf_a, inf_b, removed))
+        ec, ek = T.expected_commitment(seed, host(cv_in, n_commit + 1)[1:])
+        ok = 0
+        for i, proof, com, pok in proofs:
+            r, s_ = blinding(i)
+            ok += int(h_ok and bad == 0 and td.check(proof, r, s_) and np.array_equal(com, ec) and np.array_equal(pok, ek))
+        eok = 0
+        for i, proof, com, pok in eproofs:
+            r, s_ = blinding(i)
+            eok += int(h_ok and e2e_res["same_wires_as_tail_region"] and e2e_res["constraints_failing_on_device"] == 0 and td.check(proof, r, s_)
+                       and np.array_equal(com, ec) and np.array_equal(pok, ek))
+        if e2e_res is not None:
+            e2e_res["checked"] = {"proofs": len(eproofs), "ok": eok}
+        wc = np.empty_like(w_host)
+        O.lib().orc_fr_to_canon(O._p(w_host), O._p(wc), ctypes.c_size_t(n_wires))
+        hi = (wc[:, 1] | wc[:, 2] | wc[:, 3]) != 0
+        lo = wc[:, 0]
+        n01 = int(((~hi) & (lo <= 1)).sum()); n16 = int(((~hi) & (lo > 1) & (lo < (1 << 16))).sum()); n64 = int(((~hi) & (lo >= (1 << 16))).sum())
+        mix = {"in_{0,1}": round(n01 / n_wires, 4), "below_2^16": round(n16 / n_wires, 4), "below_2^64": round(n64 / n_wires, 4), "wider": round(1.0 - (n01 + n16 + n64) / n_wires, 4)}
+        lv = cir.level_sizes()
+        return {"value": world * steps / dt, "unit": "proofs/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "scalars": "generated",
+                "scalar_mix_measured": mix, "users_per_batch": shape[2], "assets_per_user": shape[0],
+                "circuit": {"constraints": cir.n_constraints, "log2_domain": log2, "wires": n_wires, "committed_wires": n_commit, "instructions": cir.n_instructions,
+                            "levels": int(len(lv))},
+                "end_to_end": e2e_res, "checked": {"proofs": len(proofs), "ok": ok, "h_verified": h_ok},
+                "setup_seconds": {"batch_and_compile": round(t1 - t0, 2), "key": round(t2 - t1, 2), "upload_and_first_solve": round(t3 - t2, 2)},
+                "key_tables": tables_used,
+                "note": f"BASELINE.json {tier_name}: its own compiled circuit, its own key (the circuit's sparsity), generated scalars; prove-tail region and "
+                        "end-to-end region under the same barrier / sync contract as the headline"}
+    finally:
+        if dc is not None:
+            dc.close()
+        pk.close(); cir.close()
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -934,6 +1083,7 @@ def main():
                     "w, a, b, c and the committed values come from solving a synthetic batch on the device, the key carries the circuit's sparsity, and the "
                     "line gains `end_to_end`.  Default at --log2 26: the tier's production shape (50,500,1380 / 500,500,200)")
     ap.add_argument("--no-circuit", action="store_true", help="the round-1..3 workload: D = n_wires = 2^log2, estimated scalar mixture, seeded key sparsity")
+    ap.add_argument("--no-prefetch", action="store_true", help="end-to-end region: do not start the next proof's CEX commitment chains under the current proof's prove tail")
     ap.add_argument("--e2e-steps", type=int, default=-1, help="proofs of the end-to-end region (inputs -> solver program -> commitment -> a, b, c -> prove tail); default max(3, steps // 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
@@ -1040,6 +1190,22 @@ def main():
         circuit_shape = tuple(int(x) for x in args.circuit.split(","))
     elif log2 == 26 and not args.no_circuit:
         circuit_shape = (cfg["assets"], 500, cfg["users"])
+    other_name = "zkpor500_200" if args.config == "zkpor50_1380" else "zkpor50_1380"
+    other_gen = None
+    if circuit_shape is not None and not args.circuit and not args.timed_only and args.scalars == "witness" and args.other_config_steps != 0:
+        # the other production tier first, on its own compiled circuit and key, then freed (two 4-table keys do not fit side by side)
+        def blinding_o(i):
+            g = np.random.default_rng(0xB11D + 7919 * i + rank)
+            v = g.integers(0, 1 << 60, size=8, dtype=np.uint64)
+            return v[:4].copy(), v[4:].copy()
+        osteps_g = args.other_config_steps if args.other_config_steps > 0 else max(5, args.steps // 4)
+        oshape = (CONFIGS[other_name]["assets"], 500, CONFIGS[other_name]["users"])
+        try:
+            other_gen = circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, oshape, other_name, seed, osteps_g,
+                                         args.e2e_steps if args.e2e_steps >= 0 else 3, blinding_o, args.tables)
+        except Exception as e:
+            other_gen = None
+            print(f"bench.py: the generated leg of {other_name} failed ({e}); falling back to the estimated mixture on the headline key", file=sys.stderr)
     pk = zkpor.ProvingKey(ctx)
     tables_used = args.tables
     n_public = 3
@@ -1220,9 +1386,8 @@ def main():
     other_cfg = None
     oproofs = []
     w_o = cv_o = None
-    other_name = "zkpor500_200" if args.config == "zkpor50_1380" else "zkpor50_1380"
     osteps = args.other_config_steps if args.other_config_steps >= 0 else max(5, args.steps // 4)
-    if args.scalars == "witness" and osteps > 0 and not args.timed_only:
+    if args.scalars == "witness" and osteps > 0 and not args.timed_only and other_gen is None:
         okind = CONFIGS[other_name]["fill_kind"]
         w_o = dev(32 * n_wires); cv_o = dev(32 * n_commit)
         ck(lib.zkpor_dev_fill_fr(ctx.h, vp(w_o.data_ptr()), ctypes.c_size_t(n_wires), ctypes.c_uint64(2 + rank), ctypes.c_int(okind)))
@@ -1279,21 +1444,39 @@ def main():
         esteps = args.e2e_steps if args.e2e_steps >= 0 else max(3, args.steps // 4)
         if esteps > 0:
             dc = circ["dc"]
-            w2 = dev(32 * n_wires); cv2 = dev(32 * (n_commit + 1))
+            w2s = [dev(32 * n_wires), dev(32 * n_wires)]; cv2 = dev(32 * (n_commit + 1))
+            w2 = w2s[0]
             tm_acc = {}
+            n_in_wires = circ["cir"].n_public + circ["cir"].n_secret
+            prefetch = not args.no_prefetch
+            state = {"k": 0}
 
             def e2e_proof(i):
+                # two wire vectors take turns: while proof i runs a, b, c and its prove tail, the NEXT proof's assignment is already in the other
+                # one and its two CEX commitment chains (834 serial permutations each: ~0.2 s of one wave) run on the solver's side stream
+                # (zkpor_solver_prefetch_dev) — what a prover loop does with the next witness row it already holds
                 tm = {}
                 t0_ = time.perf_counter()
-                com, pok, _ch = C.solve_on_device(ctx, dc, pk, w2.data_ptr(), cv2.data_ptr(), circ["d_in"].data_ptr(), tm)
+                cur = w2s[state["k"] % 2]; nxt = w2s[(state["k"] + 1) % 2]
+                state["k"] += 1
+                if not prefetch:
+                    C.stage_inputs(ctx, dc, cur.data_ptr(), circ["d_in"].data_ptr())
+                com, pok, _ch = C.solve_on_device(ctx, dc, pk, cur.data_ptr(), cv2.data_ptr(), circ["d_in"].data_ptr(), tm, staged=True)
                 t1_ = time.perf_counter()
-                dc.r1cs.eval_dev(w2.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), D)
+                if prefetch:
+                    C.stage_inputs(ctx, dc, nxt.data_ptr(), circ["d_in"].data_ptr())
+                    dc.solver.prefetch_dev(nxt.data_ptr(), n_in_wires)
+                dc.r1cs.eval_dev(cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), D)
                 r, s = blinding(i)
-                proof = ctx.prove_tail_dev(pk, w2.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), r, s)
+                proof = ctx.prove_tail_dev(pk, cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), r, s)
                 tm["abc_and_prove_tail_ms"] = (time.perf_counter() - t1_) * 1e3
                 tm["total_ms"] = (time.perf_counter() - t0_) * 1e3
+                state["last"] = cur
                 return proof, com, pok, tm
 
+            if prefetch:
+                C.stage_inputs(ctx, dc, w2s[0].data_ptr(), circ["d_in"].data_ptr())
+                dc.solver.prefetch_dev(w2s[0].data_ptr(), n_in_wires)
             e2e_proof(9000)                                   # warm-up
             torch.cuda.synchronize()
             ctx.phase_reset()
@@ -1322,9 +1505,12 @@ def main():
                            "constraint count within 7 % of the reference's README), a synthetic VALID batch (its hashes are the oracle's), inputs resident "
                            "in HBM, solver program + BSB22 commitment + a, b, c + prove tail on the device; the challenge is hashed on the host"}
             # the solved wire vector of the LAST e2e proof must be the one the headline proofs used (same inputs, same commitment, same challenge)
+            w2 = state["last"]
+            e2e["next_proofs_hash_chains_prefetched"] = prefetch
             e2e["same_wires_as_headline"] = bool(torch.equal(w2, w)) if args.scalars == "witness" else None
             e2e["constraints_failing_on_device"] = dc.r1cs.check_dev(w2.data_ptr())[0]
-            del w2, cv2
+            ctx.sync()
+            del w2, w2s, cv2, state
 
     # ---- every timed proof is verified, untimed: prove, then verify (prover.go:269-276).  The synthetic key is trapdoor-known, so
     # Ar / Bs / Krs and the two commitment sums are checked in the exponent at the exact size and mixture that was timed
@@ -1397,6 +1583,9 @@ def main():
             total += len(oproofs)
             other_cfg["checked"] = {"proofs": len(oproofs), "ok": oko}
             del tdo
+        if other_gen is not None:     # the other tier's generated leg checked its own proofs (its own key and wires)
+            ok += other_gen["checked"]["ok"] + (other_gen["end_to_end"]["checked"]["ok"] if other_gen["end_to_end"] else 0)
+            total += other_gen["checked"]["proofs"] + (other_gen["end_to_end"]["checked"]["proofs"] if other_gen["end_to_end"] else 0)
         per_rank_checked = [[int(x) for x in row] for row in gather_per_rank(dist, [ok, total])]
         if other_cfg is not None and "checked" in other_cfg and dist is not None:
             rows = gather_per_rank(dist, [other_cfg["checked"]["ok"], other_cfg["checked"]["proofs"]])
@@ -1417,22 +1606,32 @@ def main():
 
     if rank == 0:
         # launches of k_acc_level1_fp29 per proof: A, B1, K, Z (n ~ D points each) + 2 commitment MSMs (n/4 points)
-        units_bytes = (4 * n_wires + 2 * n_commit) * 96.0 / 6.0  # mean algorithmic bytes per launch
+        units_bytes = (3 * n_wires + D + 2 * n_commit) * 96.0 / 6.0  # mean algorithmic bytes per launch: A, B1, K over the wires, Z over the domain, 2 commitment sums
         avg_launch_s = (k1_ms / max(1, k1_calls)) * 1e-3
         achieved = units_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         bproof = algorithmic_bytes_per_proof(log2, n_wires, n_commit)
         tb, tsrc = pmc_traffic_bytes_per_launch()
-        profiled_cfg = log2 == 26 and args.scalars == "witness" and args.config == "zkpor50_1380" and not args.window and not args.chunk and tables_used == 4
+        # the committed PMC passes (profiles/r04_*) were taken on the default workload: the compiled zkpor50_1380 circuit, generated scalars, 4 tables
+        profiled_cfg = circ is not None and not args.circuit and log2 == 26 and args.scalars == "witness" and args.config == "zkpor50_1380" and not args.window and not args.chunk and tables_used == 4
+        # SURVEY §8d counts n_i = D per multi-exponentiation; the loaded key's real array lengths give the exact figure
+        if td_masks is not None:
+            n_a = n_wires - int(td_masks[0].sum()); n_b1 = n_wires - int(td_masks[1].sum()); n_k = n_wires - n_public - len(td_masks[2])
+        else:
+            n_a = n_wires - n_wires // 64; n_b1 = n_wires - n_wires // 10; n_k = n_wires - n_wires // 4
+        units_bytes_exact = (n_a + n_b1 + n_k + (D - 1) + 2 * n_commit) * 96.0 / 6.0
+        clock_ghz = 1.949     # profiles/r04_clock.txt: GRBM_GUI_ACTIVE / wall time of k_acc_level1_fp29 (power-limited; nominal 2.4)
         traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and profiled_cfg) else None
         vb_ms, vsrc = pmc_valu_issue_bound_ms()
         cw, cwsrc = valu_class_weight()
         valu = ({"issue_bound_ms_per_launch": vb_ms, "frac": vb_ms / (avg_launch_s * 1e3),
                  "frac_class_weighted": (vb_ms * cw / (avg_launch_s * 1e3)) if cw else None,
+                 "measured_clock_ghz": clock_ghz, "frac_at_measured_clock": vb_ms / (avg_launch_s * 1e3) * 2.4 / clock_ghz,
+                 "frac_class_weighted_at_measured_clock": (vb_ms * cw / (avg_launch_s * 1e3) * 2.4 / clock_ghz) if cw else None,
                  "source": f"profiles/{vsrc}: SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz nominal) / live avg launch time; "
                            f"class-weighted: the same count priced per instruction class (profiles/{cwsrc}: 24 % of the kernel's VALU "
                            "instructions are simple 32-bit ops that issue in 2 cycles when they come in runs, the rest 4 — measured per class in "
-                           "profiles/r03_valu_class.txt).  The part runs this kernel at ~2.05 GHz, not 2.4 (SQ_BUSY_CYCLES per ms, "
-                           "profiles/r01_pmc_valu_utilisation.txt): at the clock it gets, frac is ~0.9"}
+                           "profiles/r03_valu_class.txt).  The part runs this kernel at 1.95 GHz, not 2.4 (GRBM_GUI_ACTIVE per wall-clock ms, re-measured on the round-4 "
+                           "binary: profiles/r04_clock.txt; the G2 kernel 2.15, NTT passes 2.07-2.29): *_at_measured_clock price the same counts at that clock"}
                 if (vb_ms and avg_launch_s > 0 and profiled_cfg) else None)
         main_stream = ("k_acc_level1_g1", "k_acc_level1_g2", "msm_accumulate", "msm_reduce", "ntt", "pointwise", "host_assembly")
         out = {
@@ -1469,12 +1668,14 @@ def main():
             "value_uniform": uni["value"] if uni else None,
             "uniform": ({**uni, "note": "same step with every witness scalar uniform in Fr (worst case; the witness mixture is an estimate)"}
                         if uni else None),
-            "configs": ({other_name: other_cfg} if other_cfg else None),
+            "configs": ({other_name: other_gen} if other_gen else ({other_name: other_cfg} if other_cfg else None)),
             "two_in_flight": two,
             "end_to_end": e2e,
             "checked": checked,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_exact_array_sizes": (units_bytes_exact / avg_launch_s / 1e9 / HBM_PEAK_GBS) if avg_launch_s > 0 else None,
+                         "array_sizes": {"A": n_a, "B1": n_b1, "K": n_k, "Z": D - 1, "commit_bases": n_commit, "n_wires": n_wires},
                          "traffic_source": (f"profiles/{tsrc}: {tb / 1e9:.1f} GB HBM bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, "
                                             "gfx950-calibrated) / live avg launch time; the bucket method re-reads each 64 B point once per "
                                             "non-zero digit, hence traffic > algorithmic bytes") if traffic else None,

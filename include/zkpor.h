@@ -349,6 +349,8 @@ int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r1cs, int which, const uint64_t* row_p
 /* device buffers: w (n_wires Fr) in; a, b, c (domain_size Fr each) out, rows >= n_constraints written as zero (the
  * padding zkpor_compute_h_dev / zkpor_prove_tail_dev expect); asynchronous on the context's stream */
 int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r1cs, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size);
+/* the same on another context of the GPU the matrices live on (a second worker: its stream, its timers) */
+int32_t zkpor_r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size);
 /* the solver's final check on the device: counts[0] = constraints with L.w * R.w != O.w for the wire vector d_w, counts[1] = the lowest
  * such row (2^64 - 1 when none).  What gnark's solver guarantees by construction has to be CHECKED when wires come from elsewhere (the
  * structured generators): a skipped instruction's constraint is only ever seen here.  Synchronous. */
@@ -469,10 +471,12 @@ int32_t zkpor_witgen_scatter_known_dev(zkpor_ctx* ctx, void* d_w, uint8_t* d_kno
  * and the result feeds zkpor_r1cs_eval_dev / zkpor_commit_dev / zkpor_prove_tail_dev. */
 typedef struct zkpor_solver zkpor_solver;
 /* `r1cs` (all three matrices loaded) must outlive the solver; the container is copied and validated (ZKPOR_E_ARG).
- * THREADING: a solver's launches, phase timers and error text belong to the context its R1CS was created on — solvers of one R1CS
- * context must not RUN concurrently from several threads (the matrices themselves are only read: zkpor_r1cs_eval_dev on any context of
- * the GPU is fine).  A prover with two workers per GPU serialises its solver runs or gives each worker's context its own zkpor_r1cs. */
+ * THREADING: a solver's launches, phase timers and error text belong to ONE context — zkpor_solver_create binds it to the context its R1CS
+ * was created on, zkpor_solver_create_on to any context of the same GPU.  A solver is single-caller like its context; a prover with two
+ * workers per GPU creates one solver per worker context over ONE constraint-system handle (the matrices are only read; the program, ~2 GB at 2^26, is
+ * copied per solver) and the workers solve side by side (tests/test_circuit_gpu.py). */
 int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* solver_container, size_t len, zkpor_solver** out);
+int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* solver_container, size_t len, zkpor_solver** out);
 void zkpor_solver_destroy(zkpor_solver* solver);
 /* dims = {instructions, levels, constraint instructions, hint instructions, skipped instructions, levels holding an external hint,
  * kernel launches of the last run} */
@@ -485,6 +489,13 @@ int32_t zkpor_solver_dims(const zkpor_solver* solver, uint64_t dims[7]);
  * refuses its input (range check violated, zero divisor), an instruction with two unknown wires (wrong level order). */
 int32_t zkpor_solver_start_dev(zkpor_solver* solver, void* d_w, size_t n_inputs, uint8_t* d_known_or_null, uint32_t* paused_instr);
 int32_t zkpor_solver_resume_dev(zkpor_solver* solver, uint32_t* paused_instr);
+/* Pipelining across proofs: starts the NEXT proof's long serial hash chains (instructions the program flags ASYNC — the two 10 000-element
+ * CEX commitments of BatchCreateUserCircuit, circuit/batch_create_user_circuit.go:129,320: 834 chained permutations each, ~0.2 s of ONE wave)
+ * on the solver's side stream while the current proof still runs its prove tail.  d_w_next: the next proof's wire vector with the assignment
+ * already in place (wire 0 = ONE, public, secret); the next zkpor_solver_start_dev must be given exactly this pointer — it then skips those
+ * instructions and joins the side stream in front of its last level (any other pointer abandons the prefetch).  One prefetch at a time, after
+ * the current run has finished.  A prover loop has the next batch's witness row in hand while it proves the current one (prover.go:139-247). */
+int32_t zkpor_solver_prefetch_dev(zkpor_solver* solver, void* d_w_next, size_t n_inputs);
 /* the external hint the run is paused at: its evaluated input expressions (n_in x 4 limbs into in_values when not NULL) and its shape */
 int32_t zkpor_solver_external_inputs(zkpor_solver* solver, uint32_t instr, uint64_t* in_values, size_t capacity, size_t* n_in, size_t* n_out);
 /* the same into device memory (capacity >= n_in elements): the committed wires of a BSB22 commitment go straight to zkpor_commit_dev */

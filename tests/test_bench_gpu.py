@@ -66,3 +66,24 @@ def test_bench_other_tier_and_timed_only():
     d = _bench("--log2", "17", "--steps", "2", "--warmup", "1", "--config", "zkpor500_200", "--timed-only")
     assert d["config"]["tier"] == "zkpor500_200" and d["config"]["users_per_batch"] == 200
     assert d["checked"] is None and d["value_uniform"] is None and d["two_in_flight"] is None and d["configs"] is None and "boundary" not in d and "cpu_baseline" not in d and "acceptance" not in d
+
+
+def test_bench_circuit_mode_end_to_end():
+    """--circuit T,A,U: the compiled BatchCreateUserCircuit of that shape — the line's workload is then GENERATED (w, a, b, c, committed values from
+    the device-solved wires of a synthetic valid batch, a key with the circuit's sparsity) and `end_to_end` times groth16.Prove from the
+    assigned inputs: solver program + BSB22 commitment + a, b, c + prove tail, every proof checked"""
+    d = _bench("--circuit", "5,20,6", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-boundary", "--e2e-steps", "3")
+    cfgd = d["config"]
+    assert cfgd["scalars"] == "generated" and "COMPILED BatchCreateUserCircuit" in cfgd["workload"] and cfgd["users_per_batch"] == 6 and cfgd["assets_per_user"] == 5
+    mix = cfgd["scalar_mix_measured"]
+    assert abs(mix["in_{0,1}"] + mix["below_2^16"] + mix["below_2^64"] + mix["wider"] - 1.0) < 1e-3 and mix["in_{0,1}"] > 0.3
+    e = d["end_to_end"]
+    assert e["steps"] == 3 and e["value"] > 0 and abs(e["value"] - 1e3 / e["ms_per_proof"]) < 1e-6 * e["value"]
+    assert e["checked"] == {"proofs": 3, "ok": 3} and e["same_wires_as_headline"] is True and e["constraints_failing_on_device"] == 0
+    assert e["next_proofs_hash_chains_prefetched"] is True
+    c = e["circuit"]
+    assert c["shape_T_A_U"] == [5, 20, 6] and c["constraints"] > 300000 and c["levels"] < 200 and c["committed_wires"] > 40000 and c["census"]["poseidon_perm_t3"] == 28 * 6
+    assert e["value"] < d["value"]                                  # the solver costs something
+    assert d["checked"]["ok"] == d["checked"]["proofs"] and d["checked"]["proofs"] >= 3 + 3
+    for k in ("solve_phase1_ms", "commit_ms", "solve_phase2_ms", "abc_and_prove_tail_ms"):
+        assert e["phases_ms_per_proof"][k] >= 0

@@ -71,6 +71,16 @@ def test_small_batches_bit_exact_with_the_interpreter_both_poseidon_kernels(zk, 
     prove_once(zk, shape, variant)
 
 
+def test_batched_inversions_of_wide_levels_change_no_wire(zk):
+    """levels from `solver_batch_from` generic instructions on run four instructions per thread, their divisions sharing ONE field inversion
+    (csrc/solver.hip k_solve_level_batched); the default threshold (2^21) is only met by production-size batches — lowered here"""
+    zk.set_param("solver_batch_from", 64)
+    try:
+        prove_once(zk, (5, 20, 6), 1)
+    finally:
+        zk.set_param("solver_batch_from", 1 << 21)
+
+
 def test_the_500_asset_tier_shape(zk):
     """T = all assets (the zkpor500 shape: every slot of the user's list is a real CEX asset): sponges of 1000 / 3000 elements"""
     prove_once(zk, (30, 30, 2), 1)
@@ -81,6 +91,93 @@ def test_configs0_real_size_8_users_of_the_50_asset_tier(zk):
     domain 2^23, solved and proved on the device, three proofs from one loaded program"""
     dims = prove_once(zk, (50, 500, 8), 1, reps=3)
     assert dims["levels"] < 3000 and dims["external_levels"] == 1
+
+
+def test_prefetching_the_next_proofs_hash_chains_changes_no_wire(zk):
+    """zkpor_solver_prefetch_dev: the ASYNC instructions (the two CEX commitments) of the next proof started on the side stream before its run —
+    three proofs over two alternating wire vectors, each bit-identical to a run without prefetch; a prefetch for a vector the next run does
+    not use is abandoned"""
+    shape = (4, 30, 3)
+    inputs = [C.synth_inputs(*shape, seed=s) for s in (1, 2, 3)]
+    cir = C.Circuit(*shape)
+    pk = zkpor.ProvingKey(zk)
+    dc = C.DeviceCircuit(zk, cir)
+    log2 = int(np.ceil(np.log2(cir.n_constraints)))
+    n_in = cir.n_public + cir.n_secret
+    wb = [zk.alloc(32 * cir.n_wires) for _ in range(3)]
+    cvb = zk.alloc(32 * (cir.n_committed + 1))
+    try:
+        pk.synth(log2, cir.n_wires, cir.n_public, cir.n_committed, SEED)
+        plain = []
+        for inp in inputs:
+            C.solve_on_device(zk, dc, pk, wb[2].ptr, cvb.ptr, inp)
+            plain.append(wb[2].download(np.uint64, (cir.n_wires, 4)))
+        assert not np.array_equal(plain[0], plain[1])
+        C.stage_inputs(zk, dc, wb[0].ptr, inputs[0])
+        dc.solver.prefetch_dev(wb[0].ptr, n_in)
+        for i, inp in enumerate(inputs):
+            cur, nxt = wb[i % 2], wb[(i + 1) % 2]
+            C.solve_on_device(zk, dc, pk, cur.ptr, cvb.ptr, inp, staged=True)
+            if i + 1 < len(inputs):
+                C.stage_inputs(zk, dc, nxt.ptr, inputs[i + 1])
+                dc.solver.prefetch_dev(nxt.ptr, n_in)
+            assert dc.r1cs.check_dev(cur.ptr) == (0, None)
+            assert np.array_equal(cur.download(np.uint64, (cir.n_wires, 4)), plain[i])
+        # a prefetch nobody consumes: the next run is given another vector and must not be disturbed
+        C.stage_inputs(zk, dc, wb[0].ptr, inputs[2])
+        dc.solver.prefetch_dev(wb[0].ptr, n_in)
+        C.solve_on_device(zk, dc, pk, wb[2].ptr, cvb.ptr, inputs[1])
+        assert np.array_equal(wb[2].download(np.uint64, (cir.n_wires, 4)), plain[1])
+    finally:
+        for b in wb:
+            b.free()
+        cvb.free(); dc.close(); pk.close(); cir.close()
+
+
+def test_two_workers_of_one_gpu_solve_and_prove_side_by_side(zk):
+    """one zkpor_r1cs, two solvers on two contexts (zkpor_solver_create_on), two host threads: each proves its own batches — solver program,
+    commitment, a / b / c (zkpor_r1cs_eval_on), prove tail — while the other does the same; every wire vector equals the single-worker run's"""
+    import threading
+    shape = (4, 30, 3)
+    inputs = [C.synth_inputs(*shape, seed=s) for s in (11, 12, 13, 14)]
+    cir = C.Circuit(*shape)
+    log2 = int(np.ceil(np.log2(cir.n_constraints)))
+    D = 1 << log2
+    pk = zkpor.ProvingKey(zk)
+    ctx2 = zkpor.Context(0)
+    dc1 = C.DeviceCircuit(zk, cir)
+    dc2 = C.DeviceCircuit(ctx2, cir, share=dc1)
+    res = {}
+    try:
+        pk.synth(log2, cir.n_wires, cir.n_public, cir.n_committed, SEED)
+
+        def run(ctx, dc, mine, tag):
+            bufs = [ctx.alloc(32 * n) for n in (cir.n_wires, D, D, D, cir.n_committed + 1)]
+            try:
+                for k in mine:
+                    for _rep in range(2):
+                        com, pok, ch = C.solve_on_device(ctx, dc, pk, bufs[0].ptr, bufs[4].ptr, inputs[k])
+                        dc.r1cs.eval_dev(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, D, ctx=ctx)
+                        rr = O.fr_random(500 + k, 1)[0]; ss = O.fr_random(600 + k, 1)[0]
+                        proof = ctx.prove_tail_dev(pk, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, rr, ss)
+                    res[(tag, k)] = (bufs[0].download(np.uint64, (cir.n_wires, 4)), bufs[1].download(np.uint64, (D, 4)), proof, rr, ss, com)
+            except Exception as e:     # surface in the main thread
+                res[("error", tag)] = e
+            finally:
+                for b in bufs:
+                    b.free()
+
+        run(zk, dc1, [0, 1, 2, 3], "single")
+        t1 = threading.Thread(target=run, args=(zk, dc1, [0, 1], "pair")); t2 = threading.Thread(target=run, args=(ctx2, dc2, [2, 3], "pair"))
+        t1.start(); t2.start(); t1.join(); t2.join()
+        assert not [k for k in res if k[0] == "error"], res
+        for k in range(4):
+            ws, hs, proof_s, rr, ss, com_s = res[("single", k)]
+            wp, hp, proof_p, _, _, com_p = res[("pair", k)]
+            assert np.array_equal(ws, wp) and np.array_equal(hs, hp) and np.array_equal(proof_s, proof_p) and np.array_equal(com_s, com_p)
+            assert T.SynthKeyTrapdoor(SEED, cir.n_public, wp, hp[: D - 1]).check(proof_p, rr, ss)
+    finally:
+        dc2.close(); dc1.close(); ctx2.close(); pk.close(); cir.close()
 
 
 def test_a_witness_the_circuit_rejects_is_an_error_not_a_proof(zk):

@@ -133,15 +133,23 @@ def default_commitment():
 class DeviceCircuit:
     """the compiled circuit resident on the device: matrices (zkpor_r1cs_*) + solver program (zkpor_solver_*)"""
 
-    def __init__(self, ctx, circuit):
+    def __init__(self, ctx, circuit, share=None):
+        """share: another DeviceCircuit of the same circuit on the same GPU — its matrices are used (read-only), only the program is loaded
+        again, bound to `ctx` (one solver per worker context: zkpor_solver_create_on)"""
         self.ctx = ctx; self.circuit = circuit
-        self.r1cs = zkpor.R1CS(ctx, circuit.n_constraints, circuit.n_wires, circuit.coeff())
-        for m in range(3):
-            self.r1cs.set_matrix(m, *circuit.matrix(m))
-        self.solver = zkpor.Solver(self.r1cs, circuit.solver_container())
+        self.owns_r1cs = share is None
+        if share is None:
+            self.r1cs = zkpor.R1CS(ctx, circuit.n_constraints, circuit.n_wires, circuit.coeff())
+            for m in range(3):
+                self.r1cs.set_matrix(m, *circuit.matrix(m))
+        else:
+            self.r1cs = share.r1cs
+        self.solver = zkpor.Solver(self.r1cs, circuit.solver_container(), ctx=ctx)
 
     def close(self):
-        self.solver.close(); self.r1cs.close()
+        self.solver.close()
+        if self.owns_r1cs:
+            self.r1cs.close()
 
 
 def bsb22_challenge(ctx, commitment_affine):
@@ -157,7 +165,22 @@ def bsb22_challenge(ctx, commitment_affine):
     return mont
 
 
-def solve_on_device(ctx, dc, pk, d_w, d_cv, d_inputs_or_host, timings=None):
+def stage_inputs(ctx, dc, d_w, d_inputs_or_host):
+    """wire 0 = ONE and the assignment into d_w (what solve_on_device does first; call it yourself to prefetch: Solver.prefetch_dev)"""
+    c = dc.circuit
+    n_in = c.n_public + c.n_secret
+    one = np.array([0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f], np.uint64)
+    vp = ctypes.c_void_p
+    ctx._ck(ctx.lib.zkpor_dev_upload(ctx.h, vp(d_w), zkpor._p(one), ctypes.c_size_t(32)))
+    if isinstance(d_inputs_or_host, int):
+        ctx._ck(ctx.lib.zkpor_dev_copy(ctx.h, vp(d_w + 32), vp(d_inputs_or_host), ctypes.c_size_t(32 * (n_in - 1))))
+    else:
+        a = np.ascontiguousarray(d_inputs_or_host, dtype=np.uint64)
+        ctx._ck(ctx.lib.zkpor_dev_upload(ctx.h, vp(d_w + 32), zkpor._p(a), ctypes.c_size_t(a.nbytes)))
+    return n_in
+
+
+def solve_on_device(ctx, dc, pk, d_w, d_cv, d_inputs_or_host, timings=None, staged=False):
     """inputs -> the full wire vector in d_w, serving the BSB22 commitment: returns (commitment, pok, challenge).  d_inputs_or_host: a device
     pointer (int) to n_inputs Montgomery elements, or a host array (uploaded here).  d_w: n_wires x 32 B, d_cv: (1 + n_committed) x 32 B — the
     placeholder's inputs: the commitment index, then the committed wires (the values zkpor_commit_dev sums start at d_cv + 32)."""
@@ -168,12 +191,8 @@ def solve_on_device(ctx, dc, pk, d_w, d_cv, d_inputs_or_host, timings=None):
     lib = ctx.lib
     vp = ctypes.c_void_p
     t0 = time.perf_counter()
-    ctx._ck(lib.zkpor_dev_upload(ctx.h, vp(d_w), zkpor._p(one), ctypes.c_size_t(32)))
-    if isinstance(d_inputs_or_host, int):
-        ctx._ck(lib.zkpor_dev_copy(ctx.h, vp(d_w + 32), vp(d_inputs_or_host), ctypes.c_size_t(32 * (n_in - 1))))
-    else:
-        a = np.ascontiguousarray(d_inputs_or_host, dtype=np.uint64)
-        ctx._ck(lib.zkpor_dev_upload(ctx.h, vp(d_w + 32), zkpor._p(a), ctypes.c_size_t(a.nbytes)))
+    if not staged:
+        stage_inputs(ctx, dc, d_w, d_inputs_or_host)
     s = dc.solver
     paused = s.start_dev(d_w, n_in)
     t1 = time.perf_counter()

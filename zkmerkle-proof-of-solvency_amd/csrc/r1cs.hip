@@ -154,6 +154,12 @@ int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b
     if (!r) return ZKPOR_E_ARG;
     return zk::r1cs_eval_on(r->ctx, r, d_w, d_a, d_b, d_c, domain_size);
 }
+/* the same queued on ANOTHER context of the GPU (a second worker's stream and timers; the matrices are only read) */
+int32_t zkpor_r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !r) return ZKPOR_E_ARG;
+    return zk::r1cs_eval_on(ctx, r, d_w, d_a, d_b, d_c, domain_size);
+}
 /* every constraint against a wire vector on the device: counts[0] = rows with L.w * R.w != O.w, counts[1] = the lowest such row */
 int32_t zkpor_r1cs_check_dev(zkpor_r1cs* r, const void* d_w, uint64_t counts[2]) {
     ZK_ENTER(r ? r->ctx->device : -1);

@@ -64,6 +64,10 @@ struct zkpor_solver {
     zk::Fr* d_tmp = nullptr;                    // scratch for external hint values (grow-only)
     size_t tmp_cap = 0;
     hipStream_t side = nullptr;                 // ASYNC instructions
+    uint32_t* d_perr = nullptr;                 // error words of a prefetch (its kernels run beside another run's)
+    uint8_t* d_ones = nullptr;                  // n_wires bytes of 1: the `known` flags a prefetch reads (it only reads inputs)
+    void* prefetched_w = nullptr;               // the wire vector whose ASYNC instructions are already running / done on the side stream
+    bool skip_async = false;                    // this run consumes a prefetch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint64_t n_r1c = 0, n_hint = 0, n_skip = 0, n_lookup = 0, n_poseidon = 0;
     // run state (pause / resume)
@@ -77,6 +81,7 @@ struct zkpor_solver {
 
 namespace zk {
 static constexpr u32 NARROW = 512, EXT_CAP = 4096;
+static constexpr int BATCH_K = 4;                 // instructions per thread of the batched level kernel
 
 ZK_D void solver_step(const SolverProg& P, u32 ins, Fr* w, uint8_t* known, u32* err, u32* ext) {
     // an external hint is not executed: it is reported, its outputs stay unknown until the caller provides them
@@ -98,6 +103,43 @@ __global__ __launch_bounds__(256) void k_solve_level(SolverProg P, const u32* __
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n || err[0]) return;
     solver_step(P, level_instr[lo + i], w, known, err, ext);
+}
+// a VERY wide level: KB instructions per thread (strided, so that neighbouring lanes still read neighbouring list entries), their divisions
+// resolved with ONE field inversion per thread — Montgomery's trick over the thread's denominators: 3 products per quotient instead of a
+// ~40 k-instruction binary Euclid each.  The log-derivative argument behind every range check and lookup is one inverse wire per query
+// (2 x 10^7 per zkpor50_1380 proof), all in one level.
+template <int KB>
+__global__ __launch_bounds__(256) void k_solve_level_batched(SolverProg P, const u32* __restrict__ level_instr, u64 lo, u32 n, u32 stride, Fr* w, uint8_t* known,
+                                                             u32* err, u32* ext) {
+    const u32 t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= stride || err[0]) return;
+    SiPending pd[KB];
+    int np = 0;
+#pragma unroll 1
+    for (int k = 0; k < KB; ++k) {
+        const u32 i = t + (u32)k * stride;
+        if (i >= n) break;
+        const u32 ins = level_instr[lo + i];
+        if (P.kind[ins] == SI_HINT && P.hint_kind[P.calldata[P.arg[ins]]] == HK_NONE) {
+            const u32 slot = atomicAdd(&err[3], 1u);
+            if (slot < EXT_CAP) ext[slot] = ins;
+            continue;
+        }
+        const int rc = solve_instr(P, ins, w, known, &pd[np]);
+        if (rc == SE_DEFERRED) ++np;
+        else if (rc != SE_OK && atomicCAS(&err[0], 0u, (u32)rc) == 0u) err[1] = ins;
+    }
+    if (np == 0) return;
+    Fr pre[KB];                                   // pre[j] = den_0 .. den_j
+    pre[0] = pd[0].den;
+    for (int j = 1; j < np; ++j) pre[j] = Fr::mul(pre[j - 1], pd[j].den);
+    Fr inv = fr_inverse(pre[np - 1]);
+    for (int j = np - 1; j >= 0; --j) {
+        const Fr dinv = j ? Fr::mul(inv, pre[j - 1]) : inv;
+        inv = Fr::mul(inv, pd[j].den);
+        w[pd[j].wire] = Fr::mul(pd[j].num, dinv);
+        known[pd[j].wire] = 1;
+    }
 }
 
 // a run of narrow levels [l0, l1): one workgroup, a barrier per level (the writes of a level are visible to the workgroup after it)
@@ -237,7 +279,7 @@ static SolverProg prog_of(const zkpor_solver* s) {
     return P;
 }
 static void solver_free(zkpor_solver* s) {
-    void* ptrs[] = {s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
+    void* ptrs[] = {s->d_perr, s->d_ones, s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
                     s->d_cnt, s->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (s->side) (void)hipStreamDestroy(s->side);
@@ -312,7 +354,7 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                 s->next_level = l1;
                 continue;
             }
-            if (L.n_posa) {                       // fork: everything queued so far is visible to the side stream
+            if (L.n_posa && !(s->skip_async && l == 0)) {   // fork: everything queued so far is visible to the side stream
                 ZK_HIP(ctx, hipEventRecord(s->ev_fork, ctx->stream));
                 ZK_HIP(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
                 for (u32 k = 0; k < L.n_posa; ++k) {   // the inputs of a long call (10 000 expressions, some a thousand terms long) side by side first
@@ -324,7 +366,11 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                 s->side_busy = true;
                 ++s->launches;
             }
-            if (L.n_gen) {
+            if ((int64_t)L.n_gen >= ctx->solver_batch_from) {          // enough instructions to fill the chip several per thread: divisions share an inversion
+                const u32 stride = (L.n_gen + BATCH_K - 1) / BATCH_K;
+                hipLaunchKernelGGL(k_solve_level_batched<BATCH_K>, dim3((stride + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, stride, w, s->known, s->d_err, s->d_ext);
+                ++s->launches;
+            } else if (L.n_gen) {
                 hipLaunchKernelGGL(k_solve_level, dim3((L.n_gen + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, w, s->known, s->d_err, s->d_ext);
                 ++s->launches;
             }
@@ -351,7 +397,10 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
         ZK_KERNEL_CHECK(ctx);
     }
     ZK_HIP(ctx, hipMemcpyAsync(h, s->d_err, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    u32 hp[2] = {0, 0};
+    if (finished && s->skip_async) ZK_HIP(ctx, hipMemcpyAsync(hp, s->d_perr, sizeof hp, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!h[0] && hp[0]) { h[0] = hp[0]; h[1] = hp[1]; }
     if (h[0]) {
         s->running = false;
         if (s->side_busy) { (void)hipStreamSynchronize(s->side); s->side_busy = false; }
@@ -381,9 +430,15 @@ using namespace zk;
 extern "C" {
 
 int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t len, zkpor_solver** out) {
-    ZK_ENTER(r1cs ? r1cs->ctx->device : -1);
-    if (!r1cs || !container || !out) return ZKPOR_E_ARG;
-    zkpor_ctx* ctx = r1cs->ctx;
+    return zkpor_solver_create_on(r1cs ? r1cs->ctx : nullptr, r1cs, container, len, out);
+}
+
+/* the same program bound to ANOTHER context of the GPU the matrices live on: its launches, phase timers and error text belong to `ctx`, the
+ * matrices are only read — one solver per worker context, all over one zkpor_r1cs (two workers of a GPU solve side by side) */
+int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* container, size_t len, zkpor_solver** out) {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !r1cs || !container || !out) return ZKPOR_E_ARG;
+    if (ctx->device != r1cs->ctx->device) { ctx->err = "solver: the constraint matrices live on another GPU than the context"; return ZKPOR_E_ARG; }
     for (int m = 0; m < 3; ++m) if (!r1cs->row_ptr[m]) { ctx->err = "solver: the constraint matrices are not loaded"; return ZKPOR_E_STATE; }
     zkpor_solver* s = new zkpor_solver();
     s->ctx = ctx; s->r1cs = r1cs;
@@ -559,14 +614,53 @@ int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint
     if (!s || !d_w || !paused_instr) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
     if (n_inputs == 0 || n_inputs > s->r1cs->n_wires) { ctx->err = "solver: the assignment must hold 1 + nPublic + nSecret elements"; return ZKPOR_E_ARG; }
-    if (s->side_busy) { (void)hipStreamSynchronize(s->side); s->side_busy = false; }   // an abandoned run
+    s->skip_async = s->prefetched_w != nullptr && s->prefetched_w == d_w;
+    if (s->side_busy && !s->skip_async) { (void)hipStreamSynchronize(s->side); s->side_busy = false; }   // an abandoned run, or a prefetch for another vector
+    s->prefetched_w = nullptr;
     s->d_w = d_w;
     s->known = d_known_or_null ? d_known_or_null : s->d_known;
     if (!d_known_or_null) ZK_HIP(ctx, hipMemsetAsync(s->d_known, 0, s->r1cs->n_wires, ctx->stream));
     ZK_HIP(ctx, hipMemsetAsync(s->known, 1, n_inputs, ctx->stream));
     ZK_HIP(ctx, hipMemsetAsync(s->d_err, 0, 16, ctx->stream));
+    if (s->skip_async)     // the prefetched instructions' wires are (being) assigned on the side stream: flagged here, joined in front of the last level
+        for (const BigHint& a : s->asyncs) { const uint32_t* cd = s->view.calldata + s->view.arg[a.ins]; ZK_HIP(ctx, hipMemsetAsync(s->known + cd[1], 1, cd[2], ctx->stream)); }
     s->running = true; s->next_level = 0; s->pending.clear(); s->launches = 0;
     return solver_advance(s, paused_instr);
+}
+
+/* the ASYNC instructions of the NEXT proof (the two CEX commitments: 834 chained permutations each, ~0.2 s of one wave) started on the side
+ * stream while the current proof still runs its prove tail: d_w_next holds the next assignment (wire 0 = ONE, then the inputs) and must be the
+ * vector the next zkpor_solver_start_dev is given — that run then skips them and joins the side stream in front of its last level.  They must
+ * sit in the first level (they read inputs only).  One prefetch at a time. */
+int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inputs) {
+    ZK_ENTER(s ? s->ctx->device : -1);
+    if (!s || !d_w_next) return ZKPOR_E_ARG;
+    zkpor_ctx* ctx = s->ctx;
+    if (n_inputs == 0 || n_inputs > s->r1cs->n_wires) { ctx->err = "solver: the assignment must hold 1 + nPublic + nSecret elements"; return ZKPOR_E_ARG; }
+    if (s->asyncs.empty()) return ZKPOR_OK;
+    if (s->plan.empty() || s->plan[0].n_posa != s->asyncs.size()) { ctx->err = "solver: an ASYNC instruction outside the first level cannot be prefetched"; return ZKPOR_E_STATE; }
+    if (s->side_busy) { ctx->err = "solver: the side stream still runs a chain (one prefetch at a time, after the current run's last level)"; return ZKPOR_E_STATE; }
+    const size_t nw = s->r1cs->n_wires;
+    if (!s->d_ones) {
+        ZK_HIP(ctx, hipMalloc((void**)&s->d_ones, nw));
+        ZK_HIP(ctx, hipMemset(s->d_ones, 1, nw));
+        ZK_HIP(ctx, hipMalloc((void**)&s->d_perr, 16));
+    }
+    const SolverProg P = prog_of(s);
+    const LevelPlan& L = s->plan[0];
+    ZK_HIP(ctx, hipEventRecord(s->ev_fork, ctx->stream));          // the inputs were put there through this context
+    ZK_HIP(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
+    ZK_HIP(ctx, hipMemsetAsync(s->d_perr, 0, 16, s->side));
+    for (u32 k = 0; k < L.n_posa; ++k) {
+        const BigHint& a = s->asyncs[L.posa_first + k];
+        hipLaunchKernelGGL(k_hint_inputs, dim3((a.n_in + 255u) / 256u), dim3(256), 0, s->side, P, a.ins, s->d_offs + a.offs_base, a.n_in, (const Fr*)d_w_next, s->d_ones,
+                           s->d_pre + a.nb_q, s->d_perr);
+    }
+    ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_pos, L.n_posa, (Fr*)d_w_next, s->d_ones, s->d_perr, s->d_pre, s->d_pre_off + L.posa_first));
+    s->side_busy = true;
+    s->prefetched_w = d_w_next;
+    (void)n_inputs;
+    return ZKPOR_OK;
 }
 
 int32_t zkpor_solver_resume_dev(zkpor_solver* s, uint32_t* paused_instr) {

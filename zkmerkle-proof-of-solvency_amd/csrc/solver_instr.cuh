@@ -19,8 +19,11 @@ enum : uint8_t { HK_NONE = 0, HK_INTDIV = 1, HK_NBITS = 2, HK_INVZERO = 3, HK_DE
 enum : u32 { SI_R1C = 0, SI_HINT = 1, SI_SKIP = 2, SI_LOOKUP = 3, SI_POSEIDON = 4 };
 enum : int {
     SE_OK = 0, SE_ROW_RANGE = 10, SE_TWO_UNKNOWN = 11, SE_NOT_SATISFIED = 12, SE_ZERO_COEFF = 13, SE_DIV_ZERO = 14, SE_CALLDATA = 20,
-    SE_NO_HINT = 21, SE_ID_RANGE = 22, SE_INPUT_UNSOLVED = 23, SE_HINT_FAILED = 24, SE_LOOKUP_RANGE = 25, SE_COUNT_TABLE = 26, SE_COUNT_QUERY = 27
+    SE_NO_HINT = 21, SE_ID_RANGE = 22, SE_INPUT_UNSOLVED = 23, SE_HINT_FAILED = 24, SE_LOOKUP_RANGE = 25, SE_COUNT_TABLE = 26, SE_COUNT_QUERY = 27,
+    SE_DEFERRED = -1     // not an error: the instruction's wire is num / den, left to the caller (which inverts several denominators at once)
 };
+// a quotient an instruction leaves open (solve_instr with `pend`): w[wire] = num / den, den != 0
+struct SiPending { u32 wire; Fr num, den; };
 
 // the program and its constraint system, as pointers the executing side can read (device memory for the kernels, host memory for the CPU tests)
 struct SolverProg {
@@ -145,7 +148,7 @@ ZK_HD bool si_index(const Fr& x, u32 bound, u32* out) {
 
 // Executes instruction `ins`: assigns its output wire(s) in w and marks them known.  The instructions of one level are independent: no
 // instruction reads a wire another instruction of the same level assigns, so a level may run in any order or all at once.
-ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known) {
+ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known, SiPending* pend = nullptr) {
     const u32 kind = P.kind[ins], arg = P.arg[ins];
     if (kind == SI_SKIP) return SE_OK;
     if (kind == SI_LOOKUP) {   // outputs = entry[index]: call data blockOff, nbEntries, nQ, firstOut, the index expressions (shapes validated at load)
@@ -193,6 +196,7 @@ ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known) {
             val = Fr::sub(Fr::mul(v[0], v[1]), v[2]);                     // O_known + c x = L R
             if (uc == Fr::one()) {}
             else if (Fr::neg(uc) == Fr::one()) val = Fr::neg(val);
+            else if (pend) { pend->wire = x; pend->num = val; pend->den = uc; return SE_DEFERRED; }
             else val = Fr::mul(val, fr_inverse(uc));
         } else {
             const Fr& other = v[1 - which];
@@ -207,6 +211,7 @@ ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known) {
             if (uc == Fr::one()) {}
             else if (Fr::neg(uc) == Fr::one()) den = Fr::neg(den);
             else den = Fr::mul(den, uc);
+            if (pend) { pend->wire = x; pend->num = num; pend->den = den; return SE_DEFERRED; }
             val = Fr::mul(num, fr_inverse(den));
         }
         w[x] = val;
@@ -255,6 +260,7 @@ ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known) {
     }
     case HK_INVZERO: {                                                     // 1 / in[0], or 0
         if (n_in != 1 || n_out != 1) return SE_HINT_FAILED;
+        if (pend && !in[0].is_zero()) { pend->wire = outw[0]; pend->num = Fr::one(); pend->den = in[0]; return SE_DEFERRED; }
         w[outw[0]] = fr_inverse(in[0]);
         break;
     }

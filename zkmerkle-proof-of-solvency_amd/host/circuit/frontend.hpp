@@ -410,6 +410,7 @@ private:
     std::vector<int> rc_bits_;
     std::vector<u32> slow_lo_, slow_hi_;
     std::vector<u32> deferred_asserts_;
+    std::vector<std::pair<u32, u32>> async_instrs_;   // (instruction, its as-soon-as-possible level)
     PermTemplate tmpl_[zkpor_host::kPosMaxT + 1];
     std::vector<u32> committed_;
     u32 commitment_wire_ = NO_WIRE;
@@ -559,6 +560,7 @@ inline LE Builder::poseidon(const std::vector<LE>& inputs, bool async, int out_i
         calldata_.push_back((u32)out_idx | ((u32)carry_idx << 8) | ((async ? 1u : 0u) << 16));
         for (auto& e : inputs) push_le(e);
         for (size_t i = 0; i < 3 * total_sbox; ++i) producer_[base + i] = (u32)kind_.size();
+        if (async) async_instrs_.push_back({(u32)kind_.size(), lvl});
         push_instr(K_POSEIDON, off, lvl);
     }
     // the constraints, permutation after permutation
@@ -817,6 +819,7 @@ inline Compiled Builder::finish() {
             }
         }
         for (size_t i = 0; i < kind_.size(); ++i) level_[i] = alap[i];
+        for (auto& a : async_instrs_) level_[a.first] = a.second;     // a long chain that runs beside everything else starts as EARLY as it can
         producer_.clear(); producer_.shrink_to_fit();
     }
     // levels: counting sort of the instructions by level; deferred assertions go behind everything else

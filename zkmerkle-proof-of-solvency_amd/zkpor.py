@@ -775,8 +775,12 @@ class R1CS:
         self.ctx._ck(self.ctx.lib.zkpor_r1cs_check_dev(self.h, ctypes.c_void_p(d_w), c))
         return int(c[0]), (int(c[1]) if c[0] else None)
 
-    def eval_dev(self, d_w, d_a, d_b, d_c, domain_size):
-        self.ctx._ck(self.ctx.lib.zkpor_r1cs_eval_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c), ctypes.c_size_t(domain_size)))
+    def eval_dev(self, d_w, d_a, d_b, d_c, domain_size, ctx=None):
+        """ctx: queue on another context of the same GPU (a second worker); default the R1CS's own"""
+        if ctx is None:
+            self.ctx._ck(self.ctx.lib.zkpor_r1cs_eval_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c), ctypes.c_size_t(domain_size)))
+        else:
+            ctx._ck(ctx.lib.zkpor_r1cs_eval_on(ctx.h, self.h, ctypes.c_void_p(d_w), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_c), ctypes.c_size_t(domain_size)))
 
     def close(self):
         if self.h:
@@ -791,11 +795,12 @@ class Solver:
     """the solver program of a compiled circuit on the device (include/zkpor.h zkpor_solver_*): r1cs.Solve of groth16.Prove
     (prover.go:269) as one launch per level over the matrices of `r1cs`"""
 
-    def __init__(self, r1cs, container):
-        self.ctx = r1cs.ctx; self.r1cs = r1cs
-        buf = bytes(container)
+    def __init__(self, r1cs, container, ctx=None):
+        """ctx: the context the solver's launches belong to (default: the R1CS's); another context of the same GPU = another worker"""
+        self.ctx = ctx or r1cs.ctx; self.r1cs = r1cs
+        buf = np.ascontiguousarray(np.frombuffer(container, dtype=np.uint8)) if not isinstance(container, np.ndarray) else np.ascontiguousarray(container, dtype=np.uint8)
         h = ctypes.c_void_p()
-        self.ctx._ck(self.ctx.lib.zkpor_solver_create(r1cs.h, buf, ctypes.c_size_t(len(buf)), ctypes.byref(h)))
+        self.ctx._ck(self.ctx.lib.zkpor_solver_create_on(self.ctx.h, r1cs.h, _p(buf), ctypes.c_size_t(buf.nbytes), ctypes.byref(h)))
         self.h = h
 
     def dims(self):
@@ -817,6 +822,10 @@ class Solver:
         paused = ctypes.c_uint32()
         self.ctx._ck(self.ctx.lib.zkpor_solver_start_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_size_t(n_inputs), ctypes.c_void_p(d_known) if d_known else None, ctypes.byref(paused)))
         return paused.value
+
+    def prefetch_dev(self, d_w_next, n_inputs):
+        """start the NEXT proof's ASYNC instructions (the CEX commitment chains) on the side stream; d_w_next must be what the next start_dev gets"""
+        self.ctx._ck(self.ctx.lib.zkpor_solver_prefetch_dev(self.h, ctypes.c_void_p(d_w_next), ctypes.c_size_t(n_inputs)))
 
     def resume_dev(self):
         paused = ctypes.c_uint32()
