@@ -1085,6 +1085,8 @@ def main():
     ap.add_argument("--no-circuit", action="store_true", help="the round-1..3 workload: D = n_wires = 2^log2, estimated scalar mixture, seeded key sparsity")
     ap.add_argument("--no-prefetch", action="store_true", help="end-to-end region: do not start the next proof's CEX commitment chains under the current proof's prove tail")
     ap.add_argument("--e2e-steps", type=int, default=-1, help="proofs of the end-to-end region (inputs -> solver program -> commitment -> a, b, c -> prove tail); default max(3, steps // 4)")
+    ap.add_argument("--share-device", action="store_true", help="TEST ONLY: every rank proves on device 0 and the ranks meet over gloo — the launcher, the per-rank "
+                    "merge of the line, the check budgeting and the key build under contention exercised on a one-GPU box; the line says so and is no measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
                     help="warm-up + the timed region and nothing else (no uniform region, check, boundary, CPU baseline, acceptance): the "
@@ -1107,7 +1109,7 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a number for a different GPU count")
     if env_world is None and args.gpus > 1:
         visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if visible < args.gpus:
+        if visible < args.gpus and not (args.share_device and visible >= 1):
             raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {visible} GPU(s) are visible")
         import socket
         import subprocess
@@ -1129,13 +1131,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda is not available (there is no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_device:      # two RCCL ranks cannot share a device: the ranks only meet at barriers and small reductions
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     stream = torch.cuda.current_stream().cuda_stream  # launch on torch's stream so torch/HIP events see the work
     ctx = zkpor.Context(local_rank, stream)
@@ -1356,6 +1363,7 @@ def main():
 
     dt = timed_region(dist, torch.cuda.synchronize, timed_steps)
     per_rank_ms = [row[0] for row in gather_per_rank(dist, [local_t[0] / max(1, args.steps) * 1e3])]
+    per_rank_key_s = [round(row[0], 2) for row in gather_per_rank(dist, [key_seconds])]
 
     phases = {}
     for name in ("msm_decompose", "msm_sort", "msm_accumulate", "msm_reduce", "k_acc_level1_g1", "k_acc_level1_g2", "ntt", "pointwise", "host_assembly"):
@@ -1591,7 +1599,7 @@ def main():
             rows = gather_per_rank(dist, [other_cfg["checked"]["ok"], other_cfg["checked"]["proofs"]])
             other_cfg["checked"] = {"proofs": int(sum(r_[1] for r_ in rows)), "ok": int(sum(r_[0] for r_ in rows))}
         if dist is not None:
-            t = torch.tensor([ok, total, int(h_ok), 1], dtype=torch.int64, device="cuda")
+            t = torch.tensor([ok, total, int(h_ok), 1], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t)
             ok, total = int(t[0].item()), int(t[1].item())
             h_ok = bool(int(t[2].item()) == int(t[3].item()))
@@ -1639,10 +1647,12 @@ def main():
             "value": world * args.steps / dt,
             "unit": "proofs/s",
             "n_gpus": world,
+            "ranks_share_one_device": True if args.share_device else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
+            "per_rank_key_synth_and_tables_seconds": per_rank_key_s,     # untimed set-up every rank does on its own GPU before the first barrier
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

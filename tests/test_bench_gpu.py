@@ -87,3 +87,16 @@ def test_bench_circuit_mode_end_to_end():
     assert d["checked"]["ok"] == d["checked"]["proofs"] and d["checked"]["proofs"] >= 3 + 3
     for k in ("solve_phase1_ms", "commit_ms", "solve_phase2_ms", "abc_and_prove_tail_ms"):
         assert e["phases_ms_per_proof"][k] >= 0
+
+
+def test_two_ranks_on_one_device_launcher_merge_and_checks():
+    """--gpus 2 --share-device: bench.py launches two ranks itself (torch.distributed.run, 127.0.0.1), both prove on device 0 and meet over
+    gloo — what the driver's multi-GPU run exercises that a one-GPU box otherwise never does: the launcher, the barrier / MAX contract, the
+    per-rank rows of the line, the checks split over the ranks, two keys built side by side"""
+    d = _bench("--gpus", "2", "--share-device", "--log2", "17", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-boundary", "--other-config-steps", "2")
+    assert d["n_gpus"] == 2 and d["ranks_share_one_device"] is True and d["scaling"] == "weak"
+    assert len(d["per_rank_ms_per_step"]) == 2 and len(d["per_rank_key_synth_and_tables_seconds"]) == 2
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]          # whole-job rate: both ranks' proofs over the MAX time
+    rows = d["checked"]["per_rank_ok_of_total"]
+    assert len(rows) == 2 and all(r[0] == r[1] and r[1] > 0 for r in rows) and d["checked"]["ok"] == d["checked"]["proofs"] == sum(r[1] for r in rows)
+    assert d["checked"]["h_verified"] is True and "boundary" not in d and d["two_in_flight"] is None

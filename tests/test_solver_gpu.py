@@ -261,7 +261,7 @@ def synth_solver_bytes(S, mats):
     return bytes(out), len(order)
 
 
-@pytest.mark.parametrize("n_inputs,n_cons", [(6, 700), (40, 5000)])
+@pytest.mark.parametrize("n_inputs,n_cons", [(6, 700), (40, 2000)])
 def test_prove_from_the_assigned_inputs_on_the_device(zk, n_inputs, n_cons):
     """groth16.Prove (prover.go:269) as ONE call from the assigned inputs: solver program -> w, constraint matrices -> a, b, c, prove tail, all in
     HBM (zkpor_prove_inputs) — the proof equals the oracle's proof of its own solved instance bit for bit and passes the pairing check; a second

@@ -800,6 +800,11 @@ inline Compiled Builder::finish() {
             if (p != NO_WIRE && p != me && alap[p] >= my_level) alap[p] = my_level - 1;
         };
         auto need_le = [&](const u32* cd, u64& p, u32 me, u32 my_level) { const u32 nt = cd[p++]; for (u32 k = 0; k < nt; ++k) { need(cd[p + 1], me, my_level); p += 2; } };
+        // a lookup reads EVERY entry of its table (the blueprint's Solve): the entries' producers sit below the table's earliest lookup — applied once
+        // per table, at its first lookup in program order (the last the reverse sweep meets), not once per lookup (10^5 lookups x 2 x 10^4 entries)
+        std::unordered_map<u32, std::pair<u32, u32>> table_first_min;   // block -> (first lookup instruction, lowest level among its lookups)
+        for (size_t i = 0; i < kind_.size(); ++i)
+            if (kind_[i] == K_LOOKUP) { const u32 blk = calldata_[arg_[i]]; if (!table_first_min.count(blk)) table_first_min[blk] = {(u32)i, max_level_ + 1}; }
         for (size_t ii = kind_.size(); ii-- > 0;) {
             const u32 i = (u32)ii, lv = alap[i];
             const u32* cd = calldata_.data() + arg_[i];
@@ -809,8 +814,12 @@ inline Compiled Builder::finish() {
                 u64 p = 3 + (u64)cd[2];
                 for (u32 k = 0; k < cd[1]; ++k) need_le(cd, p, i, lv);
             } else if (kind_[i] == K_LOOKUP) {
-                const u32* tb = calldata_.data() + cd[0];
-                for (u32 e = 0; e < cd[1]; ++e) { u64 p = tb[1 + e]; need_le(tb, p, i, lv); }
+                auto& fm = table_first_min[cd[0]];
+                fm.second = std::min(fm.second, lv);
+                if (fm.first == i) {
+                    const u32* tb = calldata_.data() + cd[0];
+                    for (u32 e = 0; e < tb[0]; ++e) { u64 p = tb[1 + e]; need_le(tb, p, NO_WIRE, fm.second); }
+                }
                 u64 p = 4;
                 for (u32 q = 0; q < cd[2]; ++q) need_le(cd, p, i, lv);
             } else if (kind_[i] == K_POSEIDON) {

@@ -225,6 +225,34 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
         if (it != hints.by_name.end()) fn[i] = it->second;   // a missing one only matters if an instruction calls it
         is_inverse[i] = fn[i] && hints.inverse_names.count(s.hint_names[i]) ? 1 : 0;
     }
+    {   // the gadget instructions' call data is checked once, up front (a table's entries once per table, not once per lookup)
+        std::set<std::pair<uint32_t, uint32_t>> tables_ok;
+        for (uint64_t i = 0; i < s.n_instructions; ++i) {
+            const uint32_t kind = InstrKind(s, i), arg = s.arg[i];
+            if (kind == INSTR_POSEIDON && !CheckPoseidonShape(s, arg, nw, r.n_coeff)) return fail(20, "the call data of Poseidon instruction " + std::to_string(i) + " is malformed");
+            if (kind == INSTR_LOOKUP) {
+                if ((uint64_t)arg + 4 > s.n_calldata) return fail(20, "the call data of lookup " + std::to_string(i) + " is malformed");
+                const std::pair<uint32_t, uint32_t> key{s.calldata[arg], s.calldata[arg + 1]};
+                if (tables_ok.count(key)) {
+                    // only the queries: walk them
+                    uint64_t p = (uint64_t)arg + 4;
+                    bool ok = (uint64_t)s.calldata[arg + 3] + s.calldata[arg + 2] <= nw;
+                    for (uint32_t q = 0; ok && q < s.calldata[arg + 2]; ++q) {
+                        ok = p < s.n_calldata;
+                        if (!ok) break;
+                        const uint64_t nt = s.calldata[p++];
+                        ok = p + 2 * nt <= s.n_calldata;
+                        for (uint64_t t = 0; ok && t < nt; ++t) ok = s.calldata[p + 2 * t] < r.n_coeff && s.calldata[p + 1 + 2 * t] < nw;
+                        p += 2 * nt;
+                    }
+                    if (!ok) return fail(20, "the call data of lookup " + std::to_string(i) + " is malformed");
+                } else {
+                    if (!CheckLookupShape(s, arg, nw, r.n_coeff)) return fail(20, "the call data of lookup " + std::to_string(i) + " is malformed");
+                    tables_ok.insert(key);
+                }
+            }
+        }
+    }
     if (threads < 1) threads = 1;
     uint64_t widest = 0;
     for (uint64_t l = 0; l < s.n_levels; ++l) widest = std::max<uint64_t>(widest, s.level_ptr[l + 1] - s.level_ptr[l]);
@@ -252,8 +280,7 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
             *out = acc;
             return 0;
         };
-        if (kind == INSTR_LOOKUP) {              // outputs = entry[index] (gnark BlueprintLookupHint.Solve)
-            if (!CheckLookupShape(s, arg, nw, r.n_coeff)) return 20;
+        if (kind == INSTR_LOOKUP) {              // outputs = entry[index] (gnark BlueprintLookupHint.Solve); shapes were checked before the run
             const uint32_t* cd = s.calldata + arg;
             const uint32_t* tb = s.calldata + cd[0];
             uint64_t p = 4;
@@ -271,7 +298,6 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
             return 0;
         }
         if (kind == INSTR_POSEIDON) {            // the whole sponge: every S-box's three product wires
-            if (!CheckPoseidonShape(s, arg, nw, r.n_coeff)) return 20;
             const uint32_t* cd = s.calldata + arg;
             sc.in.resize(cd[0]); sc.o.resize(cd[2]);
             uint64_t p = 4;
