@@ -629,38 +629,59 @@ def poseidon_tree_leg(ctx, log2_leaves=27, depth=28):
     import zkpor as _zk
     leaves = {}
     rng = np.random.default_rng(1)
-    for tier, n_acc in ((50, 1 << 17), (500, 1 << 14)):
-        acc = np.zeros(n_acc, dtype=_zk.ACCOUNT_DTYPE)
-        k = rng.integers(tier // 10, tier + 1, size=n_acc)
-        off = np.concatenate([[0], np.cumsum(k)[:-1]])
-        acc["n_assets"] = k; acc["asset_off"] = off
-        acc["id_be"][:, 24:] = rng.integers(0, 256, size=(n_acc, 8), dtype=np.uint8)
-        acc["equity"][:, 0] = rng.integers(0, 1 << 40, size=n_acc, dtype=np.uint64)
-        tot = int(k.sum())
-        assets = np.zeros(tot, dtype=_zk.ASSET_DTYPE)
-        for name in ("equity", "debt", "loan", "margin", "portfolio_margin"):
-            assets[name] = rng.integers(0, 1 << 40, size=tot, dtype=np.uint64)
-        # sorted distinct indices per account without a Python loop: a random start + consecutive indices (valid: strictly increasing, < 500)
-        start = rng.integers(0, 500 - k + 1)
-        assets["index"] = (np.repeat(start, k) + (np.arange(tot) - np.repeat(off, k))).astype(np.uint32)
+    base = {}
+    for tier, n_acc, label in ((50, 1 << 17, "tier_50"), (500, 1 << 14, "tier_500"), (500, 1 << 18, "tier_500_saturating")):
+        n_gen = min(n_acc, 1 << 14) if tier == 500 else n_acc
+        if (tier, n_gen) not in base:
+            acc = np.zeros(n_gen, dtype=_zk.ACCOUNT_DTYPE)
+            k = rng.integers(tier // 10, tier + 1, size=n_gen)
+            off = np.concatenate([[0], np.cumsum(k)[:-1]])
+            acc["n_assets"] = k; acc["asset_off"] = off
+            acc["id_be"][:, 24:] = rng.integers(0, 256, size=(n_gen, 8), dtype=np.uint8)
+            acc["equity"][:, 0] = rng.integers(0, 1 << 40, size=n_gen, dtype=np.uint64)
+            tot = int(k.sum())
+            assets = np.zeros(tot, dtype=_zk.ASSET_DTYPE)
+            for name in ("equity", "debt", "loan", "margin", "portfolio_margin"):
+                assets[name] = rng.integers(0, 1 << 40, size=tot, dtype=np.uint64)
+            # sorted distinct indices per account without a Python loop: a random start + consecutive indices (valid: strictly increasing, < 500)
+            start = rng.integers(0, 500 - k + 1)
+            assets["index"] = (np.repeat(start, k) + (np.arange(tot) - np.repeat(off, k))).astype(np.uint32)
+            base[(tier, n_gen)] = (acc, assets)
+        acc, assets = base[(tier, n_gen)]
+        if n_acc > n_gen:     # the saturating shape: the same asset lists under more account records (different ids), no more host data
+            acc = np.tile(acc, n_acc // n_gen)
+            acc["id_be"][:, 16:24] = rng.integers(0, 256, size=(n_acc, 8), dtype=np.uint8)
         ctx.poseidon_leaves(acc[:256], assets, tier)
         ctx.phase_reset()
         got = ctx.poseidon_leaves(acc, assets, tier)
         lms, _ = ctx.phase_ms("poseidon_leaf")
         m = 128
-        sub = acc[:m].copy()
-        okl = bool(np.array_equal(got[:m], O.fr_to_be(O.account_leaves(sub, assets, tier))))
+        sub = acc[-m:].copy()
+        okl = bool(np.array_equal(got[-m:], O.fr_to_be(O.account_leaves(sub, assets, tier))))
         t0 = time.perf_counter()
         O.account_leaves(acc[:2048].copy(), assets, tier)
         cpu_acc_rate = 2048 / (time.perf_counter() - t0)
         perms_per_acc = (2 * tier) // 12 + 2
-        leaves[f"tier_{tier}"] = {"accounts": n_acc, "kernel_ms": lms, "accounts_per_s": n_acc / (lms * 1e-3), "permutations_per_account": perms_per_acc,
-                                  "checked_against_oracle": okl, "cpu_port_accounts_per_s": cpu_acc_rate}
+        leaves[label] = {"accounts": n_acc, "kernel_ms": lms, "accounts_per_s": n_acc / (lms * 1e-3), "permutations_per_account": perms_per_acc,
+                         "kernel": "16 lanes per account" if n_acc < 65536 else "one thread per account",
+                         "checked_against_oracle": okl, "cpu_port_accounts_per_s": cpu_acc_rate}
+    # ---- CEX asset-list commitments (Witness.Run, witness.go:159-183): 4 096 boundary states of the 500-asset list, one 834-permutation chain each
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cex_cases as CC
+    consts = CC.make_assets(500, seed=3); totals = CC.make_totals(4096, 500, seed=4)
+    ctx.cex_commitments(consts, totals[:8])
+    ctx.phase_reset()
+    gotc = ctx.cex_commitments(consts, totals)
+    cms, _ = ctx.phase_ms("cex_commitments")
+    okc = bool(np.array_equal(gotc[:2], O.fr_to_be(O.cex_commitments(consts, totals[:2]))))
+    cex = {"states": 4096, "assets": 500, "kernel_ms": cms, "states_per_s": 4096 / (cms * 1e-3), "permutations_per_state": 834, "kernel": "16 lanes per state",
+           "checked_against_oracle": okc}
     return {"leaves": n, "depth": depth, "build_ms": ms, "hashes_per_s": (n - 1) / (ms * 1e-3), "checked_root_split_property": ok,
             "cpu_baseline": {"value": cpu_rate, "unit": "node hashes/s", "cores": cores, "cores_source": why, "kind": "port",
                              "sample": f"oracle width-3 Poseidon (plain HADES rounds, 4 x 64-bit Montgomery) over 2^18 pairs on {cores} threads; "
                                        f"2^{log2_leaves} leaves would take {n / cpu_rate:.0f} s"},
             "account_leaves": leaves,
+            "cex_commitments": cex,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "note": "width-3 Poseidon permutation per node (~370 field products): VALU-bound like the prove tail"}}
 

@@ -18,6 +18,18 @@ def test_cex_commitments_match_oracle(zk, n_assets, n_states):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_cex_commitments_one_thread_and_sixteen_lanes_per_state(zk, mode):
+    """the 834-permutation chain of a production-size state per thread ("poseidon_coop" 0) and across sixteen lanes (1): the same commitments"""
+    zk.set_param("poseidon_coop", mode)
+    try:
+        for n_assets, n_states in ((500, 3), (7, 5)):
+            consts = C.make_assets(n_assets, seed=40 + n_assets); totals = C.make_totals(n_states, n_assets, seed=50 + n_states)
+            assert np.array_equal(zk.cex_commitments(consts, totals), O.fr_to_be(O.cex_commitments(consts, totals)))
+    finally:
+        zk.set_param("poseidon_coop", -1)
+
+
 def test_commitment_depends_on_every_field(zk):
     consts = C.make_assets(5, seed=1)
     totals = C.make_totals(1, 5, seed=2)

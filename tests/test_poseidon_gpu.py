@@ -107,6 +107,20 @@ def test_account_leaves_match_oracle(zk, tier, max_assets, n):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_account_leaves_one_thread_and_sixteen_lanes_per_account(zk, mode):
+    """"poseidon_coop" 0 = one thread per account (the saturated-throughput kernel), 1 = sixteen lanes per account (the latency kernel that small
+    launches pick by themselves): both are the oracle's leaves, for both tiers, accounts without assets and with a full list"""
+    zk.set_param("poseidon_coop", mode)
+    try:
+        for tier, max_assets, n in ((50, 50, 70), (500, 500, 9), (10, 4, 5)):
+            rng = np.random.default_rng(900 + tier + mode)
+            acc, assets = _accounts(rng, n, tier, max_assets)
+            assert np.array_equal(zk.poseidon_leaves(acc, assets, tier), O.fr_to_be(O.account_leaves(acc, assets, tier)))
+    finally:
+        zk.set_param("poseidon_coop", -1)
+
+
 def test_account_leaves_tier500_at_scale(zk):
     """tier 500 (83 full sponge blocks + a ragged one + the leaf hash per account: a chain of 85 permutations per thread) on more accounts
     than one wave holds, with asset counts from 0 to the full tier: every leaf equals the oracle's"""

@@ -63,6 +63,7 @@ struct zkpor_ctx {
     int sort_block = 0;              // workgroup size of the onesweep radix sort: 0 = rocPRIM default (1024), 256, 512 (sort.hip)
     int aux_priority = 0;            // 1: the auxiliary (digit-stream) HIP stream is created with the highest stream priority
     int64_t solver_batch_from = 1 << 21;  // levels from this many generic instructions on run 4 per thread with ONE inversion per thread (solver.hip)
+    int poseidon_coop = -1;          // account leaves / CEX commitments 16 lanes per hash chain: -1 = when a launch has fewer than 65 536 chains, 0 = never, 1 = always
     int solver_poseidon = 1;         // the solver program's Poseidon instruction: 1 = sixteen lanes per call (latency), 0 = one thread per call
     int gpu_token = 1;               // host-pointer calls of several contexts on one GPU take turns on the device (api_core.hip GpuTurn)
 };

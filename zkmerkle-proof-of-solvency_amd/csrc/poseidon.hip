@@ -630,6 +630,86 @@ ZK_D Fr29 dot(const u32* krow, const u32* xs, int n) {
 }
 }  // namespace coop
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+namespace coop {
+struct Tr { Fr* w; u32 first, sbase, n_stash, stash_first; u32* ts; };   // where the S-box wires of a traced call go
+ZK_D u32 max4(u32 v, int lane) {                                        // the maximum over the wave's four groups
+    v = max(v, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)v));
+    return max(v, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)v));
+}
+// stashed partial-round wires -> their wire ids, one conversion per lane
+ZK_D void flush(Tr& tr, int j) {
+    wave_sync();
+    if ((u32)j < 3u * tr.n_stash) tr.w[tr.first + 3u * tr.stash_first + (u32)j] = Fr29::to32_div32(ld29(tr.ts + 9 * j));
+    wave_sync();
+    tr.n_stash = 0;
+}
+// ONE permutation of width t on the group's lanes (lane j < t holds element j in st; act = this group has a block — idle groups of the wave
+// run along on a valid dummy width so that the wave stays converged for the DPP / LDS steps of the live ones).  TR: the S-box wires go out.
+template <bool TR>
+ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D, Tr& tr) {
+    const int j = lane & 15, base_lane = lane & ~15;
+    const bool mine = act && j < t;           // this lane holds a state element
+    const int tt = act ? t : 2;
+    const u32* b29 = D.tab29;
+    const u32* rc = b29 + 9 * (size_t)D.rc_off[tt];
+    const u32* mm = b29 + 9 * (size_t)D.mds_off[tt];
+    const u32* prc = b29 + 9 * (size_t)D.prc_off[tt];
+    const u32* sp = b29 + 9 * (size_t)D.sp_off[tt];
+    const u32* post = b29 + 9 * (size_t)D.post_off[tt];
+    const int rp = D.rp[tt], jj = j < tt ? j : 0;
+    for (int half = 0; half < 2; ++half) {
+        for (int rr = 0; rr < POS_RF / 2; ++rr) {          // full round: S-boxes side by side, one matrix row per lane
+            const int r = half ? POS_RF / 2 + rp + rr : rr;
+            const Fr29 u = Fr29::reduce32(Fr29::add_l(st, ld29(rc + 9 * (r * tt + jj))));
+            const Fr29 x2 = Fr29::sqr(u), x4 = Fr29::sqr(x2), x5 = Fr29::mul(x4, u);
+            if (TR) {
+                if (mine) {
+                    Fr* o = tr.w + tr.first + 3u * (tr.sbase + (u32)j);
+                    o[0] = Fr29::to32_div32(x2); o[1] = Fr29::to32_div32(x4); o[2] = Fr29::to32_div32(x5);
+                }
+                if (act) tr.sbase += (u32)t;
+            }
+            put(xs + 9 * j, x5);
+            wave_sync();
+            st = dot(mm + 9 * (jj * tt), xs, tt);
+            wave_sync();
+        }
+        if (half) break;
+        for (int i = 0; i < rp; ++i) {                       // sparse partial round: 4 products deep
+            const Fr29 s_j = Fr29::reduce32(Fr29::add_l(st, ld29(prc + 9 * (i * tt + jj))));   // lane 0: u = st0 + k0
+            const u32* srow = sp + 9 * (size_t)(i * (2 * tt - 1));
+            const Fr29 ka = ld29(srow + 9 * jj);                                            // lane 0: sp[0] (used in the 4th product), lane j: v_j
+            const Fr29 p1 = Fr29::mul(j == 0 ? s_j : ka, s_j);                               // lane 0: x^2; lane j: v_j * s_j
+            const Fr29 x4 = Fr29::sqr(p1);
+            const Fr29 x5 = Fr29::mul(x4, s_j);                                              // lane 0 only is meaningful
+            if (TR && j == 0 && act) { put(tr.ts + 9 * (3 * tr.n_stash), p1); put(tr.ts + 9 * (3 * tr.n_stash + 1), x4); put(tr.ts + 9 * (3 * tr.n_stash + 2), x5); }
+            const Fr29 X = from_lane(x5, base_lane);
+            const Fr29 kb = j == 0 ? ka : ld29(srow + 9 * (tt + jj - 1));                    // lane 0: m00; lane j: what_j
+            const Fr29 e = Fr29::mul(kb, X);
+            Fr29 dterm = p1;
+            if (j == 0 || j >= tt) dterm = Fr29::zero();
+            const Fr29 Dsum = row_sum(dterm);                                                // lane 0: sum_j v_j s_j
+            st = j == 0 ? Fr29::reduce32(Fr29::add_l(e, Dsum)) : Fr29::add_l(s_j, e);          // loose on lanes j: reduced at the next constant add
+            if (TR) {
+                if (tr.n_stash == 0) tr.stash_first = tr.sbase;
+                if (act) { ++tr.n_stash; ++tr.sbase; }
+                if (max4(tr.n_stash, lane) == 5u) flush(tr, j);   // the wave's groups stash in lockstep only when they run the same width: flush on the fullest
+            }
+        }
+        {   // the dense block left over by the optimised rounds: st[1..t-1] = post * st[1..t-1]
+            if (TR) { if (max4(tr.n_stash, lane)) flush(tr, j); }
+            const Fr29 sj = Fr29::reduce32(st);
+            put(xs + 9 * j, sj);
+            wave_sync();
+            const Fr29 nv = dot(post + 9 * ((jj ? jj - 1 : 0) * (tt - 1)), xs + 9, tt - 1);
+            if (j) st = nv;
+            wave_sync();
+        }
+    }
+}
+}  // namespace coop
+#endif
 // one wave per workgroup, four calls per wave
 __global__ __launch_bounds__(64) void k_gadget_poseidon_coop(SolverProg P, const u32* __restrict__ instr, u32 n, Fr* w, uint8_t* known, u32* err, PosDev D,
                                                             const Fr* __restrict__ pre, const u32* __restrict__ pre_off) {
@@ -640,31 +720,19 @@ __global__ __launch_bounds__(64) void k_gadget_poseidon_coop(SolverProg P, const
     const u32 call = blockIdx.x * 4u + g;
     const bool live = call < n && !err[0];
     u32* xs = xch + g * XS;
-    u32* ts = stash + g * XS;
     const u32 ins = live ? instr[call] : 0u;
     const u32* cd = P.calldata + (live ? P.arg[ins] : 0u);
-    const u32 n_in = live ? cd[0] : 0u, first = live ? cd[1] : 0u, n_out = live ? cd[2] : 0u, carry_lane = live ? ((cd[3] >> 8) & 0xffu) : 0u;
+    const u32 n_in = live ? cd[0] : 0u, n_out = live ? cd[2] : 0u, carry_lane = live ? ((cd[3] >> 8) & 0xffu) : 0u;
     const u32 pre_at = (live && pre_off) ? pre_off[call] : 0xffffffffu;   // first element of this call's inputs in `pre`, or none
     u64 p = 4;                                   // every lane walks the call data (the expressions have no index)
     Fr29 st = Fr29::zero();                      // lane 0: the capacity element carried from block to block
-    u32 done = 0, sbase = 0;                     // inputs absorbed, S-boxes written so far
-    u32 n_stash = 0, stash_first = 0;            // partial-round wires waiting in the stash: values, first S-box
-    auto flush = [&](u32 count) {                // `count` stashed values -> their wires, one conversion per lane
-        wave_sync();
-        if ((u32)j < count) {
-            const Fr v = Fr29::to32_div32(ld29(ts + 9 * j));
-            w[first + 3u * stash_first + (u32)j] = v;
-        }
-        wave_sync();
-    };
-    // lanes of dead groups run along with n_in = 0 (no loop trips) — the wave stays converged for the DPP / LDS steps of the live ones
-    u32 max_in = n_in;                            // loop bound shared by the wave: the longest call of its four groups
-    max_in = max(max_in, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)max_in));
-    max_in = max(max_in, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)max_in));
+    u32 done = 0;                                // inputs absorbed
+    Tr tr{w, live ? cd[1] : 0u, 0u, 0u, 0u, stash + g * XS};
+    // lanes of dead groups run along with n_in = 0 — the loop bound is the longest call of the wave's four groups
+    const u32 max_in = max4(n_in, lane);
     for (u32 blk = 0; blk * 12u < max_in; ++blk) {
         const bool act = done < n_in;             // this group still has a block to absorb
         const u32 k = act ? (n_in - done < 12u ? n_in - done : 12u) : 0u;
-        const int t = (int)k + 1;
         // absorb: lane 1 + i takes input done + i — from the pre-evaluated inputs of a long call, else the lane evaluates its own expression
         // (every lane walks the term counts: the expressions carry no index)
         int bad = 0;
@@ -683,73 +751,13 @@ __global__ __launch_bounds__(64) void k_gadget_poseidon_coop(SolverProg P, const
         }
         if (bad) { if (atomicCAS(&err[0], 0u, (u32)bad) == 0u) err[1] = ins; }
         if (!act) { if (j) st = Fr29::zero(); }
-        const bool mine = act && j < t;           // this lane holds a state element
-        const int tt = act ? t : 2;               // table width of idle groups: anything valid
-        const u32* b29 = D.tab29;
-        const u32* rc = b29 + 9 * (size_t)D.rc_off[tt];
-        const u32* mm = b29 + 9 * (size_t)D.mds_off[tt];
-        const u32* prc = b29 + 9 * (size_t)D.prc_off[tt];
-        const u32* sp = b29 + 9 * (size_t)D.sp_off[tt];
-        const u32* post = b29 + 9 * (size_t)D.post_off[tt];
-        const int rp = D.rp[tt], jj = j < tt ? j : 0;
-        for (int half = 0; half < 2; ++half) {
-            for (int rr = 0; rr < POS_RF / 2; ++rr) {          // full round: S-boxes side by side, one matrix row per lane
-                const int r = half ? POS_RF / 2 + rp + rr : rr;
-                const Fr29 u = Fr29::reduce32(Fr29::add_l(st, ld29(rc + 9 * (r * tt + jj))));
-                const Fr29 x2 = Fr29::sqr(u), x4 = Fr29::sqr(x2), x5 = Fr29::mul(x4, u);
-                if (mine) {
-                    Fr* o = w + first + 3u * (sbase + (u32)j);
-                    o[0] = Fr29::to32_div32(x2); o[1] = Fr29::to32_div32(x4); o[2] = Fr29::to32_div32(x5);
-                }
-                put(xs + 9 * j, x5);
-                wave_sync();
-                st = dot(mm + 9 * (jj * tt), xs, tt);
-                wave_sync();
-                if (act) sbase += (u32)t;
-            }
-            if (half) break;
-            for (int i = 0; i < rp; ++i) {                       // sparse partial round: 4 products deep
-                const Fr29 s_j = Fr29::reduce32(Fr29::add_l(st, ld29(prc + 9 * (i * tt + jj))));   // lane 0: u = st0 + k0
-                const u32* srow = sp + 9 * (size_t)(i * (2 * tt - 1));
-                const Fr29 ka = ld29(srow + 9 * jj);                                            // lane 0: sp[0] (used in P4), lane j: v_j
-                const Fr29 p1 = Fr29::mul(j == 0 ? s_j : ka, s_j);                               // lane 0: x^2; lane j: v_j * s_j
-                const Fr29 x4 = Fr29::sqr(p1);
-                const Fr29 x5 = Fr29::mul(x4, s_j);                                              // lane 0 only is meaningful
-                if (j == 0 && act) { put(ts + 9 * (3 * n_stash), p1); put(ts + 9 * (3 * n_stash + 1), x4); put(ts + 9 * (3 * n_stash + 2), x5); }
-                const Fr29 X = from_lane(x5, base_lane);
-                const Fr29 kb = j == 0 ? ka : ld29(srow + 9 * (tt + jj - 1));                    // lane 0: m00; lane j: what_j
-                const Fr29 e = Fr29::mul(kb, X);
-                Fr29 dterm = p1;
-                if (j == 0 || j >= tt) dterm = Fr29::zero();
-                const Fr29 Dsum = row_sum(dterm);                                                // lane 0: sum_j v_j s_j
-                st = j == 0 ? Fr29::reduce32(Fr29::add_l(e, Dsum)) : Fr29::add_l(s_j, e);          // loose on lanes j: reduced at the next constant add
-                if (n_stash == 0) stash_first = sbase;
-                if (act) { ++n_stash; ++sbase; }
-                // the wave's groups stash in lockstep only when they run the same width; flush on the fullest
-                u32 fill = n_stash;
-                fill = max(fill, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)fill));
-                fill = max(fill, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)fill));
-                if (fill == 5u) { flush(3u * n_stash); n_stash = 0; }
-            }
-            {   // the dense block left over by the optimised rounds: st[1..t-1] = post * st[1..t-1]
-                u32 fill = n_stash;
-                fill = max(fill, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)fill));
-                fill = max(fill, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)fill));
-                if (fill) { flush(3u * n_stash); n_stash = 0; }
-                const Fr29 sj = Fr29::reduce32(st);
-                put(xs + 9 * j, sj);
-                wave_sync();
-                const Fr29 nv = dot(post + 9 * ((jj ? jj - 1 : 0) * (tt - 1)), xs + 9, tt - 1);
-                if (j) st = nv;
-                wave_sync();
-            }
-        }
+        permute<true>(st, act, (int)k + 1, lane, xs, D, tr);
         // the next block's capacity element sits on lane 0
         const Fr29 cap = from_lane(st, base_lane + (int)carry_lane);
         if (j == 0) st = cap;
         if (act) done += k;
     }
-    if (live) for (u32 q = (u32)j; q < n_out; q += (u32)G) known[first + q] = 1;
+    if (live) for (u32 q = (u32)j; q < n_out; q += (u32)G) known[tr.first + q] = 1;
 #endif
 }
 
@@ -963,6 +971,79 @@ __global__ __launch_bounds__(64, 2) void k_account_leaves(const AccountHdr* __re
     out[i] = sp.finish(P);
 }
 
+// The same hash, one account per 16 LANES (coop::permute): a tier-500 account is a serial chain of 84 + 1 permutations, and below ~10^5 accounts
+// a launch lasts as long as ONE chain — 16 k accounts took 0.28 s with one thread each (58 k accounts/s, 256 waves on 1 024 SIMDs).  Every lane
+// walks the padding rule to the slot of its own element (integer work), the permutations run across the lanes.
+__global__ __launch_bounds__(64) void k_account_leaves_coop(const AccountHdr* __restrict__ acc, const AssetRec* __restrict__ assets,
+                                                            u32 n, int tier, Fr* __restrict__ out, PosDev D) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace coop;
+    __shared__ u32 xch[4 * XS];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, base_lane = lane & ~15;
+    const u32 i = blockIdx.x * 4u + g;
+    const bool live = i < n;
+    u32* xs = xch + g * XS;
+    AccountHdr a;
+    if (live) a = acc[i]; else { a.n_assets = 0; a.asset_off = 0; }
+    const AssetRec* as = assets + a.asset_off;
+    const u32 n_in = live ? 2u * (u32)tier : 0u;
+    // this lane's cursor over the padded slots (PaddingAccountAssets, utils.go:147-186): state after `pos` consumed slots
+    int padding = tier - (int)a.n_assets, cur_pad = 0;
+    u32 cur_idx = 0, ai = 0, pos = 0;
+    bool slot_real = false; u32 slot_ai = 0, slot_pad_idx = 0;
+    auto consume_to = [&](u32 slot) {             // consume slots pos .. slot: afterwards slot_* describe `slot`
+        while (pos <= slot) {
+            bool real = ai < a.n_assets ? !(cur_pad < padding && cur_idx < as[ai].index) : false;
+            slot_real = real;
+            if (real) { slot_ai = ai; cur_idx = as[ai].index + 1; ++ai; }
+            else { slot_pad_idx = cur_idx; ++cur_idx; ++cur_pad; }
+            ++pos;
+        }
+    };
+    Fr29 st = Fr29::zero(), last = Fr29::zero();
+    u32 done = 0;
+    Tr tr{nullptr, 0u, 0u, 0u, 0u, nullptr};
+    const u32 max_in = max4(n_in, lane);
+    for (u32 blk = 0; blk * 12u < max_in; ++blk) {
+        const bool act = done < n_in;
+        const u32 k = act ? (n_in - done < 12u ? n_in - done : 12u) : 0u;
+        if (act && j >= 1 && (u32)j <= k) {
+            const u32 e = done + (u32)j - 1u;
+            consume_to(e >> 1);
+            Fr v;
+            if (slot_real) { const AssetRec r = as[slot_ai]; v = (e & 1u) ? pack3(r.loan, r.margin, r.portfolio_margin) : pack3(r.index, r.equity, r.debt); }
+            else v = (e & 1u) ? Fr::zero() : pack3(slot_pad_idx, 0, 0);
+            st = Fr29::from32<5>(v);
+        }
+        if (!act) { if (j) st = Fr29::zero(); }
+        permute<false>(st, act, (int)k + 1, lane, xs, D, tr);
+        const Fr29 o = from_lane(st, base_lane + D.out_idx);
+        if (act) last = o;
+        const Fr29 cap = from_lane(st, base_lane + D.carry_idx);
+        if (j == 0) st = cap;
+        if (act) done += k;
+    }
+    // the leaf: Poseidon(id, equity, debt, collateral, commitment) — a fresh sponge, one block of width 6
+    st = Fr29::zero();
+    if (live) {
+        if (j == 1) st = Fr29::from32<5>(from_be32(a.id_be));
+        else if (j == 2) st = Fr29::from32<5>(from_u128(a.equity));
+        else if (j == 3) st = Fr29::from32<5>(from_u128(a.debt));
+        else if (j == 4) st = Fr29::from32<5>(from_u128(a.collateral));
+        else if (j == 5) st = last;
+    }
+    permute<false>(st, live, 6, lane, xs, D, tr);
+    const Fr29 leaf = from_lane(st, base_lane + D.out_idx);
+    if (live && j == 0) out[i] = Fr29::to32_div32(leaf);
+#endif
+}
+// below this many hash chains a launch is latency-bound and the chains run 16 lanes each ("poseidon_coop": -1 = this rule, 0 = never, 1 = always)
+static bool use_coop(const zkpor_ctx* ctx, size_t n) { return ctx->poseidon_coop < 0 ? n < 65536 : ctx->poseidon_coop != 0; }
+static void launch_account_leaves(zkpor_ctx* ctx, const AccountHdr* dacc, const AssetRec* das, u32 n, int tier, Fr* dout, const PosDev& P) {
+    if (use_coop(ctx, n)) hipLaunchKernelGGL(k_account_leaves_coop, dim3((n + 3u) / 4u), dim3(64), 0, ctx->stream, dacc, das, n, tier, dout, P);
+    else hipLaunchKernelGGL(k_account_leaves, dim3((n + 63u) / 64u), dim3(64), 0, ctx->stream, dacc, das, n, tier, dout, P);
+}
+
 // Montgomery Fr <-> 32-byte big-endian
 __global__ void k_fr_to_be(const Fr* __restrict__ in, uint8_t* __restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1069,6 +1150,46 @@ __global__ __launch_bounds__(64, 2) void k_cex_commitments(const CexAssetConst* 
         for (int e = 0; e < 18; ++e) sp.push(P, tier_elems[a * 18u + e]);
     }
     out[i] = sp.finish(P);
+}
+// one CEX state per 16 lanes: the commitment is ONE chain of 834 permutations (500 assets x 20 elements), and a run has few states — two per
+// batch, a few thousand for a whole 10^8-account run — so the launch lasts as long as one chain: 1.28 s per thread, ~0.2 s across the lanes
+__global__ __launch_bounds__(64) void k_cex_commitments_coop(const CexAssetConst* __restrict__ consts, const Fr* __restrict__ tier_elems,
+                                                             u32 n_assets, const CexTotals* __restrict__ totals, u32 n_states,
+                                                             Fr* __restrict__ out, PosDev D) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace coop;
+    __shared__ u32 xch[4 * XS];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, base_lane = lane & ~15;
+    const u32 i = blockIdx.x * 4u + g;
+    const bool live = i < n_states;
+    u32* xs = xch + g * XS;
+    const CexTotals* t = totals + (size_t)(live ? i : 0u) * n_assets;
+    const u32 n_in = live ? n_assets * 20u : 0u;
+    Fr29 st = Fr29::zero(), last = Fr29::zero();
+    u32 done = 0;
+    Tr tr{nullptr, 0u, 0u, 0u, 0u, nullptr};
+    const u32 max_in = max4(n_in, lane);
+    for (u32 blk = 0; blk * 12u < max_in; ++blk) {
+        const bool act = done < n_in;
+        const u32 k = act ? (n_in - done < 12u ? n_in - done : 12u) : 0u;
+        if (act && j >= 1 && (u32)j <= k) {
+            const u32 e = done + (u32)j - 1u, a = e / 20u, f = e % 20u;
+            Fr v;
+            if (f == 0) { const CexTotals c = t[a]; v = pack3(c.total_equity, c.total_debt, consts[a].base_price); }
+            else if (f == 1) { const CexTotals c = t[a]; v = pack3(c.loan_collateral, c.margin_collateral, c.portfolio_margin_collateral); }
+            else v = tier_elems[a * 18u + f - 2u];
+            st = Fr29::from32<5>(v);
+        }
+        if (!act) { if (j) st = Fr29::zero(); }
+        permute<false>(st, act, (int)k + 1, lane, xs, D, tr);
+        const Fr29 o = from_lane(st, base_lane + D.out_idx);
+        if (act) last = o;
+        const Fr29 cap = from_lane(st, base_lane + D.carry_idx);
+        if (j == 0) st = cap;
+        if (act) done += k;
+    }
+    if (live && j == 0) out[i] = Fr29::to32_div32(last);
+#endif
 }
 // BatchCommitment = PoseidonBytes(root, before, after, min index, max index) (witness.go:185-198); an index of 0 is the
 // byte string [0x00] there, i.e. the element 0 either way
@@ -1490,7 +1611,7 @@ int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, c
                            (n_assets_total && hipMemcpyAsync(das, assets, n_assets_total * sizeof(AssetRec), hipMemcpyHostToDevice, ctx->stream) != hipSuccess))) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
     if (rc == ZKPOR_OK) {
         PhaseScope ps(ctx, "poseidon_leaf");
-        hipLaunchKernelGGL(k_account_leaves, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, dacc, das, (u32)n, tier, dout, P);
+        launch_account_leaves(ctx, dacc, das, (u32)n, tier, dout, P);
         hipLaunchKernelGGL(k_fr_to_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dout, dbe, n);
         if (hipGetLastError() != hipSuccess) { ctx->err = "poseidon launch failed"; rc = ZKPOR_E_HIP; }
     }
@@ -1715,8 +1836,12 @@ int32_t zkpor_cex_commitments(zkpor_ctx* ctx, const zkpor_cex_asset_const_t* ass
         hipLaunchKernelGGL(k_cex_tier_elems, dim3((unsigned)((n_assets * 18 + 127) / 128)), dim3(128), 0, ctx->stream, (const CexAssetConst*)dc.p,
                            (u32)n_assets, (Fr*)de.p);
         ZK_KERNEL_CHECK(ctx);
-        hipLaunchKernelGGL(k_cex_commitments, dim3((unsigned)((n_states + 63) / 64)), dim3(64), 0, ctx->stream, (const CexAssetConst*)dc.p,
-                           (const Fr*)de.p, (u32)n_assets, (const CexTotals*)dt.p, (u32)n_states, (Fr*)dout.p, P);
+        if (use_coop(ctx, n_states))
+            hipLaunchKernelGGL(k_cex_commitments_coop, dim3((unsigned)((n_states + 3) / 4)), dim3(64), 0, ctx->stream, (const CexAssetConst*)dc.p,
+                               (const Fr*)de.p, (u32)n_assets, (const CexTotals*)dt.p, (u32)n_states, (Fr*)dout.p, P);
+        else
+            hipLaunchKernelGGL(k_cex_commitments, dim3((unsigned)((n_states + 63) / 64)), dim3(64), 0, ctx->stream, (const CexAssetConst*)dc.p,
+                               (const Fr*)de.p, (u32)n_assets, (const CexTotals*)dt.p, (u32)n_states, (Fr*)dout.p, P);
         ZK_KERNEL_CHECK(ctx);
     }
     hipLaunchKernelGGL(k_fr_to_be, dim3((unsigned)((n_states + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)dout.p, (uint8_t*)dbe.p, n_states);
@@ -1807,8 +1932,7 @@ int32_t zkpor_tree_set_accounts(zkpor_tree* t, uint64_t first_key, zkpor_account
     }
     {
         PhaseScope ps(ctx, "poseidon_leaf");
-        hipLaunchKernelGGL(k_account_leaves, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const AccountHdr*)da.p, (const AssetRec*)ds.p, (u32)n, tier,
-                           (Fr*)dl.p, P);
+        launch_account_leaves(ctx, (const AccountHdr*)da.p, (const AssetRec*)ds.p, (u32)n, tier, (Fr*)dl.p, P);
         ZK_KERNEL_CHECK(ctx);
     }
     hipLaunchKernelGGL(k_tree_set_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, t->dev, (u64)first_key, (const Fr*)dl.p, n);
