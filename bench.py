@@ -970,7 +970,7 @@ def circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, shape, tier_name, see
             com, pok, _ = C.solve_on_device(ctx, dc, pk, cur.data_ptr(), cv2.data_ptr(), d_in.data_ptr(), None, staged=True)
             C.stage_inputs(ctx, dc, nxt.data_ptr(), d_in.data_ptr())
             dc.solver.prefetch_dev(nxt.data_ptr(), n_in_wires)
-            dc.r1cs.eval_dev(cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), D)
+            dc.solver.eval_abc_dev(cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), D)
             r, s_ = blinding(i)
             proof = ctx.prove_tail_dev(pk, cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), r, s_)
             state["last"] = cur
@@ -982,6 +982,7 @@ def circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, shape, tier_name, see
         w_host = np.empty((n_wires, 4), np.uint64)
         ck(lib.zkpor_dev_download(ctx.h, zkpor._p(w_host), vp(w.data_ptr()), ctypes.c_size_t(w_host.nbytes)))      # before the e2e region reuses w
         if e2e_steps > 0:
+            dc.solver.set_abc_dev(a.data_ptr(), b.data_ptr(), c.data_ptr())
             C.stage_inputs(ctx, dc, wx.data_ptr(), d_in.data_ptr())
             dc.solver.prefetch_dev(wx.data_ptr(), n_in_wires)
             e2e(30000, None)
@@ -1104,6 +1105,7 @@ def main():
                     "w, a, b, c and the committed values come from solving a synthetic batch on the device, the key carries the circuit's sparsity, and the "
                     "line gains `end_to_end`.  Default at --log2 26: the tier's production shape (50,500,1380 / 500,500,200)")
     ap.add_argument("--no-circuit", action="store_true", help="the round-1..3 workload: D = n_wires = 2^log2, estimated scalar mixture, seeded key sparsity")
+    ap.add_argument("--no-solver-rows", action="store_true", help="end-to-end region: evaluate a, b, c of every row from the matrices (do not let the Poseidon instructions write their own rows)")
     ap.add_argument("--no-prefetch", action="store_true", help="end-to-end region: do not start the next proof's CEX commitment chains under the current proof's prove tail")
     ap.add_argument("--e2e-steps", type=int, default=-1, help="proofs of the end-to-end region (inputs -> solver program -> commitment -> a, b, c -> prove tail); default max(3, steps // 4)")
     ap.add_argument("--share-device", action="store_true", help="TEST ONLY: every rank proves on device 0 and the ranks meet over gloo — the launcher, the per-rank "
@@ -1495,7 +1497,7 @@ def main():
                 if prefetch:
                     C.stage_inputs(ctx, dc, nxt.data_ptr(), circ["d_in"].data_ptr())
                     dc.solver.prefetch_dev(nxt.data_ptr(), n_in_wires)
-                dc.r1cs.eval_dev(cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), D)
+                dc.solver.eval_abc_dev(cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), D)     # the rows the Poseidon instructions have not written already
                 r, s = blinding(i)
                 proof = ctx.prove_tail_dev(pk, cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), r, s)
                 tm["abc_and_prove_tail_ms"] = (time.perf_counter() - t1_) * 1e3
@@ -1503,6 +1505,8 @@ def main():
                 state["last"] = cur
                 return proof, com, pok, tm
 
+            if not args.no_solver_rows:
+                dc.solver.set_abc_dev(a.data_ptr(), b.data_ptr(), c.data_ptr())
             if prefetch:
                 C.stage_inputs(ctx, dc, w2s[0].data_ptr(), circ["d_in"].data_ptr())
                 dc.solver.prefetch_dev(w2s[0].data_ptr(), n_in_wires)
@@ -1536,6 +1540,8 @@ def main():
             # the solved wire vector of the LAST e2e proof must be the one the headline proofs used (same inputs, same commitment, same challenge)
             w2 = state["last"]
             e2e["next_proofs_hash_chains_prefetched"] = prefetch
+            e2e["poseidon_rows_written_by_the_solver"] = not args.no_solver_rows
+            dc.solver.set_abc_dev(None, None, None)
             e2e["same_wires_as_headline"] = bool(torch.equal(w2, w)) if args.scalars == "witness" else None
             e2e["constraints_failing_on_device"] = dc.r1cs.check_dev(w2.data_ptr())[0]
             ctx.sync()

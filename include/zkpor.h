@@ -489,6 +489,14 @@ int32_t zkpor_solver_dims(const zkpor_solver* solver, uint64_t dims[7]);
  * refuses its input (range check violated, zero divisor), an instruction with two unknown wires (wrong level order). */
 int32_t zkpor_solver_start_dev(zkpor_solver* solver, void* d_w, size_t n_inputs, uint8_t* d_known_or_null, uint32_t* paused_instr);
 int32_t zkpor_solver_resume_dev(zkpor_solver* solver, uint32_t* paused_instr);
+/* a, b, c without evaluating the hash gadget's rows twice.  Two thirds of the terms of BatchCreateUserCircuit's matrices sit in the rows of its
+ * Poseidon gadgets (14 to 79 terms each: the S-box input), and the solver's Poseidon instruction has exactly that value in a register.
+ * zkpor_solver_set_abc_dev names the prove tail's a / b / c buffers (2^log2_domain elements each) for the runs that follow: the instruction
+ * then writes a, b, c of its own rows (program container: firstRow); zkpor_solver_eval_abc_dev, called after the run, evaluates every other
+ * row (zkpor_r1cs_eval_dev restricted to them) into the same buffers.  Bit-identical to zkpor_r1cs_eval_dev of the solved vector
+ * (tests/test_circuit_gpu.py).  NULL pointers switch it off; ASYNC / prefetched instructions never write rows. */
+int32_t zkpor_solver_set_abc_dev(zkpor_solver* solver, void* d_a, void* d_b, void* d_c);
+int32_t zkpor_solver_eval_abc_dev(zkpor_solver* solver, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size);
 /* Pipelining across proofs: starts the NEXT proof's long serial hash chains (instructions the program flags ASYNC — the two 10 000-element
  * CEX commitments of BatchCreateUserCircuit, circuit/batch_create_user_circuit.go:129,320: 834 chained permutations each, ~0.2 s of ONE wave)
  * on the solver's side stream while the current proof still runs its prove tail.  d_w_next: the next proof's wire vector with the assignment

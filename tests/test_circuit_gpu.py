@@ -93,6 +93,39 @@ def test_configs0_real_size_8_users_of_the_50_asset_tier(zk):
     assert dims["levels"] < 3000 and dims["external_levels"] == 1
 
 
+def test_rows_written_by_the_poseidon_instructions_equal_the_evaluated_ones(zk):
+    """zkpor_solver_set_abc_dev / zkpor_solver_eval_abc_dev: the Poseidon instructions write a, b, c of their own constraint rows (they hold the S-box
+    input; its expression has 14 to 79 terms), the evaluation kernel does the rest — bit-identical to evaluating every row from the matrices.
+    With the per-thread kernel nothing is written by the solver and the same call evaluates everything."""
+    shape = (20, 40, 4)
+    inp = C.synth_inputs(*shape, seed=9)
+    cir = C.Circuit(*shape)
+    pk = zkpor.ProvingKey(zk)
+    dc = C.DeviceCircuit(zk, cir)
+    log2 = int(np.ceil(np.log2(cir.n_constraints)))
+    D = 1 << log2
+    bufs = [zk.alloc(32 * n) for n in (cir.n_wires, cir.n_committed + 1, D, D, D, D, D, D)]
+    try:
+        pk.synth(log2, cir.n_wires, cir.n_public, cir.n_committed, SEED)
+        for variant in (1, 0):
+            zk.set_param("solver_poseidon", variant)
+            for b in bufs[2:]:
+                b.upload(np.full((D, 4), 0xDEADBEEF, np.uint64))
+            dc.solver.set_abc_dev(bufs[2].ptr, bufs[3].ptr, bufs[4].ptr)
+            C.solve_on_device(zk, dc, pk, bufs[0].ptr, bufs[1].ptr, inp)
+            dc.solver.eval_abc_dev(bufs[0].ptr, bufs[2].ptr, bufs[3].ptr, bufs[4].ptr, D)
+            dc.r1cs.eval_dev(bufs[0].ptr, bufs[5].ptr, bufs[6].ptr, bufs[7].ptr, D)
+            for x, y in zip(bufs[2:5], bufs[5:8]):
+                assert np.array_equal(x.download(np.uint64, (D, 4)), y.download(np.uint64, (D, 4)))
+        dc.solver.set_abc_dev(None, None, None)
+        assert cir.census["poseidon_call"] > 100
+    finally:
+        zk.set_param("solver_poseidon", 1)
+        for b in bufs:
+            b.free()
+        dc.close(); pk.close(); cir.close()
+
+
 def test_prefetching_the_next_proofs_hash_chains_changes_no_wire(zk):
     """zkpor_solver_prefetch_dev: the ASYNC instructions (the two CEX commitments) of the next proof started on the side stream before its run —
     three proofs over two alternating wire vectors, each bit-identical to a run without prefetch; a prefetch for a vector the next run does

@@ -27,13 +27,19 @@ def run(shape, compare, seed=0x5A4B504F52, variant=1):
     print("  key %.2fs upload+create %.2fs" % (t3 - t2, t4 - t3), dc.solver.dims(), flush=True)
     bufs = [ctx.alloc(32 * n) for n in (cir.n_wires, D, D, D, cir.n_committed + 1)]
     try:
+        rows = os.environ.get("E2E_ROWS", "0") == "1"
+        if rows:
+            dc.solver.set_abc_dev(bufs[1].ptr, bufs[2].ptr, bufs[3].ptr)
         for rep in range(3):
             tm = {}
             ctx.phase_reset()
             ta = time.perf_counter()
             com, pok, ch = C.solve_on_device(ctx, dc, pk, bufs[0].ptr, bufs[4].ptr, inp, tm)
             tb = time.perf_counter()
-            dc.r1cs.eval_dev(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, D)
+            if rows:
+                dc.solver.eval_abc_dev(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, D)
+            else:
+                dc.r1cs.eval_dev(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, D)
             ctx.sync()
             tc = time.perf_counter()
             rr = O.fr_random(171 + rep, 1)[0]; ss = O.fr_random(272 + rep, 1)[0]

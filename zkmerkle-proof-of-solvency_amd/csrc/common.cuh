@@ -196,7 +196,7 @@ struct GpuTurn {
     void release();
 };
 // r1cs.hip: a, b, c = L.w, R.w, O.w queued on `ctx`'s stream (any context of the GPU the matrices live on: they are only read)
-int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size);
+int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size, const u32* d_skip = nullptr);
 void r1cs_dims(const zkpor_r1cs* r, size_t* n_constraints, size_t* n_wires, int* device);
 
 // solver.hip: the context and the constraint system a solver program was created on

@@ -632,15 +632,31 @@ ZK_D Fr29 dot(const u32* krow, const u32* xs, int n) {
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 namespace coop {
-struct Tr { Fr* w; u32 first, sbase, n_stash, stash_first; u32* ts; };   // where the S-box wires of a traced call go
+// where the S-box wires of a traced call go; a != nullptr: the call's constraint rows (three per S-box from `row`: u u = x^2, x^2 x^2 = x^4,
+// x^4 u = x^5) get their a, b, c written here as well — the S-box input u is in a register, evaluating its 14- to 79-term expression again
+// for the quotient is two thirds of k_r1cs_eval's terms
+struct Tr { Fr* w; u32 first, sbase, n_stash, stash_first; u32* ts; Fr* a; Fr* b; Fr* c; u32 row; };
 ZK_D u32 max4(u32 v, int lane) {                                        // the maximum over the wave's four groups
     v = max(v, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)v));
     return max(v, (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)v));
 }
-// stashed partial-round wires -> their wire ids, one conversion per lane
+// stashed partial-round values -> their wire ids (and rows), one conversion per lane.  Per S-box 3 values (x^2, x^4, x^5), or 4 (u first) with rows.
 ZK_D void flush(Tr& tr, int j) {
     wave_sync();
-    if ((u32)j < 3u * tr.n_stash) tr.w[tr.first + 3u * tr.stash_first + (u32)j] = Fr29::to32_div32(ld29(tr.ts + 9 * j));
+    if (tr.a) {
+        if ((u32)j < 4u * tr.n_stash) {
+            const Fr v = Fr29::to32_div32(ld29(tr.ts + 9 * j));
+            const u32 sb = tr.stash_first + ((u32)j >> 2), comp = (u32)j & 3u;
+            const size_t r = (size_t)tr.row + 3u * sb;
+            if (comp == 0) { tr.a[r] = v; tr.b[r] = v; tr.b[r + 2] = v; }
+            else {
+                tr.w[tr.first + 3u * sb + comp - 1u] = v;
+                if (comp == 1) { tr.c[r] = v; tr.a[r + 1] = v; tr.b[r + 1] = v; }
+                else if (comp == 2) { tr.c[r + 1] = v; tr.a[r + 2] = v; }
+                else tr.c[r + 2] = v;
+            }
+        }
+    } else if ((u32)j < 3u * tr.n_stash) tr.w[tr.first + 3u * tr.stash_first + (u32)j] = Fr29::to32_div32(ld29(tr.ts + 9 * j));
     wave_sync();
     tr.n_stash = 0;
 }
@@ -666,7 +682,15 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
             if (TR) {
                 if (mine) {
                     Fr* o = tr.w + tr.first + 3u * (tr.sbase + (u32)j);
-                    o[0] = Fr29::to32_div32(x2); o[1] = Fr29::to32_div32(x4); o[2] = Fr29::to32_div32(x5);
+                    const Fr X2 = Fr29::to32_div32(x2), X4 = Fr29::to32_div32(x4), X5 = Fr29::to32_div32(x5);
+                    o[0] = X2; o[1] = X4; o[2] = X5;
+                    if (tr.a) {
+                        const Fr U = Fr29::to32_div32(u);
+                        const size_t r0 = (size_t)tr.row + 3u * (tr.sbase + (u32)j);
+                        tr.a[r0] = U; tr.b[r0] = U; tr.c[r0] = X2;
+                        tr.a[r0 + 1] = X2; tr.b[r0 + 1] = X2; tr.c[r0 + 1] = X4;
+                        tr.a[r0 + 2] = X4; tr.b[r0 + 2] = U; tr.c[r0 + 2] = X5;
+                    }
                 }
                 if (act) tr.sbase += (u32)t;
             }
@@ -683,7 +707,10 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
             const Fr29 p1 = Fr29::mul(j == 0 ? s_j : ka, s_j);                               // lane 0: x^2; lane j: v_j * s_j
             const Fr29 x4 = Fr29::sqr(p1);
             const Fr29 x5 = Fr29::mul(x4, s_j);                                              // lane 0 only is meaningful
-            if (TR && j == 0 && act) { put(tr.ts + 9 * (3 * tr.n_stash), p1); put(tr.ts + 9 * (3 * tr.n_stash + 1), x4); put(tr.ts + 9 * (3 * tr.n_stash + 2), x5); }
+            if (TR && j == 0 && act) {
+                if (tr.a) { u32* q = tr.ts + 9 * (4 * tr.n_stash); put(q, s_j); put(q + 9, p1); put(q + 18, x4); put(q + 27, x5); }
+                else { u32* q = tr.ts + 9 * (3 * tr.n_stash); put(q, p1); put(q + 9, x4); put(q + 18, x5); }
+            }
             const Fr29 X = from_lane(x5, base_lane);
             const Fr29 kb = j == 0 ? ka : ld29(srow + 9 * (tt + jj - 1));                    // lane 0: m00; lane j: what_j
             const Fr29 e = Fr29::mul(kb, X);
@@ -694,7 +721,7 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
             if (TR) {
                 if (tr.n_stash == 0) tr.stash_first = tr.sbase;
                 if (act) { ++tr.n_stash; ++tr.sbase; }
-                if (max4(tr.n_stash, lane) == 5u) flush(tr, j);   // the wave's groups stash in lockstep only when they run the same width: flush on the fullest
+                if (max4(tr.n_stash, lane) == (tr.a ? 4u : 5u)) flush(tr, j);   // the wave's groups stash in lockstep only when they run the same width: flush on the fullest
             }
         }
         {   // the dense block left over by the optimised rounds: st[1..t-1] = post * st[1..t-1]
@@ -712,7 +739,7 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
 #endif
 // one wave per workgroup, four calls per wave
 __global__ __launch_bounds__(64) void k_gadget_poseidon_coop(SolverProg P, const u32* __restrict__ instr, u32 n, Fr* w, uint8_t* known, u32* err, PosDev D,
-                                                            const Fr* __restrict__ pre, const u32* __restrict__ pre_off) {
+                                                            const Fr* __restrict__ pre, const u32* __restrict__ pre_off, Fr* ra, Fr* rb, Fr* rc) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using namespace coop;
     __shared__ u32 xch[4 * XS], stash[4 * XS];
@@ -724,10 +751,11 @@ __global__ __launch_bounds__(64) void k_gadget_poseidon_coop(SolverProg P, const
     const u32* cd = P.calldata + (live ? P.arg[ins] : 0u);
     const u32 n_in = live ? cd[0] : 0u, n_out = live ? cd[2] : 0u, carry_lane = live ? ((cd[3] >> 8) & 0xffu) : 0u;
     const u32 pre_at = (live && pre_off) ? pre_off[call] : 0xffffffffu;   // first element of this call's inputs in `pre`, or none
-    u64 p = 4;                                   // every lane walks the call data (the expressions have no index)
+    u64 p = SI_POSEIDON_HDR;                     // every lane walks the call data (the expressions have no index)
     Fr29 st = Fr29::zero();                      // lane 0: the capacity element carried from block to block
     u32 done = 0;                                // inputs absorbed
-    Tr tr{w, live ? cd[1] : 0u, 0u, 0u, 0u, stash + g * XS};
+    const bool rows = ra != nullptr && live && cd[4] != 0xffffffffu;   // all groups of the wave agree when ra is null; a call without known rows stashes 3 per S-box
+    Tr tr{w, live ? cd[1] : 0u, 0u, 0u, 0u, stash + g * XS, rows ? ra : nullptr, rb, rc, live ? cd[4] : 0u};
     // lanes of dead groups run along with n_in = 0 — the loop bound is the longest call of the wave's four groups
     const u32 max_in = max4(n_in, lane);
     for (u32 blk = 0; blk * 12u < max_in; ++blk) {
@@ -769,7 +797,7 @@ __global__ __launch_bounds__(64, 2) void k_gadget_poseidon(SolverProg P, const u
     const u32 ins = instr[i];
     const u32* cd = P.calldata + P.arg[ins];
     const u32 n_in = cd[0], first = cd[1], n_out = cd[2], out_carry = (cd[3] >> 8) & 0xffu;
-    u64 p = 4;
+    u64 p = SI_POSEIDON_HDR;
     Fr st[POS_MAX_T];
     Fr cap = Fr::zero();
     TraceSink ts{w + first, 1, 0, 0u};
@@ -1073,14 +1101,15 @@ static int32_t pos_dev(zkpor_ctx* ctx, PosDev* P) {
 }
 
 // csrc/solver.hip: n Poseidon instructions (ids in d_instr) of one level, one thread each, on `stream`
-// d_pre / d_pre_off (may be NULL): inputs evaluated beforehand, pre_off[i] = first element of call i's inputs (0xffffffff: evaluate in the kernel)
+// d_pre / d_pre_off (may be NULL): inputs evaluated beforehand, pre_off[i] = first element of call i's inputs (0xffffffff: evaluate in the kernel).
+// d_a / d_b / d_c (may be NULL; cooperative kernel only): the calls' constraint rows are written too.
 int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverProg& P, const u32* d_instr, u32 n, Fr* w, uint8_t* known, u32* d_err,
-                               const Fr* d_pre, const u32* d_pre_off) {
+                               const Fr* d_pre, const u32* d_pre_off, Fr* d_a, Fr* d_b, Fr* d_c) {
     if (n == 0) return ZKPOR_OK;
     PosDev D;
     ZK_TRY(pos_dev(ctx, &D));
     if (ctx->solver_poseidon == 0) hipLaunchKernelGGL(k_gadget_poseidon, dim3((n + 63u) / 64u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off);
-    else hipLaunchKernelGGL(k_gadget_poseidon_coop, dim3((n + 3u) / 4u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off);
+    else hipLaunchKernelGGL(k_gadget_poseidon_coop, dim3((n + 3u) / 4u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off, d_a, d_b, d_c);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

@@ -16,11 +16,13 @@ struct R1csDev {
 };
 
 // one thread per (matrix, row); rows beyond n_constraints are the zero padding computeH expects
+// skip (may be NULL): one bit per row, set = somebody else has written a, b, c of that row already (the solver's Poseidon instruction)
 __global__ __launch_bounds__(256) void k_r1cs_eval(R1csDev M, const Fr* __restrict__ w, size_t n_constraints, size_t domain,
-                                                   Fr* __restrict__ a, Fr* __restrict__ b, Fr* __restrict__ c) {
+                                                   Fr* __restrict__ a, Fr* __restrict__ b, Fr* __restrict__ c, const u32* __restrict__ skip) {
     const size_t row = (size_t)blockIdx.x * 256u + threadIdx.x;
     const int m = blockIdx.y;
     if (row >= domain) return;
+    if (skip && row < n_constraints && ((skip[row >> 5] >> (row & 31)) & 1u)) return;
     Fr acc = Fr::zero();
     if (row < n_constraints) {
         const uint64_t t0 = M.row_ptr[m][row], t1 = M.row_ptr[m][row + 1];
@@ -75,7 +77,7 @@ static void r1cs_free(zkpor_r1cs* r) {
 
 using namespace zk;
 namespace zk {
-int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
+int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size, const u32* d_skip) {
     if (!ctx || !r || !d_w || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
     if (ctx->device != r->ctx->device) { ctx->err = "r1cs: the matrices live on another GPU than the context"; return ZKPOR_E_ARG; }
     if (domain_size < r->n_constraints) { ctx->err = "r1cs: domain smaller than the constraint count"; return ZKPOR_E_ARG; }
@@ -86,7 +88,7 @@ int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, 
     for (int m = 0; m < 3; ++m) { M.row_ptr[m] = r->row_ptr[m]; M.cid[m] = r->cid[m]; M.wid[m] = r->wid[m]; }
     PhaseScope ps(ctx, "r1cs_eval");
     hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((domain_size + 255) / 256), 3), dim3(256), 0, ctx->stream, M, (const Fr*)d_w,
-                       r->n_constraints, domain_size, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c);
+                       r->n_constraints, domain_size, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, d_skip);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

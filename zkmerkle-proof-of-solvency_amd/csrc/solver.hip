@@ -24,7 +24,7 @@
 
 namespace zk {
 int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverProg& P, const u32* d_instr, u32 n, Fr* w, uint8_t* known, u32* d_err,
-                               const Fr* d_pre, const u32* d_pre_off);   // poseidon.hip
+                               const Fr* d_pre, const u32* d_pre_off, Fr* d_a, Fr* d_b, Fr* d_c);   // poseidon.hip
 }
 
 namespace {
@@ -64,6 +64,10 @@ struct zkpor_solver {
     zk::Fr* d_tmp = nullptr;                    // scratch for external hint values (grow-only)
     size_t tmp_cap = 0;
     hipStream_t side = nullptr;                 // ASYNC instructions
+    uint32_t* d_rows = nullptr;                 // one bit per constraint: a, b, c of the row are written by a (non-ASYNC) Poseidon instruction when abc is set
+    uint64_t rows_covered = 0;
+    zk::Fr *abc_a = nullptr, *abc_b = nullptr, *abc_c = nullptr;   // zkpor_solver_set_abc_dev
+    bool abc_written = false;                   // the run that just finished wrote those rows (cooperative kernel, abc set)
     uint32_t* d_perr = nullptr;                 // error words of a prefetch (its kernels run beside another run's)
     uint8_t* d_ones = nullptr;                  // n_wires bytes of 1: the `known` flags a prefetch reads (it only reads inputs)
     void* prefetched_w = nullptr;               // the wire vector whose ASYNC instructions are already running / done on the side stream
@@ -279,7 +283,7 @@ static SolverProg prog_of(const zkpor_solver* s) {
     return P;
 }
 static void solver_free(zkpor_solver* s) {
-    void* ptrs[] = {s->d_perr, s->d_ones, s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
+    void* ptrs[] = {s->d_rows, s->d_perr, s->d_ones, s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
                     s->d_cnt, s->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (s->side) (void)hipStreamDestroy(s->side);
@@ -362,7 +366,7 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                     hipLaunchKernelGGL(k_hint_inputs, dim3((a.n_in + 255u) / 256u), dim3(256), 0, s->side, P, a.ins, s->d_offs + a.offs_base, a.n_in, (const Fr*)w, s->known,
                                        s->d_pre + a.nb_q, s->d_err);
                 }
-                ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_pos, L.n_posa, w, s->known, s->d_err, s->d_pre, s->d_pre_off + L.posa_first));
+                ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_pos, L.n_posa, w, s->known, s->d_err, s->d_pre, s->d_pre_off + L.posa_first, nullptr, nullptr, nullptr));
                 s->side_busy = true;
                 ++s->launches;
             }
@@ -374,7 +378,12 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                 hipLaunchKernelGGL(k_solve_level, dim3((L.n_gen + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, w, s->known, s->d_err, s->d_ext);
                 ++s->launches;
             }
-            if (L.n_pos) { ZK_TRY(gadget_poseidon_launch(ctx, ctx->stream, P, s->d_level_instr + L.lo + L.n_gen, L.n_pos, w, s->known, s->d_err, nullptr, nullptr)); ++s->launches; }
+            if (L.n_pos) {
+                const bool rows = s->abc_written;   // decided when the run started
+                ZK_TRY(gadget_poseidon_launch(ctx, ctx->stream, P, s->d_level_instr + L.lo + L.n_gen, L.n_pos, w, s->known, s->d_err, nullptr, nullptr,
+                                              rows ? s->abc_a : nullptr, s->abc_b, s->abc_c));
+                ++s->launches;
+            }
             if (L.n_cnt) {                        // every count hint of the level together: rows, queries, outputs
                 const CountDev* cm = (const CountDev*)s->d_cmeta + L.cnt_first;
                 ZK_HIP(ctx, hipMemsetAsync(s->d_cnt, 0, (size_t)L.cnt_rows * sizeof(u32), ctx->stream));
@@ -460,6 +469,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     std::vector<uint32_t> offs;                          // the offset pool of count / external hints
     std::map<uint32_t, BigHint> big;                     // by instruction
     uint64_t max_table = 1, pre_total = 0;
+    std::vector<uint32_t> row_bits((r1cs->n_constraints + 31) / 32 + 1, 0);
     auto const_u32 = [&](const uint32_t* cd, uint64_t p, uint32_t* out_v) {   // a constant expression's value (nbTable, nbCols)
         if (cd[p] == 0) { *out_v = 0; return true; }
         if (cd[p] != 1 || cd[p + 2] != 0) return false;
@@ -496,10 +506,17 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
         } else if (kind == SI_POSEIDON) {
             if (!zkpor_host::CheckPoseidonShape(v, arg, nw, ncoef)) return bad("the call data of Poseidon instruction " + std::to_string(i) + " is malformed");
             cls[i] = (v.calldata[arg + 3] & zkpor_host::POSEIDON_ASYNC) ? CL_POSA : CL_POS;
+            {
+                const uint64_t row0 = v.calldata[arg + 4], nrows = v.calldata[arg + 2];
+                if (row0 != 0xffffffffull) {
+                    if (row0 + nrows > r1cs->n_constraints) return bad("Poseidon instruction " + std::to_string(i) + " names rows outside the system");
+                    if (cls[i] == CL_POS) { for (uint64_t rr = row0; rr < row0 + nrows; ++rr) row_bits[rr >> 5] |= 1u << (rr & 31); s->rows_covered += nrows; }
+                }
+            }
             if (cls[i] == CL_POSA) {
                 BigHint b;
                 b.ins = (uint32_t)i; b.n_in = v.calldata[arg]; b.offs_base = offs.size(); b.nb_q = pre_total;
-                uint64_t p = 4;
+                uint64_t p = zkpor_host::POSEIDON_HDR;
                 for (uint32_t k = 0; k < b.n_in; ++k) { offs.push_back((uint32_t)p); p += 1 + 2ull * v.calldata[arg + p]; }
                 pre_total += b.n_in;
                 big[(uint32_t)i] = b;
@@ -580,7 +597,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     bool ok = up((void**)&s->d_kind, kinds.data(), v.n_instructions * 4) && up((void**)&s->d_arg, v.arg, v.n_instructions * 4) &&
               up((void**)&s->d_level_instr, li.data(), n_li * 4) && up((void**)&s->d_calldata, v.calldata, v.n_calldata * 4) &&
               up((void**)&s->d_gen_lo, gen_lo.data(), v.n_levels * 8) && up((void**)&s->d_gen_cnt, gen_cnt.data(), v.n_levels * 4) &&
-              up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up(&s->d_cmeta, cmeta.data(), cmeta.size() * sizeof(CountDev)) && up((void**)&s->d_pre_off, pre_off_host.data(), pre_off_host.size() * 4) &&
+              up((void**)&s->d_rows, row_bits.data(), row_bits.size() * 4) && up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up(&s->d_cmeta, cmeta.data(), cmeta.size() * sizeof(CountDev)) && up((void**)&s->d_pre_off, pre_off_host.data(), pre_off_host.size() * 4) &&
               hipMalloc((void**)&s->d_pre, (pre_total ? pre_total : 1) * sizeof(Fr)) == hipSuccess && up((void**)&s->d_hint_kind, s->hint_kind.data(), s->hint_kind.size()) &&
               hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 16) == hipSuccess &&
               hipMalloc((void**)&s->d_ext, EXT_CAP * sizeof(u32)) == hipSuccess && hipMalloc((void**)&s->d_cnt, max_table * sizeof(u32)) == hipSuccess &&
@@ -624,8 +641,27 @@ int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint
     ZK_HIP(ctx, hipMemsetAsync(s->d_err, 0, 16, ctx->stream));
     if (s->skip_async)     // the prefetched instructions' wires are (being) assigned on the side stream: flagged here, joined in front of the last level
         for (const BigHint& a : s->asyncs) { const uint32_t* cd = s->view.calldata + s->view.arg[a.ins]; ZK_HIP(ctx, hipMemsetAsync(s->known + cd[1], 1, cd[2], ctx->stream)); }
+    s->abc_written = s->abc_a != nullptr && ctx->solver_poseidon == 1 && s->rows_covered > 0;
     s->running = true; s->next_level = 0; s->pending.clear(); s->launches = 0;
     return solver_advance(s, paused_instr);
+}
+
+/* a, b, c (domain-size buffers of the prove tail) for the NEXT runs: the Poseidon instructions then write the rows of their own constraints
+ * while they have the S-box inputs in registers (two thirds of all terms of the real circuit's matrices sit in those rows);
+ * zkpor_solver_eval_abc_dev evaluates the rest.  NULL pointers switch it off.  ASYNC / prefetched instructions never write rows. */
+int32_t zkpor_solver_set_abc_dev(zkpor_solver* s, void* d_a, void* d_b, void* d_c) {
+    if (!s) return ZKPOR_E_ARG;
+    if ((d_a || d_b || d_c) && !(d_a && d_b && d_c)) { s->ctx->err = "solver: a, b, c are given together or not at all"; return ZKPOR_E_ARG; }
+    s->abc_a = (Fr*)d_a; s->abc_b = (Fr*)d_b; s->abc_c = (Fr*)d_c;
+    return ZKPOR_OK;
+}
+/* a, b, c = L.w, R.w, O.w for every row the finished run has not written already (all rows when zkpor_solver_set_abc_dev was not used), zero
+ * padding up to domain_size; into the buffers given to zkpor_solver_set_abc_dev, or d_a / d_b / d_c when it was not used */
+int32_t zkpor_solver_eval_abc_dev(zkpor_solver* s, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
+    ZK_ENTER(s ? s->ctx->device : -1);
+    if (!s || !d_w || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
+    if (s->abc_written && (d_a != s->abc_a || d_b != s->abc_b || d_c != s->abc_c)) { s->ctx->err = "solver: the run wrote rows into other buffers than these"; return ZKPOR_E_ARG; }
+    return zk::r1cs_eval_on(s->ctx, s->r1cs, d_w, d_a, d_b, d_c, domain_size, s->abc_written ? s->d_rows : nullptr);
 }
 
 /* the ASYNC instructions of the NEXT proof (the two CEX commitments: 834 chained permutations each, ~0.2 s of one wave) started on the side
@@ -656,7 +692,7 @@ int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inpu
         hipLaunchKernelGGL(k_hint_inputs, dim3((a.n_in + 255u) / 256u), dim3(256), 0, s->side, P, a.ins, s->d_offs + a.offs_base, a.n_in, (const Fr*)d_w_next, s->d_ones,
                            s->d_pre + a.nb_q, s->d_perr);
     }
-    ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_pos, L.n_posa, (Fr*)d_w_next, s->d_ones, s->d_perr, s->d_pre, s->d_pre_off + L.posa_first));
+    ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_pos, L.n_posa, (Fr*)d_w_next, s->d_ones, s->d_perr, s->d_pre, s->d_pre_off + L.posa_first, nullptr, nullptr, nullptr));
     s->side_busy = true;
     s->prefetched_w = d_w_next;
     (void)n_inputs;

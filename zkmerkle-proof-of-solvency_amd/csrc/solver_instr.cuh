@@ -17,6 +17,7 @@ enum : uint8_t { HK_NONE = 0, HK_INTDIV = 1, HK_NBITS = 2, HK_INVZERO = 3, HK_DE
 // poseidon.Poseidon(...) call.  HK_COUNT (gnark logderivarg countHint: millions of inputs) and kind 4 have their own kernels
 // (csrc/solver.hip, csrc/poseidon.hip); solve_instr refuses them.
 enum : u32 { SI_R1C = 0, SI_HINT = 1, SI_SKIP = 2, SI_LOOKUP = 3, SI_POSEIDON = 4 };
+enum : u32 { SI_POSEIDON_HDR = 5 };   // nIn, firstOut, nOut, flags, firstRow
 enum : int {
     SE_OK = 0, SE_ROW_RANGE = 10, SE_TWO_UNKNOWN = 11, SE_NOT_SATISFIED = 12, SE_ZERO_COEFF = 13, SE_DIV_ZERO = 14, SE_CALLDATA = 20,
     SE_NO_HINT = 21, SE_ID_RANGE = 22, SE_INPUT_UNSOLVED = 23, SE_HINT_FAILED = 24, SE_LOOKUP_RANGE = 25, SE_COUNT_TABLE = 26, SE_COUNT_QUERY = 27,

@@ -558,6 +558,7 @@ inline LE Builder::poseidon(const std::vector<LE>& inputs, bool async, int out_i
         const u64 off = calldata_.size();
         calldata_.push_back((u32)n); calldata_.push_back(base); calldata_.push_back((u32)(3 * total_sbox));
         calldata_.push_back((u32)out_idx | ((u32)carry_idx << 8) | ((async ? 1u : 0u) << 16));
+        calldata_.push_back((u32)n_constraints());      // its constraints follow as consecutive rows, three per S-box
         for (auto& e : inputs) push_le(e);
         for (size_t i = 0; i < 3 * total_sbox; ++i) producer_[base + i] = (u32)kind_.size();
         if (async) async_instrs_.push_back({(u32)kind_.size(), lvl});
@@ -823,7 +824,7 @@ inline Compiled Builder::finish() {
                 u64 p = 4;
                 for (u32 q = 0; q < cd[2]; ++q) need_le(cd, p, i, lv);
             } else if (kind_[i] == K_POSEIDON) {
-                u64 p = 4;
+                u64 p = zkpor_host::POSEIDON_HDR;
                 for (u32 k = 0; k < cd[0]; ++k) need_le(cd, p, i, lv);
             }
         }

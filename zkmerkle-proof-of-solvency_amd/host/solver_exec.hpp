@@ -300,7 +300,7 @@ inline int SolveLevelized(const R1csFileView& r, const SolverView& s, const uint
         if (kind == INSTR_POSEIDON) {            // the whole sponge: every S-box's three product wires
             const uint32_t* cd = s.calldata + arg;
             sc.in.resize(cd[0]); sc.o.resize(cd[2]);
-            uint64_t p = 4;
+            uint64_t p = POSEIDON_HDR;
             for (uint32_t i = 0; i < cd[0]; ++i) if (int rc = eval_le(cd, p, &sc.in[i])) return rc;
             PosSponge(sc.in.data(), cd[0], sc.o.data(), (int)(cd[3] & 0xff), (int)((cd[3] >> 8) & 0xff));
             for (uint32_t i = 0; i < cd[2]; ++i) { w[cd[1] + i] = sc.o[i]; known[cd[1] + i] = 1; }

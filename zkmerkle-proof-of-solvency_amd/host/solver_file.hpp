@@ -16,7 +16,9 @@
 //                        entry[index].  Entry block at blockOff (shared by all lookups of one table, gnark stores it once per blueprint):
 //                        nEntries, entryOff[nEntries] (word offsets from blockOff), the entry expressions; nbEntries <= nEntries
 //     kind 4 (poseidon): nIn, firstOutWire, nOutWires, flags (bits 0-7 digest lane, 8-15 carry lane, bit 16 = ASYNC: the outputs are read
-//                        by the last level only), then nIn input expressions; outputs = the three product wires (x^2, x^4, x^5) of
+//                        by the last level only), firstRow (the call's constraints are rows firstRow .. firstRow + nOutWires - 1, three per
+//                        S-box: in * in = x^2, x^2 * x^2 = x^4, x^4 * in = x^5 — an executor that has the S-box input in hand writes a, b, c of
+//                        these rows itself; 0xffffffff = not consecutive / unknown), then nIn input expressions; outputs = the three product wires (x^2, x^4, x^5) of
 //                        every S-box of the sponge over the inputs, permutation after permutation in round order
 #pragma once
 #include <cstdint>
@@ -37,7 +39,7 @@ struct SolverView {
     const uint32_t* calldata = nullptr;
 };
 enum { INSTR_R1C = 0, INSTR_HINT = 1, INSTR_SKIP = 2, INSTR_LOOKUP = 3, INSTR_POSEIDON = 4 };
-enum : uint32_t { POSEIDON_ASYNC = 1u << 16 };
+enum : uint32_t { POSEIDON_ASYNC = 1u << 16, POSEIDON_HDR = 5 };   // header words of a kind-4 instruction's call data
 
 // shape checks of the two gadget instructions against the call data (both executors call this before they trust an offset).
 // A version-1 stream's kind 3 is the old "skipped" alias: callers map it to INSTR_SKIP.
@@ -72,14 +74,14 @@ inline uint64_t PoseidonSboxCount(uint64_t n_in) {   // S-boxes of the sponge ov
     return full * (8 * 13 + 65) + (rem ? 8 * (rem + 1) + rp[rem + 1 - 2] : 0);
 }
 inline bool CheckPoseidonShape(const SolverView& v, uint64_t arg, uint64_t n_wires, uint64_t n_coeff) {
-    if (arg + 4 > v.n_calldata) return false;
+    if (arg + POSEIDON_HDR > v.n_calldata) return false;
     const uint32_t* cd = v.calldata + arg;
     const uint64_t n_in = cd[0], first = cd[1], n_out = cd[2];
     const uint32_t flags = cd[3];
     if (n_in == 0 || n_out != 3 * PoseidonSboxCount(n_in) || first + n_out > n_wires) return false;
     const uint32_t last_t = (uint32_t)(n_in % 12 ? n_in % 12 + 1 : 13);
     if ((flags & 0xff) >= last_t || (n_in > 12 && ((flags >> 8) & 0xff) >= 13u)) return false;   // digest lane of the last block, carry lane of the full ones
-    uint64_t p = arg + 4;
+    uint64_t p = arg + POSEIDON_HDR;
     for (uint64_t i = 0; i < n_in; ++i) {
         if (p >= v.n_calldata) return false;
         const uint64_t nt = v.calldata[p++];

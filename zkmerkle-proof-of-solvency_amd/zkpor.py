@@ -823,6 +823,16 @@ class Solver:
         self.ctx._ck(self.ctx.lib.zkpor_solver_start_dev(self.h, ctypes.c_void_p(d_w), ctypes.c_size_t(n_inputs), ctypes.c_void_p(d_known) if d_known else None, ctypes.byref(paused)))
         return paused.value
 
+    def set_abc_dev(self, d_a, d_b, d_c):
+        """the prove tail's a / b / c buffers: the Poseidon instructions of the next runs write their own rows (None, None, None = off)"""
+        vp = ctypes.c_void_p
+        self.ctx._ck(self.ctx.lib.zkpor_solver_set_abc_dev(self.h, vp(d_a) if d_a else None, vp(d_b) if d_b else None, vp(d_c) if d_c else None))
+
+    def eval_abc_dev(self, d_w, d_a, d_b, d_c, domain_size):
+        """a, b, c of every row the finished run has not written already"""
+        vp = ctypes.c_void_p
+        self.ctx._ck(self.ctx.lib.zkpor_solver_eval_abc_dev(self.h, vp(d_w), vp(d_a), vp(d_b), vp(d_c), ctypes.c_size_t(domain_size)))
+
     def prefetch_dev(self, d_w_next, n_inputs):
         """start the NEXT proof's ASYNC instructions (the CEX commitment chains) on the side stream; d_w_next must be what the next start_dev gets"""
         self.ctx._ck(self.ctx.lib.zkpor_solver_prefetch_dev(self.h, ctypes.c_void_p(d_w_next), ctypes.c_size_t(n_inputs)))
