@@ -60,6 +60,32 @@ def test_special_coefficients_and_empty_rows(zk):
         r.close()
 
 
+def test_rows_longer_than_a_threads_share_are_summed_by_a_wave(zk):
+    """rows of more than 256 terms go to one wave each (csrc/r1cs.hip k_r1cs_eval_long): lengths on both sides of the cut and of the lane
+    count, every coefficient class, short rows in between — against Python integers"""
+    rng = np.random.default_rng(41)
+    n_wires = 5000
+    table = O.fr_from_ints([0, 1, O.R_MOD - 1, 12345, 3 ** 150 % O.R_MOD, O.R_MOD - 7])
+    w = O.fr_random(9, n_wires)
+    lengths = [3, 256, 257, 0, 300, 1, 1024, 4143, 64, 511, 2, 320, 5000]
+    r = zkpor.R1CS(zk, len(lengths), n_wires, table)
+    try:
+        wi = O.fr_to_ints(w); ti = O.fr_to_ints(table)
+        want = []
+        for which in range(3):
+            ln = np.roll(np.array(lengths), which)
+            row_ptr = np.concatenate([[0], np.cumsum(ln)]).astype(np.uint64)
+            cid = rng.integers(0, table.shape[0], size=int(ln.sum())).astype(np.uint32)
+            wid = rng.integers(0, n_wires, size=int(ln.sum())).astype(np.uint32)
+            r.set_matrix(which, row_ptr, cid, wid)
+            want.append([sum(ti[cid[t]] * wi[wid[t]] for t in range(int(row_ptr[j]), int(row_ptr[j + 1]))) % O.R_MOD for j in range(len(lengths))])
+        got = r.eval(w)
+        for which in range(3):
+            assert O.fr_to_ints(got[which]) == want[which], which
+    finally:
+        r.close()
+
+
 def test_rejects_bad_indices(zk):
     table = O.fr_from_ints([1, 2])
     r = zkpor.R1CS(zk, 1, 3, table)

@@ -1,0 +1,8 @@
+set -u
+OUT=gpurun_out/r04g
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout 600 python tools/rounds/r04/coop_probe.py > $OUT/coop_probe.txt 2>&1; tail -30 $OUT/coop_probe.txt
+timeout 900 python -m pytest tests/test_circuit_gpu.py tests/test_poseidon_gpu.py tests/test_cex_gpu.py -x -q > $OUT/pytest.txt 2>&1; tail -4 $OUT/pytest.txt
+E2E_ROWS=1 timeout 600 python tools/rounds/r04/e2e_first.py 50 500 1380 1 > $OUT/e2e.log 2>&1; tail -7 $OUT/e2e.log
+timeout 900 python tools/rounds/r04/r1cs_probe.py > $OUT/r1cs_probe.txt 2>&1; tail -20 $OUT/r1cs_probe.txt

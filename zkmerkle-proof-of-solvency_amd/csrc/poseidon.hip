@@ -32,6 +32,8 @@ struct PosTables {
     u32 prc_off[POS_MAX_T + 1];
     u32 sp_off[POS_MAX_T + 1];
     u32 post_off[POS_MAX_T + 1];
+    u32* devc = nullptr;   // the 29-bit tables once more, laid out for the 16-lanes-per-call kernels (k_tables_coop below)
+    u32 c_off[POS_MAX_T + 1];
     std::vector<Fr> host;
 };
 
@@ -193,6 +195,35 @@ __global__ void k_tables_to_limbs29(const Fr* in, u32* out, u32 count) {
     for (int k = 0; k < 9; ++k) out[9u * i + k] = v.l[k];
 }
 
+// The cooperative kernels (namespace coop) hold one state element per lane and every lane needs ITS constant of the round: read from the
+// element-major blob that is one 36-byte run per lane — 18 cache lines per load instruction, and four waves of a CU behind one vector L1
+// (measured: a launch of one wave per SIMD ran 1.6x slower per wave than one wave per CU).  Here the same constants lane-interleaved: a
+// ROW is 9 limbs x 16 lanes (limb i of lane j at word 16 i + j), so a load instruction of a group reads 64 consecutive bytes, and the four
+// groups of a wave read the same 64.  Rows of width t, from c_off[t]:
+//   0..7                  full-round constants (the four rounds before, the four after the partial ones); lane j: rc[r t + j]
+//   8 + 3 i + {0, 1, 2}   partial round i: its constants k_i; lane 0: m00, lane j: v_j; lane 0: m00, lane j: what_j
+//   8 + 3 rp + c          column c of the round matrix; lane j: M[j][c]
+//   8 + 3 rp + t + c      column c of the dense block left over by the optimised rounds; lane j >= 1: post[j - 1][c]
+// Lanes j >= t hold lane 0's entries (they run along on a valid element).
+ZK_HD constexpr u32 coop_rows(int t, int rp) { return 8u + 3u * (u32)rp + 2u * (u32)t - 1u; }
+struct CoopSrc { u32 rc_off, mds_off, prc_off, sp_off, post_off, c_off; int t, rp; };
+__global__ void k_tables_coop(const u32* __restrict__ tab29, CoopSrc S, u32* __restrict__ out) {
+    const int t = S.t, rp = S.rp;
+    const u32 words = coop_rows(t, rp) * 144u;
+    for (u32 idx = blockIdx.x * blockDim.x + threadIdx.x; idx < words; idx += gridDim.x * blockDim.x) {
+        const u32 row = idx / 144u, limb = (idx % 144u) / 16u, lane = idx % 16u;
+        const u32 jj = lane < (u32)t ? lane : 0u;
+        u32 src;
+        if (row < 8u) { const u32 r = row < 4u ? row : (u32)(POS_RF / 2 + rp) + (row - 4u); src = S.rc_off + r * (u32)t + jj; }
+        else if (row < 8u + 3u * (u32)rp) {
+            const u32 i = (row - 8u) / 3u, kind = (row - 8u) % 3u, sp = S.sp_off + i * (2u * (u32)t - 1u);
+            src = kind == 0u ? S.prc_off + i * (u32)t + jj : (kind == 1u ? sp + jj : (jj == 0u ? sp : sp + (u32)t + jj - 1u));
+        } else if (row < 8u + 3u * (u32)rp + (u32)t) src = S.mds_off + jj * (u32)t + (row - 8u - 3u * (u32)rp);
+        else src = S.post_off + (jj ? jj - 1u : 0u) * (u32)(t - 1) + (row - 8u - 3u * (u32)rp - (u32)t);
+        out[S.c_off + idx] = tab29[9u * src + limb];
+    }
+}
+
 static int32_t pos_tables_get(zkpor_ctx* ctx, PosTables** out) {
     if (ctx->pos_tables) { *out = (PosTables*)ctx->pos_tables; return ZKPOR_OK; }
     PosTables* T = new PosTables();
@@ -217,6 +248,14 @@ static int32_t pos_tables_get(zkpor_ctx* ctx, PosTables** out) {
     ZK_HIP(ctx, hipMalloc((void**)&T->dev29, T->host.size() * 36));
     hipLaunchKernelGGL(k_tables_to_limbs29, dim3((unsigned)((T->host.size() + 255) / 256)), dim3(256), 0, ctx->stream, T->dev, T->dev29, (u32)T->host.size());
     ZK_KERNEL_CHECK(ctx);
+    u32 cw = 0;
+    for (int t = 2; t <= POS_MAX_T; ++t) { T->c_off[t] = cw; cw += coop_rows(t, pos_rp(t)) * 144u; }
+    ZK_HIP(ctx, hipMalloc((void**)&T->devc, (size_t)cw * 4));
+    for (int t = 2; t <= POS_MAX_T; ++t) {
+        const CoopSrc S{T->rc_off[t], T->mds_off[t], T->prc_off[t], T->sp_off[t], T->post_off[t], T->c_off[t], t, pos_rp(t)};
+        hipLaunchKernelGGL(k_tables_coop, dim3(32), dim3(256), 0, ctx->stream, (const u32*)T->dev29, S, T->devc);
+        ZK_KERNEL_CHECK(ctx);
+    }
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pos_tables = T;
     *out = T;
@@ -227,6 +266,7 @@ void pos_tables_free(zkpor_ctx* ctx) {
     PosTables* T = (PosTables*)ctx->pos_tables;
     if (T->dev) (void)hipFree(T->dev);
     if (T->dev29) (void)hipFree(T->dev29);
+    if (T->devc) (void)hipFree(T->devc);
     delete T;
     ctx->pos_tables = nullptr;
 }
@@ -428,6 +468,8 @@ struct PosDev {  // everything a kernel needs to hash
     u32 prc_off[POS_MAX_T + 1];
     u32 sp_off[POS_MAX_T + 1];
     u32 post_off[POS_MAX_T + 1];
+    const u32* tabc;                 // lane-interleaved rows for the 16-lanes-per-call kernels (k_tables_coop)
+    u32 c_off[POS_MAX_T + 1];
     ZK_HD PermTab tabs(int t) const { return {tab + rc_off[t], tab + mds_off[t], tab + prc_off[t], tab + sp_off[t], tab + post_off[t]}; }
     int rp[POS_MAX_T + 1];
     int out_idx, carry_idx;
@@ -607,11 +649,22 @@ ZK_D Fr29 ld29(const u32* p) { Fr29 r;
     for (int i = 0; i < 9; ++i) r.l[i] = p[i];
     return r; }
 template <int N> ZK_D u32 row_shl(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, true); }   // lane i <- lane i + N of its row of 16, else 0
-template <int N> ZK_D Fr29 fold(const Fr29& v) { Fr29 t;
+template <int N> ZK_D Fr29 fold(const Fr29& v) { Fr29 t;               // no carry sweep: the caller counts the bits
 #pragma unroll
-    for (int i = 0; i < 9; ++i) t.l[i] = row_shl<N>(v.l[i]);
-    return Fr29::normed(Fr29::add_l(v, t)); }
-ZK_D Fr29 row_sum(Fr29 v) { v = fold<8>(v); v = fold<4>(v); v = fold<2>(v); return fold<1>(v); }   // lane 0 of the row: sum of its 16 lanes (tight limbs)
+    for (int i = 0; i < 9; ++i) t.l[i] = v.l[i] + row_shl<N>(v.l[i]);
+    return t; }
+// lane 0 of the row: the sum of its 16 lanes.  The lanes hold products as they leave Fr29::mul (limbs 0..7 in [0, 2^29), limb 8 small and
+// signed) or zero: four of them stay below 2^31, so two sweeps do for the four folds — a signed one after the first two, an UNSIGNED one
+// at the end (four swept values reach 2^31 + 8).  Result: limbs 0..7 <= 2^29 + 3, fit for an add_l + reduce32, not for a product.
+ZK_D Fr29 row_sum(Fr29 v) {
+    v = Fr29::normed(fold<4>(fold<8>(v)));
+    v = fold<1>(fold<2>(v));
+    u32 c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c[i] = v.l[i] >> 29; v.l[i] &= Fr29::M29; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v.l[i + 1] += c[i];
+    return v; }
 ZK_D Fr29 from_lane(const Fr29& v, int src_lane) { Fr29 r;                                      // every lane: the value lane src_lane holds
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = (u32)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v.l[i]);
@@ -620,12 +673,17 @@ ZK_D void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); _
 ZK_D void put(u32* row, const Fr29& v) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) row[i] = v.l[i]; }
-// sum_c k[c] * x[c], c < n: constants from this lane's table row (global), operands from the group's exchange area (LDS)
-ZK_D Fr29 dot(const u32* krow, const u32* xs, int n) {
+// lane j's entry of a row of the lane-interleaved tables (k_tables_coop): limb i at word 16 i + j
+ZK_D Fr29 ldc(const u32* row, int j) { Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = row[16 * i + j];
+    return r; }
+// sum_c k[c] * x[c], c < n: constants from column rows c of the tables (this lane's entry), operands from the group's exchange area (LDS)
+ZK_D Fr29 dot(const u32* kcols, int j, const u32* xs, int n) {
     Fr29 acc = Fr29::zero();
     int c = 0;
-    for (; c + 1 < n; c += 2) acc = Fr29::reduce32(Fr29::add_l(acc, Fr29::mul2(ld29(krow + 9 * c), ld29(xs + 9 * c), ld29(krow + 9 * (c + 1)), ld29(xs + 9 * (c + 1)))));
-    if (c < n) acc = Fr29::reduce32(Fr29::add_l(acc, Fr29::mul(ld29(krow + 9 * c), ld29(xs + 9 * c))));
+    for (; c + 1 < n; c += 2) acc = Fr29::reduce32(Fr29::add_l(acc, Fr29::mul2(ldc(kcols + 144 * c, j), ld29(xs + 9 * c), ldc(kcols + 144 * (c + 1), j), ld29(xs + 9 * (c + 1)))));
+    if (c < n) acc = Fr29::reduce32(Fr29::add_l(acc, Fr29::mul(ldc(kcols + 144 * c, j), ld29(xs + 9 * c))));
     return acc;
 }
 }  // namespace coop
@@ -667,17 +725,14 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
     const int j = lane & 15, base_lane = lane & ~15;
     const bool mine = act && j < t;           // this lane holds a state element
     const int tt = act ? t : 2;
-    const u32* b29 = D.tab29;
-    const u32* rc = b29 + 9 * (size_t)D.rc_off[tt];
-    const u32* mm = b29 + 9 * (size_t)D.mds_off[tt];
-    const u32* prc = b29 + 9 * (size_t)D.prc_off[tt];
-    const u32* sp = b29 + 9 * (size_t)D.sp_off[tt];
-    const u32* post = b29 + 9 * (size_t)D.post_off[tt];
-    const int rp = D.rp[tt], jj = j < tt ? j : 0;
+    const int rp = D.rp[tt];
+    const u32* rows = D.tabc + D.c_off[tt];   // lane-interleaved rows of this width (k_tables_coop): lanes j >= tt read lane 0's entries
+    const u32* prow = rows + 144 * 8;         // three rows per partial round
+    const u32* mm = prow + 144 * 3 * rp;      // columns of the round matrix
+    const u32* post = mm + 144 * tt;          // columns of the dense block
     for (int half = 0; half < 2; ++half) {
         for (int rr = 0; rr < POS_RF / 2; ++rr) {          // full round: S-boxes side by side, one matrix row per lane
-            const int r = half ? POS_RF / 2 + rp + rr : rr;
-            const Fr29 u = Fr29::reduce32(Fr29::add_l(st, ld29(rc + 9 * (r * tt + jj))));
+            const Fr29 u = Fr29::reduce32(Fr29::add_l(st, ldc(rows + 144 * (half * (POS_RF / 2) + rr), j)));
             const Fr29 x2 = Fr29::sqr(u), x4 = Fr29::sqr(x2), x5 = Fr29::mul(x4, u);
             if (TR) {
                 if (mine) {
@@ -696,14 +751,14 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
             }
             put(xs + 9 * j, x5);
             wave_sync();
-            st = dot(mm + 9 * (jj * tt), xs, tt);
+            st = dot(mm, j, xs, tt);
             wave_sync();
         }
         if (half) break;
         for (int i = 0; i < rp; ++i) {                       // sparse partial round: 4 products deep
-            const Fr29 s_j = Fr29::reduce32(Fr29::add_l(st, ld29(prc + 9 * (i * tt + jj))));   // lane 0: u = st0 + k0
-            const u32* srow = sp + 9 * (size_t)(i * (2 * tt - 1));
-            const Fr29 ka = ld29(srow + 9 * jj);                                            // lane 0: sp[0] (used in the 4th product), lane j: v_j
+            const u32* pr = prow + 144 * 3 * i;
+            const Fr29 s_j = Fr29::reduce32(Fr29::add_l(st, ldc(pr, j)));                    // lane 0: u = st0 + k0
+            const Fr29 ka = ldc(pr + 144, j);                                                // lane 0: m00 (unused here), lane j: v_j
             const Fr29 p1 = Fr29::mul(j == 0 ? s_j : ka, s_j);                               // lane 0: x^2; lane j: v_j * s_j
             const Fr29 x4 = Fr29::sqr(p1);
             const Fr29 x5 = Fr29::mul(x4, s_j);                                              // lane 0 only is meaningful
@@ -712,7 +767,7 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
                 else { u32* q = tr.ts + 9 * (3 * tr.n_stash); put(q, p1); put(q + 9, x4); put(q + 18, x5); }
             }
             const Fr29 X = from_lane(x5, base_lane);
-            const Fr29 kb = j == 0 ? ka : ld29(srow + 9 * (tt + jj - 1));                    // lane 0: m00; lane j: what_j
+            const Fr29 kb = ldc(pr + 288, j);                                                // lane 0: m00; lane j: what_j
             const Fr29 e = Fr29::mul(kb, X);
             Fr29 dterm = p1;
             if (j == 0 || j >= tt) dterm = Fr29::zero();
@@ -729,7 +784,7 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
             const Fr29 sj = Fr29::reduce32(st);
             put(xs + 9 * j, sj);
             wave_sync();
-            const Fr29 nv = dot(post + 9 * ((jj ? jj - 1 : 0) * (tt - 1)), xs + 9, tt - 1);
+            const Fr29 nv = dot(post, j, xs + 9, tt - 1);
             if (j) st = nv;
             wave_sync();
         }
@@ -1091,6 +1146,8 @@ static int32_t pos_dev(zkpor_ctx* ctx, PosDev* P) {
     ZK_TRY(pos_tables_get(ctx, &T));
     P->tab = T->dev;
     P->tab29 = T->dev29;
+    P->tabc = T->devc;
+    for (int t = 2; t <= POS_MAX_T; ++t) P->c_off[t] = T->c_off[t];
     for (int t = 2; t <= POS_MAX_T; ++t) {
         P->rc_off[t] = T->rc_off[t]; P->mds_off[t] = T->mds_off[t]; P->prc_off[t] = T->prc_off[t];
         P->sp_off[t] = T->sp_off[t]; P->post_off[t] = T->post_off[t]; P->rp[t] = pos_rp(t);

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void k_r1cs_eval(R1csDev M, const Fr* __restri
     Fr acc = Fr::zero();
     if (row < n_constraints) {
         const uint64_t t0 = M.row_ptr[m][row], t1 = M.row_ptr[m][row + 1];
+        if (t1 - t0 > (uint64_t)R1CS_LONG_ROW) return;       // k_r1cs_eval_long's
         for (uint64_t t = t0; t < t1; ++t) {
             const u32 ci = M.cid[m][t];
             const uint8_t kind = M.kind[ci];
@@ -38,6 +39,34 @@ __global__ __launch_bounds__(256) void k_r1cs_eval(R1csDev M, const Fr* __restri
     }
     Fr* out = m == 0 ? a : (m == 1 ? b : c);
     out[row] = acc;
+}
+
+// the rows of more than R1CS_LONG_ROW terms of one matrix, one wave each: lane l takes terms l, l + 64, ... and the 64 partial sums meet
+// through shuffles (field addition is exact: the order does not matter)
+__global__ __launch_bounds__(256) void k_r1cs_eval_long(R1csDev M, int m, const u32* __restrict__ rows, size_t n_rows, const Fr* __restrict__ w,
+                                                        Fr* __restrict__ out, const u32* __restrict__ skip) {
+    const size_t i = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n_rows) return;
+    const u32 row = rows[i];
+    if (skip && ((skip[row >> 5] >> (row & 31)) & 1u)) return;
+    const uint64_t t0 = M.row_ptr[m][row], t1 = M.row_ptr[m][row + 1];
+    Fr acc = Fr::zero();
+    for (uint64_t t = t0 + (uint64_t)lane; t < t1; t += 64u) {
+        const u32 ci = M.cid[m][t];
+        const uint8_t kind = M.kind[ci];
+        if (kind == 3) continue;
+        const Fr x = w[M.wid[m][t]];
+        if (kind == 1) acc = Fr::add(acc, x);
+        else if (kind == 2) acc = Fr::sub(acc, x);
+        else acc = Fr::add(acc, Fr::mul(M.coeff[ci], x));
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        Fr o;
+        for (int k = 0; k < 8; ++k) o.v[k] = (u32)__shfl_down((int)acc.v[k], off, 64);
+        acc = Fr::add(acc, o);
+    }
+    if (lane == 0) out[row] = acc;
 }
 
 // the final check of a solved wire vector: L.w * R.w = O.w on every row; out[0] = rows that fail, out[1] = the lowest failing row
@@ -69,6 +98,7 @@ static void r1cs_free(zkpor_r1cs* r) {
         if (r->row_ptr[m]) (void)hipFree(r->row_ptr[m]);
         if (r->cid[m]) (void)hipFree(r->cid[m]);
         if (r->wid[m]) (void)hipFree(r->wid[m]);
+        if (r->long_rows[m]) (void)hipFree(r->long_rows[m]);
     }
     delete r;
 }
@@ -90,6 +120,13 @@ int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, 
     hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((domain_size + 255) / 256), 3), dim3(256), 0, ctx->stream, M, (const Fr*)d_w,
                        r->n_constraints, domain_size, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, d_skip);
     ZK_KERNEL_CHECK(ctx);
+    Fr* outs[3] = {(Fr*)d_a, (Fr*)d_b, (Fr*)d_c};
+    for (int m = 0; m < 3; ++m) {
+        if (!r->n_long[m]) continue;
+        hipLaunchKernelGGL(k_r1cs_eval_long, dim3((unsigned)((r->n_long[m] + 3) / 4)), dim3(256), 0, ctx->stream, M, m, (const u32*)r->long_rows[m], r->n_long[m],
+                           (const Fr*)d_w, outs[m], d_skip);
+        ZK_KERNEL_CHECK(ctx);
+    }
     return ZKPOR_OK;
 }
 void r1cs_dims(const zkpor_r1cs* r, size_t* n_constraints, size_t* n_wires, int* device) {
@@ -141,12 +178,22 @@ int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr,
     if (r->row_ptr[which]) { (void)hipFree(r->row_ptr[which]); r->row_ptr[which] = nullptr; }
     if (r->cid[which]) { (void)hipFree(r->cid[which]); r->cid[which] = nullptr; }
     if (r->wid[which]) { (void)hipFree(r->wid[which]); r->wid[which] = nullptr; }
+    if (r->long_rows[which]) { (void)hipFree(r->long_rows[which]); r->long_rows[which] = nullptr; }
+    r->n_long[which] = 0;
+    std::vector<uint32_t> longs;
+    for (size_t i = 0; i < r->n_constraints; ++i) if (row_ptr[i + 1] - row_ptr[i] > (uint64_t)R1CS_LONG_ROW) longs.push_back((uint32_t)i);
+    if (r->n_constraints > 0xffffffffull) { ctx->err = "r1cs: more than 2^32 constraints"; return ZKPOR_E_ARG; }
     if (hipMalloc((void**)&r->row_ptr[which], (r->n_constraints + 1) * 8) != hipSuccess || hipMalloc((void**)&r->cid[which], (nnz ? nnz : 1) * 4) != hipSuccess ||
         hipMalloc((void**)&r->wid[which], (nnz ? nnz : 1) * 4) != hipSuccess) { (void)hipGetLastError(); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM; }
     ZK_HIP(ctx, hipMemcpy(r->row_ptr[which], row_ptr, (r->n_constraints + 1) * 8, hipMemcpyHostToDevice));
     if (nnz) {
         ZK_HIP(ctx, hipMemcpy(r->cid[which], coeff_ids, nnz * 4, hipMemcpyHostToDevice));
         ZK_HIP(ctx, hipMemcpy(r->wid[which], wire_ids, nnz * 4, hipMemcpyHostToDevice));
+    }
+    if (!longs.empty()) {
+        if (hipMalloc((void**)&r->long_rows[which], longs.size() * 4) != hipSuccess) { (void)hipGetLastError(); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM; }
+        ZK_HIP(ctx, hipMemcpy(r->long_rows[which], longs.data(), longs.size() * 4, hipMemcpyHostToDevice));
+        r->n_long[which] = longs.size();
     }
     r->nnz[which] = nnz;
     return ZKPOR_OK;
