@@ -86,6 +86,7 @@ struct zkpor_solver {
 namespace zk {
 static constexpr u32 NARROW = 512, EXT_CAP = 4096;
 static constexpr int BATCH_K = 4;                 // instructions per thread of the batched level kernel
+static constexpr u32 BATCH_TREE_FROM = 1024;      // levels from this many generic instructions on: the divisions of a workgroup share one inversion
 
 ZK_D void solver_step(const SolverProg& P, u32 ins, Fr* w, uint8_t* known, u32* err, u32* ext) {
     // an external hint is not executed: it is reported, its outputs stay unknown until the caller provides them
@@ -108,36 +109,61 @@ __global__ __launch_bounds__(256) void k_solve_level(SolverProg P, const u32* __
     if (i >= n || err[0]) return;
     solver_step(P, level_instr[lo + i], w, known, err, ext);
 }
-// a VERY wide level: KB instructions per thread (strided, so that neighbouring lanes still read neighbouring list entries), their divisions
-// resolved with ONE field inversion per thread — Montgomery's trick over the thread's denominators: 3 products per quotient instead of a
-// ~40 k-instruction binary Euclid each.  The log-derivative argument behind every range check and lookup is one inverse wire per query
-// (2 x 10^7 per zkpor50_1380 proof), all in one level.
+// a level whose divisions share inversions: KB instructions per thread (strided, so that neighbouring lanes still read neighbouring list
+// entries), and the 256 threads of a workgroup share ONE field inversion — Montgomery's trick twice over: a thread multiplies its own
+// denominators up, the workgroup multiplies the threads' products up a binary tree in LDS, one lane inverts the root (a ~40 k-instruction
+// binary Euclid), and the inverse comes down the tree (inverse of a child = inverse of the parent x the sibling) and down the thread's list:
+// 3 products per quotient + 3 per thread.  The log-derivative argument behind every range check and lookup is one inverse wire per query
+// (2 x 10^7 per zkpor50_1380 proof, all in one level: one inversion per thread was 41 ms of the proof, per workgroup of 1 024 it is ~5).
+// A workgroup without a division leaves before the tree.
 template <int KB>
 __global__ __launch_bounds__(256) void k_solve_level_batched(SolverProg P, const u32* __restrict__ level_instr, u64 lo, u32 n, u32 stride, Fr* w, uint8_t* known,
                                                              u32* err, u32* ext) {
-    const u32 t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= stride || err[0]) return;
+    __shared__ Fr tree[512];                      // node i: the product of its leaves; children 2 i and 2 i + 1, leaves 256 ..
+    const u32 tid = threadIdx.x, t = blockIdx.x * 256u + tid;
     SiPending pd[KB];
     int np = 0;
+    if (t < stride && !err[0]) {
 #pragma unroll 1
-    for (int k = 0; k < KB; ++k) {
-        const u32 i = t + (u32)k * stride;
-        if (i >= n) break;
-        const u32 ins = level_instr[lo + i];
-        if (P.kind[ins] == SI_HINT && P.hint_kind[P.calldata[P.arg[ins]]] == HK_NONE) {
-            const u32 slot = atomicAdd(&err[3], 1u);
-            if (slot < EXT_CAP) ext[slot] = ins;
-            continue;
+        for (int k = 0; k < KB; ++k) {
+            const u32 i = t + (u32)k * stride;
+            if (i >= n) break;
+            const u32 ins = level_instr[lo + i];
+            if (P.kind[ins] == SI_HINT && P.hint_kind[P.calldata[P.arg[ins]]] == HK_NONE) {
+                const u32 slot = atomicAdd(&err[3], 1u);
+                if (slot < EXT_CAP) ext[slot] = ins;
+                continue;
+            }
+            const int rc = solve_instr(P, ins, w, known, &pd[np]);
+            if (rc == SE_DEFERRED) ++np;
+            else if (rc != SE_OK && atomicCAS(&err[0], 0u, (u32)rc) == 0u) err[1] = ins;
         }
-        const int rc = solve_instr(P, ins, w, known, &pd[np]);
-        if (rc == SE_DEFERRED) ++np;
-        else if (rc != SE_OK && atomicCAS(&err[0], 0u, (u32)rc) == 0u) err[1] = ins;
+    }
+    if (!__syncthreads_or(np)) return;
+    Fr pre[KB];                                   // pre[j] = den_0 .. den_j
+    if (np) {
+        pre[0] = pd[0].den;
+        for (int j = 1; j < np; ++j) pre[j] = Fr::mul(pre[j - 1], pd[j].den);
+    }
+    tree[256u + tid] = np ? pre[np - 1] : Fr::one();
+    __syncthreads();
+    for (u32 sz = 128u; sz >= 1u; sz >>= 1) {
+        if (tid < sz) tree[sz + tid] = Fr::mul(tree[2u * (sz + tid)], tree[2u * (sz + tid) + 1u]);
+        __syncthreads();
+    }
+    if (tid == 0) tree[1] = fr_inverse(tree[1]);
+    __syncthreads();
+    for (u32 sz = 1u; sz <= 128u; sz <<= 1) {
+        if (tid < sz) {
+            const u32 nd = sz + tid;
+            const Fr iv = tree[nd], c0 = tree[2u * nd], c1 = tree[2u * nd + 1u];
+            tree[2u * nd] = Fr::mul(iv, c1);
+            tree[2u * nd + 1u] = Fr::mul(iv, c0);
+        }
+        __syncthreads();
     }
     if (np == 0) return;
-    Fr pre[KB];                                   // pre[j] = den_0 .. den_j
-    pre[0] = pd[0].den;
-    for (int j = 1; j < np; ++j) pre[j] = Fr::mul(pre[j - 1], pd[j].den);
-    Fr inv = fr_inverse(pre[np - 1]);
+    Fr inv = tree[256u + tid];
     for (int j = np - 1; j >= 0; --j) {
         const Fr dinv = j ? Fr::mul(inv, pre[j - 1]) : inv;
         inv = Fr::mul(inv, pd[j].den);
@@ -373,6 +399,9 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
             if ((int64_t)L.n_gen >= ctx->solver_batch_from) {          // enough instructions to fill the chip several per thread: divisions share an inversion
                 const u32 stride = (L.n_gen + BATCH_K - 1) / BATCH_K;
                 hipLaunchKernelGGL(k_solve_level_batched<BATCH_K>, dim3((stride + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, stride, w, s->known, s->d_err, s->d_ext);
+                ++s->launches;
+            } else if (L.n_gen >= BATCH_TREE_FROM) {                  // one instruction per thread, one inversion per workgroup
+                hipLaunchKernelGGL(k_solve_level_batched<1>, dim3((L.n_gen + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, L.n_gen, w, s->known, s->d_err, s->d_ext);
                 ++s->launches;
             } else if (L.n_gen) {
                 hipLaunchKernelGGL(k_solve_level, dim3((L.n_gen + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, w, s->known, s->d_err, s->d_ext);
