@@ -86,6 +86,7 @@ struct zkpor_solver {
 namespace zk {
 static constexpr u32 NARROW = 512, EXT_CAP = 4096;
 static constexpr int BATCH_K = 4;                 // instructions per thread of the batched level kernel
+static constexpr u64 CHAIN_FROM = 16;             // runs of this many one-instruction levels go to k_solve_chain ("solver_chain" 0: never)
 static constexpr u32 BATCH_TREE_FROM = 1024;      // levels from this many generic instructions on: the divisions of a workgroup share one inversion
 
 ZK_D void solver_step(const SolverProg& P, u32 ins, Fr* w, uint8_t* known, u32* err, u32* ext) {
@@ -181,6 +182,120 @@ __global__ __launch_bounds__(NARROW) void k_solve_narrow(SolverProg P, const u32
         if (threadIdx.x < n && !err[0]) solver_step(P, level_instr[lo + threadIdx.x], w, known, err, ext);
         __threadfence_block();
         __syncthreads();
+    }
+}
+
+// A CHAIN: a run of levels of one instruction each (the 2 499 successive powers of the RLC challenge, batch_create_user_circuit.go:286-289).
+// In k_solve_narrow a level of the chain is a barrier plus six dependent trips to memory — instruction id, kind, row, terms, coefficient,
+// the operand the previous level stored — 5.9 us each, 14.5 ms of an otherwise idle GPU per proof.  Here one workgroup takes 256 levels at a
+// time: every thread DECODES one level's instruction (row, terms, coefficients, and the values of the operands that are known by then) side
+// by side; then the levels run in order, one lane after the other inside a wave, one wave after the other, and the value a level produces
+// travels to the next one through a register broadcast instead of through memory.  What is left per level is the field arithmetic.
+// A level that does not fit the short form (not a constraint, more than two terms in an expression, an operand produced earlier in the
+// same 256 by a level other than its predecessor) runs through the generic solver_step on what is in memory, and so does the rest of its 256.
+struct ChOpen { u32 wid, m, ck; Fr co; };                            // a term whose wire was not assigned when the round was decoded
+ZK_D u32 chain_slot(u32 x) { return (x * 2654435761u) >> 22; }      // 1 024 slots
+ZK_D u32 lane_value(u32 v, u32 k) { return (u32)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)k)); }
+__global__ __launch_bounds__(256) void k_solve_chain(SolverProg P, const u32* __restrict__ level_instr, const u64* __restrict__ gen_lo, u64 l0, u64 l1, Fr* w,
+                                                     uint8_t* known, u32* err, u32* ext) {
+    __shared__ u32 produced[1024];                // the wires this round's levels have assigned so far (open addressing)
+    __shared__ u32 carry_w, carry_dirty;
+    __shared__ Fr carry_v;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) { carry_w = 0xffffffffu; carry_dirty = 0u; carry_v = Fr::zero(); }
+    for (u64 base = l0; base < l1; base += 256u) {
+        for (u32 i = tid; i < 1024u; i += 256u) produced[i] = 0xffffffffu;
+        if (tid == 0) carry_dirty = 0u;           // memory is complete behind the barrier at the end of a round
+        // ---- decode, all levels of the round side by side: the known part of L, R, O summed, the (at most two) open terms kept
+        const u64 l = base + tid;
+        const bool have = l < l1 && !err[0];
+        u32 ins = 0, n_open = 0;
+        bool simple = false;
+        Fr a0 = Fr::zero(), a1 = Fr::zero(), a2 = Fr::zero();
+        ChOpen o0, o1;
+        o0.wid = o1.wid = 0xffffffffu; o0.m = o1.m = 0u; o0.ck = o1.ck = 3u; o0.co = o1.co = Fr::zero();
+        if (have) {
+            ins = level_instr[gen_lo[l]];
+            if (P.kind[ins] == SI_R1C && P.arg[ins] < P.n_constraints) {
+                const u32 row = P.arg[ins];
+                simple = true;
+                for (u32 m = 0; m < 3u && simple; ++m) {
+                    const u64 t0 = P.row_ptr[m][row], t1 = P.row_ptr[m][row + 1];
+                    if (t1 - t0 > 16u) { simple = false; break; }
+                    Fr acc = Fr::zero();
+                    for (u64 t = t0; t < t1; ++t) {
+                        const u32 wi = P.wid[m][t], ci = P.cid[m][t];
+                        if (known[wi]) si_add_term(acc, P.ckind[ci], P.coeff, ci, w[wi]);
+                        else if (n_open == 2u) { simple = false; break; }
+                        else {
+                            ChOpen& o = n_open ? o1 : o0;
+                            o.wid = wi; o.m = m; o.ck = P.ckind[ci]; o.co = P.coeff[ci];
+                            ++n_open;
+                        }
+                    }
+                    if (m == 0u) a0 = acc; else if (m == 1u) a1 = acc; else a2 = acc;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the levels in order
+        for (u32 wv = 0; wv < 4u; ++wv) {
+            if (wave == wv) {
+                u32 lastw = carry_w, dirty = carry_dirty;
+                Fr lastv = carry_v;
+                for (u32 k = 0; k < 64u; ++k) {
+                    u32 outx = 0xffffffffu, nd = dirty;
+                    Fr outv = Fr::zero();
+                    if (lane == k && have) {
+                        bool fast = simple && !dirty;
+                        Fr v[3] = {a0, a1, a2}, uc = Fr::zero();
+                        int which = -1;
+                        u32 x = 0;
+                        if (fast) {
+#pragma unroll
+                            for (u32 j = 0; j < 2u; ++j) {
+                                const ChOpen& o = j ? o1 : o0;
+                                if (j >= n_open) continue;
+                                if (o.wid == lastw) {                            // the predecessor's wire: its value is in the registers
+                                    Fr d = Fr::zero();
+                                    si_add_term(d, (uint8_t)o.ck, &o.co, 0u, lastv);
+                                    if (o.m == 0u) v[0] = Fr::add(v[0], d); else if (o.m == 1u) v[1] = Fr::add(v[1], d); else v[2] = Fr::add(v[2], d);
+                                } else if (which >= 0 && (which != (int)o.m || x != o.wid)) fast = false;   // a second open wire: an earlier level of this round's, or an error — memory decides
+                                else { uc = which < 0 ? o.co : Fr::add(uc, o.co); which = (int)o.m; x = o.wid; }
+                            }
+                        }
+                        if (fast && which >= 0) {                       // the open wire must not be one this round has assigned already
+                            for (u32 q = chain_slot(x);; q = (q + 1u) & 1023u) {
+                                const u32 e = produced[q];
+                                if (e == x) { fast = false; break; }
+                                if (e == 0xffffffffu) break;
+                            }
+                        }
+                        if (fast) {
+                            const int rc = si_r1c_finish(v, which, x, uc, w, known, nullptr, &outv);
+                            if (rc != SE_OK) { if (atomicCAS(&err[0], 0u, (u32)rc) == 0u) err[1] = ins; }
+                            else if (which >= 0) {
+                                outx = x;
+                                u32 q = chain_slot(x);
+                                while (produced[q] != 0xffffffffu) q = (q + 1u) & 1023u;
+                                produced[q] = x;
+                            }
+                        } else {
+                            __threadfence_block();
+                            solver_step(P, ins, w, known, err, ext);
+                            nd = 1u;
+                        }
+                    }
+                    lastw = lane_value(outx, k);
+                    dirty = lane_value(nd, k);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) lastv.v[i] = lane_value(outv.v[i], k);
+                }
+                if (lane == 0) { carry_w = lastw; carry_dirty = dirty; carry_v = lastv; }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
     }
 }
 
@@ -371,11 +486,24 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
             if (l + 1 == n_levels) ZK_TRY(join_side(s));          // ASYNC outputs are read by the last level only (the container's promise)
             const bool only_narrow = L.n_pos == 0 && L.n_posa == 0 && L.n_cnt == 0 && L.n_gen <= NARROW;
             if (only_narrow) {
+                // a chain — CHAIN_FROM or more levels of ONE generic instruction each, none of them external or the last — has its own kernel
+                auto one = [&](u64 q) { const LevelPlan& M = s->plan[q]; return q + 1 < n_levels && !M.n_pos && !M.n_posa && !M.n_cnt && M.n_gen == 1 && !M.external; };
+                auto chain_end = [&](u64 q) { while (q < n_levels && one(q)) ++q; return q; };
+                if (ctx->solver_chain && one(l)) {
+                    const u64 e = chain_end(l);
+                    if (e - l >= CHAIN_FROM) {
+                        hipLaunchKernelGGL(k_solve_chain, dim3(1), dim3(256), 0, ctx->stream, P, s->d_level_instr, s->d_gen_lo, l, e, w, s->known, s->d_err, s->d_ext);
+                        ++s->launches;
+                        s->next_level = e;
+                        continue;
+                    }
+                }
                 u64 l1 = l;                       // the run of narrow levels starting here, ended by (and including) a level with external hints
                 while (l1 < n_levels) {
                     const LevelPlan& M = s->plan[l1];
                     if (M.n_pos || M.n_posa || M.n_cnt || M.n_gen > NARROW) break;
                     if (l1 + 1 == n_levels && l1 != l && s->side_busy) break;   // the last level starts its own launch, behind the join
+                    if (ctx->solver_chain && l1 != l && one(l1) && chain_end(l1) - l1 >= CHAIN_FROM) break;   // a chain starts here
                     ++l1;
                     if (M.external) { stop = true; break; }
                 }

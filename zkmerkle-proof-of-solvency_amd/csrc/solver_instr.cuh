@@ -147,6 +147,41 @@ ZK_HD bool si_index(const Fr& x, u32 bound, u32* out) {
     return true;
 }
 
+// the end of solving ONE constraint (gnark solveR1C): v[m] = the known part of L, R, O, `which` = the expression the unknown wire x sits in
+// (-1: none, the row is an assertion), uc = the sum of its coefficients there
+ZK_HD int si_r1c_finish(const Fr* v, int which, u32 x, const Fr& uc, Fr* w, uint8_t* known, SiPending* pend, Fr* got = nullptr) {
+    if (which < 0) return Fr::mul(v[0], v[1]) == v[2] ? SE_OK : SE_NOT_SATISFIED;   // an assertion
+    if (uc.is_zero()) return SE_ZERO_COEFF;
+    Fr val;
+    if (which == 2) {
+        val = Fr::sub(Fr::mul(v[0], v[1]), v[2]);                     // O_known + c x = L R
+        if (uc == Fr::one()) {}
+        else if (Fr::neg(uc) == Fr::one()) val = Fr::neg(val);
+        else if (pend) { pend->wire = x; pend->num = val; pend->den = uc; return SE_DEFERRED; }
+        else val = Fr::mul(val, fr_inverse(uc));
+    } else {
+        const Fr& other = v[1 - which];
+        if (other.is_zero()) {                                        // gnark solveR1C: nothing to divide by — the constraint must hold as it is,
+            if (!v[2].is_zero()) return SE_DIV_ZERO;                  // (L_known + c x) * 0 = O needs O = 0 (else: "division by zero") ...
+            w[x] = Fr::zero();                                        // ... and the wire stays 0: api.DivUnchecked(0, 0) = 0 (std logderivarg relies on it)
+            known[x] = 1;
+            if (got) *got = Fr::zero();
+            return SE_OK;
+        }
+        const Fr num = Fr::sub(v[2], Fr::mul(v[which], other));       // (L_known + c x) R = O  =>  x = (O - L_known R) / (c R)
+        Fr den = other;
+        if (uc == Fr::one()) {}
+        else if (Fr::neg(uc) == Fr::one()) den = Fr::neg(den);
+        else den = Fr::mul(den, uc);
+        if (pend) { pend->wire = x; pend->num = num; pend->den = den; return SE_DEFERRED; }
+        val = Fr::mul(num, fr_inverse(den));
+    }
+    w[x] = val;
+    known[x] = 1;
+    if (got) *got = val;                                              // the caller hands the value on without reading it back
+    return SE_OK;
+}
+
 // Executes instruction `ins`: assigns its output wire(s) in w and marks them known.  The instructions of one level are independent: no
 // instruction reads a wire another instruction of the same level assigns, so a level may run in any order or all at once.
 ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known, SiPending* pend = nullptr) {
@@ -190,34 +225,7 @@ ZK_HD int solve_instr(const SolverProg& P, u32 ins, Fr* w, uint8_t* known, SiPen
             }
             v[m] = acc;
         }
-        if (which < 0) return Fr::mul(v[0], v[1]) == v[2] ? SE_OK : SE_NOT_SATISFIED;   // an assertion
-        if (uc.is_zero()) return SE_ZERO_COEFF;
-        Fr val;
-        if (which == 2) {
-            val = Fr::sub(Fr::mul(v[0], v[1]), v[2]);                     // O_known + c x = L R
-            if (uc == Fr::one()) {}
-            else if (Fr::neg(uc) == Fr::one()) val = Fr::neg(val);
-            else if (pend) { pend->wire = x; pend->num = val; pend->den = uc; return SE_DEFERRED; }
-            else val = Fr::mul(val, fr_inverse(uc));
-        } else {
-            const Fr& other = v[1 - which];
-            if (other.is_zero()) {                                        // gnark solveR1C: nothing to divide by — the constraint must hold as it is,
-                if (!v[2].is_zero()) return SE_DIV_ZERO;                  // (L_known + c x) * 0 = O needs O = 0 (else: "division by zero") ...
-                w[x] = Fr::zero();                                        // ... and the wire stays 0: api.DivUnchecked(0, 0) = 0 (std logderivarg relies on it)
-                known[x] = 1;
-                return SE_OK;
-            }
-            const Fr num = Fr::sub(v[2], Fr::mul(v[which], other));       // (L_known + c x) R = O  =>  x = (O - L_known R) / (c R)
-            Fr den = other;
-            if (uc == Fr::one()) {}
-            else if (Fr::neg(uc) == Fr::one()) den = Fr::neg(den);
-            else den = Fr::mul(den, uc);
-            if (pend) { pend->wire = x; pend->num = num; pend->den = den; return SE_DEFERRED; }
-            val = Fr::mul(num, fr_inverse(den));
-        }
-        w[x] = val;
-        known[x] = 1;
-        return SE_OK;
+        return si_r1c_finish(v, which, x, uc, w, known, pend);
     }
     // hint: nameId, nIn, nOut, out wire ids[nOut], then per input: nTerms, (coeffId, wireId)[nTerms]
     if ((u64)arg + 3 > P.n_calldata) return SE_CALLDATA;
