@@ -95,12 +95,18 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * "gpu_token" (1, the default: host-pointer proofs of several contexts on one GPU take turns on the device, see zkpor_prove_tail;
  * 0: their kernels share it freely), "host_order" (0, the default: a proof that finds the GPU free sends w first and a, b, c
  * underneath its own witness sums; 1: always everything first),
- * "poseidon_out_idx", "poseidon_carry_idx" (hash-wrapper convention) */
+ * "poseidon_out_idx", "poseidon_carry_idx" (hash-wrapper convention),
+ * the solver executor's (zkpor_solver_*): "solver_poseidon" (1, the default: a Poseidon call runs on 16 lanes; 0: in one thread),
+ * "solver_batch_from" (2^21: levels from this many generic instructions on run four per thread), "solver_chain" (1, the default: runs of
+ * one-instruction levels are decoded side by side and executed from registers; 0: the narrow-level kernel), "solver_defer_checks"
+ * (1, the default: see zkpor_solver_set_abc_dev; 0: a run executes its CHECK instructions even when a, b, c buffers are set),
+ * "poseidon_coop" (-1, the default: account leaves and CEX commitments run 16 lanes per hash chain when a launch has fewer than
+ * 65 536 chains; 0 never, 1 always) */
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);
 /* per-phase GPU time in ms accumulated since the last reset (HIP events on the context's stream).
  * names: "msm_decompose","msm_sort","msm_accumulate","msm_reduce","k_acc_level1_g1","k_acc_level1_g2" (the
  * bucket-accumulation kernel alone, one launch per call),"msm_filter","ntt","pointwise","poseidon_leaf","poseidon_tree","r1cs_eval",
- * "solver_levels","witgen_scatter";
+ * "solver_levels","rows_check","witgen_scatter","cex_commitments";
  * unknown names return 0.  calls = number of timed regions. */
 double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls);
 void zkpor_phase_reset(zkpor_ctx* ctx);
@@ -494,7 +500,14 @@ int32_t zkpor_solver_resume_dev(zkpor_solver* solver, uint32_t* paused_instr);
  * zkpor_solver_set_abc_dev names the prove tail's a / b / c buffers (2^log2_domain elements each) for the runs that follow: the instruction
  * then writes a, b, c of its own rows (program container: firstRow); zkpor_solver_eval_abc_dev, called after the run, evaluates every other
  * row (zkpor_r1cs_eval_dev restricted to them) into the same buffers.  Bit-identical to zkpor_r1cs_eval_dev of the solved vector
- * (tests/test_circuit_gpu.py).  NULL pointers switch it off; ASYNC / prefetched instructions never write rows. */
+ * (tests/test_circuit_gpu.py).  NULL pointers switch it off; ASYNC / prefetched instructions never write rows.
+ * ASSERTIONS move with it.  A third of the real circuit's instructions only VERIFY a constraint whose wires are all assigned (container:
+ * kind word bit 8, CHECK — host/solver_file.hpp).  gnark's solver evaluates each of them; a caller that computes a, b, c of every row right
+ * after the run has the same information in a x b = c.  With the buffers set (and the context parameter `solver_defer_checks` at its default
+ * 1) the run leaves the CHECK instructions out and zkpor_solver_eval_abc_dev verifies a x b = c on EVERY row after writing them (the rows
+ * the Poseidon instructions wrote included): ZKPOR_E_STATE "N constraints are not satisfied, the first one is #row" — the reference
+ * solver's error, reported one call later.  An unsatisfied assertion therefore no longer fails zkpor_solver_start_dev / resume_dev in
+ * this mode; hints, lookups and divisions fail where they did.  The call is synchronous when it checks. */
 int32_t zkpor_solver_set_abc_dev(zkpor_solver* solver, void* d_a, void* d_b, void* d_c);
 int32_t zkpor_solver_eval_abc_dev(zkpor_solver* solver, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size);
 /* Pipelining across proofs: starts the NEXT proof's long serial hash chains (instructions the program flags ASYNC — the two 10 000-element

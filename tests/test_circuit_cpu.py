@@ -136,3 +136,25 @@ def test_constraint_count_sits_where_the_reference_says():
         assert base + 1380 * per_user < 1 << 26 and base + 1380 * per_user > 1 << 25
     finally:
         one.close(); two.close()
+
+
+def test_assertions_are_flagged_check_in_the_container():
+    """host/solver_file.hpp INSTR_CHECK: the R1C instructions without an unknown wire carry bit 8 of their kind word (an executor whose caller
+    checks every row afterwards may leave them out); everything else reads the low byte — the host executor above parsed the same container"""
+    c = C.Circuit(3, 6, 2)
+    try:
+        raw = np.frombuffer(c.solver_container(), dtype=np.uint8)
+        assert bytes(raw[:8]) == b"ZKPSOLV\x02"
+        n_instr, n_levels, n_names, n_call = np.frombuffer(raw[8:40].tobytes(), dtype=np.uint64)
+        off = 40
+        for _ in range(int(n_names)):
+            l = int(np.frombuffer(raw[off:off + 4].tobytes(), dtype=np.uint32)[0]); off += 4 + l
+        off += (8 - off % 8) % 8
+        kinds = np.frombuffer(raw[off:off + 4 * int(n_instr)].tobytes(), dtype=np.uint32)
+        flagged = (kinds & 0x100) != 0
+        assert int(n_instr) == c.n_instructions and (kinds & ~np.uint32(0x1ff)).max() == 0
+        assert ((kinds[flagged] & 0xff) == 0).all()                               # only constraints are checks
+        n_assert = c.census["assert"] + c.census.get("assert_bool", 0)
+        assert flagged.sum() >= c.census["assert"] and flagged.sum() > 0.1 * c.n_instructions, (int(flagged.sum()), n_assert)
+    finally:
+        c.close()

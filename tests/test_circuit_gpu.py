@@ -235,3 +235,47 @@ def test_a_witness_the_circuit_rejects_is_an_error_not_a_proof(zk):
         for b in bufs:
             b.free()
         dc.close(); pk.close(); cir.close()
+
+
+def test_assertions_left_to_the_row_check_of_eval_abc(zk):
+    """with zkpor_solver_set_abc_dev the run leaves its CHECK instructions (the assertions: a third of the program) out and zkpor_solver_eval_abc_dev
+    verifies a x b = c on EVERY row instead: the same wires, a witness that only an assertion rejects (the tree root) passes the run and is
+    refused there with the row's number; a witness a hint rejects still fails in the run; `solver_defer_checks` 0 executes them as before"""
+    shape = (3, 6, 2)
+    inp = C.synth_inputs(*shape, seed=3)
+    cir = C.Circuit(*shape)
+    pk = zkpor.ProvingKey(zk)
+    dc = C.DeviceCircuit(zk, cir)
+    log2 = int(np.ceil(np.log2(cir.n_constraints)))
+    D = 1 << log2
+    bufs = [zk.alloc(32 * n) for n in (cir.n_wires, cir.n_committed + 1, D, D, D, cir.n_wires)]
+    try:
+        pk.synth(log2, cir.n_wires, cir.n_public, cir.n_committed, SEED)
+        C.solve_on_device(zk, dc, pk, bufs[5].ptr, bufs[1].ptr, inp)                       # the plain run: every instruction
+        launches_plain = dc.solver.dims()["launches_last_run"]
+        dc.solver.set_abc_dev(bufs[2].ptr, bufs[3].ptr, bufs[4].ptr)
+        C.solve_on_device(zk, dc, pk, bufs[0].ptr, bufs[1].ptr, inp)
+        dc.solver.eval_abc_dev(bufs[0].ptr, bufs[2].ptr, bufs[3].ptr, bufs[4].ptr, D)
+        assert np.array_equal(bufs[0].download(np.uint64, (cir.n_wires, 4)), bufs[5].download(np.uint64, (cir.n_wires, 4)))
+        assert dc.solver.dims()["launches_last_run"] <= launches_plain
+        bad = inp.copy(); bad[1, 0] ^= np.uint64(1)                                         # AccountTreeRoot: only the root assertions see it
+        C.solve_on_device(zk, dc, pk, bufs[0].ptr, bufs[1].ptr, bad)
+        with pytest.raises(zkpor.ZkporError) as e:
+            dc.solver.eval_abc_dev(bufs[0].ptr, bufs[2].ptr, bufs[3].ptr, bufs[4].ptr, D)
+        assert "not satisfied" in str(e.value) and "#" in str(e.value)
+        failing, first = dc.r1cs.check_dev(bufs[0].ptr)
+        assert failing >= shape[2] and f"#{first}" in str(e.value) and f"{failing} constraints" in str(e.value)   # one root comparison per user (+ the batch commitment)
+        meta = 6 + 114 * 6 + 7 * 3
+        worse = inp.copy(); worse[meta, 0] ^= np.uint64(1)                                  # a balance: a lookup / hint on the way refuses it
+        with pytest.raises(zkpor.ZkporError):
+            C.solve_on_device(zk, dc, pk, bufs[0].ptr, bufs[1].ptr, worse)
+        zk.set_param("solver_defer_checks", 0)
+        with pytest.raises(zkpor.ZkporError) as e:
+            C.solve_on_device(zk, dc, pk, bufs[0].ptr, bufs[1].ptr, bad)
+        assert "solver:" in str(e.value)
+        dc.solver.set_abc_dev(None, None, None)
+    finally:
+        zk.set_param("solver_defer_checks", 1)
+        for b in bufs:
+            b.free()
+        dc.close(); pk.close(); cir.close()

@@ -30,6 +30,7 @@ int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverP
 namespace {
 struct LevelPlan {          // one level of the reordered instruction list: [generic | poseidon | poseidon async | count]
     uint64_t lo = 0;
+    uint32_t n_chk = 0;                          // CHECK instructions (assertions), listed right behind the generic ones: left out when the caller checks every row itself
     uint32_t n_gen = 0, n_pos = 0, n_posa = 0, n_cnt = 0, cnt_first = 0;   // the level's count hints are counts[cnt_first .. + n_cnt)
     uint32_t posa_first = 0;                                               // its ASYNC calls are asyncs[posa_first .. + n_posa), in list order
     uint64_t cnt_rows = 0, cnt_queries = 0;                                // table rows / queries of all its count hints
@@ -68,6 +69,9 @@ struct zkpor_solver {
     uint64_t rows_covered = 0;
     zk::Fr *abc_a = nullptr, *abc_b = nullptr, *abc_c = nullptr;   // zkpor_solver_set_abc_dev
     bool abc_written = false;                   // the run that just finished wrote those rows (cooperative kernel, abc set)
+    bool checks_left = false;                   // the run (being) made leaves the CHECK instructions to zkpor_solver_eval_abc_dev (abc set, solver_defer_checks)
+    uint64_t n_check = 0;
+    uint32_t* d_gen_cnt_all = nullptr;          // generic + CHECK instructions per level (d_gen_cnt: generic only)
     uint32_t* d_perr = nullptr;                 // error words of a prefetch (its kernels run beside another run's)
     uint8_t* d_ones = nullptr;                  // n_wires bytes of 1: the `known` flags a prefetch reads (it only reads inputs)
     void* prefetched_w = nullptr;               // the wire vector whose ASYNC instructions are already running / done on the side stream
@@ -299,6 +303,13 @@ __global__ __launch_bounds__(256) void k_solve_chain(SolverProg P, const u32* __
     }
 }
 
+// a x b = c on every row (zkpor_solver_eval_abc_dev when the run left the CHECK instructions out): out[0] = rows that fail, out[1] = the lowest one
+__global__ __launch_bounds__(256) void k_rows_check(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c, size_t n, unsigned long long* out) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (Fr::mul(a[i], b[i]) != c[i]) { atomicAdd(&out[0], 1ull); atomicMin(&out[1], (unsigned long long)i); }
+}
+
 __global__ __launch_bounds__(256) void k_count_unknown(const uint8_t* __restrict__ known, size_t n, u32* err) {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     const bool miss = i < n && !known[i];
@@ -424,7 +435,7 @@ static SolverProg prog_of(const zkpor_solver* s) {
     return P;
 }
 static void solver_free(zkpor_solver* s) {
-    void* ptrs[] = {s->d_rows, s->d_perr, s->d_ones, s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
+    void* ptrs[] = {s->d_rows, s->d_perr, s->d_ones, s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_gen_cnt_all, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
                     s->d_cnt, s->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (s->side) (void)hipStreamDestroy(s->side);
@@ -484,10 +495,14 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
             const u64 l = s->next_level;
             const LevelPlan& L = s->plan[l];
             if (l + 1 == n_levels) ZK_TRY(join_side(s));          // ASYNC outputs are read by the last level only (the container's promise)
-            const bool only_narrow = L.n_pos == 0 && L.n_posa == 0 && L.n_cnt == 0 && L.n_gen <= NARROW;
+            // the generic instructions this run executes: the CHECK ones (assertions) only when nobody checks the rows afterwards
+            auto G = [&](const LevelPlan& M) { return M.n_gen + (s->checks_left ? 0u : M.n_chk); };
+            const u32* gen_cnt = s->checks_left ? s->d_gen_cnt : s->d_gen_cnt_all;
+            const u32 ng = G(L);
+            const bool only_narrow = L.n_pos == 0 && L.n_posa == 0 && L.n_cnt == 0 && ng <= NARROW;
             if (only_narrow) {
                 // a chain — CHAIN_FROM or more levels of ONE generic instruction each, none of them external or the last — has its own kernel
-                auto one = [&](u64 q) { const LevelPlan& M = s->plan[q]; return q + 1 < n_levels && !M.n_pos && !M.n_posa && !M.n_cnt && M.n_gen == 1 && !M.external; };
+                auto one = [&](u64 q) { const LevelPlan& M = s->plan[q]; return q + 1 < n_levels && !M.n_pos && !M.n_posa && !M.n_cnt && G(M) == 1 && M.n_gen == 1 && !M.external; };
                 auto chain_end = [&](u64 q) { while (q < n_levels && one(q)) ++q; return q; };
                 if (ctx->solver_chain && one(l)) {
                     const u64 e = chain_end(l);
@@ -501,13 +516,13 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                 u64 l1 = l;                       // the run of narrow levels starting here, ended by (and including) a level with external hints
                 while (l1 < n_levels) {
                     const LevelPlan& M = s->plan[l1];
-                    if (M.n_pos || M.n_posa || M.n_cnt || M.n_gen > NARROW) break;
+                    if (M.n_pos || M.n_posa || M.n_cnt || G(M) > NARROW) break;
                     if (l1 + 1 == n_levels && l1 != l && s->side_busy) break;   // the last level starts its own launch, behind the join
                     if (ctx->solver_chain && l1 != l && one(l1) && chain_end(l1) - l1 >= CHAIN_FROM) break;   // a chain starts here
                     ++l1;
                     if (M.external) { stop = true; break; }
                 }
-                hipLaunchKernelGGL(k_solve_narrow, dim3(1), dim3(NARROW), 0, ctx->stream, P, s->d_level_instr, s->d_gen_lo, s->d_gen_cnt, l, l1, w, s->known, s->d_err, s->d_ext);
+                hipLaunchKernelGGL(k_solve_narrow, dim3(1), dim3(NARROW), 0, ctx->stream, P, s->d_level_instr, s->d_gen_lo, gen_cnt, l, l1, w, s->known, s->d_err, s->d_ext);
                 ++s->launches;
                 s->next_level = l1;
                 continue;
@@ -520,24 +535,24 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                     hipLaunchKernelGGL(k_hint_inputs, dim3((a.n_in + 255u) / 256u), dim3(256), 0, s->side, P, a.ins, s->d_offs + a.offs_base, a.n_in, (const Fr*)w, s->known,
                                        s->d_pre + a.nb_q, s->d_err);
                 }
-                ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_pos, L.n_posa, w, s->known, s->d_err, s->d_pre, s->d_pre_off + L.posa_first, nullptr, nullptr, nullptr));
+                ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_chk + L.n_pos, L.n_posa, w, s->known, s->d_err, s->d_pre, s->d_pre_off + L.posa_first, nullptr, nullptr, nullptr));
                 s->side_busy = true;
                 ++s->launches;
             }
-            if ((int64_t)L.n_gen >= ctx->solver_batch_from) {          // enough instructions to fill the chip several per thread: divisions share an inversion
-                const u32 stride = (L.n_gen + BATCH_K - 1) / BATCH_K;
-                hipLaunchKernelGGL(k_solve_level_batched<BATCH_K>, dim3((stride + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, stride, w, s->known, s->d_err, s->d_ext);
+            if ((int64_t)ng >= ctx->solver_batch_from) {              // enough instructions to fill the chip several per thread: divisions share an inversion
+                const u32 stride = (ng + BATCH_K - 1) / BATCH_K;
+                hipLaunchKernelGGL(k_solve_level_batched<BATCH_K>, dim3((stride + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, ng, stride, w, s->known, s->d_err, s->d_ext);
                 ++s->launches;
-            } else if (L.n_gen >= BATCH_TREE_FROM) {                  // one instruction per thread, one inversion per workgroup
-                hipLaunchKernelGGL(k_solve_level_batched<1>, dim3((L.n_gen + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, L.n_gen, w, s->known, s->d_err, s->d_ext);
+            } else if (ng >= BATCH_TREE_FROM) {                       // one instruction per thread, one inversion per workgroup
+                hipLaunchKernelGGL(k_solve_level_batched<1>, dim3((ng + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, ng, ng, w, s->known, s->d_err, s->d_ext);
                 ++s->launches;
-            } else if (L.n_gen) {
-                hipLaunchKernelGGL(k_solve_level, dim3((L.n_gen + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, L.n_gen, w, s->known, s->d_err, s->d_ext);
+            } else if (ng) {
+                hipLaunchKernelGGL(k_solve_level, dim3((ng + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, ng, w, s->known, s->d_err, s->d_ext);
                 ++s->launches;
             }
             if (L.n_pos) {
                 const bool rows = s->abc_written;   // decided when the run started
-                ZK_TRY(gadget_poseidon_launch(ctx, ctx->stream, P, s->d_level_instr + L.lo + L.n_gen, L.n_pos, w, s->known, s->d_err, nullptr, nullptr,
+                ZK_TRY(gadget_poseidon_launch(ctx, ctx->stream, P, s->d_level_instr + L.lo + L.n_gen + L.n_chk, L.n_pos, w, s->known, s->d_err, nullptr, nullptr,
                                               rows ? s->abc_a : nullptr, s->abc_b, s->abc_c));
                 ++s->launches;
             }
@@ -619,7 +634,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     // and sort every instruction into its class
     s->hint_kind.resize(v.hint_names.size());
     for (size_t i = 0; i < v.hint_names.size(); ++i) s->hint_kind[i] = hint_kind_of_name(v.hint_names[i].c_str());
-    enum : uint8_t { CL_GEN = 0, CL_POS = 1, CL_POSA = 2, CL_CNT = 3 };
+    enum : uint8_t { CL_GEN = 0, CL_CHK = 1, CL_POS = 2, CL_POSA = 3, CL_CNT = 4 };
     std::vector<uint8_t> cls(v.n_instructions, CL_GEN), external(v.n_instructions, 0);
     std::vector<uint32_t> kinds(v.n_instructions);
     std::set<std::pair<uint32_t, uint32_t>> tables_ok;   // (block, nbEntries) already validated: a table's entries are checked once, not per lookup
@@ -638,7 +653,11 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     for (uint64_t i = 0; i < v.n_instructions; ++i) {
         const uint32_t kind = zkpor_host::InstrKind(v, i), arg = v.arg[i];
         kinds[i] = kind;
-        if (kind == SI_R1C) { if (arg >= r1cs->n_constraints) return bad("instruction " + std::to_string(i) + " names a constraint outside the system"); ++s->n_r1c; }
+        if (kind == SI_R1C) {
+            if (arg >= r1cs->n_constraints) return bad("instruction " + std::to_string(i) + " names a constraint outside the system");
+            ++s->n_r1c;
+            if (zkpor_host::InstrIsCheck(v, i)) { cls[i] = CL_CHK; ++s->n_check; }
+        }
         else if (kind == SI_LOOKUP) {
             if ((uint64_t)arg + 4 > v.n_calldata) return bad("the call data of lookup " + std::to_string(i) + " is malformed");
             const uint32_t* cd = v.calldata + arg;
@@ -712,7 +731,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     }
     // the level lists, every level reordered by class; count hints collected in level order
     const uint64_t n_li = v.level_ptr[v.n_levels];
-    std::vector<uint32_t> li(n_li), gen_cnt(v.n_levels);
+    std::vector<uint32_t> li(n_li), gen_cnt(v.n_levels), gen_cnt_all(v.n_levels);
     std::vector<uint64_t> gen_lo(v.n_levels);
     std::vector<uint32_t> pre_off_host;
     std::vector<CountDev> cmeta;
@@ -731,7 +750,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
                 if (c == CL_CNT) s->counts.push_back(big[ins]);
                 if (c == CL_POSA) { s->asyncs.push_back(big[ins]); pre_off_host.push_back((uint32_t)big[ins].nb_q); }
             }
-            if (c == CL_GEN) L.n_gen = n; else if (c == CL_POS) L.n_pos = n; else if (c == CL_POSA) { L.n_posa = n; L.posa_first = (uint32_t)(s->asyncs.size() - n); } else { L.n_cnt = n; L.cnt_first = (uint32_t)(s->counts.size() - n); }
+            if (c == CL_GEN) L.n_gen = n; else if (c == CL_CHK) L.n_chk = n; else if (c == CL_POS) L.n_pos = n; else if (c == CL_POSA) { L.n_posa = n; L.posa_first = (uint32_t)(s->asyncs.size() - n); } else { L.n_cnt = n; L.cnt_first = (uint32_t)(s->counts.size() - n); }
         }
         for (uint32_t k = 0; k < L.n_cnt; ++k) {
             const BigHint& c = s->counts[L.cnt_first + k];
@@ -743,7 +762,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
         }
         if (L.cnt_rows >= (1ull << 32)) return bad("count hints of one level cover more than 2^32 table rows");
         max_table = std::max<uint64_t>(max_table, L.cnt_rows);
-        gen_lo[l] = L.lo; gen_cnt[l] = L.n_gen;
+        gen_lo[l] = L.lo; gen_cnt[l] = L.n_gen; gen_cnt_all[l] = L.n_gen + L.n_chk;
         if (L.n_posa && l + 1 >= v.n_levels) return bad("an ASYNC instruction in the last level");
     }
     for (auto& kv : big) if (external[kv.first]) s->externals[kv.first] = kv.second;
@@ -753,10 +772,10 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     };
     bool ok = up((void**)&s->d_kind, kinds.data(), v.n_instructions * 4) && up((void**)&s->d_arg, v.arg, v.n_instructions * 4) &&
               up((void**)&s->d_level_instr, li.data(), n_li * 4) && up((void**)&s->d_calldata, v.calldata, v.n_calldata * 4) &&
-              up((void**)&s->d_gen_lo, gen_lo.data(), v.n_levels * 8) && up((void**)&s->d_gen_cnt, gen_cnt.data(), v.n_levels * 4) &&
+              up((void**)&s->d_gen_lo, gen_lo.data(), v.n_levels * 8) && up((void**)&s->d_gen_cnt, gen_cnt.data(), v.n_levels * 4) && up((void**)&s->d_gen_cnt_all, gen_cnt_all.data(), v.n_levels * 4) &&
               up((void**)&s->d_rows, row_bits.data(), row_bits.size() * 4) && up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up(&s->d_cmeta, cmeta.data(), cmeta.size() * sizeof(CountDev)) && up((void**)&s->d_pre_off, pre_off_host.data(), pre_off_host.size() * 4) &&
               hipMalloc((void**)&s->d_pre, (pre_total ? pre_total : 1) * sizeof(Fr)) == hipSuccess && up((void**)&s->d_hint_kind, s->hint_kind.data(), s->hint_kind.size()) &&
-              hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 16) == hipSuccess &&
+              hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 32) == hipSuccess &&
               hipMalloc((void**)&s->d_ext, EXT_CAP * sizeof(u32)) == hipSuccess && hipMalloc((void**)&s->d_cnt, max_table * sizeof(u32)) == hipSuccess &&
               hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess;
@@ -799,6 +818,7 @@ int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint
     if (s->skip_async)     // the prefetched instructions' wires are (being) assigned on the side stream: flagged here, joined in front of the last level
         for (const BigHint& a : s->asyncs) { const uint32_t* cd = s->view.calldata + s->view.arg[a.ins]; ZK_HIP(ctx, hipMemsetAsync(s->known + cd[1], 1, cd[2], ctx->stream)); }
     s->abc_written = s->abc_a != nullptr && ctx->solver_poseidon == 1 && s->rows_covered > 0;
+    s->checks_left = s->abc_a != nullptr && ctx->solver_defer_checks != 0 && s->n_check > 0;   // zkpor_solver_eval_abc_dev verifies a x b = c on every row instead
     s->running = true; s->next_level = 0; s->pending.clear(); s->launches = 0;
     return solver_advance(s, paused_instr);
 }
@@ -817,8 +837,25 @@ int32_t zkpor_solver_set_abc_dev(zkpor_solver* s, void* d_a, void* d_b, void* d_
 int32_t zkpor_solver_eval_abc_dev(zkpor_solver* s, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || !d_w || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
-    if (s->abc_written && (d_a != s->abc_a || d_b != s->abc_b || d_c != s->abc_c)) { s->ctx->err = "solver: the run wrote rows into other buffers than these"; return ZKPOR_E_ARG; }
-    return zk::r1cs_eval_on(s->ctx, s->r1cs, d_w, d_a, d_b, d_c, domain_size, s->abc_written ? s->d_rows : nullptr);
+    zkpor_ctx* ctx = s->ctx;
+    if ((s->abc_written || s->checks_left) && (d_a != s->abc_a || d_b != s->abc_b || d_c != s->abc_c)) { ctx->err = "solver: the run was made for other a, b, c buffers than these"; return ZKPOR_E_ARG; }
+    ZK_TRY(zk::r1cs_eval_on(ctx, s->r1cs, d_w, d_a, d_b, d_c, domain_size, s->abc_written ? s->d_rows : nullptr));
+    if (!s->checks_left) return ZKPOR_OK;
+    // the run left its CHECK instructions out: every row is verified here instead, a x b = c (the Poseidon rows the solver wrote included)
+    const size_t n = s->r1cs->n_constraints;
+    if (n == 0) return ZKPOR_OK;
+    unsigned long long h[2] = {0ull, ~0ull};
+    unsigned long long* d_out = (unsigned long long*)(s->d_err + 4);
+    {
+        PhaseScope ps(ctx, "rows_check");
+        ZK_HIP(ctx, hipMemcpyAsync(d_out, h, 16, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_rows_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_a, (const Fr*)d_b, (const Fr*)d_c, n, d_out);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[0]) { ctx->err = "solver: " + std::to_string(h[0]) + " constraints are not satisfied, the first one is #" + std::to_string(h[1]); return ZKPOR_E_STATE; }
+    return ZKPOR_OK;
 }
 
 /* the ASYNC instructions of the NEXT proof (the two CEX commitments: 834 chained permutations each, ~0.2 s of one wave) started on the side
@@ -849,7 +886,7 @@ int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inpu
         hipLaunchKernelGGL(k_hint_inputs, dim3((a.n_in + 255u) / 256u), dim3(256), 0, s->side, P, a.ins, s->d_offs + a.offs_base, a.n_in, (const Fr*)d_w_next, s->d_ones,
                            s->d_pre + a.nb_q, s->d_perr);
     }
-    ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_pos, L.n_posa, (Fr*)d_w_next, s->d_ones, s->d_perr, s->d_pre, s->d_pre_off + L.posa_first, nullptr, nullptr, nullptr));
+    ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_chk + L.n_pos, L.n_posa, (Fr*)d_w_next, s->d_ones, s->d_perr, s->d_pre, s->d_pre_off + L.posa_first, nullptr, nullptr, nullptr));
     s->side_busy = true;
     s->prefetched_w = d_w_next;
     (void)n_inputs;

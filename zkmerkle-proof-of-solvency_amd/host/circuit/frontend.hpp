@@ -93,6 +93,7 @@ struct Compiled {   // what a compile leaves behind (moved out of the builder)
     std::vector<u64> row_ptr[3];
     std::vector<u32> cid[3], wid[3];
     std::vector<u32> kind, arg;
+    std::vector<u32> check;                     // instructions that only verify their constraint (solver_file.hpp INSTR_CHECK)
     std::vector<u64> level_ptr;
     std::vector<u32> level_instr;
     std::vector<u32> calldata;
@@ -410,6 +411,7 @@ private:
     std::vector<int> rc_bits_;
     std::vector<u32> slow_lo_, slow_hi_;
     std::vector<u32> deferred_asserts_;
+    std::vector<u32> check_;                    // the R1C instructions without an unknown wire, in program order
     std::vector<std::pair<u32, u32>> async_instrs_;   // (instruction, its as-soon-as-possible level)
     PermTemplate tmpl_[zkpor_host::kPosMaxT + 1];
     std::vector<u32> committed_;
@@ -477,6 +479,7 @@ private:
         push_row(0, l); push_row(1, r); push_row(2, o);
         const u64 row = row_ptr_[0].size() - 2;
         push_instr(K_R1C, row, lvl);
+        if (out == NO_WIRE) check_.push_back((u32)kind_.size() - 1);          // an assertion: flagged CHECK in the container
         if (out == NO_WIRE && !slow_lo_.empty() && (reads_slow(l) || reads_slow(r) || reads_slow(o))) deferred_asserts_.push_back((u32)kind_.size() - 1);
     }
     LE merge(const LE& a, const LE& b, bool negate_b) {
@@ -849,7 +852,7 @@ inline Compiled Builder::finish() {
     for (u32 w : wid_[1]) c.in_r[w] = 1;
     c.coeff = std::move(coeff_);
     for (int m = 0; m < 3; ++m) { c.row_ptr[m] = std::move(row_ptr_[m]); c.cid[m] = std::move(cid_[m]); c.wid[m] = std::move(wid_[m]); }
-    c.kind = std::move(kind_); c.arg = std::move(arg_); c.calldata = std::move(calldata_); c.hint_names = std::move(hint_names_);
+    c.kind = std::move(kind_); c.arg = std::move(arg_); c.check = std::move(check_); c.calldata = std::move(calldata_); c.hint_names = std::move(hint_names_);
     c.committed = std::move(committed_); c.commitment_wire = commitment_wire_;
     c.values = std::move(val_);
     for (int i = 0; i < C_NUM; ++i) c.census[cnt_name(i)] = cnt_[i];
@@ -869,7 +872,12 @@ inline std::vector<uint8_t> SolverContainer(const Compiled& c) {
     put(h, sizeof h);
     for (auto& s : c.hint_names) { const u32 l = (u32)s.size(); put(&l, 4); put(s.data(), l); }
     pad();
-    put(c.kind.data(), c.kind.size() * 4); put(c.arg.data(), c.arg.size() * 4);
+    {   // the kind words, assertions flagged CHECK
+        std::vector<u32> kw(c.kind);
+        for (u32 i : c.check) kw[i] |= zkpor_host::INSTR_CHECK;
+        put(kw.data(), kw.size() * 4);
+    }
+    put(c.arg.data(), c.arg.size() * 4);
     pad();
     put(c.level_ptr.data(), c.level_ptr.size() * 8);
     put(c.level_instr.data(), c.level_instr.size() * 4);

@@ -39,6 +39,10 @@ struct SolverView {
     const uint32_t* calldata = nullptr;
 };
 enum { INSTR_R1C = 0, INSTR_HINT = 1, INSTR_SKIP = 2, INSTR_LOOKUP = 3, INSTR_POSEIDON = 4 };
+// bit 8 of a version-2 R1C instruction's kind word: CHECK — the constraint has no unknown wire by the time its level runs (an assertion: gnark's
+// solver only verifies it).  An executor whose caller evaluates a, b, c of EVERY row afterwards and checks a x b = c there may leave these
+// instructions out (csrc/solver.hip with zkpor_solver_set_abc_dev); every other executor treats the word as its low byte says.
+enum : uint32_t { INSTR_CHECK = 1u << 8 };
 enum : uint32_t { POSEIDON_ASYNC = 1u << 16, POSEIDON_HDR = 5 };   // header words of a kind-4 instruction's call data
 
 // shape checks of the two gadget instructions against the call data (both executors call this before they trust an offset).
@@ -93,7 +97,8 @@ inline bool CheckPoseidonShape(const SolverView& v, uint64_t arg, uint64_t n_wir
 }
 
 // the kind an executor acts on: a version-1 stream used 3 as a second spelling of "skipped"
-inline uint32_t InstrKind(const SolverView& v, uint64_t i) { const uint32_t k = v.kind[i]; return (v.version == 1 && k == 3) ? (uint32_t)INSTR_SKIP : k; }
+inline uint32_t InstrKind(const SolverView& v, uint64_t i) { const uint32_t k = v.version == 1 ? v.kind[i] : (v.kind[i] & 0xffu); return (v.version == 1 && k == 3) ? (uint32_t)INSTR_SKIP : k; }
+inline bool InstrIsCheck(const SolverView& v, uint64_t i) { return v.version >= 2 && (v.kind[i] & INSTR_CHECK) != 0; }
 
 inline int ParseSolverFile(const uint8_t* data, size_t len, SolverView* out, std::string* err) {
     auto fail = [&](const char* m) { if (err) *err = std::string("solver file: ") + m; return 1; };
@@ -130,7 +135,10 @@ inline int ParseSolverFile(const uint8_t* data, size_t len, SolverView* out, std
     off += (8 - off % 8) % 8;
     if (!take32(v.n_calldata, &v.calldata)) return fail("truncated call data");
     for (uint64_t i = 0; i < n_li; ++i) if (v.level_instr[i] >= v.n_instructions) return fail("level entry out of range");
-    for (uint64_t i = 0; i < v.n_instructions; ++i) if (v.kind[i] > max_kind) return fail("unknown instruction kind");
+    for (uint64_t i = 0; i < v.n_instructions; ++i) {
+        const uint32_t k = v.kind[i];
+        if (data[7] == 1 ? k > max_kind : ((k & 0xffu) > max_kind || (k & ~(0xffu | INSTR_CHECK)) != 0 || ((k & INSTR_CHECK) && (k & 0xffu) != INSTR_R1C))) return fail("unknown instruction kind");
+    }
     v.version = data[7];
     *out = std::move(v);
     return 0;
