@@ -314,8 +314,10 @@ def device_executor_leg(ctx):
             if s is not None:
                 s.close()
             d_w.free(); r.close()
-    out["note"] = ("inputs resident, the call returns when every wire is assigned; one field inversion (binary extended Euclid) per division and thread, no "
-                   "batching across the threads of a level yet; the same instruction semantics are unit-tested on the CPU (tests/test_solver_logic_cpu.py)")
+    out["note"] = ("round 3's two synthetic shapes, kept for comparison (VERDICT r03 item 2: 1.35e8 instructions/s and 207 ms then): inputs resident, the call returns when "
+                   "every wire is assigned; levels of 1 024 instructions and more share ONE field inversion (binary extended Euclid) per workgroup; the chained shape is a "
+                   "run of narrow levels with a division every few levels, each the latency of one inversion on one lane — the production circuit has no such chain "
+                   "(its 2 443-level chain is products only: k_solve_chain); the same instruction semantics are unit-tested on the CPU (tests/test_solver_logic_cpu.py)")
     return out
 
 

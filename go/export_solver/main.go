@@ -16,7 +16,9 @@
 //	magic "ZKPSOLV\x02"
 //	u64 nInstructions, nLevels, nHintNames, nCallData
 //	hint names: u32 length + bytes each; pad to 8
-//	u32 kind[nInstructions]   0 = solve constraint arg; 1 = hint, call data at arg; 2 = skipped (wires produced by a device generator);
+//	u32 kind[nInstructions]   0 = solve constraint arg (| 0x100 = CHECK: the constraint assigns no wire, it is only verified — found by replaying
+//	                              gnark's own instruction tree below; an executor whose caller verifies a x b = c on every row may leave these out);
+//	                          1 = hint, call data at arg; 2 = skipped (wires produced by a device generator);
 //	                          3 = table lookup (gnark's BlueprintLookupHint: std/lookup/logderivlookup): call data blockOff, nbEntries, nQ,
 //	                              firstOutWire, the nQ index expressions — the table's entries are written ONCE per table (block at blockOff:
 //	                              nEntries, entryOff[nEntries], the entry expressions), as gnark keeps them once per blueprint;
@@ -98,6 +100,13 @@ func main() {
 	}
 
 	nIns := len(r1cs.Instructions)
+	// which constraint instructions assign no wire: the same walk gnark's builder does when it levelises (Blueprint.UpdateInstructionTree
+	// inserts the wires an instruction solves into the tree; an R1C instruction that inserts none is an assertion)
+	tree := &wireTree{level: make([]int32, r1cs.GetNbInternalVariables()+r1cs.GetNbPublicVariables()+r1cs.GetNbSecretVariables())}
+	for i := range tree.level {
+		tree.level[i] = -1
+	}
+	tree.inputs = r1cs.GetNbPublicVariables() + r1cs.GetNbSecretVariables()
 	kind := make([]uint32, nIns)
 	arg := make([]uint32, nIns)
 	var callData []uint32
@@ -109,6 +118,11 @@ func main() {
 		case constraint.BlueprintR1C: // BlueprintGenericR1C: exactly one constraint
 			_ = b
 			kind[i], arg[i] = 0, uint32(ins.ConstraintOffset)
+			before := tree.inserted
+			bp.UpdateInstructionTree(ins, tree)
+			if tree.inserted == before {
+				kind[i] |= 0x100 // CHECK (host/solver_file.hpp INSTR_CHECK)
+			}
 		case constraint.BlueprintHint: // BlueprintGenericHint and the hint-carrying blueprints of the std gadgets
 			var hm constraint.HintMapping
 			b.DecompressHint(&hm, ins)
@@ -147,6 +161,9 @@ func main() {
 			callData = append(callData, ins.Calldata[3:]...)
 		default:
 			panic(fmt.Sprintf("instruction %d: blueprint %T is neither an R1C, a hint carrier nor the lookup blueprint — extend the exporter", i, bp))
+		}
+		if _, isR1C := bp.(constraint.BlueprintR1C); !isR1C {
+			bp.UpdateInstructionTree(ins, tree) // hints, lookups: their output wires enter the tree
 		}
 		if skip[i] {
 			kind[i] = 2
@@ -201,4 +218,24 @@ func main() {
 	pad()
 	put(callData)
 	fmt.Printf("%d instructions (%d skipped), %d levels, %d hint names %v, %d words of call data\n", nIns, len(skip), len(r1cs.Levels), len(names), names, len(callData))
+}
+
+// wireTree is the constraint.InstructionTree the blueprints update: which wires earlier instructions solve (inputs carry level -1 and count
+// as present: gnark's builder inserts them before the first instruction)
+type wireTree struct {
+	level    []int32
+	inserted int
+	inputs   int
+}
+
+func (t *wireTree) InsertWire(wire uint32, level constraint.Level) {
+	t.level[wire] = int32(level)
+	t.inserted++
+}
+func (t *wireTree) HasWire(wire uint32) bool { return int(wire) < t.inputs || t.level[wire] >= 0 }
+func (t *wireTree) GetWireLevel(wire uint32) constraint.Level {
+	if int(wire) < t.inputs {
+		return constraint.LevelUnset
+	}
+	return constraint.Level(t.level[wire])
 }

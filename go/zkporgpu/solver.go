@@ -108,6 +108,11 @@ func ProveOnDevice(ctx *Context, pk *ProvingKey, m *R1CS, sp *Solver, r1cs *cs_b
 	proof := &groth16_bn254.Proof{Commitments: make([]curve.G1Affine, len(commitmentInfo))}
 	var pok curve.G1Affine
 	var paused C.uint32_t
+	// a, b, c named before the run: the Poseidon instructions write their own rows, the assertions (container flag CHECK) are left to the
+	// a x b = c pass of zkpor_solver_eval_abc_dev below (include/zkpor.h; an unsatisfied constraint is reported there)
+	if err = ctx.err(C.zkpor_solver_set_abc_dev(sp.h, dABC[0], dABC[1], dABC[2])); err != nil {
+		return nil, err
+	}
 	if err = ctx.err(C.zkpor_solver_start_dev(sp.h, dW, C.size_t(len(inputs)), nil, &paused)); err != nil {
 		return nil, err
 	}
@@ -152,8 +157,8 @@ func ProveOnDevice(ctx *Context, pk *ProvingKey, m *R1CS, sp *Solver, r1cs *cs_b
 			return nil, err
 		}
 	}
-	if err = ctx.err(C.zkpor_r1cs_eval_dev(m.h, dW, dABC[0], dABC[1], dABC[2], C.size_t(domain))); err != nil {
-		return nil, err
+	if err = ctx.err(C.zkpor_solver_eval_abc_dev(sp.h, dW, dABC[0], dABC[1], dABC[2], C.size_t(domain))); err != nil {
+		return nil, err // incl. "N constraints are not satisfied, the first one is #row"
 	}
 	var r, s fr.Element
 	if _, err = r.SetRandom(); err != nil {

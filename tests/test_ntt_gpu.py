@@ -73,7 +73,7 @@ def test_fft_roundtrip_2_20(zk):
     assert np.array_equal(back, a)
 
 
-@pytest.mark.parametrize("log2d,ncons", [(3, 5), (8, 256), (10, 1000), (12, 4096), (17, 100000)])
+@pytest.mark.parametrize("log2d,ncons", [(3, 5), (8, 256), (10, 1000), (12, 4096)])   # 2^17 and up: the _large cases below
 def test_compute_h_matches_oracle(zkv, log2d, ncons):
     zk = zkv
     key = ("h", log2d, ncons)
@@ -125,7 +125,7 @@ def test_compute_h_fault_injection_detected(zk):
     assert np.array_equal(zk.compute_h(a, b, c, log2d), good)
 
 
-@pytest.mark.parametrize("log2d", [9, 13, 17, 20])
+@pytest.mark.parametrize("log2d", [9, 17, 20])
 def test_compute_h_fused_passes_equal_separate_passes(zk, log2d):
     """computeH's fused kernels ("ntt_fuse" 1, the default) — k_ntt_mid29: the two passes over the lowest field (inverse DIF last, coset
     DIT first) on one tile; k_ntt_top29: the last DIT pass of a, b and c, the pointwise quotient and the first DIF pass of h on one tile of
