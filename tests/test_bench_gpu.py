@@ -79,8 +79,10 @@ def test_bench_circuit_mode_end_to_end():
     assert abs(mix["in_{0,1}"] + mix["below_2^16"] + mix["below_2^64"] + mix["wider"] - 1.0) < 1e-3 and mix["in_{0,1}"] > 0.3
     e = d["end_to_end"]
     assert e["steps"] == 3 and e["value"] > 0 and abs(e["value"] - 1e3 / e["ms_per_proof"]) < 1e-6 * e["value"]
-    assert e["checked"] == {"proofs": 3, "ok": 3} and e["same_wires_as_headline"] is True and e["constraints_failing_on_device"] == 0
-    assert e["next_proofs_hash_chains_prefetched"] is True
+    two = e["two_in_flight"]                                        # the same with two worker contexts: their proofs are checked with the others
+    assert two["workers"] == 2 and two["value"] > 0 and two["both_workers_solved_the_same_wires"] is True
+    assert e["checked"] == {"proofs": 3 + two["steps"], "ok": 3 + two["steps"]} and e["same_wires_as_headline"] is True and e["constraints_failing_on_device"] == 0
+    assert e["next_proofs_hash_chains_prefetched"] is True and e["assertions"].startswith("left out of the run")
     c = e["circuit"]
     assert c["shape_T_A_U"] == [5, 20, 6] and c["constraints"] > 300000 and c["levels"] < 200 and c["committed_wires"] > 40000 and c["census"]["poseidon_perm_t3"] == 28 * 6
     assert e["value"] < d["value"]                                  # the solver costs something

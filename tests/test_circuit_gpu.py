@@ -81,6 +81,20 @@ def test_batched_inversions_of_wide_levels_change_no_wire(zk):
         zk.set_param("solver_batch_from", 1 << 21)
 
 
+def test_one_inversion_per_workgroup_and_long_constraints_by_waves_change_no_wire(zk):
+    """levels from `solver_tree_from` generic instructions on: the divisions of a workgroup share one inversion (product tree in LDS) and the
+    constraints of more than `solver_long` terms (256: the 1 024-term sums behind the log-derivative arguments) are left to one wave each
+    (k_solve_long).  A small batch's wide levels hold no such constraint and the default `solver_tree_from` (1 024) passes most of them by —
+    both lowered here so that every wide level takes the path and thousands of constraints go through the wave kernel, with one and with four
+    instructions per thread; `solver_long` 0 walks them in their own thread: the same wires every way"""
+    try:
+        for tree_from, batch_from, long_ in ((1, 1 << 21, 6), (1, 2, 6), (1, 1 << 21, 0)):     # 6: the range checks' recompositions, the lookups' rows ... are "long"
+            zk.set_param("solver_tree_from", tree_from); zk.set_param("solver_batch_from", batch_from); zk.set_param("solver_long", long_)
+            prove_once(zk, (5, 20, 6), 1)
+    finally:
+        zk.set_param("solver_tree_from", 1024); zk.set_param("solver_batch_from", 1 << 21); zk.set_param("solver_long", 256)
+
+
 def test_the_500_asset_tier_shape(zk):
     """T = all assets (the zkpor500 shape: every slot of the user's list is a real CEX asset): sponges of 1000 / 3000 elements"""
     prove_once(zk, (30, 30, 2), 1)

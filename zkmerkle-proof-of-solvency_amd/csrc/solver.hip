@@ -71,6 +71,7 @@ struct zkpor_solver {
     bool abc_written = false;                   // the run that just finished wrote those rows (cooperative kernel, abc set)
     bool checks_left = false;                   // the run (being) made leaves the CHECK instructions to zkpor_solver_eval_abc_dev (abc set, solver_defer_checks)
     uint64_t n_check = 0;
+    uint32_t* d_long = nullptr;                 // [0] count, [1..] the long constraints of the level being run (k_solve_long)
     uint32_t* d_gen_cnt_all = nullptr;          // generic + CHECK instructions per level (d_gen_cnt: generic only)
     uint32_t* d_perr = nullptr;                 // error words of a prefetch (its kernels run beside another run's)
     uint8_t* d_ones = nullptr;                  // n_wires bytes of 1: the `known` flags a prefetch reads (it only reads inputs)
@@ -91,7 +92,7 @@ namespace zk {
 static constexpr u32 NARROW = 512, EXT_CAP = 4096;
 static constexpr int BATCH_K = 4;                 // instructions per thread of the batched level kernel
 static constexpr u64 CHAIN_FROM = 16;             // runs of this many one-instruction levels go to k_solve_chain ("solver_chain" 0: never)
-static constexpr u32 BATCH_TREE_FROM = 1024;      // levels from this many generic instructions on: the divisions of a workgroup share one inversion
+static constexpr u32 LONG_CAP = 1u << 20;         // constraints per level a wave each takes over (k_solve_long): beyond it they stay in their thread
 
 ZK_D void solver_step(const SolverProg& P, u32 ins, Fr* w, uint8_t* known, u32* err, u32* ext) {
     // an external hint is not executed: it is reported, its outputs stay unknown until the caller provides them
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void k_solve_level(SolverProg P, const u32* __
 // A workgroup without a division leaves before the tree.
 template <int KB>
 __global__ __launch_bounds__(256) void k_solve_level_batched(SolverProg P, const u32* __restrict__ level_instr, u64 lo, u32 n, u32 stride, Fr* w, uint8_t* known,
-                                                             u32* err, u32* ext) {
+                                                             u32* err, u32* ext, u32* long_cnt, u32* long_list, u32 long_from) {
     __shared__ Fr tree[512];                      // node i: the product of its leaves; children 2 i and 2 i + 1, leaves 256 ..
     const u32 tid = threadIdx.x, t = blockIdx.x * 256u + tid;
     SiPending pd[KB];
@@ -138,6 +139,14 @@ __global__ __launch_bounds__(256) void k_solve_level_batched(SolverProg P, const
                 const u32 slot = atomicAdd(&err[3], 1u);
                 if (slot < EXT_CAP) ext[slot] = ins;
                 continue;
+            }
+            if (long_list && P.kind[ins] == SI_R1C && P.arg[ins] < P.n_constraints) {   // a long constraint: one thread would walk its terms alone
+                const u32 row = P.arg[ins];
+                const u64 nt = (P.row_ptr[0][row + 1] - P.row_ptr[0][row]) + (P.row_ptr[1][row + 1] - P.row_ptr[1][row]) + (P.row_ptr[2][row + 1] - P.row_ptr[2][row]);
+                if (nt > (u64)long_from) {
+                    const u32 slot = atomicAdd(long_cnt, 1u);
+                    if (slot < LONG_CAP) { long_list[slot] = ins; continue; }
+                }
             }
             const int rc = solve_instr(P, ins, w, known, &pd[np]);
             if (rc == SE_DEFERRED) ++np;
@@ -174,6 +183,56 @@ __global__ __launch_bounds__(256) void k_solve_level_batched(SolverProg P, const
         inv = Fr::mul(inv, pd[j].den);
         w[pd[j].wire] = Fr::mul(pd[j].num, dinv);
         known[pd[j].wire] = 1;
+    }
+}
+
+// the constraints k_solve_level_batched left aside (more than `solver_long` terms, 256 by default: the sums behind the log-derivative arguments are 1 024 terms
+// each, 18 000 of them in two levels — 9.6 ms as one thread's walk each): a wave per constraint, lane l takes terms l, l + 64, ..., the known
+// parts of L, R, O and what the lanes saw of the open wire meet through shuffles, lane 0 finishes as solve_instr would
+__global__ __launch_bounds__(256) void k_solve_long(SolverProg P, const u32* __restrict__ long_cnt, const u32* __restrict__ long_list, Fr* w, uint8_t* known, u32* err) {
+    const u32 n = min(long_cnt[0], LONG_CAP);
+    const u32 lane = threadIdx.x & 63u, nwaves = gridDim.x * 4u;
+    for (u32 i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += nwaves) {
+        const u32 ins = long_list[i], row = P.arg[ins];
+        Fr v[3], uc = Fr::zero();
+        int which = -1;
+        u32 x = 0, two = 0;
+        for (int m = 0; m < 3; ++m) {
+            Fr acc = Fr::zero();
+            for (u64 t = P.row_ptr[m][row] + lane; t < P.row_ptr[m][row + 1]; t += 64u) {
+                const u32 wi = P.wid[m][t], ci = P.cid[m][t];
+                if (known[wi]) si_add_term(acc, P.ckind[ci], P.coeff, ci, w[wi]);
+                else {
+                    if (which >= 0 && (which != m || x != wi)) two = 1u;
+                    uc = which < 0 ? P.coeff[ci] : Fr::add(uc, P.coeff[ci]);
+                    which = m; x = wi;
+                }
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                Fr o;
+                for (int k = 0; k < 8; ++k) o.v[k] = (u32)__shfl_down((int)acc.v[k], off, 64);
+                acc = Fr::add(acc, o);
+            }
+            v[m] = acc;
+        }
+        for (int off = 32; off >= 1; off >>= 1) {     // the open wire as the lanes saw it: one wire, its coefficients summed
+            const int ow = __shfl_down(which, off, 64);
+            const u32 ox = (u32)__shfl_down((int)x, off, 64), ot = (u32)__shfl_down((int)two, off, 64);
+            Fr ouc;
+            for (int k = 0; k < 8; ++k) ouc.v[k] = (u32)__shfl_down((int)uc.v[k], off, 64);
+            if (lane + (u32)off < 64u) {
+                two |= ot;
+                if (ow >= 0) {
+                    if (which >= 0 && (which != ow || x != ox)) two = 1u;
+                    uc = which < 0 ? ouc : Fr::add(uc, ouc);
+                    which = ow; x = ox;
+                }
+            }
+        }
+        if (lane == 0) {
+            const int rc = two ? (int)SE_TWO_UNKNOWN : si_r1c_finish(v, which, x, uc, w, known, nullptr);
+            if (rc != SE_OK && atomicCAS(&err[0], 0u, (u32)rc) == 0u) err[1] = ins;
+        }
     }
 }
 
@@ -435,7 +494,7 @@ static SolverProg prog_of(const zkpor_solver* s) {
     return P;
 }
 static void solver_free(zkpor_solver* s) {
-    void* ptrs[] = {s->d_rows, s->d_perr, s->d_ones, s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_gen_cnt_all, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
+    void* ptrs[] = {s->d_rows, s->d_perr, s->d_ones, s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_gen_cnt_all, s->d_long, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
                     s->d_cnt, s->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (s->side) (void)hipStreamDestroy(s->side);
@@ -539,13 +598,17 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                 s->side_busy = true;
                 ++s->launches;
             }
-            if ((int64_t)ng >= ctx->solver_batch_from) {              // enough instructions to fill the chip several per thread: divisions share an inversion
-                const u32 stride = (ng + BATCH_K - 1) / BATCH_K;
-                hipLaunchKernelGGL(k_solve_level_batched<BATCH_K>, dim3((stride + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, ng, stride, w, s->known, s->d_err, s->d_ext);
+            if ((int64_t)ng >= ctx->solver_tree_from) {
+                u32* lc = ctx->solver_long ? s->d_long : nullptr;     // long constraints go to a wave each, behind the level's launch
+                if (lc) ZK_HIP(ctx, hipMemsetAsync(lc, 0, 4, ctx->stream));
+                if ((int64_t)ng >= ctx->solver_batch_from) {          // enough instructions to fill the chip several per thread: divisions share an inversion
+                    const u32 stride = (ng + BATCH_K - 1) / BATCH_K;
+                    hipLaunchKernelGGL(k_solve_level_batched<BATCH_K>, dim3((stride + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, ng, stride, w, s->known, s->d_err, s->d_ext, lc, lc ? lc + 1 : nullptr, (u32)ctx->solver_long);
+                } else {                                              // one instruction per thread, one inversion per workgroup
+                    hipLaunchKernelGGL(k_solve_level_batched<1>, dim3((ng + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, ng, ng, w, s->known, s->d_err, s->d_ext, lc, lc ? lc + 1 : nullptr, (u32)ctx->solver_long);
+                }
                 ++s->launches;
-            } else if (ng >= BATCH_TREE_FROM) {                       // one instruction per thread, one inversion per workgroup
-                hipLaunchKernelGGL(k_solve_level_batched<1>, dim3((ng + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, ng, ng, w, s->known, s->d_err, s->d_ext);
-                ++s->launches;
+                if (lc) { hipLaunchKernelGGL(k_solve_long, dim3(512), dim3(256), 0, ctx->stream, P, (const u32*)lc, (const u32*)(lc + 1), w, s->known, s->d_err); ++s->launches; }
             } else if (ng) {
                 hipLaunchKernelGGL(k_solve_level, dim3((ng + 255u) / 256u), dim3(256), 0, ctx->stream, P, s->d_level_instr, L.lo, ng, w, s->known, s->d_err, s->d_ext);
                 ++s->launches;
@@ -775,7 +838,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
               up((void**)&s->d_gen_lo, gen_lo.data(), v.n_levels * 8) && up((void**)&s->d_gen_cnt, gen_cnt.data(), v.n_levels * 4) && up((void**)&s->d_gen_cnt_all, gen_cnt_all.data(), v.n_levels * 4) &&
               up((void**)&s->d_rows, row_bits.data(), row_bits.size() * 4) && up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up(&s->d_cmeta, cmeta.data(), cmeta.size() * sizeof(CountDev)) && up((void**)&s->d_pre_off, pre_off_host.data(), pre_off_host.size() * 4) &&
               hipMalloc((void**)&s->d_pre, (pre_total ? pre_total : 1) * sizeof(Fr)) == hipSuccess && up((void**)&s->d_hint_kind, s->hint_kind.data(), s->hint_kind.size()) &&
-              hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 32) == hipSuccess &&
+              hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 32) == hipSuccess && hipMalloc((void**)&s->d_long, (size_t)(LONG_CAP + 1u) * 4) == hipSuccess &&
               hipMalloc((void**)&s->d_ext, EXT_CAP * sizeof(u32)) == hipSuccess && hipMalloc((void**)&s->d_cnt, max_table * sizeof(u32)) == hipSuccess &&
               hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess;

@@ -7,7 +7,7 @@
 //         --zkpor_solver_external_inputs_dev--> the committed wires, still on the device --zkpor_commit_dev--> (commitment, knowledge proof)
 //         challenge = hash_to_field(commitment.Marshal() | hashed wires)   (bsb22_challenge.hpp: gnark's prove.go hashing)
 //         --zkpor_solver_external_outputs--> the hint's output wire;  --zkpor_solver_resume_dev--> the rest of the program
-//     --zkpor_r1cs_eval_dev--> a, b, c   --zkpor_prove_tail_dev--> Ar, Bs, Krs
+//     --zkpor_solver_eval_abc_dev--> a, b, c (+ a x b = c on every row)   --zkpor_prove_tail_dev--> Ar, Bs, Krs
 //
 // The solver callback of prove_batch.hpp (gnark's solver, host memory) is not needed on this path.  C++ because the build image has no Go.
 #pragma once
@@ -68,6 +68,8 @@ inline int ProveOnDevice(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, zkpor_s
     if (bufs->Reserve(ctx, n_wires, domain) != 0) return fail("device buffers");
     if (zkpor_dev_upload(ctx, bufs->w, inputs, n_inputs * 32) != ZKPOR_OK) return fail("upload");
     uint32_t paused = 0xffffffffu;
+    // a, b, c named before the run: the Poseidon instructions write their own rows, the assertions are left to eval_abc's a x b = c pass (include/zkpor.h)
+    if (zkpor_solver_set_abc_dev(solver, bufs->abc[0], bufs->abc[1], bufs->abc[2]) != ZKPOR_OK) return fail("a, b, c buffers");
     if (zkpor_solver_start_dev(solver, bufs->w, n_inputs, nullptr, &paused) != ZKPOR_OK) return fail("solve");
     while (paused != 0xffffffffu) {
         size_t n_in = 0, n_out = 0;
@@ -101,7 +103,7 @@ inline int ProveOnDevice(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, zkpor_s
         if (zkpor_solver_external_outputs(solver, paused, chm.v, 1) != ZKPOR_OK) return fail("solve");
         if (zkpor_solver_resume_dev(solver, &paused) != ZKPOR_OK) return fail("solve");
     }
-    if (zkpor_r1cs_eval_dev(r1cs, bufs->w, bufs->abc[0], bufs->abc[1], bufs->abc[2], domain) != ZKPOR_OK) return fail("constraint evaluation");
+    if (zkpor_solver_eval_abc_dev(solver, bufs->w, bufs->abc[0], bufs->abc[1], bufs->abc[2], domain) != ZKPOR_OK) return fail("constraint evaluation");   // and every row's a x b = c
     if (zkpor_prove_tail_dev(ctx, pk, bufs->w, bufs->abc[0], bufs->abc[1], bufs->abc[2], r, s, out->proof) != ZKPOR_OK) return fail("prove");
     return 0;
 }
