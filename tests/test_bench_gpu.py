@@ -58,8 +58,8 @@ def test_bench_line_small_domain():
     assert hr["input_values"] == 1 + 5 + 114 * 500 + 1380 * (7 * 50 + 5 * 500 + 30) and hr["host_core_seconds_per_proof"] > 0 and hr["host_cores_per_gpu_at_this_rate"] > 0
     de = d["solver_budget"]["device_executor_measured"]     # the same program on the device (zkpor_solver_*), a wide and a deep shape
     for shape in ("users_side_by_side", "users_chained"):
-        assert de[shape]["wire_vector_equals_builder"] is True and de[shape]["instructions_per_s"] > 0 and de[shape]["launches"] <= de[shape]["levels"]
-    assert de["users_side_by_side"]["launches"] == 12 and de["users_chained"]["levels"] > 4000 and de["users_chained"]["launches"] < 20
+        assert de[shape]["wire_vector_equals_builder"] is True and de[shape]["instructions_per_s"] > 0 and de[shape]["launches"] <= 2 * de[shape]["levels"]
+    assert de["users_side_by_side"]["launches"] == 24 and de["users_chained"]["levels"] > 4000 and de["users_chained"]["launches"] < 20
 
 
 def test_bench_other_tier_and_timed_only():

@@ -40,6 +40,7 @@ def test_wire_vector_equals_the_builders(zk, seed, users, chain):
         assert (st["constraint_instructions"], st["hint_instructions"], st["skipped"]) == (len(b.instr) - n_hint, n_hint, 0)
         widths = [len(l) for l in b.levels()]
         runs = sum(1 for i, n in enumerate(widths) if n > 512 or i == 0 or widths[i - 1] > 512)    # a launch per wide level, one per run of narrow ones
+        runs += sum(1 for n in widths if n >= 1024)       # + the wave kernel for long constraints behind every level of `solver_tree_from` instructions and more
         assert st["launches"] == runs
         a, bb, c = r.eval(w)                         # the device's own a, b, c of the solved vector
         dw = [zk.alloc(a.nbytes).upload(x) for x in (a, bb)]
