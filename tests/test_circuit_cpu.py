@@ -158,3 +158,32 @@ def test_assertions_are_flagged_check_in_the_container():
         assert flagged.sum() >= c.census["assert"] and flagged.sum() > 0.1 * c.n_instructions, (int(flagged.sum()), n_assert)
     finally:
         c.close()
+
+
+def test_the_check_flag_is_validated_and_changes_nothing_for_the_host_executor():
+    """bit 8 of a kind word is legal on a constraint instruction of a version-2 container only; any other high bit, or the flag on a hint /
+    lookup / Poseidon instruction, is a malformed container.  The host executor runs flagged instructions as the assertions they are
+    (a tampered root is refused by it, above)"""
+    import ctypes
+    L = C.host_lib()
+    c = C.Circuit(3, 6, 2)
+    try:
+        sv = bytes(c.solver_container())
+        raw = np.frombuffer(sv, dtype=np.uint8)
+        n_names = int(np.frombuffer(raw[24:32].tobytes(), dtype=np.uint64)[0])
+        off = 40
+        for _ in range(n_names):
+            off += 4 + int(np.frombuffer(raw[off:off + 4].tobytes(), dtype=np.uint32)[0])
+        off += (8 - off % 8) % 8
+        kinds = np.frombuffer(raw[off:off + 4 * c.n_instructions].tobytes(), dtype=np.uint32)
+        counts = (ctypes.c_uint64 * 4)(); err = ctypes.create_string_buffer(200)
+        parse = lambda b: L.zkh_solver_parse(b, ctypes.c_size_t(len(b)), counts, err, ctypes.c_size_t(200))
+        assert parse(sv) == 0
+        def with_kind(i, k):
+            m = bytearray(sv); m[off + 4 * i: off + 4 * i + 4] = int(k).to_bytes(4, "little"); return bytes(m)
+        a_check = int(np.nonzero((kinds & 0x100) != 0)[0][0]); a_hint = int(np.nonzero(kinds == 1)[0][0]); a_pos = int(np.nonzero(kinds == 4)[0][0])
+        assert parse(with_kind(a_check, 0)) == 0                                   # the flag is optional
+        for i, k in ((a_hint, 0x101), (a_pos, 0x104), (a_check, 0x200), (a_check, 0x10100), (a_check, 0x105)):
+            assert parse(with_kind(i, k)) != 0 and b"instruction kind" in err.value
+    finally:
+        c.close()
