@@ -95,6 +95,23 @@ def test_one_inversion_per_workgroup_and_long_constraints_by_waves_change_no_wir
         zk.set_param("solver_tree_from", 1024); zk.set_param("solver_batch_from", 1 << 21); zk.set_param("solver_long", 256)
 
 
+def test_the_long_call_beside_the_independent_levels_changes_no_wire(zk):
+    """the RLC challenge's sponge carries a join level (host/circuit/frontend.hpp poseidon(async = 2), solver_file.hpp POSEIDON_JOIN_SHIFT): the
+    executor starts it on a side stream at its level and joins it in front of its first consumer; the levels in between (Merkle paths, hints,
+    the big count hint) do not read it.  `solver_beside` 0 runs it in place.  Same wires both ways (prove_once compares with the interpreter)"""
+    cir = C.Circuit(5, 20, 6)
+    try:
+        assert cir.census["levels_beside_the_long_call"] >= 28            # at least the Merkle levels
+    finally:
+        cir.close()
+    try:
+        for beside in (1, 0):
+            zk.set_param("solver_beside", beside)
+            prove_once(zk, (5, 20, 6), 1, reps=2)
+    finally:
+        zk.set_param("solver_beside", 1)
+
+
 def test_the_500_asset_tier_shape(zk):
     """T = all assets (the zkpor500 shape: every slot of the user's list is a real CEX asset): sponges of 1000 / 3000 elements"""
     prove_once(zk, (30, 30, 2), 1)

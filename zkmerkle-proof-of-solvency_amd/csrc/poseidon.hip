@@ -794,9 +794,12 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
 #endif
 // one wave per workgroup, four calls per wave
 __global__ __launch_bounds__(64) void k_gadget_poseidon_coop(SolverProg P, const u32* __restrict__ instr, u32 n, Fr* w, uint8_t* known, u32* err, PosDev D,
-                                                            const Fr* __restrict__ pre, const u32* __restrict__ pre_off, Fr* ra, Fr* rb, Fr* rc) {
+                                                            const Fr* __restrict__ pre, const u32* __restrict__ pre_off, Fr* ra, Fr* rb, Fr* rc, int urgent) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using namespace coop;
+    // a launch of a handful of calls is somebody's critical path (the challenge sponge beside the Merkle levels, the CEX chains under the prove
+    // tail): its waves take the issue slots of their SIMD first — measured without it: 40 ms alone, 51 ms beside other levels
+    if (urgent) __builtin_amdgcn_s_setprio(3);
     __shared__ u32 xch[4 * XS], stash[4 * XS];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, base_lane = lane & ~15;
     const u32 call = blockIdx.x * 4u + g;
@@ -1166,7 +1169,7 @@ int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverP
     PosDev D;
     ZK_TRY(pos_dev(ctx, &D));
     if (ctx->solver_poseidon == 0) hipLaunchKernelGGL(k_gadget_poseidon, dim3((n + 63u) / 64u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off);
-    else hipLaunchKernelGGL(k_gadget_poseidon_coop, dim3((n + 3u) / 4u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off, d_a, d_b, d_c);
+    else hipLaunchKernelGGL(k_gadget_poseidon_coop, dim3((n + 3u) / 4u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off, d_a, d_b, d_c, n <= 64u ? 1 : 0);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }

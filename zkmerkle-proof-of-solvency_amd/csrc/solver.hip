@@ -30,6 +30,9 @@ int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverP
 namespace {
 struct LevelPlan {          // one level of the reordered instruction list: [generic | poseidon | poseidon async | count]
     uint64_t lo = 0;
+    uint32_t n_posj = 0;                         // ASYNC Poseidon calls with a join level (solver_file.hpp POSEIDON_JOIN_SHIFT): listed behind the ASYNC ones
+    uint32_t n_posj_seen = 0;
+    uint64_t join_level = 0;                     // ... the lowest of theirs: the level the side stream is joined in front of
     uint32_t n_chk = 0;                          // CHECK instructions (assertions), listed right behind the generic ones: left out when the caller checks every row itself
     uint32_t n_gen = 0, n_pos = 0, n_posa = 0, n_cnt = 0, cnt_first = 0;   // the level's count hints are counts[cnt_first .. + n_cnt)
     uint32_t posa_first = 0;                                               // its ASYNC calls are asyncs[posa_first .. + n_posa), in list order
@@ -78,6 +81,10 @@ struct zkpor_solver {
     void* prefetched_w = nullptr;               // the wire vector whose ASYNC instructions are already running / done on the side stream
     bool skip_async = false;                    // this run consumes a prefetch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side2 = nullptr;                // calls with a join level (they must not queue behind the ASYNC chains of `side`)
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    bool side2_busy = false;
+    uint64_t join2_level = 0;
     uint64_t n_r1c = 0, n_hint = 0, n_skip = 0, n_lookup = 0, n_poseidon = 0;
     // run state (pause / resume)
     bool running = false, side_busy = false;
@@ -498,6 +505,9 @@ static void solver_free(zkpor_solver* s) {
                     s->d_cnt, s->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->side2) (void)hipStreamDestroy(s->side2);
+    if (s->ev_fork2) (void)hipEventDestroy(s->ev_fork2);
+    if (s->ev_join2) (void)hipEventDestroy(s->ev_join2);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     delete s;
@@ -530,6 +540,13 @@ static int32_t tmp_reserve(zkpor_solver* s, size_t elems) {
     return ZKPOR_OK;
 }
 
+static int32_t join_side2(zkpor_solver* s) {
+    if (!s->side2_busy) return ZKPOR_OK;
+    ZK_HIP(s->ctx, hipEventRecord(s->ev_join2, s->side2));
+    ZK_HIP(s->ctx, hipStreamWaitEvent(s->ctx->stream, s->ev_join2, 0));
+    s->side2_busy = false;
+    return ZKPOR_OK;
+}
 static int32_t join_side(zkpor_solver* s) {
     if (!s->side_busy) return ZKPOR_OK;
     ZK_HIP(s->ctx, hipEventRecord(s->ev_join, s->side));
@@ -554,14 +571,16 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
             const u64 l = s->next_level;
             const LevelPlan& L = s->plan[l];
             if (l + 1 == n_levels) ZK_TRY(join_side(s));          // ASYNC outputs are read by the last level only (the container's promise)
+            if (s->side2_busy && l >= s->join2_level) ZK_TRY(join_side2(s));   // ... those of a call with a join level from that level on
+            const u64 stop_at = s->side2_busy ? s->join2_level : n_levels;      // a run of levels does not reach across the join
             // the generic instructions this run executes: the CHECK ones (assertions) only when nobody checks the rows afterwards
             auto G = [&](const LevelPlan& M) { return M.n_gen + (s->checks_left ? 0u : M.n_chk); };
             const u32* gen_cnt = s->checks_left ? s->d_gen_cnt : s->d_gen_cnt_all;
             const u32 ng = G(L);
-            const bool only_narrow = L.n_pos == 0 && L.n_posa == 0 && L.n_cnt == 0 && ng <= NARROW;
+            const bool only_narrow = L.n_pos == 0 && L.n_posa == 0 && L.n_posj == 0 && L.n_cnt == 0 && ng <= NARROW;
             if (only_narrow) {
                 // a chain — CHAIN_FROM or more levels of ONE generic instruction each, none of them external or the last — has its own kernel
-                auto one = [&](u64 q) { const LevelPlan& M = s->plan[q]; return q + 1 < n_levels && !M.n_pos && !M.n_posa && !M.n_cnt && G(M) == 1 && M.n_gen == 1 && !M.external; };
+                auto one = [&](u64 q) { const LevelPlan& M = s->plan[q]; return q + 1 < n_levels && q < stop_at && !M.n_pos && !M.n_posa && !M.n_posj && !M.n_cnt && G(M) == 1 && M.n_gen == 1 && !M.external; };
                 auto chain_end = [&](u64 q) { while (q < n_levels && one(q)) ++q; return q; };
                 if (ctx->solver_chain && one(l)) {
                     const u64 e = chain_end(l);
@@ -575,7 +594,7 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                 u64 l1 = l;                       // the run of narrow levels starting here, ended by (and including) a level with external hints
                 while (l1 < n_levels) {
                     const LevelPlan& M = s->plan[l1];
-                    if (M.n_pos || M.n_posa || M.n_cnt || G(M) > NARROW) break;
+                    if (M.n_pos || M.n_posa || M.n_posj || M.n_cnt || G(M) > NARROW || l1 >= stop_at) break;
                     if (l1 + 1 == n_levels && l1 != l && s->side_busy) break;   // the last level starts its own launch, behind the join
                     if (ctx->solver_chain && l1 != l && one(l1) && chain_end(l1) - l1 >= CHAIN_FROM) break;   // a chain starts here
                     ++l1;
@@ -596,6 +615,16 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
                 }
                 ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_chk + L.n_pos, L.n_posa, w, s->known, s->d_err, s->d_pre, s->d_pre_off + L.posa_first, nullptr, nullptr, nullptr));
                 s->side_busy = true;
+                ++s->launches;
+            }
+            if (L.n_posj) {   // calls other levels run beside (the RLC challenge's 116-permutation sponge): on their own side stream, joined in front of their first consumer
+                const u32* lst = s->d_level_instr + L.lo + L.n_gen + L.n_chk + L.n_pos + L.n_posa;
+                if (ctx->solver_beside && !s->side2_busy) {
+                    ZK_HIP(ctx, hipEventRecord(s->ev_fork2, ctx->stream));
+                    ZK_HIP(ctx, hipStreamWaitEvent(s->side2, s->ev_fork2, 0));
+                    ZK_TRY(gadget_poseidon_launch(ctx, s->side2, P, lst, L.n_posj, w, s->known, s->d_err, nullptr, nullptr, nullptr, nullptr, nullptr));
+                    s->side2_busy = true; s->join2_level = L.join_level;
+                } else ZK_TRY(gadget_poseidon_launch(ctx, ctx->stream, P, lst, L.n_posj, w, s->known, s->d_err, nullptr, nullptr, nullptr, nullptr, nullptr));   // in place: an ordinary call
                 ++s->launches;
             }
             if ((int64_t)ng >= ctx->solver_tree_from) {
@@ -635,6 +664,7 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
     const bool finished = s->next_level >= n_levels;
     if (finished) {
         ZK_TRY(join_side(s));
+        ZK_TRY(join_side2(s));
         // counted afresh every time the end is reached: a run that paused in its LAST level has been here before, with the hint's outputs still open
         ZK_HIP(ctx, hipMemsetAsync(s->d_err + 2, 0, sizeof(u32), ctx->stream));
         hipLaunchKernelGGL(k_count_unknown, dim3((unsigned)((s->r1cs->n_wires + 255) / 256)), dim3(256), 0, ctx->stream, s->known, s->r1cs->n_wires, s->d_err);
@@ -648,6 +678,7 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
     if (h[0]) {
         s->running = false;
         if (s->side_busy) { (void)hipStreamSynchronize(s->side); s->side_busy = false; }
+        if (s->side2_busy) { (void)hipStreamSynchronize(s->side2); s->side2_busy = false; }
         ctx->err = std::string("solver: ") + solver_error_text(h[0]) + " at instruction " + std::to_string(h[1]);
         return ZKPOR_E_STATE;
     }
@@ -697,7 +728,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     // and sort every instruction into its class
     s->hint_kind.resize(v.hint_names.size());
     for (size_t i = 0; i < v.hint_names.size(); ++i) s->hint_kind[i] = hint_kind_of_name(v.hint_names[i].c_str());
-    enum : uint8_t { CL_GEN = 0, CL_CHK = 1, CL_POS = 2, CL_POSA = 3, CL_CNT = 4 };
+    enum : uint8_t { CL_GEN = 0, CL_CHK = 1, CL_POS = 2, CL_POSA = 3, CL_POSJ = 4, CL_CNT = 5 };
     std::vector<uint8_t> cls(v.n_instructions, CL_GEN), external(v.n_instructions, 0);
     std::vector<uint32_t> kinds(v.n_instructions);
     std::set<std::pair<uint32_t, uint32_t>> tables_ok;   // (block, nbEntries) already validated: a table's entries are checked once, not per lookup
@@ -744,7 +775,10 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
             ++s->n_lookup;
         } else if (kind == SI_POSEIDON) {
             if (!zkpor_host::CheckPoseidonShape(v, arg, nw, ncoef)) return bad("the call data of Poseidon instruction " + std::to_string(i) + " is malformed");
-            cls[i] = (v.calldata[arg + 3] & zkpor_host::POSEIDON_ASYNC) ? CL_POSA : CL_POS;
+            {
+                const uint32_t fl = v.calldata[arg + 3];
+                cls[i] = !(fl & zkpor_host::POSEIDON_ASYNC) ? CL_POS : ((fl >> zkpor_host::POSEIDON_JOIN_SHIFT) ? CL_POSJ : CL_POSA);
+            }
             {
                 const uint64_t row0 = v.calldata[arg + 4], nrows = v.calldata[arg + 2];
                 if (row0 != 0xffffffffull) {
@@ -812,8 +846,13 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
                 if (external[ins]) L.external = true;
                 if (c == CL_CNT) s->counts.push_back(big[ins]);
                 if (c == CL_POSA) { s->asyncs.push_back(big[ins]); pre_off_host.push_back((uint32_t)big[ins].nb_q); }
+                if (c == CL_POSJ) {
+                    const uint64_t j = (uint64_t)(v.calldata[v.arg[ins] + 3] >> zkpor_host::POSEIDON_JOIN_SHIFT) - 1;
+                    if (j <= l || j >= v.n_levels) return bad("Poseidon instruction " + std::to_string(ins) + " names a join level outside (its own level, the last level]");
+                    L.join_level = L.n_posj_seen++ ? std::min(L.join_level, j) : j;
+                }
             }
-            if (c == CL_GEN) L.n_gen = n; else if (c == CL_CHK) L.n_chk = n; else if (c == CL_POS) L.n_pos = n; else if (c == CL_POSA) { L.n_posa = n; L.posa_first = (uint32_t)(s->asyncs.size() - n); } else { L.n_cnt = n; L.cnt_first = (uint32_t)(s->counts.size() - n); }
+            if (c == CL_GEN) L.n_gen = n; else if (c == CL_CHK) L.n_chk = n; else if (c == CL_POS) L.n_pos = n; else if (c == CL_POSA) { L.n_posa = n; L.posa_first = (uint32_t)(s->asyncs.size() - n); } else if (c == CL_POSJ) L.n_posj = n; else { L.n_cnt = n; L.cnt_first = (uint32_t)(s->counts.size() - n); }
         }
         for (uint32_t k = 0; k < L.n_cnt; ++k) {
             const BigHint& c = s->counts[L.cnt_first + k];
@@ -827,6 +866,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
         max_table = std::max<uint64_t>(max_table, L.cnt_rows);
         gen_lo[l] = L.lo; gen_cnt[l] = L.n_gen; gen_cnt_all[l] = L.n_gen + L.n_chk;
         if (L.n_posa && l + 1 >= v.n_levels) return bad("an ASYNC instruction in the last level");
+        if (L.n_posj && L.external) return bad("a Poseidon call with a join level in a level with external hints");
     }
     for (auto& kv : big) if (external[kv.first]) s->externals[kv.first] = kv.second;
     auto up = [&](void** d, const void* h, size_t bytes) {
@@ -841,7 +881,8 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
               hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 32) == hipSuccess && hipMalloc((void**)&s->d_long, (size_t)(LONG_CAP + 1u) * 4) == hipSuccess &&
               hipMalloc((void**)&s->d_ext, EXT_CAP * sizeof(u32)) == hipSuccess && hipMalloc((void**)&s->d_cnt, max_table * sizeof(u32)) == hipSuccess &&
               hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess && hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_fork2, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->ev_join2, hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); solver_free(s); ctx->err = "solver: out of device memory"; return ZKPOR_E_OOM; }
     *out = s;
     return ZKPOR_OK;
@@ -852,6 +893,7 @@ void zkpor_solver_destroy(zkpor_solver* s) {
     if (!s) return;
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->side) (void)hipStreamSynchronize(s->side);
+    if (s->side2) (void)hipStreamSynchronize(s->side2);
     solver_free(s);
 }
 
@@ -872,6 +914,7 @@ int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint
     if (n_inputs == 0 || n_inputs > s->r1cs->n_wires) { ctx->err = "solver: the assignment must hold 1 + nPublic + nSecret elements"; return ZKPOR_E_ARG; }
     s->skip_async = s->prefetched_w != nullptr && s->prefetched_w == d_w;
     if (s->side_busy && !s->skip_async) { (void)hipStreamSynchronize(s->side); s->side_busy = false; }   // an abandoned run, or a prefetch for another vector
+    if (s->side2_busy) { (void)hipStreamSynchronize(s->side2); s->side2_busy = false; }
     s->prefetched_w = nullptr;
     s->d_w = d_w;
     s->known = d_known_or_null ? d_known_or_null : s->d_known;

@@ -341,7 +341,7 @@ inline void DefineBatchCreateUser(Builder& api, const CircuitShape& S) {
 
     // make sure user assets contains all non-zero assets of AssetsForUpdateCex: random linear combination
     userAssetIdHashes[U] = BatchCommitment;
-    const LE randomChallenge = api.poseidon(userAssetIdHashes);
+    const LE randomChallenge = api.poseidon(userAssetIdHashes, /*async=*/api.beside() ? 2 : 0);     // 116 permutations in a row: everything that does not need the challenge runs beside it
     std::vector<LE> powersOfRandomChallenge(5 * (size_t)nCex);
     powersOfRandomChallenge[0] = randomChallenge;
     const int powersOfRandomChallengeLookupTable = api.new_table();

@@ -363,7 +363,10 @@ public:
     // product wires (x^2, x^4, x^5), round constants and the MDS layer are linear and fold into the next S-box's input expression
     // async: the call is a long serial chain whose result only feeds assertions (the CEX commitments): the executors may run it beside
     // everything else; assertions that read its wires are scheduled in the last level
-    LE poseidon(const std::vector<LE>& inputs, bool async = false, int out_idx = 1, int carry_idx = 0);
+    // async 1: the digest only feeds the last level (the CEX commitments); async 2: a long call other work can run BESIDE — the instructions that
+    // do not depend on its digest keep their as-soon-as-possible levels, everything downstream of it moves behind them, and the call carries
+    // the level it must be complete in front of (solver_file.hpp POSEIDON_JOIN_SHIFT): the RLC challenge's 116-permutation sponge
+    LE poseidon(const std::vector<LE>& inputs, int async = 0, int out_idx = 1, int carry_idx = 0);
 
     // ---- logderivlookup (gnark std/lookup/logderivlookup, 3P)
     int new_table() { tables_.emplace_back(); return (int)tables_.size() - 1; }
@@ -382,6 +385,8 @@ public:
     void set_commitment_value(const FrH& v) { commitment_value_ = v; }
     // level assignment of finish(): true (default) = as late as possible, false = gnark's as-soon-as-possible levels
     void set_alap(bool on) { alap_ = on; }
+    void set_beside(bool on) { beside_ = on; }      // async 2 calls (poseidon()): off = ordinary calls at their level
+    bool beside() const { return beside_ && alap_ && poseidon_native_; }
     void finalize_commitments();
     Compiled finish();
 
@@ -413,11 +418,12 @@ private:
     std::vector<u32> deferred_asserts_;
     std::vector<u32> check_;                    // the R1C instructions without an unknown wire, in program order
     std::vector<std::pair<u32, u32>> async_instrs_;   // (instruction, its as-soon-as-possible level)
+    std::vector<u32> beside_instrs_;                  // async 2 calls
     PermTemplate tmpl_[zkpor_host::kPosMaxT + 1];
     std::vector<u32> committed_;
     u32 commitment_wire_ = NO_WIRE;
     u32 max_level_ = 0;
-    bool alap_ = true;
+    bool alap_ = true, beside_ = true;
     u32 pow2_cid_[256];
     std::vector<u32> small_cid_;
     int rc_width_ = 0;
@@ -541,7 +547,7 @@ inline const PermTemplate& Builder::perm_template(int t) {
     return T;
 }
 
-inline LE Builder::poseidon(const std::vector<LE>& inputs, bool async, int out_idx, int carry_idx) {
+inline LE Builder::poseidon(const std::vector<LE>& inputs, int async, int out_idx, int carry_idx) {
     if (inputs.empty()) throw std::runtime_error("circuit: Poseidon of nothing");
     const size_t n = inputs.size();
     const size_t total_sbox = zkpor_host::PosSpongeSboxes(n);
@@ -560,11 +566,12 @@ inline LE Builder::poseidon(const std::vector<LE>& inputs, bool async, int out_i
         // call data = nIn, first output wire, number of output wires, out_idx | carry_idx << 8, the input expressions
         const u64 off = calldata_.size();
         calldata_.push_back((u32)n); calldata_.push_back(base); calldata_.push_back((u32)(3 * total_sbox));
-        calldata_.push_back((u32)out_idx | ((u32)carry_idx << 8) | ((async ? 1u : 0u) << 16));
+        calldata_.push_back((u32)out_idx | ((u32)carry_idx << 8) | ((async ? 1u : 0u) << 16));      // async 2: the join level is added in finish()
         calldata_.push_back((u32)n_constraints());      // its constraints follow as consecutive rows, three per S-box
         for (auto& e : inputs) push_le(e);
         for (size_t i = 0; i < 3 * total_sbox; ++i) producer_[base + i] = (u32)kind_.size();
-        if (async) async_instrs_.push_back({(u32)kind_.size(), lvl});
+        if (async == 1) async_instrs_.push_back({(u32)kind_.size(), lvl});
+        if (async == 2) beside_instrs_.push_back((u32)kind_.size());
         push_instr(K_POSEIDON, off, lvl);
     }
     // the constraints, permutation after permutation
@@ -605,7 +612,7 @@ inline LE Builder::poseidon(const std::vector<LE>& inputs, bool async, int out_i
         ++perm_count_[t];
     }
     ++cnt_[C_poseidon_call];
-    if (async && poseidon_native_) defer_assertions_reading(base, base + (u32)(3 * total_sbox));
+    if (async == 1 && poseidon_native_) defer_assertions_reading(base, base + (u32)(3 * total_sbox));
     return out;
 }
 
@@ -798,6 +805,7 @@ inline Compiled Builder::finish() {
     // over the 2 500 levels of the chain (1 + U instructions each: 2 500 launches), ALAP collects in one level behind it (the chain itself
     // becomes a run of one-instruction levels: one launch).  One reverse sweep: an instruction sits one level below its earliest consumer.
     if (alap_) {
+        const std::vector<u32> asap(level_);          // as recorded: gnark's levels
         std::vector<u32> alap(kind_.size(), max_level_);
         auto need = [&](u32 wire_id, u32 me, u32 my_level) {
             const u32 p = producer_[wire_id];
@@ -833,6 +841,72 @@ inline Compiled Builder::finish() {
         }
         for (size_t i = 0; i < kind_.size(); ++i) level_[i] = alap[i];
         for (auto& a : async_instrs_) level_[a.first] = a.second;     // a long chain that runs beside everything else starts as EARLY as it can
+        if (!beside_instrs_.empty() && poseidon_native_) {
+            // async 2.  X = everything downstream of those calls (one forward pass: program order is a topological order).  The rest keeps
+            // its EARLIEST level, X its LATEST, moved back far enough that the first consumer of a call stands behind all of the rest that
+            // comes after the call: an executor starts the call on a side stream at its level and joins it in front of that consumer — the
+            // independent levels in between (Merkle paths, range-check hints, the big count hint) run beside it.  Valid: an X instruction's
+            // producers outside X sit at or before their latest level, which is below its own; nothing outside X reads X.
+            std::vector<uint8_t> in_x(kind_.size(), 0);
+            for (u32 b : beside_instrs_) in_x[b] = 1;
+            auto from_x = [&](u32 wire_id) { const u32 p = producer_[wire_id]; return p != NO_WIRE && in_x[p]; };
+            auto le_from_x = [&](const u32* cd, u64& p) { const u32 nt = cd[p++]; bool r = false; for (u32 k = 0; k < nt; ++k) { r = r || from_x(cd[p + 1]); p += 2; } return r; };
+            std::unordered_map<u32, bool> table_x;                     // block -> some entry comes from X (decided at the table's first lookup: the entries are final by then)
+            for (size_t ii = 0; ii < kind_.size(); ++ii) {
+                const u32 i = (u32)ii;
+                if (in_x[i]) continue;
+                const u32* cd = calldata_.data() + arg_[i];
+                bool x = false;
+                if (kind_[i] == K_R1C) {
+                    for (int m = 0; m < 3 && !x; ++m) for (u64 t = row_ptr_[m][arg_[i]]; t < row_ptr_[m][arg_[i] + 1] && !x; ++t) { const u32 wd = wid_[m][t]; x = producer_[wd] != i && from_x(wd); }
+                } else if (kind_[i] == K_HINT) {
+                    u64 p = 3 + (u64)cd[2];
+                    for (u32 k = 0; k < cd[1] && !x; ++k) x = le_from_x(cd, p);
+                } else if (kind_[i] == K_LOOKUP) {
+                    auto it = table_x.find(cd[0]);
+                    if (it == table_x.end()) {
+                        const u32* tb = calldata_.data() + cd[0];
+                        bool tx = false;
+                        for (u32 e = 0; e < tb[0] && !tx; ++e) { u64 p = tb[1 + e]; tx = le_from_x(tb, p); }
+                        it = table_x.emplace(cd[0], tx).first;
+                    }
+                    x = it->second;
+                    u64 p = 4;
+                    for (u32 q = 0; q < cd[2] && !x; ++q) x = le_from_x(cd, p);
+                } else if (kind_[i] == K_POSEIDON) {
+                    u64 p = zkpor_host::POSEIDON_HDR;
+                    for (u32 k = 0; k < cd[0] && !x; ++k) x = le_from_x(cd, p);
+                }
+                in_x[i] = x ? 1 : 0;
+            }
+            std::vector<uint8_t> is_call(kind_.size(), 0), is_async1(kind_.size(), 0);
+            for (u32 b : beside_instrs_) is_call[b] = 1;
+            for (auto& a : async_instrs_) is_async1[a.first] = 1;
+            u32 call_level = 0xffffffffu, rest_max = 0, x_min = 0xffffffffu;
+            for (u32 b : beside_instrs_) call_level = std::min(call_level, asap[b]);
+            for (size_t i = 0; i < kind_.size(); ++i) {
+                if (is_call[i] || is_async1[i]) continue;
+                if (in_x[i]) x_min = std::min(x_min, alap[i]);
+                else if (asap[i] >= call_level) rest_max = std::max(rest_max, asap[i]);
+            }
+            const u32 shift = (x_min != 0xffffffffu && rest_max >= x_min) ? rest_max - x_min + 1 : 0;
+            u32 join = 0xffffffffu, top = 0;
+            for (size_t i = 0; i < kind_.size(); ++i) {
+                if (is_async1[i]) { top = std::max(top, level_[i]); continue; }
+                if (is_call[i]) level_[i] = asap[i];
+                else if (in_x[i]) { level_[i] = alap[i] + shift; join = std::min(join, level_[i]); }
+                else level_[i] = asap[i];
+                top = std::max(top, level_[i]);
+            }
+            max_level_ = top;
+            // the level a call must be complete in front of, as the executor counts levels (from 0), + 1 (0 = none); calls whose level does not
+            // fit the field stay ordinary calls at their level
+            for (u32 b : beside_instrs_) {
+                u32& flags = calldata_[arg_[b] + 3];
+                if (join != 0xffffffffu && join > level_[b] && join < (1u << 15)) flags |= (1u << 16) | (join << zkpor_host::POSEIDON_JOIN_SHIFT);   // level numbers start at 1 here: join = (join - 1) + 1
+            }
+            c.census["levels_beside_the_long_call"] = (join != 0xffffffffu && call_level != 0xffffffffu && join > call_level) ? join - call_level - 1 : 0;
+        }
         producer_.clear(); producer_.shrink_to_fit();
     }
     // levels: counting sort of the instructions by level; deferred assertions go behind everything else

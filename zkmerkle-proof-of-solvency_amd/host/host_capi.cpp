@@ -301,6 +301,7 @@ zkc_circuit* zkc_compile_batch_create_user(uint32_t user_assets, uint32_t all_as
         if (user_assets == 0 || users == 0 || user_assets > all_assets) { delete z; zkc_put_err(err, err_len, "bad shape"); return nullptr; }
         zkpor_circuit::Builder b(z->shape.n_public(), z->shape.n_secret(), (const FrH*)inputs_mont, poseidon_native != 0);
         if (commitment_mont) { FrH v; memcpy(v.v, commitment_mont, 32); b.set_commitment_value(v); }
+        if (const char* e = getenv("ZKPOR_CIRCUIT_BESIDE")) b.set_beside(atoi(e) != 0);   // experiments: 0 = the challenge sponge as an ordinary call
         zkpor_circuit::DefineBatchCreateUser(b, z->shape);
         z->c = b.finish();
         z->solver_container = zkpor_circuit::SolverContainer(z->c);

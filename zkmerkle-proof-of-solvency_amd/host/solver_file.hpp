@@ -43,7 +43,10 @@ enum { INSTR_R1C = 0, INSTR_HINT = 1, INSTR_SKIP = 2, INSTR_LOOKUP = 3, INSTR_PO
 // solver only verifies it).  An executor whose caller evaluates a, b, c of EVERY row afterwards and checks a x b = c there may leave these
 // instructions out (csrc/solver.hip with zkpor_solver_set_abc_dev); every other executor treats the word as its low byte says.
 enum : uint32_t { INSTR_CHECK = 1u << 8 };
-enum : uint32_t { POSEIDON_ASYNC = 1u << 16, POSEIDON_HDR = 5 };   // header words of a kind-4 instruction's call data
+// flags word of a kind-4 instruction: digest lane | carry lane << 8 | ASYNC << 16 | (join level + 1) << 17.  ASYNC alone: the digest only feeds the
+// LAST level.  ASYNC with a join level J (counted from 0 in the container's level order): the call may run beside levels [its own, J) — nothing in
+// them reads its wires — and must be complete in front of level J.
+enum : uint32_t { POSEIDON_ASYNC = 1u << 16, POSEIDON_JOIN_SHIFT = 17, POSEIDON_HDR = 5 };   // header words of a kind-4 instruction's call data
 
 // shape checks of the two gadget instructions against the call data (both executors call this before they trust an offset).
 // A version-1 stream's kind 3 is the old "skipped" alias: callers map it to INSTR_SKIP.
