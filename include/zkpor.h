@@ -98,7 +98,7 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * "poseidon_out_idx", "poseidon_carry_idx" (hash-wrapper convention),
  * the solver executor's (zkpor_solver_*): "solver_poseidon" (1, the default: a Poseidon call runs on 16 lanes; 0: in one thread),
  * "solver_batch_from" (2^21: levels from this many generic instructions on run four per thread), "solver_chain" (1, the default: runs of
- * one-instruction levels are decoded side by side and executed from registers; 0: the narrow-level kernel), "solver_tree_from" (1 024: levels from this many generic instructions on share one field inversion per workgroup), "solver_long" (256: those levels leave constraints of more terms than this to a wave each; 0 = never), "solver_defer_checks"
+ * one-instruction levels are decoded side by side and executed from registers; 0: the narrow-level kernel), "solver_tree_from" (1 024: levels from this many generic instructions on share one field inversion per workgroup), "solver_beside" (1, the default: a Poseidon call that carries a join level runs on a side stream beside the levels up to it; 0: in place), "solver_long" (256: those levels leave constraints of more terms than this to a wave each; 0 = never), "solver_defer_checks"
  * (1, the default: see zkpor_solver_set_abc_dev; 0: a run executes its CHECK instructions even when a, b, c buffers are set),
  * "poseidon_coop" (-1, the default: account leaves and CEX commitments run 16 lanes per hash chain when a launch has fewer than
  * 65 536 chains; 0 never, 1 always) */

@@ -1,12 +1,12 @@
 # round-4 final bench line (after the long-constraint kernel) on one MI355X
 set -u
-OUT=gpurun_out/r04y
+OUT=gpurun_out/r04x
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ( time timeout 1500 python bench.py --steps 8 --warmup 2 > $OUT/bench_default.json 2> $OUT/bench_default.err ) 2> $OUT/bench_default.time; echo "default rc=$?"; tail -2 $OUT/bench_default.err; tail -3 $OUT/bench_default.time
 python - <<'PY'
 import json
-d=json.load(open("gpurun_out/r04y/bench_default.json"))
+d=json.load(open("gpurun_out/r04x/bench_default.json"))
 print({k:d[k] for k in ("value","ms_per_step","value_uniform")}, d["checked"]["ok"], d["checked"]["proofs"])
 e=d["end_to_end"]; print({k:e[k] for k in ("value","ms_per_proof","phases_ms_per_proof","device_phases_ms_per_proof","checked","same_wires_as_headline","two_in_flight")})
 o=d["configs"]["zkpor500_200"]; print({k:o[k] for k in ("value","ms_per_step","end_to_end","checked")})
