@@ -102,3 +102,15 @@ def test_two_ranks_on_one_device_launcher_merge_and_checks():
     rows = d["checked"]["per_rank_ok_of_total"]
     assert len(rows) == 2 and all(r[0] == r[1] and r[1] > 0 for r in rows) and d["checked"]["ok"] == d["checked"]["proofs"] == sum(r[1] for r in rows)
     assert d["checked"]["h_verified"] is True and "boundary" not in d and d["two_in_flight"] is None
+
+
+def test_two_ranks_in_circuit_mode():
+    """the default workload (compiled circuit, generated scalars, `end_to_end`) under the multi-rank contract: every rank compiles, builds its key,
+    solves and proves; the end-to-end rate is the ranks' proofs over the MAX time; the two-worker region belongs to N = 1 only"""
+    d = _bench("--gpus", "2", "--share-device", "--circuit", "5,20,6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-boundary", "--e2e-steps", "2")
+    assert d["n_gpus"] == 2 and d["ranks_share_one_device"] is True and d["config"]["scalars"] == "generated"
+    rows = d["checked"]["per_rank_ok_of_total"]
+    assert len(rows) == 2 and all(r[0] == r[1] and r[1] > 0 for r in rows) and d["checked"]["ok"] == d["checked"]["proofs"]
+    e = d["end_to_end"]
+    assert e["steps"] == 2 and e["checked"]["ok"] == e["checked"]["proofs"] == 2 and e["same_wires_as_headline"] is True and e["constraints_failing_on_device"] == 0
+    assert "two_in_flight" not in e and abs(e["value"] - 2 * 1e3 / e["ms_per_proof"]) < 1e-6 * e["value"]
