@@ -187,3 +187,61 @@ def test_the_check_flag_is_validated_and_changes_nothing_for_the_host_executor()
             assert parse(with_kind(i, k)) != 0 and b"instruction kind" in err.value
     finally:
         c.close()
+
+
+def _container_parts(raw):
+    """(bytes up to the instruction table, kinds, args, level_ptr, level_instr, the rest) of a version-2 solver container"""
+    raw = np.frombuffer(bytes(raw), dtype=np.uint8)
+    n_instr, n_levels, n_names, _n_call = (int(x) for x in np.frombuffer(raw[8:40].tobytes(), dtype=np.uint64))
+    off = 40
+    for _ in range(n_names):
+        off += 4 + int(np.frombuffer(raw[off:off + 4].tobytes(), dtype=np.uint32)[0])
+    off += (8 - off % 8) % 8
+    head = raw[:off].tobytes()
+    kinds = np.frombuffer(raw[off:off + 4 * n_instr].tobytes(), dtype=np.uint32); off += 4 * n_instr
+    args = np.frombuffer(raw[off:off + 4 * n_instr].tobytes(), dtype=np.uint32); off += 4 * n_instr
+    off += (8 - off % 8) % 8
+    lp = np.frombuffer(raw[off:off + 8 * (n_levels + 1)].tobytes(), dtype=np.uint64).astype(np.int64); off += 8 * (n_levels + 1)
+    li = np.frombuffer(raw[off:off + 4 * int(lp[-1])].tobytes(), dtype=np.uint32); off += 4 * int(lp[-1])
+    off += (8 - off % 8) % 8
+    return head, kinds, args, lp, li, raw[off:].tobytes()
+
+
+def _container_with_levels(head, kinds, args, levels, rest):
+    lp = np.concatenate([[0], np.cumsum([len(l) for l in levels])]).astype("<u8")
+    li = np.concatenate(levels).astype("<u4")
+    body = head + kinds.astype("<u4").tobytes() + args.astype("<u4").tobytes()
+    body += b"\0" * (-len(body) % 8)
+    body += lp.tobytes() + li.tobytes()
+    body += b"\0" * (-len(body) % 8)
+    return body + rest
+
+
+def test_the_join_level_of_the_long_call_is_a_promise_the_program_keeps():
+    """poseidon(async = 2): the challenge sponge carries the level it must be complete in front of; nothing between its own level and that one
+    reads its wires.  Checked by moving the call: at the END of the last level before its join the program still solves to the same wires
+    (so an executor may run it beside everything in between); one level later — behind its first consumer — it does not"""
+    shape = (3, 6, 2)
+    inp = C.synth_inputs(*shape, seed=8)
+    c = C.Circuit(*shape, inputs=inp)
+    try:
+        head, kinds, args, lp, li, rest = _container_parts(c.solver_container())
+        cd = np.frombuffer(rest, dtype=np.uint32)
+        calls = [i for i in np.nonzero((kinds & 0xff) == 4)[0] if (cd[args[i] + 3] >> 17) != 0]
+        assert len(calls) == 1                                             # the RLC challenge
+        call = int(calls[0]); flags = int(cd[args[call] + 3])
+        join = (flags >> 17) - 1                                           # level index, counted from 0
+        assert flags & (1 << 16) and int(cd[args[call]]) == shape[2] + 1   # ASYNC; its inputs: one id hash per user + the batch commitment
+        levels = [li[lp[l]:lp[l + 1]].copy() for l in range(len(lp) - 1)]
+        own = next(l for l, ids in enumerate(levels) if call in ids)
+        assert own < join < len(levels) and join - own - 1 == c.census["levels_beside_the_long_call"] >= 28
+        want = c.values()
+        moved = [ids[ids != call] for ids in levels]
+        late = list(moved); late[join - 1] = np.append(late[join - 1], np.uint32(call))
+        w = c.solve_host_with(_container_with_levels(head, kinds, args, late, rest), inp, C.default_commitment(), threads=2)
+        assert np.array_equal(w, want)
+        too_late = list(moved); too_late[join] = np.append(too_late[join], np.uint32(call))
+        with pytest.raises(RuntimeError):
+            c.solve_host_with(_container_with_levels(head, kinds, args, too_late, rest), inp, C.default_commitment(), threads=2)
+    finally:
+        c.close()

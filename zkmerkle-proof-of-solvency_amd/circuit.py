@@ -117,6 +117,18 @@ class Circuit:
             raise RuntimeError("host executor: %d %s" % (rc, err.value.decode()))
         return w
 
+    def solve_host_with(self, container, inputs, commitment, threads=4, check_rows=True):
+        """the host executor over ANOTHER program for this circuit's matrices (tests rearrange the levels)"""
+        buf = np.ascontiguousarray(np.frombuffer(bytes(container), dtype=np.uint8))
+        inp = np.ascontiguousarray(inputs, dtype=np.uint64); cm = np.ascontiguousarray(commitment, dtype=np.uint64)
+        w = np.zeros((self.n_wires, 4), np.uint64)
+        err = ctypes.create_string_buffer(512)
+        rc = host_lib().zkc_solve_host_with(self.z, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes), inp.ctypes.data_as(ctypes.c_void_p),
+                                            cm.ctypes.data_as(ctypes.c_void_p), threads, w.ctypes.data_as(ctypes.c_void_p), 1 if check_rows else 0, err, ctypes.c_size_t(512))
+        if rc != 0:
+            raise RuntimeError(f"host executor: {err.value.decode()}")
+        return w
+
     def close(self):
         if self.z:
             host_lib().zkc_free(self.z)

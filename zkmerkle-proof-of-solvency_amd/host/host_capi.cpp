@@ -349,8 +349,15 @@ long zkc_synth_inputs(uint32_t user_assets, uint32_t all_assets, uint32_t users,
 }
 // the compiled program on the host executor (host/solver_exec.hpp) — commitment_mont: what the BSB22 placeholder returns.
 // w_out: n_wires x 4.  0 = ok.
+int zkc_solve_host_with(const zkc_circuit* z, const uint8_t* container, size_t container_len, const uint64_t* inputs_mont, const uint64_t* commitment_mont,
+                        int threads, uint64_t* w_out, int check_rows, char* err, size_t err_len);
 int zkc_solve_host(const zkc_circuit* z, const uint64_t* inputs_mont, const uint64_t* commitment_mont, int threads, uint64_t* w_out, int check_rows,
                    char* err, size_t err_len) {
+    return zkc_solve_host_with(z, z->solver_container.data(), z->solver_container.size(), inputs_mont, commitment_mont, threads, w_out, check_rows, err, err_len);
+}
+// the same over ANOTHER program for the circuit's matrices (tests: a container with its levels rearranged must still solve — or must not)
+int zkc_solve_host_with(const zkc_circuit* z, const uint8_t* container, size_t container_len, const uint64_t* inputs_mont, const uint64_t* commitment_mont,
+                        int threads, uint64_t* w_out, int check_rows, char* err, size_t err_len) {
     const auto& c = z->c;
     R1csFileView rv;
     rv.n_constraints = c.n_constraints; rv.n_wires = c.n_wires; rv.n_public = c.n_public; rv.n_secret = c.n_secret; rv.n_coeff = c.coeff.size();
@@ -358,7 +365,7 @@ int zkc_solve_host(const zkc_circuit* z, const uint64_t* inputs_mont, const uint
     for (int m = 0; m < 3; ++m) { rv.nnz[m] = c.cid[m].size(); rv.row_ptr[m] = c.row_ptr[m].data(); rv.coeff_ids[m] = c.cid[m].data(); rv.wire_ids[m] = c.wid[m].data(); }
     SolverView sv;
     std::string why;
-    if (ParseSolverFile(z->solver_container.data(), z->solver_container.size(), &sv, &why) != 0) { zkc_put_err(err, err_len, why); return 1; }
+    if (ParseSolverFile(container, container_len, &sv, &why) != 0) { zkc_put_err(err, err_len, why); return 1; }
     HintRegistry reg = HintRegistry::Standard();
     FrH cm; memcpy(cm.v, commitment_mont, 32);
     reg.by_name["bsb22CommitmentComputePlaceholder"] = [cm](const std::vector<FrH>&, std::vector<FrH>& out) { if (out.size() != 1) return 1; out[0] = cm; return 0; };
