@@ -245,3 +245,25 @@ def test_the_join_level_of_the_long_call_is_a_promise_the_program_keeps():
             c.solve_host_with(_container_with_levels(head, kinds, args, too_late, rest), inp, C.default_commitment(), threads=2)
     finally:
         c.close()
+
+
+def test_check_instructions_assign_no_wire():
+    """the promise behind INSTR_CHECK: a program with every flagged instruction turned into a skipped one still assigns every wire, to the same
+    values (an executor whose caller verifies a x b = c on every row loses nothing by leaving them out); un-flagged constraint instructions
+    are not dispensable — skipping ONE of them leaves a wire unassigned"""
+    shape = (3, 6, 2)
+    inp = C.synth_inputs(*shape, seed=12)
+    c = C.Circuit(*shape, inputs=inp)
+    try:
+        head, kinds, args, lp, li, rest = _container_parts(c.solver_container())
+        levels = [li[lp[l]:lp[l + 1]] for l in range(len(lp) - 1)]
+        flagged = (kinds & 0x100) != 0
+        k2 = kinds.copy(); k2[flagged] = 2                                  # INSTR_SKIP
+        w = c.solve_host_with(_container_with_levels(head, k2, args, levels, rest), inp, C.default_commitment(), threads=2)
+        assert np.array_equal(w, c.values()) and flagged.sum() > 10000
+        plain = np.nonzero(kinds == 0)[0]
+        k3 = kinds.copy(); k3[plain[len(plain) // 2]] = 2
+        with pytest.raises(RuntimeError):
+            c.solve_host_with(_container_with_levels(head, k3, args, levels, rest), inp, C.default_commitment(), threads=2)
+    finally:
+        c.close()
