@@ -95,25 +95,34 @@ def algorithmic_bytes_per_proof(log2, n_wires, n_commit):
     return msm + ntt + pointwise + commit
 
 
-def mixture_scalars(seed, n, fill_kind):
-    """host copy of the witness scalar mixture of zkpor_dev_fill_fr (csrc/api_core.hip k_fill_fr): the same proportions, numpy's generator"""
+def mixture_scalars(seed, n, fill_kind, mix=None):
+    """host copy of the witness scalar mixture of zkpor_dev_fill_fr (csrc/api_core.hip k_fill_fr): the same proportions, numpy's generator.
+    mix (circuit mode): the MEASURED classes of the solved wire vector (config.scalar_mix_measured: zero, in_{0,1}, below_2^16, below_2^64)"""
     import numpy as np
     import oracle as O
     rng = np.random.default_rng(seed)
-    sel = rng.integers(0, 100, n)
-    cuts = {1: (25, 45, 50), 2: (35, 65, 70)}.get(fill_kind, (0, 0, 0))
     canon = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
     canon[:, 3] &= np.uint64(0x0fffffffffffffff)                  # < 2^252 < r: canonical
-    small = sel < cuts[2]
-    canon[small, 1:] = 0
-    canon[sel < cuts[1], 0] &= np.uint64(0xffff)
-    canon[sel < cuts[0], 0] &= np.uint64(1)
+    if mix is not None:
+        sel = rng.random(n)
+        c01 = float(mix["in_{0,1}"]); c16 = c01 + float(mix["below_2^16"]); c64 = c16 + float(mix["below_2^64"]); cz = min(float(mix.get("zero", 0.0)), c01)
+        canon[sel < c64, 1:] = 0
+        canon[sel < c16, 0] &= np.uint64(0xffff)
+        canon[sel < c01, 0] = np.uint64(1)
+        canon[sel < cz, 0] = np.uint64(0)
+    else:
+        sel = rng.integers(0, 100, n)
+        cuts = {1: (25, 45, 50), 2: (35, 65, 70)}.get(fill_kind, (0, 0, 0))
+        small = sel < cuts[2]
+        canon[small, 1:] = 0
+        canon[sel < cuts[1], 0] &= np.uint64(0xffff)
+        canon[sel < cuts[0], 0] &= np.uint64(1)
     out = np.empty_like(canon)
     O.lib().orc_fr_from_canon(O._p(np.ascontiguousarray(canon)), O._p(out), n)
     return out
 
 
-def cpu_baseline(log2_sample, log2_full, commit_frac, fill_kind=1, mixture="25% {0,1}, 20% <2^16, 5% <2^64, 50% uniform"):
+def cpu_baseline(log2_sample, log2_full, commit_frac, fill_kind=1, mixture="25% {0,1}, 20% <2^16, 5% <2^64, 50% uniform", mix=None):
     """The CPU baseline, kind "port": oracle/cpubase.hpp — what groth16.Prove does after the solver, organised as gnark /
     gnark-crypto organise it (no-carry Montgomery on 4 x 64-bit limbs, signed-digit c = 16 Pippenger with extended-Jacobian
     buckets split over (window, chunk) tasks, zero digits skipped, cache-blocked radix-2 FFT), on ALL host cores, at a bounded sample of
@@ -136,7 +145,10 @@ def cpu_baseline(log2_sample, log2_full, commit_frac, fill_kind=1, mixture="25% 
     a0 = O.fr_random(3, n); b0 = O.fr_random(4, n); c0 = O.fr_mul(a0, b0)
     O.fast_prove_tail_work(10, p1, p2, O.fr_random(1, 1024), a0[:1024].copy(), b0[:1024].copy(), c0[:1024].copy(), 256)   # thread pool, constants
     runs = {}
-    for name, sc in (("witness", mixture_scalars(7, n, fill_kind)), ("uniform", O.fr_random(1, n))):
+    if mix is not None:       # circuit mode: the classes measured on the generated wire vector, not the survey's estimate
+        mixture = (f"measured on the solved wire vector: {100 * mix.get('zero', 0):.1f}% zero, {100 * (mix['in_{0,1}'] - mix.get('zero', 0)):.1f}% one, "
+                   f"{100 * mix['below_2^16']:.1f}% <2^16, {100 * mix['below_2^64']:.1f}% <2^64, {100 * mix['wider']:.1f}% wider")
+    for name, sc in (("witness", mixture_scalars(7, n, fill_kind, mix)), ("uniform", O.fr_random(1, n))):
         runs[name] = O.fast_prove_tail_work(log2_sample, p1, p2, sc, a0.copy(), b0.copy(), c0.copy(), nc)
     fft_s, g1_s, g2_s, com_s = runs["witness"]
     dt = fft_s + g1_s + g2_s + com_s
@@ -1821,7 +1833,8 @@ def main():
                     out["r1cs_resident"] = {"value": None, "note": f"failed: {e}"}
             if not args.no_cpu_baseline:
                 try:
-                    out["cpu_baseline"] = cpu_baseline(args.cpu_log2, log2, 0.25, cfg["fill_kind"], cfg["mixture"])
+                    out["cpu_baseline"] = cpu_baseline(args.cpu_log2, log2, 0.25, cfg["fill_kind"], cfg["mixture"],
+                                                       mix=scalar_mix if (circ is not None and args.scalars == "witness") else None)
                 except Exception as e:  # the baseline is informational; never lose the GPU line over it
                     out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
             out["solver_budget"] = solver_budget(dt / args.steps * 1e3, os.cpu_count() or 1)
