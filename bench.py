@@ -180,9 +180,9 @@ def solver_budget(gpu_ms_per_proof, host_threads, gpus_per_node=8):
             "vcpus_per_gpu_to_keep_the_gpu_busy": [round(lo * gpu_rate), round(hi * gpu_rate)],
             "solver_bound_proofs_per_s_per_gpu_on_this_host": [round(tpg / hi, 4), round(tpg / lo, 4)],
             "gpu_busy_fraction_if_fed_by_gnarks_solver_on_this_host": [round(min(1.0, tpg / hi / gpu_rate), 4), round(min(1.0, tpg / lo / gpu_rate), 4)],
-            "note": "model, not a measurement: assumes the solver scales linearly over the host threads of one GPU's share; the fix on the "
-                    "roadmap is SURVEY.md §8 f4 (a structured witness generator for BatchCreateUserCircuit on the device) with f1 "
-                    "(a, b, c evaluated in HBM, zkpor_r1cs_*) already built"}
+            "note": "model, not a measurement: what a GPU fed by gnark's HOST solver would look like, assuming the solver scales linearly over the host "
+                    "threads of one GPU's share.  Since round 4 the alternative is measured: `end_to_end` runs the solver program on the device "
+                    "(SURVEY.md §8 f4 + f1) and needs only the assigned inputs from the host (`host_row_measured`)"}
 
 
 def usable_cpus():
