@@ -19,7 +19,7 @@ def ints(a):
     return O.fr_to_ints(np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4))
 
 
-@pytest.mark.parametrize("shape", [(3, 6, 3), (4, 10, 5)])
+@pytest.mark.parametrize("shape", [(3, 6, 3), (4, 10, 5), (6, 6, 2)])   # the last: every slot of the list a real asset (the zkpor500 shape)
 def test_interpreter_accepts_a_synthetic_batch_and_the_host_executor_reproduces_it(shape):
     inp = C.synth_inputs(*shape, seed=11)
     c = C.Circuit(*shape, inputs=inp)
