@@ -17,7 +17,9 @@
  * The cgo binding a maintainer adds on the reference side is shown in INTEGRATION.md.
  *
  * Conventions
- *   - all functions return 0 on success, <0 on error (ZKPOR_E_*); they never throw, never call back into the
+ *   - all functions return 0 on success, <0 on error (ZKPOR_E_*); they never throw — every entry point is a function-try-block
+ *     (csrc/common.cuh ZK_ABI_CATCH, kept complete by tools/abi_firewall.py --check): std::bad_alloc is ZKPOR_E_OOM, any other C++
+ *     exception ZKPOR_E_HIP, its text is in the next zkpor_last_error of the calling thread — never call back into the
  *     host runtime and never retain a host pointer after returning (cgo pointer-passing rule).
  *   - field elements are gnark-crypto's in-memory form: 4 x uint64 little-endian limbs, MONTGOMERY form
  *     (fr.Element / fp.Element).  G1 affine = X,Y (64 B); G2 affine = X.A0,X.A1,Y.A0,Y.A1 (128 B);
@@ -101,7 +103,13 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * one-instruction levels are decoded side by side and executed from registers; 0: the narrow-level kernel), "solver_tree_from" (1 024: levels from this many generic instructions on share one field inversion per workgroup), "solver_beside" (1, the default: a Poseidon call that carries a join level runs on a side stream beside the levels up to it; 0: in place), "solver_long" (256: those levels leave constraints of more terms than this to a wave each; 0 = never), "solver_defer_checks"
  * (1, the default: see zkpor_solver_set_abc_dev; 0: a run executes its CHECK instructions even when a, b, c buffers are set),
  * "poseidon_coop" (-1, the default: account leaves and CEX commitments run 16 lanes per hash chain when a launch has fewer than
- * 65 536 chains; 0 never, 1 always) */
+ * 65 536 chains; 0 never, 1 always),
+ * "tail_reserve_cus" (0, the default; a multiple of 8 up to 128: the kernels of the prove tail — NTT passes, digit streams, bucket
+ * accumulations — run on HIP streams whose CU mask leaves that many compute units free, R / 8 on each XCD, so that the narrow
+ * dependent launches of ANOTHER worker context's solver program start at once instead of queueing behind full-size MSM grids:
+ * solve(i + 1) beside tail(i) with two workers per GPU — host/prover_host.hpp, bench.py `end_to_end`),
+ * "debug_validate" (0; 1: every sorted digit stream is checked on the device before its accumulation reads it — keys ascending and
+ * below the bucket count, point indices inside the key array — and a violation is ZKPOR_E_STATE instead of a GPU memory fault) */
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);
 /* per-phase GPU time in ms accumulated since the last reset (HIP events on the context's stream).
  * names: "msm_decompose","msm_sort","msm_accumulate","msm_reduce","k_acc_level1_g1","k_acc_level1_g2" (the

@@ -198,6 +198,7 @@ def test_prefetching_the_next_proofs_hash_chains_changes_no_wire(zk):
         cvb.free(); dc.close(); pk.close(); cir.close()
 
 
+@pytest.mark.isolated
 def test_two_workers_of_one_gpu_solve_and_prove_side_by_side(zk):
     """one zkpor_r1cs, two solvers on two contexts (zkpor_solver_create_on), two host threads: each proves its own batches — solver program,
     commitment, a / b / c (zkpor_r1cs_eval_on), prove tail — while the other does the same; every wire vector equals the single-worker run's"""

@@ -29,6 +29,7 @@ def drv():
     return ctypes.CDLL(so)
 
 
+@pytest.mark.isolated
 @pytest.mark.parametrize("n_workers", [2, 3])
 def test_dispatcher_drives_real_proofs_on_several_contexts(zk, drv, n_workers):
     import torch

@@ -282,6 +282,7 @@ def test_commitment_extended_groth16_verifies(zk):
     assert np.array_equal(O.g1_add(krs_excl[None, :], share[None, :])[0], krs_full)
 
 
+@pytest.mark.isolated
 @pytest.mark.parametrize("gpu_token,copy_threads", [(1, 0), (1, 3), (0, 0)])
 def test_two_callers_take_turns_on_the_device(zk, gpu_token, copy_threads):
     """two contexts of one GPU, one caller thread each, proving from host memory at the same time (what host/prover_host.hpp runs per
@@ -329,6 +330,7 @@ def test_two_callers_take_turns_on_the_device(zk, gpu_token, copy_threads):
         other.close(); pk.close()
 
 
+@pytest.mark.isolated
 def test_host_pointer_staging_survives_regrowth_and_copy_thread_changes():
     """one context, keys of different sizes one after the other (the staging area regrows, then is reused for a smaller key), the
     bounce-buffer copier rebuilt with 1, 7 and 0 (runtime path) threads in between, a commitment placed behind the prove tail's vectors — every proof

@@ -8,6 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.isolated
 def test_pipeline_demo():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pipeline_demo.py")
     spec = importlib.util.spec_from_file_location("pipeline_demo", path)

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.isolated
 def test_row_to_row(zk):
     from test_dispatcher_gpu import drv as _f  # noqa: F401  (builds the driver library if needed)
     host = ctypes.CDLL(os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd", "libzkpor_host.so"))
@@ -107,6 +108,7 @@ def _input_circuit(values, picks, challenge):
     return b, limbs, hint_at
 
 
+@pytest.mark.isolated
 def test_row_to_row_with_the_solver_on_the_device(zk):
     """Prover.GenerateAndVerifyProof with NO host solver (host/prove_on_device.hpp): the witness-table row is decoded and assigned on the host,
     the inputs cross PCIe, the solver program (with its BSB22 commitment), a / b / c and the prove tail run on the device, the proof-table row

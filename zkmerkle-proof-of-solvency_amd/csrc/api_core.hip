@@ -10,6 +10,8 @@
 using namespace zk;
 
 namespace zk {
+static thread_local char g_abi_exception[200] = {0};
+void abi_exception(const char* what) noexcept { snprintf(g_abi_exception, sizeof g_abi_exception, "%s", what ? what : "?"); }
 void pos_tables_free(zkpor_ctx* ctx);
 int32_t ensure_pinned(zkpor_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->pinned_cap) return ZKPOR_OK;
@@ -262,22 +264,22 @@ __global__ void k_fr_mul(Fr* out, const Fr* a, const Fr* b, size_t n) {
 
 extern "C" {
 
-int32_t zkpor_dev_fr_mul(zkpor_ctx* ctx, void* d_out, const void* d_a, const void* d_b, size_t n) {
+int32_t zkpor_dev_fr_mul(zkpor_ctx* ctx, void* d_out, const void* d_a, const void* d_b, size_t n) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && (!d_out || !d_a || !d_b))) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
     hipLaunchKernelGGL(k_fr_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_out, (const Fr*)d_a, (const Fr*)d_b, n);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
-int32_t zkpor_dev_copy(zkpor_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+} ZK_ABI_CATCH
+int32_t zkpor_dev_copy(zkpor_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (bytes && (!d_dst || !d_src))) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_init(int device, void* stream, zkpor_ctx** out) {
+int32_t zkpor_init(int device, void* stream, zkpor_ctx** out) try {
     if (!out) return ZKPOR_E_ARG;
     *out = nullptr;
     int count = 0;
@@ -298,9 +300,9 @@ int32_t zkpor_init(int device, void* stream, zkpor_ctx** out) {
     }
     *out = ctx;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-void zkpor_destroy(zkpor_ctx* ctx) {
+void zkpor_destroy(zkpor_ctx* ctx) try {
     if (!ctx) return;
     ZK_ENTER(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -308,6 +310,7 @@ void zkpor_destroy(zkpor_ctx* ctx) {
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->dbg_buf) (void)hipFree(ctx->dbg_buf);
     pos_tables_free(ctx);
     ntt_domains_free(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -315,22 +318,31 @@ void zkpor_destroy(zkpor_ctx* ctx) {
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
+    if (ctx->tail_aux) (void)hipStreamDestroy(ctx->tail_aux);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+} catch (...) { zk::abi_exception("exception in zkpor_destroy"); }
+
+const char* zkpor_last_error(zkpor_ctx* ctx) {
+    if (!ctx) return "null context";
+    if (zk::g_abi_exception[0]) {   // an exception stopped at the ABI on this thread since the last call: it is the error
+        try { ctx->err = std::string("C++ exception stopped at the ABI: ") + zk::g_abi_exception; } catch (...) { return zk::g_abi_exception; }
+        zk::g_abi_exception[0] = 0;
+    }
+    return ctx->err.c_str();
 }
 
-const char* zkpor_last_error(zkpor_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-
-int32_t zkpor_sync(zkpor_ctx* ctx) {
+int32_t zkpor_sync(zkpor_ctx* ctx) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 uint32_t zkpor_abi_version(void) { return ZKPOR_ABI_VERSION; }
 
-int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
+int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !name) return ZKPOR_E_ARG;
     std::string n(name);
@@ -369,13 +381,19 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) {
         if (!t || strcmp(t, "1") != 0) { ctx->err = "debug_ntt_fault is a test hook: set ZKPOR_TESTING=1 in the environment to enable it"; return ZKPOR_E_ARG; }
         return ntt_debug_fault(ctx, (int)value);
     }
+    else if (n == "tail_reserve_cus") {
+        if (value < 0 || value > 128 || value % 8) { ctx->err = "tail_reserve_cus must be 0 or a multiple of 8 up to 128"; return ZKPOR_E_ARG; }
+        for (hipStream_t* st : {&ctx->tail_stream, &ctx->tail_aux}) if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
+        ctx->tail_reserve_cus = (int)value;
+    }
+    else if (n == "debug_validate") { if (value < 0 || value > 1) { ctx->err = "debug_validate must be 0 or 1"; return ZKPOR_E_ARG; } ctx->debug_validate = (int)value; }
     else if (n == "poseidon_out_idx") ctx->pos_out = (int)value;
     else if (n == "poseidon_carry_idx") ctx->pos_carry = (int)value;
     else { ctx->err = "unknown parameter " + n; return ZKPOR_E_ARG; }
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls) {
+double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !name) return -1.0;
     auto it = ctx->phases.find(name);
@@ -383,70 +401,70 @@ double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls) {
     phase_resolve(ctx, it->second);
     if (calls) *calls = it->second.calls;
     return it->second.ms;
-}
-void zkpor_phase_reset(zkpor_ctx* ctx) {
+} catch (...) { zk::abi_exception("exception in zkpor_phase_ms"); return -1.0; }
+void zkpor_phase_reset(zkpor_ctx* ctx) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return;
     for (auto& kv : ctx->phases) { phase_resolve(ctx, kv.second); kv.second.ms = 0; kv.second.calls = 0; }
-}
+} catch (...) { zk::abi_exception("exception in zkpor_phase_reset"); }
 
-int32_t zkpor_dev_alloc(zkpor_ctx* ctx, size_t bytes, void** out) {
+int32_t zkpor_dev_alloc(zkpor_ctx* ctx, size_t bytes, void** out) try {
     if (!ctx || !out) return ZKPOR_E_ARG;
     ZK_ENTER(ctx->device);
     ZK_HIP(ctx, hipMalloc(out, bytes ? bytes : 1));
     return ZKPOR_OK;
-}
-int32_t zkpor_dev_free(zkpor_ctx* ctx, void* p) {
+} ZK_ABI_CATCH
+int32_t zkpor_dev_free(zkpor_ctx* ctx, void* p) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZK_HIP(ctx, hipFree(p));
     return ZKPOR_OK;
-}
-int32_t zkpor_dev_upload(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) {
+} ZK_ABI_CATCH
+int32_t zkpor_dev_upload(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer is not retained
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 // asynchronous upload: returns once the copy is queued; the host buffer must stay valid (and should be pinned, see
 // zkpor_host_register) until zkpor_sync.  Lets the next proof's witness cross PCIe under the current proof's kernels.
-int32_t zkpor_dev_upload_async(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) {
+int32_t zkpor_dev_upload_async(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 // page-lock a caller-owned host range (a Go slice's backing array) so uploads from it run at PCIe rate and truly
 // asynchronously; the caller unregisters it before freeing the memory
-int32_t zkpor_host_register(zkpor_ctx* ctx, void* ptr, size_t bytes) {
+int32_t zkpor_host_register(zkpor_ctx* ctx, void* ptr, size_t bytes) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !ptr || !bytes) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     return ZKPOR_OK;
-}
-int32_t zkpor_host_unregister(zkpor_ctx* ctx, void* ptr) {
+} ZK_ABI_CATCH
+int32_t zkpor_host_unregister(zkpor_ctx* ctx, void* ptr) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !ptr) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipHostUnregister(ptr));
     return ZKPOR_OK;
-}
-int32_t zkpor_dev_download(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) {
+} ZK_ABI_CATCH
+int32_t zkpor_dev_download(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-}
-int32_t zkpor_dev_fill_fr(zkpor_ctx* ctx, void* d_out, size_t n, uint64_t seed, int kind) {
+} ZK_ABI_CATCH
+int32_t zkpor_dev_fill_fr(zkpor_ctx* ctx, void* d_out, size_t n, uint64_t seed, int kind) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (!d_out && n)) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
     hipLaunchKernelGGL(k_fill_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_out, n, seed, kind);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 // ---- generic MSM ----
 static void store_jac_g1(const G1XYZZ& r, uint8_t* out) {
@@ -458,53 +476,53 @@ static void store_jac_g2(const G2XYZZ& r, uint8_t* out) {
     memcpy(out, &j, 192);
 }
 
-int32_t zkpor_g1_jac_sum(const uint8_t* parts96, size_t count, uint8_t out_jac[96]) {
+int32_t zkpor_g1_jac_sum(const uint8_t* parts96, size_t count, uint8_t out_jac[96]) try {
     if ((!parts96 && count) || !out_jac) return ZKPOR_E_ARG;
     G1Jac o;
     jac_sum<Fp>((const G1Jac*)parts96, count, &o);
     memcpy(out_jac, &o, 96);
     return ZKPOR_OK;
-}
-int32_t zkpor_g2_jac_sum(const uint8_t* parts192, size_t count, uint8_t out_jac[192]) {
+} ZK_ABI_CATCH
+int32_t zkpor_g2_jac_sum(const uint8_t* parts192, size_t count, uint8_t out_jac[192]) try {
     if ((!parts192 && count) || !out_jac) return ZKPOR_E_ARG;
     G2Jac o;
     jac_sum<Fp2>((const G2Jac*)parts192, count, &o);
     memcpy(out_jac, &o, 192);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_msm_g1_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[96]) {
+int32_t zkpor_msm_g1_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[96]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out_jac || (n && (!d_points || !d_scalars))) return ZKPOR_E_ARG;
     G1XYZZ r;
     ZK_TRY(msm_dev<Fp>(ctx, (const G1Affine*)d_points, (const Fr*)d_scalars, n, &r));
     store_jac_g1(r, out_jac);
     return ZKPOR_OK;
-}
-int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[192]) {
+} ZK_ABI_CATCH
+int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[192]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out_jac || (n && (!d_points || !d_scalars))) return ZKPOR_E_ARG;
     G2XYZZ r;
     ZK_TRY(msm_dev<Fp2>(ctx, (const G2Affine*)d_points, (const Fr*)d_scalars, n, &r));
     store_jac_g2(r, out_jac);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_msm_g1(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[96]) {
+int32_t zkpor_msm_g1(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[96]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out_jac || (n && (!points_affine || !scalars))) return ZKPOR_E_ARG;
     G1XYZZ r;
     ZK_TRY(msm_host<Fp>(ctx, points_affine, scalars, n, &r));
     store_jac_g1(r, out_jac);
     return ZKPOR_OK;
-}
-int32_t zkpor_msm_g2(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[192]) {
+} ZK_ABI_CATCH
+int32_t zkpor_msm_g2(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[192]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out_jac || (n && (!points_affine || !scalars))) return ZKPOR_E_ARG;
     G2XYZZ r;
     ZK_TRY(msm_host<Fp2>(ctx, points_affine, scalars, n, &r));
     store_jac_g2(r, out_jac);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"

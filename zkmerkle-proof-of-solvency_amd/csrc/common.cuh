@@ -6,6 +6,8 @@
 #include <vector>
 #include <map>
 #include <stdio.h>
+#include <new>
+#include <exception>
 #include <string.h>
 #include <cstring>
 #include "../../include/zkpor.h"
@@ -71,6 +73,13 @@ struct zkpor_ctx {
     int poseidon_coop = -1;          // account leaves / CEX commitments 16 lanes per hash chain: -1 = when a launch has fewer than 65 536 chains, 0 = never, 1 = always
     int solver_poseidon = 1;         // the solver program's Poseidon instruction: 1 = sixteen lanes per call (latency), 0 = one thread per call
     int gpu_token = 1;               // host-pointer calls of several contexts on one GPU take turns on the device (api_core.hip GpuTurn)
+    int tail_reserve_cus = 0;        // > 0: the prove tail's kernels (NTT passes, digit streams, accumulations) run on streams whose CU mask leaves this many
+                                     // compute units free (evenly over the XCDs) — for the narrow, dependent launches of ANOTHER worker's solver program, which
+                                     // otherwise queue behind full-size MSM grids (solve(i+1) beside tail(i): host/prover_host.hpp workers, bench.py end_to_end)
+    hipStream_t tail_stream = nullptr, tail_aux = nullptr;   // created on first use, destroyed when the parameter changes
+    int debug_validate = 0;          // 1: every sorted digit stream is checked (keys ascending and below the bucket count, point indices inside the array) on the
+                                     // accumulating stream before its level-1 kernel reads it; a violation is ZKPOR_E_STATE instead of a GPU memory fault
+    uint32_t* dbg_buf = nullptr;     // 4 words of device memory for that check
 };
 
 #define ZK_HIP(ctx, call)                                                                             \
@@ -87,6 +96,17 @@ struct zkpor_ctx {
         if (rc__ != ZKPOR_OK) return rc__; \
     } while (0)
 #define ZK_KERNEL_CHECK(ctx) ZK_HIP(ctx, hipGetLastError())
+
+// The exception firewall of the C ABI (include/zkpor.h: "never throw"): every `int32_t zkpor_*` entry point is a function-try-block
+// that ends in ZK_ABI_CATCH (tools/abi_firewall.py keeps it so).  std::vector / std::string / std::function / std::thread inside the
+// library can throw; a cgo caller cannot unwind — the reference's prover logs an error return and moves on
+// (src/prover/prover/prover.go:269-272), it must never be killed by its backend.  The text of the exception is kept per host thread
+// and shown by the next zkpor_last_error of that thread.
+namespace zk { void abi_exception(const char* what) noexcept; }
+#define ZK_ABI_CATCH                                                                                      \
+    catch (const std::bad_alloc&) { zk::abi_exception("std::bad_alloc"); return ZKPOR_E_OOM; }           \
+    catch (const std::exception& e__) { zk::abi_exception(e__.what()); return ZKPOR_E_HIP; }             \
+    catch (...) { zk::abi_exception("unknown C++ exception"); return ZKPOR_E_HIP; }
 
 namespace zk {
 

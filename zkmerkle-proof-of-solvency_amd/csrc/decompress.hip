@@ -185,7 +185,7 @@ int32_t decompress_to_device(zkpor_ctx* ctx, bool g2, const uint8_t* host_in, si
 using namespace zk;
 extern "C" {
 
-int32_t zkpor_g1_decompress(zkpor_ctx* ctx, const uint8_t* compressed32, size_t n, void* out_affine) {
+int32_t zkpor_g1_decompress(zkpor_ctx* ctx, const uint8_t* compressed32, size_t n, void* out_affine) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && (!compressed32 || !out_affine))) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
@@ -195,8 +195,8 @@ int32_t zkpor_g1_decompress(zkpor_ctx* ctx, const uint8_t* compressed32, size_t 
     if (rc == ZKPOR_OK && hipMemcpy(out_affine, d, n * 64, hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "decompress: D2H failed"; rc = ZKPOR_E_HIP; }
     (void)hipFree(d);
     return rc;
-}
-int32_t zkpor_g2_decompress(zkpor_ctx* ctx, const uint8_t* compressed64, size_t n, void* out_affine) {
+} ZK_ABI_CATCH
+int32_t zkpor_g2_decompress(zkpor_ctx* ctx, const uint8_t* compressed64, size_t n, void* out_affine) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && (!compressed64 || !out_affine))) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
@@ -206,6 +206,6 @@ int32_t zkpor_g2_decompress(zkpor_ctx* ctx, const uint8_t* compressed64, size_t 
     if (rc == ZKPOR_OK && hipMemcpy(out_affine, d, n * 128, hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "decompress: D2H failed"; rc = ZKPOR_E_HIP; }
     (void)hipFree(d);
     return rc;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"

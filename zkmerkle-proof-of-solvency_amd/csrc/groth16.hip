@@ -303,7 +303,7 @@ inline G1XYZZ g1x(const G1Affine& a) { return xyzz_from_affine<Fp>(a); }
 
 extern "C" {
 
-int32_t zkpor_pk_create(zkpor_ctx* ctx, zkpor_pk** out) {
+int32_t zkpor_pk_create(zkpor_ctx* ctx, zkpor_pk** out) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out) return ZKPOR_E_ARG;
     zkpor_pk* pk = new (std::nothrow) zkpor_pk();
@@ -311,16 +311,16 @@ int32_t zkpor_pk_create(zkpor_ctx* ctx, zkpor_pk** out) {
     pk->ctx = ctx;
     *out = pk;
     return ZKPOR_OK;
-}
-void zkpor_pk_destroy(zkpor_pk* pk) {
+} ZK_ABI_CATCH
+void zkpor_pk_destroy(zkpor_pk* pk) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk) return;
     (void)hipStreamSynchronize(pk->ctx->stream);
     pk_free_arrays(pk);
     delete pk;
-}
+} catch (...) { zk::abi_exception("exception in zkpor_pk_destroy"); }
 
-int32_t zkpor_pk_set_g1(zkpor_pk* pk, int which, const void* pts, size_t n) {
+int32_t zkpor_pk_set_g1(zkpor_pk* pk, int which, const void* pts, size_t n) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || which < 0 || which >= ZKPOR_G1_NUM || (n && !pts)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
@@ -331,8 +331,8 @@ int32_t zkpor_pk_set_g1(zkpor_pk* pk, int which, const void* pts, size_t n) {
     pk->g1_raw_n[which] = n;
     pk->ready = false;
     return ZKPOR_OK;
-}
-int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n) {
+} ZK_ABI_CATCH
+int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || which != ZKPOR_G2_B || (n && !pts)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
@@ -343,10 +343,10 @@ int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n) {
     pk->g2_raw_n = n;
     pk->ready = false;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 // compressed input (what pk.WriteTo put on disk, src/keygen/main.go:46): decompressed on the device, decompress.hip
-int32_t zkpor_pk_set_g1_compressed(zkpor_pk* pk, int which, const uint8_t* compressed32, size_t n) {
+int32_t zkpor_pk_set_g1_compressed(zkpor_pk* pk, int which, const uint8_t* compressed32, size_t n) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || which < 0 || which >= ZKPOR_G1_NUM || (n && !compressed32)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
@@ -357,8 +357,8 @@ int32_t zkpor_pk_set_g1_compressed(zkpor_pk* pk, int which, const uint8_t* compr
     ZK_TRY(zk::decompress_to_device(ctx, false, compressed32, n, pk->g1_raw[which]));
     pk->g1_raw_n[which] = n;
     return ZKPOR_OK;
-}
-int32_t zkpor_pk_set_g2_compressed(zkpor_pk* pk, int which, const uint8_t* compressed64, size_t n) {
+} ZK_ABI_CATCH
+int32_t zkpor_pk_set_g2_compressed(zkpor_pk* pk, int which, const uint8_t* compressed64, size_t n) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || which != ZKPOR_G2_B || (n && !compressed64)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
@@ -369,7 +369,7 @@ int32_t zkpor_pk_set_g2_compressed(zkpor_pk* pk, int which, const uint8_t* compr
     ZK_TRY(zk::decompress_to_device(ctx, true, compressed64, n, pk->g2_raw));
     pk->g2_raw_n = n;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"
 
@@ -440,7 +440,7 @@ extern "C" {
 int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, const void* delta, const void* beta2,
                             const void* delta2, int log2_domain, const uint8_t* inf_a, const uint8_t* inf_b,
                             size_t n_wires, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
-                            int z_order) {
+                            int z_order) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !alpha || !beta || !delta || !beta2 || !delta2 || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
@@ -453,9 +453,9 @@ int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, c
     }
     return zk_pk_finalize(pk, alpha, beta, delta, beta2, delta2, log2_domain, inf_a, inf_b, n_wires, removed.data(), n_public, z_order,
                           false, 0);
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, size_t n_committed, uint64_t seed) {
+int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, size_t n_committed, uint64_t seed) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || log2_domain < 1 || log2_domain > 28 || n_wires == 0 || n_public > n_wires) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
@@ -481,13 +481,13 @@ int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_p
     pk->ready = true;
     pk->shard = false;
     return pk_apply_tables(pk);
-}
+} ZK_ABI_CATCH
 
 /* the synthetic key with a CIRCUIT's sparsity instead of the seeded one: A / B1 / B2 are infinity exactly where inf_a / inf_b say
  * (gnark: a wire that appears in no L / R row), K exactly at the public wires and at removed_idx (the committed wires + the commitment
  * wire); the Pedersen bases hold n_basis points.  Same point generator, so oracle/trapdoor.py predicts every sum once it is given the masks. */
 int32_t zkpor_pk_synth_masked(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, const uint8_t* inf_a, const uint8_t* inf_b,
-                              const uint32_t* removed_idx, size_t n_removed, size_t n_basis, uint64_t seed) {
+                              const uint32_t* removed_idx, size_t n_removed, size_t n_basis, uint64_t seed) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || log2_domain < 1 || log2_domain > 28 || n_wires == 0 || n_public > n_wires || (n_removed && !removed_idx)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
@@ -529,17 +529,17 @@ int32_t zkpor_pk_synth_masked(zkpor_pk* pk, int log2_domain, size_t n_wires, siz
     pk->ready = true;
     pk->shard = false;
     return pk_apply_tables(pk);
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_pk_dims(zkpor_pk* pk, uint64_t dims[6]) {
+int32_t zkpor_pk_dims(zkpor_pk* pk, uint64_t dims[6]) try {
     if (!pk || !dims) return ZKPOR_E_ARG;
     if (!pk->ready) return ZKPOR_E_STATE;
     dims[0] = pk->n_wires; dims[1] = pk->n_public; dims[2] = pk->nC; dims[3] = pk->nZ;
     dims[4] = (uint64_t)pk->log2_domain; dims[5] = (uint64_t)pk->tab_m;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
+int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !dev_ptr || !n) return ZKPOR_E_ARG;
     if (!pk->ready) return ZKPOR_E_STATE;
@@ -554,15 +554,15 @@ int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
         default: return ZKPOR_E_ARG;
     }
     return ZKPOR_OK;
-}
-int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) {
+} ZK_ABI_CATCH
+int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !dev_ptr || !n || which != ZKPOR_G2_B) return ZKPOR_E_ARG;
     if (!pk->ready) return ZKPOR_E_STATE;
     if (pk->tab_m > 1) { pk->ctx->err = "pk: the arrays are interleaved fixed-base tables (msm_tables > 1), not plain point arrays"; return ZKPOR_E_STATE; }
     *dev_ptr = pk->B2; *n = pk->n_wires;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 // ------------------------------------------------------------------------------------------------ prove tail
 }  // extern "C"
@@ -600,9 +600,31 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         else
             ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     }
+    const hipStream_t caller_s = ctx->stream;
     hipStream_t main_s = ctx->stream, aux_s = ctx->aux_stream;
+    if (ctx->tail_reserve_cus > 0) {
+        // "tail_reserve_cus": everything the tail queues goes to two streams whose CU mask leaves some compute units free.  A mask bit i is
+        // compute unit i / 8 of XCD i % 8 on this part (the driver deals the bits round-robin over the XCDs), so clearing the first R bits
+        // frees R / 8 units on each of the eight XCDs.
+        if (!ctx->tail_stream) {
+            hipDeviceProp_t prop;
+            ZK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+            const int cus = prop.multiProcessorCount;
+            if (ctx->tail_reserve_cus >= cus) { ctx->err = "prove: tail_reserve_cus leaves the prove tail no compute unit"; return ZKPOR_E_ARG; }
+            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+            for (int i = ctx->tail_reserve_cus; i < cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+            ZK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->tail_stream, (uint32_t)mask.size(), mask.data()));
+            ZK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->tail_aux, (uint32_t)mask.size(), mask.data()));
+        }
+        main_s = ctx->tail_stream; aux_s = ctx->tail_aux;
+    }
     hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx), e_up = ev_get(ctx), e_wB = ev_get(ctx), e_wK = ev_get(ctx);
-    struct EvGuard { zkpor_ctx* c; hipEvent_t e[7]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up, e_wB, e_wK}, main_s};
+    struct EvGuard { zkpor_ctx* c; hipEvent_t e[7]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up, e_wB, e_wK}, caller_s};
+    if (main_s != caller_s) {   // whatever the caller queued on the context's stream (the solver, a / b / c, uploads) comes first
+        ZK_HIP(ctx, hipEventRecord(e_start, caller_s));
+        ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_start, 0));
+        ctx->stream = main_s;
+    }
     // per-array digit streams: B1 / B2 and K get the shared stream of w minus the entries of their absent points
     StreamFilter filt;
     if (ctx->msm_filter && do_w) { filt.absent[0] = pk->absentB; filt.absent[1] = pk->absentK; }
@@ -783,7 +805,7 @@ void jac_out(const XYZZ<F>& p, uint8_t* out) {
 extern "C" {
 
 int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, void* d_b, void* d_c,
-                             const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+                             const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || !d_w || !d_a || !d_b || !d_c || !r || !s || !proof_out) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
@@ -797,10 +819,10 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 int32_t zkpor_prove_tail_dev_keep(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_a, const void* d_b, const void* d_c, void* d_wa,
-                                  void* d_wb, void* d_wc, const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+                                  void* d_wb, void* d_wc, const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || !d_w || !d_a || !d_b || !d_c || !d_wa || !d_wb || !d_wc || !r || !s || !proof_out) return ZKPOR_E_ARG;
     if (d_wa == d_a || d_wb == d_b || d_wc == d_c) { ctx->err = "prove: the work buffers must differ from the inputs (use zkpor_prove_tail_dev to work in place)"; return ZKPOR_E_ARG; }
@@ -816,10 +838,10 @@ int32_t zkpor_prove_tail_dev_keep(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w,
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 // ---- single-proof split (BASELINE.json configs[4]): every GPU holds a contiguous range of each key array
-int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi) {
+int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = pk->ctx;
@@ -849,9 +871,9 @@ int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t
     pk_free_masks(pk);   // a shard's arrays were cut: it proves with the shared stream
     pk->ready = true;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_h, uint8_t sums_out[576]) {
+int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_h, uint8_t sums_out[576]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || (!d_w && !d_h) || !sums_out) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
@@ -860,10 +882,10 @@ int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, cons
     jac_out<Fp>(m.A, sums_out); jac_out<Fp>(m.B1, sums_out + 96); jac_out<Fp2>(m.B2, sums_out + 192);
     jac_out<Fp>(m.K, sums_out + 384); jac_out<Fp>(m.Z, sums_out + 480);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 int32_t zkpor_prove_assemble(const void* alpha, const void* beta, const void* delta, const void* beta2, const void* delta2,
-                             const uint8_t sums[576], const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+                             const uint8_t sums[576], const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) try {
     if (!alpha || !beta || !delta || !beta2 || !delta2 || !sums || !r || !s || !proof_out) return ZKPOR_E_ARG;
     ZK_TRY(check_blinding(nullptr, r, s));
     G1Affine a1, b1, d1; G2Affine b2, d2;
@@ -873,20 +895,20 @@ int32_t zkpor_prove_assemble(const void* alpha, const void* beta, const void* de
     m.K = jac_in<Fp>(sums + 384); m.Z = jac_in<Fp>(sums + 480);
     assemble(a1, b1, b2, m, blind_prepare(d1, d2, r, s), proof_out);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_pk_consts(zkpor_pk* pk, void* alpha, void* beta, void* delta, void* beta2, void* delta2) {
+int32_t zkpor_pk_consts(zkpor_pk* pk, void* alpha, void* beta, void* delta, void* beta2, void* delta2) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !alpha || !beta || !delta || !beta2 || !delta2) return ZKPOR_E_ARG;
     if (!pk->ready) { pk->ctx->err = "pk: key not loaded"; return ZKPOR_E_STATE; }
     memcpy(alpha, &pk->alpha, 64); memcpy(beta, &pk->beta, 64); memcpy(delta, &pk->delta, 64);
     memcpy(beta2, &pk->beta2, 128); memcpy(delta2, &pk->delta2, 128);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                          const uint64_t* c, size_t n_constraints, const uint64_t r[4], const uint64_t s[4],
-                         uint8_t proof_out[256]) {
+                         uint8_t proof_out[256]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || !w || !a || !b || !c || !r || !s || !proof_out) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
@@ -930,18 +952,19 @@ int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const 
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+        if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamSynchronize(ctx->tail_aux); }
         return rc;
     }
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 // Host-pointer form with the constraint matrices resident (zkpor_r1cs_*): only w crosses PCIe (n_wires x 32 B instead of
 // n_wires + 3 n_constraints); a, b, c are evaluated in the staging area, then the resident order of prove_sums runs
 // (computeH first, decompose + sort of w hidden under it).
 int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const uint64_t* w, const uint64_t r[4], const uint64_t s[4],
-                         uint8_t proof_out[256]) {
+                         uint8_t proof_out[256]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || !r1cs || !w || !r || !s || !proof_out) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
@@ -962,6 +985,7 @@ int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const u
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+        if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamSynchronize(ctx->tail_aux); }
     };
     GpuTurn turn;
     int32_t rc = host_upload(ctx, d_w, w, pk->n_wires * sizeof(Fr));
@@ -981,7 +1005,7 @@ int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const u
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 // groth16.Prove from the ASSIGNED INPUTS, everything after them on the device (SURVEY §8 f4 + f1 + a6): the inputs (1 + nPublic + nSecret
 // elements, gnark's order) cross PCIe, the solver program fills the wire vector in HBM (csrc/solver.hip), a, b, c are evaluated from it
@@ -989,7 +1013,7 @@ int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const u
 // BSB22 commitment drives the same steps itself (zkpor_solver_start_dev / _external_* / _resume_dev, zkpor_commit_dev, zkpor_r1cs_eval_dev,
 // zkpor_prove_tail_dev — INTEGRATION.md §1c).
 int32_t zkpor_prove_inputs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, zkpor_solver* solver, const uint64_t* inputs, size_t n_inputs,
-                           const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) {
+                           const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || !r1cs || !solver || !inputs || !r || !s || !proof_out) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "prove: key not loaded"; return ZKPOR_E_STATE; }
@@ -1012,6 +1036,7 @@ int32_t zkpor_prove_inputs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, zkpor
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+        if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamSynchronize(ctx->tail_aux); }
     };
     GpuTurn turn;
     int32_t rc = host_upload(ctx, d_w, inputs, n_inputs * sizeof(Fr));
@@ -1035,7 +1060,7 @@ int32_t zkpor_prove_inputs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, zkpor
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 // uniform Fr from the operating system's CSPRNG: 32 bytes from getrandom(2), top two bits cleared, rejected unless below the
 // modulus (acceptance ~ 0.76) — the construction of gnark-crypto's fr.Element.SetRandom.  The canonical limbs are used as the
@@ -1056,7 +1081,7 @@ static int32_t fr_random_os(zkpor_ctx* ctx, uint64_t out[4]) {
 }
 int32_t zkpor_prove_tail_rand(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                               const uint64_t* c, size_t n_constraints, uint64_t r_out[4], uint64_t s_out[4],
-                              uint8_t proof_out[256]) {
+                              uint8_t proof_out[256]) try {
     if (!ctx) return ZKPOR_E_ARG;
     uint64_t r[4], s[4];
     ZK_TRY(fr_random_os(ctx, r));
@@ -1065,9 +1090,9 @@ int32_t zkpor_prove_tail_rand(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, c
     if (r_out) memcpy(r_out, r, 32);
     if (s_out) memcpy(s_out, s, 32);
     return rc;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) {
+int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || (n && !d_values) || !out_commit || !out_pok) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "commit: key not loaded"; return ZKPOR_E_STATE; }
@@ -1095,8 +1120,8 @@ int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, siz
     G1Affine a1 = xyzz_to_affine<Fp>(c1), a2 = xyzz_to_affine<Fp>(c2);
     memcpy(out_commit, &a1, 64); memcpy(out_pok, &a2, 64);
     return ZKPOR_OK;
-}
-int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) {
+} ZK_ABI_CATCH
+int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || (n && !values) || !out_commit || !out_pok) return ZKPOR_E_ARG;
     if (!pk->ready) { ctx->err = "commit: key not loaded"; return ZKPOR_E_STATE; }
@@ -1113,7 +1138,7 @@ int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_
     // no turn on the device for these two short sums (common.cuh GpuTurn): they run next to whatever proof is on the GPU — waiting
     // for it would keep this caller from moving its proof's vectors across PCIe in the meantime
     return zkpor_commit_dev(ctx, pk, d, n, out_commit, out_pok);
-}
+} ZK_ABI_CATCH
 
 static void fp_be(const Fp& x, uint8_t* out) {
     Fp c = Fp::from_mont(x);
@@ -1133,15 +1158,15 @@ static void g2_raw(const Fp* p, uint8_t* out) {  // p = X.A0, X.A1, Y.A0, Y.A1 -
 }
 // G1Affine.Marshal() of one point handed out by this library (Montgomery limbs): X | Y big-endian, the identity as 0x40 | zeros.
 // What gnark hashes into the BSB22 challenge (constraint.SerializeCommitment).  Host arithmetic only.
-int32_t zkpor_g1_marshal(const uint8_t affine[64], uint8_t out[64]) {
+int32_t zkpor_g1_marshal(const uint8_t affine[64], uint8_t out[64]) try {
     if (!affine || !out) return ZKPOR_E_ARG;
     Fp xy[2];
     memcpy(xy, affine, 64);
     g1_raw(xy, out);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 int32_t zkpor_proof_write_raw(const uint8_t proof[256], const uint8_t* commitments, uint32_t n_commitments,
-                              const uint8_t pok[64], uint8_t* out, size_t out_cap, size_t* out_len) {
+                              const uint8_t pok[64], uint8_t* out, size_t out_cap, size_t* out_len) try {
     if (!proof || !out || !out_len || (n_commitments && (!commitments || !pok))) return ZKPOR_E_ARG;
     size_t need = 256 + 4 + (size_t)n_commitments * 64 + 64;
     if (out_cap < need) return ZKPOR_E_ARG;
@@ -1161,6 +1186,6 @@ int32_t zkpor_proof_write_raw(const uint8_t proof[256], const uint8_t* commitmen
     off += 64;
     *out_len = off;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"

@@ -76,6 +76,8 @@ inline MsmCfg msm_cfg(zkpor_ctx* ctx, size_t n, int tables = 1) {
 int32_t launch_decompose(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, u32* keys, u32* vals, u32* counter, const u32* absent0 = nullptr,
                          const u32* absent1 = nullptr);
 int32_t launch_filter(zkpor_ctx* ctx, const u32* keys, const u32* vals, u32 M, u32* seg_counts, u32 grid, u32* k0, u32* v0, u32* k1, u32* v1);
+// "debug_validate": checks a sorted stream on ctx->stream and WAITS for the verdict (msm_digits.hip)
+int32_t validate_stream(zkpor_ctx* ctx, const u32* keys, const u32* vals, u32 M, u32 NB, u32 n_idx, const char* what);
 constexpr u32 FILTER_MAX_GRID = 2048;
 // a digit-stream value = (point index << 1 | sign) in bits 0..29; bit 30 / 31 = the point is absent from array group 0 / 1
 constexpr u32 VAL_MASK = 0x3fffffffu, VAL_ABSENT0 = 1u << 30, VAL_ABSENT1 = 1u << 31;
@@ -114,6 +116,7 @@ struct DigitStream {  // sorted digits of one scalar vector, reusable across poi
     u32* keys = nullptr;
     u32* vals = nullptr;
     u32 M = 0;
+    u32 n_idx = 0;   // point indices the values may hold: scalars x tables (checked by "debug_validate")
 };
 
 // per-array streams (msm_digits.hip k_filter_write): up to two groups of arrays whose absent points are dropped from the shared stream
@@ -147,6 +150,7 @@ inline int32_t msm_digits(zkpor_ctx* ctx, const Fr* d_scalars, size_t n, const M
     char* temp = ws_alloc<char>(ctx, sort_temp + 256);
     if (!k0 || !k1 || !v0 || !v1 || !counter || !temp) { ctx->err = "msm: workspace too small"; return ZKPOR_E_OOM; }
     out->cfg = cfg;
+    out->n_idx = (u32)(n * (size_t)cfg.m);
     const bool flags_fit = n * (size_t)cfg.m < (1ull << 29);   // the absence flags live in bits 30 / 31 of a value
     {
         PhaseScope ps(ctx, "msm_decompose");
@@ -245,6 +249,7 @@ inline int32_t msm_accumulate_launch(zkpor_ctx* ctx, const DigitStream& ds, cons
         ctx->err = "msm: workspace too small"; return ZKPOR_E_OOM;
     }
     out->raw29 = raw;
+    if (ctx->debug_validate) ZK_TRY(validate_stream(ctx, ds.keys, ds.vals, M, (u32)cfg.NB, ds.n_idx, std::is_same<F, Fp>::value ? "G1" : "G2"));
     {
         PhaseScope ps(ctx, "msm_accumulate");
         if (raw) ZK_TRY(launch_level1_29(ctx, ds.keys, ds.vals, d_pts, M, L, (u32)cfg.NB, (u32*)buckets, ka, (u32*)pa));

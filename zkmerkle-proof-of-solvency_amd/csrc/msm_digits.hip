@@ -190,6 +190,40 @@ int32_t launch_filter(zkpor_ctx* ctx, const u32* keys, const u32* vals, u32 M, u
     return ZKPOR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ "debug_validate"
+// what the level-1 kernels take on trust: keys ascending and below the bucket count, point indices inside the array.  bad[0] = violations,
+// bad[1] = the first offending position, bad[2] / bad[3] = its key / value.
+__global__ __launch_bounds__(256) void k_validate_stream(const u32* __restrict__ keys, const u32* __restrict__ vals, u32 M, u32 NB, u32 n_idx, u32* __restrict__ bad) {
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < M; i += gridDim.x * 256u) {
+        const u32 k = keys[i], v = (vals[i] & VAL_MASK) >> 1;
+        if (k >= NB || (n_idx && v >= n_idx) || (i && keys[i - 1] > k)) {
+            atomicAdd(bad, 1u);
+            if (atomicMin(bad + 1, i) > i) { bad[2] = k; bad[3] = vals[i]; }
+        }
+    }
+}
+int32_t validate_stream(zkpor_ctx* ctx, const u32* keys, const u32* vals, u32 M, u32 NB, u32 n_idx, const char* what) {
+    if (!M) return ZKPOR_OK;
+    if (!ctx->dbg_buf) ZK_HIP(ctx, hipMalloc((void**)&ctx->dbg_buf, 16));
+    const u32 init[4] = {0u, 0xffffffffu, 0u, 0u};
+    u32 got[4] = {0, 0, 0, 0};
+    ZK_HIP(ctx, hipMemcpyAsync(ctx->dbg_buf, init, 16, hipMemcpyHostToDevice, ctx->stream));
+    u32 blocks = (M + 255u) / 256u;
+    if (blocks > 1024u) blocks = 1024u;
+    hipLaunchKernelGGL(k_validate_stream, dim3(blocks), dim3(256), 0, ctx->stream, keys, vals, M, NB, n_idx, ctx->dbg_buf);
+    ZK_KERNEL_CHECK(ctx);
+    ZK_HIP(ctx, hipMemcpyAsync(got, ctx->dbg_buf, 16, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (got[0]) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "msm: the sorted digit stream of a %s accumulation is corrupt: %u of %u entries (first at %u: key %u of %u buckets, value 0x%08x, %u point indices)",
+                 what, got[0], M, got[1], got[2], NB, got[3], n_idx);
+        ctx->err = msg;
+        return ZKPOR_E_STATE;
+    }
+    return ZKPOR_OK;
+}
+
 int32_t launch_decompose(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, u32* keys, u32* vals, u32* counter, const u32* absent0,
                          const u32* absent1) {
     u32 blocks = (n + 255u) / 256u;

@@ -918,7 +918,7 @@ using namespace zk;
 
 extern "C" {
 
-int32_t zkpor_fft(zkpor_ctx* ctx, uint64_t* a, int log2n, int inverse, int decimation, int on_coset) {
+int32_t zkpor_fft(zkpor_ctx* ctx, uint64_t* a, int log2n, int inverse, int decimation, int on_coset) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !a || log2n < 1 || log2n > 28) return ZKPOR_E_ARG;
     size_t bytes = ((size_t)32) << log2n;
@@ -931,34 +931,34 @@ int32_t zkpor_fft(zkpor_ctx* ctx, uint64_t* a, int log2n, int inverse, int decim
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     return rc;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_fft_dev(zkpor_ctx* ctx, void* d_a, int log2n, int inverse, int decimation, int on_coset) {
+int32_t zkpor_fft_dev(zkpor_ctx* ctx, void* d_a, int log2n, int inverse, int decimation, int on_coset) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_a || log2n < 1 || log2n > 28) return ZKPOR_E_ARG;
     return ntt_dev(ctx, (Fr*)d_a, log2n, inverse != 0, decimation == 1, on_coset != 0);
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_compute_h_shard_dev(zkpor_ctx* ctx, int log2_domain, int world_log2, int rank, void* d_a, void* d_b, void* d_c, int step) {
+int32_t zkpor_compute_h_shard_dev(zkpor_ctx* ctx, int log2_domain, int world_log2, int rank, void* d_a, void* d_b, void* d_c, int step) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_a || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
     if (step < 3 && (!d_b || !d_c)) return ZKPOR_E_ARG;
     return compute_h_shard_step(ctx, log2_domain, world_log2, rank, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, step);
-}
-int32_t zkpor_shard_transpose_dev(zkpor_ctx* ctx, void* d_out, const void* d_in, int log2_local, int world_log2, int interleave) {
+} ZK_ABI_CATCH
+int32_t zkpor_shard_transpose_dev(zkpor_ctx* ctx, void* d_out, const void* d_in, int log2_local, int world_log2, int interleave) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_out || !d_in || d_out == d_in || world_log2 < 1 || log2_local < 2 * world_log2) return ZKPOR_E_ARG;
     return shard_transpose(ctx, (Fr*)d_out, (const Fr*)d_in, log2_local, world_log2, interleave != 0);
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_compute_h_dev(zkpor_ctx* ctx, int log2_domain, void* d_a, void* d_b, void* d_c) {
+int32_t zkpor_compute_h_dev(zkpor_ctx* ctx, int log2_domain, void* d_a, void* d_b, void* d_c) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
     return compute_h_dev(ctx, log2_domain, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c);
-}
+} ZK_ABI_CATCH
 
 int32_t zkpor_compute_h(zkpor_ctx* ctx, int log2_domain, const uint64_t* a, const uint64_t* b, const uint64_t* c,
-                        size_t n_constraints, uint64_t* h_out) {
+                        size_t n_constraints, uint64_t* h_out) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !a || !b || !c || !h_out || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
     size_t N = (size_t)1 << log2_domain;
@@ -978,6 +978,6 @@ int32_t zkpor_compute_h(zkpor_ctx* ctx, int log2_domain, const uint64_t* a, cons
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     return rc;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"

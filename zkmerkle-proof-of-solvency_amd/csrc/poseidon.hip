@@ -1567,7 +1567,7 @@ using namespace zk;
 
 extern "C" {
 
-int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, size_t count, uint64_t* out) {
+int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, size_t count, uint64_t* out) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !inputs || !out || len < 1 || count == 0) return ZKPOR_E_ARG;
     PosDev P;
@@ -1586,14 +1586,14 @@ int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, 
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(din); (void)hipFree(dout);
     return rc;
-}
+} ZK_ABI_CATCH
 
 size_t zkpor_witgen_poseidon_sboxes(int t) {
     if (t != 3 && t != 5 && t != 6 && t != 13) return 0;
     return (size_t)POS_RF * t + (size_t)pos_rp(t);
 }
 
-int32_t zkpor_witgen_poseidon_trace_dev(zkpor_ctx* ctx, int t, void* d_states, size_t count, void* d_trace) {
+int32_t zkpor_witgen_poseidon_trace_dev(zkpor_ctx* ctx, int t, void* d_states, size_t count, void* d_trace) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_states || !d_trace || count == 0) return ZKPOR_E_ARG;
     if (t != 3 && t != 5 && t != 6 && t != 13) { ctx->err = "witgen: the circuit's Poseidon widths are 3, 5, 6 and 13"; return ZKPOR_E_ARG; }
@@ -1608,9 +1608,9 @@ int32_t zkpor_witgen_poseidon_trace_dev(zkpor_ctx* ctx, int t, void* d_states, s
     else hipLaunchKernelGGL(k_poseidon_trace<13>, grid, block, 0, ctx->stream, (Fr*)d_states, count, (Fr*)d_trace, P);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_witgen_limbs_dev(zkpor_ctx* ctx, const void* d_values, size_t n, int nb_limbs, void* d_limbs, void* d_multiplicity, void* d_bad) {
+int32_t zkpor_witgen_limbs_dev(zkpor_ctx* ctx, const void* d_values, size_t n, int nb_limbs, void* d_limbs, void* d_multiplicity, void* d_bad) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_values || !d_limbs || !d_multiplicity || !d_bad || n == 0 || nb_limbs < 1 || nb_limbs > 15) return ZKPOR_E_ARG;
     PhaseScope ps(ctx, "witgen_limbs");
@@ -1618,9 +1618,9 @@ int32_t zkpor_witgen_limbs_dev(zkpor_ctx* ctx, const void* d_values, size_t n, i
                        (u32*)d_multiplicity, (u32*)d_bad);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_witgen_inverse_dev(zkpor_ctx* ctx, const void* d_values, size_t n, const uint64_t challenge[4], void* d_out, void* d_bad) {
+int32_t zkpor_witgen_inverse_dev(zkpor_ctx* ctx, const void* d_values, size_t n, const uint64_t challenge[4], void* d_out, void* d_bad) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_values || !d_out || !d_bad || !challenge || n == 0) return ZKPOR_E_ARG;
     Fr c;
@@ -1630,18 +1630,18 @@ int32_t zkpor_witgen_inverse_dev(zkpor_ctx* ctx, const void* d_values, size_t n,
     hipLaunchKernelGGL(k_witgen_inverse, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, ctx->stream, (const Fr*)d_values, n, c, (Fr*)d_out, (u32*)d_bad);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_witgen_bits_dev(zkpor_ctx* ctx, const void* d_values, size_t n, int nbits, void* d_bits, void* d_bad) {
+int32_t zkpor_witgen_bits_dev(zkpor_ctx* ctx, const void* d_values, size_t n, int nbits, void* d_bits, void* d_bad) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_values || !d_bits || !d_bad || n == 0 || nbits < 1 || nbits > 254) return ZKPOR_E_ARG;
     PhaseScope ps(ctx, "witgen_bits");
     hipLaunchKernelGGL(k_witgen_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_values, n, nbits, (Fr*)d_bits, (u32*)d_bad);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_witgen_gather_dev(zkpor_ctx* ctx, const void* d_table, size_t table_len, const void* d_indices, size_t n, void* d_out, void* d_bad) {
+int32_t zkpor_witgen_gather_dev(zkpor_ctx* ctx, const void* d_table, size_t table_len, const void* d_indices, size_t n, void* d_out, void* d_bad) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_table || !d_indices || !d_out || !d_bad || n == 0 || table_len == 0 || table_len > 0xffffffffull) return ZKPOR_E_ARG;
     PhaseScope ps(ctx, "witgen_gather");
@@ -1649,9 +1649,9 @@ int32_t zkpor_witgen_gather_dev(zkpor_ctx* ctx, const void* d_table, size_t tabl
                        (Fr*)d_out, (u32*)d_bad);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_witgen_divmod_small_dev(zkpor_ctx* ctx, const void* d_values, size_t n, uint32_t divisor, void* d_quotient, void* d_remainder) {
+int32_t zkpor_witgen_divmod_small_dev(zkpor_ctx* ctx, const void* d_values, size_t n, uint32_t divisor, void* d_quotient, void* d_remainder) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_values || !d_quotient || !d_remainder || n == 0) return ZKPOR_E_ARG;
     if (divisor == 0) { ctx->err = "witgen: division by zero (big.Int.DivMod panics)"; return ZKPOR_E_ARG; }
@@ -1659,9 +1659,9 @@ int32_t zkpor_witgen_divmod_small_dev(zkpor_ctx* ctx, const void* d_values, size
     hipLaunchKernelGGL(k_witgen_divmod_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_values, n, divisor, (Fr*)d_quotient, (Fr*)d_remainder);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, const uint32_t* d_wire_ids, size_t n) {
+int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, const uint32_t* d_wire_ids, size_t n) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_w || !d_src || !d_wire_ids) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
@@ -1669,9 +1669,9 @@ int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, c
     hipLaunchKernelGGL(k_witgen_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_w, (const Fr*)d_src, d_wire_ids, n);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_witgen_scatter_known_dev(zkpor_ctx* ctx, void* d_w, uint8_t* d_known, const void* d_src, const uint32_t* d_wire_ids, size_t n) {
+int32_t zkpor_witgen_scatter_known_dev(zkpor_ctx* ctx, void* d_w, uint8_t* d_known, const void* d_src, const uint32_t* d_wire_ids, size_t n) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || ((!d_w || !d_known || !d_src || !d_wire_ids) && n)) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
@@ -1679,10 +1679,10 @@ int32_t zkpor_witgen_scatter_known_dev(zkpor_ctx* ctx, void* d_w, uint8_t* d_kno
     hipLaunchKernelGGL(k_witgen_scatter_known, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_w, d_known, (const Fr*)d_src, d_wire_ids, n);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, const zkpor_asset_t* assets,
-                              size_t n_assets_total, size_t n, int tier, uint8_t* out32) {
+                              size_t n_assets_total, size_t n, int tier, uint8_t* out32) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !accounts || !out32 || n == 0 || tier < 1 || (n_assets_total && !assets)) return ZKPOR_E_ARG;
     for (size_t i = 0; i < n; ++i) {
@@ -1708,10 +1708,10 @@ int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, c
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dacc); (void)hipFree(das); (void)hipFree(dout); (void)hipFree(dbe);
     return rc;
-}
+} ZK_ABI_CATCH
 
 int32_t zkpor_merkle_build_dev(zkpor_ctx* ctx, const void* d_leaves_mont, size_t n, int depth,
-                               const uint64_t nil_leaf_mont[4], uint64_t root_mont[4]) {
+                               const uint64_t nil_leaf_mont[4], uint64_t root_mont[4]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && !d_leaves_mont) || !nil_leaf_mont || !root_mont) return ZKPOR_E_ARG;
     Fr nil, root;
@@ -1719,10 +1719,10 @@ int32_t zkpor_merkle_build_dev(zkpor_ctx* ctx, const void* d_leaves_mont, size_t
     ZK_TRY(merkle_build_core(ctx, (const Fr*)d_leaves_mont, n, depth, nil, nullptr, &root));
     memcpy(root_mont, &root, 32);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n, int depth, const uint8_t nil_leaf[32],
-                           uint8_t* levels_out, uint8_t root_out[32]) {
+                           uint8_t* levels_out, uint8_t root_out[32]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && !leaves32_be) || !nil_leaf || !root_out) return ZKPOR_E_ARG;
     if (depth < 1 || depth > 32 || n > ((size_t)1 << depth)) { ctx->err = "merkle: bad depth / leaf count"; return ZKPOR_E_ARG; }
@@ -1750,10 +1750,10 @@ int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n,
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dbe); (void)hipFree(dleaves); if (dlev) (void)hipFree(dlev);
     return rc;
-}
+} ZK_ABI_CATCH
 
 // ---- FixedDepthMerkleTree -------------------------------------------------------------------------------------------
-int32_t zkpor_tree_create(zkpor_ctx* ctx, int depth, const uint8_t nil_leaf[32], uint64_t capacity, zkpor_tree** out) {
+int32_t zkpor_tree_create(zkpor_ctx* ctx, int depth, const uint8_t nil_leaf[32], uint64_t capacity, zkpor_tree** out) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !nil_leaf || !out) return ZKPOR_E_ARG;
     // NewFixedDepthMerkleTree panics on these (merkletree.go:138-146); here they are argument errors
@@ -1783,20 +1783,20 @@ int32_t zkpor_tree_create(zkpor_ctx* ctx, int depth, const uint8_t nil_leaf[32],
     t->root = t->nil_host[depth];  // root of the empty tree (:172)
     *out = t;
     return ZKPOR_OK;
-}
-void zkpor_tree_destroy(zkpor_tree* t) {
+} ZK_ABI_CATCH
+void zkpor_tree_destroy(zkpor_tree* t) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t) return;
     (void)hipStreamSynchronize(t->ctx->stream);
     tree_free(t);
-}
-int32_t zkpor_tree_nil_hash(zkpor_tree* t, int level, uint8_t out[32]) {
+} catch (...) { zk::abi_exception("exception in zkpor_tree_destroy"); }
+int32_t zkpor_tree_nil_hash(zkpor_tree* t, int level, uint8_t out[32]) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || !out || level < 0 || level > t->depth) return ZKPOR_E_ARG;
     fr_to_be_host(t->nil_host[level], out);
     return ZKPOR_OK;
-}
-int32_t zkpor_tree_set(zkpor_tree* t, const uint32_t* keys, const uint8_t* values32_be, size_t n) {
+} ZK_ABI_CATCH
+int32_t zkpor_tree_set(zkpor_tree* t, const uint32_t* keys, const uint8_t* values32_be, size_t n) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && (!keys || !values32_be))) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = t->ctx;
@@ -1813,8 +1813,8 @@ int32_t zkpor_tree_set(zkpor_tree* t, const uint32_t* keys, const uint8_t* value
     ZK_KERNEL_CHECK(ctx);
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-}
-int32_t zkpor_tree_set_range_dev(zkpor_tree* t, uint64_t first_key, const void* d_leaves_mont, size_t n) {
+} ZK_ABI_CATCH
+int32_t zkpor_tree_set_range_dev(zkpor_tree* t, uint64_t first_key, const void* d_leaves_mont, size_t n) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && !d_leaves_mont)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = t->ctx;
@@ -1823,8 +1823,8 @@ int32_t zkpor_tree_set_range_dev(zkpor_tree* t, uint64_t first_key, const void* 
     hipLaunchKernelGGL(k_tree_set_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, t->dev, (u64)first_key, (const Fr*)d_leaves_mont, n);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-}
-int32_t zkpor_tree_build(zkpor_tree* t) {
+} ZK_ABI_CATCH
+int32_t zkpor_tree_build(zkpor_tree* t) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = t->ctx;
@@ -1848,13 +1848,13 @@ int32_t zkpor_tree_build(zkpor_tree* t) {
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     t->root = (bit & 1u) ? top : t->nil_host[t->depth];
     return ZKPOR_OK;
-}
-int32_t zkpor_tree_root(zkpor_tree* t, uint8_t out[32]) {
+} ZK_ABI_CATCH
+int32_t zkpor_tree_root(zkpor_tree* t, uint8_t out[32]) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || !out) return ZKPOR_E_ARG;
     fr_to_be_host(t->root, out);
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 static int32_t tree_query(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out, bool proofs) {
     zkpor_ctx* ctx = t->ctx;
     if (n == 0) return ZKPOR_OK;
@@ -1870,12 +1870,12 @@ static int32_t tree_query(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
 }
-int32_t zkpor_tree_get(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out32) {
+int32_t zkpor_tree_get(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out32) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && (!keys || !out32))) return ZKPOR_E_ARG;
     return tree_query(t, keys, n, out32, false);  // keys >= capacity read as nil (:288-290)
-}
-int32_t zkpor_tree_get_proofs(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out) {
+} ZK_ABI_CATCH
+int32_t zkpor_tree_get_proofs(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && (!keys || !out))) return ZKPOR_E_ARG;
     for (size_t i = 0; i < n; ++i)
@@ -1884,9 +1884,9 @@ int32_t zkpor_tree_get_proofs(zkpor_tree* t, const uint32_t* keys, size_t n, uin
             return ZKPOR_E_ARG;
         }
     return tree_query(t, keys, n, out, true);
-}
+} ZK_ABI_CATCH
 int32_t zkpor_merkle_verify_proofs(zkpor_ctx* ctx, const uint8_t root[32], const uint32_t* keys, const uint8_t* proofs,
-                                   const uint8_t* leaves32_be, size_t n, int depth, uint8_t* ok_out) {
+                                   const uint8_t* leaves32_be, size_t n, int depth, uint8_t* ok_out) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !root || (n && (!keys || !proofs || !leaves32_be || !ok_out))) return ZKPOR_E_ARG;
     if (depth < 1 || depth > 32) { ctx->err = "merkle: bad depth"; return ZKPOR_E_ARG; }
@@ -1903,11 +1903,11 @@ int32_t zkpor_merkle_verify_proofs(zkpor_ctx* ctx, const uint8_t root[32], const
     ZK_HIP(ctx, hipMemcpyAsync(ok_out, dok.p, n, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 // ---- CEX asset-list commitments / batch commitments -------------------------------------------------------------------
 int32_t zkpor_cex_commitments(zkpor_ctx* ctx, const zkpor_cex_asset_const_t* assets, size_t n_assets, const zkpor_cex_totals_t* totals,
-                              size_t n_states, uint8_t* out32) {
+                              size_t n_states, uint8_t* out32) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !assets || !totals || !out32 || n_assets == 0 || n_assets > 0xffffu) return ZKPOR_E_ARG;
     if (n_states == 0) return ZKPOR_OK;
@@ -1938,9 +1938,9 @@ int32_t zkpor_cex_commitments(zkpor_ctx* ctx, const zkpor_cex_asset_const_t* ass
     ZK_HIP(ctx, hipMemcpyAsync(out32, dbe.p, n_states * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 int32_t zkpor_batch_commitments(zkpor_ctx* ctx, const uint8_t* roots32, const uint8_t* before32, const uint8_t* after32,
-                                const uint32_t* min_index, const uint32_t* max_index, size_t n, uint8_t* out32) {
+                                const uint32_t* min_index, const uint32_t* max_index, size_t n, uint8_t* out32) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && (!roots32 || !before32 || !after32 || !min_index || !max_index || !out32))) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
@@ -1958,11 +1958,11 @@ int32_t zkpor_batch_commitments(zkpor_ctx* ctx, const uint8_t* roots32, const ui
     ZK_HIP(ctx, hipMemcpyAsync(out32, dbe.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 // ---- account totals / collateral tiers ----------------------------------------------------------------------------------
 int32_t zkpor_account_totals(zkpor_ctx* ctx, zkpor_account_t* accounts, const zkpor_asset_t* assets, size_t n_assets_total, size_t n,
-                             const zkpor_cex_asset_const_t* cex, size_t n_cex, uint8_t* tier_info_out, uint8_t* valid_out) {
+                             const zkpor_cex_asset_const_t* cex, size_t n_cex, uint8_t* tier_info_out, uint8_t* valid_out) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !accounts || !cex || n_cex == 0 || (n_assets_total && !assets)) return ZKPOR_E_ARG;
     if (n == 0) return ZKPOR_OK;
@@ -1986,7 +1986,7 @@ int32_t zkpor_account_totals(zkpor_ctx* ctx, zkpor_account_t* accounts, const zk
     if (valid_out) ZK_HIP(ctx, hipMemcpyAsync(valid_out, dv.p, n, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 // ---- accounts straight into the tree -------------------------------------------------------------------------------------
 // buildAccountTree (src/witness/main.go:130-199) for one chunk of accounts, without the leaves ever leaving the device:
@@ -1994,7 +1994,7 @@ int32_t zkpor_account_totals(zkpor_ctx* ctx, zkpor_account_t* accounts, const zk
 // set through this in chunks and calls zkpor_tree_build once.
 int32_t zkpor_tree_set_accounts(zkpor_tree* t, uint64_t first_key, zkpor_account_t* accounts, const zkpor_asset_t* assets,
                                 size_t n_assets_total, size_t n, int tier, const zkpor_cex_asset_const_t* cex_or_null, size_t n_cex,
-                                uint8_t* valid_out_or_null) {
+                                uint8_t* valid_out_or_null) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || !accounts || n == 0 || tier < 1 || (n_assets_total && !assets)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = t->ctx;
@@ -2032,6 +2032,6 @@ int32_t zkpor_tree_set_accounts(zkpor_tree* t, uint64_t first_key, zkpor_account
     }
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"

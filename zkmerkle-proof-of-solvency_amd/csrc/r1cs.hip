@@ -137,7 +137,7 @@ void r1cs_dims(const zkpor_r1cs* r, size_t* n_constraints, size_t* n_wires, int*
 extern "C" {
 
 int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, const uint64_t* coeff_table, size_t n_coeff,
-                          zkpor_r1cs** out) {
+                          zkpor_r1cs** out) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out || !coeff_table || n_coeff == 0 || n_wires == 0 || n_wires > 0xffffffffull) return ZKPOR_E_ARG;
     zkpor_r1cs* r = new zkpor_r1cs();
@@ -158,15 +158,15 @@ int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, 
         hipMemcpy(r->coeff_kind, kind.data(), n_coeff, hipMemcpyHostToDevice) != hipSuccess) { r1cs_free(r); ctx->err = "r1cs: H2D failed"; return ZKPOR_E_HIP; }
     *out = r;
     return ZKPOR_OK;
-}
-void zkpor_r1cs_destroy(zkpor_r1cs* r) {
+} ZK_ABI_CATCH
+void zkpor_r1cs_destroy(zkpor_r1cs* r) try {
     ZK_ENTER(r ? r->ctx->device : -1);
     if (!r) return;
     (void)hipStreamSynchronize(r->ctx->stream);
     r1cs_free(r);
-}
+} catch (...) { zk::abi_exception("exception in zkpor_r1cs_destroy"); }
 int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr, const uint32_t* coeff_ids, const uint32_t* wire_ids,
-                              size_t nnz) {
+                              size_t nnz) try {
     ZK_ENTER(r ? r->ctx->device : -1);
     if (!r || which < 0 || which > 2 || !row_ptr || (nnz && (!coeff_ids || !wire_ids))) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = r->ctx;
@@ -197,20 +197,20 @@ int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr,
     }
     r->nnz[which] = nnz;
     return ZKPOR_OK;
-}
-int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
+} ZK_ABI_CATCH
+int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) try {
     ZK_ENTER(r ? r->ctx->device : -1);
     if (!r) return ZKPOR_E_ARG;
     return zk::r1cs_eval_on(r->ctx, r, d_w, d_a, d_b, d_c, domain_size);
-}
+} ZK_ABI_CATCH
 /* the same queued on ANOTHER context of the GPU (a second worker's stream and timers; the matrices are only read) */
-int32_t zkpor_r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
+int32_t zkpor_r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !r) return ZKPOR_E_ARG;
     return zk::r1cs_eval_on(ctx, r, d_w, d_a, d_b, d_c, domain_size);
-}
+} ZK_ABI_CATCH
 /* every constraint against a wire vector on the device: counts[0] = rows with L.w * R.w != O.w, counts[1] = the lowest such row */
-int32_t zkpor_r1cs_check_dev(zkpor_r1cs* r, const void* d_w, uint64_t counts[2]) {
+int32_t zkpor_r1cs_check_dev(zkpor_r1cs* r, const void* d_w, uint64_t counts[2]) try {
     ZK_ENTER(r ? r->ctx->device : -1);
     if (!r || !d_w || !counts) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = r->ctx;
@@ -231,9 +231,9 @@ int32_t zkpor_r1cs_check_dev(zkpor_r1cs* r, const void* d_w, uint64_t counts[2])
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_out);
     return rc;
-}
+} ZK_ABI_CATCH
 /* host-buffer form for tests and small circuits: w in, a/b/c (n_constraints each) out */
-int32_t zkpor_r1cs_eval(zkpor_r1cs* r, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c) {
+int32_t zkpor_r1cs_eval(zkpor_r1cs* r, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c) try {
     ZK_ENTER(r ? r->ctx->device : -1);
     if (!r || !w || !a || !b || !c) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = r->ctx;
@@ -250,6 +250,6 @@ int32_t zkpor_r1cs_eval(zkpor_r1cs* r, const uint64_t* w, uint64_t* a, uint64_t*
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     return rc;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"

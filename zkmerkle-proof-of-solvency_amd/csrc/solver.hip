@@ -704,13 +704,13 @@ zkpor_r1cs* solver_r1cs(zkpor_solver* s) { return s->r1cs; }
 using namespace zk;
 extern "C" {
 
-int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t len, zkpor_solver** out) {
+int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t len, zkpor_solver** out) try {
     return zkpor_solver_create_on(r1cs ? r1cs->ctx : nullptr, r1cs, container, len, out);
-}
+} ZK_ABI_CATCH
 
 /* the same program bound to ANOTHER context of the GPU the matrices live on: its launches, phase timers and error text belong to `ctx`, the
  * matrices are only read — one solver per worker context, all over one zkpor_r1cs (two workers of a GPU solve side by side) */
-int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* container, size_t len, zkpor_solver** out) {
+int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* container, size_t len, zkpor_solver** out) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !r1cs || !container || !out) return ZKPOR_E_ARG;
     if (ctx->device != r1cs->ctx->device) { ctx->err = "solver: the constraint matrices live on another GPU than the context"; return ZKPOR_E_ARG; }
@@ -886,18 +886,18 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     if (!ok) { (void)hipGetLastError(); solver_free(s); ctx->err = "solver: out of device memory"; return ZKPOR_E_OOM; }
     *out = s;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-void zkpor_solver_destroy(zkpor_solver* s) {
+void zkpor_solver_destroy(zkpor_solver* s) try {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s) return;
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->side) (void)hipStreamSynchronize(s->side);
     if (s->side2) (void)hipStreamSynchronize(s->side2);
     solver_free(s);
-}
+} catch (...) { zk::abi_exception("exception in zkpor_solver_destroy"); }
 
-int32_t zkpor_solver_dims(const zkpor_solver* s, uint64_t dims[7]) {
+int32_t zkpor_solver_dims(const zkpor_solver* s, uint64_t dims[7]) try {
     if (!s || !dims) return ZKPOR_E_ARG;
     dims[0] = s->view.n_instructions; dims[1] = s->view.n_levels; dims[2] = s->n_r1c; dims[3] = s->n_hint + s->n_lookup + s->n_poseidon; dims[4] = s->n_skip;
     uint64_t ext = 0;
@@ -905,9 +905,9 @@ int32_t zkpor_solver_dims(const zkpor_solver* s, uint64_t dims[7]) {
     dims[5] = ext;
     dims[6] = s->launches;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint8_t* d_known_or_null, uint32_t* paused_instr) {
+int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint8_t* d_known_or_null, uint32_t* paused_instr) try {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || !d_w || !paused_instr) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
@@ -927,20 +927,20 @@ int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint
     s->checks_left = s->abc_a != nullptr && ctx->solver_defer_checks != 0 && s->n_check > 0;   // zkpor_solver_eval_abc_dev verifies a x b = c on every row instead
     s->running = true; s->next_level = 0; s->pending.clear(); s->launches = 0;
     return solver_advance(s, paused_instr);
-}
+} ZK_ABI_CATCH
 
 /* a, b, c (domain-size buffers of the prove tail) for the NEXT runs: the Poseidon instructions then write the rows of their own constraints
  * while they have the S-box inputs in registers (two thirds of all terms of the real circuit's matrices sit in those rows);
  * zkpor_solver_eval_abc_dev evaluates the rest.  NULL pointers switch it off.  ASYNC / prefetched instructions never write rows. */
-int32_t zkpor_solver_set_abc_dev(zkpor_solver* s, void* d_a, void* d_b, void* d_c) {
+int32_t zkpor_solver_set_abc_dev(zkpor_solver* s, void* d_a, void* d_b, void* d_c) try {
     if (!s) return ZKPOR_E_ARG;
     if ((d_a || d_b || d_c) && !(d_a && d_b && d_c)) { s->ctx->err = "solver: a, b, c are given together or not at all"; return ZKPOR_E_ARG; }
     s->abc_a = (Fr*)d_a; s->abc_b = (Fr*)d_b; s->abc_c = (Fr*)d_c;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 /* a, b, c = L.w, R.w, O.w for every row the finished run has not written already (all rows when zkpor_solver_set_abc_dev was not used), zero
  * padding up to domain_size; into the buffers given to zkpor_solver_set_abc_dev, or d_a / d_b / d_c when it was not used */
-int32_t zkpor_solver_eval_abc_dev(zkpor_solver* s, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) {
+int32_t zkpor_solver_eval_abc_dev(zkpor_solver* s, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) try {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || !d_w || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
@@ -962,13 +962,13 @@ int32_t zkpor_solver_eval_abc_dev(zkpor_solver* s, const void* d_w, void* d_a, v
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h[0]) { ctx->err = "solver: " + std::to_string(h[0]) + " constraints are not satisfied, the first one is #" + std::to_string(h[1]); return ZKPOR_E_STATE; }
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 /* the ASYNC instructions of the NEXT proof (the two CEX commitments: 834 chained permutations each, ~0.2 s of one wave) started on the side
  * stream while the current proof still runs its prove tail: d_w_next holds the next assignment (wire 0 = ONE, then the inputs) and must be the
  * vector the next zkpor_solver_start_dev is given — that run then skips them and joins the side stream in front of its last level.  They must
  * sit in the first level (they read inputs only).  One prefetch at a time. */
-int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inputs) {
+int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inputs) try {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || !d_w_next) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
@@ -997,14 +997,14 @@ int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inpu
     s->prefetched_w = d_w_next;
     (void)n_inputs;
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_solver_resume_dev(zkpor_solver* s, uint32_t* paused_instr) {
+int32_t zkpor_solver_resume_dev(zkpor_solver* s, uint32_t* paused_instr) try {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || !paused_instr) return ZKPOR_E_ARG;
     if (!s->running) { s->ctx->err = "solver: no run to resume"; return ZKPOR_E_STATE; }
     return solver_advance(s, paused_instr);
-}
+} ZK_ABI_CATCH
 
 // evaluates the inputs of the external hint the run is paused at into d_out (device, n_in elements); synchronous
 static int32_t hint_inputs_to(zkpor_solver* s, uint32_t instr, Fr* d_out) {
@@ -1020,7 +1020,7 @@ static int32_t hint_inputs_to(zkpor_solver* s, uint32_t instr, Fr* d_out) {
     return ZKPOR_OK;
 }
 
-int32_t zkpor_solver_external_inputs(zkpor_solver* s, uint32_t instr, uint64_t* in_values, size_t capacity, size_t* n_in, size_t* n_out) {
+int32_t zkpor_solver_external_inputs(zkpor_solver* s, uint32_t instr, uint64_t* in_values, size_t capacity, size_t* n_in, size_t* n_out) try {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || !n_in || !n_out) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
@@ -1034,10 +1034,10 @@ int32_t zkpor_solver_external_inputs(zkpor_solver* s, uint32_t instr, uint64_t* 
     ZK_TRY(hint_inputs_to(s, instr, s->d_tmp));
     ZK_HIP(ctx, hipMemcpy(in_values, s->d_tmp, (size_t)cd[1] * sizeof(Fr), hipMemcpyDeviceToHost));
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 /* the same into device memory (d_out: capacity elements): the committed wires of a BSB22 commitment go straight to zkpor_commit_dev */
-int32_t zkpor_solver_external_inputs_dev(zkpor_solver* s, uint32_t instr, void* d_out, size_t capacity) {
+int32_t zkpor_solver_external_inputs_dev(zkpor_solver* s, uint32_t instr, void* d_out, size_t capacity) try {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || !d_out) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
@@ -1045,9 +1045,9 @@ int32_t zkpor_solver_external_inputs_dev(zkpor_solver* s, uint32_t instr, void* 
     const uint32_t* cd = s->view.calldata + s->view.arg[instr];
     if (capacity < cd[1]) { ctx->err = "solver: the buffer holds fewer elements than the hint has inputs"; return ZKPOR_E_ARG; }
     return hint_inputs_to(s, instr, (Fr*)d_out);
-}
+} ZK_ABI_CATCH
 
-int32_t zkpor_solver_external_outputs(zkpor_solver* s, uint32_t instr, const uint64_t* out_values, size_t n_out) {
+int32_t zkpor_solver_external_outputs(zkpor_solver* s, uint32_t instr, const uint64_t* out_values, size_t n_out) try {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || (!out_values && n_out)) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
@@ -1063,12 +1063,12 @@ int32_t zkpor_solver_external_outputs(zkpor_solver* s, uint32_t instr, const uin
     }
     s->pending.erase(s->pending.begin());
     return ZKPOR_OK;
-}
+} ZK_ABI_CATCH
 
 /* host-buffer form: inputs in, full wire vector out; pre-filled wires (the device generators' in a real run) given as (id, value) pairs;
  * external hints are NOT served here (the call fails with ZKPOR_E_STATE when it meets one) */
 int32_t zkpor_solver_run(zkpor_solver* s, const uint64_t* inputs, size_t n_inputs, const uint32_t* pre_ids, const uint64_t* pre_vals, size_t n_pre,
-                         uint64_t* w_out, uint64_t stats[4]) {
+                         uint64_t* w_out, uint64_t stats[4]) try {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || !inputs || !w_out || (n_pre && (!pre_ids || !pre_vals))) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
@@ -1093,6 +1093,6 @@ int32_t zkpor_solver_run(zkpor_solver* s, const uint64_t* inputs, size_t n_input
     if (rc == ZKPOR_OK) ZK_HIP(ctx, hipMemcpy(w_out, tw.p, nw * sizeof(Fr), hipMemcpyDeviceToHost));
     if (stats) { stats[0] = s->n_r1c; stats[1] = s->n_hint + s->n_lookup + s->n_poseidon; stats[2] = s->n_skip; stats[3] = s->launches; }
     return rc;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"
