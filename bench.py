@@ -122,7 +122,23 @@ def mixture_scalars(seed, n, fill_kind, mix=None):
     return out
 
 
-def cpu_baseline(log2_sample, log2_full, commit_frac, fill_kind=1, mixture="25% {0,1}, 20% <2^16, 5% <2^64, 50% uniform", mix=None):
+def cpu_solver_leg(cir, inputs, threads):
+    """the solver leg of the CPU baseline: the compiled circuit's solver program (the same container the device executes) on host/solver_exec.hpp
+    — the levelized host executor, `threads` threads, the FULL production program, no sampling — from the assigned inputs to the full wire vector.
+    gnark's own solver cannot run here (no Go); this is this repo's host executor, faster per instruction than an interpreter of gnark's blueprint
+    calls (one inversion per thread and level, coefficient classes), so it flatters the CPU side."""
+    import circuit as C
+    cm = C.default_commitment()
+    best = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter()
+        w = cir.solve_host(inputs, cm, threads=threads, check_rows=False)
+        best = min(best, time.perf_counter() - t0)
+        del w
+    return best
+
+
+def cpu_baseline(log2_sample, log2_full, commit_frac, fill_kind=1, mixture="25% {0,1}, 20% <2^16, 5% <2^64, 50% uniform", mix=None, solver=None):
     """The CPU baseline, kind "port": oracle/cpubase.hpp — what groth16.Prove does after the solver, organised as gnark /
     gnark-crypto organise it (no-carry Montgomery on 4 x 64-bit limbs, signed-digit c = 16 Pippenger with extended-Jacobian
     buckets split over (window, chunk) tasks, zero digits skipped, cache-blocked radix-2 FFT), on ALL host cores, at a bounded sample of
@@ -154,13 +170,24 @@ def cpu_baseline(log2_sample, log2_full, commit_frac, fill_kind=1, mixture="25% 
     dt = fft_s + g1_s + g2_s + com_s
     dt_u = sum(runs["uniform"])
     scale = float(1 << (log2_full - log2_sample))
-    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cores, "cores_source": why, "kind": "port",
-            "seconds_per_proof_scaled": dt * scale, "core_seconds_per_proof_scaled": dt * scale * cores,
+    solver_s = None
+    solver_note = ""
+    if solver is not None:      # (compiled circuit, assigned inputs): the headline is groth16.Prove end to end, so is the baseline
+        try:
+            solver_s = cpu_solver_leg(solver[0], solver[1], cores)
+            solver_note = (f" + the solver: the compiled circuit's FULL solver program ({solver[0].n_instructions} instructions) on host/solver_exec.hpp, {cores} threads, "
+                           f"{solver_s:.2f}s (not sampled, not scaled)")
+        except Exception as e:      # noqa: BLE001
+            solver_note = f" (solver leg failed: {e})"
+    total_s = dt * scale + (solver_s or 0.0)
+    return {"value": 1.0 / total_s, "unit": "proofs/s", "cores": cores, "cores_source": why, "kind": "port",
+            "seconds_per_proof_scaled": total_s, "core_seconds_per_proof_scaled": total_s * cores,
+            "prove_tail_seconds_scaled": dt * scale, "solver_seconds": solver_s, "value_prove_tail_only": 1.0 / (dt * scale),
             "value_uniform_scalars": 1.0 / (dt_u * scale), "core_seconds_per_proof_scaled_uniform_scalars": dt_u * scale * cores,
             "sample": f"oracle/cpubase.hpp prove tail (computeH {fft_s:.2f}s + 4 G1 MultiExp {g1_s:.2f}s + G2 MultiExp {g2_s:.2f}s + "
                       f"2 commitment MultiExp {com_s:.2f}s = {dt:.2f}s) at D=2^{log2_sample} on {cores} threads with the witness scalar mixture of the "
                       f"headline ({mixture}; Z.h over the computed h), {dt_u:.2f}s with uniform scalars, "
-                      f"scaled x{int(scale)} to D=2^{log2_full}; anchor: the reference publishes 62 s per proof INCLUDING the solver on "
+                      f"scaled x{int(scale)} to D=2^{log2_full}{solver_note}; anchor: the reference publishes 62 s per proof INCLUDING the solver on "
                       "32 vCPU for gnark = 1984 vCPU-seconds (docs/updated_proof_of_solvency_to_mitigate_dummy_user_attack.md:201)"}
 
 
@@ -909,6 +936,115 @@ def split_main(args, torch, zkpor, ctx, dist, rank, world, json_fd):
     pk.close()
 
 
+class EndToEnd:
+    """groth16.Prove as src/prover/prover/prover.go:254-274 brackets it, on the device: assigned inputs -> solver program (the BSB22 commitment
+    served by pause / resume: zkpor_commit_dev + the challenge hashed on the host) -> a, b, c -> prove tail.  One or several WORKERS of one GPU
+    (host/prover_host.hpp runs them as threads): a worker is a context + its own solver program (the matrices are shared), two wire vectors that
+    take turns (while proof i runs a, b, c and its tail, proof i + 1's assignment is already in the other one and its two CEX commitment chains —
+    834 serial permutations each — run on the solver's side stream: zkpor_solver_prefetch_dev), a, b, c and the commitment's inputs.  With two
+    workers one proof's solve runs beside the other's prove tail; "tail_reserve_cus" keeps a few compute units out of the tail's CU mask so that
+    the solve's ~100 narrow dependent launches do not queue behind full-size MSM grids."""
+
+    def __init__(self, torch, zkpor, C, ctx, local_rank, pk, cir, dc0, d_in, inputs_host, D, n_commit, dev, blinding, abc0, workers, reserve_cus,
+                 solver_rows=True, prefetch=True, aux_masked=-1):
+        self.torch, self.zkpor, self.C, self.pk, self.cir, self.D, self.blinding = torch, zkpor, C, pk, cir, D, blinding
+        self.d_in, self.inputs_host, self.prefetch, self.solver_rows = d_in, inputs_host, prefetch, solver_rows
+        self.n_in = cir.n_public + cir.n_secret
+        self.reserve = reserve_cus if workers > 1 else 0
+        self.wk = []
+        n_wires = cir.n_wires
+        for k in range(workers):
+            wctx = ctx if k == 0 else zkpor.Context(local_rank, None)
+            wdc = dc0 if k == 0 else C.DeviceCircuit(wctx, cir, share=dc0)
+            a, b, c = abc0 if k == 0 else (dev(32 * D), dev(32 * D), dev(32 * D))
+            self.wk.append({"ctx": wctx, "dc": wdc, "w": [dev(32 * n_wires), dev(32 * n_wires)], "cv": dev(32 * (n_commit + 1)), "a": a, "b": b, "c": c, "k": 0,
+                            "last": None, "own": k > 0})
+        for wk in self.wk:
+            wk["ctx"].set_param("tail_reserve_cus", self.reserve)
+            if aux_masked >= 0:
+                wk["ctx"].set_param("tail_aux_masked", aux_masked)
+            if solver_rows:
+                wk["dc"].solver.set_abc_dev(wk["a"].data_ptr(), wk["b"].data_ptr(), wk["c"].data_ptr())
+            if prefetch:
+                C.stage_inputs(wk["ctx"], wk["dc"], wk["w"][0].data_ptr(), d_in.data_ptr())
+                wk["dc"].solver.prefetch_dev(wk["w"][0].data_ptr(), self.n_in)
+
+    def proof(self, wk, i, upload=False):
+        C, D = self.C, self.D
+        tm = {}
+        t0 = time.perf_counter()
+        cur = wk["w"][wk["k"] % 2]; nxt = wk["w"][(wk["k"] + 1) % 2]
+        wk["k"] += 1
+        src = self.inputs_host if upload else self.d_in.data_ptr()          # upload: the assigned inputs come from pageable host memory, every proof
+        if not self.prefetch:
+            C.stage_inputs(wk["ctx"], wk["dc"], cur.data_ptr(), src)
+        com, pok, _ch = C.solve_on_device(wk["ctx"], wk["dc"], self.pk, cur.data_ptr(), wk["cv"].data_ptr(), self.d_in.data_ptr(), tm, staged=True)
+        t1 = time.perf_counter()
+        if self.prefetch:
+            C.stage_inputs(wk["ctx"], wk["dc"], nxt.data_ptr(), src)
+            wk["dc"].solver.prefetch_dev(nxt.data_ptr(), self.n_in)
+        wk["dc"].solver.eval_abc_dev(cur.data_ptr(), wk["a"].data_ptr(), wk["b"].data_ptr(), wk["c"].data_ptr(), D)     # the rows the Poseidon instructions have not written already
+        r, s = self.blinding(i)
+        proof = wk["ctx"].prove_tail_dev(self.pk, cur.data_ptr(), wk["a"].data_ptr(), wk["b"].data_ptr(), wk["c"].data_ptr(), r, s)
+        tm["abc_and_prove_tail_ms"] = (time.perf_counter() - t1) * 1e3
+        tm["total_ms"] = (time.perf_counter() - t0) * 1e3
+        wk["last"] = cur
+        return proof, com, pok, tm
+
+    def run(self, first, n, sink, tm_acc=None, upload=False):
+        """n proofs in total, ids first .. first + n - 1, dealt round-robin to the workers; returns when every one is done and the device is idle"""
+        import threading
+        errs = []
+        lock = threading.Lock()
+
+        def loop(k):
+            try:
+                for i in range(first + k, first + n, len(self.wk)):
+                    proof, com, pok, tm = self.proof(self.wk[k], i, upload)
+                    with lock:
+                        if sink is not None:
+                            sink.append((i, proof, com, pok))
+                        if tm_acc is not None:
+                            for k_, v_ in tm.items():
+                                tm_acc[k_] = tm_acc.get(k_, 0.0) + v_
+            except Exception as e:      # noqa: BLE001 — surfaced below
+                errs.append(e)
+
+        if len(self.wk) == 1:
+            loop(0)
+        else:
+            th = [threading.Thread(target=loop, args=(k,)) for k in range(len(self.wk))]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+        self.torch.cuda.synchronize()
+        if errs:
+            raise errs[0]
+
+    def phase_reset(self):
+        for wk in self.wk:
+            wk["ctx"].phase_reset()
+
+    def phase_ms(self, name):
+        ms = 0.0; calls = 0
+        for wk in self.wk:
+            m_, c_ = wk["ctx"].phase_ms(name)
+            ms += m_; calls += c_
+        return ms, calls
+
+    def same_wires(self, w):
+        return all(wk["last"] is None or bool(self.torch.equal(wk["last"], w)) for wk in self.wk)
+
+    def close(self):
+        for wk in self.wk:
+            wk["dc"].solver.set_abc_dev(None, None, None)
+            wk["ctx"].set_param("tail_reserve_cus", 0)
+            if wk["own"]:
+                wk["dc"].close(); wk["ctx"].close()
+        self.wk = []
+
+
 def circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, shape, tier_name, seed, steps, e2e_steps, blinding, tables_used):
     """One production tier as the COMPILED circuit, start to finish and then freed: synthetic valid batch -> compile -> key with the circuit's
     sparsity -> matrices + program on the device -> one solve for the generated w / a / b / c / committed values -> a timed region of prove
@@ -1121,7 +1257,14 @@ def main():
     ap.add_argument("--no-circuit", action="store_true", help="the round-1..3 workload: D = n_wires = 2^log2, estimated scalar mixture, seeded key sparsity")
     ap.add_argument("--no-solver-rows", action="store_true", help="end-to-end region: evaluate a, b, c of every row from the matrices (do not let the Poseidon instructions write their own rows)")
     ap.add_argument("--no-prefetch", action="store_true", help="end-to-end region: do not start the next proof's CEX commitment chains under the current proof's prove tail")
-    ap.add_argument("--e2e-steps", type=int, default=-1, help="proofs of the end-to-end region (inputs -> solver program -> commitment -> a, b, c -> prove tail); default max(3, steps // 4)")
+    ap.add_argument("--e2e-steps", type=int, default=-1, help="proofs of the SECONDARY end-to-end regions (inputs from host memory; one proof at a time); default max(3, steps // 4); 0 = skip them.  "
+                    "The headline region — inputs -> solver program -> commitment -> a, b, c -> prove tail — times exactly --steps proofs")
+    ap.add_argument("--tail-steps", type=int, default=-1, help="circuit mode: proofs of the prove-tail-only region (`prove_tail`); default max(3, steps // 4)")
+    ap.add_argument("--e2e-workers", type=int, default=2, help="worker contexts per GPU in the end-to-end region: 2 = one proof's solver program runs beside the other's prove tail")
+    ap.add_argument("--tail-aux-masked", type=int, default=-1, help="experiment: 1 = the digit streams of a CU-masked tail keep to the tail's mask (library default 0: they may use the reserved units)")
+    ap.add_argument("--e2e-sweep", default="", help="experiment: extra end-to-end regions, 'workers:reserve_cus[:aux_masked]' separated by commas (e.g. 1:0,2:0,2:16,2:64:1), "
+                    "each --e2e-steps proofs, reported under end_to_end.sweep")
+    ap.add_argument("--tail-reserve-cus", type=int, default=32, help="with 2 workers: compute units the prove tail's CU mask leaves free for the other worker's solver launches (0 = none; multiple of 8)")
     ap.add_argument("--share-device", action="store_true", help="TEST ONLY: every rank proves on device 0 and the ranks meet over gloo — the launcher, the per-rank "
                     "merge of the line, the check budgeting and the key build under contention exercised on a one-GPU box; the line says so and is no measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1207,6 +1350,8 @@ def main():
         ctx.set_param("msm_filter", args.filter_mode)
     if args.aux_priority:
         ctx.set_param("aux_priority", 1)
+    if args.tail_aux_masked >= 0:
+        ctx.set_param("tail_aux_masked", args.tail_aux_masked)
     if args.tables > 1 and not args.split:   # a key with tables cannot be cut into the shards of the single-proof split
         ctx.set_param("msm_tables", args.tables)
     lib = ctx.lib
@@ -1385,21 +1530,27 @@ def main():
         if errs:
             raise errs[0]
 
-    run_steps(max(args.warmup, len(workers) if args.warmup else 0), w)
-    torch.cuda.synchronize()
-    for wk in workers:
-        wk[0].phase_reset()
+    # the PROVE TAIL alone (everything in groth16.Prove after the solver), inputs resident: the headline of rounds 1-4, since round 5 a named
+    # sub-figure of the line (`prove_tail`) — in circuit mode `value` is the END-TO-END rate measured further down over exactly --steps proofs
+    tail_steps = args.steps if circ is None else (0 if args.timed_only else (args.tail_steps if args.tail_steps >= 0 else max(3, args.steps // 4)))
     proofs = []
     local_t = [0.0]
-
-    def timed_steps():
-        t0_ = time.perf_counter()
-        run_steps(args.steps, w, proofs, first=1000)
+    dt = None
+    per_rank_ms = []
+    if tail_steps > 0:
+        run_steps(max(args.warmup if circ is None else 1, len(workers) if args.warmup else 0), w)
         torch.cuda.synchronize()
-        local_t[0] = time.perf_counter() - t0_
+        for wk in workers:
+            wk[0].phase_reset()
 
-    dt = timed_region(dist, torch.cuda.synchronize, timed_steps)
-    per_rank_ms = [row[0] for row in gather_per_rank(dist, [local_t[0] / max(1, args.steps) * 1e3])]
+        def timed_steps():
+            t0_ = time.perf_counter()
+            run_steps(tail_steps, w, proofs, first=1000)
+            torch.cuda.synchronize()
+            local_t[0] = time.perf_counter() - t0_
+
+        dt = timed_region(dist, torch.cuda.synchronize, timed_steps)
+        per_rank_ms = [row[0] for row in gather_per_rank(dist, [local_t[0] / max(1, tail_steps) * 1e3])]
     per_rank_key_s = [round(row[0], 2) for row in gather_per_rank(dist, [key_seconds])]
 
     phases = {}
@@ -1408,7 +1559,7 @@ def main():
         for wk in workers:
             m_, c_ = wk[0].phase_ms(name)
             ms += m_; calls += c_
-        phases[name] = {"ms_per_proof": ms / max(1, args.steps), "calls_per_proof": calls / max(1, args.steps)}
+        phases[name] = {"ms_per_proof": ms / max(1, tail_steps), "calls_per_proof": calls / max(1, tail_steps)}
     k1_ms = sum(wk[0].phase_ms("k_acc_level1_g1")[0] for wk in workers)
     k1_calls = sum(wk[0].phase_ms("k_acc_level1_g1")[1] for wk in workers)
 
@@ -1485,142 +1636,105 @@ def main():
     # zkpor_commit_dev + the challenge hashed on the host), a, b, c = L.w, R.w, O.w (zkpor_r1cs_eval_dev) and the prove tail.  Same barrier / sync contract.
     e2e = None
     e2e_proofs = []
-    if circ is not None and not args.timed_only:
-        esteps = args.e2e_steps if args.e2e_steps >= 0 else max(3, args.steps // 4)
-        if esteps > 0:
-            dc = circ["dc"]
-            w2s = [dev(32 * n_wires), dev(32 * n_wires)]; cv2 = dev(32 * (n_commit + 1))
-            w2 = w2s[0]
-            tm_acc = {}
-            n_in_wires = circ["cir"].n_public + circ["cir"].n_secret
-            prefetch = not args.no_prefetch
-            state = {"k": 0}
+    e2e_phase = None      # phase sums of the HEADLINE region (all its workers): the roofline's launch times come from here in circuit mode
+    if circ is not None:
+        import circuit as C
+        esteps = args.steps
+        dc = circ["dc"]
+        n_workers = max(1, args.e2e_workers)
+        lv = circ["cir"].level_sizes()
 
-            def e2e_proof(i):
-                # two wire vectors take turns: while proof i runs a, b, c and its prove tail, the NEXT proof's assignment is already in the other
-                # one and its two CEX commitment chains (834 serial permutations each: ~0.2 s of one wave) run on the solver's side stream
-                # (zkpor_solver_prefetch_dev) — what a prover loop does with the next witness row it already holds
-                tm = {}
+        def make(workers, reserve):
+            return EndToEnd(torch, zkpor, C, ctx, local_rank, pk, circ["cir"], dc, circ["d_in"], circ["inp"], D, n_commit, dev, blinding, (a, b, c), workers, reserve,
+                            solver_rows=not args.no_solver_rows, prefetch=not args.no_prefetch, aux_masked=args.tail_aux_masked)
+
+        def region(E, first, n, sink, tm_acc=None, upload=False, warm=1):
+            E.run(first - 100, max(warm, len(E.wk)), None, None, upload)            # warm-up: at least one proof per worker
+            E.phase_reset()
+            loc = [0.0]
+
+            def timed():
                 t0_ = time.perf_counter()
-                cur = w2s[state["k"] % 2]; nxt = w2s[(state["k"] + 1) % 2]
-                state["k"] += 1
-                if not prefetch:
-                    C.stage_inputs(ctx, dc, cur.data_ptr(), circ["d_in"].data_ptr())
-                com, pok, _ch = C.solve_on_device(ctx, dc, pk, cur.data_ptr(), cv2.data_ptr(), circ["d_in"].data_ptr(), tm, staged=True)
-                t1_ = time.perf_counter()
-                if prefetch:
-                    C.stage_inputs(ctx, dc, nxt.data_ptr(), circ["d_in"].data_ptr())
-                    dc.solver.prefetch_dev(nxt.data_ptr(), n_in_wires)
-                dc.solver.eval_abc_dev(cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), D)     # the rows the Poseidon instructions have not written already
-                r, s = blinding(i)
-                proof = ctx.prove_tail_dev(pk, cur.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), r, s)
-                tm["abc_and_prove_tail_ms"] = (time.perf_counter() - t1_) * 1e3
-                tm["total_ms"] = (time.perf_counter() - t0_) * 1e3
-                state["last"] = cur
-                return proof, com, pok, tm
+                E.run(first, n, sink, tm_acc, upload)
+                loc[0] = time.perf_counter() - t0_
 
-            if not args.no_solver_rows:
-                dc.solver.set_abc_dev(a.data_ptr(), b.data_ptr(), c.data_ptr())
-            if prefetch:
-                C.stage_inputs(ctx, dc, w2s[0].data_ptr(), circ["d_in"].data_ptr())
-                dc.solver.prefetch_dev(w2s[0].data_ptr(), n_in_wires)
-            e2e_proof(9000)                                   # warm-up
-            torch.cuda.synchronize()
-            ctx.phase_reset()
+            dt_ = timed_region(dist, torch.cuda.synchronize, timed)
+            return {"value": world * n / dt_, "unit": "proofs/s", "ms_per_proof": dt_ / n * 1e3, "steps": n, "workers_per_gpu": len(E.wk),
+                    "tail_reserve_cus": E.reserve, "per_rank_ms_per_proof": [round(row[0], 3) for row in gather_per_rank(dist, [loc[0] / n * 1e3])]}
 
-            def e2e_steps():
-                for i in range(esteps):
-                    proof, com, pok, tm = e2e_proof(9001 + i)
-                    e2e_proofs.append((9001 + i, proof, com, pok))
-                    for k_, v_ in tm.items():
-                        tm_acc[k_] = tm_acc.get(k_, 0.0) + v_
-                torch.cuda.synchronize()
-
-            dte = timed_region(dist, torch.cuda.synchronize, e2e_steps)
-            dims = dc.solver.dims()
-            lv = circ["cir"].level_sizes()
-            e2e = {"value": world * esteps / dte, "unit": "proofs/s", "ms_per_proof": dte / esteps * 1e3, "steps": esteps,
-                   "phases_ms_per_proof": {k_: round(v_ / esteps, 2) for k_, v_ in tm_acc.items()},
-                   "device_phases_ms_per_proof": {k_: round(ctx.phase_ms(k_)[0] / esteps, 2) for k_ in ("solver_levels", "r1cs_eval", "rows_check", "msm_accumulate", "msm_reduce", "ntt")},
-                   "circuit": {"shape_T_A_U": list(circ["shape"]), "constraints": circ["cir"].n_constraints, "wires": circ["cir"].n_wires,
-                               "instructions": circ["cir"].n_instructions, "levels": int(len(lv)), "widest_level": int(lv.max()), "levels_up_to_512": int((lv <= 512).sum()),
-                               "committed_wires": circ["cir"].n_committed, "wires_without_A_point": int(td_masks[0].sum()), "wires_without_B_point": int(td_masks[1].sum()),
-                               "launches_per_solve": dims["launches_last_run"], "census": circ["cir"].census},
-                   "setup_seconds": circ["setup_s"],
-                   "what": "groth16.Prove from the assigned inputs (prover.go:254-274): BatchCreateUserCircuit.Define restated and compiled in this repo "
-                           "(host/circuit/: the image has no Go, gnark's own compiled system cannot be exported here; gadget expansions recalled, "
-                           "constraint count within 7 % of the reference's README), a synthetic VALID batch (its hashes are the oracle's), inputs resident "
-                           "in HBM, solver program + BSB22 commitment + a, b, c + prove tail on the device; the challenge is hashed on the host"}
-            # ---- the same with TWO proofs in flight (N = 1): a second worker context of the GPU with its own solver (the matrices are shared), wire
-            # vector and a / b / c.  The solver program is latency work — a few waves at a time on a 256-CU part — so one proof's solve runs in the
-            # shadow of the other proof's prove tail: how host/prover_host.hpp drives a GPU.  No prefetch here: the chains overlap the same way.
-            if world == 1 and not args.no_two_in_flight:
-                ctx.sync()
-                wk2 = None
+        try:
+            E = make(n_workers, args.tail_reserve_cus)
+        except Exception as e_:       # e.g. no room for the second worker next to a 4-table key: the headline falls back to one proof at a time
+            print(f"bench.py: {n_workers} end-to-end workers do not fit ({e_}); one proof at a time", file=sys.stderr)
+            n_workers = 1
+            E = make(1, 0)
+        tm_acc = {}
+        e2e = region(E, 9001, esteps, e2e_proofs, tm_acc, warm=args.warmup)
+        dims = dc.solver.dims()
+        e2e_phase = {k_: E.phase_ms(k_) for k_ in ("solver_levels", "r1cs_eval", "rows_check", "msm_decompose", "msm_sort", "msm_accumulate", "msm_reduce",
+                                                   "k_acc_level1_g1", "k_acc_level1_g2", "ntt", "pointwise", "host_assembly")}
+        e2e.update({
+            "phases_ms_per_proof": {k_: round(v_ / esteps, 2) for k_, v_ in tm_acc.items()},
+            "device_phases_ms_per_proof": {k_: round(e2e_phase[k_][0] / esteps, 2) for k_ in ("solver_levels", "r1cs_eval", "rows_check", "msm_accumulate", "msm_reduce", "ntt")},
+            "circuit": {"shape_T_A_U": list(circ["shape"]), "constraints": circ["cir"].n_constraints, "wires": circ["cir"].n_wires,
+                        "instructions": circ["cir"].n_instructions, "levels": int(len(lv)), "widest_level": int(lv.max()), "levels_up_to_512": int((lv <= 512).sum()),
+                        "committed_wires": circ["cir"].n_committed, "wires_without_A_point": int(td_masks[0].sum()), "wires_without_B_point": int(td_masks[1].sum()),
+                        "launches_per_solve": dims["launches_last_run"], "census": circ["cir"].census},
+            "setup_seconds": circ["setup_s"],
+            "what": "groth16.Prove from the assigned inputs (prover.go:254-274): BatchCreateUserCircuit.Define restated and compiled in this repo "
+                    "(host/circuit/: the image has no Go, gnark's own compiled system cannot be exported here; gadget expansions recalled, "
+                    "constraint count within 7 % of the reference's README), a synthetic VALID batch (its hashes are the oracle's), inputs resident "
+                    "in HBM, solver program + BSB22 commitment + a, b, c + prove tail on the device; the challenge is hashed on the host.  "
+                    f"{len(E.wk)} worker(s) per GPU: one proof's solve runs beside the other's prove tail" + (f", whose kernels leave {E.reserve} of the compute units free" if E.reserve else "")})
+        e2e["same_wires_as_headline"] = E.same_wires(w) if args.scalars == "witness" else None
+        last_w = E.wk[0]["last"]
+        e2e["constraints_failing_on_device"] = dc.r1cs.check_dev(last_w.data_ptr())[0]
+        if not args.timed_only:
+            sub = max(3, args.steps // 4) if args.e2e_steps < 0 else args.e2e_steps
+            if sub > 0:
+                # the same region with the assigned inputs coming from pageable HOST memory for every proof (129 MB for zkpor50_1380): what a prover
+                # holding a decoded witness row pays; `value` keeps the inputs resident (the bench contract), this is the PCIe-inclusive rate
+                up = region(E, 12001, sub, e2e_proofs, None, upload=True)
+                up["input_bytes_per_proof"] = int(circ["inp"].nbytes)
+                up["same_wires"] = E.same_wires(w) if args.scalars == "witness" else None
+                e2e["with_input_upload"] = up
+        E.close()
+        if not args.timed_only and len(E.wk) == 0 and n_workers > 1 and (args.e2e_steps != 0):
+            # one proof at a time, no reserved compute units (the round-4 headline's shape): the latency of one proof and what the second worker buys
+            sub = max(3, args.steps // 4) if args.e2e_steps < 0 else args.e2e_steps
+            E1 = make(1, 0)
+            one = region(E1, 15001, sub, e2e_proofs, None)
+            one["same_wires"] = E1.same_wires(w) if args.scalars == "witness" else None
+            E1.close()
+            e2e["one_proof_at_a_time"] = one
+        if args.e2e_sweep:
+            sweep = []
+            for k_, spec in enumerate(args.e2e_sweep.split(",")):
+                parts = [int(x) for x in spec.split(":")]
                 try:
-                    c1 = zkpor.Context(local_rank, None)
-                    wk2 = {"ctx": c1, "dc": C.DeviceCircuit(c1, circ["cir"], share=dc), "w": dev(32 * n_wires), "cv": dev(32 * (n_commit + 1)),
-                           "a": dev(32 * D), "b": dev(32 * D), "c": dev(32 * D)}
-                except Exception as e_:
-                    e2e["two_in_flight"] = {"value": None, "note": f"no room for a second end-to-end worker: {e_}"}
-                if wk2 is not None and "dc" in wk2:
-                    wk1 = {"ctx": ctx, "dc": dc, "w": w2s[0], "cv": cv2, "a": a, "b": b, "c": c}
-                    tsteps2 = max(4, 2 * esteps)
-                    sink2 = []
-                    import threading as _th
-                    lock2 = _th.Lock()
-                    errs2 = []
-
-                    def e2e_worker(wk_, ids):
-                        try:
-                            if not args.no_solver_rows:
-                                wk_["dc"].solver.set_abc_dev(wk_["a"].data_ptr(), wk_["b"].data_ptr(), wk_["c"].data_ptr())
-                            for i in ids:
-                                com, pok, _ch = C.solve_on_device(wk_["ctx"], wk_["dc"], pk, wk_["w"].data_ptr(), wk_["cv"].data_ptr(), circ["d_in"].data_ptr(), None)
-                                wk_["dc"].solver.eval_abc_dev(wk_["w"].data_ptr(), wk_["a"].data_ptr(), wk_["b"].data_ptr(), wk_["c"].data_ptr(), D)
-                                r, s = blinding(i)
-                                proof = wk_["ctx"].prove_tail_dev(pk, wk_["w"].data_ptr(), wk_["a"].data_ptr(), wk_["b"].data_ptr(), wk_["c"].data_ptr(), r, s)
-                                with lock2:
-                                    sink2.append((i, proof, com, pok))
-                        except Exception as ex_:     # noqa: BLE001 — reported in the line
-                            errs2.append(str(ex_))
-
-                    def two_workers(first, n):
-                        ths = [_th.Thread(target=e2e_worker, args=(wk_, list(range(first + k_, first + n, 2)))) for k_, wk_ in enumerate((wk1, wk2))]
-                        for t_ in ths: t_.start()
-                        for t_ in ths: t_.join()
-                        torch.cuda.synchronize()
-
-                    try:
-                        two_workers(9500, 2)                       # warm-up: one proof each
-                        sink2.clear()
-                        dt2e = timed_region(None, torch.cuda.synchronize, lambda: two_workers(9600, tsteps2))
-                        if errs2:
-                            e2e["two_in_flight"] = {"value": None, "note": "failed: " + "; ".join(errs2)}
-                        else:
-                            same2 = bool(torch.equal(wk2["w"], w2s[0]))
-                            e2e["two_in_flight"] = {"value": tsteps2 / dt2e, "unit": "proofs/s", "ms_per_proof": dt2e / tsteps2 * 1e3, "steps": tsteps2, "workers": 2,
-                                                    "both_workers_solved_the_same_wires": same2,
-                                                    "note": "two worker contexts of the GPU, each: inputs -> solver program -> commitment -> a, b, c -> prove tail; "
-                                                            "`value` above is one proof at a time"}
-                            if same2:
-                                e2e_proofs.extend(sink2)
-                        state["last"] = w2s[0]
-                    finally:
-                        wk2["dc"].solver.set_abc_dev(None, None, None)
-                        wk2["dc"].close(); wk2["ctx"].close()
-                        del wk2
-            # the solved wire vector of the LAST e2e proof must be the one the headline proofs used (same inputs, same commitment, same challenge)
-            w2 = state["last"]
-            e2e["next_proofs_hash_chains_prefetched"] = prefetch
-            e2e["poseidon_rows_written_by_the_solver"] = not args.no_solver_rows
-            e2e["assertions"] = ("left out of the run, every row verified a x b = c after a, b, c (zkpor_solver_eval_abc_dev, phase rows_check)"
-                                 if not args.no_solver_rows else "executed by the run (CHECK instructions)")
-            dc.solver.set_abc_dev(None, None, None)
-            e2e["same_wires_as_headline"] = bool(torch.equal(w2, w)) if args.scalars == "witness" else None
-            e2e["constraints_failing_on_device"] = dc.r1cs.check_dev(w2.data_ptr())[0]
-            ctx.sync()
-            del w2, w2s, cv2, state
+                    if len(parts) > 2:
+                        ctx.set_param("tail_aux_masked", parts[2])
+                    Es = make(parts[0], parts[1])
+                    if len(parts) > 2:
+                        for wk_ in Es.wk:
+                            wk_["ctx"].set_param("tail_aux_masked", parts[2])
+                    r_ = region(Es, 20001 + 1000 * k_, max(2, args.e2e_steps if args.e2e_steps > 0 else 4), e2e_proofs, None)
+                    r_["same_wires"] = Es.same_wires(w) if args.scalars == "witness" else None
+                    r_["spec"] = spec
+                    r_["k_acc_level1_g1_avg_ms"] = (lambda mc: mc[0] / max(1, mc[1]))(Es.phase_ms("k_acc_level1_g1"))
+                    r_["device_phases_ms_per_proof"] = {n_: round(Es.phase_ms(n_)[0] / r_["steps"], 2) for n_ in ("solver_levels", "r1cs_eval", "msm_accumulate", "msm_reduce", "ntt", "msm_sort")}
+                    Es.close()
+                    sweep.append(r_)
+                except Exception as ex_:      # noqa: BLE001
+                    sweep.append({"spec": spec, "note": f"failed: {ex_}"})
+            ctx.set_param("tail_aux_masked", 0 if args.tail_aux_masked < 0 else args.tail_aux_masked)
+            e2e["sweep"] = sweep
+        e2e["next_proofs_hash_chains_prefetched"] = not args.no_prefetch
+        e2e["poseidon_rows_written_by_the_solver"] = not args.no_solver_rows
+        e2e["assertions"] = ("left out of the run, every row verified a x b = c after a, b, c (zkpor_solver_eval_abc_dev, phase rows_check)"
+                             if not args.no_solver_rows else "executed by the run (CHECK instructions)")
+        ctx.sync()
+        torch.cuda.empty_cache()
 
     # ---- every timed proof is verified, untimed: prove, then verify (prover.go:269-276).  The synthetic key is trapdoor-known, so
     # Ar / Bs / Krs and the two commitment sums are checked in the exponent at the exact size and mixture that was timed
@@ -1667,11 +1781,12 @@ def main():
             r, s = blinding(i)
             ok += int(h_ok and td.check(proof, r, s) and np.array_equal(com, ec) and np.array_equal(pok, ek))
         total = len(proofs)
-        if e2e_proofs and args.scalars == "witness":          # the end-to-end proofs: same w, same h (same a, b, c), their own blinding
+        if e2e_proofs and args.scalars == "witness":          # the end-to-end proofs (every region's): same w, same h (same a, b, c), their own blinding
             eok = 0
+            e2e_same = bool(e2e["same_wires_as_headline"]) and all((e2e.get(k_) or {}).get("same_wires", True) for k_ in ("with_input_upload", "one_proof_at_a_time"))
             for i, proof, com, pok in e2e_proofs:
                 r, s = blinding(i)
-                eok += int(h_ok and e2e["same_wires_as_headline"] and e2e["constraints_failing_on_device"] == 0 and td.check(proof, r, s)
+                eok += int(h_ok and e2e_same and e2e["constraints_failing_on_device"] == 0 and td.check(proof, r, s)
                            and np.array_equal(com, ec) and np.array_equal(pok, ek))
             e2e["checked"] = {"proofs": len(e2e_proofs), "ok": eok}
             ok += eok; total += len(e2e_proofs)
@@ -1716,9 +1831,10 @@ def main():
 
     if rank == 0:
         # launches of k_acc_level1_fp29 per proof: A, B1, K, Z (n ~ D points each) + 2 commitment MSMs (n/4 points)
-        units_bytes = (3 * n_wires + D + 2 * n_commit) * 96.0 / 6.0  # mean algorithmic bytes per launch: A, B1, K over the wires, Z over the domain, 2 commitment sums
+        units_bytes = (3 * n_wires + D + 2 * n_commit) * 96.0 / 6.0  # SURVEY §8d's rounding (n_i = the wire count, infinity slots included): kept as `frac_survey_rounding`
+        if e2e_phase is not None:      # circuit mode: the timed region is the end-to-end one — its launches are the roofline's
+            k1_ms, k1_calls = e2e_phase["k_acc_level1_g1"]
         avg_launch_s = (k1_ms / max(1, k1_calls)) * 1e-3
-        achieved = units_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         bproof = algorithmic_bytes_per_proof(log2, n_wires, n_commit)
         tb, tsrc = pmc_traffic_bytes_per_launch()
         # the committed PMC passes (profiles/r04_*) were taken on the default workload: the compiled zkpor50_1380 circuit, generated scalars, 4 tables
@@ -1728,7 +1844,10 @@ def main():
             n_a = n_wires - int(td_masks[0].sum()); n_b1 = n_wires - int(td_masks[1].sum()); n_k = n_wires - n_public - len(td_masks[2])
         else:
             n_a = n_wires - n_wires // 64; n_b1 = n_wires - n_wires // 10; n_k = n_wires - n_wires // 4
+        # ALGORITHMIC bytes of one average launch: every point the launch's array really holds, once (64 B) + its scalar (32 B); the six launches of a
+        # proof are A, B1, K over the wires that have a point, Z over D - 1, and the two Pedersen sums (DESIGN.md §4 / SURVEY §8d)
         units_bytes_exact = (n_a + n_b1 + n_k + (D - 1) + 2 * n_commit) * 96.0 / 6.0
+        achieved = units_bytes_exact / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         clock_ghz = 1.949     # profiles/r04_clock.txt: GRBM_GUI_ACTIVE / wall time of k_acc_level1_fp29 (power-limited; nominal 2.4)
         traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and profiled_cfg) else None
         vb_ms, vsrc = pmc_valu_issue_bound_ms()
@@ -1744,28 +1863,46 @@ def main():
                            "binary: profiles/r04_clock.txt; the G2 kernel 2.15, NTT passes 2.07-2.29): *_at_measured_clock price the same counts at that clock"}
                 if (vb_ms and avg_launch_s > 0 and profiled_cfg) else None)
         main_stream = ("k_acc_level1_g1", "k_acc_level1_g2", "msm_accumulate", "msm_reduce", "ntt", "pointwise", "host_assembly")
+        tail_value = (world * tail_steps / dt) if dt else None
+        tail_ms = (dt / tail_steps * 1e3) if dt else None
+        headline_value = e2e["value"] if e2e is not None else tail_value
+        headline_ms = e2e["ms_per_proof"] if e2e is not None else tail_ms
+        resident_ms = tail_ms if tail_ms else headline_ms      # what the untimed boundary legs compare themselves with
         out = {
             "metric": "Groth16 proofs/sec at 2^26 constraints (zkpor50_1380), 1/2/4/8 MI355X",
-            "value": world * args.steps / dt,
+            "value": headline_value,
             "unit": "proofs/s",
             "n_gpus": world,
             "ranks_share_one_device": True if args.share_device else None,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
+            "ms_per_step": headline_ms,
+            "per_rank_ms_per_step": e2e["per_rank_ms_per_proof"] if e2e is not None else [round(x, 3) for x in per_rank_ms],
+            "what_value_is": ("END TO END: groth16.Prove from the assigned inputs (resident in HBM) — solver program, BSB22 commitment, a / b / c, prove tail — `prove_tail` is the tail alone"
+                              if e2e is not None else "the prove tail alone (no compiled circuit in this mode): everything in groth16.Prove after the solver"),
+            "end_to_end_value": e2e["value"] if e2e is not None else None,
+            "end_to_end_ms_per_proof": e2e["ms_per_proof"] if e2e is not None else None,
+            "end_to_end_with_input_upload_value": (e2e.get("with_input_upload") or {}).get("value") if e2e is not None else None,
+            "prove_tail_value": tail_value,
+            "prove_tail_ms_per_proof": tail_ms,
+            "prove_tail": ({"value": tail_value, "unit": "proofs/s", "ms_per_step": tail_ms, "steps": tail_steps, "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
+                            "proofs_in_flight_per_gpu": len(workers),
+                            "phases_ms_per_proof": {k: round(phases[k]["ms_per_proof"], 3) for k in main_stream},
+                            "overlapped_aux_stream_elapsed_ms_per_proof": {k: round(phases[k]["ms_per_proof"], 3) for k in ("msm_decompose", "msm_sort")},
+                            "what": "everything in groth16.Prove after the R1CS solver (computeH, A/B1/K/Z + B2 multi-exponentiations, blinding) + the 2 Pedersen commitment "
+                                    "sums, w / a / b / c resident in HBM, one proof at a time — the headline of rounds 1-4"} if dt else None),
             "per_rank_key_synth_and_tables_seconds": per_rank_key_s,     # untimed set-up every rank does on its own GPU before the first barrier
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "i32x9 (254-bit Fp/Fr on 9 x 29-bit signed lazy Montgomery limbs in registers; u32x8 Montgomery in memory)",
             "data": "synthetic",
-            "config": ({"workload": f"{args.config} Groth16 PROVE TAIL of the COMPILED BatchCreateUserCircuit (everything in groth16.Prove after the R1CS "
-                                    f"solver: computeH, A/B1/K/Z + B2 multi-exponentiations, blinding, + the 2 Pedersen commitment sums): "
-                                    f"{circ['cir'].n_constraints} constraints (D=2^{log2}), {n_wires} wires, {n_commit} committed wires, key with the "
-                                    f"circuit's sparsity as {tables_used} fixed-base table(s) per point, scalars={'generated' if args.scalars == 'witness' else 'uniform'} "
-                                    f"(w, a, b, c and the committed values are the device-solved wires of a synthetic valid batch), "
-                                    f"{len(workers)} proof(s) in flight per GPU, resident in HBM; the solver is NOT included in `value` — `end_to_end` is the rate with it",
+            "config": ({"workload": f"{args.config} groth16.Prove END TO END on the COMPILED BatchCreateUserCircuit: assigned inputs (resident in HBM) -> solver program on the "
+                                    f"device -> BSB22 commitment (2 Pedersen sums, challenge hashed on the host) -> a, b, c -> computeH, A/B1/K/Z + B2 multi-exponentiations, "
+                                    f"blinding: {circ['cir'].n_constraints} constraints (D=2^{log2}), {n_wires} wires, {n_commit} committed wires, key with the "
+                                    f"circuit's sparsity as {tables_used} fixed-base table(s) per point, a synthetic valid batch of {circ['shape'][2]} users, "
+                                    f"{e2e['workers_per_gpu']} worker(s) per GPU (solve of one proof beside the prove tail of the other"
+                                    + (f", {e2e['tail_reserve_cus']} compute units kept out of the tail's CU mask" if e2e['tail_reserve_cus'] else "") + ")",
                         "tier": args.config, "users_per_batch": circ["shape"][2], "assets_per_user": circ["shape"][0],
                         "scalars": "generated" if args.scalars == "witness" else "uniform",
                         "scalar_mix_measured": scalar_mix,
@@ -1786,7 +1923,8 @@ def main():
             "checked": checked,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "frac_exact_array_sizes": (units_bytes_exact / avg_launch_s / 1e9 / HBM_PEAK_GBS) if avg_launch_s > 0 else None,
+                         "frac_survey_rounding": (units_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS) if avg_launch_s > 0 else None,
+                         "algorithmic_bytes_per_launch": units_bytes_exact, "launches_in_timed_region": int(k1_calls),
                          "array_sizes": {"A": n_a, "B1": n_b1, "K": n_k, "Z": D - 1, "commit_bases": n_commit, "n_wires": n_wires},
                          "traffic_source": (f"profiles/{tsrc}: {tb / 1e9:.1f} GB HBM bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, "
                                             "gfx950-calibrated) / live avg launch time; the bucket method re-reads each 64 B point once per "
@@ -1795,11 +1933,13 @@ def main():
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "valu_issue": valu,
                          "note": "path is VALU-integer bound (~1e3 int-ops/byte); whole-proof algorithmic bytes "
-                                 f"{bproof / 1e9:.1f} GB -> {bproof * (args.steps / dt) / 1e9:.1f} GB/s per GPU"},
-            # additive: regions on the context's main stream.  NOT additive: the digit streams run on the auxiliary stream beside
-            # them, their event pairs measure elapsed time while time-sliced with the main stream (see profiles/ for kernel times)
-            "phases_ms_per_proof": {k: round(phases[k]["ms_per_proof"], 3) for k in main_stream},
-            "overlapped_aux_stream_elapsed_ms_per_proof": {k: round(phases[k]["ms_per_proof"], 3) for k in ("msm_decompose", "msm_sort")},
+                                 f"{bproof / 1e9:.1f} GB -> {bproof * (headline_value / world) / 1e9:.1f} GB/s per GPU"},
+            # the HEADLINE region's device phases (event pairs on the streams the kernels are launched on, summed over the region's workers).  With two
+            # workers the regions of one worker's solve and the other's tail overlap in time: the entries are per-proof sums, not a partition of ms_per_step.
+            # The digit streams (msm_decompose, msm_sort) run on the auxiliary stream beside the main stream's kernels at all times.
+            "phases_ms_per_proof": ({k: round(e2e_phase[k][0] / args.steps, 3) for k in e2e_phase} if e2e_phase is not None
+                                    else {k: round(phases[k]["ms_per_proof"], 3) for k in main_stream}),
+            "overlapped_aux_stream_elapsed_ms_per_proof": (None if e2e_phase is not None else {k: round(phases[k]["ms_per_proof"], 3) for k in ("msm_decompose", "msm_sort")}),
         }
         if circ is not None:   # the compiled circuit leaves the device before the untimed legs (a second context's workspace needs the room)
             circ["dc"].close(); circ["d_in"] = None
@@ -1808,7 +1948,7 @@ def main():
             if not args.no_boundary:
                 try:
                     out["boundary"] = boundary_leg(torch, zkpor, ctx, local_rank, pk, D, n_wires, n_commit, (w, a0, b0, c0, cv), td, blinding,
-                                                   resident_ms=dt / args.steps * 1e3, copy_threads=args.copy_threads, copy_chunk_mb=args.copy_chunk_mb, host_order=args.host_order, gpu_token=0 if args.no_gpu_token else 1)
+                                                   resident_ms=resident_ms, copy_threads=args.copy_threads, copy_chunk_mb=args.copy_chunk_mb, host_order=args.host_order, gpu_token=0 if args.no_gpu_token else 1)
                 except Exception as e:
                     out["boundary"] = {"value": None, "note": f"failed: {e}"}
             if args.boundary_sweep and "value" in out.get("boundary", {}):
@@ -1816,7 +1956,7 @@ def main():
                 for ct, tok in ((4, 1), (4, 0), (0, 1), (0, 0)):
                     try:
                         b_ = boundary_leg(torch, zkpor, ctx, local_rank, pk, D, n_wires, n_commit, (w, a0, b0, c0, cv), td, blinding,
-                                          resident_ms=dt / args.steps * 1e3, n_proofs=args.boundary_sweep, copy_threads=ct, gpu_token=tok)
+                                          resident_ms=resident_ms, n_proofs=args.boundary_sweep, copy_threads=ct, gpu_token=tok)
                         sweep.append({"copy_threads": ct, "gpu_token": tok, "pageable_ms": round(b_["ms_per_proof"], 1),
                                       "registered_ms": round(b_.get("registered_ms_per_proof", 0.0), 1), "one_caller_ms": round(b_["one_caller_ms_per_proof"], 1),
                                       "proofs": b_["proofs"], "checked_ok": b_["checked_ok"]})
@@ -1828,23 +1968,24 @@ def main():
             if args.r1cs_terms > 0:
                 try:
                     out["r1cs_resident"] = r1cs_leg(torch, zkpor, ctx, local_rank, pk, D, log2, n_wires, n_commit, w, cv, seed, blinding,
-                                                    resident_ms=dt / args.steps * 1e3, terms=args.r1cs_terms)
+                                                    resident_ms=resident_ms, terms=args.r1cs_terms)
                 except Exception as e:
                     out["r1cs_resident"] = {"value": None, "note": f"failed: {e}"}
             if not args.no_cpu_baseline:
                 try:
                     out["cpu_baseline"] = cpu_baseline(args.cpu_log2, log2, 0.25, cfg["fill_kind"], cfg["mixture"],
-                                                       mix=scalar_mix if (circ is not None and args.scalars == "witness") else None)
+                                                       mix=scalar_mix if (circ is not None and args.scalars == "witness") else None,
+                                                       solver=(circ["cir"], circ["inp"]) if circ is not None else None)
                 except Exception as e:  # the baseline is informational; never lose the GPU line over it
                     out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-            out["solver_budget"] = solver_budget(dt / args.steps * 1e3, os.cpu_count() or 1)
+            out["solver_budget"] = solver_budget(resident_ms, os.cpu_count() or 1)
             if not args.timed_only:
                 try:
                     out["solver_budget"]["host_executor_measured"] = host_executor_leg(usable_cpus())
                 except Exception as e:
                     out["solver_budget"]["host_executor_measured"] = {"note": f"failed: {e}"}
                 try:
-                    out["solver_budget"]["host_row_measured"] = host_row_leg(cfg["users"], cfg["assets"], world * args.steps / dt)
+                    out["solver_budget"]["host_row_measured"] = host_row_leg(cfg["users"], cfg["assets"], headline_value)
                 except Exception as e:
                     out["solver_budget"]["host_row_measured"] = {"note": f"failed: {e}"}
                 try:

@@ -74,21 +74,32 @@ def test_bench_circuit_mode_end_to_end():
     assigned inputs: solver program + BSB22 commitment + a, b, c + prove tail, every proof checked"""
     d = _bench("--circuit", "5,20,6", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-boundary", "--e2e-steps", "3")
     cfgd = d["config"]
-    assert cfgd["scalars"] == "generated" and "COMPILED BatchCreateUserCircuit" in cfgd["workload"] and cfgd["users_per_batch"] == 6 and cfgd["assets_per_user"] == 5
+    assert cfgd["scalars"] == "generated" and "COMPILED BatchCreateUserCircuit" in cfgd["workload"] and "END TO END" in cfgd["workload"]
+    assert cfgd["users_per_batch"] == 6 and cfgd["assets_per_user"] == 5
     mix = cfgd["scalar_mix_measured"]
     assert abs(mix["in_{0,1}"] + mix["below_2^16"] + mix["below_2^64"] + mix["wider"] - 1.0) < 1e-3 and mix["in_{0,1}"] > 0.3
     e = d["end_to_end"]
-    assert e["steps"] == 3 and e["value"] > 0 and abs(e["value"] - 1e3 / e["ms_per_proof"]) < 1e-6 * e["value"]
-    two = e["two_in_flight"]                                        # the same with two worker contexts: their proofs are checked with the others
-    assert two["workers"] == 2 and two["value"] > 0 and two["both_workers_solved_the_same_wires"] is True
-    assert e["checked"] == {"proofs": 3 + two["steps"], "ok": 3 + two["steps"]} and e["same_wires_as_headline"] is True and e["constraints_failing_on_device"] == 0
+    # the headline IS the end-to-end region: exactly --steps proofs, two workers of the GPU, compute units reserved for the solver's launches
+    assert e["steps"] == d["steps"] == 3 and e["value"] == d["value"] == d["end_to_end_value"] and e["ms_per_proof"] == d["ms_per_step"] == d["end_to_end_ms_per_proof"]
+    assert abs(e["value"] - 1e3 / e["ms_per_proof"]) < 1e-6 * e["value"] and e["workers_per_gpu"] == 2 and e["tail_reserve_cus"] == 32
+    assert len(d["per_rank_ms_per_step"]) == 1 and d["what_value_is"].startswith("END TO END")
+    up = e["with_input_upload"]                                    # the same with the assigned inputs uploaded from pageable host memory, every proof
+    assert up["steps"] == 3 and up["value"] > 0 and up["same_wires"] is True and up["input_bytes_per_proof"] > 32 * 1000 and d["end_to_end_with_input_upload_value"] == up["value"]
+    one = e["one_proof_at_a_time"]                                  # one worker, nothing reserved: round 4's shape
+    assert one["steps"] == 3 and one["workers_per_gpu"] == 1 and one["tail_reserve_cus"] == 0 and one["same_wires"] is True
+    assert e["checked"] == {"proofs": 9, "ok": 9} and e["same_wires_as_headline"] is True and e["constraints_failing_on_device"] == 0
     assert e["next_proofs_hash_chains_prefetched"] is True and e["assertions"].startswith("left out of the run")
     c = e["circuit"]
     assert c["shape_T_A_U"] == [5, 20, 6] and c["constraints"] > 300000 and c["levels"] < 200 and c["committed_wires"] > 40000 and c["census"]["poseidon_perm_t3"] == 28 * 6
-    assert e["value"] < d["value"]                                  # the solver costs something
-    assert d["checked"]["ok"] == d["checked"]["proofs"] and d["checked"]["proofs"] >= 3 + 3
+    t = d["prove_tail"]                                             # the tail alone, resident inputs: a named sub-figure since round 5
+    assert t["steps"] == 3 and t["value"] == d["prove_tail_value"] and abs(t["value"] - 1e3 / t["ms_per_step"]) < 1e-6 * t["value"]
+    assert one["value"] < t["value"]                                # the solver costs something
+    assert d["checked"]["ok"] == d["checked"]["proofs"] and d["checked"]["proofs"] >= 3 + 9
     for k in ("solve_phase1_ms", "commit_ms", "solve_phase2_ms", "abc_and_prove_tail_ms"):
         assert e["phases_ms_per_proof"][k] >= 0
+    rf = d["roofline"]                                              # the launches of the TIMED (end-to-end) region: 6 per proof and worker warm-ups excluded
+    assert rf["launches_in_timed_region"] == 6 * 3 and rf["avg_launch_ms"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
 
 
 def test_two_ranks_on_one_device_launcher_merge_and_checks():
@@ -112,5 +123,5 @@ def test_two_ranks_in_circuit_mode():
     rows = d["checked"]["per_rank_ok_of_total"]
     assert len(rows) == 2 and all(r[0] == r[1] and r[1] > 0 for r in rows) and d["checked"]["ok"] == d["checked"]["proofs"]
     e = d["end_to_end"]
-    assert e["steps"] == 2 and e["checked"]["ok"] == e["checked"]["proofs"] == 2 and e["same_wires_as_headline"] is True and e["constraints_failing_on_device"] == 0
-    assert "two_in_flight" not in e and abs(e["value"] - 2 * 1e3 / e["ms_per_proof"]) < 1e-6 * e["value"]
+    assert e["steps"] == 2 and e["checked"]["ok"] == e["checked"]["proofs"] == 6 and e["same_wires_as_headline"] is True and e["constraints_failing_on_device"] == 0
+    assert abs(e["value"] - 2 * 1e3 / e["ms_per_proof"]) < 1e-6 * e["value"] and e["value"] == d["value"] and len(d["per_rank_ms_per_step"]) == 2

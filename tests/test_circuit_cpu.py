@@ -138,6 +138,63 @@ def test_constraint_count_sits_where_the_reference_says():
         one.close(); two.close()
 
 
+def test_where_the_constraint_gap_to_the_reference_sits():
+    """README.md:12-14 again, taken apart: the reference's three figures are a line in the user's asset count —
+    281 200 - 42 300 over 450 slots = 530.9 constraints per user asset slot, 15 756 per user on top, 6.63 M shared.  The same three numbers
+    of the restatement, from four compilations: the shared base is within 2 %, the per-user fixed part within 5 %, and the gap sits in
+    the per-asset slope (-36 of 531 constraints per slot: the slot's 4 CmpNOp / 4 AssertIsLessOrEqualNOp / 29 lookup queries and its share
+    of the collateral arithmetic are recalled expansions, circuit/utils.go:12-225) — three quarters of the per-user gap at 50 assets,
+    nearly all of it at 500."""
+    n = {}
+    census = {}
+    for sh in ((50, 500, 1), (50, 500, 2), (500, 500, 1), (500, 500, 2)):
+        c = C.Circuit(*sh)
+        n[sh] = c.n_constraints; census[sh] = dict(c.census)
+        c.close()
+    pu50 = n[(50, 500, 2)] - n[(50, 500, 1)]; pu500 = n[(500, 500, 2)] - n[(500, 500, 1)]
+    base = n[(50, 500, 1)] - pu50
+    slope = (pu500 - pu50) / 450.0; fixed = pu50 - 50 * slope
+    ref_slope = (281200 - 42300) / 450.0; ref_fixed = 42300 - 50 * ref_slope
+    assert abs(base / 6630000 - 1) < 0.02, base
+    assert abs(fixed / ref_fixed - 1) < 0.05, fixed
+    assert -0.09 < slope / ref_slope - 1 < -0.04, slope                      # the gap: 495 against 531 per slot
+    for T, ref in ((50, 42300), (500, 281200)):
+        gap = ref - (fixed + T * slope)
+        assert gap > 0 and (ref_slope - slope) * T / gap > 0.7, (T, gap)
+    # gadget calls per user asset slot (what the slope is made of): every count is linear in the slot count
+    per_slot = {k: (census[(500, 500, 2)].get(k, 0) - census[(500, 500, 1)].get(k, 0) - census[(50, 500, 2)].get(k, 0) + census[(50, 500, 1)].get(k, 0)) / 450.0
+                for k in ("assert", "inverse", "mul", "lookup_query", "is_zero", "cmp", "assert_le", "assert_bool", "lookup_call")}
+    assert per_slot["cmp"] == 4 and per_slot["assert_le"] == 4 and abs(per_slot["lookup_query"] - 29) < 1e-9 and per_slot["lookup_call"] == 3
+    assert 150 < per_slot["inverse"] < 160 and 170 < per_slot["assert"] < 190
+
+
+def test_the_wire_vector_satisfies_the_statement_in_python_integers():
+    """an evaluator of (L w) o (R w) = O w in Python integers (tests/r1cs_bigint.py: the matrices, the coefficient table and w only —
+    no header of the package's executors) accepts the host executor's wire vector, finds the assigned inputs in their slots, and
+    names the rows a flipped wire breaks (VERDICT r04 missing #4: the solver had no check outside its own package)"""
+    import r1cs_bigint as RB
+    shape = (4, 10, 5)
+    inp = C.synth_inputs(*shape, seed=13)
+    c = C.Circuit(*shape)
+    try:
+        w = c.solve_host(inp, C.default_commitment(), threads=3, check_rows=False)
+        mats = [c.matrix(m) for m in range(3)]
+        bad, _ = RB.failing_rows(c.coeff(), mats, w)
+        assert bad.size == 0
+        assert np.array_equal(w[1:1 + inp.shape[0]], inp) and ints(w[:1]) == [1]
+        t = w.copy()
+        k = c.n_wires // 2
+        t[k] = O.fr_from_ints([(ints(t[k:k + 1])[0] + 1) % R])[0]
+        bad, _ = RB.failing_rows(c.coeff(), mats, t)
+        assert bad.size > 0
+        lo, hi = mats[0][0], None
+        # every failing row really mentions the flipped wire in one of its three expressions
+        for row in bad[:20]:
+            assert any(k in mats[m][2][mats[m][0][row]:mats[m][0][row + 1]] for m in range(3))
+    finally:
+        c.close()
+
+
 def test_assertions_are_flagged_check_in_the_container():
     """host/solver_file.hpp INSTR_CHECK: the R1C instructions without an unknown wire carry bit 8 of their kind word (an executor whose caller
     checks every row afterwards may leave them out); everything else reads the low byte — the host executor above parsed the same container"""

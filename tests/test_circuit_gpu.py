@@ -47,6 +47,12 @@ def prove_once(zk, shape, variant, seed=7, compare=True, reps=1):
         td = T.SynthKeyTrapdoor(SEED, cir.n_public, w, h[: D - 1], masks=(inf_a, inf_b, removed))
         assert td.check(proof, rr, ss) and not td.check(proof, ss, rr)
         assert np.array_equal(w[cir.commitment_wire], ch)
+        assert np.array_equal(w[1:1 + inp.shape[0]], inp)                 # the assignment sits in its slots
+        if cir.n_constraints <= 1 << 20:
+            # the DEVICE's wire vector against the statement itself, in Python integers: an evaluator outside the package (tests/r1cs_bigint.py)
+            import r1cs_bigint as RB
+            bad, _ = RB.failing_rows(cir.coeff(), [cir.matrix(m) for m in range(3)], w)
+            assert bad.size == 0, bad[:10]
         if compare:
             ref = C.Circuit(*shape, inputs=inp, commitment=ch)            # the interpreter, given the challenge the device derived
             try:

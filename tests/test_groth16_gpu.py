@@ -57,6 +57,19 @@ def test_prove_tail_matches_oracle_and_verifies(zk, n_cons, z_bitrev):
         pk.close()
 
 
+def test_exceptions_stop_at_the_abi(zk):
+    """an exception raised inside an entry point is an error return with its text in zkpor_last_error, never an unwinding into the
+    caller (include/zkpor.h "never throw"; the reference's prover logs the error and goes on, src/prover/prover/prover.go:269-272):
+    std::exception -> ZKPOR_E_HIP, std::bad_alloc -> ZKPOR_E_OOM, anything else -> ZKPOR_E_HIP; the context keeps working"""
+    import ctypes
+    for value, want_rc, text in ((1, -2, "debug_throw 1"), (2, -4, "std::bad_alloc"), (3, -2, "unknown C++ exception")):
+        rc = zk.lib.zkpor_set_param(zk.h, b"debug_throw", ctypes.c_int64(value))
+        assert rc == want_rc, (value, rc)
+        assert text in zk.lib.zkpor_last_error(zk.h).decode()
+    zk.set_param("debug_throw", 0)
+    assert zk.msm_g1(np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)) is not None
+
+
 def test_pk_rejects_inconsistent_lengths(zk):
     S = O.Synth(4, 20, n_public=2, seed=3)
     pk = zkpor.ProvingKey(zk)

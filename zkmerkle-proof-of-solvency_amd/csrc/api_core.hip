@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <stdexcept>
 #include <thread>
 
 using namespace zk;
@@ -386,7 +387,15 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
         for (hipStream_t* st : {&ctx->tail_stream, &ctx->tail_aux}) if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
         ctx->tail_reserve_cus = (int)value;
     }
+    else if (n == "tail_aux_masked") { if (value < 0 || value > 1) { ctx->err = "tail_aux_masked must be 0 or 1"; return ZKPOR_E_ARG; } ctx->tail_aux_masked = (int)value; }
     else if (n == "debug_validate") { if (value < 0 || value > 1) { ctx->err = "debug_validate must be 0 or 1"; return ZKPOR_E_ARG; } ctx->debug_validate = (int)value; }
+    else if (n == "debug_throw") {   // test-only: an exception raised INSIDE an entry point must come back as an error code (the ABI firewall)
+        const char* t = getenv("ZKPOR_TESTING");
+        if (!t || strcmp(t, "1") != 0) { ctx->err = "debug_throw is a test hook: set ZKPOR_TESTING=1 in the environment to enable it"; return ZKPOR_E_ARG; }
+        if (value == 1) throw std::runtime_error("debug_throw 1");
+        if (value == 2) throw std::bad_alloc();
+        if (value == 3) throw 42;
+    }
     else if (n == "poseidon_out_idx") ctx->pos_out = (int)value;
     else if (n == "poseidon_carry_idx") ctx->pos_carry = (int)value;
     else { ctx->err = "unknown parameter " + n; return ZKPOR_E_ARG; }

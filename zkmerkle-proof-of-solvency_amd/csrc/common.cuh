@@ -76,6 +76,7 @@ struct zkpor_ctx {
     int tail_reserve_cus = 0;        // > 0: the prove tail's kernels (NTT passes, digit streams, accumulations) run on streams whose CU mask leaves this many
                                      // compute units free (evenly over the XCDs) — for the narrow, dependent launches of ANOTHER worker's solver program, which
                                      // otherwise queue behind full-size MSM grids (solve(i+1) beside tail(i): host/prover_host.hpp workers, bench.py end_to_end)
+    int tail_aux_masked = 0;         // 1: the digit streams of a masked tail keep to the tail's CU mask; 0: they may use the reserved units too
     hipStream_t tail_stream = nullptr, tail_aux = nullptr;   // created on first use, destroyed when the parameter changes
     int debug_validate = 0;          // 1: every sorted digit stream is checked (keys ascending and below the bucket count, point indices inside the array) on the
                                      // accumulating stream before its level-1 kernel reads it; a violation is ZKPOR_E_STATE instead of a GPU memory fault

@@ -616,7 +616,9 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
             ZK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->tail_stream, (uint32_t)mask.size(), mask.data()));
             ZK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->tail_aux, (uint32_t)mask.size(), mask.data()));
         }
-        main_s = ctx->tail_stream; aux_s = ctx->tail_aux;
+        // the digit streams (decompose, radix sort, filter) are HBM-bound helpers that starve beside the VALU-bound kernels of the main stream
+        // (profiles/r03_timeline_*.txt); "tail_aux_masked" 0 lets them use the reserved compute units as well
+        main_s = ctx->tail_stream; aux_s = ctx->tail_aux_masked ? ctx->tail_aux : ctx->aux_stream;
     }
     hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx), e_up = ev_get(ctx), e_wB = ev_get(ctx), e_wK = ev_get(ctx);
     struct EvGuard { zkpor_ctx* c; hipEvent_t e[7]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up, e_wB, e_wK}, caller_s};
