@@ -220,22 +220,29 @@ func main() {
 	fmt.Printf("%d instructions (%d skipped), %d levels, %d hint names %v, %d words of call data\n", nIns, len(skip), len(r1cs.Levels), len(names), names, len(callData))
 }
 
-// wireTree is the constraint.InstructionTree the blueprints update: which wires earlier instructions solve (inputs carry level -1 and count
-// as present: gnark's builder inserts them before the first instruction)
+// wireTree is the constraint.InstructionTree the blueprints update while gnark levelises a system.  gnark's contract (constraint/core.go,
+// 3P-recalled — ADVICE r04): HasWire is FALSE for inputs and constants and TRUE for every internal wire; an internal wire no instruction
+// has solved yet reports GetWireLevel == LevelUnset.  BlueprintGenericR1C.UpdateInstructionTree skips the wires without HasWire, takes
+// the one internal wire that is still LevelUnset as the constraint's output and inserts it one level above its deepest solved operand —
+// so an R1C instruction that inserts NO wire has no unknown left: an assertion (CHECK).  `inserted` counts InsertWire calls on internal
+// wires only (round 4 had HasWire inverted: products of intermediates were flagged CHECK and assertions over inputs were not).
 type wireTree struct {
-	level    []int32
+	level    []int32 // per wire; -1 = LevelUnset
 	inserted int
-	inputs   int
+	inputs   int // 1 + nPublic + nSecret wires in front: never solved by an instruction
 }
 
 func (t *wireTree) InsertWire(wire uint32, level constraint.Level) {
+	if int(wire) < t.inputs || int(wire) >= len(t.level) {
+		return
+	}
 	t.level[wire] = int32(level)
 	t.inserted++
 }
-func (t *wireTree) HasWire(wire uint32) bool { return int(wire) < t.inputs || t.level[wire] >= 0 }
+func (t *wireTree) HasWire(wire uint32) bool { return int(wire) >= t.inputs && int(wire) < len(t.level) }
 func (t *wireTree) GetWireLevel(wire uint32) constraint.Level {
-	if int(wire) < t.inputs {
+	if !t.HasWire(wire) {
 		return constraint.LevelUnset
 	}
-	return constraint.Level(t.level[wire])
+	return constraint.Level(t.level[wire]) // -1 == constraint.LevelUnset until inserted
 }

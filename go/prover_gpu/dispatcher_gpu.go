@@ -182,6 +182,14 @@ func (d *dispatcher) runLoop(w *gpuWorker, heights <-chan int64) error {
 	}
 }
 
+// loadedTier reads Prover.CurrentSnarkParamsInUse under the tier lock: LoadSnarkParamsOnce writes it holding d.tier.Lock (ADVICE r04:
+// park / unpark read it bare — a data race under `go test -race`)
+func (d *dispatcher) loadedTier() int {
+	d.tier.RLock()
+	defer d.tier.RUnlock()
+	return d.p.CurrentSnarkParamsInUse
+}
+
 // tierOfRow: the tier the prover would load for this row (decided by the first user: circuit.SetBatchCreateUserCircuitWitness :363-366)
 func tierOfRow(bw *witness.BatchWitness) int {
 	wc := utils.DecodeBatchWitness(bw.WitnessData)
@@ -190,7 +198,7 @@ func tierOfRow(bw *witness.BatchWitness) int {
 
 // park keeps a row of another tier for later while the feed is still running; false = prove it now
 func (d *dispatcher) park(bw *witness.BatchWitness) bool {
-	cur := d.p.CurrentSnarkParamsInUse
+	cur := d.loadedTier()
 	if cur == 0 { // nothing loaded yet: the first row decides
 		return false
 	}
@@ -221,8 +229,8 @@ func (d *dispatcher) unpark() *witness.BatchWitness {
 		return nil
 	}
 	// rows of the tier that is loaded go first: the other workers are still proving them
-	if rows := d.parked[d.p.CurrentSnarkParamsInUse]; len(rows) > 0 {
-		best = d.p.CurrentSnarkParamsInUse
+	if cur := d.loadedTier(); len(d.parked[cur]) > 0 {
+		best = cur
 	}
 	bw := d.parked[best][0]
 	d.parked[best] = d.parked[best][1:]

@@ -12,6 +12,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "zkmerkle-proof
 
 def pytest_configure(config):
     os.environ.setdefault("ZKPOR_TESTING", "1")   # enables the library's test-only hooks (zkpor_set_param "debug_ntt_fault")
+    os.environ.setdefault("ZKPOR_ABORT_TRACE", "1")   # a SIGABRT from ANY thread (the HIP / HSA runtimes abort from their own) leaves its native stack on stderr
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); runs through the C ABI of libzkpor.so")
     config.addinivalue_line("markers", "isolated: the test body runs in a child interpreter (threads / several contexts / subprocess drivers): "
                                        "a native crash is a failed test, not a dead session")

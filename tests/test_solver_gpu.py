@@ -195,6 +195,46 @@ def test_external_hints_pause_and_resume(zk):
         d_w.free(); s.close(); r.close()
 
 
+def test_a_level_with_more_external_hints_than_the_old_list_held(zk):
+    """5 000 external hints side by side in ONE level (the list the level kernels report them through held 4 096 until round 4 and a level
+    beyond it was ZKPOR_E_STATE): the list now holds every external hint of the program; all are served, in instruction
+    order, and the wires behind them come out right"""
+    n = 5000
+    rng = np.random.default_rng(8)
+    vals = [int(v) for v in rng.integers(1, 1 << 62, size=n)]
+    b = SC.Builder([3], vals)
+    base = b.n_public
+    ext = lambda ins: ((ins[0] * 3 + 1) % SC.R,)
+    outs = []
+    for i in range(n):
+        e_in = [b.wire(base + i)]
+        outs.append(b.hint("AnotherHintOfTheCaller", e_in, list(ext([b.eval(e) for e in e_in])))[0])
+    acc = b.mul(b.wire(outs[0]), b.wire(outs[-1]))
+    b.is_zero(b.sub(b.wire(acc), b.wire(acc)))
+    r, s = device_system(zk, b)
+    d_w = zk.alloc(len(b.val) * 32)
+    try:
+        host_w = np.zeros((len(b.val), 4), np.uint64)
+        n_in = b.n_public + b.n_secret
+        host_w[:n_in] = inputs_of(b)
+        d_w.upload(host_w)
+        served = 0
+        last = -1
+        paused = s.start_dev(d_w.ptr, n_in)
+        while paused != zkpor.NOT_PAUSED:
+            assert paused > last
+            last = paused
+            ins_vals, n_out = s.external_inputs(paused)
+            assert n_out == 1
+            s.external_outputs(paused, SC.to_mont_limbs(list(ext(SC.from_mont_limbs(ins_vals)))))
+            served += 1
+            paused = s.resume_dev()
+        assert served == n
+        assert np.array_equal(d_w.download(np.uint64, (len(b.val), 4)), SC.to_mont_limbs(b.val))
+    finally:
+        d_w.free(); s.close(); r.close()
+
+
 def test_failures_are_errors(zk):
     def fails(b, text, vals=None, solver=None):
         r, s = device_system(zk, b, solver=solver)

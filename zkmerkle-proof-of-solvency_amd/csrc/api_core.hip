@@ -5,6 +5,10 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/prctl.h>
+#include <unistd.h>
 #include <stdexcept>
 #include <thread>
 
@@ -112,6 +116,44 @@ void bounce_free(zkpor_ctx* ctx) {
     if (ctx->bounce && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);  // no DMA may still read the buffers
     delete (Bounce*)ctx->bounce;
     ctx->bounce = nullptr;
+}
+
+// ---- ZKPOR_ABORT_TRACE=1: the native stack of whichever thread raises SIGABRT, on stderr, before the process dies ----
+// The HIP / HSA runtimes abort() from their own threads on a device exception, and a Python caller's faulthandler can only say "some thread
+// that is not mine" (GPUTEST_r04: a silent rc 134 inside zkpor_prove_tail).  Async-signal-safe enough for a process that is dying anyway:
+// backtrace() is pre-loaded at install time, the symbols go straight to fd 2.  The previous handler (faulthandler's) runs afterwards.
+namespace {
+struct sigaction g_prev_abrt;
+bool g_abort_trace_on = false;
+void abort_trace(int sig) {
+    static const char head[] = "\n[zkpor] SIGABRT raised on thread ";
+    (void)!write(2, head, sizeof head - 1);
+    char name[32] = {0};
+    (void)prctl(PR_GET_NAME, name, 0, 0, 0);
+    (void)!write(2, name, strlen(name));
+    static const char mid[] = " - native stack:\n";
+    (void)!write(2, mid, sizeof mid - 1);
+    void* fr[96];
+    const int n = backtrace(fr, 96);
+    backtrace_symbols_fd(fr, n, 2);
+    (void)sigaction(sig, &g_prev_abrt, nullptr);     // hand over to whoever was there before (Python's faulthandler, else the default action)
+    (void)raise(sig);
+}
+}  // namespace
+void abort_trace_install() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* e = getenv("ZKPOR_ABORT_TRACE");
+        if (!e || strcmp(e, "1") != 0) return;
+        void* fr[4];
+        (void)backtrace(fr, 4);                      // loads the unwinder now, not inside the handler
+        struct sigaction sa;
+        memset(&sa, 0, sizeof sa);
+        sa.sa_handler = abort_trace;
+        sigemptyset(&sa.sa_mask);
+        sa.sa_flags = SA_NODEFER;
+        g_abort_trace_on = sigaction(SIGABRT, &sa, &g_prev_abrt) == 0;
+    });
 }
 
 // ---- turns on the device (common.cuh GpuTurn): one flag per GPU, shared by every context of the process ----
@@ -283,6 +325,7 @@ int32_t zkpor_dev_copy(zkpor_ctx* ctx, void* d_dst, const void* d_src, size_t by
 int32_t zkpor_init(int device, void* stream, zkpor_ctx** out) try {
     if (!out) return ZKPOR_E_ARG;
     *out = nullptr;
+    zk::abort_trace_install();
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZKPOR_E_NODEVICE;
     hipDeviceProp_t prop;

@@ -103,7 +103,7 @@ struct zkpor_ctx {
 // library can throw; a cgo caller cannot unwind — the reference's prover logs an error return and moves on
 // (src/prover/prover/prover.go:269-272), it must never be killed by its backend.  The text of the exception is kept per host thread
 // and shown by the next zkpor_last_error of that thread.
-namespace zk { void abi_exception(const char* what) noexcept; }
+namespace zk { void abi_exception(const char* what) noexcept; void abort_trace_install(); }
 #define ZK_ABI_CATCH                                                                                      \
     catch (const std::bad_alloc&) { zk::abi_exception("std::bad_alloc"); return ZKPOR_E_OOM; }           \
     catch (const std::exception& e__) { zk::abi_exception(e__.what()); return ZKPOR_E_HIP; }             \

@@ -62,7 +62,8 @@ struct zkpor_solver {
     uint64_t* d_gen_lo = nullptr;
     uint8_t *d_hint_kind = nullptr, *d_known = nullptr;
     uint32_t* d_err = nullptr;                  // [0] first error code, [1] its instruction, [2] wires never assigned, [3] externals met in the level just run
-    uint32_t* d_ext = nullptr;                  // external hint instructions of the level just run (capacity EXT_CAP)
+    uint32_t* d_ext = nullptr;                  // external hint instructions of the level just run (capacity ext_cap)
+    uint32_t ext_cap = 0;                       // = max(EXT_CAP, external hints of the whole program): a level can never report more than fit
     uint32_t* d_cnt = nullptr;                  // histograms of the count hints of the level being served (the largest level's table rows)
     void* d_cmeta = nullptr;                    // zk::CountDev per count hint, level order
     zk::Fr* d_tmp = nullptr;                    // scratch for external hint values (grow-only)
@@ -86,6 +87,8 @@ struct zkpor_solver {
     bool side2_busy = false;
     uint64_t join2_level = 0;
     uint64_t n_r1c = 0, n_hint = 0, n_skip = 0, n_lookup = 0, n_poseidon = 0;
+    uint64_t async_max_wire = 0;                // the highest wire an ASYNC call's input expressions read: a prefetch is legal only if it is an input wire
+    bool run_ok = false;                        // the last run reached its end without an error: its d_w (and the rows it wrote) may be proved over
     // run state (pause / resume)
     bool running = false, side_busy = false;
     uint64_t next_level = 0;
@@ -107,7 +110,7 @@ ZK_D void solver_step(const SolverProg& P, u32 ins, Fr* w, uint8_t* known, u32* 
         const u32 name = P.calldata[P.arg[ins]];
         if (P.hint_kind[name] == HK_NONE) {
             const u32 slot = atomicAdd(&err[3], 1u);
-            if (slot < EXT_CAP) ext[slot] = ins;
+            if (slot < P.ext_cap) ext[slot] = ins;
             return;
         }
     }
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void k_solve_level_batched(SolverProg P, const
             const u32 ins = level_instr[lo + i];
             if (P.kind[ins] == SI_HINT && P.hint_kind[P.calldata[P.arg[ins]]] == HK_NONE) {
                 const u32 slot = atomicAdd(&err[3], 1u);
-                if (slot < EXT_CAP) ext[slot] = ins;
+                if (slot < P.ext_cap) ext[slot] = ins;
                 continue;
             }
             if (long_list && P.kind[ins] == SI_R1C && P.arg[ins] < P.n_constraints) {   // a long constraint: one thread would walk its terms alone
@@ -370,6 +373,19 @@ __global__ __launch_bounds__(256) void k_solve_chain(SolverProg P, const u32* __
 }
 
 // a x b = c on every row (zkpor_solver_eval_abc_dev when the run left the CHECK instructions out): out[0] = rows that fail, out[1] = the lowest one
+// a Poseidon instruction that names its constraint rows (firstRow) writes a, b, c of those rows itself and r1cs_eval skips them: the rows must
+// really be the call's S-box products — row firstRow + k is `... = wire firstOut + k`: an O expression of ONE term, coefficient one, on exactly
+// that wire.  calls: (firstOut, firstRow, rows, instruction) quadruples.  bad[0] = violations, bad[1] = the lowest offending instruction.
+__global__ __launch_bounds__(256) void k_check_poseidon_rows(const u64* __restrict__ o_ptr, const u32* __restrict__ o_cid, const u32* __restrict__ o_wid,
+                                                             const uint8_t* __restrict__ ckind, const u32* __restrict__ calls, u32 n_calls, u32* __restrict__ bad) {
+    for (u32 c = blockIdx.x; c < n_calls; c += gridDim.x) {
+        const u32 first = calls[4 * c], row0 = calls[4 * c + 1], rows = calls[4 * c + 2], ins = calls[4 * c + 3];
+        for (u32 k = threadIdx.x; k < rows; k += 256u) {
+            const u64 lo = o_ptr[row0 + k], hi = o_ptr[row0 + k + 1];
+            if (hi - lo != 1 || o_wid[lo] != first + k || ckind[o_cid[lo]] != 1) { atomicAdd(bad, 1u); atomicMin(bad + 1, ins); }
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_rows_check(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c, size_t n, unsigned long long* out) {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -498,6 +514,7 @@ static SolverProg prog_of(const zkpor_solver* s) {
     P.n_constraints = (u32)r->n_constraints; P.n_wires = (u32)r->n_wires; P.n_coeff = (u32)r->n_coeff;
     P.kind = s->d_kind; P.arg = s->d_arg; P.calldata = s->d_calldata; P.n_calldata = s->view.n_calldata;
     P.hint_kind = s->d_hint_kind; P.n_hint_names = (u32)s->hint_kind.size();
+    P.ext_cap = s->ext_cap;
     return P;
 }
 static void solver_free(zkpor_solver* s) {
@@ -683,7 +700,7 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
         return ZKPOR_E_STATE;
     }
     if (h[3]) {   // external hints met in the last level: serve them one by one (a level is small next to what a commitment costs)
-        if (h[3] > EXT_CAP) { s->running = false; ctx->err = "solver: more external hints in one level than the executor records"; return ZKPOR_E_STATE; }
+        if (h[3] > s->ext_cap) { s->running = false; ctx->err = "solver: a level reported more external hints than the program holds"; return ZKPOR_E_STATE; }   // cannot happen: the list holds every external hint of the program
         s->pending.resize(h[3]);
         ZK_HIP(ctx, hipMemcpy(s->pending.data(), s->d_ext, h[3] * sizeof(u32), hipMemcpyDeviceToHost));
         std::sort(s->pending.begin(), s->pending.end());
@@ -693,7 +710,13 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
     }
     if (finished) {
         s->running = false;
-        if (h[2]) { ctx->err = "solver: " + std::to_string(h[2]) + " wires were never assigned"; return ZKPOR_E_STATE; }
+        if (h[2]) {
+            ctx->err = "solver: " + std::to_string(h[2]) + " wires were never assigned";
+            // a constraint that SOLVES a wire but carries the CHECK flag was left out with the assertions: the exporter's flags are wrong, not the witness
+            if (s->checks_left) ctx->err += " (this run left the " + std::to_string(s->n_check) + " CHECK-flagged instructions to the row check: if the program's flags are not trustworthy — a new exporter — set the context parameter solver_defer_checks to 0)";
+            return ZKPOR_E_STATE;
+        }
+        s->run_ok = true;      // this d_w (and the rows the run wrote) may be proved over: zkpor_solver_eval_abc_dev
     }
     return ZKPOR_OK;
 }
@@ -736,6 +759,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     std::map<uint32_t, BigHint> big;                     // by instruction
     uint64_t max_table = 1, pre_total = 0;
     std::vector<uint32_t> row_bits((r1cs->n_constraints + 31) / 32 + 1, 0);
+    std::vector<uint32_t> pos_rows;                      // (first output wire, first row, rows, instruction) of every call that writes its own rows
     auto const_u32 = [&](const uint32_t* cd, uint64_t p, uint32_t* out_v) {   // a constant expression's value (nbTable, nbCols)
         if (cd[p] == 0) { *out_v = 0; return true; }
         if (cd[p] != 1 || cd[p + 2] != 0) return false;
@@ -783,14 +807,26 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
                 const uint64_t row0 = v.calldata[arg + 4], nrows = v.calldata[arg + 2];
                 if (row0 != 0xffffffffull) {
                     if (row0 + nrows > r1cs->n_constraints) return bad("Poseidon instruction " + std::to_string(i) + " names rows outside the system");
-                    if (cls[i] == CL_POS) { for (uint64_t rr = row0; rr < row0 + nrows; ++rr) row_bits[rr >> 5] |= 1u << (rr & 31); s->rows_covered += nrows; }
+                    if (cls[i] == CL_POS) {
+                        for (uint64_t rr = row0; rr < row0 + nrows; ++rr) {
+                            if (row_bits[rr >> 5] & (1u << (rr & 31))) return bad("Poseidon instructions " + std::to_string(i) + " and an earlier one both claim constraint row " + std::to_string(rr));
+                            row_bits[rr >> 5] |= 1u << (rr & 31);
+                        }
+                        s->rows_covered += nrows;
+                        pos_rows.push_back(v.calldata[arg + 1]); pos_rows.push_back((uint32_t)row0); pos_rows.push_back((uint32_t)nrows); pos_rows.push_back((uint32_t)i);
+                    }
                 }
             }
             if (cls[i] == CL_POSA) {
                 BigHint b;
                 b.ins = (uint32_t)i; b.n_in = v.calldata[arg]; b.offs_base = offs.size(); b.nb_q = pre_total;
                 uint64_t p = zkpor_host::POSEIDON_HDR;
-                for (uint32_t k = 0; k < b.n_in; ++k) { offs.push_back((uint32_t)p); p += 1 + 2ull * v.calldata[arg + p]; }
+                for (uint32_t k = 0; k < b.n_in; ++k) {
+                    offs.push_back((uint32_t)p);
+                    const uint64_t nt = v.calldata[arg + p];
+                    for (uint64_t t = 0; t < nt; ++t) s->async_max_wire = std::max<uint64_t>(s->async_max_wire, v.calldata[arg + p + 2 + 2 * t]);   // a prefetch reads these from the bare assignment
+                    p += 1 + 2 * nt;
+                }
                 pre_total += b.n_in;
                 big[(uint32_t)i] = b;
             }
@@ -879,11 +915,33 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
               up((void**)&s->d_rows, row_bits.data(), row_bits.size() * 4) && up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up(&s->d_cmeta, cmeta.data(), cmeta.size() * sizeof(CountDev)) && up((void**)&s->d_pre_off, pre_off_host.data(), pre_off_host.size() * 4) &&
               hipMalloc((void**)&s->d_pre, (pre_total ? pre_total : 1) * sizeof(Fr)) == hipSuccess && up((void**)&s->d_hint_kind, s->hint_kind.data(), s->hint_kind.size()) &&
               hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 32) == hipSuccess && hipMalloc((void**)&s->d_long, (size_t)(LONG_CAP + 1u) * 4) == hipSuccess &&
-              hipMalloc((void**)&s->d_ext, EXT_CAP * sizeof(u32)) == hipSuccess && hipMalloc((void**)&s->d_cnt, max_table * sizeof(u32)) == hipSuccess &&
+              hipMalloc((void**)&s->d_ext, (size_t)(s->ext_cap = (u32)std::max<size_t>(EXT_CAP, s->externals.size() + 1)) * sizeof(u32)) == hipSuccess && hipMalloc((void**)&s->d_cnt, max_table * sizeof(u32)) == hipSuccess &&
               hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess && hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_fork2, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->ev_join2, hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); solver_free(s); ctx->err = "solver: out of device memory"; return ZKPOR_E_OOM; }
+    if (!pos_rows.empty()) {   // the rows the Poseidon instructions will write instead of r1cs_eval: checked against the O matrix, once, here
+        u32* d_calls = nullptr;
+        u32 h[2] = {0u, 0xffffffffu};
+        hipError_t e = hipMalloc((void**)&d_calls, pos_rows.size() * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_calls, pos_rows.data(), pos_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s->d_err + 4, h, 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            const u32 n_calls = (u32)(pos_rows.size() / 4);
+            hipLaunchKernelGGL(k_check_poseidon_rows, dim3(n_calls < 4096u ? n_calls : 4096u), dim3(256), 0, ctx->stream, (const u64*)r1cs->row_ptr[2], (const u32*)r1cs->cid[2],
+                               (const u32*)r1cs->wid[2], (const uint8_t*)r1cs->coeff_kind, (const u32*)d_calls, n_calls, s->d_err + 4);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h, s->d_err + 4, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (d_calls) (void)hipFree(d_calls);
+        if (e != hipSuccess) { solver_free(s); ctx->err = std::string("solver: checking the Poseidon rows: ") + hipGetErrorString(e); return ZKPOR_E_HIP; }
+        if (h[0]) {
+            solver_free(s);
+            ctx->err = "solver: " + std::to_string(h[0]) + " of the constraint rows Poseidon instructions claim (firstRow) are not `... = output wire` of that call; the first such instruction is " + std::to_string(h[1]);
+            return ZKPOR_E_ARG;
+        }
+    }
     *out = s;
     return ZKPOR_OK;
 } ZK_ABI_CATCH
@@ -925,7 +983,7 @@ int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint
         for (const BigHint& a : s->asyncs) { const uint32_t* cd = s->view.calldata + s->view.arg[a.ins]; ZK_HIP(ctx, hipMemsetAsync(s->known + cd[1], 1, cd[2], ctx->stream)); }
     s->abc_written = s->abc_a != nullptr && ctx->solver_poseidon == 1 && s->rows_covered > 0;
     s->checks_left = s->abc_a != nullptr && ctx->solver_defer_checks != 0 && s->n_check > 0;   // zkpor_solver_eval_abc_dev verifies a x b = c on every row instead
-    s->running = true; s->next_level = 0; s->pending.clear(); s->launches = 0;
+    s->running = true; s->run_ok = false; s->next_level = 0; s->pending.clear(); s->launches = 0;
     return solver_advance(s, paused_instr);
 } ZK_ABI_CATCH
 
@@ -945,6 +1003,11 @@ int32_t zkpor_solver_eval_abc_dev(zkpor_solver* s, const void* d_w, void* d_a, v
     if (!s || !d_w || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
     if ((s->abc_written || s->checks_left) && (d_a != s->abc_a || d_b != s->abc_b || d_c != s->abc_c)) { ctx->err = "solver: the run was made for other a, b, c buffers than these"; return ZKPOR_E_ARG; }
+    // rows the run wrote are skipped below and assertions it left out are verified here: both only mean something for the vector THAT run solved, to its end
+    if ((s->abc_written || s->checks_left) && (!s->run_ok || d_w != s->d_w)) {
+        ctx->err = !s->run_ok ? "solver: no completed run to take a, b, c from (the last run failed, is paused, or none was made)" : "solver: d_w is not the wire vector the last run solved";
+        return ZKPOR_E_STATE;
+    }
     ZK_TRY(zk::r1cs_eval_on(ctx, s->r1cs, d_w, d_a, d_b, d_c, domain_size, s->abc_written ? s->d_rows : nullptr));
     if (!s->checks_left) return ZKPOR_OK;
     // the run left its CHECK instructions out: every row is verified here instead, a x b = c (the Poseidon rows the solver wrote included)
@@ -976,6 +1039,8 @@ int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inpu
     if (s->asyncs.empty()) return ZKPOR_OK;
     if (s->plan.empty() || s->plan[0].n_posa != s->asyncs.size()) { ctx->err = "solver: an ASYNC instruction outside the first level cannot be prefetched"; return ZKPOR_E_STATE; }
     if (s->side_busy) { ctx->err = "solver: the side stream still runs a chain (one prefetch at a time, after the current run's last level)"; return ZKPOR_E_STATE; }
+    // a prefetch evaluates the calls' inputs from the bare assignment (every wire taken as known): legal only when they read input wires
+    if (s->async_max_wire >= n_inputs) { ctx->err = "solver: an ASYNC instruction reads wire " + std::to_string(s->async_max_wire) + ", not an input (the assignment holds " + std::to_string(n_inputs) + " elements): it cannot be prefetched"; return ZKPOR_E_STATE; }
     const size_t nw = s->r1cs->n_wires;
     if (!s->d_ones) {
         ZK_HIP(ctx, hipMalloc((void**)&s->d_ones, nw));
@@ -995,7 +1060,6 @@ int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inpu
     ZK_TRY(gadget_poseidon_launch(ctx, s->side, P, s->d_level_instr + L.lo + L.n_gen + L.n_chk + L.n_pos, L.n_posa, (Fr*)d_w_next, s->d_ones, s->d_perr, s->d_pre, s->d_pre_off + L.posa_first, nullptr, nullptr, nullptr));
     s->side_busy = true;
     s->prefetched_w = d_w_next;
-    (void)n_inputs;
     return ZKPOR_OK;
 } ZK_ABI_CATCH
 

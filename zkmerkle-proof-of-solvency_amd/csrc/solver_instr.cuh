@@ -34,6 +34,7 @@ struct SolverProg {
     const u32* kind; const u32* arg;                              // per instruction
     const u32* calldata; u64 n_calldata;                          // hint call data (layout: host/solver_file.hpp)
     const uint8_t* hint_kind; u32 n_hint_names;                   // HK_* per hint name id
+    u32 ext_cap = 0;                                              // device executor: entries of its external-hint list (every external hint of the program fits)
 };
 
 ZK_HD void si_add_term(Fr& acc, uint8_t k, const Fr* coeff, u32 cid, const Fr& x) {

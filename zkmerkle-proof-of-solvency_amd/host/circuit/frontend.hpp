@@ -570,7 +570,14 @@ inline LE Builder::poseidon(const std::vector<LE>& inputs, int async, int out_id
         calldata_.push_back((u32)n_constraints());      // its constraints follow as consecutive rows, three per S-box
         for (auto& e : inputs) push_le(e);
         for (size_t i = 0; i < 3 * total_sbox; ++i) producer_[base + i] = (u32)kind_.size();
-        if (async == 1) async_instrs_.push_back({(u32)kind_.size(), lvl});
+        if (async == 1) {
+            // finish() puts an async-1 call back at its as-soon-as-possible level while its producers may have moved late, and a prefetch
+            // (zkpor_solver_prefetch_dev) evaluates its inputs from the bare assignment: both are only sound when the inputs ARE the assignment
+            for (auto& e : inputs)
+                for (u32 t = 0; t < e.size(); ++t)
+                    if (e[t].wire >= n_public_ + n_secret_) throw std::runtime_error("circuit: an async Poseidon call may read input wires only (it read internal wire " + std::to_string(e[t].wire) + ")");
+            async_instrs_.push_back({(u32)kind_.size(), lvl});
+        }
         if (async == 2) beside_instrs_.push_back((u32)kind_.size());
         push_instr(K_POSEIDON, off, lvl);
     }
