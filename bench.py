@@ -1687,6 +1687,7 @@ def main():
                     "in HBM, solver program + BSB22 commitment + a, b, c + prove tail on the device; the challenge is hashed on the host.  "
                     f"{len(E.wk)} worker(s) per GPU: one proof's solve runs beside the other's prove tail" + (f", whose kernels leave {E.reserve} of the compute units free" if E.reserve else "")})
         e2e["same_wires_as_headline"] = E.same_wires(w) if args.scalars == "witness" else None
+        e2e["bucket_additions_per_proof"] = {k_: ctx.stat(k_) for k_ in ("msm_entries_w", "msm_entries_w_B", "msm_entries_w_K", "msm_entries_h")}   # sorted digit-stream entries of A / B1, B2 / K / Z
         last_w = E.wk[0]["last"]
         e2e["constraints_failing_on_device"] = dc.r1cs.check_dev(last_w.data_ptr())[0]
         if not args.timed_only:
@@ -1852,7 +1853,21 @@ def main():
         traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and profiled_cfg) else None
         vb_ms, vsrc = pmc_valu_issue_bound_ms()
         cw, cwsrc = valu_class_weight()
-        valu = ({"issue_bound_ms_per_launch": vb_ms, "frac": vb_ms / (avg_launch_s * 1e3),
+        adds = e2e.get("bucket_additions_per_proof") if e2e is not None else None
+        per_add = None
+        try:      # lane-instructions per bucket addition: the four big launches of a proof (A, B1, K, Z) in the committed SQ_INSTS_VALU pass over this run's additions
+            import glob as _g
+            _f = sorted(_g.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu.json")))[-1]
+            _pl = json.load(open(_f))["kernels"]["k_acc_level1_fp29"].get("per_launch")
+            if _pl and adds and profiled_cfg:
+                big = sorted(_pl, key=lambda x_: -x_["valu_wave_insts"])[:4]
+                n_adds = adds["msm_entries_w"] + adds["msm_entries_w_B"] + adds["msm_entries_w_K"] + adds["msm_entries_h"]
+                per_add = {"value": sum(x_["valu_wave_insts"] for x_ in big) * 64.0 / n_adds, "bucket_additions": n_adds,
+                           "note": f"64 x SQ_INSTS_VALU (wave instructions, profiles/{os.path.basename(_f)}) of the A, B1, K, Z launches / their sorted digit-stream entries in this run: "
+                                   "VALU instructions per lane and mixed addition, staging, key compares and idle lanes included"}
+        except Exception:      # noqa: BLE001 — informational
+            per_add = None
+        valu = ({"issue_bound_ms_per_launch": vb_ms, "frac": vb_ms / (avg_launch_s * 1e3), "lane_instructions_per_bucket_add": per_add,
                  "frac_class_weighted": (vb_ms * cw / (avg_launch_s * 1e3)) if cw else None,
                  "measured_clock_ghz": clock_ghz, "frac_at_measured_clock": vb_ms / (avg_launch_s * 1e3) * 2.4 / clock_ghz,
                  "frac_class_weighted_at_measured_clock": (vb_ms * cw / (avg_launch_s * 1e3) * 2.4 / clock_ghz) if cw else None,

@@ -117,6 +117,9 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);
  * "solver_levels","rows_check","witgen_scatter","cex_commitments";
  * unknown names return 0.  calls = number of timed regions. */
 double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls);
+/* counters of the context's last call, by name (0 for an unknown name): "msm_entries_w", "msm_entries_w_B", "msm_entries_w_K", "msm_entries_h" = the
+ * sorted digit-stream entries (= bucket additions) of the last prove tail's A / B1 and B2 / K / Z multi-exponentiations */
+int32_t zkpor_stat(zkpor_ctx* ctx, const char* name, uint64_t* value);
 void zkpor_phase_reset(zkpor_ctx* ctx);
 
 /* ---- proving key (replaces pk.UnsafeReadFrom's in-RAM key with an HBM-resident one) ------------------- */

@@ -12,7 +12,14 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "zkmerkle-proof
 
 def pytest_configure(config):
     os.environ.setdefault("ZKPOR_TESTING", "1")   # enables the library's test-only hooks (zkpor_set_param "debug_ntt_fault")
-    os.environ.setdefault("ZKPOR_ABORT_TRACE", "1")   # a SIGABRT from ANY thread (the HIP / HSA runtimes abort from their own) leaves its native stack on stderr
+    # a SIGABRT from ANY thread (the HIP / HSA runtimes abort from their own) leaves its native stack behind — in a FILE: pytest captures fd 2
+    # during a test and a dying process takes the capture with it (which is how GPUTEST_r04's abort came to look silent)
+    trace_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(trace_dir, exist_ok=True)
+        os.environ.setdefault("ZKPOR_ABORT_TRACE", os.path.join(trace_dir, "abort_trace.log"))
+    except OSError:
+        os.environ.setdefault("ZKPOR_ABORT_TRACE", "1")
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); runs through the C ABI of libzkpor.so")
     config.addinivalue_line("markers", "isolated: the test body runs in a child interpreter (threads / several contexts / subprocess drivers): "
                                        "a native crash is a failed test, not a dead session")

@@ -21,22 +21,32 @@ KERNELS = {  # substring of the kernel name -> (label, FETCH_SIZE correction)
 }
 
 
+PER_PROOF = {"k_acc_level1_fp29": 6}   # launches of one proof: 2 Pedersen sums (tiny) + A, B1, K, Z; the set-up solve adds 2 tiny ones in front of the first proof
+
+
 def load(path, counter):
-    agg = collections.defaultdict(lambda: [0.0, 0])
+    rows = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
         for sub, (label, _) in KERNELS.items():
             if sub in r["Kernel_Name"]:
-                agg[label][0] += float(r["Counter_Value"]); agg[label][1] += 1
+                rows[label].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
                 break
+    agg = {}
+    for label, lst in rows.items():
+        lst.sort()
+        if label in PER_PROOF:      # whole proofs only: the launches in front of the first proof belong to the set-up solve
+            lst = lst[len(lst) % PER_PROOF[label]:]
+        agg[label] = [sum(x[1] for x in lst), len(lst)]
     return agg
 
 
 def main():
     fetch = load(sys.argv[1], "FETCH_SIZE"); write = load(sys.argv[2], "WRITE_SIZE")
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --log2 26 --steps 1 "
-                      "--warmup 0 --timed-only (two separate passes, tools/rounds/r03_profile.sh)",
+    cmd = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 1 --warmup 0 --timed-only"
+    script = sys.argv[5] if len(sys.argv) > 5 else "the round's profile script under tools/rounds/"
+    out = {"command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace --output-format csv -- {cmd} (two separate passes, {script})",
            "calibration": "FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 wide coalesced read streams report exactly 1/2 of the true bytes "
                           "(calibrated in round 1 on k_fr_mul: 4.29 GB true reads -> 2.147 GB reported, k_h_pointwise 6.44 -> 3.22; WRITE_SIZE exact), "
                           "as MI355X_MICROARCH.md says; the 64-byte random point gathers of the G1 level-1 kernel are counted 1:1 "

@@ -6,6 +6,7 @@
 #include <memory>
 #include <mutex>
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <sys/prctl.h>
 #include <unistd.h>
@@ -125,17 +126,19 @@ void bounce_free(zkpor_ctx* ctx) {
 namespace {
 struct sigaction g_prev_abrt;
 bool g_abort_trace_on = false;
+int g_abort_fd = 2;     // ZKPOR_ABORT_TRACE=1: stderr; any other value: a file of that name (a test runner that captures fd 2 loses it with the process)
 void abort_trace(int sig) {
+    const int fd = g_abort_fd;
     static const char head[] = "\n[zkpor] SIGABRT raised on thread ";
-    (void)!write(2, head, sizeof head - 1);
+    (void)!write(fd, head, sizeof head - 1);
     char name[32] = {0};
     (void)prctl(PR_GET_NAME, name, 0, 0, 0);
-    (void)!write(2, name, strlen(name));
+    (void)!write(fd, name, strlen(name));
     static const char mid[] = " - native stack:\n";
-    (void)!write(2, mid, sizeof mid - 1);
+    (void)!write(fd, mid, sizeof mid - 1);
     void* fr[96];
     const int n = backtrace(fr, 96);
-    backtrace_symbols_fd(fr, n, 2);
+    backtrace_symbols_fd(fr, n, fd);
     (void)sigaction(sig, &g_prev_abrt, nullptr);     // hand over to whoever was there before (Python's faulthandler, else the default action)
     (void)raise(sig);
 }
@@ -144,7 +147,11 @@ void abort_trace_install() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char* e = getenv("ZKPOR_ABORT_TRACE");
-        if (!e || strcmp(e, "1") != 0) return;
+        if (!e || !*e || strcmp(e, "0") == 0) return;
+        if (strcmp(e, "1") != 0) {
+            const int fd = open(e, O_WRONLY | O_CREAT | O_APPEND, 0644);
+            if (fd >= 0) g_abort_fd = fd;
+        }
         void* fr[4];
         (void)backtrace(fr, 4);                      // loads the unwinder now, not inside the handler
         struct sigaction sa;
@@ -454,6 +461,12 @@ double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls) try {
     if (calls) *calls = it->second.calls;
     return it->second.ms;
 } catch (...) { zk::abi_exception("exception in zkpor_phase_ms"); return -1.0; }
+int32_t zkpor_stat(zkpor_ctx* ctx, const char* name, uint64_t* value) try {
+    if (!ctx || !name || !value) return ZKPOR_E_ARG;
+    auto it = ctx->stats.find(name);
+    *value = it == ctx->stats.end() ? 0 : it->second;
+    return ZKPOR_OK;
+} ZK_ABI_CATCH
 void zkpor_phase_reset(zkpor_ctx* ctx) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return;

@@ -44,6 +44,7 @@ struct zkpor_ctx {
     std::map<int, void*> ntt_domains;
     // timers
     std::map<std::string, PhaseTimer> phases;
+    std::map<std::string, uint64_t> stats;   // counters of the last call, by name (zkpor_stat): digit-stream sizes of the last prove tail
     std::vector<hipEvent_t> event_pool;
     // small pinned host staging buffer
     void* pinned = nullptr;

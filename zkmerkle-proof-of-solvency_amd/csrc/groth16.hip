@@ -644,6 +644,16 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     ZK_TRY(ensure_pinned(ctx, 16 * MSM_SLOT_BYTES));
     char* pin = (char*)ctx->pinned;
     const size_t D = (size_t)1 << n;
+    {   // ZKPOR_DEBUG_ADDR=1: the address ranges this call's kernels may touch, on stderr — a GPU memory fault report names an address, this names the buffer
+        static const bool dbg = [] { const char* e = getenv("ZKPOR_DEBUG_ADDR"); return e && e[0] == '1'; }();
+        if (dbg) {
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            fprintf(stderr, "[zkpor addr] prove_sums log2=%d host=%d nw=%zu nZ=%zu ws=%p+%zu (dw %zu dh %zu) stage=%p+%zu w=%p a=%p b=%p c=%p A=%p B1=%p K=%p Z=%p B2=%p mB=%p mK=%p pin=%p free=%zuMB\n",
+                    n, host ? 1 : 0, pk->n_wires, nZ, (void*)ctx->ws, ctx->ws_cap, need_dw, need_dh, (void*)ctx->stage, ctx->stage_cap, d_w, d_a, d_b, d_c, (void*)pk->A, (void*)pk->B1, (void*)pk->K,
+                    (void*)pk->Z, (void*)pk->B2, (void*)pk->absentB, (void*)pk->absentK, (void*)pin, fr >> 20);
+        }
+    }
     ZK_HIP(ctx, hipEventRecord(e_start, main_s));
     if (host) {
         // w first: everything the witness sums need
@@ -673,6 +683,7 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         // e_w: the sorted shared stream (A starts on it); e_wB: + the B filter; e_wK: + the K filter (the filters hide under A)
         ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw, n_filters ? &filt : nullptr, &dswB, &dswK, e_w, e_wB));
         ZK_HIP(ctx, hipEventRecord(e_wK, aux_s));
+        ctx->stats["msm_entries_w"] = dsw.M; ctx->stats["msm_entries_w_B"] = dswB.M; ctx->stats["msm_entries_w_K"] = dswK.M;   // bucket additions of A / B1, B2 / K
         off_dh = ctx->ws_off;
         ctx->stream = main_s;
         // 3. queue the witness accumulations (they reuse one workspace region in stream order)
@@ -710,6 +721,7 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         ctx->ws_off = off_dh;
         ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_h, 0));
         ZK_TRY(msm_digits(ctx, (const Fr*)d_a, nZ, cfgh, sorth, &dsh));
+        ctx->stats["msm_entries_h"] = dsh.M;
         ZK_HIP(ctx, hipEventRecord(e_hs, aux_s));
         ctx->stream = main_s;
         // 5. Z . h

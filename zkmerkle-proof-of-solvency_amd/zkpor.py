@@ -108,6 +108,11 @@ class Context:
         ms = self.lib.zkpor_phase_ms(self.h, name.encode(), ctypes.byref(calls))
         return ms, calls.value
 
+    def stat(self, name):
+        v = ctypes.c_uint64()
+        self._ck(self.lib.zkpor_stat(self.h, name.encode(), ctypes.byref(v)))
+        return v.value
+
     def phase_reset(self):
         self.lib.zkpor_phase_reset(self.h)
 
