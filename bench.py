@@ -1978,7 +1978,7 @@ def main():
                     except Exception as e:
                         sweep.append({"copy_threads": ct, "gpu_token": tok, "note": f"failed: {e}"})
                 out["boundary_sweep"] = sweep
-                ctx.set_param("copy_threads", 0 if args.copy_threads < 0 else args.copy_threads)
+                ctx.set_param("copy_threads", 4 if args.copy_threads < 0 else args.copy_threads)
                 ctx.set_param("gpu_token", 0 if args.no_gpu_token else 1)
             if args.r1cs_terms > 0:
                 try:

@@ -84,9 +84,13 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * 2^26, m = 4 costs 112 GB of HBM instead of 28 and buys 12 digits of 22 bits instead of 13 of 20 at the same number of buckets
  * (6 % fewer bucket additions; built on the device at load time, ~14 s).  Such a key cannot be cut into shards, and "msm_window" must
  * not change between the load and the proofs,
- * "copy_threads" (how pageable host memory crosses PCIe in the host-pointer entry points: 0, the default, hands the range to the HIP
- * runtime, which page-locks it on the fly and lets the DMA engine read the caller's pages — 56 GB/s measured; n > 0 copies through
- * pinned bounce buffers with n host threads — 30 GB/s, for hosts where page-locking on the fly is not available),
+ * "copy_threads" (how PAGEABLE host memory crosses PCIe in the host-pointer entry points: n > 0, default 4 since round 5, copies through
+ * the context's pinned bounce buffers with n host threads — 30 GB/s, and the GPU never reads a page the library does not own; 0 hands the
+ * range to the HIP runtime, which page-locks it on the fly and lets the DMA engine read the caller's pages — 56 GB/s measured, but pages the
+ * kernel may still migrate (a transparent-huge-page collapse under the copy: DESIGN.md §6c) are then read by the GPU.  Memory page-locked
+ * ONCE by the caller (zkpor_host_register, the recommended form for a Go prover's long-lived slices) is always handed to the DMA engine
+ * directly, whatever this parameter says.  Every other entry point that takes host data — key arrays, matrices, inputs — copies
+ * through the bounce buffers as well),
  * "msm_chunk" 0 = automatic (64 from 2^22 scalars up, else 32), otherwise 4..4096 (below 4 the partial-sum recursion does not shrink),
  * "msm_tail_chunk" (8, the default: entries per thread of the partial-sum levels below 2^21 entries — their duration is one thread's
  * chain of additions; 0 = "msm_chunk" everywhere; 4..64),

@@ -315,7 +315,7 @@ def test_two_callers_take_turns_on_the_device(zk, gpu_token, copy_threads):
             return x
         w, a, b, c = fr(n), fr(n - 5), fr(n - 5), fr(n - 5)
         blind = [(O.fr_random(100 + i, 1)[0], O.fr_random(200 + i, 1)[0]) for i in range(12)]
-        zk.set_param("gpu_token", 1); zk.set_param("copy_threads", 0)
+        zk.set_param("gpu_token", 1); zk.set_param("copy_threads", 4)     # the library defaults: bounce buffers
         want = [zk.prove_tail(pk, w, a, b, c, r, s) for r, s in blind]
         got = [None] * len(blind)
         errs = []
@@ -339,7 +339,7 @@ def test_two_callers_take_turns_on_the_device(zk, gpu_token, copy_threads):
         for g, x in zip(got, want):
             assert np.array_equal(g, x)
     finally:
-        zk.set_param("gpu_token", 1); zk.set_param("copy_threads", 0)
+        zk.set_param("gpu_token", 1); zk.set_param("copy_threads", 4)
         other.close(); pk.close()
 
 

@@ -8,7 +8,8 @@ import csv
 import sys
 
 KERNELS = ("k_acc_level1_fp29", "k_acc_level1_g2pair29", "k_ntt_pass29", "k_ntt_mid29", "k_ntt_top29", "k_acc_levelN29", "k_reduce_level29",
-           "k_reduce_scan29", "k_decompose", "k_filter_write", "k_solve_level", "k_solve_narrow", "k_r1cs_eval", "k_gadget_poseidon")
+           "k_reduce_scan29", "k_decompose", "k_filter_write", "k_solve_level", "k_solve_narrow", "k_r1cs_eval", "k_gadget_poseidon",
+           "k_hash2_level", "k_tree_level", "k_account_leaves_coop", "k_account_leaves", "k_cex_commitments_coop", "k_cex_commitments")
 
 
 def main():
@@ -22,7 +23,7 @@ def main():
                 break
     tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
     lines = [f"# {tag}: effective clock per kernel = GRBM_GUI_ACTIVE / dispatch wall time (rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace, csv;",
-             "# python bench.py --log2 26 --steps 1 --warmup 0 --timed-only).  GRBM_GUI_ACTIVE is summed over the counter's instances by rocprofv3:",
+             f"# {sys.argv[4] if len(sys.argv) > 4 else 'python bench.py --steps 1 --warmup 0 --timed-only'}).  GRBM_GUI_ACTIVE is summed over the counter's instances by rocprofv3:",
              "# 'per_instance' divides by the instance count inferred from the longest kernel (a value near 2.4 GHz x its wall time).",
              f"{'kernel':28s} {'launches':>8s} {'ms_total':>10s} {'GRBM_GUI_ACTIVE':>18s} {'cycles/ms':>12s}"]
     rows = []

@@ -195,7 +195,7 @@ void GpuTurn::release() {
     held = false;
 }
 
-int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, bool allow_runtime_pin) {
     if (!bytes) return ZKPOR_OK;
     if (!ctx->copy_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     hipPointerAttribute_t at;
@@ -204,9 +204,11 @@ int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes
         return ZKPOR_OK;
     }
     (void)hipGetLastError();  // an unregistered pointer is the expected case, not an error
-    if (ctx->copy_threads == 0) {
-        // "copy_threads" 0: hand the pageable range to the HIP runtime, which page-locks it on the fly and lets the DMA engine read the
-        // caller's pages directly (no CPU copy at all; the call may block until the range has been read)
+    if (ctx->copy_threads == 0 && allow_runtime_pin) {
+        // "copy_threads" 0 (opt-in since round 5): hand the pageable range to the HIP runtime, which page-locks it on the fly and lets the DMA
+        // engine read the caller's pages directly (no CPU copy at all; the call may block until the range has been read).  Fastest (56 GB/s),
+        // but the GPU then reads pages the kernel may still migrate — a transparent-huge-page collapse of a MADV_HUGEPAGE range (numpy marks
+        // every array of >= 4 MiB so) under the copy is the one explanation round 5 found for GPUTEST_r04's abort.
         ZK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
         return ZKPOR_OK;
     }
@@ -221,7 +223,7 @@ int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes
             ZK_HIP(ctx, hipHostMalloc((void**)&nb->buf[i], nb->CHUNK, hipHostMallocDefault));   // ~Bounce frees what exists on the way out
             ZK_HIP(ctx, hipEventCreateWithFlags(&nb->ev[i], hipEventDisableTiming));
         }
-        nb->start(ctx->copy_threads);
+        nb->start(ctx->copy_threads > 0 ? ctx->copy_threads : 1);
         b = nb.release();
         ctx->bounce = b;
     }
@@ -237,6 +239,21 @@ int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes
         ZK_HIP(ctx, hipEventRecord(b->ev[s], ctx->copy_stream));
         b->used[s] = true;
     }
+    return ZKPOR_OK;
+}
+// Host memory of unknown kind -> device, complete when the call returns.  Small ranges go through the runtime's own staging buffers (a CPU copy
+// inside hipMemcpy); large pageable ones through the context's pinned bounce buffers — the library never lets the DMA engine read pages it
+// does not own (see host_upload).  dst must not be in use by work queued on other streams than ctx->stream.
+int32_t h2d_sync(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!bytes) return ZKPOR_OK;
+    if (bytes <= ((size_t)256 << 10)) {      // below every pinning threshold of the runtime: staged by the runtime itself
+        ZK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return ZKPOR_OK;
+    }
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));     // what is queued on the context's stream comes first (it may still read dst)
+    ZK_TRY(host_upload(ctx, d_dst, h_src, bytes, false));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     return ZKPOR_OK;
 }
 }  // namespace zk
@@ -297,8 +314,7 @@ static int32_t msm_host(zkpor_ctx* ctx, const void* pts, const uint64_t* scalars
     hipError_t e = hipMalloc(&dsc, n * 32);
     if (e != hipSuccess) { (void)hipFree(dp); ctx->err = "hipMalloc scalars"; return ZKPOR_E_OOM; }
     int32_t rc = ZKPOR_OK;
-    if (hipMemcpyAsync(dp, pts, n * sizeof(Affine<F>), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(dsc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+    if (h2d_sync(ctx, dp, pts, n * sizeof(Affine<F>)) != ZKPOR_OK || h2d_sync(ctx, dsc, scalars, n * 32) != ZKPOR_OK) {
         ctx->err = "H2D copy failed"; rc = ZKPOR_E_HIP;
     }
     if (rc == ZKPOR_OK) rc = msm_dev<F>(ctx, (const Affine<F>*)dp, (const Fr*)dsc, n, r);
@@ -489,8 +505,7 @@ int32_t zkpor_dev_free(zkpor_ctx* ctx, void* p) try {
 int32_t zkpor_dev_upload(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
-    ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer is not retained
+    ZK_TRY(zk::h2d_sync(ctx, dst, src, bytes));      // complete on return: the host buffer is not retained
     return ZKPOR_OK;
 } ZK_ABI_CATCH
 // asynchronous upload: returns once the copy is queued; the host buffer must stay valid (and should be pinned, see

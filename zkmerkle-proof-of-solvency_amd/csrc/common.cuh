@@ -55,7 +55,7 @@ struct zkpor_ctx {
     size_t stage_cap = 0;
     hipStream_t copy_stream = nullptr;
     void* bounce = nullptr;          // zk::Bounce*
-    int copy_threads = 0;            // 0 = the HIP runtime moves pageable ranges (page-locks them on the fly: 56 GB/s measured); n > 0 = n host threads fill pinned bounce buffers (30 GB/s)
+    int copy_threads = 4;            // n > 0 = n host threads fill pinned bounce buffers (30 GB/s; the default since round 5); 0 = the HIP runtime page-locks pageable ranges on the fly (56 GB/s measured; see host_upload)
     int copy_chunk_mb = 32;          // size of one of the four pinned bounce buffers
     int host_order = 0;              // zkpor_prove_tail from host memory: 0 = w first, a/b/c under the witness sums; 1 = everything first, then the resident order
     int msm_reduce_scan = 1;         // small bucket-reduction levels: one lane (G2: lane pair) per bucket, scan + tree sums; 2 = G1 only (round 2), 0 = serial walk
@@ -205,7 +205,9 @@ int32_t stage_reserve(zkpor_ctx* ctx, size_t bytes);
 // the DMA engine directly; pageable ones (a Go / numpy heap slice) go through pinned bounce buffers filled by a few host
 // threads, chunk k+1 being copied by the CPU while chunk k crosses PCIe.  Returns when the last chunk is QUEUED: the source
 // range is no longer needed afterwards unless it was page-locked (then: until the copy stream has drained).
-int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, bool allow_runtime_pin = true);
+// host memory of unknown kind -> device, complete on return; never lets the runtime page-lock the caller's range (api_core.hip)
+int32_t h2d_sync(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 void bounce_free(zkpor_ctx* ctx);
 // One caller at a time runs the GPU part of a host-pointer call on a device (the others keep moving their vectors across PCIe
 // meanwhile).  Without it two callers drift into lockstep: their kernels share the GPU, finish together, and then both copy at

@@ -160,7 +160,7 @@ int32_t decompress_to_device(zkpor_ctx* ctx, bool g2, const uint8_t* host_in, si
     int32_t rc = ZKPOR_OK;
     u32 herr[2] = {0, 0};
     DecompConsts K = decomp_consts();
-    if (hipMemcpyAsync(din, host_in, n * per, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+    if (zk::h2d_sync(ctx, din, host_in, n * per) != ZKPOR_OK ||
         hipMemsetAsync(derr, 0, 8, ctx->stream) != hipSuccess) { ctx->err = "decompress: H2D failed"; rc = ZKPOR_E_HIP; }
     if (rc == ZKPOR_OK) {
         PhaseScope ps(ctx, "decompress");

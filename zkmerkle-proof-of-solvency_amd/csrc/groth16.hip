@@ -326,7 +326,7 @@ int32_t zkpor_pk_set_g1(zkpor_pk* pk, int which, const void* pts, size_t n) try 
     zkpor_ctx* ctx = pk->ctx;
     if (pk->g1_raw[which]) { ZK_HIP(ctx, hipFree(pk->g1_raw[which])); pk->g1_raw[which] = nullptr; }
     ZK_HIP(ctx, hipMalloc(&pk->g1_raw[which], (n ? n : 1) * 64));
-    ZK_HIP(ctx, hipMemcpyAsync(pk->g1_raw[which], pts, n * 64, hipMemcpyHostToDevice, ctx->stream));
+    ZK_TRY(zk::h2d_sync(ctx, pk->g1_raw[which], pts, n * 64));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pk->g1_raw_n[which] = n;
     pk->ready = false;
@@ -338,7 +338,7 @@ int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n) try 
     zkpor_ctx* ctx = pk->ctx;
     if (pk->g2_raw) { ZK_HIP(ctx, hipFree(pk->g2_raw)); pk->g2_raw = nullptr; }
     ZK_HIP(ctx, hipMalloc(&pk->g2_raw, (n ? n : 1) * 128));
-    ZK_HIP(ctx, hipMemcpyAsync(pk->g2_raw, pts, n * 128, hipMemcpyHostToDevice, ctx->stream));
+    ZK_TRY(zk::h2d_sync(ctx, pk->g2_raw, pts, n * 128));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pk->g2_raw_n = n;
     pk->ready = false;
@@ -511,7 +511,7 @@ int32_t zkpor_pk_synth_masked(zkpor_pk* pk, int log2_domain, size_t n_wires, siz
     int32_t rc = ZKPOR_OK;
     auto apply = [&](const uint8_t* h, int which) {
         if (!h || rc != ZKPOR_OK) return;
-        if (hipMemcpyAsync(d_mask, h, n_wires, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "pk: H2D failed"; rc = ZKPOR_E_HIP; return; }
+        if (zk::h2d_sync(ctx, d_mask, h, n_wires) != ZKPOR_OK) { ctx->err = "pk: H2D failed"; rc = ZKPOR_E_HIP; return; }
         if (which == 0) hipLaunchKernelGGL(k_mask_points<G1Affine>, dim3(grid), dim3(256), 0, ctx->stream, pk->A, d_mask, n_wires);
         if (which == 1) { hipLaunchKernelGGL(k_mask_points<G1Affine>, dim3(grid), dim3(256), 0, ctx->stream, pk->B1, d_mask, n_wires);
                           hipLaunchKernelGGL(k_mask_points<G2Affine>, dim3(grid), dim3(256), 0, ctx->stream, pk->B2, d_mask, n_wires); }

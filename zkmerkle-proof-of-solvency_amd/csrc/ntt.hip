@@ -925,7 +925,7 @@ int32_t zkpor_fft(zkpor_ctx* ctx, uint64_t* a, int log2n, int inverse, int decim
     Fr* d = nullptr;
     ZK_HIP(ctx, hipMalloc((void**)&d, bytes));
     int32_t rc = ZKPOR_OK;
-    if (hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+    if (zk::h2d_sync(ctx, d, a, bytes) != ZKPOR_OK) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
     if (rc == ZKPOR_OK) rc = ntt_dev(ctx, d, log2n, inverse != 0, decimation == 1, on_coset != 0);
     if (rc == ZKPOR_OK && hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H failed"; rc = ZKPOR_E_HIP; }
     (void)hipStreamSynchronize(ctx->stream);
@@ -969,7 +969,7 @@ int32_t zkpor_compute_h(zkpor_ctx* ctx, int log2_domain, const uint64_t* a, cons
     const uint64_t* src[3] = {a, b, c};
     for (int i = 0; i < 3 && rc == ZKPOR_OK; ++i) {
         if (hipMemsetAsync(d + i * N, 0, N * sizeof(Fr), ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(d + i * N, src[i], n_constraints * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            zk::h2d_sync(ctx, d + i * N, src[i], n_constraints * sizeof(Fr)) != ZKPOR_OK) {
             ctx->err = "H2D failed"; rc = ZKPOR_E_HIP;
         }
     }

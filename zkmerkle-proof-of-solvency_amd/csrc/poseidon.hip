@@ -1500,7 +1500,7 @@ struct DevTmp {
     ~DevTmp() { if (p) (void)hipFree(p); }
     int32_t put(zkpor_ctx* ctx, const void* src, size_t bytes) {
         ZK_HIP(ctx, hipMalloc(&p, bytes ? bytes : 1));
-        if (bytes) ZK_HIP(ctx, hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (bytes) ZK_TRY(zk::h2d_sync(ctx, p, src, bytes));
         return ZKPOR_OK;
     }
     int32_t make(zkpor_ctx* ctx, size_t bytes) { ZK_HIP(ctx, hipMalloc(&p, bytes ? bytes : 1)); return ZKPOR_OK; }
@@ -1576,7 +1576,7 @@ int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, 
     ZK_HIP(ctx, hipMalloc((void**)&din, len * count * sizeof(Fr)));
     if (hipMalloc((void**)&dout, count * sizeof(Fr)) != hipSuccess) { (void)hipFree(din); ctx->err = "out of device memory"; return ZKPOR_E_OOM; }
     int32_t rc = ZKPOR_OK;
-    if (hipMemcpyAsync(din, inputs, len * count * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+    if (zk::h2d_sync(ctx, din, inputs, len * count * sizeof(Fr)) != ZKPOR_OK) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
     if (rc == ZKPOR_OK) {
         if (len == 2) hipLaunchKernelGGL(k_hash2_level, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, din, (u32)(2 * count), Fr::zero(), dout, P);
         else hipLaunchKernelGGL(k_hash_many, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, din, (u32)len, (u32)count, dout, P);
@@ -1696,8 +1696,8 @@ int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, c
     int32_t rc = ZKPOR_OK;
     if (hipMalloc((void**)&dacc, n * sizeof(AccountHdr)) != hipSuccess || hipMalloc((void**)&das, (n_assets_total + 1) * sizeof(AssetRec)) != hipSuccess ||
         hipMalloc((void**)&dout, n * sizeof(Fr)) != hipSuccess || hipMalloc((void**)&dbe, n * 32) != hipSuccess) { ctx->err = "out of device memory"; rc = ZKPOR_E_OOM; }
-    if (rc == ZKPOR_OK && (hipMemcpyAsync(dacc, accounts, n * sizeof(AccountHdr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                           (n_assets_total && hipMemcpyAsync(das, assets, n_assets_total * sizeof(AssetRec), hipMemcpyHostToDevice, ctx->stream) != hipSuccess))) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+    if (rc == ZKPOR_OK && (zk::h2d_sync(ctx, dacc, accounts, n * sizeof(AccountHdr)) != ZKPOR_OK ||
+                           (n_assets_total && zk::h2d_sync(ctx, das, assets, n_assets_total * sizeof(AssetRec)) != ZKPOR_OK))) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
     if (rc == ZKPOR_OK) {
         PhaseScope ps(ctx, "poseidon_leaf");
         launch_account_leaves(ctx, dacc, das, (u32)n, tier, dout, P);
@@ -1734,7 +1734,7 @@ int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n,
     if (hipMalloc((void**)&dbe, (be_cnt + 1) * 32) != hipSuccess || hipMalloc((void**)&dleaves, (n + 1) * sizeof(Fr)) != hipSuccess ||
         (tot && hipMalloc((void**)&dlev, tot * sizeof(Fr)) != hipSuccess)) { ctx->err = "out of device memory"; rc = ZKPOR_E_OOM; }
     if (rc == ZKPOR_OK && n) {
-        if (hipMemcpyAsync(dbe, leaves32_be, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
+        if (zk::h2d_sync(ctx, dbe, leaves32_be, n * 32) != ZKPOR_OK) { ctx->err = "H2D failed"; rc = ZKPOR_E_HIP; }
         else hipLaunchKernelGGL(k_fr_from_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dbe, dleaves, n);
     }
     Fr root;

@@ -154,8 +154,8 @@ int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, 
     if (hipMalloc((void**)&r->coeff, n_coeff * sizeof(Fr)) != hipSuccess || hipMalloc((void**)&r->coeff_kind, n_coeff) != hipSuccess) {
         (void)hipGetLastError(); r1cs_free(r); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM;
     }
-    if (hipMemcpy(r->coeff, tab, n_coeff * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(r->coeff_kind, kind.data(), n_coeff, hipMemcpyHostToDevice) != hipSuccess) { r1cs_free(r); ctx->err = "r1cs: H2D failed"; return ZKPOR_E_HIP; }
+    if (zk::h2d_sync(ctx, r->coeff, tab, n_coeff * sizeof(Fr)) != ZKPOR_OK ||
+        zk::h2d_sync(ctx, r->coeff_kind, kind.data(), n_coeff) != ZKPOR_OK) { r1cs_free(r); ctx->err = "r1cs: H2D failed"; return ZKPOR_E_HIP; }
     *out = r;
     return ZKPOR_OK;
 } ZK_ABI_CATCH
@@ -185,14 +185,14 @@ int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr,
     if (r->n_constraints > 0xffffffffull) { ctx->err = "r1cs: more than 2^32 constraints"; return ZKPOR_E_ARG; }
     if (hipMalloc((void**)&r->row_ptr[which], (r->n_constraints + 1) * 8) != hipSuccess || hipMalloc((void**)&r->cid[which], (nnz ? nnz : 1) * 4) != hipSuccess ||
         hipMalloc((void**)&r->wid[which], (nnz ? nnz : 1) * 4) != hipSuccess) { (void)hipGetLastError(); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM; }
-    ZK_HIP(ctx, hipMemcpy(r->row_ptr[which], row_ptr, (r->n_constraints + 1) * 8, hipMemcpyHostToDevice));
+    ZK_TRY(zk::h2d_sync(ctx, r->row_ptr[which], row_ptr, (r->n_constraints + 1) * 8));
     if (nnz) {
-        ZK_HIP(ctx, hipMemcpy(r->cid[which], coeff_ids, nnz * 4, hipMemcpyHostToDevice));
-        ZK_HIP(ctx, hipMemcpy(r->wid[which], wire_ids, nnz * 4, hipMemcpyHostToDevice));
+        ZK_TRY(zk::h2d_sync(ctx, r->cid[which], coeff_ids, nnz * 4));
+        ZK_TRY(zk::h2d_sync(ctx, r->wid[which], wire_ids, nnz * 4));
     }
     if (!longs.empty()) {
         if (hipMalloc((void**)&r->long_rows[which], longs.size() * 4) != hipSuccess) { (void)hipGetLastError(); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM; }
-        ZK_HIP(ctx, hipMemcpy(r->long_rows[which], longs.data(), longs.size() * 4, hipMemcpyHostToDevice));
+        ZK_TRY(zk::h2d_sync(ctx, r->long_rows[which], longs.data(), longs.size() * 4));
         r->n_long[which] = longs.size();
     }
     r->nnz[which] = nnz;
@@ -241,7 +241,7 @@ int32_t zkpor_r1cs_eval(zkpor_r1cs* r, const uint64_t* w, uint64_t* a, uint64_t*
     Fr* d = nullptr;
     ZK_HIP(ctx, hipMalloc((void**)&d, (r->n_wires + 3 * (n ? n : 1)) * sizeof(Fr)));
     int32_t rc = ZKPOR_OK;
-    if (hipMemcpyAsync(d, w, r->n_wires * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "r1cs: H2D failed"; rc = ZKPOR_E_HIP; }
+    if (zk::h2d_sync(ctx, d, w, r->n_wires * sizeof(Fr)) != ZKPOR_OK) { ctx->err = "r1cs: H2D failed"; rc = ZKPOR_E_HIP; }
     Fr* da = d + r->n_wires;
     if (rc == ZKPOR_OK) rc = zkpor_r1cs_eval_dev(r, d, da, da + n, da + 2 * n, n);
     uint64_t* outs[3] = {a, b, c};

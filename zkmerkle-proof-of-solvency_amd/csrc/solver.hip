@@ -907,7 +907,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     for (auto& kv : big) if (external[kv.first]) s->externals[kv.first] = kv.second;
     auto up = [&](void** d, const void* h, size_t bytes) {
         if (hipMalloc(d, bytes ? bytes : 4) != hipSuccess) { (void)hipGetLastError(); return false; }
-        return bytes == 0 || hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
+        return bytes == 0 || zk::h2d_sync(ctx, *d, h, bytes) == ZKPOR_OK;
     };
     bool ok = up((void**)&s->d_kind, kinds.data(), v.n_instructions * 4) && up((void**)&s->d_arg, v.arg, v.n_instructions * 4) &&
               up((void**)&s->d_level_instr, li.data(), n_li * 4) && up((void**)&s->d_calldata, v.calldata, v.n_calldata * 4) &&
@@ -1038,7 +1038,12 @@ int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inpu
     if (n_inputs == 0 || n_inputs > s->r1cs->n_wires) { ctx->err = "solver: the assignment must hold 1 + nPublic + nSecret elements"; return ZKPOR_E_ARG; }
     if (s->asyncs.empty()) return ZKPOR_OK;
     if (s->plan.empty() || s->plan[0].n_posa != s->asyncs.size()) { ctx->err = "solver: an ASYNC instruction outside the first level cannot be prefetched"; return ZKPOR_E_STATE; }
-    if (s->side_busy) { ctx->err = "solver: the side stream still runs a chain (one prefetch at a time, after the current run's last level)"; return ZKPOR_E_STATE; }
+    if (s->side_busy) {
+        if (s->running) { ctx->err = "solver: the side stream still runs a chain of the run in progress (one prefetch at a time, after the current run's last level)"; return ZKPOR_E_STATE; }
+        // an earlier prefetch nobody consumed (the caller dropped that proof): it is abandoned — wait for its chain, then start this one
+        ZK_HIP(ctx, hipStreamSynchronize(s->side));
+        s->side_busy = false; s->prefetched_w = nullptr;
+    }
     // a prefetch evaluates the calls' inputs from the bare assignment (every wire taken as known): legal only when they read input wires
     if (s->async_max_wire >= n_inputs) { ctx->err = "solver: an ASYNC instruction reads wire " + std::to_string(s->async_max_wire) + ", not an input (the assignment holds " + std::to_string(n_inputs) + " elements): it cannot be prefetched"; return ZKPOR_E_STATE; }
     const size_t nw = s->r1cs->n_wires;
@@ -1148,8 +1153,8 @@ int32_t zkpor_solver_run(zkpor_solver* s, const uint64_t* inputs, size_t n_input
     struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } tw, tk;   // freed on every path
     ZK_HIP(ctx, hipMalloc(&tw.p, nw * sizeof(Fr)));
     ZK_HIP(ctx, hipMalloc(&tk.p, nw));
-    ZK_HIP(ctx, hipMemcpy(tw.p, hw.data(), nw * sizeof(Fr), hipMemcpyHostToDevice));
-    ZK_HIP(ctx, hipMemcpy(tk.p, hk.data(), nw, hipMemcpyHostToDevice));
+    ZK_TRY(zk::h2d_sync(ctx, tw.p, hw.data(), nw * sizeof(Fr)));
+    ZK_TRY(zk::h2d_sync(ctx, tk.p, hk.data(), nw));
     uint32_t paused = 0xffffffffu;
     int32_t rc = zkpor_solver_start_dev(s, tw.p, n_inputs, (uint8_t*)tk.p, &paused);
     if (rc == ZKPOR_OK && paused != 0xffffffffu) { s->running = false; ctx->err = "solver: external hint at instruction " + std::to_string(paused) + " (serve it through zkpor_solver_start_dev / _external_* / _resume_dev)"; rc = ZKPOR_E_STATE; }
