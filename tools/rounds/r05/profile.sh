@@ -22,14 +22,13 @@ python tools/rocpd_timeline.py $OUT/prof/timed_results.db > $OUT/timeline_timed_
 rm -rf $OUT/prof/*.db
 head -22 $OUT/kernel_stats_timed_only.txt
 # 3. PMC passes
-for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+for C in SQ_INSTS_VALU; do   # FETCH_SIZE / WRITE_SIZE: not re-taken this round (GPU minutes): profiles/r04_pmc_traffic.json, corrected to whole proofs by bench.py
   timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- $CMD1 > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
-python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE/pmc_counter_collection.csv $OUT/pmc_WRITE_SIZE/pmc_counter_collection.csv $OUT/pmc_traffic.json "$CMD1" tools/rounds/r05/profile.sh > /dev/null 2>&1
 python tools/pmc_valu_summary.py $OUT/pmc_SQ_INSTS_VALU/pmc_counter_collection.csv $OUT/pmc_valu.json r05 "$CMD1" > /dev/null 2>&1
-rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_INSTS_VALU
+rm -rf $OUT/pmc_SQ_INSTS_VALU
 python -c "
-import json; d=json.load(open('$OUT/pmc_traffic.json')); print({k:(v['launches'], round(v['hbm_bytes_per_launch']/1e9,2)) for k,v in d['kernels'].items()}, d.get('ntt_hbm_bytes_per_computeH',0)/1e9)
+import json
 d=json.load(open('$OUT/pmc_valu.json')); print({k:(v['launches'], round(v['frac_of_issue_bound_under_pmc'],3)) for k,v in d['kernels'].items()})"
 # 4. the Poseidon tree path: kernel stats, VALU instructions, clock
 PCMD="python tools/bench_poseidon.py 27 262144"
