@@ -44,3 +44,15 @@ rm -rf $OUT/ppmc_SQ_INSTS_VALU $OUT/ppmc_GRBM_GUI_ACTIVE
 head -12 $OUT/poseidon_kernel_stats.txt; cat $OUT/poseidon_clock.txt | head -12; cat $OUT/poseidon_bench.json
 python -c "
 import json; d=json.load(open('$OUT/poseidon_pmc_valu.json')); print({k:(v['launches'], round(v['frac_of_issue_bound_under_pmc'],3), round(v['time_ms_total_under_pmc'],1)) for k,v in d['kernels'].items()})"
+# 5. VERDICT r04 item 8, measured: 24-bit windows (11 digits instead of 12, 2^23 buckets per window) against the bucket reduction's cost — one worker, tail + solve in turn
+timeout 500 python bench.py --steps 4 --warmup 1 --timed-only --e2e-workers 1 --window 24 > $OUT/bench_window24.json 2> $OUT/bench_window24.err; echo "window24 rc=$?"; tail -2 $OUT/bench_window24.err
+timeout 500 python bench.py --steps 4 --warmup 1 --timed-only --e2e-workers 1 > $OUT/bench_window22_one_worker.json 2> $OUT/bench_window22_one_worker.err
+python - <<'PY'
+import json
+for f in ("bench_window24", "bench_window22_one_worker"):
+    try:
+        d = json.load(open(f"gpurun_out/r05p/{f}.json"))
+        print(f, d["ms_per_step"], d["phases_ms_per_proof"], d["roofline"]["avg_launch_ms"], d["end_to_end"].get("bucket_additions_per_proof"))
+    except Exception as e:
+        print(f, "failed", e)
+PY
