@@ -128,6 +128,41 @@ def mixture_scalars(seed, n, fill_kind, mix=None):
 
 
 def cpu_solver_leg(cir, inputs, threads):
+    """(see _cpu_solver_leg) run in a forked child: the host executor has never been run at the production size outside this leg, and the line the
+    driver records must not depend on it — a crash or a hang there is a note in `cpu_baseline.sample`, not a dead bench"""
+    import pickle
+    import select
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:      # child: CPU work only (no HIP call), then out without running any exit handler of the parent's runtime
+        code = 1
+        try:
+            os.close(r)
+            os.write(w, pickle.dumps(_cpu_solver_leg(cir, inputs, threads)))
+            code = 0
+        except BaseException:      # noqa: BLE001
+            pass
+        finally:
+            os._exit(code)
+    os.close(w)
+    buf = b""
+    deadline = time.time() + 300
+    while time.time() < deadline:
+        if select.select([r], [], [], 1.0)[0]:
+            chunk = os.read(r, 65536)
+            if not chunk:
+                break
+            buf += chunk
+    else:
+        os.kill(pid, 9)
+    os.close(r)
+    _, status = os.waitpid(pid, 0)
+    if not buf:
+        raise RuntimeError(f"the host executor's child ended with status {status} (signal {status & 0x7f}) without a result")
+    return pickle.loads(buf)
+
+
+def _cpu_solver_leg(cir, inputs, threads):
     """the solver leg of the CPU baseline: the compiled circuit's solver program (the same container the device executes) on host/solver_exec.hpp
     — the levelized host executor, `threads` threads, the FULL production program, no sampling — from the assigned inputs to the full wire vector.
     gnark's own solver cannot run here (no Go); this is this repo's host executor, faster per instruction than an interpreter of gnark's blueprint
@@ -1278,6 +1313,8 @@ def main():
                          "form to run under rocprofv3 so that its per-kernel averages cover exactly the launches `roofline` averages")
     ap.add_argument("--cpu-log2", type=int, default=0, help="log2 of the CPU baseline sample (0 = by core count: 2^23 from 64 threads up)")
     args = ap.parse_args()
+    import faulthandler
+    faulthandler.enable()      # a native crash leaves the Python stack of every thread on stderr
     if args.timed_only:
         args.no_check = args.no_boundary = args.no_cpu_baseline = True
         args.r1cs_terms = 0

@@ -70,6 +70,14 @@ func (p *Prover) RunInProcess(rerun bool, gpus []int, workersPerGPU int) error {
 				return fmt.Errorf("GPU %d: %w", g, err)
 			}
 			defer ctx.Close()
+			if workersPerGPU > 1 {
+				// round 5: the prove tail's kernels leave 32 of the 256 compute units free (a CU mask on their HIP streams), so that the OTHER worker's solver
+				// program — ~100 narrow, dependent launches — starts at once instead of queueing behind full-size MSM grids: one proof's solve under the
+				// other's prove tail (DESIGN.md §6c; bench.py end_to_end).  Harmless with a host solver (nothing then runs beside the tail but copies).
+				if err := ctx.SetParam("tail_reserve_cus", 32); err != nil {
+					return fmt.Errorf("GPU %d: %w", g, err)
+				}
+			}
 			workers = append(workers, &gpuWorker{gpu: g, ctx: ctx})
 		}
 	}

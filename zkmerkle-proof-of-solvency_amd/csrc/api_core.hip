@@ -115,6 +115,7 @@ struct Bounce {
 
 void bounce_free(zkpor_ctx* ctx) {
     if (ctx->bounce && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);  // no DMA may still read the buffers
+    if (ctx->bounce && ctx->stream) (void)hipStreamSynchronize(ctx->stream);             // (h2d_sync copies on the context's own stream)
     delete (Bounce*)ctx->bounce;
     ctx->bounce = nullptr;
 }
@@ -195,12 +196,30 @@ void GpuTurn::release() {
     held = false;
 }
 
-int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, bool allow_runtime_pin) {
+int32_t stream_create_own_queue(zkpor_ctx* ctx, hipStream_t* out, int reserve_cus) {
+    hipDeviceProp_t prop;
+    ZK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int cus = prop.multiProcessorCount;
+    if (reserve_cus < 0 || reserve_cus >= cus) { ctx->err = "stream: the CU mask would leave no compute unit"; return ZKPOR_E_ARG; }
+    // mask bit i is compute unit i / 8 of XCD i % 8 on this part (the driver deals the bits round-robin over the XCDs): clearing the first R bits
+    // frees R / 8 units on each of the eight XCDs
+    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+    for (int i = reserve_cus; i < cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    ZK_HIP(ctx, hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()));
+    return ZKPOR_OK;
+}
+
+// `on`: the stream the copies are queued on — the context's copy stream (created on first use) for the host-pointer prove tail, whose uploads run
+// beside kernels; the context's own stream for h2d_sync (a sixth stream would share a hardware queue with one of the others)
+int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, bool allow_runtime_pin, hipStream_t on) {
     if (!bytes) return ZKPOR_OK;
-    if (!ctx->copy_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!on) {
+        if (!ctx->copy_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        on = ctx->copy_stream;
+    }
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, h_src) == hipSuccess && at.type == hipMemoryTypeHost) {
-        ZK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        ZK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, on));
         return ZKPOR_OK;
     }
     (void)hipGetLastError();  // an unregistered pointer is the expected case, not an error
@@ -209,7 +228,7 @@ int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes
         // engine read the caller's pages directly (no CPU copy at all; the call may block until the range has been read).  Fastest (56 GB/s),
         // but the GPU then reads pages the kernel may still migrate — a transparent-huge-page collapse of a MADV_HUGEPAGE range (numpy marks
         // every array of >= 4 MiB so) under the copy is the one explanation round 5 found for GPUTEST_r04's abort.
-        ZK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        ZK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, on));
         return ZKPOR_OK;
     }
     Bounce* b = (Bounce*)ctx->bounce;
@@ -235,8 +254,8 @@ int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes
         b->next = (s + 1) % Bounce::SLOTS;
         if (b->used[s]) ZK_HIP(ctx, hipEventSynchronize(b->ev[s]));  // the DMA that last read this slot is done
         b->copy(b->buf[s], src + off, n);
-        ZK_HIP(ctx, hipMemcpyAsync(dst + off, b->buf[s], n, hipMemcpyHostToDevice, ctx->copy_stream));
-        ZK_HIP(ctx, hipEventRecord(b->ev[s], ctx->copy_stream));
+        ZK_HIP(ctx, hipMemcpyAsync(dst + off, b->buf[s], n, hipMemcpyHostToDevice, on));
+        ZK_HIP(ctx, hipEventRecord(b->ev[s], on));
         b->used[s] = true;
     }
     return ZKPOR_OK;
@@ -251,9 +270,8 @@ int32_t h2d_sync(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return ZKPOR_OK;
     }
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));     // what is queued on the context's stream comes first (it may still read dst)
-    ZK_TRY(host_upload(ctx, d_dst, h_src, bytes, false));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    ZK_TRY(host_upload(ctx, d_dst, h_src, bytes, false, ctx->stream));     // in the context's own stream: behind whatever it queued before
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
 }
 }  // namespace zk
@@ -387,6 +405,7 @@ void zkpor_destroy(zkpor_ctx* ctx) try {
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
     if (ctx->tail_aux) (void)hipStreamDestroy(ctx->tail_aux);
+    if (ctx->tail_aux_free) (void)hipStreamDestroy(ctx->tail_aux_free);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 } catch (...) { zk::abi_exception("exception in zkpor_destroy"); }
@@ -450,7 +469,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     }
     else if (n == "tail_reserve_cus") {
         if (value < 0 || value > 128 || value % 8) { ctx->err = "tail_reserve_cus must be 0 or a multiple of 8 up to 128"; return ZKPOR_E_ARG; }
-        for (hipStream_t* st : {&ctx->tail_stream, &ctx->tail_aux}) if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
+        for (hipStream_t* st : {&ctx->tail_stream, &ctx->tail_aux, &ctx->tail_aux_free}) if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
         ctx->tail_reserve_cus = (int)value;
     }
     else if (n == "tail_aux_masked") { if (value < 0 || value > 1) { ctx->err = "tail_aux_masked must be 0 or 1"; return ZKPOR_E_ARG; } ctx->tail_aux_masked = (int)value; }

@@ -78,7 +78,7 @@ struct zkpor_ctx {
                                      // compute units free (evenly over the XCDs) — for the narrow, dependent launches of ANOTHER worker's solver program, which
                                      // otherwise queue behind full-size MSM grids (solve(i+1) beside tail(i): host/prover_host.hpp workers, bench.py end_to_end)
     int tail_aux_masked = 0;         // 1: the digit streams of a masked tail keep to the tail's CU mask; 0: they may use the reserved units too
-    hipStream_t tail_stream = nullptr, tail_aux = nullptr;   // created on first use, destroyed when the parameter changes
+    hipStream_t tail_stream = nullptr, tail_aux = nullptr, tail_aux_free = nullptr;   // created on first use, destroyed when the parameter changes (tail_aux_free: every CU, own hardware queue)
     int debug_validate = 0;          // 1: every sorted digit stream is checked (keys ascending and below the bucket count, point indices inside the array) on the
                                      // accumulating stream before its level-1 kernel reads it; a violation is ZKPOR_E_STATE instead of a GPU memory fault
     uint32_t* dbg_buf = nullptr;     // 4 words of device memory for that check
@@ -205,9 +205,15 @@ int32_t stage_reserve(zkpor_ctx* ctx, size_t bytes);
 // the DMA engine directly; pageable ones (a Go / numpy heap slice) go through pinned bounce buffers filled by a few host
 // threads, chunk k+1 being copied by the CPU while chunk k crosses PCIe.  Returns when the last chunk is QUEUED: the source
 // range is no longer needed afterwards unless it was page-locked (then: until the copy stream has drained).
-int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, bool allow_runtime_pin = true);
+int32_t host_upload(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, bool allow_runtime_pin = true, hipStream_t on = nullptr);
 // host memory of unknown kind -> device, complete on return; never lets the runtime page-lock the caller's range (api_core.hip)
 int32_t h2d_sync(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+// A HIP stream with its OWN hardware queue.  The runtime multiplexes ordinary streams onto a pool of four hardware queues, in order: a kernel
+// of one stream waits behind whatever another stream of the same queue launched before it — a 0.2 s hash chain on a solver's side stream in front
+// of a decompose on the digit stream was a 135 ms hole in every proof (profiles/r05_timeline_hole.txt).  A stream created with a CU mask gets a
+// queue of its own; `reserve` compute units are left out of the mask (0 = every CU: only the queue is wanted).  Such streams synchronise with the
+// legacy NULL stream, which the per-proof paths therefore never use.
+int32_t stream_create_own_queue(zkpor_ctx* ctx, hipStream_t* out, int reserve_cus);
 void bounce_free(zkpor_ctx* ctx);
 // One caller at a time runs the GPU part of a host-pointer call on a device (the others keep moving their vectors across PCIe
 // meanwhile).  Without it two callers drift into lockstep: their kernels share the GPU, finish together, and then both copy at

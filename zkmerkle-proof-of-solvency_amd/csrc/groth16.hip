@@ -607,21 +607,20 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         // compute unit i / 8 of XCD i % 8 on this part (the driver deals the bits round-robin over the XCDs), so clearing the first R bits
         // frees R / 8 units on each of the eight XCDs.
         if (!ctx->tail_stream) {
-            hipDeviceProp_t prop;
-            ZK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-            const int cus = prop.multiProcessorCount;
-            if (ctx->tail_reserve_cus >= cus) { ctx->err = "prove: tail_reserve_cus leaves the prove tail no compute unit"; return ZKPOR_E_ARG; }
-            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
-            for (int i = ctx->tail_reserve_cus; i < cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-            ZK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->tail_stream, (uint32_t)mask.size(), mask.data()));
-            ZK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->tail_aux, (uint32_t)mask.size(), mask.data()));
+            ZK_TRY(stream_create_own_queue(ctx, &ctx->tail_stream, ctx->tail_reserve_cus));
+            ZK_TRY(stream_create_own_queue(ctx, &ctx->tail_aux, ctx->tail_reserve_cus));
+            ZK_TRY(stream_create_own_queue(ctx, &ctx->tail_aux_free, 0));
         }
         // the digit streams (decompose, radix sort, filter) are HBM-bound helpers that starve beside the VALU-bound kernels of the main stream
-        // (profiles/r03_timeline_*.txt); "tail_aux_masked" 0 lets them use the reserved compute units as well
-        main_s = ctx->tail_stream; aux_s = ctx->tail_aux_masked ? ctx->tail_aux : ctx->aux_stream;
+        // (profiles/r03_timeline_*.txt); "tail_aux_masked" 0 lets them use the reserved compute units as well — on a stream with its own hardware queue
+        main_s = ctx->tail_stream; aux_s = ctx->tail_aux_masked ? ctx->tail_aux : ctx->tail_aux_free;
     }
     hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx), e_up = ev_get(ctx), e_wB = ev_get(ctx), e_wK = ev_get(ctx);
     struct EvGuard { zkpor_ctx* c; hipEvent_t e[7]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up, e_wB, e_wK}, caller_s};
+    // several workers of a GPU with a reserved-CU tail: ONE prove tail at a time (two would only time-slice each other on the same compute units), so
+    // that the other worker's SOLVE is what runs beside it; the waiting worker sleeps here, its solver's prefetched chains keep running
+    GpuTurn own_turn;
+    if (ctx->tail_reserve_cus > 0 && !turn) { own_turn.acquire(ctx); turn = &own_turn; }
     if (main_s != caller_s) {   // whatever the caller queued on the context's stream (the solver, a / b / c, uploads) comes first
         ZK_HIP(ctx, hipEventRecord(e_start, caller_s));
         ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_start, 0));

@@ -88,6 +88,7 @@ struct zkpor_solver {
     uint64_t join2_level = 0;
     uint64_t n_r1c = 0, n_hint = 0, n_skip = 0, n_lookup = 0, n_poseidon = 0;
     uint64_t async_max_wire = 0;                // the highest wire an ASYNC call's input expressions read: a prefetch is legal only if it is an input wire
+    bool side_own_queue = false;                // the side streams were re-created with hardware queues of their own (several workers per GPU)
     bool run_ok = false;                        // the last run reached its end without an error: its d_w (and the rows it wrote) may be proved over
     // run state (pause / resume)
     bool running = false, side_busy = false;
@@ -702,7 +703,8 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
     if (h[3]) {   // external hints met in the last level: serve them one by one (a level is small next to what a commitment costs)
         if (h[3] > s->ext_cap) { s->running = false; ctx->err = "solver: a level reported more external hints than the program holds"; return ZKPOR_E_STATE; }   // cannot happen: the list holds every external hint of the program
         s->pending.resize(h[3]);
-        ZK_HIP(ctx, hipMemcpy(s->pending.data(), s->d_ext, h[3] * sizeof(u32), hipMemcpyDeviceToHost));
+        ZK_HIP(ctx, hipMemcpyAsync(s->pending.data(), s->d_ext, h[3] * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));   // never the NULL stream: it waits for every blocking stream of the device
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         std::sort(s->pending.begin(), s->pending.end());
         ZK_HIP(ctx, hipMemsetAsync(s->d_err + 3, 0, sizeof(u32), ctx->stream));
         *paused_instr = s->pending.front();
@@ -718,6 +720,21 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
         }
         s->run_ok = true;      // this d_w (and the rows the run wrote) may be proved over: zkpor_solver_eval_abc_dev
     }
+    return ZKPOR_OK;
+}
+// With several workers per GPU ("tail_reserve_cus") the side streams — 0.2 s hash chains — get hardware queues of their own, once: in the runtime's pool of
+// four they would sit in front of some other stream's kernels (common.cuh stream_create_own_queue)
+int32_t solver_side_queues(zkpor_solver* s) {
+    zkpor_ctx* ctx = s->ctx;
+    if (ctx->tail_reserve_cus <= 0 || s->side_own_queue) return ZKPOR_OK;
+    if (s->running || s->side_busy || s->side2_busy) return ZKPOR_OK;      // not under a run or a chain in flight: next time
+    hipStream_t a = nullptr, b = nullptr;
+    ZK_TRY(stream_create_own_queue(ctx, &a, 0));
+    if (stream_create_own_queue(ctx, &b, 0) != ZKPOR_OK) { (void)hipStreamDestroy(a); return ZKPOR_E_HIP; }
+    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+    if (s->side2) { (void)hipStreamSynchronize(s->side2); (void)hipStreamDestroy(s->side2); }
+    s->side = a; s->side2 = b;
+    s->side_own_queue = true;
     return ZKPOR_OK;
 }
 zkpor_ctx* solver_ctx(zkpor_solver* s) { return s->ctx; }
@@ -970,6 +987,7 @@ int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint
     if (!s || !d_w || !paused_instr) return ZKPOR_E_ARG;
     zkpor_ctx* ctx = s->ctx;
     if (n_inputs == 0 || n_inputs > s->r1cs->n_wires) { ctx->err = "solver: the assignment must hold 1 + nPublic + nSecret elements"; return ZKPOR_E_ARG; }
+    ZK_TRY(solver_side_queues(s));
     s->skip_async = s->prefetched_w != nullptr && s->prefetched_w == d_w;
     if (s->side_busy && !s->skip_async) { (void)hipStreamSynchronize(s->side); s->side_busy = false; }   // an abandoned run, or a prefetch for another vector
     if (s->side2_busy) { (void)hipStreamSynchronize(s->side2); s->side2_busy = false; }
@@ -1037,6 +1055,7 @@ int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inpu
     zkpor_ctx* ctx = s->ctx;
     if (n_inputs == 0 || n_inputs > s->r1cs->n_wires) { ctx->err = "solver: the assignment must hold 1 + nPublic + nSecret elements"; return ZKPOR_E_ARG; }
     if (s->asyncs.empty()) return ZKPOR_OK;
+    ZK_TRY(solver_side_queues(s));
     if (s->plan.empty() || s->plan[0].n_posa != s->asyncs.size()) { ctx->err = "solver: an ASYNC instruction outside the first level cannot be prefetched"; return ZKPOR_E_STATE; }
     if (s->side_busy) {
         if (s->running) { ctx->err = "solver: the side stream still runs a chain of the run in progress (one prefetch at a time, after the current run's last level)"; return ZKPOR_E_STATE; }
@@ -1049,7 +1068,7 @@ int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inpu
     const size_t nw = s->r1cs->n_wires;
     if (!s->d_ones) {
         ZK_HIP(ctx, hipMalloc((void**)&s->d_ones, nw));
-        ZK_HIP(ctx, hipMemset(s->d_ones, 1, nw));
+        ZK_HIP(ctx, hipMemsetAsync(s->d_ones, 1, nw, ctx->stream));      // ordered in front of the fork event below
         ZK_HIP(ctx, hipMalloc((void**)&s->d_perr, 16));
     }
     const SolverProg P = prog_of(s);
@@ -1101,7 +1120,8 @@ int32_t zkpor_solver_external_inputs(zkpor_solver* s, uint32_t instr, uint64_t* 
     if (cd[1] == 0) return ZKPOR_OK;
     ZK_TRY(tmp_reserve(s, cd[1]));                // not the staging area: the caller's d_w may live there (zkpor_prove_inputs)
     ZK_TRY(hint_inputs_to(s, instr, s->d_tmp));
-    ZK_HIP(ctx, hipMemcpy(in_values, s->d_tmp, (size_t)cd[1] * sizeof(Fr), hipMemcpyDeviceToHost));
+    ZK_HIP(ctx, hipMemcpyAsync(in_values, s->d_tmp, (size_t)cd[1] * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
 } ZK_ABI_CATCH
 
