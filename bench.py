@@ -764,7 +764,28 @@ def poseidon_tree_leg(ctx, log2_leaves=27, depth=28):
             "account_leaves": leaves,
             "cex_commitments": cex,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "valu_issue": poseidon_valu_issue(ms, n),
                          "note": "width-3 Poseidon permutation per node (~370 field products): VALU-bound like the prove tail"}}
+
+
+def poseidon_valu_issue(build_ms, leaves):
+    """the tree build against its VALU issue bound: wave instructions of k_hash2_level from the committed SQ_INSTS_VALU pass over the
+    same build (profiles/r05_poseidon_pmc_valu.json: 2^27 leaves) x 4 issue cycles / (1024 SIMDs x clock), over this run's build time; the clock the kernel gets is in
+    profiles/r05_poseidon_clock.txt (2.37 GHz: the level kernels are not power-limited the way the MSM kernels are)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r05_poseidon_pmc_valu.json")))
+        k = d["kernels"]["k_hash2_level"]
+        if leaves != 1 << 27:
+            return None
+        bound = float(k["issue_bound_ms_total"])          # at the nominal 2.4 GHz
+        clock = 2.367
+        return {"issue_bound_ms": bound, "frac": bound / build_ms, "measured_clock_ghz": clock, "frac_at_measured_clock": bound * 2.4 / clock / build_ms,
+                "valu_wave_instructions": k["valu_wave_insts_total"], "instructions_per_node_hash_per_lane": k["valu_wave_insts_total"] * 64.0 / (leaves - 1),
+                "source": "profiles/r05_poseidon_pmc_valu.json, r05_poseidon_clock.txt, r05_poseidon_rocprofv3_kernel_stats.txt (tools/rounds/r05/profile.sh: tools/bench_poseidon.py 27 262144)",
+                "verdict": "the level kernels issue a VALU instruction on every SIMD in 96-99 % of the cycles they are given: an LDS-fused subtree kernel (SURVEY K11) would save HBM traffic "
+                           "(13 GB -> 4.5 GB per build, 1-2 ms at the rate the part streams) and 24 launches, not instructions — not built"}
+    except Exception:      # noqa: BLE001 — informational
+        return None
 
 
 def witness_gen_leg(ctx, users=1380, tier=50, n_wires=1 << 26):
