@@ -770,10 +770,10 @@ def poseidon_tree_leg(ctx, log2_leaves=27, depth=28):
 
 def poseidon_valu_issue(build_ms, leaves):
     """the tree build against its VALU issue bound: wave instructions of k_hash2_level from the committed SQ_INSTS_VALU pass over the
-    same build (profiles/r05_poseidon_pmc_valu.json: 2^27 leaves) x 4 issue cycles / (1024 SIMDs x clock), over this run's build time; the clock the kernel gets is in
+    same build (profiles/r05_poseidon_valu_pmc.json: 2^27 leaves) x 4 issue cycles / (1024 SIMDs x clock), over this run's build time; the clock the kernel gets is in
     profiles/r05_poseidon_clock.txt (2.37 GHz: the level kernels are not power-limited the way the MSM kernels are)"""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r05_poseidon_pmc_valu.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r05_poseidon_valu_pmc.json")))
         k = d["kernels"]["k_hash2_level"]
         if leaves != 1 << 27:
             return None
@@ -781,7 +781,7 @@ def poseidon_valu_issue(build_ms, leaves):
         clock = 2.367
         return {"issue_bound_ms": bound, "frac": bound / build_ms, "measured_clock_ghz": clock, "frac_at_measured_clock": bound * 2.4 / clock / build_ms,
                 "valu_wave_instructions": k["valu_wave_insts_total"], "instructions_per_node_hash_per_lane": k["valu_wave_insts_total"] * 64.0 / (leaves - 1),
-                "source": "profiles/r05_poseidon_pmc_valu.json, r05_poseidon_clock.txt, r05_poseidon_rocprofv3_kernel_stats.txt (tools/rounds/r05/profile.sh: tools/bench_poseidon.py 27 262144)",
+                "source": "profiles/r05_poseidon_valu_pmc.json, r05_poseidon_clock.txt, r05_poseidon_rocprofv3_kernel_stats.txt (tools/rounds/r05/profile.sh: tools/bench_poseidon.py 27 262144)",
                 "verdict": "the level kernels issue a VALU instruction on every SIMD in 96-99 % of the cycles they are given: an LDS-fused subtree kernel (SURVEY K11) would save HBM traffic "
                            "(13 GB -> 4.5 GB per build, 1-2 ms at the rate the part streams) and 24 launches, not instructions — not built"}
     except Exception:      # noqa: BLE001 — informational
@@ -1324,7 +1324,8 @@ def main():
     ap.add_argument("--e2e-workers", type=int, default=2, help="worker contexts per GPU in the end-to-end region: 2 = one proof's solver program runs beside the other's prove tail")
     ap.add_argument("--tail-aux-masked", type=int, default=-1, help="experiment: 1 = the digit streams of a CU-masked tail keep to the tail's mask (library default 0: they may use the reserved units)")
     ap.add_argument("--e2e-sweep", default="", help="experiment: extra end-to-end regions, 'workers:reserve_cus[:aux_masked]' separated by commas (e.g. 1:0,2:0,2:16,2:64:1), "
-                    "each --e2e-steps proofs, reported under end_to_end.sweep")
+                    "each --e2e-steps proofs, reported under end_to_end.sweep.  KNOWN: a second setting with reserved compute units segfaults inside zkpor_prove_tail_dev "
+                    "(a context's masked streams destroyed and created again; DESIGN.md 6c) - one setting per process")
     ap.add_argument("--tail-reserve-cus", type=int, default=32, help="with 2 workers: compute units the prove tail's CU mask leaves free for the other worker's solver launches (0 = none; multiple of 8)")
     ap.add_argument("--share-device", action="store_true", help="TEST ONLY: every rank proves on device 0 and the ranks meet over gloo — the launcher, the per-rank "
                     "merge of the line, the check budgeting and the key build under contention exercised on a one-GPU box; the line says so and is no measurement")
@@ -1932,6 +1933,8 @@ def main():
             per_add = None
         valu = ({"issue_bound_ms_per_launch": vb_ms, "frac": vb_ms / (avg_launch_s * 1e3), "lane_instructions_per_bucket_add": per_add,
                  "frac_class_weighted": (vb_ms * cw / (avg_launch_s * 1e3)) if cw else None,
+                 "compute_units_the_kernel_may_use": 256 - (e2e["tail_reserve_cus"] if e2e is not None else 0),
+                 "frac_of_its_compute_units_at_measured_clock": vb_ms / (avg_launch_s * 1e3) * 2.4 / clock_ghz * 256.0 / (256 - (e2e["tail_reserve_cus"] if e2e is not None else 0)),
                  "measured_clock_ghz": clock_ghz, "frac_at_measured_clock": vb_ms / (avg_launch_s * 1e3) * 2.4 / clock_ghz,
                  "frac_class_weighted_at_measured_clock": (vb_ms * cw / (avg_launch_s * 1e3) * 2.4 / clock_ghz) if cw else None,
                  "source": f"profiles/{vsrc}: SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz nominal) / live avg launch time; "

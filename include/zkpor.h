@@ -111,7 +111,10 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * "tail_reserve_cus" (0, the default; a multiple of 8 up to 128: the kernels of the prove tail — NTT passes, digit streams, bucket
  * accumulations — run on HIP streams whose CU mask leaves that many compute units free, R / 8 on each XCD, so that the narrow
  * dependent launches of ANOTHER worker context's solver program start at once instead of queueing behind full-size MSM grids:
- * solve(i + 1) beside tail(i) with two workers per GPU — host/prover_host.hpp, bench.py `end_to_end`),
+ * solve(i + 1) beside tail(i) with two workers per GPU — host/prover_host.hpp, bench.py `end_to_end`: 380 -> 340 ms per zkpor50_1380 proof.  With it
+ * a prove tail takes the device turn ("gpu_token": one tail at a time, the other worker's solve beside it) and the long streams get hardware
+ * queues of their own.  Set it ONCE per context, before the first proof: changing it destroys and re-creates the masked streams, and a second
+ * generation of them crashed inside the HIP runtime in round 5),
  * "debug_validate" (0; 1: every sorted digit stream is checked on the device before its accumulation reads it — keys ascending and
  * below the bucket count, point indices inside the key array — and a violation is ZKPOR_E_STATE instead of a GPU memory fault) */
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);
