@@ -606,10 +606,14 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         // "tail_reserve_cus": everything the tail queues goes to two streams whose CU mask leaves some compute units free.  A mask bit i is
         // compute unit i / 8 of XCD i % 8 on this part (the driver deals the bits round-robin over the XCDs), so clearing the first R bits
         // frees R / 8 units on each of the eight XCDs.
-        if (!ctx->tail_stream) {
-            ZK_TRY(stream_create_own_queue(ctx, &ctx->tail_stream, ctx->tail_reserve_cus));
-            ZK_TRY(stream_create_own_queue(ctx, &ctx->tail_aux, ctx->tail_reserve_cus));
-            ZK_TRY(stream_create_own_queue(ctx, &ctx->tail_aux_free, 0));
+        if (!ctx->tail_stream || !ctx->tail_aux || !ctx->tail_aux_free) {   // all three or none: a failure half way must not leave a null stream behind
+            hipStream_t st[3] = {nullptr, nullptr, nullptr};
+            int32_t rc = stream_create_own_queue(ctx, &st[0], ctx->tail_reserve_cus);
+            if (rc == ZKPOR_OK) rc = stream_create_own_queue(ctx, &st[1], ctx->tail_reserve_cus);
+            if (rc == ZKPOR_OK) rc = stream_create_own_queue(ctx, &st[2], 0);
+            if (rc != ZKPOR_OK) { for (hipStream_t x : st) if (x) (void)hipStreamDestroy(x); return rc; }
+            for (hipStream_t* old : {&ctx->tail_stream, &ctx->tail_aux, &ctx->tail_aux_free}) if (*old) { (void)hipStreamSynchronize(*old); (void)hipStreamDestroy(*old); }
+            ctx->tail_stream = st[0]; ctx->tail_aux = st[1]; ctx->tail_aux_free = st[2];
         }
         // the digit streams (decompose, radix sort, filter) are HBM-bound helpers that starve beside the VALU-bound kernels of the main stream
         // (profiles/r03_timeline_*.txt); "tail_aux_masked" 0 lets them use the reserved compute units as well — on a stream with its own hardware queue
