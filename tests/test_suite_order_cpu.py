@@ -39,3 +39,12 @@ def test_the_old_order_is_still_available_for_replays():
     r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "--collect-only", "-q", "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     ids = [l for l in r.stdout.splitlines() if "::" in l]
     assert ids[0].startswith("tests/test_account_totals_gpu.py")
+
+
+def test_a_native_abort_in_an_isolated_body_is_one_failed_test():
+    """the mechanism itself: a body that abort()s from a non-Python thread (what GPUTEST_r04 died of) fails ITS test with the child's output,
+    the session goes on to the next test and prints its summary"""
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/probe_isolated_case.py", "-q", "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, r.stdout[-1500:]
+    assert "1 failed, 1 passed" in r.stdout and "isolated child exited with" in r.stdout
+    assert "Fatal Python error: Aborted" in r.stdout          # the child's own faulthandler output is part of the failure report
