@@ -482,4 +482,29 @@ int orc_quotient_identity(int log2d, const Fr* a, const Fr* b, const Fr* c, size
     return Fr::sub(e.lhs, e.rhs).is_zero() ? 1 : 0;
 }
 
+// ---- R1CS satisfaction from the statement alone (TEST INFRASTRUCTURE; gnark's contract for r1cs.Solve — constraint/bn254/solver.go, reached through
+// groth16.Prove at src/prover/prover/prover.go:269 — is a wire vector with (L w) o (R w) = O w on every row): three CSR matrices whose entries index a
+// coefficient table, Montgomery limbs, this file's own field arithmetic (bn254.hpp) — nothing of the package's executors.  Returns the number of failing rows,
+// *first_bad = the lowest one (or n_constraints).  An index outside its table counts the row as failing.
+uint64_t orc_r1cs_failing_rows(const Fr* coeff, uint64_t n_coeff, const uint64_t* const row_ptr[3], const uint32_t* const cid[3], const uint32_t* const wid[3],
+                               uint64_t n_constraints, const Fr* w, uint64_t n_wires, uint64_t* first_bad) {
+    uint64_t bad = 0, lowest = n_constraints;
+#pragma omp parallel for schedule(static) reduction(+ : bad) reduction(min : lowest)
+    for (uint64_t r = 0; r < n_constraints; ++r) {
+        Fr v[3];
+        bool ok = true;
+        for (int m = 0; m < 3; ++m) {
+            Fr acc = Fr::zero();
+            for (uint64_t p = row_ptr[m][r]; p < row_ptr[m][r + 1]; ++p) {
+                if (cid[m][p] >= n_coeff || wid[m][p] >= n_wires) { ok = false; break; }
+                acc = Fr::add(acc, Fr::mul(coeff[cid[m][p]], w[wid[m][p]]));
+            }
+            v[m] = acc;
+        }
+        if (!ok || !Fr::sub(Fr::mul(v[0], v[1]), v[2]).is_zero()) { ++bad; if (r < lowest) lowest = r; }
+    }
+    if (first_bad) *first_bad = lowest;
+    return bad;
+}
+
 }  // extern "C"

@@ -441,6 +441,24 @@ class Synth:
             pass
 
 
+def r1cs_failing_rows(coeff_table, mats, w):
+    """(failing rows, the lowest one or None) of (L w) o (R w) = O w — mats = [(row_ptr u64, coeff_ids u32, wire_ids u32)] for L, R, O, Montgomery limbs
+    (oracle/capi.cpp orc_r1cs_failing_rows: the statement only, the oracle's own field arithmetic)"""
+    co = _u64(coeff_table).reshape(-1, 4); wv = _u64(w).reshape(-1, 4)
+    rp = [np.ascontiguousarray(m[0], dtype=np.uint64) for m in mats]
+    ci = [np.ascontiguousarray(m[1], dtype=np.uint32) for m in mats]
+    wi = [np.ascontiguousarray(m[2], dtype=np.uint32) for m in mats]
+    n = rp[0].shape[0] - 1
+    assert all(x.shape[0] == n + 1 for x in rp)
+    P3 = ctypes.c_void_p * 3
+    first = ctypes.c_uint64()
+    L = lib()
+    L.orc_r1cs_failing_rows.restype = ctypes.c_uint64
+    bad = L.orc_r1cs_failing_rows(_p(co), ctypes.c_uint64(co.shape[0]), P3(*[x.ctypes.data for x in rp]), P3(*[x.ctypes.data for x in ci]), P3(*[x.ctypes.data for x in wi]),
+                                  ctypes.c_uint64(n), _p(wv), ctypes.c_uint64(wv.shape[0]), ctypes.byref(first))
+    return int(bad), (int(first.value) if bad else None)
+
+
 def pairing(P, Q):
     """reduced Tate pairing t(P, Q) as 12 Fp (oracle/pairing.hpp)"""
     out = np.empty((12, 4), dtype=np.uint64)

@@ -187,6 +187,9 @@ def test_the_wire_vector_satisfies_the_statement_in_python_integers():
         t[k] = O.fr_from_ints([(ints(t[k:k + 1])[0] + 1) % R])[0]
         bad, _ = RB.failing_rows(c.coeff(), mats, t)
         assert bad.size > 0
+        # the oracle's evaluator (C++, its own field arithmetic: what the GPU tests apply at sizes Python integers are too slow for) agrees row for row
+        assert O.r1cs_failing_rows(c.coeff(), mats, w) == (0, None)
+        assert O.r1cs_failing_rows(c.coeff(), mats, t) == (int(bad.size), int(bad[0]))
         lo, hi = mats[0][0], None
         # every failing row really mentions the flipped wire in one of its three expressions
         for row in bad[:20]:

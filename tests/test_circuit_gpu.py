@@ -48,10 +48,15 @@ def prove_once(zk, shape, variant, seed=7, compare=True, reps=1):
         assert td.check(proof, rr, ss) and not td.check(proof, ss, rr)
         assert np.array_equal(w[cir.commitment_wire], ch)
         assert np.array_equal(w[1:1 + inp.shape[0]], inp)                 # the assignment sits in its slots
+        # the DEVICE's wire vector against the statement itself — (L w) o (R w) = O w from the matrices, the coefficient table and w alone, by evaluators
+        # outside the package: the oracle's (oracle/capi.cpp orc_r1cs_failing_rows, its own field arithmetic; every size up to 2^24 rows) and, for the
+        # small shapes, Python integers as well (tests/r1cs_bigint.py)
+        mats = [cir.matrix(m) for m in range(3)]
+        if cir.n_constraints <= 1 << 24:
+            assert O.r1cs_failing_rows(cir.coeff(), mats, w) == (0, None)
         if cir.n_constraints <= 1 << 20:
-            # the DEVICE's wire vector against the statement itself, in Python integers: an evaluator outside the package (tests/r1cs_bigint.py)
             import r1cs_bigint as RB
-            bad, _ = RB.failing_rows(cir.coeff(), [cir.matrix(m) for m in range(3)], w)
+            bad, _ = RB.failing_rows(cir.coeff(), mats, w)
             assert bad.size == 0, bad[:10]
         if compare:
             ref = C.Circuit(*shape, inputs=inp, commitment=ch)            # the interpreter, given the challenge the device derived
