@@ -113,8 +113,10 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * dependent launches of ANOTHER worker context's solver program start at once instead of queueing behind full-size MSM grids:
  * solve(i + 1) beside tail(i) with two workers per GPU — host/prover_host.hpp, bench.py `end_to_end`: 380 -> 340 ms per zkpor50_1380 proof.  With it
  * a prove tail takes the device turn ("gpu_token": one tail at a time, the other worker's solve beside it) and the long streams get hardware
- * queues of their own.  Set it ONCE per context, before the first proof: changing it destroys and re-creates the masked streams, and a second
- * generation of them crashed inside the HIP runtime in round 5),
+ * queues of their own.  It applies to the device split only (zkpor_solver_* ... zkpor_prove_tail_dev): a host-pointer call holds the device turn
+ * over its own solve AND tail, nothing runs beside it, and its tail keeps every compute unit.  The value may change between proofs: a context
+ * keeps one pair of masked streams per value it has had (at most four different non-zero values; a fifth is ZKPOR_E_STATE and leaves the setting
+ * as it was) and destroys none of them before zkpor_destroy — round 5's destroy-and-re-create crashed inside the HIP runtime),
  * "debug_validate" (0; 1: every sorted digit stream is checked on the device before its accumulation reads it — keys ascending and
  * below the bucket count, point indices inside the key array — and a violation is ZKPOR_E_STATE instead of a GPU memory fault) */
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);

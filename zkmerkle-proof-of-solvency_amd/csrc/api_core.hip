@@ -390,7 +390,11 @@ int32_t zkpor_init(int device, void* stream, zkpor_ctx** out) try {
 void zkpor_destroy(zkpor_ctx* ctx) try {
     if (!ctx) return;
     ZK_ENTER(ctx->device);
+    // every stream drained first, then the events (they name the stream they were last recorded on), then the streams
     (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t st : {ctx->aux_stream, ctx->copy_stream, ctx->tail_aux_free}) if (st) (void)hipStreamSynchronize(st);
+    for (auto& ts : ctx->tail_sets) { (void)hipStreamSynchronize(ts.main); (void)hipStreamSynchronize(ts.aux); }
+    for (hipStream_t st : ctx->retired_streams) (void)hipStreamSynchronize(st);
     for (auto& kv : ctx->phases)
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -403,9 +407,9 @@ void zkpor_destroy(zkpor_ctx* ctx) try {
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-    if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
-    if (ctx->tail_aux) (void)hipStreamDestroy(ctx->tail_aux);
+    for (auto& ts : ctx->tail_sets) { (void)hipStreamDestroy(ts.main); (void)hipStreamDestroy(ts.aux); }
     if (ctx->tail_aux_free) (void)hipStreamDestroy(ctx->tail_aux_free);
+    for (hipStream_t st : ctx->retired_streams) (void)hipStreamDestroy(st);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 } catch (...) { zk::abi_exception("exception in zkpor_destroy"); }
@@ -442,7 +446,8 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "msm_filter") { if (value < 0 || value > 2) { ctx->err = "msm_filter must be 0, 1 or 2"; return ZKPOR_E_ARG; } ctx->msm_filter = (int)value; }
     else if (n == "msm_filter_grid") { if (value < 0 || value > 2048) { ctx->err = "msm_filter_grid must be in [0,2048]"; return ZKPOR_E_ARG; } ctx->msm_filter_grid = (int)value; }
     else if (n == "ntt_fuse") { if (value < 0 || value > 1) { ctx->err = "ntt_fuse must be 0 or 1"; return ZKPOR_E_ARG; } ctx->ntt_fuse = (int)value; }
-    else if (n == "sort_block") { if (value != 0 && value != 256 && value != 512) { ctx->err = "sort_block must be 0 (rocPRIM default), 256 or 512"; return ZKPOR_E_ARG; } ctx->sort_block = (int)value; }
+    else if (n == "sort_grid") { if (value < 0 || value > 8192) { ctx->err = "sort_grid must be in [0,8192] (0 = two workgroups per compute unit)"; return ZKPOR_E_ARG; } ctx->sort_grid = (int)value; }
+    else if (n == "sort_block") { if (value != 0 && value != 256 && value != 512) { ctx->err = "sort_block must be 0, 256 or 512"; return ZKPOR_E_ARG; } }   // rounds 3-5: the workgroup size of rocPRIM's onesweep; accepted and ignored since the sort is sort.hip's
     else if (n == "msm_reduce_scan") { if (value < 0 || value > 2) { ctx->err = "msm_reduce_scan must be 0, 1 or 2"; return ZKPOR_E_ARG; } ctx->msm_reduce_scan = (int)value; }
     else if (n == "msm_tail_chunk") { if (value != 0 && (value < 4 || value > 64)) { ctx->err = "msm_tail_chunk must be 0 or 4..64"; return ZKPOR_E_ARG; } ctx->msm_tail_chunk = (int)value; }
     else if (n == "aux_priority") {
@@ -469,8 +474,17 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     }
     else if (n == "tail_reserve_cus") {
         if (value < 0 || value > 128 || value % 8) { ctx->err = "tail_reserve_cus must be 0 or a multiple of 8 up to 128"; return ZKPOR_E_ARG; }
-        for (hipStream_t* st : {&ctx->tail_stream, &ctx->tail_aux, &ctx->tail_aux_free}) if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
+        // no stream is destroyed here (common.cuh tail_sets): a value the context has had before gets its old pair back, a new one a new pair at the next
+        // prove tail, and a context that has used up its pairs keeps its setting and says so
+        bool known = value == 0;
+        for (auto& ts : ctx->tail_sets) known |= ts.reserve == (int)value;
+        if (!known && ctx->tail_sets.size() >= zkpor_ctx::TAIL_SETS_MAX) {
+            ctx->err = "tail_reserve_cus: this context has already created masked streams for " + std::to_string(zkpor_ctx::TAIL_SETS_MAX) + " different values (they live as long as the context); use one of those or another context";
+            return ZKPOR_E_STATE;
+        }
         ctx->tail_reserve_cus = (int)value;
+        ctx->tail_stream = ctx->tail_aux = nullptr;
+        for (auto& ts : ctx->tail_sets) if (ts.reserve == (int)value) { ctx->tail_stream = ts.main; ctx->tail_aux = ts.aux; }
     }
     else if (n == "tail_aux_masked") { if (value < 0 || value > 1) { ctx->err = "tail_aux_masked must be 0 or 1"; return ZKPOR_E_ARG; } ctx->tail_aux_masked = (int)value; }
     else if (n == "debug_validate") { if (value < 0 || value > 1) { ctx->err = "debug_validate must be 0 or 1"; return ZKPOR_E_ARG; } ctx->debug_validate = (int)value; }

@@ -63,7 +63,7 @@ struct zkpor_ctx {
     int msm_filter = 1;              // per-array digit streams: drop the entries of absent points before B1 / B2 and K (msm_digits.hip)
     int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 256: one per CU — bandwidth, not wave slots)
     int ntt_fuse = 1;                // computeH: the two passes over the lowest field (inverse DIF last, coset DIT first) in one kernel (ntt.hip k_ntt_mid29)
-    int sort_block = 0;              // workgroup size of the onesweep radix sort: 0 = rocPRIM default (1024), 256, 512 (sort.hip)
+    int sort_grid = 0;               // workgroups of the digit-stream sort's persistent kernels (sort.hip): 0 = two per compute unit
     int aux_priority = 0;            // 1: the auxiliary (digit-stream) HIP stream is created with the highest stream priority
     int solver_defer_checks = 1;     // with zkpor_solver_set_abc_dev: the run leaves its CHECK instructions (assertions) out and zkpor_solver_eval_abc_dev verifies a x b = c on EVERY row; 0 = the run executes them
     int64_t solver_tree_from = 1024; // levels from this many generic instructions on: the divisions of a workgroup share one inversion, long constraints go to k_solve_long
@@ -78,7 +78,15 @@ struct zkpor_ctx {
                                      // compute units free (evenly over the XCDs) — for the narrow, dependent launches of ANOTHER worker's solver program, which
                                      // otherwise queue behind full-size MSM grids (solve(i+1) beside tail(i): host/prover_host.hpp workers, bench.py end_to_end)
     int tail_aux_masked = 0;         // 1: the digit streams of a masked tail keep to the tail's CU mask; 0: they may use the reserved units too
-    hipStream_t tail_stream = nullptr, tail_aux = nullptr, tail_aux_free = nullptr;   // created on first use, destroyed when the parameter changes (tail_aux_free: every CU, own hardware queue)
+    // The masked streams, created on first use and NEVER destroyed before the context itself: one (main, aux) pair per value "tail_reserve_cus" has
+    // had (at most TAIL_SETS_MAX values per context), tail_aux_free (every CU, own hardware queue) once.  Round 5 destroyed and re-created them when the
+    // parameter changed and the second generation crashed inside the HIP runtime: events of the context (the phase timers' pending pairs, the pool)
+    // still name the stream they were last recorded on.  tail_stream / tail_aux are the pair of the current value (null until a tail has run with it).
+    struct TailSet { int reserve; hipStream_t main, aux; };
+    static constexpr size_t TAIL_SETS_MAX = 4;
+    std::vector<TailSet> tail_sets;
+    hipStream_t tail_stream = nullptr, tail_aux = nullptr, tail_aux_free = nullptr;
+    std::vector<hipStream_t> retired_streams;   // streams a handle of this context replaced (a solver's first side streams): destroyed with the context
     int debug_validate = 0;          // 1: every sorted digit stream is checked (keys ascending and below the bucket count, point indices inside the array) on the
                                      // accumulating stream before its level-1 kernel reads it; a violation is ZKPOR_E_STATE instead of a GPU memory fault
     uint32_t* dbg_buf = nullptr;     // 4 words of device memory for that check
@@ -214,6 +222,10 @@ int32_t h2d_sync(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 // queue of its own; `reserve` compute units are left out of the mask (0 = every CU: only the queue is wanted).  Such streams synchronise with the
 // legacy NULL stream, which the per-proof paths therefore never use.
 int32_t stream_create_own_queue(zkpor_ctx* ctx, hipStream_t* out, int reserve_cus);
+// after a failed call: nothing the prove tail queued on its own streams (all of them: the unmasked digit stream too) may still touch the stage or the workspace
+inline void drain_tail_streams(zkpor_ctx* ctx) {
+    for (hipStream_t st : {ctx->tail_stream, ctx->tail_aux, ctx->tail_aux_free}) if (st) (void)hipStreamSynchronize(st);
+}
 void bounce_free(zkpor_ctx* ctx);
 // One caller at a time runs the GPU part of a host-pointer call on a device (the others keep moving their vectors across PCIe
 // meanwhile).  Without it two callers drift into lockstep: their kernels share the GPU, finish together, and then both copy at
@@ -237,12 +249,5 @@ void r1cs_dims(const zkpor_r1cs* r, size_t* n_constraints, size_t* n_wires, int*
 // solver.hip: the context and the constraint system a solver program was created on
 zkpor_ctx* solver_ctx(zkpor_solver* s);
 zkpor_r1cs* solver_r1cs(zkpor_solver* s);
-
-// sort.hip (rocPRIM radix sort of (key,value) u32 pairs, keys in [0, 2^end_bit))
-int32_t sort_pairs_temp_bytes(zkpor_ctx* ctx, size_t n, int end_bit, size_t* bytes);
-
-// sorts (k0,v0); the sorted data ends up in (k_out, v_out) which alias one of the two buffers
-int32_t sort_pairs(zkpor_ctx* ctx, void* temp, size_t temp_bytes, u32* k0, u32* k1, u32* v0, u32* v1, size_t n,
-                   int end_bit, u32** k_out, u32** v_out);
 
 }  // namespace zk

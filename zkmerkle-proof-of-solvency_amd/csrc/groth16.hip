@@ -602,17 +602,28 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     }
     const hipStream_t caller_s = ctx->stream;
     hipStream_t main_s = ctx->stream, aux_s = ctx->aux_stream;
-    if (ctx->tail_reserve_cus > 0) {
+    // the mask is for a tail that runs BESIDE another worker's device solve (the *_dev split: zkpor_solver_start_dev ... zkpor_prove_tail_dev).  A
+    // host-pointer call holds the device turn from before its own solve to its last kernel — no solve ever overlaps its tail — so masking it would only
+    // take compute units away from VALU-bound kernels (up to 12 % per tail on the dispatcher's host-solver path)
+    const bool masked = ctx->tail_reserve_cus > 0 && !host && !turn;
+    if (masked) {
         // "tail_reserve_cus": everything the tail queues goes to two streams whose CU mask leaves some compute units free.  A mask bit i is
         // compute unit i / 8 of XCD i % 8 on this part (the driver deals the bits round-robin over the XCDs), so clearing the first R bits
         // frees R / 8 units on each of the eight XCDs.
-        if (!ctx->tail_stream || !ctx->tail_aux || !ctx->tail_aux_free) {   // all three or none: a failure half way must not leave a null stream behind
-            hipStream_t st[3] = {nullptr, nullptr, nullptr};
-            int32_t rc = stream_create_own_queue(ctx, &st[0], ctx->tail_reserve_cus);
-            if (rc == ZKPOR_OK) rc = stream_create_own_queue(ctx, &st[1], ctx->tail_reserve_cus);
-            if (rc == ZKPOR_OK) rc = stream_create_own_queue(ctx, &st[2], 0);
-            if (rc != ZKPOR_OK) { for (hipStream_t x : st) if (x) (void)hipStreamDestroy(x); return rc; }
-            for (hipStream_t* old : {&ctx->tail_stream, &ctx->tail_aux, &ctx->tail_aux_free}) if (*old) { (void)hipStreamSynchronize(*old); (void)hipStreamDestroy(*old); }
+        if (!ctx->tail_stream || !ctx->tail_aux || !ctx->tail_aux_free) {   // the pair of this value and the unmasked digit stream: created once, kept until the context goes
+            if (ctx->tail_sets.size() >= zkpor_ctx::TAIL_SETS_MAX && !ctx->tail_stream) { ctx->err = "prove: no masked stream pair left for this tail_reserve_cus"; return ZKPOR_E_STATE; }
+            hipStream_t st[3] = {ctx->tail_stream, ctx->tail_aux, ctx->tail_aux_free};
+            int32_t rc = ZKPOR_OK;
+            const bool new_pair = !st[0];
+            if (new_pair) { rc = stream_create_own_queue(ctx, &st[0], ctx->tail_reserve_cus); if (rc == ZKPOR_OK) rc = stream_create_own_queue(ctx, &st[1], ctx->tail_reserve_cus); }
+            const bool new_free = !st[2];
+            if (rc == ZKPOR_OK && new_free) rc = stream_create_own_queue(ctx, &st[2], 0);
+            if (rc != ZKPOR_OK) {   // nothing half-made stays behind (these streams have never been used: destroying them is safe)
+                if (new_pair) { if (st[0]) (void)hipStreamDestroy(st[0]); if (st[1]) (void)hipStreamDestroy(st[1]); }
+                if (new_free && st[2]) (void)hipStreamDestroy(st[2]);
+                return rc;
+            }
+            if (new_pair) ctx->tail_sets.push_back({ctx->tail_reserve_cus, st[0], st[1]});
             ctx->tail_stream = st[0]; ctx->tail_aux = st[1]; ctx->tail_aux_free = st[2];
         }
         // the digit streams (decompose, radix sort, filter) are HBM-bound helpers that starve beside the VALU-bound kernels of the main stream
@@ -624,7 +635,7 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     // several workers of a GPU with a reserved-CU tail: ONE prove tail at a time (two would only time-slice each other on the same compute units), so
     // that the other worker's SOLVE is what runs beside it; the waiting worker sleeps here, its solver's prefetched chains keep running
     GpuTurn own_turn;
-    if (ctx->tail_reserve_cus > 0 && !turn) { own_turn.acquire(ctx); turn = &own_turn; }
+    if (masked) { own_turn.acquire(ctx); turn = &own_turn; }
     if (main_s != caller_s) {   // whatever the caller queued on the context's stream (the solver, a / b / c, uploads) comes first
         ZK_HIP(ctx, hipEventRecord(e_start, caller_s));
         ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_start, 0));
@@ -969,7 +980,7 @@ int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const 
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
-        if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamSynchronize(ctx->tail_aux); }
+        zk::drain_tail_streams(ctx);
         return rc;
     }
     HostPhase hp(ctx, "host_assembly");
@@ -1002,7 +1013,7 @@ int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const u
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
-        if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamSynchronize(ctx->tail_aux); }
+        zk::drain_tail_streams(ctx);
     };
     GpuTurn turn;
     int32_t rc = host_upload(ctx, d_w, w, pk->n_wires * sizeof(Fr));
@@ -1053,7 +1064,7 @@ int32_t zkpor_prove_inputs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, zkpor
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
-        if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamSynchronize(ctx->tail_aux); }
+        zk::drain_tail_streams(ctx);
     };
     GpuTurn turn;
     int32_t rc = host_upload(ctx, d_w, inputs, n_inputs * sizeof(Fr));

@@ -2,9 +2,10 @@
 // groth16.Prove runs on the host (reference call site src/prover/prover/prover.go:269).
 //
 // MI355X-first structure ("sort once, accumulate many"):
-//   1. k_decompose   scalars (Montgomery Fr) -> signed c-bit digits -> compacted (key = window|bucket,
-//                    val = point index|sign) pairs; zero digits are dropped (witness vectors are full of them).
-//   2. rocPRIM radix sort of the pairs by key: every bucket becomes a contiguous run.
+//   1. sort.hip      scalars (Montgomery Fr) -> signed c-bit digits -> (key = window|bucket, val = point index|sign)
+//                    pairs; zero digits are dropped (witness vectors are full of them).
+//   2. sort.hip: the pairs grouped by key, most significant digit first (own kernels; step 1 is fused into its first level): every bucket
+//                    becomes a contiguous run.
 //   3. k_acc_level1  perfectly load-balanced segmented sum: each thread owns exactly L consecutive sorted
 //                    entries (not a bucket), gathers the 64/128-byte affine points and accumulates runs in XYZZ
 //                    registers.  Runs that lie inside the chunk are finished buckets and go straight to HBM;
@@ -73,8 +74,17 @@ inline MsmCfg msm_cfg(zkpor_ctx* ctx, size_t n, int tables = 1) {
 
 // ------------------------------------------------------------------------------------------------ launchers
 // defined next to the kernel instantiations (one translation unit per field / inlining policy)
-int32_t launch_decompose(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, u32* keys, u32* vals, u32* counter, const u32* absent0 = nullptr,
-                         const u32* absent1 = nullptr);
+// sort.hip: the digit stream of a scalar vector, grouped by bucket (keys ascending).  The plan = the levels of the most-significant-digit-first
+// sort for a key space and the layout of its counter arrays in the scratch area.
+struct DigitSortPlan {
+    int nlev = 1;
+    int r[4] = {0, 0, 0, 0}, shift[4] = {0, 0, 0, 0};   // level l splits on (key >> shift[l]) & (2^r[l] - 1)
+    u32 n_child[4] = {0, 0, 0, 0};                      // key prefixes at level l: ((NB - 1) >> shift[l]) + 1
+    size_t off_C[4] = {0, 0, 0, 0}, off_bs = 0, bytes = 0;
+};
+DigitSortPlan digit_sort_plan(const MsmCfg& cfg);
+int32_t digit_sort(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, const DigitSortPlan& plan, u32* kA, u32* vA, u32* kB, u32* vB, u32* counter,
+                   char* temp, const u32* absent0, const u32* absent1, u32 Ms[3], u32** k_out, u32** v_out);
 int32_t launch_filter(zkpor_ctx* ctx, const u32* keys, const u32* vals, u32 M, u32* seg_counts, u32 grid, u32* k0, u32* v0, u32* k1, u32* v1);
 // "debug_validate": checks a sorted stream on ctx->stream and WAITS for the verdict (msm_digits.hip)
 int32_t validate_stream(zkpor_ctx* ctx, const u32* keys, const u32* vals, u32 M, u32 NB, u32 n_idx, const char* what);
@@ -128,8 +138,8 @@ inline size_t digits_ws_bytes(zkpor_ctx* ctx, size_t n, const MsmCfg& cfg, size_
     size_t cap = n * (size_t)cfg.W;
     WsPlan p;
     p.add<u32>(cap); p.add<u32>(cap); p.add<u32>(cap); p.add<u32>(cap); p.add<u32>(64);
-    size_t tb = 0;
-    sort_pairs_temp_bytes(ctx, cap, cfg.key_bits, &tb);
+    (void)ctx;
+    size_t tb = digit_sort_plan(cfg).bytes;
     if (n_filters > 0 && tb < 2 * FILTER_MAX_GRID * sizeof(u32)) tb = 2 * FILTER_MAX_GRID * sizeof(u32);   // the filter's segment counts reuse the sort's scratch
     *sort_temp = tb;
     p.add<char>(tb + 256);
@@ -152,21 +162,12 @@ inline int32_t msm_digits(zkpor_ctx* ctx, const Fr* d_scalars, size_t n, const M
     out->cfg = cfg;
     out->n_idx = (u32)(n * (size_t)cfg.m);
     const bool flags_fit = n * (size_t)cfg.m < (1ull << 29);   // the absence flags live in bits 30 / 31 of a value
-    {
-        PhaseScope ps(ctx, "msm_decompose");
-        ZK_HIP(ctx, hipMemsetAsync(counter, 0, 64, ctx->stream));
-        ZK_TRY(launch_decompose(ctx, d_scalars, (u32)n, cfg, k0, v0, counter, (filt && flags_fit) ? filt->absent[0] : nullptr, (filt && flags_fit) ? filt->absent[1] : nullptr));
-    }
     u32 Ms[3] = {0, 0, 0};
-    ZK_HIP(ctx, hipMemcpyAsync(Ms, counter, 12, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // decompose + group by bucket (sort.hip; phases "msm_decompose" = the counting pass over the scalars, "msm_sort" = everything after it)
+    ZK_TRY(digit_sort(ctx, d_scalars, (u32)n, cfg, digit_sort_plan(cfg), k0, v0, k1, v1, counter, temp, (filt && flags_fit) ? filt->absent[0] : nullptr,
+                      (filt && flags_fit) ? filt->absent[1] : nullptr, Ms, &out->keys, &out->vals));
     const u32 M = Ms[0];
     out->M = M;
-    out->keys = k0; out->vals = v0;
-    if (M > 1) {
-        PhaseScope ps(ctx, "msm_sort");
-        ZK_TRY(sort_pairs(ctx, temp, sort_temp, k0, k1, v0, v1, M, cfg.key_bits, &out->keys, &out->vals));
-    }
     if (ev_sorted) ZK_HIP(ctx, hipEventRecord(ev_sorted, ctx->stream));
     // per-array streams: ONE stable filter pass pair over the sorted stream produces both groups; their sizes were counted by the decomposition
     if (out_f0) *out_f0 = *out;                            // not filtered: the shared stream itself

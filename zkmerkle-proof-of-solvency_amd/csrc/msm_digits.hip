@@ -1,99 +1,13 @@
-// MSM step 1: scalar -> signed-digit (bucket key, point index) stream.  See msm.cuh.
+// MSM, beside the digit stream (sort.hip builds it): the per-array stream filter and the "debug_validate" check.  See msm.cuh.
 #include "msm_kernels.cuh"
 namespace zk {
-
-// ------------------------------------------------------------------------------------------------ decompose
-// low c bits of s, then s >>= c (static register indexing only: no scratch)
-ZK_D u32 take_digit(Fr& s, int c) {
-    u32 d = s.v[0] & ((1u << c) - 1u);
-#pragma unroll
-    for (int i = 0; i < 7; ++i) s.v[i] = (s.v[i] >> c) | (s.v[i + 1] << (32 - c));
-    s.v[7] >>= c;
-    return d;
-}
-
-// One thread per scalar.  Two passes over the digits (count, then write) so nothing spills; entries of one
-// 256-thread block are appended with ONE global atomic.
-__global__ __launch_bounds__(256) void k_decompose(const Fr* __restrict__ scalars, u32 n, int c, int W, int tables, int piece, u32 bpw,
-                                                   u32* __restrict__ out_keys, u32* __restrict__ out_vals,
-                                                   u32* __restrict__ counter, const u32* __restrict__ absent0, const u32* __restrict__ absent1) {
-    __shared__ u32 wave_tot[4];
-    __shared__ u32 block_base;
-    const u32 i = blockIdx.x * 256u + threadIdx.x;
-    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    Fr s = Fr::zero();
-    u32 cnt = 0;
-    const u32 half = 1u << (c - 1);
-    if (i < n) {
-        s = Fr::from_mont(scalars[i]);
-        Fr t = s;
-        u32 carry = 0;
-        for (int w = 0; w < W; ++w) {
-            u32 d = take_digit(t, c) + carry;
-            carry = d > half ? 1u : 0u;
-            d = carry ? (1u << c) - d : d;
-            cnt += d != 0;
-        }
-    }
-    // block-exclusive prefix of cnt
-    u32 x = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        u32 y = __shfl_up(x, off);
-        if ((int)lane >= off) x += y;
-    }
-    if (lane == 63) wave_tot[wv] = x;
-    // the sizes of the per-array streams (k_filter_write keeps the entries of wires present in the array): counter[1 + g]
-    __shared__ u32 wave_c[2][4];
-    const bool counting = absent0 || absent1;
-    u32 flags = 0;   // bits 30 / 31 of every value this scalar emits: its point is absent from group 0 / 1 (read here, where the index is at hand
-                     // and the mask words are shared by 32 neighbouring threads — the filter then streams without a single lookup)
-    if (counting) {
-        const u32 word = i < n ? i >> 5 : 0u, bit = i & 31u;
-        if (absent0 && i < n && ((absent0[word] >> bit) & 1u)) flags |= VAL_ABSENT0;
-        if (absent1 && i < n && ((absent1[word] >> bit) & 1u)) flags |= VAL_ABSENT1;
-        u32 c0 = (i < n && !(flags & VAL_ABSENT0)) ? cnt : 0u;
-        u32 c1 = (i < n && !(flags & VAL_ABSENT1)) ? cnt : 0u;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); }
-        if (lane == 0) { wave_c[0][wv] = c0; wave_c[1][wv] = c1; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 t = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        block_base = t ? atomicAdd(counter, t) : 0u;
-        if (counting) {   // one atomic per block and counter, like the stream's own
-            const u32 c0 = wave_c[0][0] + wave_c[0][1] + wave_c[0][2] + wave_c[0][3], c1 = wave_c[1][0] + wave_c[1][1] + wave_c[1][2] + wave_c[1][3];
-            if (c0) atomicAdd(counter + 1, c0);
-            if (c1) atomicAdd(counter + 2, c1);
-        }
-    }
-    __syncthreads();
-    u32 pos = block_base + x - cnt;
-    for (u32 k = 0; k < wv; ++k) pos += wave_tot[k];
-    if (i < n && cnt) {
-        u32 carry = 0;
-        for (int w = 0; w < W; ++w) {
-            u32 d = take_digit(s, c) + carry;
-            carry = d > half ? 1u : 0u;
-            d = carry ? (1u << c) - d : d;
-            if (d) {
-                // digit w of the scalar = bucket window w % piece against table w / piece of point i (msm.cuh MsmCfg)
-                const u32 q = (u32)w / (u32)piece;
-                out_keys[pos] = ((u32)w - q * (u32)piece) * bpw + (d - 1u);
-                out_vals[pos] = ((i * (u32)tables + q) << 1) | carry | flags;  // carry == 1 <=> the digit is negative
-                ++pos;
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ per-array streams
 // A STABLE filter of the sorted (key, val) stream that drops the entries whose point is absent from a group of key arrays
 // (group 0: pk.InfinityB for B1 / B2; group 1: the public and committed wires K leaves out).  The shared stream of w serves four
 // arrays; in the level-1 kernel an entry whose point is infinity costs a full addition slot of its wave (the other lanes add, this
 // one idles) and a 64-byte gather — 25 % of K's and 10 % of B's lane-time at the production shapes.  The absence flags ride in bits 30 / 31
-// of the values (set by k_decompose), so the filter is pure streaming.  Both groups are produced in ONE
+// of the values (set by sort.hip k_dsort_scatter0), so the filter is pure streaming.  Both groups are produced in ONE
 // pass pair over the stream, by a SMALL persistent grid (one or two workgroups per CU): the kernels run beside the VALU-bound
 // accumulation of A and must take memory bandwidth, not wave slots (a library compaction with a full-size grid cost the proof 39 ms —
 // profiles/r03_filter.txt).  Pass 1 counts what each workgroup's contiguous segment keeps, pass 2 writes: order, hence every run of
@@ -224,11 +138,4 @@ int32_t validate_stream(zkpor_ctx* ctx, const u32* keys, const u32* vals, u32 M,
     return ZKPOR_OK;
 }
 
-int32_t launch_decompose(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, u32* keys, u32* vals, u32* counter, const u32* absent0,
-                         const u32* absent1) {
-    u32 blocks = (n + 255u) / 256u;
-    hipLaunchKernelGGL(k_decompose, dim3(blocks), dim3(256), 0, ctx->stream, d_scalars, n, cfg.c, cfg.W, cfg.m, cfg.piece, cfg.bpw, keys, vals, counter, absent0, absent1);
-    ZK_KERNEL_CHECK(ctx);
-    return ZKPOR_OK;
-}
 }  // namespace zk

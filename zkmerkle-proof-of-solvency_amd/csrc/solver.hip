@@ -731,8 +731,9 @@ int32_t solver_side_queues(zkpor_solver* s) {
     hipStream_t a = nullptr, b = nullptr;
     ZK_TRY(stream_create_own_queue(ctx, &a, 0));
     if (stream_create_own_queue(ctx, &b, 0) != ZKPOR_OK) { (void)hipStreamDestroy(a); return ZKPOR_E_HIP; }
-    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
-    if (s->side2) { (void)hipStreamSynchronize(s->side2); (void)hipStreamDestroy(s->side2); }
+    // the first pair is parked, not destroyed: the solver's events were recorded on it (the context destroys what it has retired)
+    if (s->side) { (void)hipStreamSynchronize(s->side); ctx->retired_streams.push_back(s->side); }
+    if (s->side2) { (void)hipStreamSynchronize(s->side2); ctx->retired_streams.push_back(s->side2); }
     s->side = a; s->side2 = b;
     s->side_own_queue = true;
     return ZKPOR_OK;

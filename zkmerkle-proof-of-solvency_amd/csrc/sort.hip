@@ -1,55 +1,423 @@
-// Bucket grouping for the Pippenger MSM: radix sort of (window|bucket key, point index|sign) pairs.
-// rocPRIM's onesweep radix sort is a library primitive (like a plain GEMM would be); everything around it is ours.
+// MSM steps 1 + 2, hand-written for gfx950: scalars -> signed c-bit digits -> (bucket key, point index | sign) entries GROUPED BY BUCKET.
+// Replaces gnark-crypto's partitionScalars + the per-chunk bucket walk of ecc/bn254/multiexp.go (third-party, recalled; reference call site
+// src/prover/prover/prover.go:269).  Rounds 1-5 used rocPRIM's onesweep radix sort behind a separate decompose kernel; this file is what the
+// consumer actually needs, and nothing more:
 //
-// The sort runs on the auxiliary stream UNDER the NTT passes and the bucket accumulations of the main stream.  rocPRIM's default
-// onesweep kernel for 4-byte pairs uses 1024-thread workgroups: next to a long-running kernel whose 256-thread workgroups trickle
-// out one at a time (and are replaced at once by the next workgroup of the same kernel) a 16-wave workgroup almost never finds a CU
-// with 16 free wave slots, so a 3 ms pass took 70-90 ms and the main stream ended up waiting for it (profiles/r03_timeline.txt).
-// "sort_block" selects a configuration with 256- or 512-thread workgroups that compete for freed slots on equal terms.
-#include "common.cuh"
-#include <rocprim/rocprim.hpp>
-
+//   * The level-1 accumulation only needs every bucket's entries CONTIGUOUS (a group law is commutative): no stability, no order inside a
+//     bucket.  So the sort is most-significant-digit first, and an entry's rank inside a tile is one LDS atomic (`ds_add_rtn`) instead of a
+//     stable match / ballot ranking; a tile's run in each child segment is reserved with ONE global atomic per (tile, child).
+//   * Level 0 is FUSED with the digit decomposition: the scalars are read twice (count, scatter: 2 x 32 B per scalar) and the unsorted entry
+//     stream — 96 B per scalar written, then read by a histogram pass and the first sort pass — never exists.
+//   * Every level is count -> exclusive scan -> scatter over the key prefix `key >> shift`: the children of level l are the parents of level
+//     l + 1, tiles never straddle a parent, so a tile touches at most 2^r <= 512 children (LDS counters), and after the scatter the cursor array
+//     IS the array of segment ends the next level walks.  23 key bits (3 bucket windows of 2^21 at the production size) = levels of 7 + 8 + 8 bits.
+//   * The kernels run BESIDE the VALU-bound NTT passes and bucket accumulations of the main stream ("memory-bound helpers must run
+//     on a small persistent grid"): 256-thread workgroups, <= 56 VGPRs and 40 KB of LDS so that one fits next to three resident workgroups of the
+//     level-1 kernel, a persistent grid that takes work in chunks from a ticket counter, entries staged through LDS so that a wave's stores cover
+//     whole runs.  rocPRIM's 1024-thread onesweep workgroups waited for 16 free wave slots on ONE compute unit (profiles/r03_timeline_before.txt).
+//
+// Output: keys ascending (the children of every level are laid out in prefix order), values = (point index << 1 | sign) | absence flags.
+#include "msm_kernels.cuh"
 namespace zk {
 
 namespace {
-using cfg256 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                          rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<256, 16>, 8,
-                                                                              rocprim::block_radix_rank_algorithm::match>>;
-using cfg512 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                          rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<512, 12>, 8,
-                                                                              rocprim::block_radix_rank_algorithm::match>>;
+constexpr u32 DS_THREADS = 256, DS_TILE = 4096, DS_MAXR = 9, DS_NB = 1u << DS_MAXR;
+constexpr u32 DS_CHUNK_TILES = 16;                 // entries per ticket of a level >= 1 kernel: 16 tiles
+constexpr u32 DS_SCALARS_PER_TICKET = 2048;        // scalars per ticket of the level-0 kernels
+constexpr u32 DS_DW = 16;                          // digits of a scalar per level-0 tile: 256 scalars x 16 digits = one LDS tile
 
-template <class Cfg>
-hipError_t run(void* temp, size_t& tb, rocprim::double_buffer<u32>& k, rocprim::double_buffer<u32>& v, size_t n, int end_bit, hipStream_t s) {
-    return rocprim::radix_sort_pairs<Cfg>(temp, tb, k, v, n, 0, (unsigned)end_bit, s);
+// low c bits of s, then s >>= c (static register indexing only: no scratch)
+ZK_D u32 take_digit(Fr& s, int c) {
+    u32 d = s.v[0] & ((1u << c) - 1u);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s.v[i] = (s.v[i] >> c) | (s.v[i + 1] << (32 - c));
+    s.v[7] >>= c;
+    return d;
 }
-hipError_t dispatch(int block, void* temp, size_t& tb, rocprim::double_buffer<u32>& k, rocprim::double_buffer<u32>& v, size_t n, int end_bit, hipStream_t s) {
-    if (block == 256) return run<cfg256>(temp, tb, k, v, n, end_bit, s);
-    if (block == 512) return run<cfg512>(temp, tb, k, v, n, end_bit, s);
-    return run<rocprim::default_config>(temp, tb, k, v, n, end_bit, s);
+
+struct DsCfg { int c, W, tables, piece; u32 bpw; };
+
+struct DsShared {
+    u32 sk[DS_TILE], sv[DS_TILE];
+    u32 cnt[DS_NB], cur[DS_NB], lpre[DS_NB], gbase[DS_NB];
+    u32 wsum[4], misc[8];
+};
+
+// after a count phase: reserve this tile's run in every child (one global atomic each), the tile-local exclusive prefix of the counts, and the
+// placing cursors.  nb <= 512 counters, two per thread.  Leaves cnt[] zeroed for the next tile.
+ZK_D void ds_reserve(DsShared& S, u32 nb, u32* __restrict__ cursor, u32 child0, u32 n_child) {
+    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const u32 i0 = 2u * t, i1 = 2u * t + 1u;
+    const u32 a = i0 < nb ? S.cnt[i0] : 0u, b = i1 < nb ? S.cnt[i1] : 0u;
+    u32 x = a + b;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 y = __shfl_up(x, off);
+        if ((int)lane >= off) x += y;
+    }
+    if (lane == 63u) S.wsum[wv] = x;
+    if (a && child0 + i0 < n_child) S.gbase[i0] = atomicAdd(cursor + child0 + i0, a);
+    if (b && child0 + i1 < n_child) S.gbase[i1] = atomicAdd(cursor + child0 + i1, b);
+    __syncthreads();
+    u32 ex = x - (a + b);
+    for (u32 w = 0; w < wv; ++w) ex += S.wsum[w];
+    if (i0 < nb) { S.lpre[i0] = ex; S.cur[i0] = ex; S.cnt[i0] = 0u; }
+    if (i1 < nb) { S.lpre[i1] = ex + a; S.cur[i1] = ex + a; S.cnt[i1] = 0u; }
+    __syncthreads();
+}
+
+// the staged tile (sk / sv hold `len` entries grouped by child, child d at [lpre[d], lpre[d] + count)) -> its reserved runs: consecutive lanes write
+// consecutive addresses inside a run
+ZK_D void ds_write_out(const DsShared& S, u32 len, int shift, u32 mask, u32* __restrict__ out_k, u32* __restrict__ out_v) {
+    for (u32 j = threadIdx.x; j < len; j += DS_THREADS) {
+        const u32 k = S.sk[j];
+        const u32 d = (k >> shift) & mask;
+        const u32 dest = S.gbase[d] + (j - S.lpre[d]);
+        out_k[dest] = k;
+        out_v[dest] = S.sv[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ level 0: fused with the decomposition
+// digits w0 .. w0 + nd - 1 of a scalar whose already-shifted remainder is `t` and whose pending carry is `carry` (both advanced); f(key, val) per
+// non-zero digit.  Digit w of the scalar = bucket window w % piece against table w / piece of point i (msm.cuh MsmCfg).
+template <class Fn>
+ZK_D void ds_digits(Fr& t, u32& carry, int w0, int nd, const DsCfg& cfg, u32 i, u32 flags, Fn f) {
+    const u32 half = 1u << (cfg.c - 1);
+    for (int w = w0; w < w0 + nd; ++w) {
+        u32 d = take_digit(t, cfg.c) + carry;
+        carry = d > half ? 1u : 0u;
+        d = carry ? (1u << cfg.c) - d : d;
+        if (d) {
+            const u32 q = (u32)w / (u32)cfg.piece;
+            f(((u32)w - q * (u32)cfg.piece) * cfg.bpw + (d - 1u), ((i * (u32)cfg.tables + q) << 1) | carry | flags);   // carry == 1 <=> the digit is negative
+        }
+    }
+}
+
+// counts: C0[key >> shift0] over every entry, counter[0] = entries, counter[1 + g] = entries whose point is present in array group g (the sizes of the
+// per-array streams, msm_digits.hip k_filter_write).  ticket: one u32, zero on entry.
+__global__ __launch_bounds__(DS_THREADS) void k_dsort_count0(const Fr* __restrict__ scalars, u32 n, DsCfg cfg, int shift0, u32 nb0, u32* __restrict__ C0,
+                                                             u32* __restrict__ counter, u32* __restrict__ ticket, const u32* __restrict__ absent0,
+                                                             const u32* __restrict__ absent1) {
+    __shared__ u32 cnt[DS_NB];
+    __shared__ u32 s_ticket;
+    for (u32 i = threadIdx.x; i < nb0; i += DS_THREADS) cnt[i] = 0u;
+    u32 tot = 0, tot0 = 0, tot1 = 0;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const u32 base = s_ticket * DS_SCALARS_PER_TICKET;
+        if (base >= n) break;
+        for (u32 i = base + threadIdx.x; i < base + DS_SCALARS_PER_TICKET && i < n; i += DS_THREADS) {
+            Fr t = Fr::from_mont(scalars[i]);
+            u32 carry = 0, c_here = 0;
+            ds_digits(t, carry, 0, cfg.W, cfg, i, 0u, [&](u32 key, u32) { atomicAdd(&cnt[key >> shift0], 1u); ++c_here; });
+            tot += c_here;
+            if (absent0 || absent1) {
+                const u32 word = i >> 5, bit = i & 31u;
+                if (!(absent0 && ((absent0[word] >> bit) & 1u))) tot0 += c_here;
+                if (!(absent1 && ((absent1[word] >> bit) & 1u))) tot1 += c_here;
+            }
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < nb0; i += DS_THREADS) if (cnt[i]) atomicAdd(C0 + i, cnt[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { tot += __shfl_down(tot, off); tot0 += __shfl_down(tot0, off); tot1 += __shfl_down(tot1, off); }
+    if ((threadIdx.x & 63u) == 0u) {
+        if (tot) atomicAdd(counter, tot);
+        if (tot0) atomicAdd(counter + 1, tot0);
+        if (tot1) atomicAdd(counter + 2, tot1);
+    }
+}
+
+// scatter: C0 holds the children's start offsets on entry and their end offsets on exit
+__global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter0(const Fr* __restrict__ scalars, u32 n, DsCfg cfg, int shift0, u32 nb0, u32* __restrict__ C0,
+                                                               u32* __restrict__ ticket, const u32* __restrict__ absent0, const u32* __restrict__ absent1,
+                                                               u32* __restrict__ out_k, u32* __restrict__ out_v) {
+    __shared__ DsShared S;
+    for (u32 i = threadIdx.x; i < DS_NB; i += DS_THREADS) S.cnt[i] = 0u;
+    const u32 mask = 0xffffffffu;      // level 0: the child IS key >> shift0
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) S.misc[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const u32 base = S.misc[0] * DS_SCALARS_PER_TICKET;
+        if (base >= n) break;
+        for (u32 blk = base; blk < base + DS_SCALARS_PER_TICKET && blk < n; blk += DS_THREADS) {
+            const u32 i = blk + threadIdx.x;
+            const bool live = i < n;
+            Fr t = live ? Fr::from_mont(scalars[i]) : Fr::zero();
+            u32 carry = 0, flags = 0;
+            if (live && (absent0 || absent1)) {   // bits 30 / 31 of every value this scalar emits: its point is absent from group 0 / 1
+                const u32 word = i >> 5, bit = i & 31u;
+                if (absent0 && ((absent0[word] >> bit) & 1u)) flags |= VAL_ABSENT0;
+                if (absent1 && ((absent1[word] >> bit) & 1u)) flags |= VAL_ABSENT1;
+            }
+            for (int w0 = 0; w0 < cfg.W; w0 += (int)DS_DW) {
+                const int nd = cfg.W - w0 < (int)DS_DW ? cfg.W - w0 : (int)DS_DW;
+                // pass 1 over this tile's digits: count per child (on a copy of the running state)
+                u32 mine = 0;
+                if (live) {
+                    Fr t1 = t; u32 c1 = carry;
+                    ds_digits(t1, c1, w0, nd, cfg, i, flags, [&](u32 key, u32) { atomicAdd(&S.cnt[key >> shift0], 1u); ++mine; });
+                }
+                __syncthreads();
+                // the tile's length: sum of `mine`
+                u32 x = mine;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off);
+                if ((threadIdx.x & 63u) == 0u) S.misc[4 + (threadIdx.x >> 6)] = x;
+                ds_reserve(S, nb0, C0, 0u, nb0);
+                const u32 len = S.misc[4] + S.misc[5] + S.misc[6] + S.misc[7];
+                // pass 2: the same digits again, placed
+                if (live) ds_digits(t, carry, w0, nd, cfg, i, flags, [&](u32 key, u32 val) { const u32 p = atomicAdd(&S.cur[key >> shift0], 1u); S.sk[p] = key; S.sv[p] = val; });
+                __syncthreads();
+                ds_write_out(S, len, shift0, mask, out_k, out_v);
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ levels >= 1
+// first index s in [0, n_par) with ends[s] > pos (ends ascending, ends[n_par - 1] > pos): a 256-ary search, one probe per thread and round
+ZK_D u32 ds_find_seg(DsShared& S, const u32* __restrict__ ends, u32 n_par, u32 pos) {
+    u32 lo = 0, hi = n_par;
+    const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    for (;;) {
+        const u32 span = hi - lo;
+        const u32 stride = (span + DS_THREADS - 1u) / DS_THREADS;
+        u32 idx = lo + (t + 1u) * stride - 1u;
+        const bool inside = lo + t * stride < hi;
+        if (idx >= hi) idx = hi - 1u;
+        const bool flag = inside && ends[idx] > pos;
+        const unsigned long long b = __ballot(flag);
+        __syncthreads();                                   // wsum of the previous round / caller has been read
+        if (lane == 0u) S.wsum[wv] = b ? wv * 64u + (u32)__ffsll((long long)b) - 1u : 0xffffffffu;
+        __syncthreads();
+        u32 tmin = S.wsum[0];
+        for (u32 w = 1; w < 4; ++w) tmin = S.wsum[w] < tmin ? S.wsum[w] : tmin;
+        if (tmin == 0xffffffffu) return n_par - 1u;        // cannot happen (pos < ends[n_par - 1]); keeps the walk inside the array
+        const u32 nlo = lo + tmin * stride;
+        if (stride == 1u) return nlo;
+        hi = nlo + stride < hi ? nlo + stride : hi;
+        lo = nlo;
+    }
+}
+
+// counts of one level: C[key >> shift] over all M entries.  ends = the previous level's cursor array (= its children's end offsets), n_par of them.
+__global__ __launch_bounds__(DS_THREADS) void k_dsort_count(const u32* __restrict__ keys, u32 M, int shift, int r, const u32* __restrict__ ends, u32 n_par,
+                                                            u32* __restrict__ C, u32 n_child, u32* __restrict__ ticket) {
+    __shared__ DsShared S;
+    const u32 nb = 1u << r, mask = nb - 1u;
+    for (u32 i = threadIdx.x; i < DS_NB; i += DS_THREADS) S.cnt[i] = 0u;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) S.misc[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+        u32 pos = S.misc[0] * (DS_CHUNK_TILES * DS_TILE);
+        if (pos >= M) break;
+        const u32 cend = (M - pos > DS_CHUNK_TILES * DS_TILE) ? pos + DS_CHUNK_TILES * DS_TILE : M;
+        while (pos < cend) {
+            const u32 seg = ds_find_seg(S, ends, n_par, pos);
+            const u32 seg_end = ends[seg];
+            const u32 stop = seg_end < cend ? seg_end : cend;
+#pragma unroll 4
+            for (u32 j = pos + threadIdx.x; j < stop; j += DS_THREADS) atomicAdd(&S.cnt[(keys[j] >> shift) & mask], 1u);
+            __syncthreads();
+            for (u32 d = threadIdx.x; d < nb; d += DS_THREADS) {
+                const u32 c = S.cnt[d];
+                if (c) { S.cnt[d] = 0u; if ((seg << r) + d < n_child) atomicAdd(C + (seg << r) + d, c); }
+            }
+            pos = stop;
+        }
+    }
+}
+
+__global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter(const u32* __restrict__ keys, const u32* __restrict__ vals, u32 M, int shift, int r,
+                                                              const u32* __restrict__ ends, u32 n_par, u32* __restrict__ C, u32 n_child,
+                                                              u32* __restrict__ ticket, u32* __restrict__ out_k, u32* __restrict__ out_v) {
+    __shared__ DsShared S;
+    const u32 nb = 1u << r, mask = nb - 1u;
+    for (u32 i = threadIdx.x; i < DS_NB; i += DS_THREADS) S.cnt[i] = 0u;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) S.misc[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+        u32 pos = S.misc[0] * (DS_CHUNK_TILES * DS_TILE);
+        if (pos >= M) break;
+        const u32 cend = (M - pos > DS_CHUNK_TILES * DS_TILE) ? pos + DS_CHUNK_TILES * DS_TILE : M;
+        u32 seg = 0, seg_end = 0;
+        while (pos < cend) {
+            if (pos >= seg_end) { seg = ds_find_seg(S, ends, n_par, pos); seg_end = ends[seg]; }
+            u32 len = seg_end - pos;
+            if (len > cend - pos) len = cend - pos;
+            if (len > DS_TILE) len = DS_TILE;
+#pragma unroll 4
+            for (u32 j = threadIdx.x; j < len; j += DS_THREADS) atomicAdd(&S.cnt[(keys[pos + j] >> shift) & mask], 1u);
+            __syncthreads();
+            ds_reserve(S, nb, C, seg << r, n_child);
+#pragma unroll 4
+            for (u32 j = threadIdx.x; j < len; j += DS_THREADS) {
+                const u32 k = keys[pos + j];
+                const u32 p = atomicAdd(&S.cur[(k >> shift) & mask], 1u);
+                S.sk[p] = k;
+                S.sv[p] = vals[pos + j];
+            }
+            __syncthreads();
+            ds_write_out(S, len, shift, mask, out_k, out_v);
+            __syncthreads();
+            pos += len;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ exclusive scan of a counter array, in place
+constexpr u32 SCAN_BLOCK = 4096;   // 256 threads x 16
+__global__ __launch_bounds__(256) void k_scan_sums(const u32* __restrict__ C, u32 n, u32* __restrict__ bs) {
+    __shared__ u32 ws[4];
+    const u32 base = blockIdx.x * SCAN_BLOCK;
+    u32 x = 0;
+    for (u32 k = 0; k < 16; ++k) { const u32 i = base + k * 256u + threadIdx.x; if (i < n) x += C[i]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off);
+    if ((threadIdx.x & 63u) == 0u) ws[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) bs[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// one workgroup: exclusive scan of the block sums (a few thousand at most), in place
+__global__ __launch_bounds__(256) void k_scan_top(u32* __restrict__ bs, u32 nblocks) {
+    __shared__ u32 ws[4];
+    __shared__ u32 carry_s;
+    if (threadIdx.x == 0) carry_s = 0u;
+    __syncthreads();
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (u32 base = 0; base < nblocks; base += 256u) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = i < nblocks ? bs[i] : 0u;
+        u32 x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(x, off); if ((int)lane >= off) x += y; }
+        if (lane == 63u) ws[wv] = x;
+        __syncthreads();
+        u32 ex = carry_s + x - v;
+        for (u32 w = 0; w < wv; ++w) ex += ws[w];
+        if (i < nblocks) bs[i] = ex;
+        __syncthreads();
+        if (threadIdx.x == 255u) carry_s = ex + v;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_apply(u32* __restrict__ C, u32 n, const u32* __restrict__ bs) {
+    __shared__ u32 ws[4];
+    const u32 base = blockIdx.x * SCAN_BLOCK + threadIdx.x * 16u;   // 16 consecutive counters per thread
+    u32 v[16];
+    u32 s = 0;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) { v[k] = base + k < n ? C[base + k] : 0u; s += v[k]; }
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    u32 x = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(x, off); if ((int)lane >= off) x += y; }
+    if (lane == 63u) ws[wv] = x;
+    __syncthreads();
+    u32 ex = bs[blockIdx.x] + x - s;
+    for (u32 w = 0; w < wv; ++w) ex += ws[w];
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) { if (base + k < n) C[base + k] = ex; ex += v[k]; }
+}
+
+int32_t scan_in_place(zkpor_ctx* ctx, u32* C, u32 n, u32* bs) {
+    const u32 nblocks = (n + SCAN_BLOCK - 1u) / SCAN_BLOCK;
+    hipLaunchKernelGGL(k_scan_sums, dim3(nblocks), dim3(256), 0, ctx->stream, C, n, bs);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, ctx->stream, bs, nblocks);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(256), 0, ctx->stream, C, n, bs);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
 }
 }  // namespace
 
-int32_t sort_pairs_temp_bytes(zkpor_ctx* ctx, size_t n, int end_bit, size_t* bytes) {
-    size_t best = 0;
-    for (int block : {0, 256, 512}) {   // the workspace is sized once: take the largest of the selectable configurations
-        rocprim::double_buffer<u32> k(nullptr, nullptr);
-        rocprim::double_buffer<u32> v(nullptr, nullptr);
-        size_t tb = 0;
-        ZK_HIP(ctx, dispatch(block, nullptr, tb, k, v, n, end_bit, ctx->stream));
-        if (tb > best) best = tb;
+// the levels of a key space of NB buckets: the bits are dealt as evenly as ceil(key_bits / 9) levels allow, the narrower levels first (level 0
+// has the emptiest tiles: a witness vector is half zeros)
+DigitSortPlan digit_sort_plan(const MsmCfg& cfg) {
+    DigitSortPlan p;
+    const int kb = cfg.key_bits;
+    p.nlev = (kb + (int)DS_MAXR - 1) / (int)DS_MAXR;
+    if (p.nlev < 1) p.nlev = 1;
+    const int base = kb / p.nlev, extra = kb % p.nlev;
+    int used = 0;
+    size_t off = 0;
+    for (int l = 0; l < p.nlev; ++l) {
+        p.r[l] = base + (l >= p.nlev - extra ? 1 : 0);
+        used += p.r[l];
+        p.shift[l] = kb - used;
+        p.n_child[l] = ((cfg.NB - 1u) >> p.shift[l]) + 1u;
+        p.off_C[l] = off;
+        off += align_up((size_t)p.n_child[l] * sizeof(u32), 256);
     }
-    *bytes = best;
-    return ZKPOR_OK;
+    const u32 nblocks = (p.n_child[p.nlev - 1] + SCAN_BLOCK - 1u) / SCAN_BLOCK;
+    p.off_bs = off;
+    off += align_up((size_t)(nblocks + 1u) * sizeof(u32), 256);
+    p.bytes = off;
+    return p;
 }
 
-int32_t sort_pairs(zkpor_ctx* ctx, void* temp, size_t temp_bytes, u32* k0, u32* k1, u32* v0, u32* v1, size_t n,
-                   int end_bit, u32** k_out, u32** v_out) {
-    rocprim::double_buffer<u32> k(k0, k1);
-    rocprim::double_buffer<u32> v(v0, v1);
-    ZK_HIP(ctx, dispatch(ctx->sort_block, temp, temp_bytes, k, v, n, end_bit, ctx->stream));
-    *k_out = k.current();
-    *v_out = v.current();
+// counter: 64 zeroable bytes = [0] entries, [1], [2] per-array entries, [4 ..] the kernels' tickets.  temp: plan.bytes.  (kA, vA), (kB, vB): two buffer
+// pairs of n * W entries; the grouped stream ends up in one of them.  Synchronises ctx->stream once (the host needs the entry counts to size the
+// accumulation launches).
+int32_t digit_sort(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg, const DigitSortPlan& plan, u32* kA, u32* vA, u32* kB, u32* vB,
+                   u32* counter, char* temp, const u32* absent0, const u32* absent1, u32 Ms[3], u32** k_out, u32** v_out) {
+    const DsCfg dc{cfg.c, cfg.W, cfg.m, cfg.piece, cfg.bpw};
+    int grid = ctx->sort_grid;
+    if (grid <= 0) {
+        hipDeviceProp_t prop;
+        ZK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        grid = 2 * prop.multiProcessorCount;      // two 256-thread workgroups per compute unit: bandwidth, not wave slots
+    }
+    u32* C[4];
+    for (int l = 0; l < plan.nlev; ++l) C[l] = (u32*)(temp + plan.off_C[l]);
+    u32* bs = (u32*)(temp + plan.off_bs);
+    u32* ticket = counter + 4;
+    {
+        PhaseScope ps(ctx, "msm_decompose");
+        ZK_HIP(ctx, hipMemsetAsync(counter, 0, 64, ctx->stream));
+        ZK_HIP(ctx, hipMemsetAsync(temp, 0, plan.off_bs, ctx->stream));
+        const u32 tickets0 = (n + DS_SCALARS_PER_TICKET - 1u) / DS_SCALARS_PER_TICKET;
+        const u32 g0 = tickets0 < (u32)grid ? tickets0 : (u32)grid;
+        hipLaunchKernelGGL(k_dsort_count0, dim3(g0 ? g0 : 1u), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], counter, ticket,
+                           absent0, absent1);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(Ms, counter, 12, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const u32 M = Ms[0];
+    *k_out = kB; *v_out = vB;
+    if (M == 0) return ZKPOR_OK;
+    PhaseScope ps(ctx, "msm_sort");
+    {
+        ZK_TRY(scan_in_place(ctx, C[0], plan.n_child[0], bs));
+        const u32 tickets0 = (n + DS_SCALARS_PER_TICKET - 1u) / DS_SCALARS_PER_TICKET;
+        const u32 g0 = tickets0 < (u32)grid ? tickets0 : (u32)grid;
+        hipLaunchKernelGGL(k_dsort_scatter0, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
+        ZK_KERNEL_CHECK(ctx);
+    }
+    u32 *src_k = kB, *src_v = vB, *dst_k = kA, *dst_v = vA;
+    const u32 chunks = (M + DS_CHUNK_TILES * DS_TILE - 1u) / (DS_CHUNK_TILES * DS_TILE);
+    const u32 g = chunks < (u32)grid ? chunks : (u32)grid;
+    for (int l = 1; l < plan.nlev; ++l) {
+        hipLaunchKernelGGL(k_dsort_count, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l], plan.n_child[l],
+                           ticket + 2 * l);
+        ZK_KERNEL_CHECK(ctx);
+        ZK_TRY(scan_in_place(ctx, C[l], plan.n_child[l], bs));
+        hipLaunchKernelGGL(k_dsort_scatter, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, src_v, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l],
+                           plan.n_child[l], ticket + 2 * l + 1, dst_k, dst_v);
+        ZK_KERNEL_CHECK(ctx);
+        std::swap(src_k, dst_k); std::swap(src_v, dst_v);
+    }
+    *k_out = src_k; *v_out = src_v;
     return ZKPOR_OK;
 }
 
