@@ -1007,7 +1007,7 @@ class EndToEnd:
     the solve's ~100 narrow dependent launches do not queue behind full-size MSM grids."""
 
     def __init__(self, torch, zkpor, C, ctx, local_rank, pk, cir, dc0, d_in, inputs_host, D, n_commit, dev, blinding, abc0, workers, reserve_cus,
-                 solver_rows=True, prefetch=True, aux_masked=-1):
+                 solver_rows=True, prefetch=True, aux_masked=-1, sort_params=None):
         self.torch, self.zkpor, self.C, self.pk, self.cir, self.D, self.blinding = torch, zkpor, C, pk, cir, D, blinding
         self.d_in, self.inputs_host, self.prefetch, self.solver_rows = d_in, inputs_host, prefetch, solver_rows
         self.n_in = cir.n_public + cir.n_secret
@@ -1024,6 +1024,9 @@ class EndToEnd:
             wk["ctx"].set_param("tail_reserve_cus", self.reserve)
             if aux_masked >= 0:
                 wk["ctx"].set_param("tail_aux_masked", aux_masked)
+            for name_ in ("sort_grid", "sort_tile"):     # worker contexts take the main context's sort settings (--sort-grid / --sort-tile)
+                if sort_params and sort_params.get(name_, -1) >= 0:
+                    wk["ctx"].set_param(name_, sort_params[name_])
             if solver_rows:
                 wk["dc"].solver.set_abc_dev(wk["a"].data_ptr(), wk["b"].data_ptr(), wk["c"].data_ptr())
             if prefetch:
@@ -1296,8 +1299,8 @@ def main():
     ap.add_argument("--tables", type=int, default=4, help="fixed-base tables per key point (msm_tables; 1 = plain arrays): the default "
                     "4 holds the key as 4 interleaved tables (112 GB of the 288 GB at 2^26) and buys 12 digits of 22 bits instead of "
                     "13 of 20 at the same number of buckets — 6 %% fewer bucket additions (profiles/r02_tables.txt)")
-    ap.add_argument("--sort-block", type=int, default=-1, help="workgroup size of the onesweep radix sort under the main stream's kernels: 0 = rocPRIM's "
-                    "default (1024 threads), 256, 512; -1 = library default")
+    ap.add_argument("--sort-grid", type=int, default=-1, help="experiment: workgroups of the digit-stream sort's persistent kernels (sort_grid; library default: two per compute unit)")
+    ap.add_argument("--sort-tile", type=int, default=-1, help="experiment: entries a sort workgroup stages in LDS at a time (sort_tile: 1024 / 2048 / 4096)")
     ap.add_argument("--no-filter", action="store_true", help="experiment: accumulate B1 / B2 / K from the shared digit stream of w instead of the "
                     "per-array streams without the entries of absent points (context parameter msm_filter 0)")
     ap.add_argument("--filter-mode", type=int, default=-1, help="experiment: msm_filter 0 / 1 (filter beside A) / 2 (A waits for the filter)")
@@ -1402,8 +1405,10 @@ def main():
         ctx.set_param("msm_tail_chunk", args.tail_chunk)
     if args.no_reduce_scan:
         ctx.set_param("msm_reduce_scan", 0)
-    if args.sort_block >= 0:
-        ctx.set_param("sort_block", args.sort_block)
+    if args.sort_grid >= 0:
+        ctx.set_param("sort_grid", args.sort_grid)
+    if args.sort_tile >= 0:
+        ctx.set_param("sort_tile", args.sort_tile)
     if args.no_filter:
         ctx.set_param("msm_filter", 0)
     if args.no_ntt_fuse:
@@ -1710,7 +1715,8 @@ def main():
 
         def make(workers, reserve):
             return EndToEnd(torch, zkpor, C, ctx, local_rank, pk, circ["cir"], dc, circ["d_in"], circ["inp"], D, n_commit, dev, blinding, (a, b, c), workers, reserve,
-                            solver_rows=not args.no_solver_rows, prefetch=not args.no_prefetch, aux_masked=args.tail_aux_masked)
+                            solver_rows=not args.no_solver_rows, prefetch=not args.no_prefetch, aux_masked=args.tail_aux_masked,
+                            sort_params={"sort_grid": args.sort_grid, "sort_tile": args.sort_tile})
 
         def region(E, first, n, sink, tm_acc=None, upload=False, warm=1):
             E.run(first - 100, max(warm, len(E.wk)), None, None, upload)            # warm-up: at least one proof per worker
@@ -1783,6 +1789,9 @@ def main():
                     if len(parts) > 2:
                         for wk_ in Es.wk:
                             wk_["ctx"].set_param("tail_aux_masked", parts[2])
+                    for wk_ in Es.wk:       # fields 4 / 5 of a spec: the digit-stream sort's grid and LDS tile (csrc/sort.hip), 0 = library default
+                        wk_["ctx"].set_param("sort_grid", parts[3] if len(parts) > 3 else max(0, args.sort_grid))
+                        wk_["ctx"].set_param("sort_tile", parts[4] if len(parts) > 4 else max(0, args.sort_tile))
                     r_ = region(Es, 20001 + 1000 * k_, max(2, args.e2e_steps if args.e2e_steps > 0 else 4), e2e_proofs, None)
                     r_["same_wires"] = Es.same_wires(w) if args.scalars == "witness" else None
                     r_["spec"] = spec
@@ -1793,6 +1802,7 @@ def main():
                 except Exception as ex_:      # noqa: BLE001
                     sweep.append({"spec": spec, "note": f"failed: {ex_}"})
             ctx.set_param("tail_aux_masked", 0 if args.tail_aux_masked < 0 else args.tail_aux_masked)
+            ctx.set_param("sort_grid", max(0, args.sort_grid)); ctx.set_param("sort_tile", max(0, args.sort_tile))
             e2e["sweep"] = sweep
         e2e["next_proofs_hash_chains_prefetched"] = not args.no_prefetch
         e2e["poseidon_rows_written_by_the_solver"] = not args.no_solver_rows

@@ -211,6 +211,15 @@ int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n);
 int32_t zkpor_msm_g1(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[96]);
 int32_t zkpor_msm_g2(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[192]);
 int32_t zkpor_msm_g1_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[96]);
+/* Test-facing: steps 1 + 2 of every multi-exponentiation alone (csrc/sort.hip; gnark-crypto's partitionScalars + bucket walk, call site
+ * src/prover/prover/prover.go:269) — the signed-digit stream of n device-resident scalars, grouped by bucket, copied to HOST buffers of `cap`
+ * entries each: keys_out[j] = (digit position % piece) * 2^(c-1) + |digit| - 1, ascending; vals_out[j] = ((scalar index * tables + digit position /
+ * piece) << 1 | (digit negative)) | bit 30 if absent0[index] | bit 31 if absent1[index] (one byte per scalar, either may be NULL); zero digits are
+ * dropped.  info = { entries, entries whose scalar is not in absent0, ... not in absent1, c, digits per scalar W, piece, 2^(c-1), sort levels }.
+ * Window c: the context's "msm_window" or the automatic choice for (n, tables).  At most 2^27 scalars.  ZKPOR_E_ARG when cap is too small
+ * (info[0] says what is needed). */
+int32_t zkpor_msm_digits_dev(zkpor_ctx* ctx, const void* d_scalars, size_t n, int tables, const uint8_t* absent0, const uint8_t* absent1,
+                             uint32_t* keys_out, uint32_t* vals_out, size_t cap, uint64_t info[8]);
 int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[192]);
 
 /* sum of `count` Jacobian points on the HOST (no device needed): combines the partial results of a multi-GPU split of one

@@ -34,9 +34,9 @@ def pytest_configure(config):
 # ---- order of the GPU suite (one abort at test 65 of 497 erased 430 parity tests behind it) ----
 # 1. the oracle-parity files of the hot path (MSM, NTT, Poseidon, tree, Groth16 parity cases, a / b / c, solver, generators, key file),
 # 2. the rest of the single-context files, 3. the full-size cases, 4. everything that spawns threads, contexts or processes — last.
-_ORDER = ["test_msm_gpu", "test_ntt_gpu", "test_poseidon_gpu", "test_merkle_tree_gpu", "test_groth16_gpu", "test_r1cs_gpu", "test_solver_gpu",
+_ORDER = ["test_sort_gpu", "test_msm_gpu", "test_ntt_gpu", "test_poseidon_gpu", "test_merkle_tree_gpu", "test_groth16_gpu", "test_r1cs_gpu", "test_solver_gpu",
           "test_witgen_gpu", "test_keyfile_gpu", "test_decompress_gpu", "test_cex_gpu", "test_account_totals_gpu", "test_circuit_gpu",
-          "test_witness_host_gpu", "test_split_gpu", "test_fullsize_gpu", "test_prove_batch_gpu", "test_pipeline_gpu", "test_dispatcher_gpu",
+          "test_witness_host_gpu", "test_split_gpu", "test_fullsize_gpu", "test_headline_fullsize_gpu", "test_prove_batch_gpu", "test_pipeline_gpu", "test_dispatcher_gpu",
           "test_bench_gpu"]
 
 

@@ -447,6 +447,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "msm_filter_grid") { if (value < 0 || value > 2048) { ctx->err = "msm_filter_grid must be in [0,2048]"; return ZKPOR_E_ARG; } ctx->msm_filter_grid = (int)value; }
     else if (n == "ntt_fuse") { if (value < 0 || value > 1) { ctx->err = "ntt_fuse must be 0 or 1"; return ZKPOR_E_ARG; } ctx->ntt_fuse = (int)value; }
     else if (n == "sort_grid") { if (value < 0 || value > 8192) { ctx->err = "sort_grid must be in [0,8192] (0 = two workgroups per compute unit)"; return ZKPOR_E_ARG; } ctx->sort_grid = (int)value; }
+    else if (n == "sort_tile") { if (value != 0 && value != 1024 && value != 2048 && value != 4096) { ctx->err = "sort_tile must be 0 (4096), 1024, 2048 or 4096"; return ZKPOR_E_ARG; } ctx->sort_tile = (int)value; }
     else if (n == "sort_block") { if (value != 0 && value != 256 && value != 512) { ctx->err = "sort_block must be 0, 256 or 512"; return ZKPOR_E_ARG; } }   // rounds 3-5: the workgroup size of rocPRIM's onesweep; accepted and ignored since the sort is sort.hip's
     else if (n == "msm_reduce_scan") { if (value < 0 || value > 2) { ctx->err = "msm_reduce_scan must be 0, 1 or 2"; return ZKPOR_E_ARG; } ctx->msm_reduce_scan = (int)value; }
     else if (n == "msm_tail_chunk") { if (value != 0 && (value < 4 || value > 64)) { ctx->err = "msm_tail_chunk must be 0 or 4..64"; return ZKPOR_E_ARG; } ctx->msm_tail_chunk = (int)value; }
@@ -618,6 +619,50 @@ int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_sca
     G2XYZZ r;
     ZK_TRY(msm_dev<Fp2>(ctx, (const G2Affine*)d_points, (const Fr*)d_scalars, n, &r));
     store_jac_g2(r, out_jac);
+    return ZKPOR_OK;
+} ZK_ABI_CATCH
+
+int32_t zkpor_msm_digits_dev(zkpor_ctx* ctx, const void* d_scalars, size_t n, int tables, const uint8_t* absent0, const uint8_t* absent1, uint32_t* keys_out,
+                             uint32_t* vals_out, size_t cap, uint64_t info[8]) try {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx || !info || (n && !d_scalars) || (cap && (!keys_out || !vals_out))) return ZKPOR_E_ARG;
+    if (n >= ((size_t)1 << 27) || tables < 1 || tables > 8) { ctx->err = "msm_digits: at most 2^27 scalars, 1..8 tables"; return ZKPOR_E_ARG; }
+    const MsmCfg cfg = msm_cfg(ctx, n ? n : 1, tables);
+    size_t sort_temp = 0;
+    const size_t nwords = (n + 31) / 32;
+    WsPlan extra; extra.add<u32>(nwords + 1); extra.add<u32>(nwords + 1);
+    ZK_TRY(ws_reserve(ctx, digits_ws_bytes(ctx, n ? n : 1, cfg, &sort_temp) + extra.total));
+    // the absence bitmaps (one BYTE per scalar from the caller, as zkpor_pk_set_consts takes its infinity masks) packed to the device's bit form
+    u32* d_abs[2] = {nullptr, nullptr};
+    const uint8_t* src[2] = {absent0, absent1};
+    for (int g = 0; g < 2; ++g) {
+        if (!src[g]) continue;
+        std::vector<u32> bits(nwords + 1, 0u);
+        for (size_t i = 0; i < n; ++i) if (src[g][i]) bits[i >> 5] |= 1u << (i & 31);
+        d_abs[g] = ws_alloc<u32>(ctx, nwords + 1);
+        ZK_TRY(h2d_sync(ctx, d_abs[g], bits.data(), (nwords + 1) * sizeof(u32)));
+    }
+    DigitStream ds;
+    StreamFilter filt; filt.absent[0] = d_abs[0]; filt.absent[1] = d_abs[1];
+    info[0] = info[1] = info[2] = 0;
+    if (n) {
+        // the shared stream only (no filter outputs): the sizes of the per-array streams are counted by the decomposition all the same
+        size_t cap_n = n * (size_t)cfg.W;
+        u32 *k0 = ws_alloc<u32>(ctx, cap_n), *k1 = ws_alloc<u32>(ctx, cap_n), *v0 = ws_alloc<u32>(ctx, cap_n), *v1 = ws_alloc<u32>(ctx, cap_n);
+        u32* counter = ws_alloc<u32>(ctx, 64);
+        char* temp = ws_alloc<char>(ctx, sort_temp + 256);
+        if (!k0 || !k1 || !v0 || !v1 || !counter || !temp) { ctx->err = "msm_digits: workspace too small"; return ZKPOR_E_OOM; }
+        u32 Ms[3] = {0, 0, 0};
+        ZK_TRY(digit_sort(ctx, (const Fr*)d_scalars, (u32)n, cfg, digit_sort_plan(cfg), k0, v0, k1, v1, counter, temp, d_abs[0], d_abs[1], Ms, &ds.keys, &ds.vals));
+        info[0] = Ms[0]; info[1] = Ms[1]; info[2] = Ms[2];
+        if (Ms[0] > cap) { ctx->err = "msm_digits: the stream has " + std::to_string(Ms[0]) + " entries, the output buffers hold " + std::to_string(cap); return ZKPOR_E_ARG; }
+        if (Ms[0]) {
+            ZK_HIP(ctx, hipMemcpyAsync(keys_out, ds.keys, (size_t)Ms[0] * 4, hipMemcpyDeviceToHost, ctx->stream));
+            ZK_HIP(ctx, hipMemcpyAsync(vals_out, ds.vals, (size_t)Ms[0] * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    info[3] = (uint64_t)cfg.c; info[4] = (uint64_t)cfg.W; info[5] = (uint64_t)cfg.piece; info[6] = cfg.bpw; info[7] = (uint64_t)digit_sort_plan(cfg).nlev;
     return ZKPOR_OK;
 } ZK_ABI_CATCH
 

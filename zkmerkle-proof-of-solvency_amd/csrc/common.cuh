@@ -64,6 +64,7 @@ struct zkpor_ctx {
     int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 256: one per CU — bandwidth, not wave slots)
     int ntt_fuse = 1;                // computeH: the two passes over the lowest field (inverse DIF last, coset DIT first) in one kernel (ntt.hip k_ntt_mid29)
     int sort_grid = 0;               // workgroups of the digit-stream sort's persistent kernels (sort.hip): 0 = two per compute unit
+    int sort_tile = 0;               // entries a sort workgroup stages in LDS at a time: 0 = 4096 (40 KB of LDS), 2048 (24 KB), 1024 (16 KB)
     int aux_priority = 0;            // 1: the auxiliary (digit-stream) HIP stream is created with the highest stream priority
     int solver_defer_checks = 1;     // with zkpor_solver_set_abc_dev: the run leaves its CHECK instructions (assertions) out and zkpor_solver_eval_abc_dev verifies a x b = c on EVERY row; 0 = the run executes them
     int64_t solver_tree_from = 1024; // levels from this many generic instructions on: the divisions of a workgroup share one inversion, long constraints go to k_solve_long

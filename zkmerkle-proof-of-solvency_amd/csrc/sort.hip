@@ -21,10 +21,12 @@
 namespace zk {
 
 namespace {
-constexpr u32 DS_THREADS = 256, DS_TILE = 4096, DS_MAXR = 9, DS_NB = 1u << DS_MAXR;
-constexpr u32 DS_CHUNK_TILES = 16;                 // entries per ticket of a level >= 1 kernel: 16 tiles
+constexpr u32 DS_THREADS = 256, DS_MAXR = 9, DS_NB = 1u << DS_MAXR;
+constexpr u32 DS_CHUNK = 1u << 16;                 // entries per ticket of a level >= 1 kernel
 constexpr u32 DS_SCALARS_PER_TICKET = 2048;        // scalars per ticket of the level-0 kernels
-constexpr u32 DS_DW = 16;                          // digits of a scalar per level-0 tile: 256 scalars x 16 digits = one LDS tile
+// TILE = the entries a workgroup stages in LDS at a time ("sort_tile": 4096 / 2048 / 1024 -> 40 / 24 / 16 KB of LDS per workgroup).  The footprint
+// decides what the sort displaces on a compute unit it shares with the main stream's kernels (four 36 KB NTT tiles, three 35 KB level-1 workgroups);
+// a smaller tile writes shorter runs.  A level-0 tile = 256 scalars x TILE / 256 digits.
 
 // low c bits of s, then s >>= c (static register indexing only: no scratch)
 ZK_D u32 take_digit(Fr& s, int c) {
@@ -37,15 +39,17 @@ ZK_D u32 take_digit(Fr& s, int c) {
 
 struct DsCfg { int c, W, tables, piece; u32 bpw; };
 
+template <u32 TILE>
 struct DsShared {
-    u32 sk[DS_TILE], sv[DS_TILE];
+    u32 sk[TILE], sv[TILE];
     u32 cnt[DS_NB], cur[DS_NB], lpre[DS_NB], gbase[DS_NB];
     u32 wsum[4], misc[8];
 };
 
 // after a count phase: reserve this tile's run in every child (one global atomic each), the tile-local exclusive prefix of the counts, and the
 // placing cursors.  nb <= 512 counters, two per thread.  Leaves cnt[] zeroed for the next tile.
-ZK_D void ds_reserve(DsShared& S, u32 nb, u32* __restrict__ cursor, u32 child0, u32 n_child) {
+template <class SH>
+ZK_D void ds_reserve(SH& S, u32 nb, u32* __restrict__ cursor, u32 child0, u32 n_child) {
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const u32 i0 = 2u * t, i1 = 2u * t + 1u;
     const u32 a = i0 < nb ? S.cnt[i0] : 0u, b = i1 < nb ? S.cnt[i1] : 0u;
@@ -68,7 +72,8 @@ ZK_D void ds_reserve(DsShared& S, u32 nb, u32* __restrict__ cursor, u32 child0, 
 
 // the staged tile (sk / sv hold `len` entries grouped by child, child d at [lpre[d], lpre[d] + count)) -> its reserved runs: consecutive lanes write
 // consecutive addresses inside a run
-ZK_D void ds_write_out(const DsShared& S, u32 len, int shift, u32 mask, u32* __restrict__ out_k, u32* __restrict__ out_v) {
+template <class SH>
+ZK_D void ds_write_out(const SH& S, u32 len, int shift, u32 mask, u32* __restrict__ out_k, u32* __restrict__ out_v) {
     for (u32 j = threadIdx.x; j < len; j += DS_THREADS) {
         const u32 k = S.sk[j];
         const u32 d = (k >> shift) & mask;
@@ -134,10 +139,12 @@ __global__ __launch_bounds__(DS_THREADS) void k_dsort_count0(const Fr* __restric
 }
 
 // scatter: C0 holds the children's start offsets on entry and their end offsets on exit
+template <u32 TILE>
 __global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter0(const Fr* __restrict__ scalars, u32 n, DsCfg cfg, int shift0, u32 nb0, u32* __restrict__ C0,
                                                                u32* __restrict__ ticket, const u32* __restrict__ absent0, const u32* __restrict__ absent1,
                                                                u32* __restrict__ out_k, u32* __restrict__ out_v) {
-    __shared__ DsShared S;
+    __shared__ DsShared<TILE> S;
+    constexpr int DS_DW = (int)(TILE / DS_THREADS);
     for (u32 i = threadIdx.x; i < DS_NB; i += DS_THREADS) S.cnt[i] = 0u;
     const u32 mask = 0xffffffffu;      // level 0: the child IS key >> shift0
     for (;;) {
@@ -156,8 +163,8 @@ __global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter0(const Fr* __restr
                 if (absent0 && ((absent0[word] >> bit) & 1u)) flags |= VAL_ABSENT0;
                 if (absent1 && ((absent1[word] >> bit) & 1u)) flags |= VAL_ABSENT1;
             }
-            for (int w0 = 0; w0 < cfg.W; w0 += (int)DS_DW) {
-                const int nd = cfg.W - w0 < (int)DS_DW ? cfg.W - w0 : (int)DS_DW;
+            for (int w0 = 0; w0 < cfg.W; w0 += DS_DW) {
+                const int nd = cfg.W - w0 < DS_DW ? cfg.W - w0 : DS_DW;
                 // pass 1 over this tile's digits: count per child (on a copy of the running state)
                 u32 mine = 0;
                 if (live) {
@@ -184,7 +191,8 @@ __global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter0(const Fr* __restr
 
 // ------------------------------------------------------------------------------------------------ levels >= 1
 // first index s in [0, n_par) with ends[s] > pos (ends ascending, ends[n_par - 1] > pos): a 256-ary search, one probe per thread and round
-ZK_D u32 ds_find_seg(DsShared& S, const u32* __restrict__ ends, u32 n_par, u32 pos) {
+template <class SH>
+ZK_D u32 ds_find_seg(SH& S, const u32* __restrict__ ends, u32 n_par, u32 pos) {
     u32 lo = 0, hi = n_par;
     const u32 t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     for (;;) {
@@ -211,16 +219,16 @@ ZK_D u32 ds_find_seg(DsShared& S, const u32* __restrict__ ends, u32 n_par, u32 p
 // counts of one level: C[key >> shift] over all M entries.  ends = the previous level's cursor array (= its children's end offsets), n_par of them.
 __global__ __launch_bounds__(DS_THREADS) void k_dsort_count(const u32* __restrict__ keys, u32 M, int shift, int r, const u32* __restrict__ ends, u32 n_par,
                                                             u32* __restrict__ C, u32 n_child, u32* __restrict__ ticket) {
-    __shared__ DsShared S;
+    __shared__ DsShared<64> S;      // counters only: nothing is staged
     const u32 nb = 1u << r, mask = nb - 1u;
     for (u32 i = threadIdx.x; i < DS_NB; i += DS_THREADS) S.cnt[i] = 0u;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) S.misc[0] = atomicAdd(ticket, 1u);
         __syncthreads();
-        u32 pos = S.misc[0] * (DS_CHUNK_TILES * DS_TILE);
+        u32 pos = S.misc[0] * DS_CHUNK;
         if (pos >= M) break;
-        const u32 cend = (M - pos > DS_CHUNK_TILES * DS_TILE) ? pos + DS_CHUNK_TILES * DS_TILE : M;
+        const u32 cend = (M - pos > DS_CHUNK) ? pos + DS_CHUNK : M;
         while (pos < cend) {
             const u32 seg = ds_find_seg(S, ends, n_par, pos);
             const u32 seg_end = ends[seg];
@@ -237,25 +245,26 @@ __global__ __launch_bounds__(DS_THREADS) void k_dsort_count(const u32* __restric
     }
 }
 
+template <u32 TILE>
 __global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter(const u32* __restrict__ keys, const u32* __restrict__ vals, u32 M, int shift, int r,
                                                               const u32* __restrict__ ends, u32 n_par, u32* __restrict__ C, u32 n_child,
                                                               u32* __restrict__ ticket, u32* __restrict__ out_k, u32* __restrict__ out_v) {
-    __shared__ DsShared S;
+    __shared__ DsShared<TILE> S;
     const u32 nb = 1u << r, mask = nb - 1u;
     for (u32 i = threadIdx.x; i < DS_NB; i += DS_THREADS) S.cnt[i] = 0u;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) S.misc[0] = atomicAdd(ticket, 1u);
         __syncthreads();
-        u32 pos = S.misc[0] * (DS_CHUNK_TILES * DS_TILE);
+        u32 pos = S.misc[0] * DS_CHUNK;
         if (pos >= M) break;
-        const u32 cend = (M - pos > DS_CHUNK_TILES * DS_TILE) ? pos + DS_CHUNK_TILES * DS_TILE : M;
+        const u32 cend = (M - pos > DS_CHUNK) ? pos + DS_CHUNK : M;
         u32 seg = 0, seg_end = 0;
         while (pos < cend) {
             if (pos >= seg_end) { seg = ds_find_seg(S, ends, n_par, pos); seg_end = ends[seg]; }
             u32 len = seg_end - pos;
             if (len > cend - pos) len = cend - pos;
-            if (len > DS_TILE) len = DS_TILE;
+            if (len > TILE) len = TILE;
 #pragma unroll 4
             for (u32 j = threadIdx.x; j < len; j += DS_THREADS) atomicAdd(&S.cnt[(keys[pos + j] >> shift) & mask], 1u);
             __syncthreads();
@@ -377,6 +386,7 @@ int32_t digit_sort(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg
         ZK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
         grid = 2 * prop.multiProcessorCount;      // two 256-thread workgroups per compute unit: bandwidth, not wave slots
     }
+    const int tile = ctx->sort_tile == 1024 || ctx->sort_tile == 2048 ? ctx->sort_tile : 4096;
     u32* C[4];
     for (int l = 0; l < plan.nlev; ++l) C[l] = (u32*)(temp + plan.off_C[l]);
     u32* bs = (u32*)(temp + plan.off_bs);
@@ -401,19 +411,22 @@ int32_t digit_sort(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg
         ZK_TRY(scan_in_place(ctx, C[0], plan.n_child[0], bs));
         const u32 tickets0 = (n + DS_SCALARS_PER_TICKET - 1u) / DS_SCALARS_PER_TICKET;
         const u32 g0 = tickets0 < (u32)grid ? tickets0 : (u32)grid;
-        hipLaunchKernelGGL(k_dsort_scatter0, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
+        if (tile == 1024) hipLaunchKernelGGL(k_dsort_scatter0<1024>, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
+        else if (tile == 2048) hipLaunchKernelGGL(k_dsort_scatter0<2048>, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
+        else hipLaunchKernelGGL(k_dsort_scatter0<4096>, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
         ZK_KERNEL_CHECK(ctx);
     }
     u32 *src_k = kB, *src_v = vB, *dst_k = kA, *dst_v = vA;
-    const u32 chunks = (M + DS_CHUNK_TILES * DS_TILE - 1u) / (DS_CHUNK_TILES * DS_TILE);
+    const u32 chunks = (M + DS_CHUNK - 1u) / DS_CHUNK;
     const u32 g = chunks < (u32)grid ? chunks : (u32)grid;
     for (int l = 1; l < plan.nlev; ++l) {
         hipLaunchKernelGGL(k_dsort_count, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l], plan.n_child[l],
                            ticket + 2 * l);
         ZK_KERNEL_CHECK(ctx);
         ZK_TRY(scan_in_place(ctx, C[l], plan.n_child[l], bs));
-        hipLaunchKernelGGL(k_dsort_scatter, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, src_v, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l],
-                           plan.n_child[l], ticket + 2 * l + 1, dst_k, dst_v);
+        if (tile == 1024) hipLaunchKernelGGL(k_dsort_scatter<1024>, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, src_v, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l], plan.n_child[l], ticket + 2 * l + 1, dst_k, dst_v);
+        else if (tile == 2048) hipLaunchKernelGGL(k_dsort_scatter<2048>, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, src_v, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l], plan.n_child[l], ticket + 2 * l + 1, dst_k, dst_v);
+        else hipLaunchKernelGGL(k_dsort_scatter<4096>, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, src_v, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l], plan.n_child[l], ticket + 2 * l + 1, dst_k, dst_v);
         ZK_KERNEL_CHECK(ctx);
         std::swap(src_k, dst_k); std::swap(src_v, dst_v);
     }

@@ -251,6 +251,20 @@ class Context:
         self._ck(self.lib.zkpor_msm_g2_dev(self.h, ctypes.c_void_p(d_points), ctypes.c_void_p(d_scalars), ctypes.c_size_t(n), _p(out)))
         return out
 
+    def msm_digits_dev(self, d_scalars, n, tables=1, absent0=None, absent1=None, cap=None):
+        """test-facing (zkpor_msm_digits_dev): the signed-digit stream of n resident scalars grouped by bucket -> (keys, vals, info dict)"""
+        info = np.zeros(8, dtype=np.uint64)
+        a0 = None if absent0 is None else np.ascontiguousarray(absent0, dtype=np.uint8)
+        a1 = None if absent1 is None else np.ascontiguousarray(absent1, dtype=np.uint8)
+        if cap is None:
+            cap = n * 130
+        keys = np.empty(cap, dtype=np.uint32); vals = np.empty(cap, dtype=np.uint32)
+        self._ck(self.lib.zkpor_msm_digits_dev(self.h, ctypes.c_void_p(d_scalars), ctypes.c_size_t(n), ctypes.c_int(tables), _p(a0) if a0 is not None else None,
+                                                _p(a1) if a1 is not None else None, _p(keys), _p(vals), ctypes.c_size_t(cap), _p(info)))
+        m = int(info[0])
+        names = ("entries", "entries_group0", "entries_group1", "c", "W", "piece", "bpw", "levels")
+        return keys[:m], vals[:m], {k: int(v) for k, v in zip(names, info)}
+
     # ---- NTT / H ----
     def fft(self, a, log2n, inverse=False, decimation=1, on_coset=False):
         a = _u64(a).copy()
