@@ -765,7 +765,7 @@ def poseidon_tree_leg(ctx, log2_leaves=27, depth=28):
             "cex_commitments": cex,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "valu_issue": poseidon_valu_issue(ms, n),
-                         "note": "width-3 Poseidon permutation per node (~370 field products): VALU-bound like the prove tail"}}
+                         "note": "width-3 Poseidon permutation per node (604 field products in the optimised form, csrc/poseidon.hip): VALU-bound like the prove tail"}}
 
 
 def poseidon_valu_issue(build_ms, leaves):

@@ -143,6 +143,37 @@ def test_compute_h_fused_passes_equal_separate_passes(zk, log2d):
         assert np.array_equal(fused, O.compute_h(a, b, c, log2d))
 
 
+@pytest.mark.parametrize("log2n", [9, 13, 17, 18, 20])
+def test_generated_twiddles_equal_tabulated_ones(zk, log2n):
+    """"ntt_twiddles": the inter-pass twiddles w^((l k) << s0) as the product of two half-table entries (one more field product per element) instead of a
+    read from the field's table (2 GiB per direction for the highest field at 2^26: 15 GB of the 86 GB a computeH moved).  Every mode of the
+    transform and computeH with its fused kernels, generated everywhere (2) and where the table exceeds 16 MiB (1: from 2^20 up): bit-identical"""
+    a = O.fr_random(2000 + log2n, 1 << log2n)
+    n = (1 << log2n) - 5
+    ha = O.fr_random(71, n); hb = O.fr_random(72, n); hc = O.fr_mul(ha, hb)
+    want = {}
+    for mode in (0, 2, 1):
+        zk.set_param("ntt_twiddles", mode)
+        try:
+            for inverse in (False, True):
+                for dec in (O.DIT, O.DIF):
+                    for coset in (False, True):
+                        got = zk.fft(a, log2n, inverse, dec, coset)
+                        if mode == 0:
+                            want[(inverse, dec, coset)] = got
+                        else:
+                            assert np.array_equal(got, want[(inverse, dec, coset)]), (mode, inverse, dec, coset)
+            h = zk.compute_h(ha, hb, hc, log2n)
+            if mode == 0:
+                want["h"] = h
+                if log2n <= 17:
+                    assert np.array_equal(h, O.compute_h(ha, hb, hc, log2n))
+            else:
+                assert np.array_equal(h, want["h"]), mode
+        finally:
+            zk.set_param("ntt_twiddles", 0)
+
+
 def test_compute_h_zero_and_ragged(zk):
     # n_constraints = 0..1: zero padding path; h of the zero polynomial is zero
     z = np.zeros((1, 4), np.uint64)

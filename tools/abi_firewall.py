@@ -13,6 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = sorted(glob.glob(os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd", "csrc", "*.hip")))
 HEAD = re.compile(r"^int32_t zkpor_\w+\(")
+CLOSE = re.compile(r"^\} ZK_ABI_CATCH(_IN\(.*\))?\s*$")      # ZK_ABI_CATCH_IN(ctx): the text goes into that context (common.cuh)
 
 
 def transform(lines):
@@ -38,7 +39,7 @@ def transform(lines):
                 raise SystemExit(f"cannot parse the body opener of {name}: {line!r}")
             wrapped = line.rstrip().endswith("try {")
             e = j + 1
-            while out[e].rstrip("\n") not in ("}", "} ZK_ABI_CATCH"):
+            while out[e].rstrip("\n") != "}" and not CLOSE.match(out[e]):
                 e += 1
             if not wrapped:
                 missing.append(name)

@@ -2,7 +2,8 @@
 # round 6: how much of a compute unit may the digit-stream sort take?  grid (workgroups) x LDS tile, two workers / 32 reserved, in one process
 O=gpurun_out/r06d
 mkdir -p $O
-timeout 1200 python3 -X faulthandler bench.py --timed-only --steps 6 --warmup 2 --e2e-steps 6 --e2e-sweep "2:32:0:256:4096,2:32:0:128:4096,2:32:0:256:2048,2:32:0:512:2048,2:32:0:256:1024,2:32:0:512:1024,2:32:0:1024:1024,2:32:0:64:4096,1:0:0:256:2048,1:0:0:128:4096" > $O/bench.json 2> $O/bench.err; echo "rc=$?"; tail -5 $O/bench.err | cut -c1-300
+ZKPOR_ABORT_TRACE=$O/native_trace.log timeout 1200 python3 -X faulthandler bench.py --timed-only --steps 6 --warmup 2 --e2e-steps 6 --e2e-sweep "2:32:0:256:4096,2:32:0:128:4096,2:32:0:256:2048,2:32:0:512:2048,2:32:0:256:1024,2:32:0:512:1024,2:32:0:1024:1024,2:32:0:64:4096,1:0:0:256:2048,1:0:0:128:4096" > $O/bench.json 2> $O/bench.err; echo "rc=$?"; tail -5 $O/bench.err | cut -c1-300
+[ -s $O/native_trace.log ] && head -60 $O/native_trace.log
 python - <<'PY'
 import json
 d=json.load(open("gpurun_out/r06d/bench.json"))

@@ -18,6 +18,13 @@ using namespace zk;
 namespace zk {
 static thread_local char g_abi_exception[200] = {0};
 void abi_exception(const char* what) noexcept { snprintf(g_abi_exception, sizeof g_abi_exception, "%s", what ? what : "?"); }
+void abi_exception_clear() noexcept { g_abi_exception[0] = 0; }
+void abi_exception_in(zkpor_ctx* ctx, const char* what) noexcept {
+    if (ctx) {
+        try { ctx->err = std::string("C++ exception stopped at the ABI: ") + (what ? what : "?"); return; } catch (...) {}   // no memory for the text either: the thread's buffer
+    }
+    abi_exception(what);
+}
 void pos_tables_free(zkpor_ctx* ctx);
 int32_t ensure_pinned(zkpor_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->pinned_cap) return ZKPOR_OK;
@@ -125,13 +132,15 @@ void bounce_free(zkpor_ctx* ctx) {
 // that is not mine" (GPUTEST_r04: a silent rc 134 inside zkpor_prove_tail).  Async-signal-safe enough for a process that is dying anyway:
 // backtrace() is pre-loaded at install time, the symbols go straight to fd 2.  The previous handler (faulthandler's) runs afterwards.
 namespace {
-struct sigaction g_prev_abrt;
+struct sigaction g_prev_abrt, g_prev_segv, g_prev_bus;
 bool g_abort_trace_on = false;
 int g_abort_fd = 2;     // ZKPOR_ABORT_TRACE=1: stderr; any other value: a file of that name (a test runner that captures fd 2 loses it with the process)
 void abort_trace(int sig) {
     const int fd = g_abort_fd;
-    static const char head[] = "\n[zkpor] SIGABRT raised on thread ";
-    (void)!write(fd, head, sizeof head - 1);
+    static const char head_a[] = "\n[zkpor] SIGABRT raised on thread ", head_s[] = "\n[zkpor] SIGSEGV raised on thread ", head_b[] = "\n[zkpor] SIGBUS raised on thread ";
+    if (sig == SIGSEGV) (void)!write(fd, head_s, sizeof head_s - 1);
+    else if (sig == SIGBUS) (void)!write(fd, head_b, sizeof head_b - 1);
+    else (void)!write(fd, head_a, sizeof head_a - 1);
     char name[32] = {0};
     (void)prctl(PR_GET_NAME, name, 0, 0, 0);
     (void)!write(fd, name, strlen(name));
@@ -140,7 +149,7 @@ void abort_trace(int sig) {
     void* fr[96];
     const int n = backtrace(fr, 96);
     backtrace_symbols_fd(fr, n, fd);
-    (void)sigaction(sig, &g_prev_abrt, nullptr);     // hand over to whoever was there before (Python's faulthandler, else the default action)
+    (void)sigaction(sig, sig == SIGSEGV ? &g_prev_segv : sig == SIGBUS ? &g_prev_bus : &g_prev_abrt, nullptr);     // hand over to whoever was there before (Python's faulthandler, else the default action)
     (void)raise(sig);
 }
 }  // namespace
@@ -161,6 +170,12 @@ void abort_trace_install() {
         sigemptyset(&sa.sa_mask);
         sa.sa_flags = SA_NODEFER;
         g_abort_trace_on = sigaction(SIGABRT, &sa, &g_prev_abrt) == 0;
+        // round 6: a memory fault of a HOST thread inside the library or the runtime as well (the masked-stream crash of round 5 was one: "Segmentation
+        // fault" inside zkpor_prove_tail_dev and nothing else).  Installed BEFORE Python's faulthandler only if the library is loaded first; either way the
+        // previous handler runs after the stack is out.
+        sa.sa_flags = SA_NODEFER | SA_ONSTACK;
+        (void)sigaction(SIGSEGV, &sa, &g_prev_segv);
+        (void)sigaction(SIGBUS, &sa, &g_prev_bus);
     });
 }
 
@@ -196,7 +211,32 @@ void GpuTurn::release() {
     held = false;
 }
 
+// CU-masked streams are never handed back to the runtime: a context (or a solver) that goes away parks them in a process-wide pool and the next one that
+// asks for the same (device, reserve) takes them from there.  Round 5's crash came with the SECOND generation of masked streams of a process; round 6
+// still met it once when a worker context was destroyed and created again (a host SIGSEGV inside zkpor_prove_tail_dev, gpurun_out/r06d) although no
+// stream of a LIVE context was destroyed any more.  hipStreamDestroy of a masked stream is the one call both runs had in common; the pool removes it, and
+// bounds the hardware queues a process ever creates by the most it uses at one time.
+namespace {
+struct PooledStream { int device, reserve; hipStream_t st; };
+std::mutex g_stream_pool_mu;
+std::vector<PooledStream> g_stream_pool;
+}  // namespace
+void stream_release_own_queue(int device, hipStream_t st, int reserve_cus) {
+    if (!st) return;
+    (void)hipStreamSynchronize(st);
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    try { g_stream_pool.push_back({device, reserve_cus, st}); } catch (...) { /* out of host memory: the stream is leaked, not destroyed */ }
+}
 int32_t stream_create_own_queue(zkpor_ctx* ctx, hipStream_t* out, int reserve_cus) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        for (size_t i = 0; i < g_stream_pool.size(); ++i)
+            if (g_stream_pool[i].device == ctx->device && g_stream_pool[i].reserve == reserve_cus) {
+                *out = g_stream_pool[i].st;
+                g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+                return ZKPOR_OK;
+            }
+    }
     hipDeviceProp_t prop;
     ZK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
     const int cus = prop.multiProcessorCount;
@@ -355,13 +395,13 @@ int32_t zkpor_dev_fr_mul(zkpor_ctx* ctx, void* d_out, const void* d_a, const voi
     hipLaunchKernelGGL(k_fr_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_out, (const Fr*)d_a, (const Fr*)d_b, n);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_dev_copy(zkpor_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (bytes && (!d_dst || !d_src))) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_init(int device, void* stream, zkpor_ctx** out) try {
     if (!out) return ZKPOR_E_ARG;
@@ -407,8 +447,8 @@ void zkpor_destroy(zkpor_ctx* ctx) try {
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-    for (auto& ts : ctx->tail_sets) { (void)hipStreamDestroy(ts.main); (void)hipStreamDestroy(ts.aux); }
-    if (ctx->tail_aux_free) (void)hipStreamDestroy(ctx->tail_aux_free);
+    for (auto& ts : ctx->tail_sets) { zk::stream_release_own_queue(ctx->device, ts.main, ts.reserve); zk::stream_release_own_queue(ctx->device, ts.aux, ts.reserve); }
+    zk::stream_release_own_queue(ctx->device, ctx->tail_aux_free, 0);
     for (hipStream_t st : ctx->retired_streams) (void)hipStreamDestroy(st);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -428,7 +468,7 @@ int32_t zkpor_sync(zkpor_ctx* ctx) try {
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 uint32_t zkpor_abi_version(void) { return ZKPOR_ABI_VERSION; }
 
@@ -445,6 +485,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "ntt_tile_log") { if (value < 9 || value > 12) { ctx->err = "ntt_tile_log must be in [9,12]"; return ZKPOR_E_ARG; } ctx->ntt_tile_log = (int)value; }
     else if (n == "msm_filter") { if (value < 0 || value > 2) { ctx->err = "msm_filter must be 0, 1 or 2"; return ZKPOR_E_ARG; } ctx->msm_filter = (int)value; }
     else if (n == "msm_filter_grid") { if (value < 0 || value > 2048) { ctx->err = "msm_filter_grid must be in [0,2048]"; return ZKPOR_E_ARG; } ctx->msm_filter_grid = (int)value; }
+    else if (n == "ntt_twiddles") { if (value < 0 || value > 2) { ctx->err = "ntt_twiddles must be 0 (tables), 1 (generated where the table exceeds 16 MiB) or 2 (generated everywhere)"; return ZKPOR_E_ARG; } ctx->ntt_twiddles = (int)value; }
     else if (n == "ntt_fuse") { if (value < 0 || value > 1) { ctx->err = "ntt_fuse must be 0 or 1"; return ZKPOR_E_ARG; } ctx->ntt_fuse = (int)value; }
     else if (n == "sort_grid") { if (value < 0 || value > 8192) { ctx->err = "sort_grid must be in [0,8192] (0 = two workgroups per compute unit)"; return ZKPOR_E_ARG; } ctx->sort_grid = (int)value; }
     else if (n == "sort_tile") { if (value != 0 && value != 1024 && value != 2048 && value != 4096) { ctx->err = "sort_tile must be 0 (4096), 1024, 2048 or 4096"; return ZKPOR_E_ARG; } ctx->sort_tile = (int)value; }
@@ -500,7 +541,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "poseidon_carry_idx") ctx->pos_carry = (int)value;
     else { ctx->err = "unknown parameter " + n; return ZKPOR_E_ARG; }
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 double zkpor_phase_ms(zkpor_ctx* ctx, const char* name, uint64_t* calls) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -516,7 +557,7 @@ int32_t zkpor_stat(zkpor_ctx* ctx, const char* name, uint64_t* value) try {
     auto it = ctx->stats.find(name);
     *value = it == ctx->stats.end() ? 0 : it->second;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 void zkpor_phase_reset(zkpor_ctx* ctx) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return;
@@ -528,20 +569,20 @@ int32_t zkpor_dev_alloc(zkpor_ctx* ctx, size_t bytes, void** out) try {
     ZK_ENTER(ctx->device);
     ZK_HIP(ctx, hipMalloc(out, bytes ? bytes : 1));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_dev_free(zkpor_ctx* ctx, void* p) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZK_HIP(ctx, hipFree(p));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_dev_upload(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_TRY(zk::h2d_sync(ctx, dst, src, bytes));      // complete on return: the host buffer is not retained
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 // asynchronous upload: returns once the copy is queued; the host buffer must stay valid (and should be pinned, see
 // zkpor_host_register) until zkpor_sync.  Lets the next proof's witness cross PCIe under the current proof's kernels.
 int32_t zkpor_dev_upload_async(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) try {
@@ -549,7 +590,7 @@ int32_t zkpor_dev_upload_async(zkpor_ctx* ctx, void* dst, const void* src, size_
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 // page-lock a caller-owned host range (a Go slice's backing array) so uploads from it run at PCIe rate and truly
 // asynchronously; the caller unregisters it before freeing the memory
 int32_t zkpor_host_register(zkpor_ctx* ctx, void* ptr, size_t bytes) try {
@@ -557,20 +598,20 @@ int32_t zkpor_host_register(zkpor_ctx* ctx, void* ptr, size_t bytes) try {
     if (!ctx || !ptr || !bytes) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_host_unregister(zkpor_ctx* ctx, void* ptr) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !ptr) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipHostUnregister(ptr));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_dev_download(zkpor_ctx* ctx, void* dst, const void* src, size_t bytes) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_dev_fill_fr(zkpor_ctx* ctx, void* d_out, size_t n, uint64_t seed, int kind) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (!d_out && n)) return ZKPOR_E_ARG;
@@ -578,7 +619,7 @@ int32_t zkpor_dev_fill_fr(zkpor_ctx* ctx, void* d_out, size_t n, uint64_t seed, 
     hipLaunchKernelGGL(k_fill_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_out, n, seed, kind);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 // ---- generic MSM ----
 static void store_jac_g1(const G1XYZZ& r, uint8_t* out) {
@@ -612,7 +653,7 @@ int32_t zkpor_msm_g1_dev(zkpor_ctx* ctx, const void* d_points, const void* d_sca
     ZK_TRY(msm_dev<Fp>(ctx, (const G1Affine*)d_points, (const Fr*)d_scalars, n, &r));
     store_jac_g1(r, out_jac);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, uint8_t out_jac[192]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out_jac || (n && (!d_points || !d_scalars))) return ZKPOR_E_ARG;
@@ -620,7 +661,7 @@ int32_t zkpor_msm_g2_dev(zkpor_ctx* ctx, const void* d_points, const void* d_sca
     ZK_TRY(msm_dev<Fp2>(ctx, (const G2Affine*)d_points, (const Fr*)d_scalars, n, &r));
     store_jac_g2(r, out_jac);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_msm_digits_dev(zkpor_ctx* ctx, const void* d_scalars, size_t n, int tables, const uint8_t* absent0, const uint8_t* absent1, uint32_t* keys_out,
                              uint32_t* vals_out, size_t cap, uint64_t info[8]) try {
@@ -664,7 +705,7 @@ int32_t zkpor_msm_digits_dev(zkpor_ctx* ctx, const void* d_scalars, size_t n, in
     }
     info[3] = (uint64_t)cfg.c; info[4] = (uint64_t)cfg.W; info[5] = (uint64_t)cfg.piece; info[6] = cfg.bpw; info[7] = (uint64_t)digit_sort_plan(cfg).nlev;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_msm_g1(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[96]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -673,7 +714,7 @@ int32_t zkpor_msm_g1(zkpor_ctx* ctx, const void* points_affine, const uint64_t* 
     ZK_TRY(msm_host<Fp>(ctx, points_affine, scalars, n, &r));
     store_jac_g1(r, out_jac);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_msm_g2(zkpor_ctx* ctx, const void* points_affine, const uint64_t* scalars, size_t n, uint8_t out_jac[192]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out_jac || (n && (!points_affine || !scalars))) return ZKPOR_E_ARG;
@@ -681,6 +722,6 @@ int32_t zkpor_msm_g2(zkpor_ctx* ctx, const void* points_affine, const uint64_t* 
     ZK_TRY(msm_host<Fp2>(ctx, points_affine, scalars, n, &r));
     store_jac_g2(r, out_jac);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 }  // extern "C"

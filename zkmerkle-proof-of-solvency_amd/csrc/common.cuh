@@ -62,6 +62,7 @@ struct zkpor_ctx {
     int msm_tail_chunk = 8;          // entries per thread of the SMALL partial-sum levels (< 2^21 entries): their duration is the serial chain, not the work; 0 = msm_chunk
     int msm_filter = 1;              // per-array digit streams: drop the entries of absent points before B1 / B2 and K (msm_digits.hip)
     int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 256: one per CU — bandwidth, not wave slots)
+    int ntt_twiddles = 0;            // inter-pass twiddles of the fields whose table exceeds the L2 (2 GiB per direction at 2^26): 0 = read from the table, 1 = generated from two half tables (one more product per element, 15 GB less traffic per computeH)
     int ntt_fuse = 1;                // computeH: the two passes over the lowest field (inverse DIF last, coset DIT first) in one kernel (ntt.hip k_ntt_mid29)
     int sort_grid = 0;               // workgroups of the digit-stream sort's persistent kernels (sort.hip): 0 = two per compute unit
     int sort_tile = 0;               // entries a sort workgroup stages in LDS at a time: 0 = 4096 (40 KB of LDS), 2048 (24 KB), 1024 (16 KB)
@@ -113,11 +114,19 @@ struct zkpor_ctx {
 // library can throw; a cgo caller cannot unwind — the reference's prover logs an error return and moves on
 // (src/prover/prover/prover.go:269-272), it must never be killed by its backend.  The text of the exception is kept per host thread
 // and shown by the next zkpor_last_error of that thread.
-namespace zk { void abi_exception(const char* what) noexcept; void abort_trace_install(); }
+// ZK_ABI_CATCH_IN(ctx-expression): the same, for entry points that have a context in scope (the parameters of a function are visible in the
+// handlers of its function-try-block) — the text goes straight into THAT context's error string, inside a nested try: under cgo a goroutine may
+// move to another OS thread between the failing call and zkpor_last_error, and a per-thread text would be lost, or shown later for another context
+// (ADVICE r05).  Entry points without a handle keep the per-thread buffer, which every entry (ZK_ENTER) clears.
+namespace zk { void abi_exception(const char* what) noexcept; void abi_exception_in(zkpor_ctx* ctx, const char* what) noexcept; void abi_exception_clear() noexcept; void abort_trace_install(); }
 #define ZK_ABI_CATCH                                                                                      \
     catch (const std::bad_alloc&) { zk::abi_exception("std::bad_alloc"); return ZKPOR_E_OOM; }           \
     catch (const std::exception& e__) { zk::abi_exception(e__.what()); return ZKPOR_E_HIP; }             \
     catch (...) { zk::abi_exception("unknown C++ exception"); return ZKPOR_E_HIP; }
+#define ZK_ABI_CATCH_IN(ctx_expr)                                                                                   \
+    catch (const std::bad_alloc&) { zk::abi_exception_in((ctx_expr), "std::bad_alloc"); return ZKPOR_E_OOM; }       \
+    catch (const std::exception& e__) { zk::abi_exception_in((ctx_expr), e__.what()); return ZKPOR_E_HIP; }         \
+    catch (...) { zk::abi_exception_in((ctx_expr), "unknown C++ exception"); return ZKPOR_E_HIP; }
 
 namespace zk {
 
@@ -128,6 +137,7 @@ namespace zk {
 struct DevGuard {
     int prev = -1;
     explicit DevGuard(int dev) {
+        abi_exception_clear();   // a text left by an earlier call of this thread that nobody asked for is not this call's error
         if (dev < 0) return;
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess) cur = -1;
@@ -223,6 +233,8 @@ int32_t h2d_sync(zkpor_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 // queue of its own; `reserve` compute units are left out of the mask (0 = every CU: only the queue is wanted).  Such streams synchronise with the
 // legacy NULL stream, which the per-proof paths therefore never use.
 int32_t stream_create_own_queue(zkpor_ctx* ctx, hipStream_t* out, int reserve_cus);
+// ... and back: such a stream is never destroyed, it waits in a process-wide pool for the next caller with the same (device, reserve) — api_core.hip
+void stream_release_own_queue(int device, hipStream_t st, int reserve_cus);
 // after a failed call: nothing the prove tail queued on its own streams (all of them: the unmasked digit stream too) may still touch the stage or the workspace
 inline void drain_tail_streams(zkpor_ctx* ctx) {
     for (hipStream_t st : {ctx->tail_stream, ctx->tail_aux, ctx->tail_aux_free}) if (st) (void)hipStreamSynchronize(st);

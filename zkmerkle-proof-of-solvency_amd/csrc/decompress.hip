@@ -195,7 +195,7 @@ int32_t zkpor_g1_decompress(zkpor_ctx* ctx, const uint8_t* compressed32, size_t 
     if (rc == ZKPOR_OK && hipMemcpy(out_affine, d, n * 64, hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "decompress: D2H failed"; rc = ZKPOR_E_HIP; }
     (void)hipFree(d);
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_g2_decompress(zkpor_ctx* ctx, const uint8_t* compressed64, size_t n, void* out_affine) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || (n && (!compressed64 || !out_affine))) return ZKPOR_E_ARG;
@@ -206,6 +206,6 @@ int32_t zkpor_g2_decompress(zkpor_ctx* ctx, const uint8_t* compressed64, size_t 
     if (rc == ZKPOR_OK && hipMemcpy(out_affine, d, n * 128, hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "decompress: D2H failed"; rc = ZKPOR_E_HIP; }
     (void)hipFree(d);
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 }  // extern "C"

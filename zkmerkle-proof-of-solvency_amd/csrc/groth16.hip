@@ -311,7 +311,7 @@ int32_t zkpor_pk_create(zkpor_ctx* ctx, zkpor_pk** out) try {
     pk->ctx = ctx;
     *out = pk;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 void zkpor_pk_destroy(zkpor_pk* pk) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk) return;
@@ -331,7 +331,7 @@ int32_t zkpor_pk_set_g1(zkpor_pk* pk, int which, const void* pts, size_t n) try 
     pk->g1_raw_n[which] = n;
     pk->ready = false;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || which != ZKPOR_G2_B || (n && !pts)) return ZKPOR_E_ARG;
@@ -343,7 +343,7 @@ int32_t zkpor_pk_set_g2(zkpor_pk* pk, int which, const void* pts, size_t n) try 
     pk->g2_raw_n = n;
     pk->ready = false;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 
 // compressed input (what pk.WriteTo put on disk, src/keygen/main.go:46): decompressed on the device, decompress.hip
 int32_t zkpor_pk_set_g1_compressed(zkpor_pk* pk, int which, const uint8_t* compressed32, size_t n) try {
@@ -357,7 +357,7 @@ int32_t zkpor_pk_set_g1_compressed(zkpor_pk* pk, int which, const uint8_t* compr
     ZK_TRY(zk::decompress_to_device(ctx, false, compressed32, n, pk->g1_raw[which]));
     pk->g1_raw_n[which] = n;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 int32_t zkpor_pk_set_g2_compressed(zkpor_pk* pk, int which, const uint8_t* compressed64, size_t n) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || which != ZKPOR_G2_B || (n && !compressed64)) return ZKPOR_E_ARG;
@@ -369,7 +369,7 @@ int32_t zkpor_pk_set_g2_compressed(zkpor_pk* pk, int which, const uint8_t* compr
     ZK_TRY(zk::decompress_to_device(ctx, true, compressed64, n, pk->g2_raw));
     pk->g2_raw_n = n;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 
 }  // extern "C"
 
@@ -453,7 +453,7 @@ int32_t zkpor_pk_set_consts(zkpor_pk* pk, const void* alpha, const void* beta, c
     }
     return zk_pk_finalize(pk, alpha, beta, delta, beta2, delta2, log2_domain, inf_a, inf_b, n_wires, removed.data(), n_public, z_order,
                           false, 0);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 
 int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_public, size_t n_committed, uint64_t seed) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
@@ -481,7 +481,7 @@ int32_t zkpor_pk_synth(zkpor_pk* pk, int log2_domain, size_t n_wires, size_t n_p
     pk->ready = true;
     pk->shard = false;
     return pk_apply_tables(pk);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 
 /* the synthetic key with a CIRCUIT's sparsity instead of the seeded one: A / B1 / B2 are infinity exactly where inf_a / inf_b say
  * (gnark: a wire that appears in no L / R row), K exactly at the public wires and at removed_idx (the committed wires + the commitment
@@ -529,7 +529,7 @@ int32_t zkpor_pk_synth_masked(zkpor_pk* pk, int log2_domain, size_t n_wires, siz
     pk->ready = true;
     pk->shard = false;
     return pk_apply_tables(pk);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 
 int32_t zkpor_pk_dims(zkpor_pk* pk, uint64_t dims[6]) try {
     if (!pk || !dims) return ZKPOR_E_ARG;
@@ -537,7 +537,7 @@ int32_t zkpor_pk_dims(zkpor_pk* pk, uint64_t dims[6]) try {
     dims[0] = pk->n_wires; dims[1] = pk->n_public; dims[2] = pk->nC; dims[3] = pk->nZ;
     dims[4] = (uint64_t)pk->log2_domain; dims[5] = (uint64_t)pk->tab_m;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 
 int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
@@ -554,7 +554,7 @@ int32_t zkpor_pk_g1_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) try 
         default: return ZKPOR_E_ARG;
     }
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) try {
     ZK_ENTER(pk ? pk->ctx->device : -1);
     if (!pk || !dev_ptr || !n || which != ZKPOR_G2_B) return ZKPOR_E_ARG;
@@ -562,7 +562,7 @@ int32_t zkpor_pk_g2_dev(zkpor_pk* pk, int which, void** dev_ptr, size_t* n) try 
     if (pk->tab_m > 1) { pk->ctx->err = "pk: the arrays are interleaved fixed-base tables (msm_tables > 1), not plain point arrays"; return ZKPOR_E_STATE; }
     *dev_ptr = pk->B2; *n = pk->n_wires;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 
 // ------------------------------------------------------------------------------------------------ prove tail
 }  // extern "C"
@@ -618,9 +618,9 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
             if (new_pair) { rc = stream_create_own_queue(ctx, &st[0], ctx->tail_reserve_cus); if (rc == ZKPOR_OK) rc = stream_create_own_queue(ctx, &st[1], ctx->tail_reserve_cus); }
             const bool new_free = !st[2];
             if (rc == ZKPOR_OK && new_free) rc = stream_create_own_queue(ctx, &st[2], 0);
-            if (rc != ZKPOR_OK) {   // nothing half-made stays behind (these streams have never been used: destroying them is safe)
-                if (new_pair) { if (st[0]) (void)hipStreamDestroy(st[0]); if (st[1]) (void)hipStreamDestroy(st[1]); }
-                if (new_free && st[2]) (void)hipStreamDestroy(st[2]);
+            if (rc != ZKPOR_OK) {   // nothing half-made stays behind: back to the pool
+                if (new_pair) { stream_release_own_queue(ctx->device, st[0], ctx->tail_reserve_cus); stream_release_own_queue(ctx->device, st[1], ctx->tail_reserve_cus); }
+                if (new_free) stream_release_own_queue(ctx->device, st[2], 0);
                 return rc;
             }
             if (new_pair) ctx->tail_sets.push_back({ctx->tail_reserve_cus, st[0], st[1]});
@@ -847,7 +847,7 @@ int32_t zkpor_prove_tail_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_prove_tail_dev_keep(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_a, const void* d_b, const void* d_c, void* d_wa,
                                   void* d_wb, void* d_wc, const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) try {
@@ -866,7 +866,7 @@ int32_t zkpor_prove_tail_dev_keep(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w,
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 // ---- single-proof split (BASELINE.json configs[4]): every GPU holds a contiguous range of each key array
 int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t z_lo, size_t z_hi) try {
@@ -899,7 +899,7 @@ int32_t zkpor_pk_keep_range(zkpor_pk* pk, size_t wire_lo, size_t wire_hi, size_t
     pk_free_masks(pk);   // a shard's arrays were cut: it proves with the shared stream
     pk->ready = true;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 
 int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, const void* d_h, uint8_t sums_out[576]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -910,7 +910,7 @@ int32_t zkpor_prove_sums_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, cons
     jac_out<Fp>(m.A, sums_out); jac_out<Fp>(m.B1, sums_out + 96); jac_out<Fp2>(m.B2, sums_out + 192);
     jac_out<Fp>(m.K, sums_out + 384); jac_out<Fp>(m.Z, sums_out + 480);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_prove_assemble(const void* alpha, const void* beta, const void* delta, const void* beta2, const void* delta2,
                              const uint8_t sums[576], const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[256]) try {
@@ -932,7 +932,7 @@ int32_t zkpor_pk_consts(zkpor_pk* pk, void* alpha, void* beta, void* delta, void
     memcpy(alpha, &pk->alpha, 64); memcpy(beta, &pk->beta, 64); memcpy(delta, &pk->delta, 64);
     memcpy(beta2, &pk->beta2, 128); memcpy(delta2, &pk->delta2, 128);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? pk->ctx : nullptr))
 
 int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const uint64_t* a, const uint64_t* b,
                          const uint64_t* c, size_t n_constraints, const uint64_t r[4], const uint64_t s[4],
@@ -986,7 +986,7 @@ int32_t zkpor_prove_tail(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, const 
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 // Host-pointer form with the constraint matrices resident (zkpor_r1cs_*): only w crosses PCIe (n_wires x 32 B instead of
 // n_wires + 3 n_constraints); a, b, c are evaluated in the staging area, then the resident order of prove_sums runs
@@ -1033,7 +1033,7 @@ int32_t zkpor_prove_r1cs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, const u
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 // groth16.Prove from the ASSIGNED INPUTS, everything after them on the device (SURVEY §8 f4 + f1 + a6): the inputs (1 + nPublic + nSecret
 // elements, gnark's order) cross PCIe, the solver program fills the wire vector in HBM (csrc/solver.hip), a, b, c are evaluated from it
@@ -1088,7 +1088,7 @@ int32_t zkpor_prove_inputs(zkpor_ctx* ctx, zkpor_pk* pk, zkpor_r1cs* r1cs, zkpor
     HostPhase hp(ctx, "host_assembly");
     assemble(pk->alpha, pk->beta, pk->beta2, m, bl, proof_out);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 // uniform Fr from the operating system's CSPRNG: 32 bytes from getrandom(2), top two bits cleared, rejected unless below the
 // modulus (acceptance ~ 0.76) — the construction of gnark-crypto's fr.Element.SetRandom.  The canonical limbs are used as the
@@ -1118,7 +1118,7 @@ int32_t zkpor_prove_tail_rand(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* w, c
     if (r_out) memcpy(r_out, r, 32);
     if (s_out) memcpy(s_out, s, 32);
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -1148,7 +1148,7 @@ int32_t zkpor_commit_dev(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_values, siz
     G1Affine a1 = xyzz_to_affine<Fp>(c1), a2 = xyzz_to_affine<Fp>(c2);
     memcpy(out_commit, &a1, 64); memcpy(out_pok, &a2, 64);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_t n, uint8_t out_commit[64], uint8_t out_pok[64]) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !pk || (n && !values) || !out_commit || !out_pok) return ZKPOR_E_ARG;
@@ -1166,7 +1166,7 @@ int32_t zkpor_commit(zkpor_ctx* ctx, zkpor_pk* pk, const uint64_t* values, size_
     // no turn on the device for these two short sums (common.cuh GpuTurn): they run next to whatever proof is on the GPU — waiting
     // for it would keep this caller from moving its proof's vectors across PCIe in the meantime
     return zkpor_commit_dev(ctx, pk, d, n, out_commit, out_pok);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 static void fp_be(const Fp& x, uint8_t* out) {
     Fp c = Fp::from_mont(x);

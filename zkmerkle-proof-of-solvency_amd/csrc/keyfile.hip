@@ -180,7 +180,7 @@ int32_t zkpor_pk_load_gnark_mem(zkpor_pk* pk, const uint8_t* data, size_t len, s
     if (rc != ZKPOR_OK) { ctx->err = "pk file: G2.B: " + ctx->err; return rc; }
     return zkpor_pk_set_consts(pk, g1c, g1c + 64, g1c + 128, g2c, g2c + 128, log2d, data + L.off_inf_a, data + L.off_inf_b,
                                (size_t)L.n_wires, n_public, committed_idx, n_committed, z_order);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? zk_pk_ctx(pk) : nullptr))
 
 // One rank's share of a split key: wires [wire_lo, wire_hi) and Z points [z_lo, z_hi) only.  A, B and K are
 // stored compacted, so the wire range is translated into ranges of the compacted arrays by counting the mask bytes in front of it;
@@ -246,7 +246,7 @@ int32_t zkpor_pk_load_gnark_shard_mem(zkpor_pk* pk, const uint8_t* data, size_t 
     if (rc != ZKPOR_OK) { ctx->err = "pk file: G2.B: " + ctx->err; return rc; }
     return zk_pk_finalize(pk, g1c, g1c + 64, g1c + 128, g2c, g2c + 128, log2d, ia + wire_lo, ib + wire_lo, wire_hi - wire_lo,
                           removed.data() + wire_lo, (size_t)pub, ZKPOR_Z_ORDER_BITREV, true, z_hi - z_lo);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? zk_pk_ctx(pk) : nullptr))
 
 static int32_t with_mapped_file(zkpor_ctx* ctx, const char* path, const std::function<int32_t(const uint8_t*, size_t)>& fn) {
     int fd = open(path, O_RDONLY);
@@ -269,7 +269,7 @@ int32_t zkpor_pk_load_gnark_shard(zkpor_pk* pk, const char* path, size_t n_publi
     return with_mapped_file(zk_pk_ctx(pk), path, [&](const uint8_t* d, size_t n) {
         return zkpor_pk_load_gnark_shard_mem(pk, d, n, n_public, committed_idx, n_committed, wire_lo, wire_hi, z_lo, z_hi, z_order, info);
     });
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? zk_pk_ctx(pk) : nullptr))
 
 int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, const uint32_t* committed_idx, size_t n_committed,
                             int z_order, zkpor_pk_layout_t* info) try {
@@ -278,6 +278,6 @@ int32_t zkpor_pk_load_gnark(zkpor_pk* pk, const char* path, size_t n_public, con
     return with_mapped_file(zk_pk_ctx(pk), path, [&](const uint8_t* d, size_t n) {
         return zkpor_pk_load_gnark_mem(pk, d, n, n_public, committed_idx, n_committed, z_order, info);
     });
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((pk ? zk_pk_ctx(pk) : nullptr))
 
 }  // extern "C"

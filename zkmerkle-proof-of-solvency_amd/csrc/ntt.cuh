@@ -16,6 +16,7 @@ struct NttDomain {
     bool have29 = false;
     Fr* mem29 = nullptr;
     Fr *g_lo29, *g_hi29, *gi_lo29, *gi_hi29, *g_hi_ninv29, *gi_hi_ninv29;
+    Fr *tw_lo29 = nullptr, *tw_hi29 = nullptr, *twi_lo29 = nullptr, *twi_hi29 = nullptr;   // w^e, w^-e half tables, 2^261 form ("ntt_twiddles" 1)
     u32 *small_fwd29, *small_inv29;             // 256 x 9 limbs each
     Fr n_inv29;
     Fr* full_fwd29[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -159,7 +159,8 @@ struct PassArgs29 {
     const Fr* src;               // where this pass LOADS from (x unless the transform's first pass reads the caller's untouched input)
     int n, lo, kb, clog;
     const u32* small29;          // w_512^j, 9 limbs each
-    const Fr* tw_full;           // [k_m << lo | l], packed 2^261 form
+    const Fr* tw_full;           // [k_m << lo | l], packed 2^261 form; null = generated: w^e = tw_lo[e & mask] * tw_hi[e >> tb] ("ntt_twiddles" 1)
+    const Fr* tw_lo; const Fr* tw_hi;   // the two half tables of w (or 1 / w), 2^261 form: 2 x 2^(n/2) entries, L2-resident
     int scale_load, scale_store;  // 0 none, 1 constant, 2 g^p, 3 g^rev(p)
     const Fr* g_lo; const Fr* g_hi; int tb;
     Fr konst;
@@ -178,6 +179,13 @@ ZK_D Fr29 ld29(const u32* t) {
 ZK_D void st29(u32* t, const Fr29& v) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) t[i] = v.l[i];
+}
+// the inter-pass twiddle w^((l * km) << s0) of element (km, l) of a field (l = the GLOBAL low index): from the field's table, or — "ntt_twiddles" 1,
+// unsharded transforms — as the product of two half-table entries: one more field product per element instead of a 32-byte read from a 2 GiB table
+ZK_D Fr29 twiddle29(const PassArgs29& A, u32 km, u32 l, int lo_eff) {
+    if (A.tw_full) return Fr29::from32<0>(A.tw_full[((size_t)km << lo_eff) | l]);
+    const u32 e = (l * km) << (A.n_glob - lo_eff - A.kb);
+    return Fr29::mul(Fr29::from32<0>(A.tw_lo[e & ((1u << A.tb) - 1u)]), Fr29::from32<0>(A.tw_hi[e >> A.tb]));
 }
 ZK_D Fr29 scale29(const PassArgs29& A, int mode, const Fr29& v, u32 p) {
     if (mode == 1) return Fr29::mul(v, Fr29::from32<0>(A.konst));
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
         const Fr raw = A.src[p];
         Fr29 v = A.in_gnark ? Fr29::from32<5>(raw) : Fr29::from32<0>(raw);
         if (A.scale_load) v = scale29(A, A.scale_load, v, ((p << A.p_shift) | A.p_or) + A.p_add);
-        if (!DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << (lo + A.p_shift)) | (((l0 + c) << A.p_shift) | A.p_or)]));
+        if (!DIF && lo > 0) v = Fr29::mul(v, twiddle29(A, brev(m, kb), ((l0 + c) << A.p_shift) | A.p_or, lo + A.p_shift));
         else if (!DIF && A.in_gnark && !A.scale_load) v = Fr29::reduce32(v);  // the product-free first stage adds two loaded values: keep |v| < 32r
         st29(tile + 9u * li, v);
     }
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
         if (lo > 0) { c = idx & (C - 1u); m = idx >> clog; p = (hi << (lo + kb)) + (m << lo) + l0 + c; li = m * C + c; }
         else { m = idx & (F - 1u); c = idx >> kb; p = ((hi + c) << kb) + m; li = c * F + m; }
         Fr29 v = ld29(tile + 9u * li);
-        if (DIF && lo > 0) v = Fr29::mul(v, Fr29::from32<0>(A.tw_full[((size_t)brev(m, kb) << (lo + A.p_shift)) | (((l0 + c) << A.p_shift) | A.p_or)]));
+        if (DIF && lo > 0) v = Fr29::mul(v, twiddle29(A, brev(m, kb), ((l0 + c) << A.p_shift) | A.p_or, lo + A.p_shift));
         if (A.scale_store) v = scale29(A, A.scale_store, v, ((p << A.p_shift) | A.p_or) + A.p_add);
         A.x[p] = A.out_gnark ? Fr29::to32_div32(v) : Fr29::reduce32_pos(v).pack32();
     }
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(256) void k_ntt_top29(PassArgs29 T, Fr* xb, Fr* xc,
             const u32 idx = threadIdx.x + 256u * k;
             const u32 c = idx & (C - 1u), m = idx >> clog, p = (hi << (lo + kb)) + (m << lo) + l0 + c;
             Fr29 e = Fr29::from32<0>(x[p]);
-            e = Fr29::mul(e, Fr29::from32<0>(T.tw_full[((size_t)brev(m, kb) << lo) | (l0 + c)]));
+            e = Fr29::mul(e, twiddle29(T, brev(m, kb), l0 + c, lo));
             st29(tile + 9u * idx, e);
         }
         __syncthreads();
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256) void k_ntt_top29(PassArgs29 T, Fr* xb, Fr* xc,
         const u32 idx = threadIdx.x + 256u * k;
         const u32 c = idx & (C - 1u), m = idx >> clog, p = (hi << (lo + kb)) + (m << lo) + l0 + c;
         Fr29 e = ld29(tile + 9u * idx);
-        e = Fr29::mul(e, Fr29::from32<0>(I.tw_full[((size_t)brev(m, kb) << lo) | (l0 + c)]));
+        e = Fr29::mul(e, twiddle29(I, brev(m, kb), l0 + c, lo));
         I.x[p] = Fr29::reduce32_pos(e).pack32();
     }
 }
@@ -509,7 +517,7 @@ int32_t ntt_domain_get(zkpor_ctx* ctx, int n, NttDomain** out) {
     {
         Fr c32 = one;
         for (int i = 0; i < 5; ++i) c32 = Fr::add(c32, c32);
-        size_t total29 = (size_t)2 * nlo + (size_t)6 * nhi + 512 + 2 * 288;  // 288 Fr = 256 x 9 words
+        size_t total29 = (size_t)4 * nlo + (size_t)6 * nhi + 512 + 2 * 288;  // 288 Fr = 256 x 9 words
         d->have29 = false;
         if (hipMalloc((void**)&d->mem29, total29 * sizeof(Fr)) == hipSuccess) {
             Fr* q = d->mem29;
@@ -517,6 +525,8 @@ int32_t ntt_domain_get(zkpor_ctx* ctx, int n, NttDomain** out) {
             d->g_lo29 = take29(nlo); d->gi_lo29 = take29(nlo);
             d->g_hi29 = take29(nhi); d->gi_hi29 = take29(nhi); d->g_hi_ninv29 = take29(nhi); d->gi_hi_ninv29 = take29(nhi);
             Fr* tw_hi32 = take29(nhi); Fr* twi_hi32 = take29(nhi);
+            d->tw_hi29 = tw_hi32; d->twi_hi29 = twi_hi32;
+            d->tw_lo29 = take29(nlo); d->twi_lo29 = take29(nlo);
             Fr* sm_f = take29(256); Fr* sm_i = take29(256);
             d->small_fwd29 = (u32*)take29(288); d->small_inv29 = (u32*)take29(288);
             ZK_TRY(make_table(ctx, g, c32, 0, nlo, d->g_lo29));
@@ -527,6 +537,8 @@ int32_t ntt_domain_get(zkpor_ctx* ctx, int n, NttDomain** out) {
             ZK_TRY(make_table(ctx, gi, Fr::mul(d->n_inv, c32), d->tb, nhi, d->gi_hi_ninv29));
             ZK_TRY(make_table(ctx, w, c32, d->tb, nhi, tw_hi32));
             ZK_TRY(make_table(ctx, wi, c32, d->tb, nhi, twi_hi32));
+            ZK_TRY(make_table(ctx, w, c32, 0, nlo, d->tw_lo29));
+            ZK_TRY(make_table(ctx, wi, c32, 0, nlo, d->twi_lo29));
             ZK_TRY(make_table(ctx, w512, c32, 0, 256, sm_f));
             ZK_TRY(make_table(ctx, w512i, c32, 0, 256, sm_i));
             hipLaunchKernelGGL(k_unpack29, dim3(1), dim3(256), 0, ctx->stream, sm_f, d->small_fwd29, 256u);
@@ -661,6 +673,10 @@ static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, b
         A.clog = avail < cmax ? avail : cmax;
         A.small29 = inverse ? d->small_inv29 : d->small_fwd29;
         A.tw_full = inverse ? d->full_inv29[fi] : d->full_fwd29[fi];
+        A.tw_lo = inverse ? d->twi_lo29 : d->tw_lo29; A.tw_hi = inverse ? d->twi_hi29 : d->tw_hi29;
+        // "ntt_twiddles" 1: the fields whose table does not fit the L2 (the highest field of a 2^26 domain: 2 GiB per direction) generate their twiddles
+        // (2: every field, whatever its size — the tests' way to reach the generated form at small sizes)
+        if ((ctx->ntt_twiddles == 1 && ((size_t)32 << (fl.lo + fl.kb)) > ((size_t)16 << 20)) || ctx->ntt_twiddles == 2) A.tw_full = nullptr;
         A.tb = d->tb;
         A.scale_load = 0; A.scale_store = 0; A.g_lo = nullptr; A.g_hi = nullptr; A.konst = c32;
         A.in_gnark = step == 0; A.out_gnark = step == nf - 1;
@@ -763,6 +779,7 @@ static int32_t ntt_shard_stage(zkpor_ctx* ctx, NttDomain* d, Fr* x, int wlog, in
         A.clog = avail < cmax ? avail : cmax;
         A.small29 = inverse ? d->small_inv29 : d->small_fwd29;
         A.tw_full = inverse ? d->full_inv29[fi] : d->full_fwd29[fi];
+        A.tw_lo = inverse ? d->twi_lo29 : d->tw_lo29; A.tw_hi = inverse ? d->twi_hi29 : d->tw_hi29;   // (a sharded transform always reads its tables)
         A.tb = d->tb;
         A.scale_load = 0; A.scale_store = 0; A.g_lo = nullptr; A.g_hi = nullptr; A.konst = c32;
         A.in_gnark = step == 0; A.out_gnark = step == nf - 1;
@@ -931,31 +948,31 @@ int32_t zkpor_fft(zkpor_ctx* ctx, uint64_t* a, int log2n, int inverse, int decim
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_fft_dev(zkpor_ctx* ctx, void* d_a, int log2n, int inverse, int decimation, int on_coset) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_a || log2n < 1 || log2n > 28) return ZKPOR_E_ARG;
     return ntt_dev(ctx, (Fr*)d_a, log2n, inverse != 0, decimation == 1, on_coset != 0);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_compute_h_shard_dev(zkpor_ctx* ctx, int log2_domain, int world_log2, int rank, void* d_a, void* d_b, void* d_c, int step) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_a || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
     if (step < 3 && (!d_b || !d_c)) return ZKPOR_E_ARG;
     return compute_h_shard_step(ctx, log2_domain, world_log2, rank, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, step);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_shard_transpose_dev(zkpor_ctx* ctx, void* d_out, const void* d_in, int log2_local, int world_log2, int interleave) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_out || !d_in || d_out == d_in || world_log2 < 1 || log2_local < 2 * world_log2) return ZKPOR_E_ARG;
     return shard_transpose(ctx, (Fr*)d_out, (const Fr*)d_in, log2_local, world_log2, interleave != 0);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_compute_h_dev(zkpor_ctx* ctx, int log2_domain, void* d_a, void* d_b, void* d_c) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_a || !d_b || !d_c) return ZKPOR_E_ARG;
     return compute_h_dev(ctx, log2_domain, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_compute_h(zkpor_ctx* ctx, int log2_domain, const uint64_t* a, const uint64_t* b, const uint64_t* c,
                         size_t n_constraints, uint64_t* h_out) try {
@@ -978,6 +995,6 @@ int32_t zkpor_compute_h(zkpor_ctx* ctx, int log2_domain, const uint64_t* a, cons
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 }  // extern "C"

@@ -1586,7 +1586,7 @@ int32_t zkpor_poseidon_hash(zkpor_ctx* ctx, const uint64_t* inputs, size_t len, 
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(din); (void)hipFree(dout);
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 size_t zkpor_witgen_poseidon_sboxes(int t) {
     if (t != 3 && t != 5 && t != 6 && t != 13) return 0;
@@ -1608,7 +1608,7 @@ int32_t zkpor_witgen_poseidon_trace_dev(zkpor_ctx* ctx, int t, void* d_states, s
     else hipLaunchKernelGGL(k_poseidon_trace<13>, grid, block, 0, ctx->stream, (Fr*)d_states, count, (Fr*)d_trace, P);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_witgen_limbs_dev(zkpor_ctx* ctx, const void* d_values, size_t n, int nb_limbs, void* d_limbs, void* d_multiplicity, void* d_bad) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -1618,7 +1618,7 @@ int32_t zkpor_witgen_limbs_dev(zkpor_ctx* ctx, const void* d_values, size_t n, i
                        (u32*)d_multiplicity, (u32*)d_bad);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_witgen_inverse_dev(zkpor_ctx* ctx, const void* d_values, size_t n, const uint64_t challenge[4], void* d_out, void* d_bad) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -1630,7 +1630,7 @@ int32_t zkpor_witgen_inverse_dev(zkpor_ctx* ctx, const void* d_values, size_t n,
     hipLaunchKernelGGL(k_witgen_inverse, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, ctx->stream, (const Fr*)d_values, n, c, (Fr*)d_out, (u32*)d_bad);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_witgen_bits_dev(zkpor_ctx* ctx, const void* d_values, size_t n, int nbits, void* d_bits, void* d_bad) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -1639,7 +1639,7 @@ int32_t zkpor_witgen_bits_dev(zkpor_ctx* ctx, const void* d_values, size_t n, in
     hipLaunchKernelGGL(k_witgen_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_values, n, nbits, (Fr*)d_bits, (u32*)d_bad);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_witgen_gather_dev(zkpor_ctx* ctx, const void* d_table, size_t table_len, const void* d_indices, size_t n, void* d_out, void* d_bad) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -1649,7 +1649,7 @@ int32_t zkpor_witgen_gather_dev(zkpor_ctx* ctx, const void* d_table, size_t tabl
                        (Fr*)d_out, (u32*)d_bad);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_witgen_divmod_small_dev(zkpor_ctx* ctx, const void* d_values, size_t n, uint32_t divisor, void* d_quotient, void* d_remainder) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -1659,7 +1659,7 @@ int32_t zkpor_witgen_divmod_small_dev(zkpor_ctx* ctx, const void* d_values, size
     hipLaunchKernelGGL(k_witgen_divmod_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_values, n, divisor, (Fr*)d_quotient, (Fr*)d_remainder);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, const uint32_t* d_wire_ids, size_t n) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -1669,7 +1669,7 @@ int32_t zkpor_witgen_scatter_dev(zkpor_ctx* ctx, void* d_w, const void* d_src, c
     hipLaunchKernelGGL(k_witgen_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_w, (const Fr*)d_src, d_wire_ids, n);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_witgen_scatter_known_dev(zkpor_ctx* ctx, void* d_w, uint8_t* d_known, const void* d_src, const uint32_t* d_wire_ids, size_t n) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -1679,7 +1679,7 @@ int32_t zkpor_witgen_scatter_known_dev(zkpor_ctx* ctx, void* d_w, uint8_t* d_kno
     hipLaunchKernelGGL(k_witgen_scatter_known, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr*)d_w, d_known, (const Fr*)d_src, d_wire_ids, n);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, const zkpor_asset_t* assets,
                               size_t n_assets_total, size_t n, int tier, uint8_t* out32) try {
@@ -1708,7 +1708,7 @@ int32_t zkpor_poseidon_leaves(zkpor_ctx* ctx, const zkpor_account_t* accounts, c
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dacc); (void)hipFree(das); (void)hipFree(dout); (void)hipFree(dbe);
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_merkle_build_dev(zkpor_ctx* ctx, const void* d_leaves_mont, size_t n, int depth,
                                const uint64_t nil_leaf_mont[4], uint64_t root_mont[4]) try {
@@ -1719,7 +1719,7 @@ int32_t zkpor_merkle_build_dev(zkpor_ctx* ctx, const void* d_leaves_mont, size_t
     ZK_TRY(merkle_build_core(ctx, (const Fr*)d_leaves_mont, n, depth, nil, nullptr, &root));
     memcpy(root_mont, &root, 32);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n, int depth, const uint8_t nil_leaf[32],
                            uint8_t* levels_out, uint8_t root_out[32]) try {
@@ -1750,7 +1750,7 @@ int32_t zkpor_merkle_build(zkpor_ctx* ctx, const uint8_t* leaves32_be, size_t n,
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dbe); (void)hipFree(dleaves); if (dlev) (void)hipFree(dlev);
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 // ---- FixedDepthMerkleTree -------------------------------------------------------------------------------------------
 int32_t zkpor_tree_create(zkpor_ctx* ctx, int depth, const uint8_t nil_leaf[32], uint64_t capacity, zkpor_tree** out) try {
@@ -1783,7 +1783,7 @@ int32_t zkpor_tree_create(zkpor_ctx* ctx, int depth, const uint8_t nil_leaf[32],
     t->root = t->nil_host[depth];  // root of the empty tree (:172)
     *out = t;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 void zkpor_tree_destroy(zkpor_tree* t) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t) return;
@@ -1795,7 +1795,7 @@ int32_t zkpor_tree_nil_hash(zkpor_tree* t, int level, uint8_t out[32]) try {
     if (!t || !out || level < 0 || level > t->depth) return ZKPOR_E_ARG;
     fr_to_be_host(t->nil_host[level], out);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((t ? t->ctx : nullptr))
 int32_t zkpor_tree_set(zkpor_tree* t, const uint32_t* keys, const uint8_t* values32_be, size_t n) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && (!keys || !values32_be))) return ZKPOR_E_ARG;
@@ -1813,7 +1813,7 @@ int32_t zkpor_tree_set(zkpor_tree* t, const uint32_t* keys, const uint8_t* value
     ZK_KERNEL_CHECK(ctx);
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((t ? t->ctx : nullptr))
 int32_t zkpor_tree_set_range_dev(zkpor_tree* t, uint64_t first_key, const void* d_leaves_mont, size_t n) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && !d_leaves_mont)) return ZKPOR_E_ARG;
@@ -1823,7 +1823,7 @@ int32_t zkpor_tree_set_range_dev(zkpor_tree* t, uint64_t first_key, const void* 
     hipLaunchKernelGGL(k_tree_set_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, t->dev, (u64)first_key, (const Fr*)d_leaves_mont, n);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((t ? t->ctx : nullptr))
 int32_t zkpor_tree_build(zkpor_tree* t) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t) return ZKPOR_E_ARG;
@@ -1848,13 +1848,13 @@ int32_t zkpor_tree_build(zkpor_tree* t) try {
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     t->root = (bit & 1u) ? top : t->nil_host[t->depth];
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((t ? t->ctx : nullptr))
 int32_t zkpor_tree_root(zkpor_tree* t, uint8_t out[32]) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || !out) return ZKPOR_E_ARG;
     fr_to_be_host(t->root, out);
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((t ? t->ctx : nullptr))
 static int32_t tree_query(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out, bool proofs) {
     zkpor_ctx* ctx = t->ctx;
     if (n == 0) return ZKPOR_OK;
@@ -1874,7 +1874,7 @@ int32_t zkpor_tree_get(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* o
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && (!keys || !out32))) return ZKPOR_E_ARG;
     return tree_query(t, keys, n, out32, false);  // keys >= capacity read as nil (:288-290)
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((t ? t->ctx : nullptr))
 int32_t zkpor_tree_get_proofs(zkpor_tree* t, const uint32_t* keys, size_t n, uint8_t* out) try {
     ZK_ENTER(t ? t->ctx->device : -1);
     if (!t || (n && (!keys || !out))) return ZKPOR_E_ARG;
@@ -1884,7 +1884,7 @@ int32_t zkpor_tree_get_proofs(zkpor_tree* t, const uint32_t* keys, size_t n, uin
             return ZKPOR_E_ARG;
         }
     return tree_query(t, keys, n, out, true);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((t ? t->ctx : nullptr))
 int32_t zkpor_merkle_verify_proofs(zkpor_ctx* ctx, const uint8_t root[32], const uint32_t* keys, const uint8_t* proofs,
                                    const uint8_t* leaves32_be, size_t n, int depth, uint8_t* ok_out) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -1903,7 +1903,7 @@ int32_t zkpor_merkle_verify_proofs(zkpor_ctx* ctx, const uint8_t root[32], const
     ZK_HIP(ctx, hipMemcpyAsync(ok_out, dok.p, n, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 // ---- CEX asset-list commitments / batch commitments -------------------------------------------------------------------
 int32_t zkpor_cex_commitments(zkpor_ctx* ctx, const zkpor_cex_asset_const_t* assets, size_t n_assets, const zkpor_cex_totals_t* totals,
@@ -1938,7 +1938,7 @@ int32_t zkpor_cex_commitments(zkpor_ctx* ctx, const zkpor_cex_asset_const_t* ass
     ZK_HIP(ctx, hipMemcpyAsync(out32, dbe.p, n_states * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_batch_commitments(zkpor_ctx* ctx, const uint8_t* roots32, const uint8_t* before32, const uint8_t* after32,
                                 const uint32_t* min_index, const uint32_t* max_index, size_t n, uint8_t* out32) try {
     ZK_ENTER(ctx ? ctx->device : -1);
@@ -1958,7 +1958,7 @@ int32_t zkpor_batch_commitments(zkpor_ctx* ctx, const uint8_t* roots32, const ui
     ZK_HIP(ctx, hipMemcpyAsync(out32, dbe.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 // ---- account totals / collateral tiers ----------------------------------------------------------------------------------
 int32_t zkpor_account_totals(zkpor_ctx* ctx, zkpor_account_t* accounts, const zkpor_asset_t* assets, size_t n_assets_total, size_t n,
@@ -1986,7 +1986,7 @@ int32_t zkpor_account_totals(zkpor_ctx* ctx, zkpor_account_t* accounts, const zk
     if (valid_out) ZK_HIP(ctx, hipMemcpyAsync(valid_out, dv.p, n, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 // ---- accounts straight into the tree -------------------------------------------------------------------------------------
 // buildAccountTree (src/witness/main.go:130-199) for one chunk of accounts, without the leaves ever leaving the device:
@@ -2032,6 +2032,6 @@ int32_t zkpor_tree_set_accounts(zkpor_tree* t, uint64_t first_key, zkpor_account
     }
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((t ? t->ctx : nullptr))
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 // Layout follows gnark's compiled constraint system: a linear expression is a list of terms (coefficient id, wire id),
 // coefficients live in a small shared table (most terms use 1 or -1); three CSR matrices share the table.
 #include "common.cuh"
+#include <memory>
 #include "r1cs.cuh"
 
 namespace zk {
@@ -140,7 +141,8 @@ int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, 
                           zkpor_r1cs** out) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !out || !coeff_table || n_coeff == 0 || n_wires == 0 || n_wires > 0xffffffffull) return ZKPOR_E_ARG;
-    zkpor_r1cs* r = new zkpor_r1cs();
+    std::unique_ptr<zkpor_r1cs, void (*)(zkpor_r1cs*)> hold(new zkpor_r1cs(), r1cs_free);   // freed on every error return and on an exception stopped at the ABI
+    zkpor_r1cs* r = hold.get();
     r->ctx = ctx; r->n_constraints = n_constraints; r->n_wires = n_wires; r->n_coeff = n_coeff;
     std::vector<uint8_t> kind(n_coeff, 0);
     const Fr* tab = (const Fr*)coeff_table;
@@ -152,13 +154,13 @@ int32_t zkpor_r1cs_create(zkpor_ctx* ctx, size_t n_constraints, size_t n_wires, 
         else if (memcmp(&tab[i], &mone, sizeof(Fr)) == 0) kind[i] = 2;
     }
     if (hipMalloc((void**)&r->coeff, n_coeff * sizeof(Fr)) != hipSuccess || hipMalloc((void**)&r->coeff_kind, n_coeff) != hipSuccess) {
-        (void)hipGetLastError(); r1cs_free(r); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM;
+        (void)hipGetLastError(); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM;
     }
     if (zk::h2d_sync(ctx, r->coeff, tab, n_coeff * sizeof(Fr)) != ZKPOR_OK ||
-        zk::h2d_sync(ctx, r->coeff_kind, kind.data(), n_coeff) != ZKPOR_OK) { r1cs_free(r); ctx->err = "r1cs: H2D failed"; return ZKPOR_E_HIP; }
-    *out = r;
+        zk::h2d_sync(ctx, r->coeff_kind, kind.data(), n_coeff) != ZKPOR_OK) { ctx->err = "r1cs: H2D failed"; return ZKPOR_E_HIP; }
+    *out = hold.release();
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 void zkpor_r1cs_destroy(zkpor_r1cs* r) try {
     ZK_ENTER(r ? r->ctx->device : -1);
     if (!r) return;
@@ -197,18 +199,18 @@ int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr,
     }
     r->nnz[which] = nnz;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((r ? r->ctx : nullptr))
 int32_t zkpor_r1cs_eval_dev(zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) try {
     ZK_ENTER(r ? r->ctx->device : -1);
     if (!r) return ZKPOR_E_ARG;
     return zk::r1cs_eval_on(r->ctx, r, d_w, d_a, d_b, d_c, domain_size);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((r ? r->ctx : nullptr))
 /* the same queued on ANOTHER context of the GPU (a second worker's stream and timers; the matrices are only read) */
 int32_t zkpor_r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !r) return ZKPOR_E_ARG;
     return zk::r1cs_eval_on(ctx, r, d_w, d_a, d_b, d_c, domain_size);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 /* every constraint against a wire vector on the device: counts[0] = rows with L.w * R.w != O.w, counts[1] = the lowest such row */
 int32_t zkpor_r1cs_check_dev(zkpor_r1cs* r, const void* d_w, uint64_t counts[2]) try {
     ZK_ENTER(r ? r->ctx->device : -1);
@@ -231,7 +233,7 @@ int32_t zkpor_r1cs_check_dev(zkpor_r1cs* r, const void* d_w, uint64_t counts[2])
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_out);
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((r ? r->ctx : nullptr))
 /* host-buffer form for tests and small circuits: w in, a/b/c (n_constraints each) out */
 int32_t zkpor_r1cs_eval(zkpor_r1cs* r, const uint64_t* w, uint64_t* a, uint64_t* b, uint64_t* c) try {
     ZK_ENTER(r ? r->ctx->device : -1);
@@ -250,6 +252,6 @@ int32_t zkpor_r1cs_eval(zkpor_r1cs* r, const uint64_t* w, uint64_t* a, uint64_t*
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((r ? r->ctx : nullptr))
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <set>
 #include "common.cuh"
+#include <memory>
 #include "r1cs.cuh"
 #include "solver_instr.cuh"
 #include "../host/solver_file.hpp"
@@ -522,8 +523,12 @@ static void solver_free(zkpor_solver* s) {
     void* ptrs[] = {s->d_rows, s->d_perr, s->d_ones, s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_gen_cnt_all, s->d_long, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
                     s->d_cnt, s->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (s->side) (void)hipStreamDestroy(s->side);
-    if (s->side2) (void)hipStreamDestroy(s->side2);
+    // side streams with hardware queues of their own go back to the pool (common.cuh stream_release_own_queue), ordinary ones to the runtime
+    for (hipStream_t st : {s->side, s->side2}) {
+        if (!st) continue;
+        if (s->side_own_queue) stream_release_own_queue(s->ctx ? s->ctx->device : 0, st, 0);
+        else { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    }
     if (s->ev_fork2) (void)hipEventDestroy(s->ev_fork2);
     if (s->ev_join2) (void)hipEventDestroy(s->ev_join2);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -730,7 +735,7 @@ int32_t solver_side_queues(zkpor_solver* s) {
     if (s->running || s->side_busy || s->side2_busy) return ZKPOR_OK;      // not under a run or a chain in flight: next time
     hipStream_t a = nullptr, b = nullptr;
     ZK_TRY(stream_create_own_queue(ctx, &a, 0));
-    if (stream_create_own_queue(ctx, &b, 0) != ZKPOR_OK) { (void)hipStreamDestroy(a); return ZKPOR_E_HIP; }
+    if (stream_create_own_queue(ctx, &b, 0) != ZKPOR_OK) { stream_release_own_queue(ctx->device, a, 0); return ZKPOR_E_HIP; }
     // the first pair is parked, not destroyed: the solver's events were recorded on it (the context destroys what it has retired)
     if (s->side) { (void)hipStreamSynchronize(s->side); ctx->retired_streams.push_back(s->side); }
     if (s->side2) { (void)hipStreamSynchronize(s->side2); ctx->retired_streams.push_back(s->side2); }
@@ -747,7 +752,7 @@ extern "C" {
 
 int32_t zkpor_solver_create(zkpor_r1cs* r1cs, const uint8_t* container, size_t len, zkpor_solver** out) try {
     return zkpor_solver_create_on(r1cs ? r1cs->ctx : nullptr, r1cs, container, len, out);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((r1cs ? r1cs->ctx : nullptr))
 
 /* the same program bound to ANOTHER context of the GPU the matrices live on: its launches, phase timers and error text belong to `ctx`, the
  * matrices are only read — one solver per worker context, all over one zkpor_r1cs (two workers of a GPU solve side by side) */
@@ -756,13 +761,16 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     if (!ctx || !r1cs || !container || !out) return ZKPOR_E_ARG;
     if (ctx->device != r1cs->ctx->device) { ctx->err = "solver: the constraint matrices live on another GPU than the context"; return ZKPOR_E_ARG; }
     for (int m = 0; m < 3; ++m) if (!r1cs->row_ptr[m]) { ctx->err = "solver: the constraint matrices are not loaded"; return ZKPOR_E_STATE; }
-    zkpor_solver* s = new zkpor_solver();
+    // held until the program is fully loaded: an exception on the way (std::bad_alloc from a vector that scales with the program is the realistic
+    // one; it stops at the ABI firewall) or an error return frees the object and whatever it owns on the device
+    std::unique_ptr<zkpor_solver, void (*)(zkpor_solver*)> hold(new zkpor_solver(), solver_free);
+    zkpor_solver* s = hold.get();
     s->ctx = ctx; s->r1cs = r1cs;
     s->container.assign(container, container + len);
     std::string why;
-    if (zkpor_host::ParseSolverFile(s->container.data(), len, &s->view, &why) != 0) { ctx->err = why; delete s; return ZKPOR_E_ARG; }
+    if (zkpor_host::ParseSolverFile(s->container.data(), len, &s->view, &why) != 0) { ctx->err = why; return ZKPOR_E_ARG; }
     const auto& v = s->view;
-    auto bad = [&](const std::string& m) { ctx->err = "solver: " + m; delete s; return ZKPOR_E_ARG; };
+    auto bad = [&](const std::string& m) { ctx->err = "solver: " + m; return ZKPOR_E_ARG; };
     if (v.n_calldata >= (1ull << 32)) return bad("call data beyond 2^32 words");
     const uint64_t nw = r1cs->n_wires, ncoef = r1cs->n_coeff;
     // validate what the kernels index with — constraint ids, call-data offsets and shapes, wire / coefficient ids inside the call data —
@@ -937,7 +945,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
               hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) == hipSuccess && hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_fork2, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->ev_join2, hipEventDisableTiming) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); solver_free(s); ctx->err = "solver: out of device memory"; return ZKPOR_E_OOM; }
+    if (!ok) { (void)hipGetLastError(); ctx->err = "solver: out of device memory"; return ZKPOR_E_OOM; }
     if (!pos_rows.empty()) {   // the rows the Poseidon instructions will write instead of r1cs_eval: checked against the O matrix, once, here
         u32* d_calls = nullptr;
         u32 h[2] = {0u, 0xffffffffu};
@@ -953,16 +961,15 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
         if (e == hipSuccess) e = hipMemcpyAsync(h, s->d_err + 4, 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (d_calls) (void)hipFree(d_calls);
-        if (e != hipSuccess) { solver_free(s); ctx->err = std::string("solver: checking the Poseidon rows: ") + hipGetErrorString(e); return ZKPOR_E_HIP; }
+        if (e != hipSuccess) { ctx->err = std::string("solver: checking the Poseidon rows: ") + hipGetErrorString(e); return ZKPOR_E_HIP; }
         if (h[0]) {
-            solver_free(s);
             ctx->err = "solver: " + std::to_string(h[0]) + " of the constraint rows Poseidon instructions claim (firstRow) are not `... = output wire` of that call; the first such instruction is " + std::to_string(h[1]);
             return ZKPOR_E_ARG;
         }
     }
-    *out = s;
+    *out = hold.release();
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN(ctx)
 
 void zkpor_solver_destroy(zkpor_solver* s) try {
     ZK_ENTER(s ? s->ctx->device : -1);
@@ -981,7 +988,7 @@ int32_t zkpor_solver_dims(const zkpor_solver* s, uint64_t dims[7]) try {
     dims[5] = ext;
     dims[6] = s->launches;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((s ? zk::solver_ctx(const_cast<zkpor_solver*>(s)) : nullptr))
 
 int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint8_t* d_known_or_null, uint32_t* paused_instr) try {
     ZK_ENTER(s ? s->ctx->device : -1);
@@ -1004,7 +1011,7 @@ int32_t zkpor_solver_start_dev(zkpor_solver* s, void* d_w, size_t n_inputs, uint
     s->checks_left = s->abc_a != nullptr && ctx->solver_defer_checks != 0 && s->n_check > 0;   // zkpor_solver_eval_abc_dev verifies a x b = c on every row instead
     s->running = true; s->run_ok = false; s->next_level = 0; s->pending.clear(); s->launches = 0;
     return solver_advance(s, paused_instr);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((s ? zk::solver_ctx(s) : nullptr))
 
 /* a, b, c (domain-size buffers of the prove tail) for the NEXT runs: the Poseidon instructions then write the rows of their own constraints
  * while they have the S-box inputs in registers (two thirds of all terms of the real circuit's matrices sit in those rows);
@@ -1014,7 +1021,7 @@ int32_t zkpor_solver_set_abc_dev(zkpor_solver* s, void* d_a, void* d_b, void* d_
     if ((d_a || d_b || d_c) && !(d_a && d_b && d_c)) { s->ctx->err = "solver: a, b, c are given together or not at all"; return ZKPOR_E_ARG; }
     s->abc_a = (Fr*)d_a; s->abc_b = (Fr*)d_b; s->abc_c = (Fr*)d_c;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((s ? zk::solver_ctx(s) : nullptr))
 /* a, b, c = L.w, R.w, O.w for every row the finished run has not written already (all rows when zkpor_solver_set_abc_dev was not used), zero
  * padding up to domain_size; into the buffers given to zkpor_solver_set_abc_dev, or d_a / d_b / d_c when it was not used */
 int32_t zkpor_solver_eval_abc_dev(zkpor_solver* s, const void* d_w, void* d_a, void* d_b, void* d_c, size_t domain_size) try {
@@ -1044,7 +1051,7 @@ int32_t zkpor_solver_eval_abc_dev(zkpor_solver* s, const void* d_w, void* d_a, v
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h[0]) { ctx->err = "solver: " + std::to_string(h[0]) + " constraints are not satisfied, the first one is #" + std::to_string(h[1]); return ZKPOR_E_STATE; }
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((s ? zk::solver_ctx(s) : nullptr))
 
 /* the ASYNC instructions of the NEXT proof (the two CEX commitments: 834 chained permutations each, ~0.2 s of one wave) started on the side
  * stream while the current proof still runs its prove tail: d_w_next holds the next assignment (wire 0 = ONE, then the inputs) and must be the
@@ -1086,14 +1093,14 @@ int32_t zkpor_solver_prefetch_dev(zkpor_solver* s, void* d_w_next, size_t n_inpu
     s->side_busy = true;
     s->prefetched_w = d_w_next;
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((s ? zk::solver_ctx(s) : nullptr))
 
 int32_t zkpor_solver_resume_dev(zkpor_solver* s, uint32_t* paused_instr) try {
     ZK_ENTER(s ? s->ctx->device : -1);
     if (!s || !paused_instr) return ZKPOR_E_ARG;
     if (!s->running) { s->ctx->err = "solver: no run to resume"; return ZKPOR_E_STATE; }
     return solver_advance(s, paused_instr);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((s ? zk::solver_ctx(s) : nullptr))
 
 // evaluates the inputs of the external hint the run is paused at into d_out (device, n_in elements); synchronous
 static int32_t hint_inputs_to(zkpor_solver* s, uint32_t instr, Fr* d_out) {
@@ -1124,7 +1131,7 @@ int32_t zkpor_solver_external_inputs(zkpor_solver* s, uint32_t instr, uint64_t* 
     ZK_HIP(ctx, hipMemcpyAsync(in_values, s->d_tmp, (size_t)cd[1] * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((s ? zk::solver_ctx(s) : nullptr))
 
 /* the same into device memory (d_out: capacity elements): the committed wires of a BSB22 commitment go straight to zkpor_commit_dev */
 int32_t zkpor_solver_external_inputs_dev(zkpor_solver* s, uint32_t instr, void* d_out, size_t capacity) try {
@@ -1135,7 +1142,7 @@ int32_t zkpor_solver_external_inputs_dev(zkpor_solver* s, uint32_t instr, void* 
     const uint32_t* cd = s->view.calldata + s->view.arg[instr];
     if (capacity < cd[1]) { ctx->err = "solver: the buffer holds fewer elements than the hint has inputs"; return ZKPOR_E_ARG; }
     return hint_inputs_to(s, instr, (Fr*)d_out);
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((s ? zk::solver_ctx(s) : nullptr))
 
 int32_t zkpor_solver_external_outputs(zkpor_solver* s, uint32_t instr, const uint64_t* out_values, size_t n_out) try {
     ZK_ENTER(s ? s->ctx->device : -1);
@@ -1153,7 +1160,7 @@ int32_t zkpor_solver_external_outputs(zkpor_solver* s, uint32_t instr, const uin
     }
     s->pending.erase(s->pending.begin());
     return ZKPOR_OK;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((s ? zk::solver_ctx(s) : nullptr))
 
 /* host-buffer form: inputs in, full wire vector out; pre-filled wires (the device generators' in a real run) given as (id, value) pairs;
  * external hints are NOT served here (the call fails with ZKPOR_E_STATE when it meets one) */
@@ -1183,6 +1190,6 @@ int32_t zkpor_solver_run(zkpor_solver* s, const uint64_t* inputs, size_t n_input
     if (rc == ZKPOR_OK) ZK_HIP(ctx, hipMemcpy(w_out, tw.p, nw * sizeof(Fr), hipMemcpyDeviceToHost));
     if (stats) { stats[0] = s->n_r1c; stats[1] = s->n_hint + s->n_lookup + s->n_poseidon; stats[2] = s->n_skip; stats[3] = s->launches; }
     return rc;
-} ZK_ABI_CATCH
+} ZK_ABI_CATCH_IN((s ? zk::solver_ctx(s) : nullptr))
 
 }  // extern "C"
