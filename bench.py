@@ -1007,7 +1007,7 @@ class EndToEnd:
     the solve's ~100 narrow dependent launches do not queue behind full-size MSM grids."""
 
     def __init__(self, torch, zkpor, C, ctx, local_rank, pk, cir, dc0, d_in, inputs_host, D, n_commit, dev, blinding, abc0, workers, reserve_cus,
-                 solver_rows=True, prefetch=True, aux_masked=-1, sort_params=None):
+                 solver_rows=True, prefetch=True, aux_masked=-1, sort_params=None, tail_mode=0):
         self.torch, self.zkpor, self.C, self.pk, self.cir, self.D, self.blinding = torch, zkpor, C, pk, cir, D, blinding
         self.d_in, self.inputs_host, self.prefetch, self.solver_rows = d_in, inputs_host, prefetch, solver_rows
         self.n_in = cir.n_public + cir.n_secret
@@ -1020,11 +1020,14 @@ class EndToEnd:
             a, b, c = abc0 if k == 0 else (dev(32 * D), dev(32 * D), dev(32 * D))
             self.wk.append({"ctx": wctx, "dc": wdc, "w": [dev(32 * n_wires), dev(32 * n_wires)], "cv": dev(32 * (n_commit + 1)), "a": a, "b": b, "c": c, "k": 0,
                             "last": None, "own": k > 0})
+        self.tail_mode = tail_mode if workers > 1 else 0      # 1: tails on their own streams + the device turn without a reserve; 2: + the workers' own streams at high priority
         for wk in self.wk:
+            wk["ctx"].set_param("tail_streams", 1 if self.tail_mode >= 1 else 0)
+            wk["ctx"].set_param("stream_priority", 1 if self.tail_mode >= 2 else 0)
             wk["ctx"].set_param("tail_reserve_cus", self.reserve)
             if aux_masked >= 0:
                 wk["ctx"].set_param("tail_aux_masked", aux_masked)
-            for name_ in ("sort_grid", "sort_tile"):     # worker contexts take the main context's sort settings (--sort-grid / --sort-tile)
+            for name_ in ("sort_grid", "sort_tile", "ntt_twiddles"):     # worker contexts take the main context's sort settings (--sort-grid / --sort-tile)
                 if sort_params and sort_params.get(name_, -1) >= 0:
                     wk["ctx"].set_param(name_, sort_params[name_])
             if solver_rows:
@@ -1104,6 +1107,8 @@ class EndToEnd:
         for wk in self.wk:
             wk["dc"].solver.set_abc_dev(None, None, None)
             wk["ctx"].set_param("tail_reserve_cus", 0)
+            wk["ctx"].set_param("tail_streams", 0)
+            wk["ctx"].set_param("stream_priority", 0)
             if wk["own"]:
                 wk["dc"].close(); wk["ctx"].close()
         self.wk = []
@@ -1300,6 +1305,9 @@ def main():
                     "4 holds the key as 4 interleaved tables (112 GB of the 288 GB at 2^26) and buys 12 digits of 22 bits instead of "
                     "13 of 20 at the same number of buckets — 6 %% fewer bucket additions (profiles/r02_tables.txt)")
     ap.add_argument("--sort-grid", type=int, default=-1, help="experiment: workgroups of the digit-stream sort's persistent kernels (sort_grid; library default: two per compute unit)")
+    ap.add_argument("--tail-mode", type=int, default=0, help="experiment, 2 workers: 1 = the prove tail on its own streams + the device turn WITHOUT a CU reserve "
+                    "(tail_streams), 2 = and the workers' own streams (solver, a / b / c, commitment) at the highest stream priority (stream_priority)")
+    ap.add_argument("--ntt-twiddles", type=int, default=-1, help="experiment: 1 = the highest field's inter-pass twiddles generated from two half tables instead of read from its 2 GiB table (ntt_twiddles)")
     ap.add_argument("--sort-tile", type=int, default=-1, help="experiment: entries a sort workgroup stages in LDS at a time (sort_tile: 1024 / 2048 / 4096)")
     ap.add_argument("--no-filter", action="store_true", help="experiment: accumulate B1 / B2 / K from the shared digit stream of w instead of the "
                     "per-array streams without the entries of absent points (context parameter msm_filter 0)")
@@ -1409,6 +1417,8 @@ def main():
         ctx.set_param("sort_grid", args.sort_grid)
     if args.sort_tile >= 0:
         ctx.set_param("sort_tile", args.sort_tile)
+    if args.ntt_twiddles >= 0:
+        ctx.set_param("ntt_twiddles", args.ntt_twiddles)
     if args.no_filter:
         ctx.set_param("msm_filter", 0)
     if args.no_ntt_fuse:
@@ -1713,10 +1723,11 @@ def main():
         n_workers = max(1, args.e2e_workers)
         lv = circ["cir"].level_sizes()
 
-        def make(workers, reserve):
+        def make(workers, reserve, tail_mode=None):
             return EndToEnd(torch, zkpor, C, ctx, local_rank, pk, circ["cir"], dc, circ["d_in"], circ["inp"], D, n_commit, dev, blinding, (a, b, c), workers, reserve,
                             solver_rows=not args.no_solver_rows, prefetch=not args.no_prefetch, aux_masked=args.tail_aux_masked,
-                            sort_params={"sort_grid": args.sort_grid, "sort_tile": args.sort_tile})
+                            sort_params={"sort_grid": args.sort_grid, "sort_tile": args.sort_tile, "ntt_twiddles": args.ntt_twiddles},
+                            tail_mode=args.tail_mode if tail_mode is None else tail_mode)
 
         def region(E, first, n, sink, tm_acc=None, upload=False, warm=1):
             E.run(first - 100, max(warm, len(E.wk)), None, None, upload)            # warm-up: at least one proof per worker
@@ -1785,13 +1796,14 @@ def main():
                 try:
                     if len(parts) > 2:
                         ctx.set_param("tail_aux_masked", parts[2])
-                    Es = make(parts[0], parts[1])
+                    Es = make(parts[0], parts[1], parts[6] if len(parts) > 6 else None)      # field 7: tail_mode (EndToEnd)
                     if len(parts) > 2:
                         for wk_ in Es.wk:
                             wk_["ctx"].set_param("tail_aux_masked", parts[2])
                     for wk_ in Es.wk:       # fields 4 / 5 of a spec: the digit-stream sort's grid and LDS tile (csrc/sort.hip), 0 = library default
                         wk_["ctx"].set_param("sort_grid", parts[3] if len(parts) > 3 else max(0, args.sort_grid))
                         wk_["ctx"].set_param("sort_tile", parts[4] if len(parts) > 4 else max(0, args.sort_tile))
+                        wk_["ctx"].set_param("ntt_twiddles", parts[5] if len(parts) > 5 else max(0, args.ntt_twiddles))      # field 6: 1 = inter-field twiddles generated, not read
                     r_ = region(Es, 20001 + 1000 * k_, max(2, args.e2e_steps if args.e2e_steps > 0 else 4), e2e_proofs, None)
                     r_["same_wires"] = Es.same_wires(w) if args.scalars == "witness" else None
                     r_["spec"] = spec
@@ -1802,7 +1814,7 @@ def main():
                 except Exception as ex_:      # noqa: BLE001
                     sweep.append({"spec": spec, "note": f"failed: {ex_}"})
             ctx.set_param("tail_aux_masked", 0 if args.tail_aux_masked < 0 else args.tail_aux_masked)
-            ctx.set_param("sort_grid", max(0, args.sort_grid)); ctx.set_param("sort_tile", max(0, args.sort_tile))
+            ctx.set_param("sort_grid", max(0, args.sort_grid)); ctx.set_param("sort_tile", max(0, args.sort_tile)); ctx.set_param("ntt_twiddles", max(0, args.ntt_twiddles))
             e2e["sweep"] = sweep
         e2e["next_proofs_hash_chains_prefetched"] = not args.no_prefetch
         e2e["poseidon_rows_written_by_the_solver"] = not args.no_solver_rows

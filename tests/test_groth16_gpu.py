@@ -553,3 +553,67 @@ def test_tail_reserve_cus_may_change_between_proofs():
             x.free()
         pk.close()
         zk.close()
+
+
+@pytest.mark.isolated
+@pytest.mark.parametrize("reserve,tail_streams,priority,early", [(32, 0, 0, 1), (32, 0, 0, 0), (0, 1, 1, 1), (16, 1, 0, 1)])
+def test_two_workers_device_tails_take_turns_with_every_stream_setting(zk, reserve, tail_streams, priority, early):
+    """the *_dev split with two worker contexts of one GPU (bench.py's headline shape, host/prover_host.hpp's workers): a masked tail
+    ("tail_reserve_cus"), a tail on its own streams without a reserve ("tail_streams") beside a worker whose own stream has the highest
+    priority ("stream_priority"), and the digit stream of w built BEFORE the device turn is waited for ("tail_digits_early": the path a
+    worker takes when the other's tail is running) or after — twelve proofs from two threads, every one equal to the single-context proof for
+    its blinding, bit for bit"""
+    import threading
+    log2 = 17
+    n = 1 << log2
+    D = n
+    pk = zkpor.ProvingKey(zk)
+    other = zkpor.Context(0)
+    ctxs = [zk, other]
+    bufs = []
+    try:
+        pk.synth(log2, n, 3, 0, 0x7A12)
+        rng = np.random.default_rng(5)
+        def fr(m):
+            x = rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64)
+            x[:, 3] &= np.uint64((1 << 60) - 1)
+            return x
+        w, a, b, c = fr(n), fr(D), fr(D), fr(D)
+        blind = [(O.fr_random(300 + i, 1)[0], O.fr_random(400 + i, 1)[0]) for i in range(12)]
+        per = []
+        for cx in ctxs:
+            src = [cx.alloc(32 * D).upload(v) for v in (a, b, c)]
+            work = [cx.alloc(32 * D) for _ in range(3)]
+            dw = cx.alloc(32 * n).upload(w)
+            per.append((src, work, dw)); bufs += src + work + [dw]
+        prove = lambda k, r, s: ctxs[k].prove_tail_dev_keep(pk, per[k][2].ptr, per[k][0][0].ptr, per[k][0][1].ptr, per[k][0][2].ptr,
+                                                           per[k][1][0].ptr, per[k][1][1].ptr, per[k][1][2].ptr, r, s)
+        want = [prove(0, r, s) for r, s in blind]
+        for cx in ctxs:
+            cx.set_param("tail_streams", tail_streams); cx.set_param("stream_priority", priority)
+            cx.set_param("tail_reserve_cus", reserve); cx.set_param("tail_digits_early", early)
+        got = [None] * len(blind)
+        errs = []
+
+        def run(k):
+            try:
+                for i in range(k, len(blind), 2):
+                    got[i] = prove(k, *blind[i])
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for g, x in zip(got, want):
+            assert np.array_equal(g, x)
+    finally:
+        for cx in ctxs:
+            cx.set_param("tail_reserve_cus", 0); cx.set_param("tail_streams", 0); cx.set_param("tail_digits_early", 1)
+        zk.set_param("stream_priority", 0)
+        for x in bufs:
+            x.free()
+        other.close(); pk.close()

@@ -96,6 +96,26 @@ def test_every_level_count_of_the_sort(zk, window, tables):
     _check(keys, vals, info, ints, tables)
 
 
+@pytest.mark.parametrize("window,tables", [(22, 4), (20, 1)])
+def test_compile_time_level_0_equals_the_generic_one(zk, window, tables):
+    """the production shapes have a level 0 with the window, the digit count and the table count as template parameters (digits by static shifts,
+    kept in registers between the passes, zero scalars skipped before their Montgomery reduction); "sort_generic" 1 runs the runtime-window
+    kernels on the same input: the same entries (both against the Python decomposition), blocks of zero scalars and a ragged tail included"""
+    ints = _scalars(3000, 31, "witness") + [0] * 700 + _scalars(411, 32, "edges") + [0] * 5
+    rng = np.random.default_rng(3)
+    a0 = (rng.integers(0, 7, len(ints)) == 0).astype(np.uint8)
+    got = {}
+    for generic in (0, 1):
+        zk.set_param("sort_generic", generic)
+        try:
+            keys, vals, info = _run(zk, ints, tables, window, a0, None)
+        finally:
+            zk.set_param("sort_generic", 0)
+        _check(keys, vals, info, ints, tables, a0, None)
+        got[generic] = np.sort((keys.astype(np.uint64) << np.uint64(32)) | vals.astype(np.uint64))
+    assert np.array_equal(got[0], got[1])
+
+
 def test_absence_flags_and_per_array_counts(zk):
     n = 5000
     ints = _scalars(n, 5, "witness")

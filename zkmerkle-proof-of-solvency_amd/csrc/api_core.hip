@@ -488,6 +488,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "ntt_twiddles") { if (value < 0 || value > 2) { ctx->err = "ntt_twiddles must be 0 (tables), 1 (generated where the table exceeds 16 MiB) or 2 (generated everywhere)"; return ZKPOR_E_ARG; } ctx->ntt_twiddles = (int)value; }
     else if (n == "ntt_fuse") { if (value < 0 || value > 1) { ctx->err = "ntt_fuse must be 0 or 1"; return ZKPOR_E_ARG; } ctx->ntt_fuse = (int)value; }
     else if (n == "sort_grid") { if (value < 0 || value > 8192) { ctx->err = "sort_grid must be in [0,8192] (0 = two workgroups per compute unit)"; return ZKPOR_E_ARG; } ctx->sort_grid = (int)value; }
+    else if (n == "sort_generic") { if (value < 0 || value > 1) { ctx->err = "sort_generic must be 0 or 1"; return ZKPOR_E_ARG; } ctx->sort_generic = (int)value; }
     else if (n == "sort_tile") { if (value != 0 && value != 1024 && value != 2048 && value != 4096) { ctx->err = "sort_tile must be 0 (4096), 1024, 2048 or 4096"; return ZKPOR_E_ARG; } ctx->sort_tile = (int)value; }
     else if (n == "sort_block") { if (value != 0 && value != 256 && value != 512) { ctx->err = "sort_block must be 0, 256 or 512"; return ZKPOR_E_ARG; } }   // rounds 3-5: the workgroup size of rocPRIM's onesweep; accepted and ignored since the sort is sort.hip's
     else if (n == "msm_reduce_scan") { if (value < 0 || value > 2) { ctx->err = "msm_reduce_scan must be 0, 1 or 2"; return ZKPOR_E_ARG; } ctx->msm_reduce_scan = (int)value; }
@@ -518,7 +519,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
         if (value < 0 || value > 128 || value % 8) { ctx->err = "tail_reserve_cus must be 0 or a multiple of 8 up to 128"; return ZKPOR_E_ARG; }
         // no stream is destroyed here (common.cuh tail_sets): a value the context has had before gets its old pair back, a new one a new pair at the next
         // prove tail, and a context that has used up its pairs keeps its setting and says so
-        bool known = value == 0;
+        bool known = value == 0 && !ctx->tail_streams;
         for (auto& ts : ctx->tail_sets) known |= ts.reserve == (int)value;
         if (!known && ctx->tail_sets.size() >= zkpor_ctx::TAIL_SETS_MAX) {
             ctx->err = "tail_reserve_cus: this context has already created masked streams for " + std::to_string(zkpor_ctx::TAIL_SETS_MAX) + " different values (they live as long as the context); use one of those or another context";
@@ -527,6 +528,26 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
         ctx->tail_reserve_cus = (int)value;
         ctx->tail_stream = ctx->tail_aux = nullptr;
         for (auto& ts : ctx->tail_sets) if (ts.reserve == (int)value) { ctx->tail_stream = ts.main; ctx->tail_aux = ts.aux; }
+    }
+    else if (n == "tail_digits_early") { if (value < 0 || value > 1) { ctx->err = "tail_digits_early must be 0 or 1"; return ZKPOR_E_ARG; } ctx->tail_digits_early = (int)value; }
+    else if (n == "tail_streams") {
+        if (value < 0 || value > 1) { ctx->err = "tail_streams must be 0 or 1"; return ZKPOR_E_ARG; }
+        ctx->tail_streams = (int)value;
+    }
+    else if (n == "stream_priority") {
+        if (value < 0 || value > 1) { ctx->err = "stream_priority must be 0 or 1"; return ZKPOR_E_ARG; }
+        if (!ctx->own_stream) { ctx->err = "stream_priority: the context runs on the caller's stream (zkpor_init): create that stream with the priority you want"; return ZKPOR_E_STATE; }
+        if ((int)value != ctx->stream_priority) {
+            int lo = 0, hi = 0;
+            ZK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            hipStream_t fresh = nullptr;
+            if (value == 1 && hi != lo) ZK_HIP(ctx, hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, hi));
+            else ZK_HIP(ctx, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+            ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->retired_streams.push_back(ctx->stream);      // not destroyed while events of the context may name it (common.cuh)
+            ctx->stream = fresh;
+            ctx->stream_priority = (int)value;
+        }
     }
     else if (n == "tail_aux_masked") { if (value < 0 || value > 1) { ctx->err = "tail_aux_masked must be 0 or 1"; return ZKPOR_E_ARG; } ctx->tail_aux_masked = (int)value; }
     else if (n == "debug_validate") { if (value < 0 || value > 1) { ctx->err = "debug_validate must be 0 or 1"; return ZKPOR_E_ARG; } ctx->debug_validate = (int)value; }

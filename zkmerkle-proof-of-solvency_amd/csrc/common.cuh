@@ -65,6 +65,7 @@ struct zkpor_ctx {
     int ntt_twiddles = 0;            // inter-pass twiddles of the fields whose table exceeds the L2 (2 GiB per direction at 2^26): 0 = read from the table, 1 = generated from two half tables (one more product per element, 15 GB less traffic per computeH)
     int ntt_fuse = 1;                // computeH: the two passes over the lowest field (inverse DIF last, coset DIT first) in one kernel (ntt.hip k_ntt_mid29)
     int sort_grid = 0;               // workgroups of the digit-stream sort's persistent kernels (sort.hip): 0 = two per compute unit
+    int sort_generic = 0;            // 1: the runtime-window level 0 of the sort even for the shapes that have a compile-time one (tests compare the two)
     int sort_tile = 0;               // entries a sort workgroup stages in LDS at a time: 0 = 4096 (40 KB of LDS), 2048 (24 KB), 1024 (16 KB)
     int aux_priority = 0;            // 1: the auxiliary (digit-stream) HIP stream is created with the highest stream priority
     int solver_defer_checks = 1;     // with zkpor_solver_set_abc_dev: the run leaves its CHECK instructions (assertions) out and zkpor_solver_eval_abc_dev verifies a x b = c on EVERY row; 0 = the run executes them
@@ -79,13 +80,18 @@ struct zkpor_ctx {
     int tail_reserve_cus = 0;        // > 0: the prove tail's kernels (NTT passes, digit streams, accumulations) run on streams whose CU mask leaves this many
                                      // compute units free (evenly over the XCDs) — for the narrow, dependent launches of ANOTHER worker's solver program, which
                                      // otherwise queue behind full-size MSM grids (solve(i+1) beside tail(i): host/prover_host.hpp workers, bench.py end_to_end)
+    int tail_digits_early = 1;       // a tail that has to wait for the device turn builds its digit stream of w first, beside the other worker's tail (groth16.hip prove_sums)
+    int tail_streams = 0;            // 1: the prove tail runs on its own pair of streams (hardware queues of their own) and takes the device turn even WITHOUT a reserve
+                                     // (tail_reserve_cus 0: every compute unit) — for workers whose solver runs on a high-priority stream ("stream_priority")
+    int stream_priority = 0;         // 1: the context's own stream was re-created with the highest stream priority (the solver's narrow dependent launches then get the
+                                     // compute units that free up before another worker's full-size tail grids do, without a CU reserve)
     int tail_aux_masked = 0;         // 1: the digit streams of a masked tail keep to the tail's CU mask; 0: they may use the reserved units too
     // The masked streams, created on first use and NEVER destroyed before the context itself: one (main, aux) pair per value "tail_reserve_cus" has
     // had (at most TAIL_SETS_MAX values per context), tail_aux_free (every CU, own hardware queue) once.  Round 5 destroyed and re-created them when the
     // parameter changed and the second generation crashed inside the HIP runtime: events of the context (the phase timers' pending pairs, the pool)
     // still name the stream they were last recorded on.  tail_stream / tail_aux are the pair of the current value (null until a tail has run with it).
     struct TailSet { int reserve; hipStream_t main, aux; };
-    static constexpr size_t TAIL_SETS_MAX = 4;
+    static constexpr size_t TAIL_SETS_MAX = 5;
     std::vector<TailSet> tail_sets;
     hipStream_t tail_stream = nullptr, tail_aux = nullptr, tail_aux_free = nullptr;
     std::vector<hipStream_t> retired_streams;   // streams a handle of this context replaced (a solver's first side streams): destroyed with the context

@@ -605,7 +605,7 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     // the mask is for a tail that runs BESIDE another worker's device solve (the *_dev split: zkpor_solver_start_dev ... zkpor_prove_tail_dev).  A
     // host-pointer call holds the device turn from before its own solve to its last kernel — no solve ever overlaps its tail — so masking it would only
     // take compute units away from VALU-bound kernels (up to 12 % per tail on the dispatcher's host-solver path)
-    const bool masked = ctx->tail_reserve_cus > 0 && !host && !turn;
+    const bool masked = (ctx->tail_reserve_cus > 0 || ctx->tail_streams) && !host && !turn;
     if (masked) {
         // "tail_reserve_cus": everything the tail queues goes to two streams whose CU mask leaves some compute units free.  A mask bit i is
         // compute unit i / 8 of XCD i % 8 on this part (the driver deals the bits round-robin over the XCDs), so clearing the first R bits
@@ -634,8 +634,15 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     struct EvGuard { zkpor_ctx* c; hipEvent_t e[7]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up, e_wB, e_wK}, caller_s};
     // several workers of a GPU with a reserved-CU tail: ONE prove tail at a time (two would only time-slice each other on the same compute units), so
     // that the other worker's SOLVE is what runs beside it; the waiting worker sleeps here, its solver's prefetched chains keep running
+    // Round 6: when ANOTHER worker's tail holds the device, this proof's digit stream of w (decompose + sort + filters: bandwidth and LDS, no field
+    // arithmetic) is built BEFORE the turn is waited for — beside the other tail's accumulations, where LDS is free — instead of beside this proof's
+    // own NTT passes, whose four 36 KB tiles per compute unit it would displace ("tail_digits_early", default 1; a free device keeps the usual order).
     GpuTurn own_turn;
-    if (masked) { own_turn.acquire(ctx); turn = &own_turn; }
+    bool early_digits = false;
+    if (masked) {
+        if (ctx->tail_digits_early && do_w && !host && !own_turn.try_acquire(ctx)) early_digits = true;
+        else { own_turn.acquire(ctx); turn = &own_turn; }       // (a no-op when try_acquire got it)
+    }
     if (main_s != caller_s) {   // whatever the caller queued on the context's stream (the solver, a / b / c, uploads) comes first
         ZK_HIP(ctx, hipEventRecord(e_start, caller_s));
         ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_start, 0));
@@ -668,6 +675,27 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
                     (void*)pk->Z, (void*)pk->B2, (void*)pk->absentB, (void*)pk->absentK, (void*)pin, fr >> 20);
         }
     }
+    DigitStream dsw, dsh, dswB, dswK;
+    auto digits_w = [&](hipEvent_t after) -> int32_t {   // the digit stream of the witness on the auxiliary stream (serves A, B1, B2, K)
+        ctx->stream = aux_s;
+        // `after` orders the digit kernels (they write the shared workspace, they read w) behind whatever is already queued on the main / the caller's stream —
+        // also on the host path, where e_up (the copy stream) alone would not; free when that stream is idle
+        ZK_HIP(ctx, hipStreamWaitEvent(aux_s, after, 0));
+        if (host) ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_up, 0));
+        // e_w: the sorted shared stream (A starts on it); e_wB: + the B filter; e_wK: + the K filter (the filters hide under A)
+        ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw, n_filters ? &filt : nullptr, &dswB, &dswK, e_w, e_wB));
+        ZK_HIP(ctx, hipEventRecord(e_wK, aux_s));
+        ctx->stats["msm_entries_w"] = dsw.M; ctx->stats["msm_entries_w_B"] = dswB.M; ctx->stats["msm_entries_w_K"] = dswK.M;   // bucket additions of A / B1, B2 / K
+        ctx->stream = main_s;
+        return ZKPOR_OK;
+    };
+    size_t off_dh = need_dw;
+    if (early_digits) {
+        if (main_s == caller_s) ZK_HIP(ctx, hipEventRecord(e_start, caller_s));     // (else recorded above: everything the caller queued, the solver's w included)
+        ZK_TRY(digits_w(e_start));
+        off_dh = ctx->ws_off;
+        own_turn.acquire(ctx); turn = &own_turn;
+    }
     ZK_HIP(ctx, hipEventRecord(e_start, main_s));
     if (host) {
         // w first: everything the witness sums need
@@ -679,9 +707,7 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         else ZK_TRY(compute_h_dev(ctx, n, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c));
     }
     if (!host) ZK_HIP(ctx, hipEventRecord(e_h, main_s));
-    // 2. digit stream of the witness on the auxiliary stream (serves A, B1, B2, K)
-    DigitStream dsw, dsh, dswB, dswK;
-    size_t off_dh = need_dw;
+    // 2. digit stream of the witness on the auxiliary stream (unless it was built before the turn)
     const size_t mark = need_dw + need_dh;
     MsmPending pA, pB1, pK, pB2, pZ;
     auto queue_b2 = [&]() -> int32_t {
@@ -689,17 +715,10 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         return msm_accumulate_launch<Fp2>(ctx, dswB, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2);
     };
     if (do_w) {
-        ctx->stream = aux_s;
-        // e_start orders the digit kernels (they write the shared workspace) after whatever is already queued on the main stream —
-        // also on the host path, where e_up (the copy stream) alone would not; free when the main stream is idle
-        ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_start, 0));
-        if (host) ZK_HIP(ctx, hipStreamWaitEvent(aux_s, e_up, 0));
-        // e_w: the sorted shared stream (A starts on it); e_wB: + the B filter; e_wK: + the K filter (the filters hide under A)
-        ZK_TRY(msm_digits(ctx, (const Fr*)d_w, pk->n_wires, cfgw, sortw, &dsw, n_filters ? &filt : nullptr, &dswB, &dswK, e_w, e_wB));
-        ZK_HIP(ctx, hipEventRecord(e_wK, aux_s));
-        ctx->stats["msm_entries_w"] = dsw.M; ctx->stats["msm_entries_w_B"] = dswB.M; ctx->stats["msm_entries_w_K"] = dswK.M;   // bucket additions of A / B1, B2 / K
-        off_dh = ctx->ws_off;
-        ctx->stream = main_s;
+        if (!early_digits) {
+            ZK_TRY(digits_w(e_start));
+            off_dh = ctx->ws_off;
+        }
         // 3. queue the witness accumulations (they reuse one workspace region in stream order)
         ctx->ws_off = mark;
         // "msm_filter" 2: A waits for the filter as well, so that the filter runs on an otherwise idle GPU (with a full-size grid) instead of

@@ -731,7 +731,7 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
 // four they would sit in front of some other stream's kernels (common.cuh stream_create_own_queue)
 int32_t solver_side_queues(zkpor_solver* s) {
     zkpor_ctx* ctx = s->ctx;
-    if (ctx->tail_reserve_cus <= 0 || s->side_own_queue) return ZKPOR_OK;
+    if ((ctx->tail_reserve_cus <= 0 && !ctx->tail_streams) || s->side_own_queue) return ZKPOR_OK;
     if (s->running || s->side_busy || s->side2_busy) return ZKPOR_OK;      // not under a run or a chain in flight: next time
     hipStream_t a = nullptr, b = nullptr;
     ZK_TRY(stream_create_own_queue(ctx, &a, 0));

@@ -189,6 +189,129 @@ __global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter0(const Fr* __restr
     }
 }
 
+// ---- level 0 with the window, the digit count and the table count known at compile time (the production shapes) ----
+// The generic kernels above shift the whole 256-bit scalar once per digit and recompute the digits in every pass (about 1 700 VALU instructions per
+// scalar, zero or not); the main stream's kernels are VALU-bound, so every instruction here is paid for there (profiles/r06_sort_grid_tile_sweep.json).
+// With C, W, M constant a digit is two static-index shifts, the W keys stay in registers between the passes, and a scalar whose words are all zero
+// (half of a solved wire vector) is skipped before its Montgomery reduction.
+template <int C, int W, int M>
+ZK_D u32 ds_digits_static(const Fr& s, u32 (&key)[W], u32& neg) {
+    constexpr int PIECE = (W + M - 1) / M;
+    constexpr u32 HALF = 1u << (C - 1), MASK = (1u << C) - 1u;
+    u32 carry = 0, nz = 0;
+    neg = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int bit = w * C, limb = bit >> 5, off = bit & 31;
+        u32 d = limb < 8 ? s.v[limb < 8 ? limb : 7] >> off : 0u;
+        if (off + C > 32 && limb + 1 < 8) d |= s.v[limb + 1 < 8 ? limb + 1 : 7] << (32 - off);
+        d = (d & MASK) + carry;
+        carry = d > HALF ? 1u : 0u;
+        d = carry ? (1u << C) - d : d;
+        const int q = w / PIECE;
+        key[w] = (u32)(w - q * PIECE) * HALF + (d - 1u);
+        nz |= (d ? 1u : 0u) << w;
+        neg |= carry << w;
+    }
+    return nz;
+}
+ZK_D bool fr_words_zero(const Fr& s) { return (s.v[0] | s.v[1] | s.v[2] | s.v[3] | s.v[4] | s.v[5] | s.v[6] | s.v[7]) == 0u; }
+
+template <int C, int W, int M>
+__global__ __launch_bounds__(DS_THREADS) void k_dsort_count0_s(const Fr* __restrict__ scalars, u32 n, int shift0, u32 nb0, u32* __restrict__ C0,
+                                                               u32* __restrict__ counter, u32* __restrict__ ticket, const u32* __restrict__ absent0,
+                                                               const u32* __restrict__ absent1) {
+    __shared__ u32 cnt[DS_NB];
+    __shared__ u32 s_ticket;
+    for (u32 i = threadIdx.x; i < nb0; i += DS_THREADS) cnt[i] = 0u;
+    u32 tot = 0, tot0 = 0, tot1 = 0;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const u32 base = s_ticket * DS_SCALARS_PER_TICKET;
+        if (base >= n) break;
+        for (u32 i = base + threadIdx.x; i < base + DS_SCALARS_PER_TICKET && i < n; i += DS_THREADS) {
+            const Fr raw = scalars[i];
+            if (fr_words_zero(raw)) continue;
+            const Fr t = Fr::from_mont(raw);
+            u32 key[W], neg;
+            const u32 nz = ds_digits_static<C, W, M>(t, key, neg);
+#pragma unroll
+            for (int w = 0; w < W; ++w) if ((nz >> w) & 1u) atomicAdd(&cnt[key[w] >> shift0], 1u);
+            const u32 c_here = (u32)__popc(nz);
+            tot += c_here;
+            if (absent0 || absent1) {
+                const u32 word = i >> 5, bit = i & 31u;
+                if (!(absent0 && ((absent0[word] >> bit) & 1u))) tot0 += c_here;
+                if (!(absent1 && ((absent1[word] >> bit) & 1u))) tot1 += c_here;
+            }
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < nb0; i += DS_THREADS) if (cnt[i]) atomicAdd(C0 + i, cnt[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { tot += __shfl_down(tot, off); tot0 += __shfl_down(tot0, off); tot1 += __shfl_down(tot1, off); }
+    if ((threadIdx.x & 63u) == 0u) {
+        if (tot) atomicAdd(counter, tot);
+        if (tot0) atomicAdd(counter + 1, tot0);
+        if (tot1) atomicAdd(counter + 2, tot1);
+    }
+}
+
+template <int C, int W, int M>
+__global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter0_s(const Fr* __restrict__ scalars, u32 n, int shift0, u32 nb0, u32* __restrict__ C0,
+                                                                 u32* __restrict__ ticket, const u32* __restrict__ absent0, const u32* __restrict__ absent1,
+                                                                 u32* __restrict__ out_k, u32* __restrict__ out_v) {
+    static_assert(W * DS_THREADS <= 4096, "one tile holds a block's digits");
+    __shared__ DsShared<4096> S;
+    for (u32 i = threadIdx.x; i < DS_NB; i += DS_THREADS) S.cnt[i] = 0u;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) S.misc[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const u32 base = S.misc[0] * DS_SCALARS_PER_TICKET;
+        if (base >= n) break;
+        for (u32 blk = base; blk < base + DS_SCALARS_PER_TICKET && blk < n; blk += DS_THREADS) {
+            const u32 i = blk + threadIdx.x;
+            u32 key[W], neg = 0, nz = 0;
+            if (i < n) {
+                const Fr raw = scalars[i];
+                if (!fr_words_zero(raw)) nz = ds_digits_static<C, W, M>(Fr::from_mont(raw), key, neg);
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w) if ((nz >> w) & 1u) atomicAdd(&S.cnt[key[w] >> shift0], 1u);
+            u32 x = (u32)__popc(nz);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off);
+            if ((threadIdx.x & 63u) == 0u) S.misc[4 + (threadIdx.x >> 6)] = x;
+            __syncthreads();
+            const u32 len = S.misc[4] + S.misc[5] + S.misc[6] + S.misc[7];
+            if (len == 0u) { __syncthreads(); continue; }            // a block of zero scalars (uniform: every thread read the same sums)
+            ds_reserve(S, nb0, C0, 0u, nb0);
+            if (nz) {
+                u32 flags = 0;
+                if (absent0 || absent1) {   // bits 30 / 31 of every value this scalar emits: its point is absent from group 0 / 1
+                    const u32 word = i >> 5, bit = i & 31u;
+                    if (absent0 && ((absent0[word] >> bit) & 1u)) flags |= VAL_ABSENT0;
+                    if (absent1 && ((absent1[word] >> bit) & 1u)) flags |= VAL_ABSENT1;
+                }
+                constexpr int PIECE = (W + M - 1) / M;
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    if ((nz >> w) & 1u) {
+                        const u32 p = atomicAdd(&S.cur[key[w] >> shift0], 1u);
+                        S.sk[p] = key[w];
+                        S.sv[p] = ((i * (u32)M + (u32)(w / PIECE)) << 1) | ((neg >> w) & 1u) | flags;
+                    }
+            }
+            __syncthreads();
+            ds_write_out(S, len, shift0, 0xffffffffu, out_k, out_v);
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ levels >= 1
 // first index s in [0, n_par) with ends[s] > pos (ends ascending, ends[n_par - 1] > pos): a 256-ary search, one probe per thread and round
 template <class SH>
@@ -387,6 +510,8 @@ int32_t digit_sort(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg
         grid = 2 * prop.multiProcessorCount;      // two 256-thread workgroups per compute unit: bandwidth, not wave slots
     }
     const int tile = ctx->sort_tile == 1024 || ctx->sort_tile == 2048 ? ctx->sort_tile : 4096;
+    // the shapes with a compile-time level 0: 22-bit windows over 4 tables (the production key), 20-bit windows over plain arrays; "sort_generic" 1 = never
+    const int spec = (ctx->sort_generic || tile != 4096) ? 0 : (cfg.c == 22 && cfg.W == 12 && cfg.m == 4) ? 1 : (cfg.c == 20 && cfg.W == 13 && cfg.m == 1) ? 2 : 0;
     u32* C[4];
     for (int l = 0; l < plan.nlev; ++l) C[l] = (u32*)(temp + plan.off_C[l]);
     u32* bs = (u32*)(temp + plan.off_bs);
@@ -397,7 +522,9 @@ int32_t digit_sort(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg
         ZK_HIP(ctx, hipMemsetAsync(temp, 0, plan.off_bs, ctx->stream));
         const u32 tickets0 = (n + DS_SCALARS_PER_TICKET - 1u) / DS_SCALARS_PER_TICKET;
         const u32 g0 = tickets0 < (u32)grid ? tickets0 : (u32)grid;
-        hipLaunchKernelGGL(k_dsort_count0, dim3(g0 ? g0 : 1u), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], counter, ticket,
+        if (spec == 1) hipLaunchKernelGGL((k_dsort_count0_s<22, 12, 4>), dim3(g0 ? g0 : 1u), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, plan.shift[0], plan.n_child[0], C[0], counter, ticket, absent0, absent1);
+        else if (spec == 2) hipLaunchKernelGGL((k_dsort_count0_s<20, 13, 1>), dim3(g0 ? g0 : 1u), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, plan.shift[0], plan.n_child[0], C[0], counter, ticket, absent0, absent1);
+        else hipLaunchKernelGGL(k_dsort_count0, dim3(g0 ? g0 : 1u), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], counter, ticket,
                            absent0, absent1);
         ZK_KERNEL_CHECK(ctx);
     }
@@ -411,7 +538,9 @@ int32_t digit_sort(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg
         ZK_TRY(scan_in_place(ctx, C[0], plan.n_child[0], bs));
         const u32 tickets0 = (n + DS_SCALARS_PER_TICKET - 1u) / DS_SCALARS_PER_TICKET;
         const u32 g0 = tickets0 < (u32)grid ? tickets0 : (u32)grid;
-        if (tile == 1024) hipLaunchKernelGGL(k_dsort_scatter0<1024>, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
+        if (spec == 1) hipLaunchKernelGGL((k_dsort_scatter0_s<22, 12, 4>), dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
+        else if (spec == 2) hipLaunchKernelGGL((k_dsort_scatter0_s<20, 13, 1>), dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
+        else if (tile == 1024) hipLaunchKernelGGL(k_dsort_scatter0<1024>, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
         else if (tile == 2048) hipLaunchKernelGGL(k_dsort_scatter0<2048>, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
         else hipLaunchKernelGGL(k_dsort_scatter0<4096>, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
         ZK_KERNEL_CHECK(ctx);
