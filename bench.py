@@ -1027,7 +1027,7 @@ class EndToEnd:
             wk["ctx"].set_param("tail_reserve_cus", self.reserve)
             if aux_masked >= 0:
                 wk["ctx"].set_param("tail_aux_masked", aux_masked)
-            for name_ in ("sort_grid", "sort_tile", "ntt_twiddles"):     # worker contexts take the main context's sort settings (--sort-grid / --sort-tile)
+            for name_ in ("sort_grid", "sort_tile", "ntt_twiddles", "sort_stage"):     # worker contexts take the main context's sort settings (--sort-grid / --sort-tile)
                 if sort_params and sort_params.get(name_, -1) >= 0:
                     wk["ctx"].set_param(name_, sort_params[name_])
             if solver_rows:
@@ -1305,9 +1305,10 @@ def main():
                     "4 holds the key as 4 interleaved tables (112 GB of the 288 GB at 2^26) and buys 12 digits of 22 bits instead of "
                     "13 of 20 at the same number of buckets — 6 %% fewer bucket additions (profiles/r02_tables.txt)")
     ap.add_argument("--sort-grid", type=int, default=-1, help="experiment: workgroups of the digit-stream sort's persistent kernels (sort_grid; library default: two per compute unit)")
-    ap.add_argument("--tail-mode", type=int, default=0, help="experiment, 2 workers: 1 = the prove tail on its own streams + the device turn WITHOUT a CU reserve "
+    ap.add_argument("--tail-mode", type=int, default=1, help="experiment, 2 workers: 1 = the prove tail on its own streams + the device turn WITHOUT a CU reserve "
                     "(tail_streams), 2 = and the workers' own streams (solver, a / b / c, commitment) at the highest stream priority (stream_priority)")
     ap.add_argument("--ntt-twiddles", type=int, default=-1, help="experiment: 1 = the highest field's inter-pass twiddles generated from two half tables instead of read from its 2 GiB table (ntt_twiddles)")
+    ap.add_argument("--sort-stage", type=int, default=-1, help="experiment: 0 = the sort's scatter passes store straight to memory (4 KB of LDS per workgroup), 1 = staged through LDS (sort_stage)")
     ap.add_argument("--sort-tile", type=int, default=-1, help="experiment: entries a sort workgroup stages in LDS at a time (sort_tile: 1024 / 2048 / 4096)")
     ap.add_argument("--no-filter", action="store_true", help="experiment: accumulate B1 / B2 / K from the shared digit stream of w instead of the "
                     "per-array streams without the entries of absent points (context parameter msm_filter 0)")
@@ -1334,10 +1335,10 @@ def main():
     ap.add_argument("--tail-steps", type=int, default=-1, help="circuit mode: proofs of the prove-tail-only region (`prove_tail`); default max(3, steps // 4)")
     ap.add_argument("--e2e-workers", type=int, default=2, help="worker contexts per GPU in the end-to-end region: 2 = one proof's solver program runs beside the other's prove tail")
     ap.add_argument("--tail-aux-masked", type=int, default=-1, help="experiment: 1 = the digit streams of a CU-masked tail keep to the tail's mask (library default 0: they may use the reserved units)")
-    ap.add_argument("--e2e-sweep", default="", help="experiment: extra end-to-end regions, 'workers:reserve_cus[:aux_masked]' separated by commas (e.g. 1:0,2:0,2:16,2:64:1), "
-                    "each --e2e-steps proofs, reported under end_to_end.sweep.  KNOWN: a second setting with reserved compute units segfaults inside zkpor_prove_tail_dev "
-                    "(a context's masked streams destroyed and created again; DESIGN.md 6c) - one setting per process")
-    ap.add_argument("--tail-reserve-cus", type=int, default=32, help="with 2 workers: compute units the prove tail's CU mask leaves free for the other worker's solver launches (0 = none; multiple of 8)")
+    ap.add_argument("--e2e-sweep", default="", help="experiment: extra end-to-end regions, 'workers:reserve_cus[:aux_masked[:sort_grid[:sort_tile[:ntt_twiddles[:tail_mode[:sort_stage]]]]]]' "
+                    "separated by commas (e.g. 1:0,2:32,2:0:0:128:4096:0:1), each --e2e-steps proofs, reported under end_to_end.sweep.  Do not walk through many reserve "
+                    "values in one process: every value adds hardware queues that stay (profiles/r06_tail_mode_sweep.json)")
+    ap.add_argument("--tail-reserve-cus", type=int, default=0, help="with 2 workers: compute units the prove tail's CU mask leaves free for the other worker's solver launches (0 = none; multiple of 8)")
     ap.add_argument("--share-device", action="store_true", help="TEST ONLY: every rank proves on device 0 and the ranks meet over gloo — the launcher, the per-rank "
                     "merge of the line, the check budgeting and the key build under contention exercised on a one-GPU box; the line says so and is no measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1419,6 +1420,8 @@ def main():
         ctx.set_param("sort_tile", args.sort_tile)
     if args.ntt_twiddles >= 0:
         ctx.set_param("ntt_twiddles", args.ntt_twiddles)
+    if args.sort_stage >= 0:
+        ctx.set_param("sort_stage", args.sort_stage)
     if args.no_filter:
         ctx.set_param("msm_filter", 0)
     if args.no_ntt_fuse:
@@ -1726,7 +1729,7 @@ def main():
         def make(workers, reserve, tail_mode=None):
             return EndToEnd(torch, zkpor, C, ctx, local_rank, pk, circ["cir"], dc, circ["d_in"], circ["inp"], D, n_commit, dev, blinding, (a, b, c), workers, reserve,
                             solver_rows=not args.no_solver_rows, prefetch=not args.no_prefetch, aux_masked=args.tail_aux_masked,
-                            sort_params={"sort_grid": args.sort_grid, "sort_tile": args.sort_tile, "ntt_twiddles": args.ntt_twiddles},
+                            sort_params={"sort_grid": args.sort_grid, "sort_tile": args.sort_tile, "ntt_twiddles": args.ntt_twiddles, "sort_stage": args.sort_stage},
                             tail_mode=args.tail_mode if tail_mode is None else tail_mode)
 
         def region(E, first, n, sink, tm_acc=None, upload=False, warm=1):
@@ -1741,7 +1744,7 @@ def main():
 
             dt_ = timed_region(dist, torch.cuda.synchronize, timed)
             return {"value": world * n / dt_, "unit": "proofs/s", "ms_per_proof": dt_ / n * 1e3, "steps": n, "workers_per_gpu": len(E.wk),
-                    "tail_reserve_cus": E.reserve, "per_rank_ms_per_proof": [round(row[0], 3) for row in gather_per_rank(dist, [loc[0] / n * 1e3])]}
+                    "tail_reserve_cus": E.reserve, "tail_mode": E.tail_mode, "per_rank_ms_per_proof": [round(row[0], 3) for row in gather_per_rank(dist, [loc[0] / n * 1e3])]}
 
         try:
             E = make(n_workers, args.tail_reserve_cus)
@@ -1766,7 +1769,8 @@ def main():
                     "(host/circuit/: the image has no Go, gnark's own compiled system cannot be exported here; gadget expansions recalled, "
                     "constraint count within 7 % of the reference's README), a synthetic VALID batch (its hashes are the oracle's), inputs resident "
                     "in HBM, solver program + BSB22 commitment + a, b, c + prove tail on the device; the challenge is hashed on the host.  "
-                    f"{len(E.wk)} worker(s) per GPU: one proof's solve runs beside the other's prove tail" + (f", whose kernels leave {E.reserve} of the compute units free" if E.reserve else "")})
+                    f"{len(E.wk)} worker(s) per GPU: one proof's solve runs beside the other's prove tail" + (f", whose kernels leave {E.reserve} of the compute units free" if E.reserve else "")
+                    + (" (the tail on hardware queues of its own, one tail at a time, no compute unit reserved: tail_streams)" if E.tail_mode else "")})
         e2e["same_wires_as_headline"] = E.same_wires(w) if args.scalars == "witness" else None
         e2e["bucket_additions_per_proof"] = {k_: ctx.stat(k_) for k_ in ("msm_entries_w", "msm_entries_w_B", "msm_entries_w_K", "msm_entries_h")}   # sorted digit-stream entries of A / B1, B2 / K / Z
         last_w = E.wk[0]["last"]
@@ -1804,6 +1808,7 @@ def main():
                         wk_["ctx"].set_param("sort_grid", parts[3] if len(parts) > 3 else max(0, args.sort_grid))
                         wk_["ctx"].set_param("sort_tile", parts[4] if len(parts) > 4 else max(0, args.sort_tile))
                         wk_["ctx"].set_param("ntt_twiddles", parts[5] if len(parts) > 5 else max(0, args.ntt_twiddles))      # field 6: 1 = inter-field twiddles generated, not read
+                        wk_["ctx"].set_param("sort_stage", parts[7] if len(parts) > 7 else (1 if args.sort_stage < 0 else args.sort_stage))   # field 8: 0 = the sort's entries straight to memory
                     r_ = region(Es, 20001 + 1000 * k_, max(2, args.e2e_steps if args.e2e_steps > 0 else 4), e2e_proofs, None)
                     r_["same_wires"] = Es.same_wires(w) if args.scalars == "witness" else None
                     r_["spec"] = spec
@@ -1814,7 +1819,7 @@ def main():
                 except Exception as ex_:      # noqa: BLE001
                     sweep.append({"spec": spec, "note": f"failed: {ex_}"})
             ctx.set_param("tail_aux_masked", 0 if args.tail_aux_masked < 0 else args.tail_aux_masked)
-            ctx.set_param("sort_grid", max(0, args.sort_grid)); ctx.set_param("sort_tile", max(0, args.sort_tile)); ctx.set_param("ntt_twiddles", max(0, args.ntt_twiddles))
+            ctx.set_param("sort_grid", max(0, args.sort_grid)); ctx.set_param("sort_tile", max(0, args.sort_tile)); ctx.set_param("ntt_twiddles", max(0, args.ntt_twiddles)); ctx.set_param("sort_stage", 1 if args.sort_stage < 0 else args.sort_stage)
             e2e["sweep"] = sweep
         e2e["next_proofs_hash_chains_prefetched"] = not args.no_prefetch
         e2e["poseidon_rows_written_by_the_solver"] = not args.no_solver_rows
@@ -2005,7 +2010,8 @@ def main():
                                     f"blinding: {circ['cir'].n_constraints} constraints (D=2^{log2}), {n_wires} wires, {n_commit} committed wires, key with the "
                                     f"circuit's sparsity as {tables_used} fixed-base table(s) per point, a synthetic valid batch of {circ['shape'][2]} users, "
                                     f"{e2e['workers_per_gpu']} worker(s) per GPU (solve of one proof beside the prove tail of the other"
-                                    + (f", {e2e['tail_reserve_cus']} compute units kept out of the tail's CU mask" if e2e['tail_reserve_cus'] else "") + ")",
+                                    + (f", {e2e['tail_reserve_cus']} compute units kept out of the tail's CU mask" if e2e['tail_reserve_cus'] else "")
+                                    + (", the tail on hardware queues of its own, one tail at a time, no compute unit reserved" if e2e.get("tail_mode") else "") + ")",
                         "tier": args.config, "users_per_batch": circ["shape"][2], "assets_per_user": circ["shape"][0],
                         "scalars": "generated" if args.scalars == "witness" else "uniform",
                         "scalar_mix_measured": scalar_mix,

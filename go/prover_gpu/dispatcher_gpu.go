@@ -71,10 +71,12 @@ func (p *Prover) RunInProcess(rerun bool, gpus []int, workersPerGPU int) error {
 			}
 			defer ctx.Close()
 			if workersPerGPU > 1 {
-				// round 5: the prove tail's kernels leave 32 of the 256 compute units free (a CU mask on their HIP streams), so that the OTHER worker's solver
-				// program — ~100 narrow, dependent launches — starts at once instead of queueing behind full-size MSM grids: one proof's solve under the
-				// other's prove tail (DESIGN.md §6c; bench.py end_to_end).  Harmless with a host solver (nothing then runs beside the tail but copies).
-				if err := ctx.SetParam("tail_reserve_cus", 32); err != nil {
+				// round 6: with several workers per GPU the prove tail runs on HIP streams with hardware queues of their own and takes the device turn — ONE
+				// tail at a time, the other worker's solver program beside it, competing for compute units as they free up ("tail_streams"; no compute unit is
+				// reserved any more: round 5's 32-unit reserve cost every tail 12.5 % of the machine, 339 -> 328 ms per zkpor50_1380 proof,
+				// profiles/r06_ab_reserve_vs_own_queues.json).  It applies to the device-solver path only (ProveOnDevice: zkpor_solver_* ... zkpor_prove_tail_dev);
+				// a host-pointer call (Prove: gnark's solver on the host, then zkpor_prove_tail) holds the turn over its whole device part and is never masked.
+				if err := ctx.SetParam("tail_streams", 1); err != nil {
 					return fmt.Errorf("GPU %d: %w", g, err)
 				}
 			}

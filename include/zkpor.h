@@ -97,6 +97,14 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * "msm_reduce_scan" (1, the default: the small levels of the bucket reduction run one lane — G2: one lane pair — per bucket; 2: G1
  * only; 0: the serial walk),
  * "msm_filter" (1, the default: B1 / B2 and K accumulate from the witness digit stream minus the entries of their absent points),
+ * the digit-stream sort's (csrc/sort.hip; rocPRIM's "sort_block" of rounds 3-5 is accepted and ignored): "sort_grid" (0, the default: the library's
+ * choice; else the number of its persistent 256-thread workgroups — what the sort costs the main stream's kernels is RESIDENCE),
+ * "sort_stage" (1: a tile's entries are staged through LDS and leave as whole runs, 40 KB per workgroup; 0: straight to memory from a 4 KB
+ * workgroup), "sort_tile" (0 = 4096: entries staged at a time, 1024 / 2048 / 4096), "sort_generic" (0; 1: the runtime-window level 0 even for the
+ * shapes that have a compile-time one — tests compare the two),
+ * "ntt_twiddles" (0, the default: the inter-pass twiddles of every index field are read from its table; 1: fields whose table exceeds 16 MiB — the
+ * highest field of a 2^26 domain, 2 GiB per direction — generate them from two half tables, one more field product per element and 15 GB less
+ * HBM traffic per computeH; measured: no faster; 2: every field, for tests),
  * "ntt_fuse" (1, the default: computeH's neighbouring passes over one index field run as one kernel),
  * "gpu_token" (1, the default: host-pointer proofs of several contexts on one GPU take turns on the device, see zkpor_prove_tail;
  * 0: their kernels share it freely), "host_order" (0, the default: a proof that finds the GPU free sends w first and a, b, c
@@ -117,6 +125,12 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * over its own solve AND tail, nothing runs beside it, and its tail keeps every compute unit.  The value may change between proofs: a context
  * keeps one pair of masked streams per value it has had (at most four different non-zero values; a fifth is ZKPOR_E_STATE and leaves the setting
  * as it was) and destroys none of them before zkpor_destroy — round 5's destroy-and-re-create crashed inside the HIP runtime),
+ * "tail_streams" (0; 1: the prove tail runs on its own streams — hardware queues of their own — and takes the device turn even WITHOUT a
+ * reserve, "tail_reserve_cus" 0: the other worker's solver launches compete for compute units as they free up instead of owning a share),
+ * "stream_priority" (0; 1: the context's own stream — solver, a / b / c, commitment — is re-created with the highest stream priority; only
+ * for contexts created without a caller's stream; measured: changes nothing next to "tail_streams"),
+ * "tail_digits_early" (1, the default: a tail that finds another worker's tail on the device builds its digit stream of w BEFORE it waits for
+ * the turn, beside that tail's accumulations, instead of beside its own NTT passes; 0: after the turn),
  * "debug_validate" (0; 1: every sorted digit stream is checked on the device before its accumulation reads it — keys ascending and
  * below the bucket count, point indices inside the key array — and a violation is ZKPOR_E_STATE instead of a GPU memory fault) */
 int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value);

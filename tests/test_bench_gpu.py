@@ -79,9 +79,9 @@ def test_bench_circuit_mode_end_to_end():
     mix = cfgd["scalar_mix_measured"]
     assert abs(mix["in_{0,1}"] + mix["below_2^16"] + mix["below_2^64"] + mix["wider"] - 1.0) < 1e-3 and mix["in_{0,1}"] > 0.3
     e = d["end_to_end"]
-    # the headline IS the end-to-end region: exactly --steps proofs, two workers of the GPU, compute units reserved for the solver's launches
+    # the headline IS the end-to-end region: exactly --steps proofs, two workers of the GPU, the tail on its own hardware queues and no compute unit reserved (round 6)
     assert e["steps"] == d["steps"] == 3 and e["value"] == d["value"] == d["end_to_end_value"] and e["ms_per_proof"] == d["ms_per_step"] == d["end_to_end_ms_per_proof"]
-    assert abs(e["value"] - 1e3 / e["ms_per_proof"]) < 1e-6 * e["value"] and e["workers_per_gpu"] == 2 and e["tail_reserve_cus"] == 32
+    assert abs(e["value"] - 1e3 / e["ms_per_proof"]) < 1e-6 * e["value"] and e["workers_per_gpu"] == 2 and e["tail_reserve_cus"] == 0 and e["tail_mode"] == 1
     assert len(d["per_rank_ms_per_step"]) == 1 and d["what_value_is"].startswith("END TO END")
     up = e["with_input_upload"]                                    # the same with the assigned inputs uploaded from pageable host memory, every proof
     assert up["steps"] == 3 and up["value"] > 0 and up["same_wires"] is True and up["input_bytes_per_proof"] > 32 * 1000 and d["end_to_end_with_input_upload_value"] == up["value"]

@@ -12,6 +12,15 @@ import zkpor
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["staged", "lite"])
+def _scatter_form(zk, request):
+    """every case through both forms of the scatter passes: a tile's entries staged through LDS (whole runs per store) and straight to memory
+    from a 4 KB workgroup ("sort_stage" 0)"""
+    zk.set_param("sort_stage", request.param)
+    yield
+    zk.set_param("sort_stage", 1)
+
+
 def _expected(ints, c, W, piece, bpw, tables, absent0=None, absent1=None):
     """the decomposition in Python integers: digit w of scalar i, signed, in (-2^(c-1), 2^(c-1)]"""
     half = 1 << (c - 1)

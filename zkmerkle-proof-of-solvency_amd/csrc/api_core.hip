@@ -225,6 +225,9 @@ void stream_release_own_queue(int device, hipStream_t st, int reserve_cus) {
     if (!st) return;
     (void)hipStreamSynchronize(st);
     std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    // an idle hardware queue is not free: a process that had collected ~25 of them (a sweep over five reserve values, two workers each) ran the SAME
+    // region 1.7x slower than at its start (profiles/r06_tail_mode_sweep.json) — the pool is for re-use by the next context, not a museum
+    if (g_stream_pool.size() >= 12) { (void)hipStreamDestroy(st); return; }
     try { g_stream_pool.push_back({device, reserve_cus, st}); } catch (...) { /* out of host memory: the stream is leaked, not destroyed */ }
 }
 int32_t stream_create_own_queue(zkpor_ctx* ctx, hipStream_t* out, int reserve_cus) {
@@ -433,7 +436,7 @@ void zkpor_destroy(zkpor_ctx* ctx) try {
     // every stream drained first, then the events (they name the stream they were last recorded on), then the streams
     (void)hipStreamSynchronize(ctx->stream);
     for (hipStream_t st : {ctx->aux_stream, ctx->copy_stream, ctx->tail_aux_free}) if (st) (void)hipStreamSynchronize(st);
-    for (auto& ts : ctx->tail_sets) { (void)hipStreamSynchronize(ts.main); (void)hipStreamSynchronize(ts.aux); }
+    for (auto& ts : ctx->tail_sets) { (void)hipStreamSynchronize(ts.main); if (ts.aux) (void)hipStreamSynchronize(ts.aux); }
     for (hipStream_t st : ctx->retired_streams) (void)hipStreamSynchronize(st);
     for (auto& kv : ctx->phases)
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -488,6 +491,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "ntt_twiddles") { if (value < 0 || value > 2) { ctx->err = "ntt_twiddles must be 0 (tables), 1 (generated where the table exceeds 16 MiB) or 2 (generated everywhere)"; return ZKPOR_E_ARG; } ctx->ntt_twiddles = (int)value; }
     else if (n == "ntt_fuse") { if (value < 0 || value > 1) { ctx->err = "ntt_fuse must be 0 or 1"; return ZKPOR_E_ARG; } ctx->ntt_fuse = (int)value; }
     else if (n == "sort_grid") { if (value < 0 || value > 8192) { ctx->err = "sort_grid must be in [0,8192] (0 = two workgroups per compute unit)"; return ZKPOR_E_ARG; } ctx->sort_grid = (int)value; }
+    else if (n == "sort_stage") { if (value < 0 || value > 1) { ctx->err = "sort_stage must be 0 or 1"; return ZKPOR_E_ARG; } ctx->sort_stage = (int)value; }
     else if (n == "sort_generic") { if (value < 0 || value > 1) { ctx->err = "sort_generic must be 0 or 1"; return ZKPOR_E_ARG; } ctx->sort_generic = (int)value; }
     else if (n == "sort_tile") { if (value != 0 && value != 1024 && value != 2048 && value != 4096) { ctx->err = "sort_tile must be 0 (4096), 1024, 2048 or 4096"; return ZKPOR_E_ARG; } ctx->sort_tile = (int)value; }
     else if (n == "sort_block") { if (value != 0 && value != 256 && value != 512) { ctx->err = "sort_block must be 0, 256 or 512"; return ZKPOR_E_ARG; } }   // rounds 3-5: the workgroup size of rocPRIM's onesweep; accepted and ignored since the sort is sort.hip's

@@ -64,7 +64,8 @@ struct zkpor_ctx {
     int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 256: one per CU — bandwidth, not wave slots)
     int ntt_twiddles = 0;            // inter-pass twiddles of the fields whose table exceeds the L2 (2 GiB per direction at 2^26): 0 = read from the table, 1 = generated from two half tables (one more product per element, 15 GB less traffic per computeH)
     int ntt_fuse = 1;                // computeH: the two passes over the lowest field (inverse DIF last, coset DIT first) in one kernel (ntt.hip k_ntt_mid29)
-    int sort_grid = 0;               // workgroups of the digit-stream sort's persistent kernels (sort.hip): 0 = two per compute unit
+    int sort_grid = 0;               // workgroups of the digit-stream sort's persistent kernels (sort.hip): 0 = one per two compute units (128 on an MI355X)
+    int sort_stage = 1;              // the sort's scatter passes: 1 = a tile's entries staged through LDS (whole runs per store), 0 = straight to memory (4 KB of LDS per workgroup)
     int sort_generic = 0;            // 1: the runtime-window level 0 of the sort even for the shapes that have a compile-time one (tests compare the two)
     int sort_tile = 0;               // entries a sort workgroup stages in LDS at a time: 0 = 4096 (40 KB of LDS), 2048 (24 KB), 1024 (16 KB)
     int aux_priority = 0;            // 1: the auxiliary (digit-stream) HIP stream is created with the highest stream priority
@@ -91,7 +92,7 @@ struct zkpor_ctx {
     // parameter changed and the second generation crashed inside the HIP runtime: events of the context (the phase timers' pending pairs, the pool)
     // still name the stream they were last recorded on.  tail_stream / tail_aux are the pair of the current value (null until a tail has run with it).
     struct TailSet { int reserve; hipStream_t main, aux; };
-    static constexpr size_t TAIL_SETS_MAX = 5;
+    static constexpr size_t TAIL_SETS_MAX = 4;
     std::vector<TailSet> tail_sets;
     hipStream_t tail_stream = nullptr, tail_aux = nullptr, tail_aux_free = nullptr;
     std::vector<hipStream_t> retired_streams;   // streams a handle of this context replaced (a solver's first side streams): destroyed with the context

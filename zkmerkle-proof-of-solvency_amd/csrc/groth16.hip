@@ -610,25 +610,27 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         // "tail_reserve_cus": everything the tail queues goes to two streams whose CU mask leaves some compute units free.  A mask bit i is
         // compute unit i / 8 of XCD i % 8 on this part (the driver deals the bits round-robin over the XCDs), so clearing the first R bits
         // frees R / 8 units on each of the eight XCDs.
-        if (!ctx->tail_stream || !ctx->tail_aux || !ctx->tail_aux_free) {   // the pair of this value and the unmasked digit stream: created once, kept until the context goes
-            if (ctx->tail_sets.size() >= zkpor_ctx::TAIL_SETS_MAX && !ctx->tail_stream) { ctx->err = "prove: no masked stream pair left for this tail_reserve_cus"; return ZKPOR_E_STATE; }
-            hipStream_t st[3] = {ctx->tail_stream, ctx->tail_aux, ctx->tail_aux_free};
-            int32_t rc = ZKPOR_OK;
-            const bool new_pair = !st[0];
-            if (new_pair) { rc = stream_create_own_queue(ctx, &st[0], ctx->tail_reserve_cus); if (rc == ZKPOR_OK) rc = stream_create_own_queue(ctx, &st[1], ctx->tail_reserve_cus); }
-            const bool new_free = !st[2];
-            if (rc == ZKPOR_OK && new_free) rc = stream_create_own_queue(ctx, &st[2], 0);
-            if (rc != ZKPOR_OK) {   // nothing half-made stays behind: back to the pool
-                if (new_pair) { stream_release_own_queue(ctx->device, st[0], ctx->tail_reserve_cus); stream_release_own_queue(ctx->device, st[1], ctx->tail_reserve_cus); }
-                if (new_free) stream_release_own_queue(ctx->device, st[2], 0);
-                return rc;
-            }
-            if (new_pair) ctx->tail_sets.push_back({ctx->tail_reserve_cus, st[0], st[1]});
-            ctx->tail_stream = st[0]; ctx->tail_aux = st[1]; ctx->tail_aux_free = st[2];
+        // Only the streams this setting USES are created (an idle hardware queue is not free: profiles/r06_tail_mode_sweep.json): the main stream of this
+        // reserve value; for the digit streams either the masked one of the pair ("tail_aux_masked" 1) or the unmasked one (0, the default; with a
+        // reserve of 0 — "tail_streams" — the two are the same thing and the unmasked one serves).  Created once, kept until the context goes.
+        const bool want_masked_aux = ctx->tail_aux_masked && ctx->tail_reserve_cus > 0;
+        if (!ctx->tail_stream) {
+            if (ctx->tail_sets.size() >= zkpor_ctx::TAIL_SETS_MAX) { ctx->err = "prove: no masked stream left for this tail_reserve_cus"; return ZKPOR_E_STATE; }
+            hipStream_t st = nullptr;
+            ZK_TRY(stream_create_own_queue(ctx, &st, ctx->tail_reserve_cus));
+            ctx->tail_sets.push_back({ctx->tail_reserve_cus, st, nullptr});
+            ctx->tail_stream = st; ctx->tail_aux = nullptr;
         }
-        // the digit streams (decompose, radix sort, filter) are HBM-bound helpers that starve beside the VALU-bound kernels of the main stream
+        if (want_masked_aux && !ctx->tail_aux) {
+            hipStream_t st = nullptr;
+            ZK_TRY(stream_create_own_queue(ctx, &st, ctx->tail_reserve_cus));
+            for (auto& ts : ctx->tail_sets) if (ts.reserve == ctx->tail_reserve_cus) ts.aux = st;
+            ctx->tail_aux = st;
+        }
+        if (!want_masked_aux && !ctx->tail_aux_free) ZK_TRY(stream_create_own_queue(ctx, &ctx->tail_aux_free, 0));
+        // the digit streams (decompose, sort, filter) are HBM-bound helpers that starve beside the VALU-bound kernels of the main stream
         // (profiles/r03_timeline_*.txt); "tail_aux_masked" 0 lets them use the reserved compute units as well — on a stream with its own hardware queue
-        main_s = ctx->tail_stream; aux_s = ctx->tail_aux_masked ? ctx->tail_aux : ctx->tail_aux_free;
+        main_s = ctx->tail_stream; aux_s = want_masked_aux ? ctx->tail_aux : ctx->tail_aux_free;
     }
     hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx), e_up = ev_get(ctx), e_wB = ev_get(ctx), e_wK = ev_get(ctx);
     struct EvGuard { zkpor_ctx* c; hipEvent_t e[7]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up, e_wB, e_wK}, caller_s};

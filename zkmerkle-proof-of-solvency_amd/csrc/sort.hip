@@ -407,6 +407,111 @@ __global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter(const u32* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ scatter without LDS staging ("sort_stage" 0)
+// What the sort costs the main stream is residence (profiles/r06_sort_v2_and_ntt_twiddles_sweep.json): a workgroup that stages 4096 entries holds
+// 40 KB of LDS and displaces one of the four NTT tiles of its compute unit.  This form keeps only the counters in LDS (4 KB): after the count pass a
+// child's cursor in LDS is its reserved GLOBAL position, and the placing pass stores every entry straight to memory (two 4-byte stores, neighbouring
+// ranks to neighbouring addresses — merged in the L2, not in the wave).  No prefix scan, one barrier less per tile, and since nothing is staged a
+// tile may be long (LITE_TILE entries: longer runs per child).
+constexpr u32 LITE_TILE = 16384;
+struct DsLite { u32 cnt[DS_NB], cur[DS_NB], wsum[4], misc[8]; };
+
+// cnt[] -> reserved global positions in cur[]; cnt[] zeroed; ends with a barrier
+ZK_D void ds_reserve_lite(DsLite& S, u32 nb, u32* __restrict__ cursor, u32 child0, u32 n_child) {
+    for (u32 d = threadIdx.x; d < nb; d += DS_THREADS) {
+        const u32 c = S.cnt[d];
+        if (c) { S.cnt[d] = 0u; if (child0 + d < n_child) S.cur[d] = atomicAdd(cursor + child0 + d, c); }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter_lite(const u32* __restrict__ keys, const u32* __restrict__ vals, u32 M, int shift, int r,
+                                                                   const u32* __restrict__ ends, u32 n_par, u32* __restrict__ C, u32 n_child,
+                                                                   u32* __restrict__ ticket, u32* __restrict__ out_k, u32* __restrict__ out_v) {
+    __shared__ DsLite S;
+    const u32 nb = 1u << r, mask = nb - 1u;
+    for (u32 i = threadIdx.x; i < DS_NB; i += DS_THREADS) S.cnt[i] = 0u;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) S.misc[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+        u32 pos = S.misc[0] * DS_CHUNK;
+        if (pos >= M) break;
+        const u32 cend = (M - pos > DS_CHUNK) ? pos + DS_CHUNK : M;
+        u32 seg = 0, seg_end = 0;
+        while (pos < cend) {
+            if (pos >= seg_end) { seg = ds_find_seg(S, ends, n_par, pos); seg_end = ends[seg]; }
+            u32 len = seg_end - pos;
+            if (len > cend - pos) len = cend - pos;
+            if (len > LITE_TILE) len = LITE_TILE;
+#pragma unroll 4
+            for (u32 j = threadIdx.x; j < len; j += DS_THREADS) atomicAdd(&S.cnt[(keys[pos + j] >> shift) & mask], 1u);
+            __syncthreads();
+            ds_reserve_lite(S, nb, C, seg << r, n_child);
+#pragma unroll 4
+            for (u32 j = threadIdx.x; j < len; j += DS_THREADS) {
+                const u32 k = keys[pos + j];
+                const u32 dest = atomicAdd(&S.cur[(k >> shift) & mask], 1u);
+                out_k[dest] = k;
+                out_v[dest] = vals[pos + j];
+            }
+            __syncthreads();
+            pos += len;
+        }
+    }
+}
+
+template <int C, int W, int M>
+__global__ __launch_bounds__(DS_THREADS) void k_dsort_scatter0_lite(const Fr* __restrict__ scalars, u32 n, int shift0, u32 nb0, u32* __restrict__ C0,
+                                                                    u32* __restrict__ ticket, const u32* __restrict__ absent0, const u32* __restrict__ absent1,
+                                                                    u32* __restrict__ out_k, u32* __restrict__ out_v) {
+    __shared__ DsLite S;
+    for (u32 i = threadIdx.x; i < DS_NB; i += DS_THREADS) S.cnt[i] = 0u;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) S.misc[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const u32 base = S.misc[0] * DS_SCALARS_PER_TICKET;
+        if (base >= n) break;
+        // a tile = TWO blocks of 256 scalars (nothing is staged: the keys of a thread's two scalars wait in registers)
+        for (u32 blk = base; blk < base + DS_SCALARS_PER_TICKET && blk < n; blk += 2u * DS_THREADS) {
+            u32 key[2][W], neg[2] = {0, 0}, nz[2] = {0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32 i = blk + (u32)h * DS_THREADS + threadIdx.x;
+                if (i < n && i < base + DS_SCALARS_PER_TICKET) {
+                    const Fr raw = scalars[i];
+                    if (!fr_words_zero(raw)) nz[h] = ds_digits_static<C, W, M>(Fr::from_mont(raw), key[h], neg[h]);
+                }
+#pragma unroll
+                for (int w = 0; w < W; ++w) if ((nz[h] >> w) & 1u) atomicAdd(&S.cnt[key[h][w] >> shift0], 1u);
+            }
+            __syncthreads();
+            ds_reserve_lite(S, nb0, C0, 0u, nb0);
+            constexpr int PIECE = (W + M - 1) / M;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!nz[h]) continue;
+                const u32 i = blk + (u32)h * DS_THREADS + threadIdx.x;
+                u32 flags = 0;
+                if (absent0 || absent1) {   // bits 30 / 31 of every value this scalar emits: its point is absent from group 0 / 1
+                    const u32 word = i >> 5, bit = i & 31u;
+                    if (absent0 && ((absent0[word] >> bit) & 1u)) flags |= VAL_ABSENT0;
+                    if (absent1 && ((absent1[word] >> bit) & 1u)) flags |= VAL_ABSENT1;
+                }
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    if ((nz[h] >> w) & 1u) {
+                        const u32 dest = atomicAdd(&S.cur[key[h][w] >> shift0], 1u);
+                        out_k[dest] = key[h][w];
+                        out_v[dest] = ((i * (u32)M + (u32)(w / PIECE)) << 1) | ((neg[h] >> w) & 1u) | flags;
+                    }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ exclusive scan of a counter array, in place
 constexpr u32 SCAN_BLOCK = 4096;   // 256 threads x 16
 __global__ __launch_bounds__(256) void k_scan_sums(const u32* __restrict__ C, u32 n, u32* __restrict__ bs) {
@@ -507,10 +612,12 @@ int32_t digit_sort(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg
     if (grid <= 0) {
         hipDeviceProp_t prop;
         ZK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        grid = 2 * prop.multiProcessorCount;      // two 256-thread workgroups per compute unit: bandwidth, not wave slots
+        grid = prop.multiProcessorCount / 2;      // one 256-thread workgroup on every second compute unit: what the sort costs the main stream grows with its residence, and
+        if (grid < 1) grid = 1;                   // 128 workgroups still finish both digit streams inside a proof (profiles/r06_sort_grid_tile_sweep.json: 64 starve the accumulations)
     }
     const int tile = ctx->sort_tile == 1024 || ctx->sort_tile == 2048 ? ctx->sort_tile : 4096;
     // the shapes with a compile-time level 0: 22-bit windows over 4 tables (the production key), 20-bit windows over plain arrays; "sort_generic" 1 = never
+    const bool lite = ctx->sort_stage == 0;      // "sort_stage" 0: entries go straight to memory (4 KB of LDS per workgroup), 1: staged through LDS
     const int spec = (ctx->sort_generic || tile != 4096) ? 0 : (cfg.c == 22 && cfg.W == 12 && cfg.m == 4) ? 1 : (cfg.c == 20 && cfg.W == 13 && cfg.m == 1) ? 2 : 0;
     u32* C[4];
     for (int l = 0; l < plan.nlev; ++l) C[l] = (u32*)(temp + plan.off_C[l]);
@@ -538,7 +645,9 @@ int32_t digit_sort(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg
         ZK_TRY(scan_in_place(ctx, C[0], plan.n_child[0], bs));
         const u32 tickets0 = (n + DS_SCALARS_PER_TICKET - 1u) / DS_SCALARS_PER_TICKET;
         const u32 g0 = tickets0 < (u32)grid ? tickets0 : (u32)grid;
-        if (spec == 1) hipLaunchKernelGGL((k_dsort_scatter0_s<22, 12, 4>), dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
+        if (spec == 1 && lite) hipLaunchKernelGGL((k_dsort_scatter0_lite<22, 12, 4>), dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
+        else if (spec == 2 && lite) hipLaunchKernelGGL((k_dsort_scatter0_lite<20, 13, 1>), dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
+        else if (spec == 1) hipLaunchKernelGGL((k_dsort_scatter0_s<22, 12, 4>), dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
         else if (spec == 2) hipLaunchKernelGGL((k_dsort_scatter0_s<20, 13, 1>), dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
         else if (tile == 1024) hipLaunchKernelGGL(k_dsort_scatter0<1024>, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
         else if (tile == 2048) hipLaunchKernelGGL(k_dsort_scatter0<2048>, dim3(g0), dim3(DS_THREADS), 0, ctx->stream, d_scalars, n, dc, plan.shift[0], plan.n_child[0], C[0], ticket + 1, absent0, absent1, kB, vB);
@@ -553,7 +662,8 @@ int32_t digit_sort(zkpor_ctx* ctx, const Fr* d_scalars, u32 n, const MsmCfg& cfg
                            ticket + 2 * l);
         ZK_KERNEL_CHECK(ctx);
         ZK_TRY(scan_in_place(ctx, C[l], plan.n_child[l], bs));
-        if (tile == 1024) hipLaunchKernelGGL(k_dsort_scatter<1024>, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, src_v, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l], plan.n_child[l], ticket + 2 * l + 1, dst_k, dst_v);
+        if (lite) hipLaunchKernelGGL(k_dsort_scatter_lite, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, src_v, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l], plan.n_child[l], ticket + 2 * l + 1, dst_k, dst_v);
+        else if (tile == 1024) hipLaunchKernelGGL(k_dsort_scatter<1024>, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, src_v, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l], plan.n_child[l], ticket + 2 * l + 1, dst_k, dst_v);
         else if (tile == 2048) hipLaunchKernelGGL(k_dsort_scatter<2048>, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, src_v, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l], plan.n_child[l], ticket + 2 * l + 1, dst_k, dst_v);
         else hipLaunchKernelGGL(k_dsort_scatter<4096>, dim3(g), dim3(DS_THREADS), 0, ctx->stream, src_k, src_v, M, plan.shift[l], plan.r[l], C[l - 1], plan.n_child[l - 1], C[l], plan.n_child[l], ticket + 2 * l + 1, dst_k, dst_v);
         ZK_KERNEL_CHECK(ctx);
