@@ -997,6 +997,26 @@ def split_main(args, torch, zkpor, ctx, dist, rank, world, json_fd):
     pk.close()
 
 
+def compile_circuit(C, dist, world, rank, shape, share=True):
+    """the tier's compiled circuit for this rank.  With several ranks on the node ONE of them compiles (10 s, ~13 GB of matrices) and hands the arrays to
+    the others through /dev/shm (circuit.py export_shared / SharedCircuit: mapped, not copied) — eight ranks compiling side by side on a 16-CPU
+    cgroup was the first thing a --gpus 8 run did.  Every rank still synthesises and assigns its OWN batch (its own seed)."""
+    if world <= 1 or dist is None or not share:
+        return C.Circuit(*shape)
+    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_" + "_".join(str(x) for x in shape)
+    cir = None
+    if rank == 0:
+        cir = C.Circuit(*shape)
+        C.export_shared(cir, tag)
+    dist.barrier()
+    if rank != 0:
+        cir = C.SharedCircuit(tag)
+    dist.barrier()                      # everybody has mapped the files: they can go (the mappings keep the pages)
+    if rank == 0:
+        C.unlink_shared(tag)
+    return cir
+
+
 class EndToEnd:
     """groth16.Prove as src/prover/prover/prover.go:254-274 brackets it, on the device: assigned inputs -> solver program (the BSB22 commitment
     served by pause / resume: zkpor_commit_dev + the challenge hashed on the host) -> a, b, c -> prove tail.  One or several WORKERS of one GPU
@@ -1129,7 +1149,7 @@ def circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, shape, tier_name, see
     ck = ctx._ck
     t0 = time.perf_counter()
     inp = C.synth_inputs(*shape, seed=17 + rank)
-    cir = C.Circuit(*shape)
+    cir = compile_circuit(C, dist, world, rank, shape)
     t1 = time.perf_counter()
     log2 = max(10, int(np.ceil(np.log2(cir.n_constraints))))
     D = 1 << log2
@@ -1339,6 +1359,7 @@ def main():
                     "separated by commas (e.g. 1:0,2:32,2:0:0:128:4096:0:1), each --e2e-steps proofs, reported under end_to_end.sweep.  Do not walk through many reserve "
                     "values in one process: every value adds hardware queues that stay (profiles/r06_tail_mode_sweep.json)")
     ap.add_argument("--tail-reserve-cus", type=int, default=0, help="with 2 workers: compute units the prove tail's CU mask leaves free for the other worker's solver launches (0 = none; multiple of 8)")
+    ap.add_argument("--no-share-compile", action="store_true", help="several ranks: every rank compiles the circuit itself instead of mapping rank 0's arrays from /dev/shm")
     ap.add_argument("--share-device", action="store_true", help="TEST ONLY: every rank proves on device 0 and the ranks meet over gloo — the launcher, the per-rank "
                     "merge of the line, the check budgeting and the key build under contention exercised on a one-GPU box; the line says so and is no measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1486,7 +1507,7 @@ def main():
         t_c = time.perf_counter()
         inp = C.synth_inputs(*circuit_shape, seed=7 + rank)
         t_c1 = time.perf_counter()
-        cir = C.Circuit(*circuit_shape)
+        cir = compile_circuit(C, dist, world, rank, circuit_shape, share=not args.no_share_compile)
         t_c2 = time.perf_counter()
         log2 = max(10, int(np.ceil(np.log2(cir.n_constraints))))
         D = 1 << log2

@@ -327,3 +327,33 @@ def test_check_instructions_assign_no_wire():
             c.solve_host_with(_container_with_levels(head, k3, args, levels, rest), inp, C.default_commitment(), threads=2)
     finally:
         c.close()
+
+
+def test_a_compiled_circuit_travels_to_other_ranks_through_shared_memory():
+    """bench.py --gpus N: rank 0 compiles the tier's circuit and the others MAP its arrays from /dev/shm (circuit.py export_shared / SharedCircuit)
+    instead of compiling eight times side by side — the same dimensions, census and arrays behind the same read interface, and the files may be
+    unlinked as soon as every rank has mapped them"""
+    import os
+    cir = C.Circuit(4, 12, 3)
+    tag = f"test_{os.getpid()}"
+    try:
+        d = C.export_shared(cir, tag)
+        assert os.path.exists(os.path.join(d, "meta.json"))
+        sh = C.SharedCircuit(tag)
+        C.unlink_shared(tag)                                    # mapped pages stay valid after the unlink
+        assert not os.path.exists(d)
+        assert sh.shape == cir.shape and sh.dims == cir.dims and sh.census == cir.census
+        for name in ("n_wires", "n_public", "n_secret", "n_constraints", "n_committed", "commitment_wire", "n_instructions", "n_levels"):
+            assert getattr(sh, name) == getattr(cir, name)
+        assert np.array_equal(sh.coeff(), cir.coeff()) and np.array_equal(sh.committed(), cir.committed())
+        for m in range(3):
+            for x, y in zip(sh.matrix(m), cir.matrix(m)):
+                assert x.dtype == y.dtype and np.array_equal(x, y)
+        for x, y in zip(sh.infinity_masks(), cir.infinity_masks()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(sh.level_sizes(), cir.level_sizes())
+        assert np.array_equal(sh.solver_container(), cir.solver_container())
+        sh.close()
+    finally:
+        C.unlink_shared(tag)
+        cir.close()

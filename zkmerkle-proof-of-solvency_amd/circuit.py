@@ -135,6 +135,87 @@ class Circuit:
             self.z = None
 
 
+# ---- one compile per NODE: the compiled circuit handed to the other ranks through /dev/shm ----
+# `bench.py --gpus 8` is eight processes; the compile (10 s, ~13 GB of matrices) is the same for every rank of a tier.  Rank 0 compiles and
+# writes the arrays every consumer reads — coefficient table, three CSR matrices, solver container, commitment info, level sizes — as .npy files
+# under /dev/shm; the others map them (no copy: the page cache holds ONE set) behind the same read interface as `Circuit`.
+_SHARED_ARRAYS = ("coeff", "row_ptr0", "cid0", "wid0", "row_ptr1", "cid1", "wid1", "row_ptr2", "cid2", "wid2", "committed", "in_l", "in_r", "level_ptr", "container")
+
+
+def shared_dir(tag):
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    return os.path.join(base, "zkpor_circuit_" + "".join(ch if ch.isalnum() or ch in "-_" else "_" for ch in str(tag)))
+
+
+def export_shared(circuit, tag):
+    """write a compiled Circuit's arrays for SharedCircuit(tag); returns the directory"""
+    d = shared_dir(tag)
+    os.makedirs(d, exist_ok=True)
+    arrays = {"coeff": circuit.coeff(), "committed": circuit.committed(), "container": circuit.solver_container(),
+              "in_l": circuit._view("zkc_in_l", circuit.n_wires), "in_r": circuit._view("zkc_in_r", circuit.n_wires),
+              "level_ptr": circuit._view("zkc_level_ptr", circuit.n_levels + 1)}
+    for m in range(3):
+        rp, cid, wid = circuit.matrix(m)
+        arrays[f"row_ptr{m}"] = rp; arrays[f"cid{m}"] = cid; arrays[f"wid{m}"] = wid
+    for name in _SHARED_ARRAYS:
+        np.save(os.path.join(d, name + ".npy"), np.ascontiguousarray(arrays[name]))
+    with open(os.path.join(d, "meta.json.tmp"), "w") as f:
+        json.dump({"shape": list(circuit.shape), "dims": circuit.dims, "census": circuit.census}, f)
+    os.replace(os.path.join(d, "meta.json.tmp"), os.path.join(d, "meta.json"))       # the meta file appears last: a reader that finds it finds everything
+    return d
+
+
+def unlink_shared(tag):
+    d = shared_dir(tag)
+    if os.path.isdir(d):
+        for n in os.listdir(d):
+            try:
+                os.unlink(os.path.join(d, n))
+            except OSError:
+                pass
+        try:
+            os.rmdir(d)
+        except OSError:
+            pass
+
+
+class SharedCircuit:
+    """the read side: a circuit another process compiled (export_shared), mapped read-only.  Everything DeviceCircuit, the key synthesis and the
+    checks read from a Circuit; no interpreter, no host executor (those stay with the process that compiled)"""
+
+    def __init__(self, tag):
+        d = shared_dir(tag)
+        with open(os.path.join(d, "meta.json")) as f:
+            meta = json.load(f)
+        self.shape = tuple(meta["shape"]); self.dims = meta["dims"]; self.census = meta["census"]
+        for k, v in self.dims.items():
+            setattr(self, k, v)
+        self._a = {name: np.load(os.path.join(d, name + ".npy"), mmap_mode="r") for name in _SHARED_ARRAYS}
+        self.interpreted = False
+        self.z = None
+
+    def coeff(self):
+        return self._a["coeff"]
+
+    def matrix(self, m):
+        return (self._a[f"row_ptr{m}"], self._a[f"cid{m}"], self._a[f"wid{m}"])
+
+    def committed(self):
+        return self._a["committed"]
+
+    def infinity_masks(self):
+        return (np.asarray(self._a["in_l"]) == 0).astype(np.uint8), (np.asarray(self._a["in_r"]) == 0).astype(np.uint8)
+
+    def level_sizes(self):
+        return np.diff(np.asarray(self._a["level_ptr"]).astype(np.int64))
+
+    def solver_container(self):
+        return self._a["container"]
+
+    def close(self):
+        self._a = {}
+
+
 def default_commitment():
     """the value the interpreter gives the commitment wire when none is passed (frontend.hpp commitment_value_), Montgomery form"""
     out = np.zeros(4, np.uint64)
