@@ -59,6 +59,23 @@ def pmc_traffic_bytes_per_launch(kernel="k_acc_level1_fp29"):
         return None, None
 
 
+def measured_clock_ghz(kernel="k_acc_level1_fp29", default=1.949):
+    """the clock the part grants `kernel` (GRBM_GUI_ACTIVE per wall-clock ms of its dispatches) from the latest committed profiles/r*_clock*.txt
+    (tools/pmc_clock_summary.py); the nominal clock is 2.4 GHz, the level-1 kernel is power-limited below 2"""
+    import glob
+    import re
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_clock*.txt")))):
+        try:
+            for line in open(f):
+                if line.startswith(kernel + " "):
+                    m = re.search(r"->\s*([0-9.]+)\s*GHz", line)
+                    if m:
+                        return float(m.group(1)), os.path.basename(f)
+        except Exception:      # noqa: BLE001
+            continue
+    return default, "r04_clock.txt"
+
+
 def pmc_valu_issue_bound_ms(kernel="k_acc_level1_fp29"):
     """VALU issue-rate bound of one average launch of `kernel` (ms): wave-instructions counted by rocprofv3 SQ_INSTS_VALU in
     the committed profile x 4 issue cycles / (1024 SIMDs x nominal clock).  The path is integer-VALU work, so this — not
@@ -1961,7 +1978,7 @@ def main():
         # proof are A, B1, K over the wires that have a point, Z over D - 1, and the two Pedersen sums (DESIGN.md §4 / SURVEY §8d)
         units_bytes_exact = (n_a + n_b1 + n_k + (D - 1) + 2 * n_commit) * 96.0 / 6.0
         achieved = units_bytes_exact / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        clock_ghz = 1.949     # profiles/r04_clock.txt: GRBM_GUI_ACTIVE / wall time of k_acc_level1_fp29 (power-limited; nominal 2.4)
+        clock_ghz, clock_src = measured_clock_ghz()     # GRBM_GUI_ACTIVE / wall time of k_acc_level1_fp29 (power-limited; nominal 2.4)
         traffic = (tb / avg_launch_s / 1e9) if (tb and avg_launch_s > 0 and profiled_cfg) else None
         vb_ms, vsrc = pmc_valu_issue_bound_ms()
         cw, cwsrc = valu_class_weight()
@@ -1983,13 +2000,13 @@ def main():
                  "frac_class_weighted": (vb_ms * cw / (avg_launch_s * 1e3)) if cw else None,
                  "compute_units_the_kernel_may_use": 256 - (e2e["tail_reserve_cus"] if e2e is not None else 0),
                  "frac_of_its_compute_units_at_measured_clock": vb_ms / (avg_launch_s * 1e3) * 2.4 / clock_ghz * 256.0 / (256 - (e2e["tail_reserve_cus"] if e2e is not None else 0)),
-                 "measured_clock_ghz": clock_ghz, "frac_at_measured_clock": vb_ms / (avg_launch_s * 1e3) * 2.4 / clock_ghz,
+                 "measured_clock_ghz": clock_ghz, "measured_clock_source": f"profiles/{clock_src}", "frac_at_measured_clock": vb_ms / (avg_launch_s * 1e3) * 2.4 / clock_ghz,
                  "frac_class_weighted_at_measured_clock": (vb_ms * cw / (avg_launch_s * 1e3) * 2.4 / clock_ghz) if cw else None,
                  "source": f"profiles/{vsrc}: SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz nominal) / live avg launch time; "
                            f"class-weighted: the same count priced per instruction class (profiles/{cwsrc}: 24 % of the kernel's VALU "
                            "instructions are simple 32-bit ops that issue in 2 cycles when they come in runs, the rest 4 — measured per class in "
-                           "profiles/r03_valu_class.txt).  The part runs this kernel at 1.95 GHz, not 2.4 (GRBM_GUI_ACTIVE per wall-clock ms, re-measured on the round-4 "
-                           "binary: profiles/r04_clock.txt; the G2 kernel 2.15, NTT passes 2.07-2.29): *_at_measured_clock price the same counts at that clock"}
+                           "profiles/r03_valu_class.txt).  The part runs this kernel well below 2.4 GHz (GRBM_GUI_ACTIVE per wall-clock ms: "
+                           f"profiles/{clock_src}; round 4: 1.95, round 6: 1.89; the G2 kernel 2.05-2.15, NTT passes 2.0-2.3): *_at_measured_clock price the same counts at that clock"}
                 if (vb_ms and avg_launch_s > 0 and profiled_cfg) else None)
         main_stream = ("k_acc_level1_g1", "k_acc_level1_g2", "msm_accumulate", "msm_reduce", "ntt", "pointwise", "host_assembly")
         tail_value = (world * tail_steps / dt) if dt else None

@@ -13,6 +13,11 @@ KERNELS = {  # substring of the kernel name -> (label, FETCH_SIZE correction)
     "k_ntt_pass29": ("k_ntt_pass29", 2.0),                  # wide coalesced streams read back at 1/2 (per launch: see ntt_per_launch below)
     "k_ntt_mid29": ("k_ntt_mid29", 2.0),                    # lowest field: contiguous 8 KiB tiles
     "k_ntt_top29": ("k_ntt_top29", 1.0),                    # highest field: 64-128 B segments, counted 1:1
+    "k_dsort_count0": ("k_dsort_count0", 2.0),              # round 6: the digit-stream sort (csrc/sort.hip): coalesced streams in, runs out
+    "k_dsort_scatter0": ("k_dsort_scatter0", 2.0),
+    "k_dsort_count": ("k_dsort_count", 2.0),
+    "k_dsort_scatter": ("k_dsort_scatter", 2.0),
+    "k_r1cs_eval": ("k_r1cs_eval", 1.0),
     "k_filter_write": ("k_filter_write", 2.0),
     "k_filter_count": ("k_filter_count", 2.0),
     "k_h_pointwise": ("k_h_pointwise", 2.0),

@@ -8,7 +8,7 @@ import json
 import sys
 
 KERNELS = ("k_acc_level1_fp29", "k_acc_level1_g2pair29", "k_ntt_pass29", "k_ntt_mid29", "k_ntt_top29", "k_acc_levelN29", "k_reduce_level29", "k_reduce_scan29", "k_h_pointwise",
-           "k_decompose", "k_filter_write", "k_filter_count",
+           "k_dsort_count0", "k_dsort_scatter0", "k_dsort_count", "k_dsort_scatter", "k_scan_", "k_r1cs_eval", "k_solve_level", "k_count_queries", "k_decompose", "k_filter_write", "k_filter_count",
            "k_hash2_level", "k_tree_level", "k_account_leaves_coop", "k_account_leaves", "k_cex_commitments_coop", "k_cex_commitments")
 
 

@@ -221,9 +221,18 @@ struct PooledStream { int device, reserve; hipStream_t st; };
 std::mutex g_stream_pool_mu;
 std::vector<PooledStream> g_stream_pool;
 }  // namespace
+// at process exit the parked streams go back to the runtime BEFORE its own exit handlers run (atexit: last registered, first run) — left alive they
+// took rocprofv3's teardown down with them (a SIGSEGV in __cxa_finalize after every output was written: gpurun_out/r06p)
+void stream_pool_drain_at_exit() {
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    for (auto& p : g_stream_pool) (void)hipStreamDestroy(p.st);
+    g_stream_pool.clear();
+}
 void stream_release_own_queue(int device, hipStream_t st, int reserve_cus) {
     if (!st) return;
     (void)hipStreamSynchronize(st);
+    static std::once_flag once;
+    std::call_once(once, [] { (void)atexit(stream_pool_drain_at_exit); });
     std::lock_guard<std::mutex> lk(g_stream_pool_mu);
     // an idle hardware queue is not free: a process that had collected ~25 of them (a sweep over five reserve values, two workers each) ran the SAME
     // region 1.7x slower than at its start (profiles/r06_tail_mode_sweep.json) — the pool is for re-use by the next context, not a museum
