@@ -30,6 +30,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 
 # BASELINE.json configs[1] / configs[2]: both production tiers target D = 2^26 with the same array sizes;
 # they differ in the witness scalar mixture (zkpor_dev_fill_fr kind) — estimates from a static count of Define (Appendix B)
+EXTRA_PARAMS = {}   # --param NAME=VALUE: library parameters every context of the run takes (experiments)
 CONFIGS = {
     "zkpor50_1380": {"fill_kind": 1, "users": 1380, "assets": 50,
                      "mixture": "25% {0,1}, 20% <2^16, 5% <2^64, 50% uniform"},
@@ -1067,6 +1068,8 @@ class EndToEnd:
             for name_ in ("sort_grid", "sort_tile", "ntt_twiddles", "sort_stage"):     # worker contexts take the main context's sort settings (--sort-grid / --sort-tile)
                 if sort_params and sort_params.get(name_, -1) >= 0:
                     wk["ctx"].set_param(name_, sort_params[name_])
+            for name_, val_ in EXTRA_PARAMS.items():      # --param
+                wk["ctx"].set_param(name_, val_)
             if solver_rows:
                 wk["dc"].solver.set_abc_dev(wk["a"].data_ptr(), wk["b"].data_ptr(), wk["c"].data_ptr())
             if prefetch:
@@ -1379,6 +1382,8 @@ def main():
     ap.add_argument("--no-share-compile", action="store_true", help="several ranks: every rank compiles the circuit itself instead of mapping rank 0's arrays from /dev/shm")
     ap.add_argument("--share-device", action="store_true", help="TEST ONLY: every rank proves on device 0 and the ranks meet over gloo — the launcher, the per-rank "
                     "merge of the line, the check budgeting and the key build under contention exercised on a one-GPU box; the line says so and is no measurement")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="experiment: zkpor_set_param(NAME, VALUE) on the main context and on every worker context (repeatable), "
+                    "e.g. --param r1cs_order=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
                     help="warm-up + the timed region and nothing else (no uniform region, check, boundary, CPU baseline, acceptance): the "
@@ -1474,6 +1479,10 @@ def main():
         ctx.set_param("tail_aux_masked", args.tail_aux_masked)
     if args.tables > 1 and not args.split:   # a key with tables cannot be cut into the shards of the single-proof split
         ctx.set_param("msm_tables", args.tables)
+    for nv in args.param:
+        name_, _, val_ = nv.partition("=")
+        EXTRA_PARAMS[name_] = int(val_)
+        ctx.set_param(name_, int(val_))
     lib = ctx.lib
 
     if args.split:
@@ -2020,6 +2029,7 @@ def main():
             "unit": "proofs/s",
             "n_gpus": world,
             "ranks_share_one_device": True if args.share_device else None,
+            "experiment_params": dict(EXTRA_PARAMS) or None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": headline_ms,

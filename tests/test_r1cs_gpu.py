@@ -43,6 +43,54 @@ def test_eval_matches_oracle(zk, n_cons):
         r.close()
 
 
+def test_rows_in_evaluation_order_equal_rows_in_natural_order(zk):
+    """round 6: k_r1cs_eval walks a matrix's rows by shape — term count, then the pattern of coefficient kinds, natural order inside a class — so that
+    the 64 rows of a wave run the same iterations through the same branches ("r1cs_order" 1, the default); 0 is one thread per row in natural
+    order.  Rows of every length from 0 to beyond the long-row limit, all four coefficient kinds mixed: the same a, b, c both ways, the zero padding up
+    to the domain included, and both equal to Python integers"""
+    rng = np.random.default_rng(11)
+    n_w, n_c = 700, 3000
+    table = O.fr_from_ints([0, 1, O.R_MOD - 1, 7, 12345678901234567890, O.R_MOD - 2])
+    lens = rng.choice([0, 1, 2, 3, 3, 3, 4, 5, 8, 16, 17, 40, 79, 255, 256, 257, 600], size=n_c)
+    row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    nnz = int(row_ptr[-1])
+    w = O.fr_random(77, n_w)
+    mats = []
+    for m in range(3):
+        cid = rng.integers(0, 6, nnz).astype(np.uint32); wid = rng.integers(0, n_w, nnz).astype(np.uint32)
+        mats.append((np.roll(lens, 17 * m), cid, wid))
+    r = zkpor.R1CS(zk, n_c, n_w, table)
+    D = 4096
+    bufs = [zk.alloc(32 * D) for _ in range(3)]
+    dw = zk.alloc(32 * n_w).upload(w)
+    try:
+        rps = []
+        for m, (ln, cid, wid) in enumerate(mats):
+            rp = np.concatenate([[0], np.cumsum(ln)]).astype(np.uint64)
+            rps.append(rp)
+            r.set_matrix(m, rp, cid, wid)
+        got = {}
+        for order in (1, 0):
+            zk.set_param("r1cs_order", order)
+            for b_ in bufs:
+                b_.upload(np.full((D, 4), 0xABCDEF, np.uint64))
+            r.eval_dev(dw.ptr, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, D)
+            got[order] = [b_.download(np.uint64, (D, 4)) for b_ in bufs]
+        for x, y in zip(got[0], got[1]):
+            assert np.array_equal(x, y) and not x[n_c:].any()
+        wi = O.fr_to_ints(w); ti = O.fr_to_ints(table)
+        for m, (ln, cid, wid) in enumerate(mats):
+            vals = O.fr_to_ints(got[1][m][:n_c])
+            for j in list(range(0, n_c, 97)) + [int(np.argmax(ln))]:
+                acc = sum(ti[cid[t]] * wi[wid[t]] for t in range(int(rps[m][j]), int(rps[m][j + 1]))) % O.R_MOD
+                assert vals[j] == acc, (m, j)
+    finally:
+        zk.set_param("r1cs_order", 1)
+        for b_ in bufs + [dw]:
+            b_.free()
+        r.close()
+
+
 def test_special_coefficients_and_empty_rows(zk):
     """0, 1, -1 and a generic coefficient in one row; an empty linear expression evaluates to 0"""
     table = O.fr_from_ints([0, 1, O.R_MOD - 1, 12345])

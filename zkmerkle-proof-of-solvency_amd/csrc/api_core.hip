@@ -512,6 +512,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
         ctx->aux_priority = (int)value;
     }
     else if (n == "poseidon_coop") { if (value < -1 || value > 1) { ctx->err = "poseidon_coop must be -1 (by size), 0 or 1"; return ZKPOR_E_ARG; } ctx->poseidon_coop = (int)value; }
+    else if (n == "r1cs_order") { if (value < 0 || value > 1) { ctx->err = "r1cs_order must be 0 (natural) or 1 (by row shape)"; return ZKPOR_E_ARG; } ctx->r1cs_order = (int)value; }
     else if (n == "solver_defer_checks") { if (value < 0 || value > 1) { ctx->err = "solver_defer_checks must be 0 or 1"; return ZKPOR_E_ARG; } ctx->solver_defer_checks = (int)value; }
     else if (n == "solver_tree_from") { if (value < 1) { ctx->err = "solver_tree_from must be positive"; return ZKPOR_E_ARG; } ctx->solver_tree_from = value; }
     else if (n == "solver_beside") { if (value < 0 || value > 1) { ctx->err = "solver_beside must be 0 or 1"; return ZKPOR_E_ARG; } ctx->solver_beside = (int)value; }

@@ -69,6 +69,7 @@ struct zkpor_ctx {
     int sort_generic = 0;            // 1: the runtime-window level 0 of the sort even for the shapes that have a compile-time one (tests compare the two)
     int sort_tile = 0;               // entries a sort workgroup stages in LDS at a time: 0 = 4096 (40 KB of LDS), 2048 (24 KB), 1024 (16 KB)
     int aux_priority = 0;            // 1: the auxiliary (digit-stream) HIP stream is created with the highest stream priority
+    int r1cs_order = 1;              // a, b, c = L.w, R.w, O.w: 1 = the rows in the matrix's evaluation order (equal length and coefficient pattern side by side: r1cs.cuh), 0 = natural order
     int solver_defer_checks = 1;     // with zkpor_solver_set_abc_dev: the run leaves its CHECK instructions (assertions) out and zkpor_solver_eval_abc_dev verifies a x b = c on EVERY row; 0 = the run executes them
     int64_t solver_tree_from = 1024; // levels from this many generic instructions on: the divisions of a workgroup share one inversion, long constraints go to k_solve_long
     int solver_beside = 1;           // Poseidon calls with a join level run on a side stream beside the levels up to it; 0 = in place, as ordinary calls

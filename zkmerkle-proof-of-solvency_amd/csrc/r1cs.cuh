@@ -18,6 +18,11 @@ struct zkpor_r1cs {
     size_t nnz[3] = {0, 0, 0};
     uint32_t* long_rows[3] = {nullptr, nullptr, nullptr};   // rows of more than R1CS_LONG_ROW terms: summed by a wave each (k_r1cs_eval_long)
     size_t n_long[3] = {0, 0, 0};
+    // round 6: the other rows in the order k_r1cs_eval walks them — by term count, then by the pattern of their coefficient kinds (rows of one gadget
+    // side by side), natural order inside a class.  One thread per row in NATURAL order made every wave last as long as its longest row and run
+    // every branch its 64 rows took: 9.3 G wave-instructions per zkpor50_1380 proof for 0.5 G of lane work (profiles/r06_pmc_valu.json)
+    uint32_t* perm[3] = {nullptr, nullptr, nullptr};
+    size_t n_perm[3] = {0, 0, 0};
     std::vector<zk::Fr> h_coeff;    // host copy of the table (the solver reads constant hint inputs — table sizes — when a program is loaded)
 };
 

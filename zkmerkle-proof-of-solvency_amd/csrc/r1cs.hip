@@ -14,31 +14,39 @@ namespace zk {
 struct R1csDev {
     const Fr* coeff; const uint8_t* kind;
     const uint64_t* row_ptr[3]; const u32* cid[3]; const u32* wid[3];
+    const u32* perm[3]; u32 n_perm[3];     // the rows of up to R1CS_LONG_ROW terms in evaluation order (r1cs.cuh); null = natural order
 };
 
-// one thread per (matrix, row); rows beyond n_constraints are the zero padding computeH expects
+// one thread per (matrix, row), the rows taken in the matrix's evaluation order (perm: rows of equal length and coefficient pattern side by side, so
+// that the 64 rows of a wave run the same number of iterations through the same branches); the threads behind them write the zero padding computeH
+// expects in rows n_constraints .. domain - 1.
 // skip (may be NULL): one bit per row, set = somebody else has written a, b, c of that row already (the solver's Poseidon instruction)
 __global__ __launch_bounds__(256) void k_r1cs_eval(R1csDev M, const Fr* __restrict__ w, size_t n_constraints, size_t domain,
                                                    Fr* __restrict__ a, Fr* __restrict__ b, Fr* __restrict__ c, const u32* __restrict__ skip) {
-    const size_t row = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     const int m = blockIdx.y;
-    if (row >= domain) return;
-    if (skip && row < n_constraints && ((skip[row >> 5] >> (row & 31)) & 1u)) return;
-    Fr acc = Fr::zero();
-    if (row < n_constraints) {
-        const uint64_t t0 = M.row_ptr[m][row], t1 = M.row_ptr[m][row + 1];
-        if (t1 - t0 > (uint64_t)R1CS_LONG_ROW) return;       // k_r1cs_eval_long's
-        for (uint64_t t = t0; t < t1; ++t) {
-            const u32 ci = M.cid[m][t];
-            const uint8_t kind = M.kind[ci];
-            if (kind == 3) continue;
-            const Fr x = w[M.wid[m][t]];
-            if (kind == 1) acc = Fr::add(acc, x);
-            else if (kind == 2) acc = Fr::sub(acc, x);
-            else acc = Fr::add(acc, Fr::mul(M.coeff[ci], x));
-        }
-    }
+    const u32* perm = M.perm[m];
+    const size_t n_rows = perm ? (size_t)M.n_perm[m] : n_constraints;
     Fr* out = m == 0 ? a : (m == 1 ? b : c);
+    if (i >= n_rows) {                                       // padding rows
+        const size_t row = n_constraints + (i - n_rows);
+        if (row < domain) out[row] = Fr::zero();
+        return;
+    }
+    const size_t row = perm ? (size_t)perm[i] : i;
+    if (skip && ((skip[row >> 5] >> (row & 31)) & 1u)) return;
+    Fr acc = Fr::zero();
+    const uint64_t t0 = M.row_ptr[m][row], t1 = M.row_ptr[m][row + 1];
+    if (t1 - t0 > (uint64_t)R1CS_LONG_ROW) return;           // k_r1cs_eval_long's (natural order only: the evaluation order leaves them out)
+    for (uint64_t t = t0; t < t1; ++t) {
+        const u32 ci = M.cid[m][t];
+        const uint8_t kind = M.kind[ci];
+        if (kind == 3) continue;
+        const Fr x = w[M.wid[m][t]];
+        if (kind == 1) acc = Fr::add(acc, x);
+        else if (kind == 2) acc = Fr::sub(acc, x);
+        else acc = Fr::add(acc, Fr::mul(M.coeff[ci], x));
+    }
     out[row] = acc;
 }
 
@@ -100,6 +108,7 @@ static void r1cs_free(zkpor_r1cs* r) {
         if (r->cid[m]) (void)hipFree(r->cid[m]);
         if (r->wid[m]) (void)hipFree(r->wid[m]);
         if (r->long_rows[m]) (void)hipFree(r->long_rows[m]);
+        if (r->perm[m]) (void)hipFree(r->perm[m]);
     }
     delete r;
 }
@@ -116,9 +125,16 @@ int32_t r1cs_eval_on(zkpor_ctx* ctx, zkpor_r1cs* r, const void* d_w, void* d_a, 
     if (domain_size == 0) return ZKPOR_OK;
     R1csDev M;
     M.coeff = r->coeff; M.kind = r->coeff_kind;
-    for (int m = 0; m < 3; ++m) { M.row_ptr[m] = r->row_ptr[m]; M.cid[m] = r->cid[m]; M.wid[m] = r->wid[m]; }
+    const bool sorted = ctx->r1cs_order != 0;
+    size_t threads = 0;
+    for (int m = 0; m < 3; ++m) {
+        M.row_ptr[m] = r->row_ptr[m]; M.cid[m] = r->cid[m]; M.wid[m] = r->wid[m];
+        M.perm[m] = sorted ? r->perm[m] : nullptr; M.n_perm[m] = (u32)r->n_perm[m];
+        const size_t t = (M.perm[m] ? r->n_perm[m] : r->n_constraints) + (domain_size - r->n_constraints);
+        if (t > threads) threads = t;
+    }
     PhaseScope ps(ctx, "r1cs_eval");
-    hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((domain_size + 255) / 256), 3), dim3(256), 0, ctx->stream, M, (const Fr*)d_w,
+    hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((threads + 255) / 256), 3), dim3(256), 0, ctx->stream, M, (const Fr*)d_w,
                        r->n_constraints, domain_size, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, d_skip);
     ZK_KERNEL_CHECK(ctx);
     Fr* outs[3] = {(Fr*)d_a, (Fr*)d_b, (Fr*)d_c};
@@ -181,7 +197,8 @@ int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr,
     if (r->cid[which]) { (void)hipFree(r->cid[which]); r->cid[which] = nullptr; }
     if (r->wid[which]) { (void)hipFree(r->wid[which]); r->wid[which] = nullptr; }
     if (r->long_rows[which]) { (void)hipFree(r->long_rows[which]); r->long_rows[which] = nullptr; }
-    r->n_long[which] = 0;
+    if (r->perm[which]) { (void)hipFree(r->perm[which]); r->perm[which] = nullptr; }
+    r->n_long[which] = 0; r->n_perm[which] = 0;
     std::vector<uint32_t> longs;
     for (size_t i = 0; i < r->n_constraints; ++i) if (row_ptr[i + 1] - row_ptr[i] > (uint64_t)R1CS_LONG_ROW) longs.push_back((uint32_t)i);
     if (r->n_constraints > 0xffffffffull) { ctx->err = "r1cs: more than 2^32 constraints"; return ZKPOR_E_ARG; }
@@ -196,6 +213,34 @@ int32_t zkpor_r1cs_set_matrix(zkpor_r1cs* r, int which, const uint64_t* row_ptr,
         if (hipMalloc((void**)&r->long_rows[which], longs.size() * 4) != hipSuccess) { (void)hipGetLastError(); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM; }
         ZK_TRY(zk::h2d_sync(ctx, r->long_rows[which], longs.data(), longs.size() * 4));
         r->n_long[which] = longs.size();
+    }
+    {   // the evaluation order of the rows of up to R1CS_LONG_ROW terms: a stable counting sort by (term count, pattern of coefficient kinds).  The pattern of
+        // a short row is its kinds themselves (2 bits per term, hashed to a byte), of a longer one the number of its generic coefficients: rows a gadget
+        // emits for every user / asset / round meet in one class, in natural order.  One pass over the terms on the host, once per loaded matrix.
+        const size_t n = r->n_constraints;
+        std::vector<uint8_t> kind(r->n_coeff);
+        const Fr one = Fr::one(), mone = Fr::neg(one);
+        for (size_t i = 0; i < r->n_coeff; ++i) kind[i] = r->h_coeff[i].is_zero() ? 3 : (memcmp(&r->h_coeff[i], &one, sizeof(Fr)) == 0 ? 1 : (memcmp(&r->h_coeff[i], &mone, sizeof(Fr)) == 0 ? 2 : 0));
+        std::vector<uint32_t> key(n);
+        constexpr uint32_t CLASSES = (R1CS_LONG_ROW + 2u) << 8;
+        std::vector<uint32_t> start(CLASSES + 1, 0);
+        size_t kept = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const uint64_t t0 = row_ptr[i], len = row_ptr[i + 1] - t0;
+            if (len > (uint64_t)R1CS_LONG_ROW) { key[i] = 0xffffffffu; continue; }
+            uint32_t sig = 0;
+            if (len <= 16) { for (uint64_t t = 0; t < len; ++t) sig = sig * 4u + kind[coeff_ids[t0 + t]]; sig = (sig * 2654435761u) >> 24; }
+            else { uint32_t g = 0; for (uint64_t t = 0; t < len; ++t) g += kind[coeff_ids[t0 + t]] == 0; sig = g > 255u ? 255u : g; }
+            key[i] = ((uint32_t)len << 8) | sig;
+            ++start[key[i] + 1];
+            ++kept;
+        }
+        for (uint32_t k = 0; k < CLASSES; ++k) start[k + 1] += start[k];
+        std::vector<uint32_t> perm(kept ? kept : 1);
+        for (size_t i = 0; i < n; ++i) if (key[i] != 0xffffffffu) perm[start[key[i]]++] = (uint32_t)i;
+        if (hipMalloc((void**)&r->perm[which], (kept ? kept : 1) * 4) != hipSuccess) { (void)hipGetLastError(); ctx->err = "r1cs: out of device memory"; return ZKPOR_E_OOM; }
+        ZK_TRY(zk::h2d_sync(ctx, r->perm[which], perm.data(), (kept ? kept : 1) * 4));
+        r->n_perm[which] = kept;
     }
     r->nnz[which] = nnz;
     return ZKPOR_OK;
@@ -224,7 +269,7 @@ int32_t zkpor_r1cs_check_dev(zkpor_r1cs* r, const void* d_w, uint64_t counts[2])
     int32_t rc = ZKPOR_OK;
     R1csDev M;
     M.coeff = r->coeff; M.kind = r->coeff_kind;
-    for (int m = 0; m < 3; ++m) { M.row_ptr[m] = r->row_ptr[m]; M.cid[m] = r->cid[m]; M.wid[m] = r->wid[m]; }
+    for (int m = 0; m < 3; ++m) { M.row_ptr[m] = r->row_ptr[m]; M.cid[m] = r->cid[m]; M.wid[m] = r->wid[m]; M.perm[m] = nullptr; M.n_perm[m] = 0; }
     if (hipMemcpyAsync(d_out, counts, 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "r1cs: H2D failed"; rc = ZKPOR_E_HIP; }
     if (rc == ZKPOR_OK) {
         hipLaunchKernelGGL(k_r1cs_check, dim3((unsigned)((r->n_constraints + 255) / 256)), dim3(256), 0, ctx->stream, M, (const Fr*)d_w, r->n_constraints, d_out);
