@@ -78,6 +78,12 @@ int32_t zkpor_init(int device, void* stream, zkpor_ctx** out);
 void zkpor_destroy(zkpor_ctx* ctx);
 const char* zkpor_last_error(zkpor_ctx* ctx);
 int32_t zkpor_sync(zkpor_ctx* ctx);
+/* hand the context's grow-only scratch back to the device: the workspace of the multi-exponentiations (digit streams, accumulation regions), the
+ * staging area of the host-pointer calls, the NTT domains' twiddle tables.  Everything is re-created on demand by the next call that needs it
+ * (a 2^26 proof: ~0.1 s once).  Waits for the context's streams first.  Keys, trees, matrices and solver programs are handles of their own and stay.
+ * For a prover that switches tiers (the reference loads another key when the batch shape changes, src/prover/prover/prover.go:60-90: the old
+ * tier's 40-60 GB of scratch would otherwise stay beside the new key) and for a process that shares its GPU with another one. */
+int32_t zkpor_trim(zkpor_ctx* ctx);
 /* tuning knobs: "msm_window" (bits, 0 = auto), "msm_chunk" (entries per accumulation thread),
  * "msm_tables" (1..8, default 1; applies to keys loaded AFTER it is set): m > 1 stores every key array as m interleaved
  * fixed-base tables, entry i*m + q = 2^(q * piece * c) P_i, so that the digits of a scalar share ceil(W / m) bucket windows: at
@@ -97,6 +103,11 @@ int32_t zkpor_sync(zkpor_ctx* ctx);
  * "msm_reduce_scan" (1, the default: the small levels of the bucket reduction run one lane — G2: one lane pair — per bucket; 2: G1
  * only; 0: the serial walk),
  * "msm_filter" (1, the default: B1 / B2 and K accumulate from the witness digit stream minus the entries of their absent points),
+ * "msm_chain" (1, the default since round 6: everything of a prove-tail sum after its level-1 kernel — the partial-sum levels, the bucket reduction,
+ * the copies of the finals: ~40 short dependent launches — runs on a second stream beside the NEXT sum's level-1 kernel, the sums' workspace in two
+ * regions that take turns; 0: one stream, one region, every sum behind the one before),
+ * "r1cs_order" (1, the default since round 6: a, b, c = L.w, R.w, O.w walk a matrix's rows by shape — term count, then the pattern of coefficient
+ * kinds — so that the rows of a wave run the same iterations; 0: natural order.  The results are the same bits),
  * the digit-stream sort's (csrc/sort.hip; rocPRIM's "sort_block" of rounds 3-5 is accepted and ignored): "sort_grid" (0, the default: the library's
  * choice; else the number of its persistent 256-thread workgroups — what the sort costs the main stream's kernels is RESIDENCE),
  * "sort_stage" (1: a tile's entries are staged through LDS and leave as whole runs, 40 KB per workgroup; 0: straight to memory from a 4 KB

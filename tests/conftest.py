@@ -53,11 +53,19 @@ def pytest_collection_modifyitems(config, items):
     items.sort(key=key)   # stable: the order inside a file is kept; CPU files (no rank) stay in front, in their own order
 
 
+_SESSION_ZK = []   # the session fixture's context, while it lives
+
+
 def pytest_pyfunc_call(pyfuncitem):
     """`@pytest.mark.isolated`: run this one test in a child pytest and report its verdict.  The child sees ZKPOR_ISOLATED_CHILD=1 and
     runs the body in-process; a SIGABRT / SIGSEGV / GPU fault there is this test's failure, with the tail of the child's output."""
     if not pyfuncitem.get_closest_marker("isolated") or os.environ.get("ZKPOR_ISOLATED_CHILD") == "1" or os.environ.get("ZKPOR_SUITE_ORDER") == "plain":
         return None
+    if _SESSION_ZK:      # the child proves at full size on the same GPU: the session context's grown scratch (40-60 GB after the full-size files) must not sit beside it
+        try:
+            _SESSION_ZK[0].trim()
+        except Exception:  # noqa: BLE001 — a context that cannot trim is the child's problem to report, not this hook's
+            pass
     env = dict(os.environ, ZKPOR_ISOLATED_CHILD="1")
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", pyfuncitem.nodeid]
     try:
@@ -76,5 +84,7 @@ def zk():
     """one libzkpor context on cuda:0 — fails loudly (no fallback) when the HIP library or the GPU is missing"""
     import zkpor
     ctx = zkpor.Context(0)
+    _SESSION_ZK.append(ctx)
     yield ctx
+    _SESSION_ZK.clear()
     ctx.close()

@@ -556,13 +556,14 @@ def test_tail_reserve_cus_may_change_between_proofs():
 
 
 @pytest.mark.isolated
-@pytest.mark.parametrize("reserve,tail_streams,priority,early", [(32, 0, 0, 1), (32, 0, 0, 0), (0, 1, 1, 1), (16, 1, 0, 1)])
-def test_two_workers_device_tails_take_turns_with_every_stream_setting(zk, reserve, tail_streams, priority, early):
+@pytest.mark.parametrize("reserve,tail_streams,priority,early,chain", [(32, 0, 0, 1, 1), (32, 0, 0, 0, 0), (0, 1, 1, 1, 1), (16, 1, 0, 1, 0), (0, 1, 0, 1, 0)])
+def test_two_workers_device_tails_take_turns_with_every_stream_setting(zk, reserve, tail_streams, priority, early, chain):
     """the *_dev split with two worker contexts of one GPU (bench.py's headline shape, host/prover_host.hpp's workers): a masked tail
     ("tail_reserve_cus"), a tail on its own streams without a reserve ("tail_streams") beside a worker whose own stream has the highest
     priority ("stream_priority"), and the digit stream of w built BEFORE the device turn is waited for ("tail_digits_early": the path a
-    worker takes when the other's tail is running) or after — twelve proofs from two threads, every one equal to the single-context proof for
-    its blinding, bit for bit"""
+    worker takes when the other's tail is running) or after, the sums' partial-sum levels and reductions on a chain stream of their own ("msm_chain",
+    round 6: two workspace regions taking turns) or on the tail's one stream — twelve proofs from two threads, every one equal to the single-context,
+    single-stream proof for its blinding, bit for bit"""
     import threading
     log2 = 17
     n = 1 << log2
@@ -588,8 +589,10 @@ def test_two_workers_device_tails_take_turns_with_every_stream_setting(zk, reser
             per.append((src, work, dw)); bufs += src + work + [dw]
         prove = lambda k, r, s: ctxs[k].prove_tail_dev_keep(pk, per[k][2].ptr, per[k][0][0].ptr, per[k][0][1].ptr, per[k][0][2].ptr,
                                                            per[k][1][0].ptr, per[k][1][1].ptr, per[k][1][2].ptr, r, s)
+        zk.set_param("msm_chain", 0)
         want = [prove(0, r, s) for r, s in blind]
         for cx in ctxs:
+            cx.set_param("msm_chain", chain)
             cx.set_param("tail_streams", tail_streams); cx.set_param("stream_priority", priority)
             cx.set_param("tail_reserve_cus", reserve); cx.set_param("tail_digits_early", early)
         got = [None] * len(blind)
@@ -612,8 +615,36 @@ def test_two_workers_device_tails_take_turns_with_every_stream_setting(zk, reser
             assert np.array_equal(g, x)
     finally:
         for cx in ctxs:
-            cx.set_param("tail_reserve_cus", 0); cx.set_param("tail_streams", 0); cx.set_param("tail_digits_early", 1)
+            cx.set_param("tail_reserve_cus", 0); cx.set_param("tail_streams", 0); cx.set_param("tail_digits_early", 1); cx.set_param("msm_chain", 1)
         zk.set_param("stream_priority", 0)
         for x in bufs:
             x.free()
         other.close(); pk.close()
+
+
+def test_the_chain_stream_changes_nothing_but_the_order_of_launches(zk):
+    """"msm_chain" (round 6): a sum's partial-sum levels, bucket reduction and copies on a second stream, beside the NEXT sum's level-1 kernel, the
+    sums' workspace in two regions that take turns — switched on and off between proofs of one context, on the context's own stream, from host
+    memory and from device memory: the same 256 bytes every time, equal to the oracle's proof"""
+    S = O.Synth(6, 1500, n_public=3, seed=21, z_bitrev=True)
+    pk = _load_pk(zk, S, zkpor.Z_ORDER_BITREV)
+    D = 1 << S.log2d
+    pad = lambda v: np.concatenate([v, np.zeros((D - v.shape[0], 4), np.uint64)])
+    bufs = [zk.alloc(32 * D) for _ in range(3)]
+    dw = zk.alloc(32 * S.n_wires).upload(S.w)
+    try:
+        r = O.fr_random(31, 1)[0]; s_ = O.fr_random(32, 1)[0]
+        want = S.prove_tail(r, s_)
+        for chain in (1, 0, 1, 1, 0):
+            zk.set_param("msm_chain", chain)
+            assert np.array_equal(zk.prove_tail(pk, S.w, S.a, S.b, S.c, r, s_), want), chain
+            for b_, v in zip(bufs, (S.a, S.b, S.c)):
+                b_.upload(pad(v))
+            assert np.array_equal(zk.prove_tail_dev(pk, dw.ptr, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, r, s_), want), chain
+            if chain == 0:
+                zk.trim()        # zkpor_trim: workspace, second region, staging area, NTT tables go back to the device and come back on demand
+    finally:
+        zk.set_param("msm_chain", 1)
+        for b_ in bufs + [dw]:
+            b_.free()
+        pk.close()

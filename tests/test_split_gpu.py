@@ -141,7 +141,9 @@ def test_shards_loaded_straight_from_the_key_file(zk, tmp_path, world, from_file
                 consts = pk.consts()
                 got = zk.prove_sums_dev(pk, dw.ptr + 32 * w_lo, dh.ptr + 32 * z_lo)
                 ref.keep_range(w_lo, w_hi, z_lo, z_hi)
-                assert np.array_equal(got, zk.prove_sums_dev(ref, dw.ptr + 32 * w_lo, dh.ptr + 32 * z_lo))
+                # the same five POINTS (affine): the Jacobian triple of a sum depends on the order of the additions inside a bucket, and the digit-stream sort
+                # of round 6 ranks the entries of a bucket with LDS atomics — the order, and with it the representation, may change from run to run
+                assert _affine5(got) == _affine5(zk.prove_sums_dev(ref, dw.ptr + 32 * w_lo, dh.ptr + 32 * z_lo))
                 with pytest.raises(zkpor.ZkporError, match="the key is a shard"):
                     zk.prove_tail(pk, S.w, S.a, S.b, S.c, r, s)
                 parts.append(got)
@@ -156,6 +158,33 @@ def test_shards_loaded_straight_from_the_key_file(zk, tmp_path, world, from_file
         with pytest.raises(zkpor.ZkporError, match="shard range outside the key"):
             pk.load_gnark_shard(data, S.n_public, 0, S.n_wires + 1, 0, 1)
     finally:
+        pk.close()
+
+
+def test_an_empty_sum_leaves_no_event_behind(zk):
+    """"msm_chain" (round 6): a sum's chain of short launches runs on a second stream and the call's final wait is for the LAST chain's event.  A sum
+    without entries (h = 0: Z.h; w = 0: the four witness sums) launches nothing and records nothing — the wait must then be for the last sum that did
+    run, not for a stale event: the other sums of such a call equal those of the full call, several times over"""
+    S = O.Synth(7, 900, n_public=2, seed=57)
+    D = 1 << S.log2d
+    pk = _load(zk, S)
+    h = O.compute_h(S.a, S.b, S.c, S.log2d)
+    dw = zk.alloc(32 * S.n_wires).upload(S.w); dh = zk.alloc(32 * D).upload(h)
+    zw = zk.alloc(32 * S.n_wires).upload(np.zeros((S.n_wires, 4), np.uint64)); zh = zk.alloc(32 * D).upload(np.zeros((D, 4), np.uint64))
+    inf = lambda sums, lo, hi: not np.asarray(sums)[lo + (hi - lo) * 2 // 3:hi].any()      # Jacobian Z = 0
+    try:
+        full = _affine5(zk.prove_sums_dev(pk, dw.ptr, dh.ptr))
+        for chain in (1, 1, 0, 1):
+            zk.set_param("msm_chain", chain)
+            a = zk.prove_sums_dev(pk, dw.ptr, zh.ptr)                  # Z.h empty, it is the LAST sum queued
+            assert inf(a, 480, 576) and _affine5(a)[:3] == full[:3] and _affine5(a)[4] == full[4]
+            b = zk.prove_sums_dev(pk, zw.ptr, dh.ptr)                  # only Z.h runs
+            assert all(inf(b, lo, hi) for lo, hi in ((0, 96), (96, 192), (192, 384), (384, 480))) and _affine5(b)[3] == full[3]
+            assert _affine5(zk.prove_sums_dev(pk, dw.ptr, dh.ptr)) == full
+    finally:
+        zk.set_param("msm_chain", 1)
+        for x in (dw, dh, zw, zh):
+            x.free()
         pk.close()
 
 

@@ -444,13 +444,14 @@ void zkpor_destroy(zkpor_ctx* ctx) try {
     ZK_ENTER(ctx->device);
     // every stream drained first, then the events (they name the stream they were last recorded on), then the streams
     (void)hipStreamSynchronize(ctx->stream);
-    for (hipStream_t st : {ctx->aux_stream, ctx->copy_stream, ctx->tail_aux_free}) if (st) (void)hipStreamSynchronize(st);
-    for (auto& ts : ctx->tail_sets) { (void)hipStreamSynchronize(ts.main); if (ts.aux) (void)hipStreamSynchronize(ts.aux); }
+    for (hipStream_t st : {ctx->aux_stream, ctx->copy_stream, ctx->tail_aux_free, ctx->chain_stream}) if (st) (void)hipStreamSynchronize(st);
+    for (auto& ts : ctx->tail_sets) { (void)hipStreamSynchronize(ts.main); if (ts.aux) (void)hipStreamSynchronize(ts.aux); if (ts.chain) (void)hipStreamSynchronize(ts.chain); }
     for (hipStream_t st : ctx->retired_streams) (void)hipStreamSynchronize(st);
     for (auto& kv : ctx->phases)
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->ws2) (void)hipFree(ctx->ws2);
     if (ctx->dbg_buf) (void)hipFree(ctx->dbg_buf);
     pos_tables_free(ctx);
     ntt_domains_free(ctx);
@@ -459,7 +460,8 @@ void zkpor_destroy(zkpor_ctx* ctx) try {
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-    for (auto& ts : ctx->tail_sets) { zk::stream_release_own_queue(ctx->device, ts.main, ts.reserve); zk::stream_release_own_queue(ctx->device, ts.aux, ts.reserve); }
+    if (ctx->chain_stream) (void)hipStreamDestroy(ctx->chain_stream);
+    for (auto& ts : ctx->tail_sets) { zk::stream_release_own_queue(ctx->device, ts.main, ts.reserve); zk::stream_release_own_queue(ctx->device, ts.aux, ts.reserve); zk::stream_release_own_queue(ctx->device, ts.chain, ts.reserve); }
     zk::stream_release_own_queue(ctx->device, ctx->tail_aux_free, 0);
     for (hipStream_t st : ctx->retired_streams) (void)hipStreamDestroy(st);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -479,6 +481,19 @@ int32_t zkpor_sync(zkpor_ctx* ctx) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx) return ZKPOR_E_ARG;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKPOR_OK;
+} ZK_ABI_CATCH_IN(ctx)
+
+int32_t zkpor_trim(zkpor_ctx* ctx) try {
+    ZK_ENTER(ctx ? ctx->device : -1);
+    if (!ctx) return ZKPOR_E_ARG;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t st : {ctx->aux_stream, ctx->copy_stream, ctx->tail_aux_free, ctx->chain_stream}) if (st) ZK_HIP(ctx, hipStreamSynchronize(st));
+    for (auto& ts : ctx->tail_sets) for (hipStream_t st : {ts.main, ts.aux, ts.chain}) if (st) ZK_HIP(ctx, hipStreamSynchronize(st));
+    if (ctx->ws) { (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_cap = 0; ctx->ws_off = 0; }
+    if (ctx->ws2) { (void)hipFree(ctx->ws2); ctx->ws2 = nullptr; ctx->ws2_cap = 0; }
+    if (ctx->stage) { (void)hipFree(ctx->stage); ctx->stage = nullptr; ctx->stage_cap = 0; }
+    ntt_domains_free(ctx);
     return ZKPOR_OK;
 } ZK_ABI_CATCH_IN(ctx)
 
@@ -504,6 +519,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "sort_generic") { if (value < 0 || value > 1) { ctx->err = "sort_generic must be 0 or 1"; return ZKPOR_E_ARG; } ctx->sort_generic = (int)value; }
     else if (n == "sort_tile") { if (value != 0 && value != 1024 && value != 2048 && value != 4096) { ctx->err = "sort_tile must be 0 (4096), 1024, 2048 or 4096"; return ZKPOR_E_ARG; } ctx->sort_tile = (int)value; }
     else if (n == "sort_block") { if (value != 0 && value != 256 && value != 512) { ctx->err = "sort_block must be 0, 256 or 512"; return ZKPOR_E_ARG; } }   // rounds 3-5: the workgroup size of rocPRIM's onesweep; accepted and ignored since the sort is sort.hip's
+    else if (n == "msm_chain") { if (value < 0 || value > 1) { ctx->err = "msm_chain must be 0 or 1"; return ZKPOR_E_ARG; } ctx->msm_chain = (int)value; }
     else if (n == "msm_reduce_scan") { if (value < 0 || value > 2) { ctx->err = "msm_reduce_scan must be 0, 1 or 2"; return ZKPOR_E_ARG; } ctx->msm_reduce_scan = (int)value; }
     else if (n == "msm_tail_chunk") { if (value != 0 && (value < 4 || value > 64)) { ctx->err = "msm_tail_chunk must be 0 or 4..64"; return ZKPOR_E_ARG; } ctx->msm_tail_chunk = (int)value; }
     else if (n == "aux_priority") {
@@ -540,8 +556,8 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
             return ZKPOR_E_STATE;
         }
         ctx->tail_reserve_cus = (int)value;
-        ctx->tail_stream = ctx->tail_aux = nullptr;
-        for (auto& ts : ctx->tail_sets) if (ts.reserve == (int)value) { ctx->tail_stream = ts.main; ctx->tail_aux = ts.aux; }
+        ctx->tail_stream = ctx->tail_aux = ctx->tail_chain = nullptr;
+        for (auto& ts : ctx->tail_sets) if (ts.reserve == (int)value) { ctx->tail_stream = ts.main; ctx->tail_aux = ts.aux; ctx->tail_chain = ts.chain; }
     }
     else if (n == "tail_digits_early") { if (value < 0 || value > 1) { ctx->err = "tail_digits_early must be 0 or 1"; return ZKPOR_E_ARG; } ctx->tail_digits_early = (int)value; }
     else if (n == "tail_streams") {

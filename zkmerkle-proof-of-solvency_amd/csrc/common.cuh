@@ -60,6 +60,7 @@ struct zkpor_ctx {
     int host_order = 0;              // zkpor_prove_tail from host memory: 0 = w first, a/b/c under the witness sums; 1 = everything first, then the resident order
     int msm_reduce_scan = 1;         // small bucket-reduction levels: one lane (G2: lane pair) per bucket, scan + tree sums; 2 = G1 only (round 2), 0 = serial walk
     int msm_tail_chunk = 8;          // entries per thread of the SMALL partial-sum levels (< 2^21 entries): their duration is the serial chain, not the work; 0 = msm_chunk
+    int msm_chain = 1;               // the prove tail's sums: everything after a sum's level-1 kernel (partial-sum levels, bucket reduction, copies) on a second stream, beside the next sum's level-1 kernel (msm.cuh MsmChain); 0 = one stream
     int msm_filter = 1;              // per-array digit streams: drop the entries of absent points before B1 / B2 and K (msm_digits.hip)
     int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 256: one per CU — bandwidth, not wave slots)
     int ntt_twiddles = 0;            // inter-pass twiddles of the fields whose table exceeds the L2 (2 GiB per direction at 2^26): 0 = read from the table, 1 = generated from two half tables (one more product per element, 15 GB less traffic per computeH)
@@ -92,10 +93,13 @@ struct zkpor_ctx {
     // had (at most TAIL_SETS_MAX values per context), tail_aux_free (every CU, own hardware queue) once.  Round 5 destroyed and re-created them when the
     // parameter changed and the second generation crashed inside the HIP runtime: events of the context (the phase timers' pending pairs, the pool)
     // still name the stream they were last recorded on.  tail_stream / tail_aux are the pair of the current value (null until a tail has run with it).
-    struct TailSet { int reserve; hipStream_t main, aux; };
+    struct TailSet { int reserve; hipStream_t main, aux, chain; };
     static constexpr size_t TAIL_SETS_MAX = 4;
     std::vector<TailSet> tail_sets;
     hipStream_t tail_stream = nullptr, tail_aux = nullptr, tail_aux_free = nullptr;
+    hipStream_t tail_chain = nullptr;           // "msm_chain": the chain stream of the current reserve value's set (own hardware queue, the tail's mask)
+    hipStream_t chain_stream = nullptr;         // ... and of a tail that runs on the context's own stream (an ordinary stream)
+    char* ws2 = nullptr; size_t ws2_cap = 0;    // "msm_chain": the second accumulation region (B1, B2), sized by the sums' ACTUAL entry counts, grow-only (groth16.hip prove_sums)
     std::vector<hipStream_t> retired_streams;   // streams a handle of this context replaced (a solver's first side streams): destroyed with the context
     int debug_validate = 0;          // 1: every sorted digit stream is checked (keys ascending and below the bucket count, point indices inside the array) on the
                                      // accumulating stream before its level-1 kernel reads it; a violation is ZKPOR_E_STATE instead of a GPU memory fault
@@ -245,7 +249,7 @@ int32_t stream_create_own_queue(zkpor_ctx* ctx, hipStream_t* out, int reserve_cu
 void stream_release_own_queue(int device, hipStream_t st, int reserve_cus);
 // after a failed call: nothing the prove tail queued on its own streams (all of them: the unmasked digit stream too) may still touch the stage or the workspace
 inline void drain_tail_streams(zkpor_ctx* ctx) {
-    for (hipStream_t st : {ctx->tail_stream, ctx->tail_aux, ctx->tail_aux_free}) if (st) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : {ctx->tail_stream, ctx->tail_aux, ctx->tail_aux_free, ctx->tail_chain, ctx->chain_stream}) if (st) (void)hipStreamSynchronize(st);
 }
 void bounce_free(zkpor_ctx* ctx);
 // One caller at a time runs the GPU part of a host-pointer call on a device (the others keep moving their vectors across PCIe

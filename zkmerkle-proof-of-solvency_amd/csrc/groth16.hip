@@ -618,8 +618,14 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
             if (ctx->tail_sets.size() >= zkpor_ctx::TAIL_SETS_MAX) { ctx->err = "prove: no masked stream left for this tail_reserve_cus"; return ZKPOR_E_STATE; }
             hipStream_t st = nullptr;
             ZK_TRY(stream_create_own_queue(ctx, &st, ctx->tail_reserve_cus));
-            ctx->tail_sets.push_back({ctx->tail_reserve_cus, st, nullptr});
-            ctx->tail_stream = st; ctx->tail_aux = nullptr;
+            ctx->tail_sets.push_back({ctx->tail_reserve_cus, st, nullptr, nullptr});
+            ctx->tail_stream = st; ctx->tail_aux = nullptr; ctx->tail_chain = nullptr;
+        }
+        if (ctx->msm_chain && !ctx->tail_chain) {
+            hipStream_t st = nullptr;
+            ZK_TRY(stream_create_own_queue(ctx, &st, ctx->tail_reserve_cus));
+            for (auto& ts : ctx->tail_sets) if (ts.reserve == ctx->tail_reserve_cus) ts.chain = st;
+            ctx->tail_chain = st;
         }
         if (want_masked_aux && !ctx->tail_aux) {
             hipStream_t st = nullptr;
@@ -632,8 +638,19 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         // (profiles/r03_timeline_*.txt); "tail_aux_masked" 0 lets them use the reserved compute units as well — on a stream with its own hardware queue
         main_s = ctx->tail_stream; aux_s = want_masked_aux ? ctx->tail_aux : ctx->tail_aux_free;
     }
+    // "msm_chain": the sums' partial-sum levels / reductions / copies on a stream of their own (msm.cuh MsmChain), two workspace regions taking turns
+    hipStream_t chain_s = nullptr;
+    if (ctx->msm_chain) {
+        if (masked) chain_s = ctx->tail_chain;
+        else {
+            if (!ctx->chain_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->chain_stream, hipStreamNonBlocking));
+            chain_s = ctx->chain_stream;
+        }
+    }
     hipEvent_t e_start = ev_get(ctx), e_h = ev_get(ctx), e_w = ev_get(ctx), e_hs = ev_get(ctx), e_up = ev_get(ctx), e_wB = ev_get(ctx), e_wK = ev_get(ctx);
-    struct EvGuard { zkpor_ctx* c; hipEvent_t e[7]; hipStream_t m; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up, e_wB, e_wK}, caller_s};
+    MsmChain chains[5];
+    for (auto& ch : chains) { ch.stream = chain_s; ch.ev_level1 = ev_get(ctx); ch.ev_done = ev_get(ctx); }
+    struct EvGuard { zkpor_ctx* c; hipEvent_t e[7]; hipStream_t m; MsmChain* ch; ~EvGuard() { c->stream = m; for (auto x : e) c->event_pool.push_back(x); for (int i = 0; i < 5; ++i) { c->event_pool.push_back(ch[i].ev_level1); c->event_pool.push_back(ch[i].ev_done); } } } guard{ctx, {e_start, e_h, e_w, e_hs, e_up, e_wB, e_wK}, caller_s, chains};
     // several workers of a GPU with a reserved-CU tail: ONE prove tail at a time (two would only time-slice each other on the same compute units), so
     // that the other worker's SOLVE is what runs beside it; the waiting worker sleeps here, its solver's prefetched chains keep running
     // Round 6: when ANOTHER worker's tail holds the device, this proof's digit stream of w (decompose + sort + filters: bandwidth and LDS, no field
@@ -663,7 +680,15 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     size_t need_dh = digits_ws_bytes(ctx, nZ ? nZ : 1, cfgh, &sorth);
     size_t need_aw = accumulate_ws_bytes<Fp2>(cfgw, pk->n_wires * (size_t)cfgw.W);
     size_t need_ah = accumulate_ws_bytes<Fp>(cfgh, (nZ ? nZ : 1) * (size_t)cfgh.W);
-    ZK_TRY(ws_reserve(ctx, need_dw + need_dh + (need_aw > need_ah ? need_aw : need_ah)));
+    // one accumulation region the sums reuse in stream order — or, with a chain stream, two that take turns: region 0 (here, behind the digit streams) for
+    // A, K, Z, region 1 (ctx->ws2, below) for B1 and B2.  A sum's level-1 kernel waits for the chain of the region's previous user (which has had a whole
+    // level-1 kernel's time to finish)
+    size_t region0 = need_aw > need_ah ? need_aw : need_ah;
+    if (chain_s) {
+        const size_t need_aw1 = accumulate_ws_bytes<Fp>(cfgw, pk->n_wires * (size_t)cfgw.W);
+        region0 = need_aw1 > need_ah ? need_aw1 : need_ah;
+    }
+    ZK_TRY(ws_reserve(ctx, need_dw + need_dh + region0));
     ZK_TRY(ensure_pinned(ctx, 16 * MSM_SLOT_BYTES));
     char* pin = (char*)ctx->pinned;
     const size_t D = (size_t)1 << n;
@@ -712,9 +737,52 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
     // 2. digit stream of the witness on the auxiliary stream (unless it was built before the turn)
     const size_t mark = need_dw + need_dh;
     MsmPending pA, pB1, pK, pB2, pZ;
+    hipEvent_t region_busy[2] = {nullptr, nullptr};     // ev_done of the chain that used the region last
+    int taken_region[5] = {0, 0, 0, 0, 0};
+    hipEvent_t last_chain = nullptr, last_level1 = nullptr;
+    // sum `which` (0 A, 1 B1, 2 K, 3 B2, 4 Z) takes its region: the level-1 kernel (it clears the buckets) behind the region's previous chain.
+    // Region 1 is an arena of its own, sized when B1 is queued — by then the host knows the entry count of the B stream — for the larger of its two users
+    // (B2's G2 images) plus an eighth: 6.4 GB for zkpor50_1380 instead of the 13.2 GB a worst-case stream (every digit of every scalar non-zero) would need,
+    // so that the two regions together are no larger than the one region of round 5.  It grows (behind a wait for the chain stream) when a witness needs more;
+    // if it cannot, the sum runs unchained in region 0.
+    struct ArenaSwap {   // ws_alloc serves from ctx->ws: a sum of region 1 sees ctx->ws2 as its arena for the duration of its queueing
+        zkpor_ctx* c; char* ws; size_t cap; bool on = false;
+        explicit ArenaSwap(zkpor_ctx* c_) : c(c_), ws(c_->ws), cap(c_->ws_cap) {}
+        void to_ws2() { c->ws = c->ws2; c->ws_cap = c->ws2_cap; c->ws_off = 0; on = true; }
+        ~ArenaSwap() { if (on) { c->ws = ws; c->ws_cap = cap; } }
+    };
+    auto region_of = [&](int which) { return (chain_s && (which == 1 || which == 3)) ? 1 : 0; };
+    auto take_region = [&](int which, ArenaSwap& arena) -> const MsmChain* {
+        int r = region_of(which);
+        if (r == 1) {
+            size_t need = accumulate_ws_bytes<Fp2>(cfgw, dswB.M) + (1u << 20);
+            if (need > ctx->ws2_cap) {
+                need += need / 8;
+                (void)hipStreamSynchronize(chain_s);      // region 1's previous user
+                if (ctx->ws2) { (void)hipFree(ctx->ws2); ctx->ws2 = nullptr; ctx->ws2_cap = 0; }
+                if (hipMalloc((void**)&ctx->ws2, need) == hipSuccess) ctx->ws2_cap = need;
+                else { (void)hipGetLastError(); ctx->ws2 = nullptr; r = 0; }
+            }
+        }
+        if (r == 1) arena.to_ws2(); else ctx->ws_off = mark;
+        if (!chain_s) return nullptr;
+        if (region_busy[0] && r == 0) (void)hipStreamWaitEvent(main_s, region_busy[0], 0);
+        if (region_busy[1] && r == 1) (void)hipStreamWaitEvent(main_s, region_busy[1], 0);
+        taken_region[which] = r;
+        return (r == 1 || region_of(which) == 0) ? &chains[which] : nullptr;     // a region-1 sum that fell back to region 0 runs unchained
+    };
+    // ... and leaves its events behind — only if it recorded them (an empty sum launches nothing)
+    auto queued = [&](int which, const MsmPending& p) {
+        if (!p.chained) return;
+        region_busy[taken_region[which]] = chains[which].ev_done;
+        last_chain = chains[which].ev_done; last_level1 = chains[which].ev_level1;
+    };
     auto queue_b2 = [&]() -> int32_t {
-        ctx->ws_off = mark;
-        return msm_accumulate_launch<Fp2>(ctx, dswB, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2);
+        ArenaSwap arena(ctx);
+        const MsmChain* ch = take_region(3, arena);
+        ZK_TRY(msm_accumulate_launch<Fp2>(ctx, dswB, pk->B2, pin + 6 * MSM_SLOT_BYTES, pin + 8 * MSM_SLOT_BYTES, &pB2, ch));
+        queued(3, pB2);
+        return ZKPOR_OK;
     };
     if (do_w) {
         if (!early_digits) {
@@ -722,17 +790,29 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
             off_dh = ctx->ws_off;
         }
         // 3. queue the witness accumulations (they reuse one workspace region in stream order)
-        ctx->ws_off = mark;
         // "msm_filter" 2: A waits for the filter as well, so that the filter runs on an otherwise idle GPU (with a full-size grid) instead of
         // beside A's VALU-bound kernel, where it is starved and starves (profiles/r03_filter.txt)
         ZK_HIP(ctx, hipStreamWaitEvent(main_s, (n_filters && ctx->msm_filter == 2) ? e_wK : e_w, 0));
-        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->A, pin + 0 * MSM_SLOT_BYTES, pin + 1 * MSM_SLOT_BYTES, &pA));
-        ctx->ws_off = mark;
+        {
+            ArenaSwap arena(ctx);
+            const MsmChain* ch = take_region(0, arena);
+            ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsw, pk->A, pin + 0 * MSM_SLOT_BYTES, pin + 1 * MSM_SLOT_BYTES, &pA, ch));
+            queued(0, pA);
+        }
         ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_wB, 0));
-        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dswB, pk->B1, pin + 2 * MSM_SLOT_BYTES, pin + 3 * MSM_SLOT_BYTES, &pB1));
-        ctx->ws_off = mark;
+        {
+            ArenaSwap arena(ctx);
+            const MsmChain* ch = take_region(1, arena);
+            ZK_TRY(msm_accumulate_launch<Fp>(ctx, dswB, pk->B1, pin + 2 * MSM_SLOT_BYTES, pin + 3 * MSM_SLOT_BYTES, &pB1, ch));
+            queued(1, pB1);
+        }
         ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_wK, 0));
-        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dswK, pk->K, pin + 4 * MSM_SLOT_BYTES, pin + 5 * MSM_SLOT_BYTES, &pK));
+        {
+            ArenaSwap arena(ctx);
+            const MsmChain* ch = take_region(2, arena);
+            ZK_TRY(msm_accumulate_launch<Fp>(ctx, dswK, pk->K, pin + 4 * MSM_SLOT_BYTES, pin + 5 * MSM_SLOT_BYTES, &pK, ch));
+            queued(2, pK);
+        }
         if (!host) ZK_TRY(queue_b2());
     }
     if (host) {
@@ -760,11 +840,20 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         ZK_HIP(ctx, hipEventRecord(e_hs, aux_s));
         ctx->stream = main_s;
         // 5. Z . h
-        ctx->ws_off = mark;
         ZK_HIP(ctx, hipStreamWaitEvent(main_s, e_hs, 0));
-        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsh, pk->Z, pin + 10 * MSM_SLOT_BYTES, pin + 11 * MSM_SLOT_BYTES, &pZ));
+        ArenaSwap arena(ctx);
+        const MsmChain* ch = take_region(4, arena);
+        ZK_TRY(msm_accumulate_launch<Fp>(ctx, dsh, pk->Z, pin + 10 * MSM_SLOT_BYTES, pin + 11 * MSM_SLOT_BYTES, &pZ, ch));
+        queued(4, pZ);
     }
+    if (last_chain) ZK_HIP(ctx, hipStreamWaitEvent(main_s, last_chain, 0));   // the chain stream runs in order: its last chain is behind every other
     if (while_gpu_runs) (*while_gpu_runs)();  // host work that needs no device result: everything is queued, nothing is waited for yet
+    if (turn && last_level1) {
+        // the last sum's level-1 kernel is the last launch of this call that fills the device: behind it only a chain of short dependent launches is
+        // left, and the next caller's first kernels (its NTT passes) may as well run beside that
+        ZK_HIP(ctx, hipEventSynchronize(last_level1));
+        turn->release();
+    }
     ZK_HIP(ctx, hipStreamSynchronize(main_s));
     if (turn) turn->release();   // the device is free for the next caller while this one finishes on the host
     HostPhase hp(ctx, "host_assembly");

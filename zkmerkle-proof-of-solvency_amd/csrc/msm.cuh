@@ -221,17 +221,24 @@ struct MsmPending {  // a multi-exponentiation whose kernels are queued; its per
     u64 Kmul = 0;
     bool empty = true;
     bool raw29 = false;  // finals are raw 29-bit images (converted on the host) rather than XYZZ<F>
+    bool chained = false;  // the part after level 1 went to the chain stream: its events WERE recorded (an empty sum records nothing)
     void* hS = nullptr;  // W finals, pinned
     void* hY = nullptr;
 };
+
+// Round 6 ("msm_chain"): everything of a multi-exponentiation AFTER its level-1 kernel — the partial-sum levels, the bucket reduction, the copies of the
+// finals: ~40 short dependent launches, 5-6 ms during which the device is mostly idle — may run on a second stream, beside the NEXT sum's level-1
+// kernel on ctx->stream.  ev_level1 is recorded on ctx->stream behind the level-1 kernel (the chain waits for it), ev_done on the chain stream behind the
+// last copy: whoever reuses this sum's workspace region, and the final host wait, must wait for ev_done.
+struct MsmChain { hipStream_t stream = nullptr; hipEvent_t ev_level1 = nullptr, ev_done = nullptr; };
 
 // queue bucket accumulation + reduction for one point array on ctx->stream; NO host synchronisation: the W per-window
 // (S, Y) pairs are copied to the pinned slots in stream order, so the next accumulation may reuse the workspace.
 template <class F>
 inline int32_t msm_accumulate_launch(zkpor_ctx* ctx, const DigitStream& ds, const Affine<F>* d_pts, void* pinned_S,
-                                     void* pinned_Y, MsmPending* out) {
+                                     void* pinned_Y, MsmPending* out, const MsmChain* chain = nullptr) {
     const MsmCfg& cfg = ds.cfg;
-    out->cfg = cfg; out->hS = pinned_S; out->hY = pinned_Y; out->Kmul = 0;
+    out->cfg = cfg; out->hS = pinned_S; out->hY = pinned_Y; out->Kmul = 0; out->chained = false;
     out->empty = ds.M == 0;
     if (ds.M == 0) return ZKPOR_OK;
     const u32 M = ds.M;
@@ -255,6 +262,17 @@ inline int32_t msm_accumulate_launch(zkpor_ctx* ctx, const DigitStream& ds, cons
         PhaseScope ps(ctx, "msm_accumulate");
         if (raw) ZK_TRY(launch_level1_29(ctx, ds.keys, ds.vals, d_pts, M, L, (u32)cfg.NB, (u32*)buckets, ka, (u32*)pa));
         else ZK_TRY(launch_level1(ctx, ds.keys, ds.vals, d_pts, M, L, (u32)cfg.NB, (XYZZ<F>*)buckets, ka, (XYZZ<F>*)pa));
+    }
+    // the rest on the chain stream (when there is one); the context's stream is restored on every way out
+    struct StreamBack { zkpor_ctx* c; hipStream_t s; ~StreamBack() { c->stream = s; } } stream_back{ctx, ctx->stream};
+    const bool chained = chain && chain->stream && chain->stream != ctx->stream;
+    if (chained) {
+        ZK_HIP(ctx, hipEventRecord(chain->ev_level1, ctx->stream));
+        ZK_HIP(ctx, hipStreamWaitEvent(chain->stream, chain->ev_level1, 0));
+        ctx->stream = chain->stream;
+    }
+    {
+        PhaseScope ps(ctx, "msm_accumulate");
         size_t T = T1;
         char* src = pa; u32* srck = ka; char* dst = pb; u32* dstk = kb;
         while (T > 1) {
@@ -294,6 +312,7 @@ inline int32_t msm_accumulate_launch(zkpor_ctx* ctx, const DigitStream& ds, cons
     out->Kmul = Kmul;
     ZK_HIP(ctx, hipMemcpyAsync(pinned_S, fin_S, fin_bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipMemcpyAsync(pinned_Y, fin_Y, fin_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (chained) { ZK_HIP(ctx, hipEventRecord(chain->ev_done, chain->stream)); out->chained = true; }
     return ZKPOR_OK;
 }
 

@@ -87,6 +87,11 @@ class Context:
         if rc != 0:
             raise ZkporError(f"zkpor_init failed with {rc} (no usable gfx950 device?)")
         self.h = h
+        # ZKPOR_PARAMS="name=value,...": experiment hook (like ZKPOR_LIB) — parameters every context of the process starts with, so that a whole test file
+        # can be run under a non-default setting
+        for nv in filter(None, os.environ.get("ZKPOR_PARAMS", "").split(",")):
+            name, _, val = nv.partition("=")
+            self.set_param(name.strip(), int(val))
 
     def _ck(self, rc):
         if rc != 0:
@@ -102,6 +107,10 @@ class Context:
 
     def sync(self):
         self._ck(self.lib.zkpor_sync(self.h))
+
+    def trim(self):
+        """zkpor_trim: the context's grow-only scratch (workspace, staging area, NTT tables) back to the device; re-created on demand"""
+        self._ck(self.lib.zkpor_trim(self.h))
 
     def phase_ms(self, name):
         calls = ctypes.c_uint64()
