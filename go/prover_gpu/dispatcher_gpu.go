@@ -52,6 +52,7 @@ type dispatcher struct {
 	parkMu  sync.Mutex
 	parked  map[int][]*witness.BatchWitness // by tier; rows already CASed to Received by this process
 	drained bool                            // the feed has ended: parked tiers are proved now, one switch per tier
+	workers []*gpuWorker                    // every worker of the process (set once, before the loops start): a tier switch trims their contexts
 }
 
 // RunInProcess is Prover.Run for one process that drives `gpus` with `workersPerGPU` workers each.
@@ -83,6 +84,7 @@ func (p *Prover) RunInProcess(rerun bool, gpus []int, workersPerGPU int) error {
 			workers = append(workers, &gpuWorker{gpu: g, ctx: ctx})
 		}
 	}
+	d.workers = workers
 	heights := make(chan int64, 4*len(workers))
 	if !rerun {
 		go d.feed(heights) // replaces BRPOP: the queue IS the Published rows of the witness table
@@ -354,6 +356,13 @@ func (d *dispatcher) generateAndVerifyProof(w *gpuWorker, bwit *utils.BatchCreat
 	for tier != p.CurrentSnarkParamsInUse {
 		d.tier.RUnlock()
 		d.tier.Lock() // every proof in flight has finished
+		if tier != p.CurrentSnarkParamsInUse {
+			// round 6: the old tier's scratch (digit streams, accumulation regions, NTT tables: 40-60 GB per worker context after 2^26 proofs) goes back to
+			// the device before the new tier's key arrives beside the old one (zkpor_trim; the next proof re-creates what it needs)
+			for _, ow := range d.workers {
+				_ = ow.ctx.Trim()
+			}
+		}
 		p.LoadSnarkParamsOnce(tier) // no-op if another worker switched meanwhile; uploads the tier's key to every GPU in p.GPUs
 		d.tier.Unlock()
 		d.tier.RLock()

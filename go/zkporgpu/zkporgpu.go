@@ -47,6 +47,11 @@ func (c *Context) SetParam(name string, value int64) error {
 	return c.err(C.zkpor_set_param(c.h, cname, C.int64_t(value)))
 }
 
+// Trim hands the context's grow-only scratch (multi-exponentiation workspace, staging area, NTT tables: 40-60 GB after 2^26 proofs) back to
+// the device (zkpor_trim); the next proof re-creates what it needs.  LoadSnarkParamsOnce calls it on every worker context before it uploads
+// another tier's key, so that the old tier's scratch does not sit beside the new key.
+func (c *Context) Trim() error { return c.err(C.zkpor_trim(c.h)) }
+
 func (c *Context) Close() {
 	if c.h != nil {
 		C.zkpor_destroy(c.h)

@@ -317,6 +317,19 @@ def test_compute_h_sharded_equals_unsharded(zk, log2, wlog):
             b.free()
 
 
+@pytest.mark.isolated
+def test_the_ranks_one_after_the_other_on_one_gpu():
+    """tools/split_one_gpu.py at 2^20: the run that was done once at 2^28 on one MI355X (profiles/r06_split_2p28_eight_shards_one_gpu.json; BASELINE.json
+    configs[4]) — computeH sharded 8 ways with the all-to-alls as device copies, the key's eight ranges summed one after the other, the partial sums
+    added on the host: the sharded h is the unsharded h bit for bit and satisfies the quotient identity, the proof is what the key's discrete logs predict"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import split_one_gpu
+    res = split_one_gpu.run(20, 3, check_h="yes", log=lambda s: None)
+    assert res["sharded_h_equals_unsharded_h"] is True and res["h_satisfies_the_quotient_identity"] is True
+    assert res["proof_equals_the_trapdoor_prediction"] is True and res["another_blinding_is_rejected"] is True
+    assert len(res["sums_ms_per_rank"]) == 8
+
+
 def test_split_nccl_all_visible_gpus(tmp_path):
     """the same worker with one rank per visible GPU (2, 4 or 8): scatter / all-to-all / all-gather over RCCL between real devices,
     rank-0 computeH and sharded computeH; opt-in (ZKPOR_TEST_MULTI_GPU=1) and skipped on a one-GPU box"""

@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""ONE proof split W ways (BASELINE.json configs[4]: a 2^28-constraint proof over 8 MI355X) with the W ranks run ONE AFTER THE OTHER on one GPU.
+
+What a rank of `bench.py --split` does on its own GPU runs here for rank 0, 1, ... W-1 in turn through the same entry points of the C ABI
+(zkpor_compute_h_shard_dev, zkpor_shard_transpose_dev, zkpor_pk_keep_range, zkpor_prove_sums_dev, zkpor_prove_assemble); what RCCL moves between
+the ranks (seven all-to-alls of 1/W of a vector, one 576-byte all-gather) is done with device-to-device copies.  No xGMI, no RCCL: what this run
+establishes is that the 2^28 PATH works and is right — index algebra of the sharded transform at 28 bits, 32-bit digit-stream indexing per shard,
+the key ranges, the host-side addition of the partial sums — and what a rank's share of the work costs in time and HBM.  The proof is checked
+against the synthetic key's discrete logs (oracle/trapdoor.py, streamed in chunks) and h against its definition (oracle/quotient.hpp) when the
+host has the memory for a, b, c, h at once (4 x 32 x 2^log2 bytes).
+
+    python tools/split_one_gpu.py --log2 28 --wlog 3 --out gpurun_out/split_2p28.json
+
+Reference: groth16.Prove (src/prover/prover/prover.go:269); gnark has no multi-device counterpart."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "zkmerkle-proof-of-solvency_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+SEED = 0x5A4B504F52
+
+
+def _vp(x):
+    return ctypes.c_void_p(x)
+
+
+def _view(zkpor, zk, ptr, nbytes):
+    v = zkpor.DevBuf.__new__(zkpor.DevBuf)
+    v.ctx = zk; v.ptr = ptr; v.nbytes = nbytes
+    return v
+
+
+def _chunks(n, step):
+    for lo in range(0, n, step):
+        yield lo, min(n, lo + step)
+
+
+def trapdoor_dots(zkpor, zk, O, T, seed, n_public, d_w, n_wires, d_h, n_z, chunk=1 << 22):
+    """<sA, w>, <sB, w>, <sK, w>, <sZ, h> with w and h streamed from the device in chunks (oracle/trapdoor.py's numpy generator: nothing of the
+    device code, nothing of the fused C form either)"""
+    acc = {k: O.fr_from_ints([0])[0] for k in "ABKZ"}
+
+    def add(key, arr, lo, hi, x, inf_below=0):
+        c = T.synth_scalars_canon(seed, arr, lo, hi, None, inf_below)
+        m = np.empty_like(c)
+        O.lib().orc_fr_from_canon(O._p(c), O._p(m), hi - lo)
+        acc[key] = O.fr_add(acc[key].reshape(1, 4), O.fr_dot(m, x).reshape(1, 4))[0]
+
+    for lo, hi in _chunks(n_wires, chunk):
+        x = _view(zkpor, zk, d_w + 32 * lo, 32 * (hi - lo)).download(np.uint64, (hi - lo, 4))
+        add("A", T.G1_A, lo, hi, x); add("B", T.G1_B, lo, hi, x); add("K", T.G1_K, lo, hi, x, inf_below=n_public)
+    for lo, hi in _chunks(n_z, chunk):
+        x = _view(zkpor, zk, d_h + 32 * lo, 32 * (hi - lo)).download(np.uint64, (hi - lo, 4))
+        add("Z", T.G1_Z, lo, hi, x)
+    return acc
+
+
+def run(log2, wlog, check_h="auto", reference_h=True, log=print):
+    import oracle as O
+    import split
+    import trapdoor as T
+    import zkpor
+    W = 1 << wlog
+    n = 1 << log2
+    nl = log2 - wlog
+    res = {"log2": log2, "ranks": W, "what": "one proof, key and computeH sharded %d ways, the ranks run one after the other on ONE MI355X "
+           "(device-to-device copies in place of the all-to-alls / the all-gather)" % W}
+    zk = zkpor.Context(0)
+    cp = lambda dst, src, nbytes: zk._ck(zk.lib.zkpor_dev_copy(zk.h, _vp(dst), _vp(src), ctypes.c_size_t(nbytes)))
+    bufs = []
+
+    def alloc(nbytes):
+        b = zk.alloc(nbytes); bufs.append(b)
+        return b
+
+    try:
+        w = alloc(32 * n)
+        full = {k: alloc(32 * n) for k in "abc"}
+        zk.fill_fr(w, n, 2, 1)                                   # the witness-like mixture of the full-size tests
+        zk.fill_fr(full["a"], n, 11, 0); zk.fill_fr(full["b"], n, 12, 0)
+        zk._ck(zk.lib.zkpor_dev_fr_mul(zk.h, _vp(full["c"].ptr), _vp(full["a"].ptr), _vp(full["b"].ptr), ctypes.c_size_t(n)))
+        # ---- D_low slices: rank r holds the elements at positions p = r mod W (one de-interleave of the whole vector: out[r * M + i] = in[i * W + r])
+        loc = {}
+        stage = alloc(32 * n)
+        for k in "abc":
+            zk.shard_transpose_dev(stage.ptr, full[k].ptr, log2, wlog, False)
+            loc[k] = [alloc(32 << nl) for _ in range(W)]
+            for r in range(W):
+                cp(loc[k][r].ptr, stage.ptr + r * (32 << nl), 32 << nl)
+        tmp = [_view(zkpor, zk, stage.ptr + r * (32 << nl), 32 << nl) for r in range(W)]     # the exchange's receive buffers
+        chunk = 32 << (nl - wlog)
+
+        def all_to_all(b, to_high):
+            if not to_high:
+                for r in range(W):
+                    zk.shard_transpose_dev(tmp[r].ptr, b[r].ptr, nl, wlog, False)
+                for s in range(W):
+                    for d in range(W):
+                        cp(b[d].ptr + s * chunk, tmp[s].ptr + d * chunk, chunk)
+            else:
+                for s in range(W):
+                    for d in range(W):
+                        cp(tmp[d].ptr + s * chunk, b[s].ptr + d * chunk, chunk)
+                for r in range(W):
+                    zk.shard_transpose_dev(b[r].ptr, tmp[r].ptr, nl, wlog, True)
+
+        # ---- computeH over the W ranks: per-rank time of every step (a rank of the real run does exactly one of the W calls of a step)
+        step_ms = []
+        ptrs = lambda r: (loc["a"][r].ptr, loc["b"][r].ptr, loc["c"][r].ptr)
+        for step in range(4):
+            per_rank = []
+            for r in range(W):
+                zk.sync(); t0 = time.perf_counter()
+                if step < 3:
+                    zk.compute_h_shard_dev(log2, wlog, r, *ptrs(r), step)
+                else:
+                    zk.compute_h_shard_dev(log2, wlog, r, loc["a"][r].ptr, None, None, 3)
+                zk.sync(); per_rank.append((time.perf_counter() - t0) * 1e3)
+            step_ms.append(per_rank)
+            if step == 0:
+                for k in "abc":
+                    all_to_all(loc[k], True)
+            elif step == 1:
+                for k in "abc":
+                    all_to_all(loc[k], False)
+            elif step == 2:
+                all_to_all(loc["a"], True)
+        res["compute_h_sharded_ms_per_rank_by_step"] = [[round(x, 2) for x in s] for s in step_ms]
+        res["compute_h_sharded_ms_per_rank"] = round(sum(max(s) for s in step_ms), 2)
+        res["all_to_all_bytes_per_rank"] = 7 * (32 << nl) * (W - 1) // W
+        log(f"computeH sharded: {res['compute_h_sharded_ms_per_rank']} ms per rank (max over ranks, summed over the four steps)")
+        # rank r's block of h = positions [r * 2^nl, (r + 1) * 2^nl) of h in the order of the key's Z: put them side by side
+        h = stage
+        for r in range(W):
+            cp(h.ptr + r * (32 << nl), loc["a"][r].ptr, 32 << nl)
+        for k in "bc":
+            for b in loc[k]:
+                b.free(); bufs.remove(b)
+        for b in loc["a"]:
+            b.free(); bufs.remove(b)
+        # ---- the unsharded transform on the same inputs, where the device supports the size: the same bits
+        if reference_h:
+            try:
+                zk.sync(); t0 = time.perf_counter()
+                zk.compute_h_dev(log2, full["a"].ptr, full["b"].ptr, full["c"].ptr)
+                zk.sync(); res["compute_h_unsharded_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+                same = True
+                for lo, hi in _chunks(n, 1 << 23):
+                    x = _view(zkpor, zk, h.ptr + 32 * lo, 32 * (hi - lo)).download(np.uint64, (hi - lo, 4))
+                    y = _view(zkpor, zk, full["a"].ptr + 32 * lo, 32 * (hi - lo)).download(np.uint64, (hi - lo, 4))
+                    same &= bool(np.array_equal(x, y))
+                res["sharded_h_equals_unsharded_h"] = same
+                log(f"unsharded computeH {res['compute_h_unsharded_ms']} ms, same bits: {same}")
+            except zkpor.ZkporError as e:
+                res["compute_h_unsharded"] = f"not available at this size: {e}"
+        # ---- the five sums, shard by shard
+        r_bl = O.fr_random(71, 1)[0]; s_bl = O.fr_random(72, 1)[0]
+        parts, shard_ms, shard_phases, consts = [], [], [], None
+        for r in range(W):
+            pk = zkpor.ProvingKey(zk)
+            try:
+                pk.synth(log2, n, 3, 0, SEED)
+                if consts is None:
+                    consts = pk.consts()
+                w_lo, w_hi = split.wire_range(n, r, W); z_lo, z_hi = split.z_range(n, r, W)
+                pk.keep_range(w_lo, w_hi, z_lo, z_hi)
+                zk.phase_reset(); zk.sync(); t0 = time.perf_counter()
+                parts.append(zk.prove_sums_dev(pk, w.ptr + 32 * w_lo, h.ptr + 32 * z_lo))
+                shard_ms.append((time.perf_counter() - t0) * 1e3)
+                shard_phases.append({k: round(zk.phase_ms(k)[0], 2) for k in ("msm_sort", "msm_accumulate", "msm_reduce", "k_acc_level1_g1", "k_acc_level1_g2")})
+                log(f"rank {r}: five sums over wires [{w_lo}, {w_hi}) and h [{z_lo}, {z_hi}) in {shard_ms[-1]:.1f} ms")
+            finally:
+                pk.close()
+            zk.trim()
+        res["sums_ms_per_rank"] = [round(x, 2) for x in shard_ms]
+        res["sums_phases_rank0"] = shard_phases[0]
+        res["estimated_ms_per_proof_on_%d_gpus_without_exchange" % W] = round(res["compute_h_sharded_ms_per_rank"] + max(shard_ms[1:] or shard_ms), 2)
+        proof = zkpor.prove_assemble(consts, split.add_partial_sums(np.stack(parts)), r_bl, s_bl)
+        # ---- checks
+        t0 = time.perf_counter()
+        dots = trapdoor_dots(zkpor, zk, O, T, SEED, 3, w.ptr, n, h.ptr, n - 1)
+        td = T.SynthKeyTrapdoor(SEED, 3, np.zeros((1, 4), np.uint64), np.zeros((1, 4), np.uint64))
+        td.dA, td.dB, td.dK, td.dZ = dots["A"], dots["B"], dots["K"], dots["Z"]
+        res["proof_equals_the_trapdoor_prediction"] = bool(td.check(proof, r_bl, s_bl))
+        r2 = O.fr_random(73, 1)[0]
+        res["another_blinding_is_rejected"] = not td.check(proof, r2, s_bl)
+        res["trapdoor_seconds"] = round(time.perf_counter() - t0, 1)
+        log(f"trapdoor: {res['proof_equals_the_trapdoor_prediction']} ({res['trapdoor_seconds']} s)")
+        avail = 0
+        try:
+            for line in open("/proc/meminfo"):
+                if line.startswith("MemAvailable"):
+                    avail = int(line.split()[1]) * 1024
+        except OSError:
+            pass
+        lim = None
+        for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            try:
+                v = open(f).read().strip()
+                lim = None if v == "max" else int(v)
+                break
+            except (OSError, ValueError):
+                pass
+        res["host_memory"] = {"MemAvailable": avail, "cgroup_limit": lim}
+        need = 4 * 32 * n * 1.25
+        if check_h == "yes" or (check_h == "auto" and avail > need and (lim is None or lim > need)):
+            t0 = time.perf_counter()
+            zk.fill_fr(full["a"], n, 11, 0); zk.fill_fr(full["b"], n, 12, 0)     # computeH worked in place: the inputs again, from their seeds
+            zk._ck(zk.lib.zkpor_dev_fr_mul(zk.h, _vp(full["c"].ptr), _vp(full["a"].ptr), _vp(full["b"].ptr), ctypes.c_size_t(n)))
+            host = [full[k].download(np.uint64, (n, 4)) for k in "abc"] + [h.download(np.uint64, (n, 4))]
+            res["h_satisfies_the_quotient_identity"] = bool(O.quotient_identity(log2, host[0], host[1], host[2], host[3], O.fr_random(4242, 1)[0]))
+            res["quotient_identity_seconds"] = round(time.perf_counter() - t0, 1)
+            log(f"quotient identity: {res['h_satisfies_the_quotient_identity']} ({res['quotient_identity_seconds']} s)")
+        else:
+            res["h_satisfies_the_quotient_identity"] = None
+            res["h_check_skipped"] = "host memory"
+        res["proof_hex"] = bytes(proof).hex()
+        return res
+    finally:
+        for b in bufs:
+            try:
+                b.free()
+            except Exception:  # noqa: BLE001
+                pass
+        zk.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2", type=int, default=28)
+    ap.add_argument("--wlog", type=int, default=3)
+    ap.add_argument("--check-h", choices=["auto", "yes", "no"], default="auto")
+    ap.add_argument("--no-reference-h", action="store_true")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    res = run(args.log2, args.wlog, args.check_h, not args.no_reference_h, log=lambda s: print(s, file=sys.stderr, flush=True))
+    txt = json.dumps(res, indent=1)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        open(args.out, "w").write(txt + "\n")
+    print(txt)
+    ok = res.get("proof_equals_the_trapdoor_prediction") and res.get("h_satisfies_the_quotient_identity") is not False and res.get("sharded_h_equals_unsharded_h") is not False
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
