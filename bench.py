@@ -425,8 +425,22 @@ def shard_heights(n_batches, rank, world):
     return range(lo, lo + base + (1 if rank < extra else 0))
 
 
+_T0 = time.perf_counter()
+_REGION = [0]
+
+
+def trace(msg):
+    """ZKPOR_BENCH_TRACE=1: where the run is, on stderr (a GPU hang or an abort kills the process before its one JSON line)"""
+    if os.environ.get("ZKPOR_BENCH_TRACE") == "1":
+        print(f"[bench {time.perf_counter() - _T0:8.2f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def timed_region(dist, sync, run):
     """the bench contract: barrier + device sync on both sides of the timed work, MAX of the elapsed time over ranks"""
+    _REGION[0] += 1
+    import inspect
+    where = inspect.stack()[1]
+    trace(f"timed region {_REGION[0]} starts (bench.py:{where.lineno})")
     sync()
     if dist is not None:
         dist.barrier()
@@ -438,6 +452,7 @@ def timed_region(dist, sync, run):
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    trace(f"timed region {_REGION[0]} done: {dt * 1e3:.1f} ms")
     if dist is not None:
         import torch
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -1069,7 +1084,11 @@ class EndToEnd:
                 if sort_params and sort_params.get(name_, -1) >= 0:
                     wk["ctx"].set_param(name_, sort_params[name_])
             for name_, val_ in EXTRA_PARAMS.items():      # --param
-                wk["ctx"].set_param(name_, val_)
+                try:
+                    wk["ctx"].set_param(name_, val_)
+                except zkpor.ZkporError:
+                    if wk["own"]:
+                        raise
             if solver_rows:
                 wk["dc"].solver.set_abc_dev(wk["a"].data_ptr(), wk["b"].data_ptr(), wk["c"].data_ptr())
             if prefetch:
@@ -1154,7 +1173,7 @@ class EndToEnd:
         self.wk = []
 
 
-def circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, shape, tier_name, seed, steps, e2e_steps, blinding, tables_used):
+def circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, shape, tier_name, seed, steps, e2e_steps, blinding, tables_used, local_rank=0, workers=2, tail_mode=1):
     """One production tier as the COMPILED circuit, start to finish and then freed: synthetic valid batch -> compile -> key with the circuit's
     sparsity -> matrices + program on the device -> one solve for the generated w / a / b / c / committed values -> a timed region of prove
     tails (same contract as the headline) -> a timed end-to-end region -> every proof checked (r1cs check on the device, h by the quotient
@@ -1167,6 +1186,7 @@ def circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, shape, tier_name, see
     lib = ctx.lib
     vp = ctypes.c_void_p
     ck = ctx._ck
+    trace(f"tier leg {tier_name} starts")
     t0 = time.perf_counter()
     inp = C.synth_inputs(*shape, seed=17 + rank)
     cir = compile_circuit(C, dist, world, rank, shape)
@@ -1256,11 +1276,36 @@ def circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, shape, tier_name, see
             last = state["last"]
             w_last = np.empty((n_wires, 4), np.uint64)
             ck(lib.zkpor_dev_download(ctx.h, zkpor._p(w_last), vp(last.data_ptr()), ctypes.c_size_t(w_last.nbytes)))
-            e2e_res = {"value": world * e2e_steps / dte, "ms_per_proof": dte / e2e_steps * 1e3, "steps": e2e_steps,
+            e2e_res = {"value": world * e2e_steps / dte, "ms_per_proof": dte / e2e_steps * 1e3, "steps": e2e_steps, "workers_per_gpu": 1,
                        "same_wires_as_tail_region": bool(np.array_equal(w_last, w_host)), "constraints_failing_on_device": dc.r1cs.check_dev(last.data_ptr())[0]}
             del w_last
             ctx.sync()
+            if workers > 1:
+                # round 6: the headline's shape for this tier too — `workers` worker contexts, one proof's solve beside the other's prove tail (EndToEnd)
+                E = None
+                try:
+                    E = EndToEnd(torch, zkpor, C, ctx, local_rank, pk, cir, dc, d_in, inp, D, n_commit, dev, blinding, (a, b, c), workers, 0, tail_mode=tail_mode)
+                    nw = max(2 * workers, e2e_steps + e2e_steps % workers)
+                    E.run(40000, workers, None)
+                    wproofs = []
+                    dtw = timed_region(dist, torch.cuda.synchronize, lambda: E.run(40100, nw, wproofs))
+                    same = E.same_wires(w)
+                    failing = max(dc.r1cs.check_dev(wk_["last"].data_ptr())[0] for wk_ in E.wk if wk_["last"] is not None)
+                    e2e_res["two_workers"] = {"value": world * nw / dtw, "ms_per_proof": dtw / nw * 1e3, "steps": nw, "workers_per_gpu": len(E.wk), "tail_mode": E.tail_mode,
+                                              "same_wires_as_tail_region": same, "constraints_failing_on_device": failing}
+                    eproofs_w = wproofs
+                except Exception as ex_:       # noqa: BLE001 — e.g. no room for the second worker: the one-worker figure stands
+                    e2e_res["two_workers"] = {"note": f"failed: {ex_}"}
+                    eproofs_w = []
+                finally:
+                    if E is not None:
+                        E.close()
+                    dc.solver.set_abc_dev(a.data_ptr(), b.data_ptr(), c.data_ptr())
+            else:
+                eproofs_w = []
         # checks
+        trace(f"tier leg {tier_name}: regions done, checks start")
+
         def host(t, n):
             out = np.empty((n, 4), dtype=np.uint64)
             ck(lib.zkpor_dev_download(ctx.h, zkpor._p(out), vp(t.data_ptr()), ctypes.c_size_t(out.nbytes)))
@@ -1281,6 +1326,14 @@ def circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, shape, tier_name, see
                        and np.array_equal(com, ec) and np.array_equal(pok, ek))
         if e2e_res is not None:
             e2e_res["checked"] = {"proofs": len(eproofs), "ok": eok}
+            tw = e2e_res.get("two_workers")
+            if tw and "value" in tw:
+                wok = 0
+                for i, proof, com, pok in eproofs_w:
+                    r, s_ = blinding(i)
+                    wok += int(h_ok and tw["same_wires_as_tail_region"] and tw["constraints_failing_on_device"] == 0 and td.check(proof, r, s_)
+                               and np.array_equal(com, ec) and np.array_equal(pok, ek))
+                tw["checked"] = {"proofs": len(eproofs_w), "ok": wok}
         wc = np.empty_like(w_host)
         O.lib().orc_fr_to_canon(O._p(w_host), O._p(wc), ctypes.c_size_t(n_wires))
         hi = (wc[:, 1] | wc[:, 2] | wc[:, 3]) != 0
@@ -1382,6 +1435,8 @@ def main():
     ap.add_argument("--no-share-compile", action="store_true", help="several ranks: every rank compiles the circuit itself instead of mapping rank 0's arrays from /dev/shm")
     ap.add_argument("--share-device", action="store_true", help="TEST ONLY: every rank proves on device 0 and the ranks meet over gloo — the launcher, the per-rank "
                     "merge of the line, the check budgeting and the key build under contention exercised on a one-GPU box; the line says so and is no measurement")
+    ap.add_argument("--ctx-stream", choices=["torch", "own", "own_queue"], default="torch", help="experiment: the main context's stream — torch's current stream (default), a stream of the "
+                    "library's own, or one with a hardware queue of its own (stream_own_queue)")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="experiment: zkpor_set_param(NAME, VALUE) on the main context and on every worker context (repeatable), "
                     "e.g. --param r1cs_order=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1444,7 +1499,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     stream = torch.cuda.current_stream().cuda_stream  # launch on torch's stream so torch/HIP events see the work
+    if args.ctx_stream != "torch":       # experiment: the main context on a stream of its own (regions are bracketed by device-wide synchronisation either way)
+        stream = None
     ctx = zkpor.Context(local_rank, stream)
+    if args.ctx_stream == "own_queue":
+        ctx.set_param("stream_own_queue", 1)
     if args.window:
         ctx.set_param("msm_window", args.window)
     if args.chunk:
@@ -1482,7 +1541,10 @@ def main():
     for nv in args.param:
         name_, _, val_ = nv.partition("=")
         EXTRA_PARAMS[name_] = int(val_)
-        ctx.set_param(name_, int(val_))
+        try:
+            ctx.set_param(name_, int(val_))
+        except zkpor.ZkporError as e_:      # e.g. stream_own_queue: the main context runs on torch's stream; the worker contexts take it
+            print(f"bench.py: --param {nv} not applied to the main context ({e_})", file=sys.stderr)
     lib = ctx.lib
 
     if args.split:
@@ -1520,7 +1582,8 @@ def main():
         oshape = (CONFIGS[other_name]["assets"], 500, CONFIGS[other_name]["users"])
         try:
             other_gen = circuit_tier_leg(torch, zkpor, ctx, dist, world, rank, oshape, other_name, seed, osteps_g,
-                                         args.e2e_steps if args.e2e_steps >= 0 else 3, blinding_o, args.tables)
+                                         args.e2e_steps if args.e2e_steps >= 0 else 3, blinding_o, args.tables, local_rank=local_rank,
+                                         workers=max(1, args.e2e_workers), tail_mode=args.tail_mode)
         except Exception as e:
             other_gen = None
             print(f"bench.py: the generated leg of {other_name} failed ({e}); falling back to the estimated mixture on the headline key", file=sys.stderr)
@@ -1831,7 +1894,9 @@ def main():
                 up["input_bytes_per_proof"] = int(circ["inp"].nbytes)
                 up["same_wires"] = E.same_wires(w) if args.scalars == "witness" else None
                 e2e["with_input_upload"] = up
+        trace("end-to-end headline regions done, closing the workers")
         E.close()
+        trace("workers closed")
         if not args.timed_only and len(E.wk) == 0 and n_workers > 1 and (args.e2e_steps != 0):
             # one proof at a time, no reserved compute units (the round-4 headline's shape): the latency of one proof and what the second worker buys
             sub = max(3, args.steps // 4) if args.e2e_steps < 0 else args.e2e_steps
@@ -1894,6 +1959,7 @@ def main():
             return out
 
         ok = 0
+        trace("checks of the timed proofs start (host)")
         h_full = host(workers[0][1], D)                # prove_tail_dev leaves h in `a`, in the order of the key's Z
         # h is device output: before the trapdoor check may use it, verify it against its DEFINITION from the inputs alone —
         # H(tau)(tau^D - 1) = A(tau)B(tau) - C(tau) at a random tau, A, B, C by barycentric sums over a0, b0, c0 (oracle/quotient.hpp;

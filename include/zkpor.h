@@ -105,7 +105,9 @@ int32_t zkpor_trim(zkpor_ctx* ctx);
  * "msm_filter" (1, the default: B1 / B2 and K accumulate from the witness digit stream minus the entries of their absent points),
  * "msm_chain" (1, the default since round 6: everything of a prove-tail sum after its level-1 kernel — the partial-sum levels, the bucket reduction,
  * the copies of the finals: ~40 short dependent launches — runs on a second stream beside the NEXT sum's level-1 kernel, the sums' workspace in two
- * regions that take turns; 0: one stream, one region, every sum behind the one before),
+ * regions that take turns.  1 applies to tails that run on streams with hardware queues of their own ("tail_streams" / "tail_reserve_cus": 318 -> 298 ms per
+ * zkpor50_1380 proof with two workers); on ordinary streams, which share four hardware queues, the short launches queue behind long kernels of the
+ * other streams and the tail gets SLOWER (281 -> 359 ms) — 2 forces it there too (tests); 0: one stream, one region, every sum behind the one before),
  * "r1cs_order" (1, the default since round 6: a, b, c = L.w, R.w, O.w walk a matrix's rows by shape — term count, then the pattern of coefficient
  * kinds — so that the rows of a wave run the same iterations; 0: natural order.  The results are the same bits),
  * the digit-stream sort's (csrc/sort.hip; rocPRIM's "sort_block" of rounds 3-5 is accepted and ignored): "sort_grid" (0, the default: the library's

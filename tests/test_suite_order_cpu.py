@@ -27,7 +27,7 @@ def test_parity_files_first_isolated_bodies_last():
     assert files[:len(head)] == head
     pos = {i: k for k, i in enumerate(ids)}
     iso = [i for i in ids if any(n in i for n in ("test_two_callers_take_turns_on_the_device", "test_host_pointer_staging_survives", "test_two_workers_of_one_gpu", "test_dispatcher_drives_real_proofs",
-                                                   "test_row_to_row", "test_pipeline_demo", "test_two_workers_device_tails", "test_headline_"))]
+                                                   "test_row_to_row", "test_pipeline_demo", "test_two_workers_device_tails", "test_headline_", "test_the_ranks_one_after_the_other"))]
     assert len(iso) >= 10
     first_iso = min(pos[i] for i in iso)
     assert all(pos[i] < first_iso for i in ids if i not in iso)          # nothing in-process runs behind an isolated body

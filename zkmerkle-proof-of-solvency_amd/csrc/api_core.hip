@@ -460,11 +460,11 @@ void zkpor_destroy(zkpor_ctx* ctx) try {
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-    if (ctx->chain_stream) (void)hipStreamDestroy(ctx->chain_stream);
+    zk::stream_release_own_queue(ctx->device, ctx->chain_stream, 0);
     for (auto& ts : ctx->tail_sets) { zk::stream_release_own_queue(ctx->device, ts.main, ts.reserve); zk::stream_release_own_queue(ctx->device, ts.aux, ts.reserve); zk::stream_release_own_queue(ctx->device, ts.chain, ts.reserve); }
     zk::stream_release_own_queue(ctx->device, ctx->tail_aux_free, 0);
     for (hipStream_t st : ctx->retired_streams) (void)hipStreamDestroy(st);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) { if (ctx->stream_pooled) zk::stream_release_own_queue(ctx->device, ctx->stream, 0); else (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
 } catch (...) { zk::abi_exception("exception in zkpor_destroy"); }
 
@@ -519,7 +519,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "sort_generic") { if (value < 0 || value > 1) { ctx->err = "sort_generic must be 0 or 1"; return ZKPOR_E_ARG; } ctx->sort_generic = (int)value; }
     else if (n == "sort_tile") { if (value != 0 && value != 1024 && value != 2048 && value != 4096) { ctx->err = "sort_tile must be 0 (4096), 1024, 2048 or 4096"; return ZKPOR_E_ARG; } ctx->sort_tile = (int)value; }
     else if (n == "sort_block") { if (value != 0 && value != 256 && value != 512) { ctx->err = "sort_block must be 0, 256 or 512"; return ZKPOR_E_ARG; } }   // rounds 3-5: the workgroup size of rocPRIM's onesweep; accepted and ignored since the sort is sort.hip's
-    else if (n == "msm_chain") { if (value < 0 || value > 1) { ctx->err = "msm_chain must be 0 or 1"; return ZKPOR_E_ARG; } ctx->msm_chain = (int)value; }
+    else if (n == "msm_chain") { if (value < 0 || value > 2) { ctx->err = "msm_chain must be 0, 1 (tails on streams with their own hardware queues) or 2 (every tail)"; return ZKPOR_E_ARG; } ctx->msm_chain = (int)value; }
     else if (n == "msm_reduce_scan") { if (value < 0 || value > 2) { ctx->err = "msm_reduce_scan must be 0, 1 or 2"; return ZKPOR_E_ARG; } ctx->msm_reduce_scan = (int)value; }
     else if (n == "msm_tail_chunk") { if (value != 0 && (value < 4 || value > 64)) { ctx->err = "msm_tail_chunk must be 0 or 4..64"; return ZKPOR_E_ARG; } ctx->msm_tail_chunk = (int)value; }
     else if (n == "aux_priority") {
@@ -577,6 +577,21 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
             ctx->retired_streams.push_back(ctx->stream);      // not destroyed while events of the context may name it (common.cuh)
             ctx->stream = fresh;
             ctx->stream_priority = (int)value;
+        }
+    }
+    else if (n == "stream_own_queue") {
+        // the context's OWN stream (solver levels, a / b / c, the commitment) on a hardware queue of its own.  Ordinary streams are dealt round-robin onto
+        // four hardware queues in creation order: whether two workers' streams — or a worker's stream and somebody's digit stream — end up in ONE queue, each
+        // waiting behind the other's launches, is an accident of what the process created before (bench.py: the same two-worker region 298 or 326 ms)
+        if (value < 0 || value > 1) { ctx->err = "stream_own_queue must be 0 or 1"; return ZKPOR_E_ARG; }
+        if (!ctx->own_stream) { ctx->err = "stream_own_queue: the context runs on the caller's stream (zkpor_init): create that stream with hipExtStreamCreateWithCUMask"; return ZKPOR_E_STATE; }
+        if (value == 1 && !ctx->stream_pooled) {
+            hipStream_t fresh = nullptr;
+            ZK_TRY(stream_create_own_queue(ctx, &fresh, 0));
+            ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->retired_streams.push_back(ctx->stream);      // not destroyed while events of the context may name it (common.cuh)
+            ctx->stream = fresh;
+            ctx->stream_pooled = true;
         }
     }
     else if (n == "tail_aux_masked") { if (value < 0 || value > 1) { ctx->err = "tail_aux_masked must be 0 or 1"; return ZKPOR_E_ARG; } ctx->tail_aux_masked = (int)value; }

@@ -24,6 +24,7 @@ struct zkpor_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool stream_pooled = false;      // "stream_own_queue": the own stream has a hardware queue of its own and goes back to the process-wide pool, not to hipStreamDestroy
     hipStream_t aux_stream = nullptr;  // digit streams (decompose + sort) of the prove tail run here, beside the ALU-bound kernels
     std::string err;
     // bump-allocated workspace, regrown on demand
@@ -60,7 +61,7 @@ struct zkpor_ctx {
     int host_order = 0;              // zkpor_prove_tail from host memory: 0 = w first, a/b/c under the witness sums; 1 = everything first, then the resident order
     int msm_reduce_scan = 1;         // small bucket-reduction levels: one lane (G2: lane pair) per bucket, scan + tree sums; 2 = G1 only (round 2), 0 = serial walk
     int msm_tail_chunk = 8;          // entries per thread of the SMALL partial-sum levels (< 2^21 entries): their duration is the serial chain, not the work; 0 = msm_chunk
-    int msm_chain = 1;               // the prove tail's sums: everything after a sum's level-1 kernel (partial-sum levels, bucket reduction, copies) on a second stream, beside the next sum's level-1 kernel (msm.cuh MsmChain); 0 = one stream
+    int msm_chain = 1;               // the prove tail's sums: everything after a sum's level-1 kernel (partial-sum levels, bucket reduction, copies) on a second stream, beside the next sum's level-1 kernel (msm.cuh MsmChain) — 1: for tails on streams with their own hardware queues ("tail_streams" / "tail_reserve_cus"), 2: every tail, 0 = one stream
     int msm_filter = 1;              // per-array digit streams: drop the entries of absent points before B1 / B2 and K (msm_digits.hip)
     int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 256: one per CU — bandwidth, not wave slots)
     int ntt_twiddles = 0;            // inter-pass twiddles of the fields whose table exceeds the L2 (2 GiB per direction at 2^26): 0 = read from the table, 1 = generated from two half tables (one more product per element, 15 GB less traffic per computeH)

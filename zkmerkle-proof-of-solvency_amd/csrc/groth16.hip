@@ -639,11 +639,15 @@ int32_t prove_sums(zkpor_ctx* ctx, zkpor_pk* pk, const void* d_w, void* d_a, voi
         main_s = ctx->tail_stream; aux_s = want_masked_aux ? ctx->tail_aux : ctx->tail_aux_free;
     }
     // "msm_chain": the sums' partial-sum levels / reductions / copies on a stream of their own (msm.cuh MsmChain), two workspace regions taking turns
+    // Only for a tail on streams with hardware queues of their own (`masked`: two workers per GPU, the headline shape) unless "msm_chain" is 2: on ORDINARY streams —
+    // which the runtime multiplexes onto four hardware queues in order — the chain's short launches land in a queue behind the digit stream's long sort
+    // kernels, or in front of the next level-1 kernel: measured 281 -> 359 ms per prove tail (gpurun_out/r06x, one worker), against 318 -> 298 ms where every
+    // stream has its queue.  2 = also then (tests run both paths).
     hipStream_t chain_s = nullptr;
     if (ctx->msm_chain) {
         if (masked) chain_s = ctx->tail_chain;
-        else {
-            if (!ctx->chain_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->chain_stream, hipStreamNonBlocking));
+        else if (ctx->msm_chain == 2) {
+            if (!ctx->chain_stream) ZK_TRY(stream_create_own_queue(ctx, &ctx->chain_stream, 0));    // its own hardware queue (full CU mask)
             chain_s = ctx->chain_stream;
         }
     }
