@@ -142,6 +142,11 @@ int32_t zkpor_trim(zkpor_ctx* ctx);
  * reserve, "tail_reserve_cus" 0: the other worker's solver launches compete for compute units as they free up instead of owning a share),
  * "stream_priority" (0; 1: the context's own stream — solver, a / b / c, commitment — is re-created with the highest stream priority; only
  * for contexts created without a caller's stream; measured: changes nothing next to "tail_streams"),
+ * "stream_own_queue" (1, the default since round 6 for contexts created without a caller's stream: the context's own stream — solver levels, a / b / c, the
+ * commitment, an unmasked prove tail — has a hardware queue of its own.  Ordinary HIP streams are dealt onto four hardware queues in creation order, so
+ * whether two workers' streams share a queue, each waiting behind the other's launches, was an accident of what the process had created before: the
+ * same two-worker region 327 or 308 ms per proof, two tails in flight 300 or 272 ms (profiles/r06_stream_own_queue_ab.json).  Such a stream synchronises with
+ * the legacy NULL stream: a caller that launches on the NULL stream serialises with it.  0: an ordinary stream, the round-5 behaviour),
  * "tail_digits_early" (1, the default: a tail that finds another worker's tail on the device builds its digit stream of w BEFORE it waits for
  * the turn, beside that tail's accumulations, instead of beside its own NTT passes; 0: after the turn),
  * "debug_validate" (0; 1: every sorted digit stream is checked on the device before its accumulation reads it — keys ascending and

@@ -591,6 +591,8 @@ def test_two_workers_device_tails_take_turns_with_every_stream_setting(zk, reser
                                                            per[k][1][0].ptr, per[k][1][1].ptr, per[k][1][2].ptr, r, s)
         zk.set_param("msm_chain", 0)
         want = [prove(0, r, s) for r, s in blind]
+        if chain:
+            other.set_param("stream_own_queue", 1)      # the second worker's own stream on a hardware queue of its own (round 6)
         for cx in ctxs:
             cx.set_param("msm_chain", chain)
             cx.set_param("tail_streams", tail_streams); cx.set_param("stream_priority", priority)

@@ -432,7 +432,14 @@ int32_t zkpor_init(int device, void* stream, zkpor_ctx** out) try {
     if (stream) {
         ctx->stream = (hipStream_t)stream;
     } else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ZKPOR_E_HIP; }
+        // Round 6: the context's own stream has a hardware queue of its own ("stream_own_queue" 1, the default).  The runtime deals ORDINARY streams onto four
+        // hardware queues in creation order; two contexts of one GPU whose streams land in one queue wait behind each other's launches — the same
+        // two-worker region ran 327 or 308 ms per proof depending on what the process had created before (profiles/r06_stream_own_queue_ab.json)
+        if (zk::stream_create_own_queue(ctx, &ctx->stream, 0) == ZKPOR_OK) ctx->stream_pooled = true;
+        else {
+            (void)hipGetLastError();
+            if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ZKPOR_E_HIP; }
+        }
         ctx->own_stream = true;
     }
     *out = ctx;
@@ -447,6 +454,7 @@ void zkpor_destroy(zkpor_ctx* ctx) try {
     for (hipStream_t st : {ctx->aux_stream, ctx->copy_stream, ctx->tail_aux_free, ctx->chain_stream}) if (st) (void)hipStreamSynchronize(st);
     for (auto& ts : ctx->tail_sets) { (void)hipStreamSynchronize(ts.main); if (ts.aux) (void)hipStreamSynchronize(ts.aux); if (ts.chain) (void)hipStreamSynchronize(ts.chain); }
     for (hipStream_t st : ctx->retired_streams) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : ctx->retired_own_queue) (void)hipStreamSynchronize(st);
     for (auto& kv : ctx->phases)
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -464,6 +472,7 @@ void zkpor_destroy(zkpor_ctx* ctx) try {
     for (auto& ts : ctx->tail_sets) { zk::stream_release_own_queue(ctx->device, ts.main, ts.reserve); zk::stream_release_own_queue(ctx->device, ts.aux, ts.reserve); zk::stream_release_own_queue(ctx->device, ts.chain, ts.reserve); }
     zk::stream_release_own_queue(ctx->device, ctx->tail_aux_free, 0);
     for (hipStream_t st : ctx->retired_streams) (void)hipStreamDestroy(st);
+    for (hipStream_t st : ctx->retired_own_queue) zk::stream_release_own_queue(ctx->device, st, 0);
     if (ctx->own_stream) { if (ctx->stream_pooled) zk::stream_release_own_queue(ctx->device, ctx->stream, 0); else (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
 } catch (...) { zk::abi_exception("exception in zkpor_destroy"); }
@@ -574,15 +583,14 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
             if (value == 1 && hi != lo) ZK_HIP(ctx, hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, hi));
             else ZK_HIP(ctx, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
             ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            ctx->retired_streams.push_back(ctx->stream);      // not destroyed while events of the context may name it (common.cuh)
+            if (ctx->stream_pooled) ctx->retired_own_queue.push_back(ctx->stream); else ctx->retired_streams.push_back(ctx->stream);   // not destroyed while events of the context may name it (common.cuh)
             ctx->stream = fresh;
+            ctx->stream_pooled = false;
             ctx->stream_priority = (int)value;
         }
     }
     else if (n == "stream_own_queue") {
-        // the context's OWN stream (solver levels, a / b / c, the commitment) on a hardware queue of its own.  Ordinary streams are dealt round-robin onto
-        // four hardware queues in creation order: whether two workers' streams — or a worker's stream and somebody's digit stream — end up in ONE queue, each
-        // waiting behind the other's launches, is an accident of what the process created before (bench.py: the same two-worker region 298 or 326 ms)
+        // the context's OWN stream (solver levels, a / b / c, the commitment) on a hardware queue of its own — the default since round 6 (zkpor_init); 0 = an ordinary stream
         if (value < 0 || value > 1) { ctx->err = "stream_own_queue must be 0 or 1"; return ZKPOR_E_ARG; }
         if (!ctx->own_stream) { ctx->err = "stream_own_queue: the context runs on the caller's stream (zkpor_init): create that stream with hipExtStreamCreateWithCUMask"; return ZKPOR_E_STATE; }
         if (value == 1 && !ctx->stream_pooled) {
@@ -592,6 +600,13 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
             ctx->retired_streams.push_back(ctx->stream);      // not destroyed while events of the context may name it (common.cuh)
             ctx->stream = fresh;
             ctx->stream_pooled = true;
+        } else if (value == 0 && ctx->stream_pooled) {        // back to an ordinary stream (experiments; the round-5 behaviour)
+            hipStream_t fresh = nullptr;
+            ZK_HIP(ctx, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+            ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->retired_own_queue.push_back(ctx->stream);    // back to the pool with the context, never to hipStreamDestroy
+            ctx->stream = fresh;
+            ctx->stream_pooled = false;
         }
     }
     else if (n == "tail_aux_masked") { if (value < 0 || value > 1) { ctx->err = "tail_aux_masked must be 0 or 1"; return ZKPOR_E_ARG; } ctx->tail_aux_masked = (int)value; }

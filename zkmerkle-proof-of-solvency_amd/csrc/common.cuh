@@ -102,6 +102,7 @@ struct zkpor_ctx {
     hipStream_t chain_stream = nullptr;         // ... and of a tail that runs on the context's own stream (an ordinary stream)
     char* ws2 = nullptr; size_t ws2_cap = 0;    // "msm_chain": the second accumulation region (B1, B2), sized by the sums' ACTUAL entry counts, grow-only (groth16.hip prove_sums)
     std::vector<hipStream_t> retired_streams;   // streams a handle of this context replaced (a solver's first side streams): destroyed with the context
+    std::vector<hipStream_t> retired_own_queue; // ... those of them that have a hardware queue of their own: back to the process-wide pool with the context
     int debug_validate = 0;          // 1: every sorted digit stream is checked (keys ascending and below the bucket count, point indices inside the array) on the
                                      // accumulating stream before its level-1 kernel reads it; a violation is ZKPOR_E_STATE instead of a GPU memory fault
     uint32_t* dbg_buf = nullptr;     // 4 words of device memory for that check
