@@ -103,11 +103,12 @@ int32_t zkpor_trim(zkpor_ctx* ctx);
  * "msm_reduce_scan" (1, the default: the small levels of the bucket reduction run one lane — G2: one lane pair — per bucket; 2: G1
  * only; 0: the serial walk),
  * "msm_filter" (1, the default: B1 / B2 and K accumulate from the witness digit stream minus the entries of their absent points),
- * "msm_chain" (1, the default since round 6: everything of a prove-tail sum after its level-1 kernel — the partial-sum levels, the bucket reduction,
+ * "msm_chain" (2, the default since round 6: everything of a prove-tail sum after its level-1 kernel — the partial-sum levels, the bucket reduction,
  * the copies of the finals: ~40 short dependent launches — runs on a second stream beside the NEXT sum's level-1 kernel, the sums' workspace in two
- * regions that take turns.  1 applies to tails that run on streams with hardware queues of their own ("tail_streams" / "tail_reserve_cus": 318 -> 298 ms per
- * zkpor50_1380 proof with two workers); on ordinary streams, which share four hardware queues, the short launches queue behind long kernels of the
- * other streams and the tail gets SLOWER (281 -> 359 ms) — 2 forces it there too (tests); 0: one stream, one region, every sum behind the one before),
+ * regions that take turns: 318 -> 298 ms per zkpor50_1380 proof with two workers, 351 -> 298 ms per proof for two host-pointer callers.  The chain stream
+ * has a hardware queue of its own: on an ORDINARY stream — the runtime deals those onto four hardware queues — its short launches queued behind long
+ * kernels of other streams and the tail got slower (281 -> 359 ms, the first version).  1: only tails on "tail_streams" / "tail_reserve_cus" streams;
+ * 0: one stream, one region, every sum behind the one before),
  * "r1cs_order" (1, the default since round 6: a, b, c = L.w, R.w, O.w walk a matrix's rows by shape — term count, then the pattern of coefficient
  * kinds — so that the rows of a wave run the same iterations; 0: natural order.  The results are the same bits),
  * the digit-stream sort's (csrc/sort.hip; rocPRIM's "sort_block" of rounds 3-5 is accepted and ignored): "sort_grid" (0, the default: the library's
@@ -119,11 +120,16 @@ int32_t zkpor_trim(zkpor_ctx* ctx);
  * highest field of a 2^26 domain, 2 GiB per direction — generate them from two half tables, one more field product per element and 15 GB less
  * HBM traffic per computeH; measured: no faster; 2: every field, for tests),
  * "ntt_fuse" (1, the default: computeH's neighbouring passes over one index field run as one kernel),
+ * "ntt_h" (1, the default since round 6: computeH runs SIX transforms — the inverse coset transform is linear, so c's coefficients, which its
+ * inverse transform has produced anyway, are subtracted behind it and c never goes to the coset; 0: gnark's seven.  The same h bit for bit,
+ * for every a, b, c),
  * "gpu_token" (1, the default: host-pointer proofs of several contexts on one GPU take turns on the device, see zkpor_prove_tail;
  * 0: their kernels share it freely), "host_order" (0, the default: a proof that finds the GPU free sends w first and a, b, c
  * underneath its own witness sums; 1: always everything first),
  * "poseidon_out_idx", "poseidon_carry_idx" (hash-wrapper convention),
  * the solver executor's (zkpor_solver_*): "solver_poseidon" (1, the default: a Poseidon call runs on 16 lanes; 0: in one thread),
+ * "poseidon_defer" (64, the default: a launch of up to this many 16-lane calls — the challenge sponge, the CEX chains — parks the S-box inputs raw and a
+ * wide kernel behind it converts them and writes wires and rows; same bits; 0 = the waves convert as they go),
  * "solver_batch_from" (2^21: levels from this many generic instructions on run four per thread), "solver_chain" (1, the default: runs of
  * one-instruction levels are decoded side by side and executed from registers; 0: the narrow-level kernel), "solver_tree_from" (1 024: levels from this many generic instructions on share one field inversion per workgroup), "solver_beside" (1, the default: a Poseidon call that carries a join level runs on a side stream beside the levels up to it; 0: in place), "solver_long" (256: those levels leave constraints of more terms than this to a wave each; 0 = never), "solver_defer_checks"
  * (1, the default: see zkpor_solver_set_abc_dev; 0: a run executes its CHECK instructions even when a, b, c buffers are set),

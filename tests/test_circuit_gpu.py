@@ -17,10 +17,12 @@ pytestmark = pytest.mark.gpu
 SEED = 0x5A4B504F52
 
 
-def prove_once(zk, shape, variant, seed=7, compare=True, reps=1):
+def prove_once(zk, shape, variant, seed=7, compare=True, reps=1, defer=None):
     inp = C.synth_inputs(*shape, seed=seed)
     cir = C.Circuit(*shape)
     zk.set_param("solver_poseidon", variant)
+    if defer is not None:
+        zk.set_param("poseidon_defer", defer)
     log2 = max(4, int(np.ceil(np.log2(cir.n_constraints))))
     D = 1 << log2
     inf_a, inf_b = cir.infinity_masks()
@@ -72,7 +74,7 @@ def prove_once(zk, shape, variant, seed=7, compare=True, reps=1):
         if dc:
             dc.close()
         pk.close(); cir.close()
-        zk.set_param("solver_poseidon", 1)
+        zk.set_param("solver_poseidon", 1); zk.set_param("poseidon_defer", 64)
 
 
 @pytest.mark.parametrize("variant", [1, 0])
@@ -80,6 +82,16 @@ def prove_once(zk, shape, variant, seed=7, compare=True, reps=1):
 def test_small_batches_bit_exact_with_the_interpreter_both_poseidon_kernels(zk, shape, variant):
     """(20, 40, 4) walks the ragged sponge widths 3, 5, 6, 9 and 13; (3, 6, 3) the widths 2, 3, 4, 6, 7, 13"""
     prove_once(zk, shape, variant)
+
+
+@pytest.mark.parametrize("defer", [0, 65535])
+@pytest.mark.parametrize("shape", [(3, 6, 3), (20, 40, 4)])
+def test_parked_sbox_inputs_expand_to_the_same_wires(zk, shape, defer):
+    """"poseidon_defer" (round 6): launches of up to that many 16-lane calls park every S-box input raw in the S-box's own wire slots and
+    k_sbox_expand behind them recomputes x^2, x^4, x^5, converts and writes (csrc/poseidon.hip).  0: no launch does (the waves convert as they go);
+    65535: every launch of these shapes does, the wide Merkle levels included; the default (64: the sponge, the CEX chains, the narrow levels) runs in every
+    other test of this file.  Same wires as the interpreter each way."""
+    prove_once(zk, shape, 1, defer=defer)
 
 
 def test_batched_inversions_of_wide_levels_change_no_wire(zk):
@@ -149,8 +161,8 @@ def test_rows_written_by_the_poseidon_instructions_equal_the_evaluated_ones(zk):
     bufs = [zk.alloc(32 * n) for n in (cir.n_wires, cir.n_committed + 1, D, D, D, D, D, D)]
     try:
         pk.synth(log2, cir.n_wires, cir.n_public, cir.n_committed, SEED)
-        for variant in (1, 0):
-            zk.set_param("solver_poseidon", variant)
+        for variant, defer in ((1, 64), (1, 65535), (1, 0), (0, 64)):
+            zk.set_param("solver_poseidon", variant); zk.set_param("poseidon_defer", defer)
             for b in bufs[2:]:
                 b.upload(np.full((D, 4), 0xDEADBEEF, np.uint64))
             dc.solver.set_abc_dev(bufs[2].ptr, bufs[3].ptr, bufs[4].ptr)
@@ -162,7 +174,7 @@ def test_rows_written_by_the_poseidon_instructions_equal_the_evaluated_ones(zk):
         dc.solver.set_abc_dev(None, None, None)
         assert cir.census["poseidon_call"] > 100
     finally:
-        zk.set_param("solver_poseidon", 1)
+        zk.set_param("solver_poseidon", 1); zk.set_param("poseidon_defer", 64)
         for b in bufs:
             b.free()
         dc.close(); pk.close(); cir.close()

@@ -617,7 +617,7 @@ def test_two_workers_device_tails_take_turns_with_every_stream_setting(zk, reser
             assert np.array_equal(g, x)
     finally:
         for cx in ctxs:
-            cx.set_param("tail_reserve_cus", 0); cx.set_param("tail_streams", 0); cx.set_param("tail_digits_early", 1); cx.set_param("msm_chain", 1)
+            cx.set_param("tail_reserve_cus", 0); cx.set_param("tail_streams", 0); cx.set_param("tail_digits_early", 1); cx.set_param("msm_chain", 2)
         zk.set_param("stream_priority", 0)
         for x in bufs:
             x.free()
@@ -637,7 +637,7 @@ def test_the_chain_stream_changes_nothing_but_the_order_of_launches(zk):
     try:
         r = O.fr_random(31, 1)[0]; s_ = O.fr_random(32, 1)[0]
         want = S.prove_tail(r, s_)
-        for chain in (2, 0, 2, 2, 0):          # 2: also on the context's ordinary streams (1, the default, chains only tails that have hardware queues of their own)
+        for chain in (2, 0, 2, 2, 0):          # 2, the default: every tail, the chain stream on a hardware queue of its own (1 chains only tails on "tail_streams" streams)
             zk.set_param("msm_chain", chain)
             assert np.array_equal(zk.prove_tail(pk, S.w, S.a, S.b, S.c, r, s_), want), chain
             for b_, v in zip(bufs, (S.a, S.b, S.c)):
@@ -646,7 +646,7 @@ def test_the_chain_stream_changes_nothing_but_the_order_of_launches(zk):
             if chain == 0:
                 zk.trim()        # zkpor_trim: workspace, second region, staging area, NTT tables go back to the device and come back on demand
     finally:
-        zk.set_param("msm_chain", 1)
+        zk.set_param("msm_chain", 2)
         for b_ in bufs + [dw]:
             b_.free()
         pk.close()

@@ -174,6 +174,28 @@ def test_generated_twiddles_equal_tabulated_ones(zk, log2n):
             zk.set_param("ntt_twiddles", 0)
 
 
+@pytest.mark.parametrize("log2d", [9, 10, 12, 17, 20])
+@pytest.mark.parametrize("valid", [True, False])
+def test_six_transforms_give_the_seven_transform_h_for_any_c(zk, log2d, valid):
+    """"ntt_h" 1 (round 6, the default): c is only taken to its coefficients; den * c is subtracted behind h's inverse coset transform, which is linear —
+    gnark's computeH takes c to the coset as well (seven transforms; "ntt_h" 0).  The same h bit for bit, also for a c that is NOT a b on the domain
+    (nothing in the rearrangement uses the constraint), against the seven-transform schedule and, where the oracle finishes in seconds, against the
+    oracle's literal restatement of gnark's computeH (oracle.compute_h: seven transforms)"""
+    n = (1 << log2d) - (5 if log2d > 9 else 0)
+    a = O.fr_random(71, n); b = O.fr_random(72, n)
+    c = O.fr_mul(a, b) if valid else O.fr_random(73, n)
+    six = zk.compute_h(a, b, c, log2d)
+    zk.set_param("ntt_h", 0)
+    try:
+        seven = zk.compute_h(a, b, c, log2d)
+    finally:
+        zk.set_param("ntt_h", 1)
+    assert np.array_equal(six, seven)
+    if log2d <= 17:
+        assert np.array_equal(six, O.compute_h(a, b, c, log2d))
+    # in place on the device with preserved inputs is what the prove tail runs: tests/test_groth16_gpu.py (proofs bit-exact with the oracle under both schedules)
+
+
 def test_compute_h_zero_and_ragged(zk):
     # n_constraints = 0..1: zero padding path; h of the zero polynomial is zero
     z = np.zeros((1, 4), np.uint64)

@@ -182,7 +182,7 @@ def test_an_empty_sum_leaves_no_event_behind(zk):
             assert all(inf(b, lo, hi) for lo, hi in ((0, 96), (96, 192), (192, 384), (384, 480))) and _affine5(b)[3] == full[3]
             assert _affine5(zk.prove_sums_dev(pk, dw.ptr, dh.ptr)) == full
     finally:
-        zk.set_param("msm_chain", 1)
+        zk.set_param("msm_chain", 2)
         for x in (dw, dh, zw, zh):
             x.free()
         pk.close()

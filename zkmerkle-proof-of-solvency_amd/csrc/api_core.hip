@@ -522,6 +522,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "msm_filter") { if (value < 0 || value > 2) { ctx->err = "msm_filter must be 0, 1 or 2"; return ZKPOR_E_ARG; } ctx->msm_filter = (int)value; }
     else if (n == "msm_filter_grid") { if (value < 0 || value > 2048) { ctx->err = "msm_filter_grid must be in [0,2048]"; return ZKPOR_E_ARG; } ctx->msm_filter_grid = (int)value; }
     else if (n == "ntt_twiddles") { if (value < 0 || value > 2) { ctx->err = "ntt_twiddles must be 0 (tables), 1 (generated where the table exceeds 16 MiB) or 2 (generated everywhere)"; return ZKPOR_E_ARG; } ctx->ntt_twiddles = (int)value; }
+    else if (n == "ntt_h") { if (value < 0 || value > 1) { ctx->err = "ntt_h must be 0 (seven transforms) or 1 (six)"; return ZKPOR_E_ARG; } ctx->ntt_h = (int)value; }
     else if (n == "ntt_fuse") { if (value < 0 || value > 1) { ctx->err = "ntt_fuse must be 0 or 1"; return ZKPOR_E_ARG; } ctx->ntt_fuse = (int)value; }
     else if (n == "sort_grid") { if (value < 0 || value > 8192) { ctx->err = "sort_grid must be in [0,8192] (0 = two workgroups per compute unit)"; return ZKPOR_E_ARG; } ctx->sort_grid = (int)value; }
     else if (n == "sort_stage") { if (value < 0 || value > 1) { ctx->err = "sort_stage must be 0 or 1"; return ZKPOR_E_ARG; } ctx->sort_stage = (int)value; }
@@ -544,6 +545,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "solver_long") { if (value < 0 || value > (1 << 30)) { ctx->err = "solver_long must be 0 (off) or a term count"; return ZKPOR_E_ARG; } ctx->solver_long = (int)value; }
     else if (n == "solver_chain") { if (value < 0 || value > 1) { ctx->err = "solver_chain must be 0 or 1"; return ZKPOR_E_ARG; } ctx->solver_chain = (int)value; }
     else if (n == "solver_batch_from") { if (value < 1) { ctx->err = "solver_batch_from must be positive"; return ZKPOR_E_ARG; } ctx->solver_batch_from = value; }
+    else if (n == "poseidon_defer") { if (value < 0 || value > 65535) { ctx->err = "poseidon_defer must be 0 ... 65535 (calls per launch)"; return ZKPOR_E_ARG; } ctx->poseidon_defer = value; }
     else if (n == "solver_poseidon") { if (value < 0 || value > 1) { ctx->err = "solver_poseidon must be 0 (one thread per call) or 1 (sixteen lanes per call)"; return ZKPOR_E_ARG; } ctx->solver_poseidon = (int)value; }
     else if (n == "gpu_token") { if (value < 0 || value > 1) { ctx->err = "gpu_token must be 0 or 1"; return ZKPOR_E_ARG; } ctx->gpu_token = (int)value; }
     else if (n == "host_order") { if (value < 0 || value > 1) { ctx->err = "host_order must be 0 or 1"; return ZKPOR_E_ARG; } ctx->host_order = (int)value; }

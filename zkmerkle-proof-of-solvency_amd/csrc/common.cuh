@@ -61,11 +61,12 @@ struct zkpor_ctx {
     int host_order = 0;              // zkpor_prove_tail from host memory: 0 = w first, a/b/c under the witness sums; 1 = everything first, then the resident order
     int msm_reduce_scan = 1;         // small bucket-reduction levels: one lane (G2: lane pair) per bucket, scan + tree sums; 2 = G1 only (round 2), 0 = serial walk
     int msm_tail_chunk = 8;          // entries per thread of the SMALL partial-sum levels (< 2^21 entries): their duration is the serial chain, not the work; 0 = msm_chunk
-    int msm_chain = 1;               // the prove tail's sums: everything after a sum's level-1 kernel (partial-sum levels, bucket reduction, copies) on a second stream, beside the next sum's level-1 kernel (msm.cuh MsmChain) — 1: for tails on streams with their own hardware queues ("tail_streams" / "tail_reserve_cus"), 2: every tail, 0 = one stream
+    int msm_chain = 2;               // the prove tail's sums: everything after a sum's level-1 kernel (partial-sum levels, bucket reduction, copies) on a second stream with a hardware queue of its own, beside the next sum's level-1 kernel (msm.cuh MsmChain) — 2 (the default): every tail, 1: only tails on "tail_streams" / "tail_reserve_cus" streams, 0 = one stream
     int msm_filter = 1;              // per-array digit streams: drop the entries of absent points before B1 / B2 and K (msm_digits.hip)
     int msm_filter_grid = 0;         // workgroups of the filter kernels (0 = 256: one per CU — bandwidth, not wave slots)
     int ntt_twiddles = 0;            // inter-pass twiddles of the fields whose table exceeds the L2 (2 GiB per direction at 2^26): 0 = read from the table, 1 = generated from two half tables (one more product per element, 15 GB less traffic per computeH)
     int ntt_fuse = 1;                // computeH: the two passes over the lowest field (inverse DIF last, coset DIT first) in one kernel (ntt.hip k_ntt_mid29)
+    int ntt_h = 1;                   // computeH: 1 = six transforms (c's coefficients are subtracted behind h's inverse coset transform instead of c going to the coset: the transform is linear), 0 = gnark's seven; the same h bit for bit
     int sort_grid = 0;               // workgroups of the digit-stream sort's persistent kernels (sort.hip): 0 = one per two compute units (128 on an MI355X)
     int sort_stage = 1;              // the sort's scatter passes: 1 = a tile's entries staged through LDS (whole runs per store), 0 = straight to memory (4 KB of LDS per workgroup)
     int sort_generic = 0;            // 1: the runtime-window level 0 of the sort even for the shapes that have a compile-time one (tests compare the two)
@@ -80,6 +81,7 @@ struct zkpor_ctx {
     int64_t solver_batch_from = 1 << 21;  // levels from this many generic instructions on run 4 per thread with ONE inversion per thread (solver.hip)
     int poseidon_coop = -1;          // account leaves / CEX commitments 16 lanes per hash chain: -1 = when a launch has fewer than 65 536 chains, 0 = never, 1 = always
     int solver_poseidon = 1;         // the solver program's Poseidon instruction: 1 = sixteen lanes per call (latency), 0 = one thread per call
+    int64_t poseidon_defer = 64;     // Poseidon launches of up to this many calls (16 lanes each) park their S-box inputs raw and leave conversions, wires and rows to a wide kernel behind them (poseidon.hip k_sbox_expand); 0 = never
     int gpu_token = 1;               // host-pointer calls of several contexts on one GPU take turns on the device (api_core.hip GpuTurn)
     int tail_reserve_cus = 0;        // > 0: the prove tail's kernels (NTT passes, digit streams, accumulations) run on streams whose CU mask leaves this many
                                      // compute units free (evenly over the XCDs) — for the narrow, dependent launches of ANOTHER worker's solver program, which

@@ -169,6 +169,8 @@ struct PassArgs29 {
     // the inter-pass twiddles and of the scale need the GLOBAL memory position: p_glob = ((p << p_shift) | p_or) + p_add
     int n_glob, p_shift;
     u32 p_or, p_add;
+    // computeH without c's coset transform ("ntt_h" 1): the LAST pass of h subtracts sub[p] (packed 2^261 form, [0, 4r)) behind its store scale
+    const Fr* sub = nullptr;
 };
 ZK_D Fr29 ld29(const u32* t) {
     Fr29 r;
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass29(PassArgs29 A) {
         Fr29 v = ld29(tile + 9u * li);
         if (DIF && lo > 0) v = Fr29::mul(v, twiddle29(A, brev(m, kb), ((l0 + c) << A.p_shift) | A.p_or, lo + A.p_shift));
         if (A.scale_store) v = scale29(A, A.scale_store, v, ((p << A.p_shift) | A.p_or) + A.p_add);
+        if (A.sub) v = Fr29::sub_l(v, Fr29::from32<0>(A.sub[p]));      // a product's (-r, 2r) minus [0, 4r): inside what to32_div32 / reduce32_pos take
         A.x[p] = A.out_gnark ? Fr29::to32_div32(v) : Fr29::reduce32_pos(v).pack32();
     }
 }
@@ -367,7 +370,8 @@ __global__ __launch_bounds__(256) void k_ntt_mid29(PassArgs29 A, PassArgs29 B) {
 // store with the DIF post-twiddle.  Saves the three stores, the pointwise kernel (two 32-bit products per element become two 29-bit
 // ones), one load, and three launches; with k_ntt_mid29: 21 + 1 -> 15 launches and 14 x 2 GiB less traffic per computeH at 2^26.
 // T = the DIT pass's arguments for a (xb, xc: the other two vectors); I = the DIF pass's arguments for a; den29 = 32 / (g^D - 1).
-template <int PER>   // tile elements per thread: 2 or 4
+// NV = 2 ("ntt_h" 1): a and b only, h' = a b / (g^D - 1) — c never goes to the coset, its coefficients are subtracted at the very end (compute_h_dev)
+template <int PER, int NV>   // tile elements per thread: 2 or 4; vectors: 3 or 2
 __global__ __launch_bounds__(256) void k_ntt_top29(PassArgs29 T, Fr* xb, Fr* xc, PassArgs29 I, Fr den29) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32* tile = (u32*)smem_raw;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void k_ntt_top29(PassArgs29 T, Fr* xb, Fr* xc,
     Fr29 acc[PER];
     Fr* const xs[3] = {T.x, xb, xc};
 #pragma unroll 1
-    for (int v = 0; v < 3; ++v) {
+    for (int v = 0; v < NV; ++v) {
         const Fr* x = xs[v];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(256) void k_ntt_top29(PassArgs29 T, Fr* xb, Fr* xc,
         for (int k = 0; k < PER; ++k) {
             const Fr29 e = ld29(tile + 9u * (threadIdx.x + 256u * k));
             if (v == 0) acc[k] = e;
-            else if (v == 1) acc[k] = Fr29::mul(acc[k], e);
+            else if (v == 1) { acc[k] = Fr29::mul(acc[k], e); if (NV == 2) acc[k] = Fr29::mul(Fr29::from32<0>(den29), acc[k]); }
             else acc[k] = Fr29::mul(Fr29::from32<0>(den29), Fr29::sub_l(acc[k], e));
         }
     }
@@ -606,7 +610,7 @@ void ntt_domains_free(zkpor_ctx* ctx) {
 struct ScaleSpec { int mode = 0; const Fr* g_lo = nullptr; const Fr* g_hi = nullptr; Fr konst; };
 
 static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
-                            const ScaleSpec& last_store, const Fr* src, int step_lo = 0, int step_hi = 99, PassArgs29* only_args = nullptr);
+                            const ScaleSpec& last_store, const Fr* src, int step_lo = 0, int step_hi = 99, PassArgs29* only_args = nullptr, const Fr* last_sub = nullptr);
 // src (optional): the transform reads its input from there and leaves it untouched; x receives every pass's output
 static int32_t run_passes(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
                           const ScaleSpec& last_store, const Fr* src = nullptr) {
@@ -655,8 +659,20 @@ static const Fr* table29(const NttDomain* d, const Fr* t) {
     if (t == d->gi_hi_ninv) return d->gi_hi_ninv29;
     return nullptr;
 }
+static int32_t launch_pass29(zkpor_ctx* ctx, const PassArgs29& A, bool dif) {
+    u32 blocks = (u32)(((size_t)1 << A.n) >> (A.kb + A.clog));
+    size_t smem = ((size_t)36 << A.kb) << A.clog;
+    if (smem > 64 * 1024) {  // beyond the default dynamic-LDS limit (gfx950 has 160 KiB per CU); per device, so no caching here
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if (dif) hipLaunchKernelGGL(k_ntt_pass29<true>, dim3(blocks), dim3(256), smem, ctx->stream, A);
+    else hipLaunchKernelGGL(k_ntt_pass29<false>, dim3(blocks), dim3(256), smem, ctx->stream, A);
+    ZK_KERNEL_CHECK(ctx);
+    return ZKPOR_OK;
+}
 static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, bool dif, const ScaleSpec& first_load,
-                            const ScaleSpec& last_store, const Fr* src, int step_lo, int step_hi, PassArgs29* only_args) {
+                            const ScaleSpec& last_store, const Fr* src, int step_lo, int step_hi, PassArgs29* only_args, const Fr* last_sub) {
     Field f[8];
     int nf = plan_fields(d->n, f);
     Fr c32 = Fr::one();
@@ -693,16 +709,9 @@ static int32_t run_passes29(zkpor_ctx* ctx, NttDomain* d, Fr* x, bool inverse, b
             else { A.g_lo = table29(d, last_store.g_lo); A.g_hi = table29(d, last_store.g_hi); }
         }
         if ((A.scale_load > 1 || A.scale_store > 1) && (!A.g_lo || !A.g_hi)) { ctx->err = "ntt: no 2^261-form table for this scale"; return ZKPOR_E_ARG; }
+        if (step == nf - 1) A.sub = last_sub;
         if (only_args) { *only_args = A; return ZKPOR_OK; }   // the caller launches a fused kernel with these arguments
-        u32 blocks = (u32)(((size_t)1 << d->n) >> (fl.kb + A.clog));
-        size_t smem = ((size_t)36 << fl.kb) << A.clog;
-        if (smem > 64 * 1024) {  // beyond the default dynamic-LDS limit (gfx950 has 160 KiB per CU); per device, so no caching here
-            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
-        if (dif) hipLaunchKernelGGL(k_ntt_pass29<true>, dim3(blocks), dim3(256), smem, ctx->stream, A);
-        else hipLaunchKernelGGL(k_ntt_pass29<false>, dim3(blocks), dim3(256), smem, ctx->stream, A);
-        ZK_KERNEL_CHECK(ctx);
+        ZK_TRY(launch_pass29(ctx, A, dif));
     }
     return ZKPOR_OK;
 }
@@ -895,7 +904,23 @@ int32_t compute_h_dev(zkpor_ctx* ctx, int n, Fr* a, Fr* b, Fr* c, const Fr* a_in
         Fr* v[3] = {a, b, c};
         const Fr* in[3] = {a_in, b_in, c_in};     // inputs the caller wants preserved: the first pass reads them, a / b / c are the work buffers
         const bool fuse = ntt_fusable(ctx, d);
-        for (int i = 0; i < 3; ++i) ZK_TRY(run_inverse_then_coset_forward(ctx, d, v[i], pre, in[i], fuse));
+        // "ntt_h" 1 (round 6): SIX transforms instead of gnark's seven.  The inverse coset transform is linear, so
+        //   h = icFFT(den (a_c b_c - c_c)) = icFFT(den a_c b_c) - den c,      c = the COEFFICIENTS of c, which its inverse transform has already produced:
+        // c never goes to the coset; its DIF inverse transform ends with the constant den / N at the store, stays in the packed inter-pass form and in
+        // the bit-reversed order h's own last DIF pass stores in, and that pass subtracts it behind its post-twiddle.  The same h for EVERY a, b, c (no
+        // use is made of a b = c on the domain), bit for bit: tests/test_ntt_gpu.py runs both schedules against the oracle.
+        const bool skip_c = fuse && ctx->ntt_h == 1;
+        for (int i = 0; i < (skip_c ? 2 : 3); ++i) ZK_TRY(run_inverse_then_coset_forward(ctx, d, v[i], pre, in[i], fuse));
+        if (skip_c) {
+            Field f[8];
+            const int nf = plan_fields(n, f);
+            ScaleSpec kc; kc.mode = 1; kc.konst = Fr::mul(d->den, d->n_inv);
+            PassArgs29 L;
+            ZK_TRY(run_passes29(ctx, d, c, true, true, none, none, c_in, 0, nf - 1));
+            ZK_TRY(run_passes29(ctx, d, c, true, true, none, kc, c_in, nf - 1, nf, &L));
+            L.out_gnark = 0;                     // stays in the packed 2^261 form: read back once, by h's last pass
+            ZK_TRY(launch_pass29(ctx, L, true));
+        }
         if (fuse) {
             Field f[8];
             const int nf = plan_fields(n, f);
@@ -909,10 +934,13 @@ int32_t compute_h_dev(zkpor_ctx* ctx, int n, Fr* a, Fr* b, Fr* c, const Fr* a_in
             const int tl = T.kb + T.clog;
             const u32 blocks = (u32)(((size_t)1 << n) >> tl);
             const size_t smem = (size_t)36 << tl;
-            if (tl == 10) hipLaunchKernelGGL(k_ntt_top29<4>, dim3(blocks), dim3(256), smem, ctx->stream, T, b, c, I, den29);
-            else hipLaunchKernelGGL(k_ntt_top29<2>, dim3(blocks), dim3(256), smem, ctx->stream, T, b, c, I, den29);
+            if (skip_c) {
+                if (tl == 10) hipLaunchKernelGGL((k_ntt_top29<4, 2>), dim3(blocks), dim3(256), smem, ctx->stream, T, b, c, I, den29);
+                else hipLaunchKernelGGL((k_ntt_top29<2, 2>), dim3(blocks), dim3(256), smem, ctx->stream, T, b, c, I, den29);
+            } else if (tl == 10) hipLaunchKernelGGL((k_ntt_top29<4, 3>), dim3(blocks), dim3(256), smem, ctx->stream, T, b, c, I, den29);
+            else hipLaunchKernelGGL((k_ntt_top29<2, 3>), dim3(blocks), dim3(256), smem, ctx->stream, T, b, c, I, den29);
             ZK_KERNEL_CHECK(ctx);
-            ZK_TRY(run_passes29(ctx, d, a, true, true, none, post, nullptr, 1, nf));              // the remaining DIF passes of h
+            ZK_TRY(run_passes29(ctx, d, a, true, true, none, post, nullptr, 1, nf, nullptr, skip_c ? c : nullptr));   // the remaining DIF passes of h (the last one: minus den c)
             return ZKPOR_OK;
         }
     }

@@ -718,9 +718,19 @@ ZK_D void flush(Tr& tr, int j) {
     wave_sync();
     tr.n_stash = 0;
 }
+// the S-box input u parked in its raw 9 x 29-bit form in the first 36 bytes of the S-box's own three wire slots (TR == 2): k_sbox_expand recomputes
+// x^2, x^4, x^5 from it, converts and writes wires and rows with every lane busy — the serial wave keeps no conversion (a product and a
+// canonicalisation each) and no stash on its critical path
+ZK_D void park(Fr* slot, const Fr29& u) {
+    u32* o = (u32*)slot;
+    *(uint4*)o = make_uint4(u.l[0], u.l[1], u.l[2], u.l[3]);
+    *(uint4*)(o + 4) = make_uint4(u.l[4], u.l[5], u.l[6], u.l[7]);
+    o[8] = u.l[8];
+}
 // ONE permutation of width t on the group's lanes (lane j < t holds element j in st; act = this group has a block — idle groups of the wave
-// run along on a valid dummy width so that the wave stays converged for the DPP / LDS steps of the live ones).  TR: the S-box wires go out.
-template <bool TR>
+// run along on a valid dummy width so that the wave stays converged for the DPP / LDS steps of the live ones).  TR: the S-box wires go out —
+// 1: converted and stored here, 2: the S-box inputs parked raw for k_sbox_expand.
+template <int TR>
 ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D, Tr& tr) {
     const int j = lane & 15, base_lane = lane & ~15;
     const bool mine = act && j < t;           // this lane holds a state element
@@ -734,7 +744,10 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
         for (int rr = 0; rr < POS_RF / 2; ++rr) {          // full round: S-boxes side by side, one matrix row per lane
             const Fr29 u = Fr29::reduce32(Fr29::add_l(st, ldc(rows + 144 * (half * (POS_RF / 2) + rr), j)));
             const Fr29 x2 = Fr29::sqr(u), x4 = Fr29::sqr(x2), x5 = Fr29::mul(x4, u);
-            if (TR) {
+            if (TR == 2) {
+                if (mine) park(tr.w + tr.first + 3u * (tr.sbase + (u32)j), u);
+                if (act) tr.sbase += (u32)t;
+            } else if (TR) {
                 if (mine) {
                     Fr* o = tr.w + tr.first + 3u * (tr.sbase + (u32)j);
                     const Fr X2 = Fr29::to32_div32(x2), X4 = Fr29::to32_div32(x4), X5 = Fr29::to32_div32(x5);
@@ -762,7 +775,10 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
             const Fr29 p1 = Fr29::mul(j == 0 ? s_j : ka, s_j);                               // lane 0: x^2; lane j: v_j * s_j
             const Fr29 x4 = Fr29::sqr(p1);
             const Fr29 x5 = Fr29::mul(x4, s_j);                                              // lane 0 only is meaningful
-            if (TR && j == 0 && act) {
+            if (TR == 2) {
+                if (j == 0 && act) park(tr.w + tr.first + 3u * tr.sbase, s_j);
+                if (act) ++tr.sbase;
+            } else if (TR && j == 0 && act) {
                 if (tr.a) { u32* q = tr.ts + 9 * (4 * tr.n_stash); put(q, s_j); put(q + 9, p1); put(q + 18, x4); put(q + 27, x5); }
                 else { u32* q = tr.ts + 9 * (3 * tr.n_stash); put(q, p1); put(q + 9, x4); put(q + 18, x5); }
             }
@@ -773,14 +789,14 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
             if (j == 0 || j >= tt) dterm = Fr29::zero();
             const Fr29 Dsum = row_sum(dterm);                                                // lane 0: sum_j v_j s_j
             st = j == 0 ? Fr29::reduce32(Fr29::add_l(e, Dsum)) : Fr29::add_l(s_j, e);          // loose on lanes j: reduced at the next constant add
-            if (TR) {
+            if (TR == 1) {
                 if (tr.n_stash == 0) tr.stash_first = tr.sbase;
                 if (act) { ++tr.n_stash; ++tr.sbase; }
                 if (max4(tr.n_stash, lane) == (tr.a ? 4u : 5u)) flush(tr, j);   // the wave's groups stash in lockstep only when they run the same width: flush on the fullest
             }
         }
         {   // the dense block left over by the optimised rounds: st[1..t-1] = post * st[1..t-1]
-            if (TR) { if (max4(tr.n_stash, lane)) flush(tr, j); }
+            if (TR == 1) { if (max4(tr.n_stash, lane)) flush(tr, j); }
             const Fr29 sj = Fr29::reduce32(st);
             put(xs + 9 * j, sj);
             wave_sync();
@@ -792,7 +808,8 @@ ZK_D void permute(Fr29& st, bool act, int t, int lane, u32* xs, const PosDev& D,
 }
 }  // namespace coop
 #endif
-// one wave per workgroup, four calls per wave
+// one wave per workgroup, four calls per wave.  TR 1: wires (and rows) converted and written by the wave itself; 2: S-box inputs parked, k_sbox_expand behind it
+template <int TR>
 __global__ __launch_bounds__(64) void k_gadget_poseidon_coop(SolverProg P, const u32* __restrict__ instr, u32 n, Fr* w, uint8_t* known, u32* err, PosDev D,
                                                             const Fr* __restrict__ pre, const u32* __restrict__ pre_off, Fr* ra, Fr* rb, Fr* rc, int urgent) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -837,13 +854,43 @@ __global__ __launch_bounds__(64) void k_gadget_poseidon_coop(SolverProg P, const
         }
         if (bad) { if (atomicCAS(&err[0], 0u, (u32)bad) == 0u) err[1] = ins; }
         if (!act) { if (j) st = Fr29::zero(); }
-        permute<true>(st, act, (int)k + 1, lane, xs, D, tr);
+        permute<TR>(st, act, (int)k + 1, lane, xs, D, tr);
         // the next block's capacity element sits on lane 0
         const Fr29 cap = from_lane(st, base_lane + (int)carry_lane);
         if (j == 0) st = cap;
         if (act) done += k;
     }
     if (live) for (u32 q = (u32)j; q < n_out; q += (u32)G) known[tr.first + q] = 1;
+#endif
+}
+
+// behind k_gadget_poseidon_coop<2>: a thread per S-box of a call (blockIdx.y) — the parked input u back from the S-box's own wire slots, x^2, x^4, x^5
+// from it, the three wires in memory form and, with ra, the S-box's three rows (u u = x^2, x^2 x^2 = x^4, x^4 u = x^5).  The same field elements the
+// serial wave went on with, so the same canonical words as the wave's own conversions (tests/test_circuit_gpu.py runs both).
+__global__ __launch_bounds__(128) void k_sbox_expand(SolverProg P, const u32* __restrict__ instr, Fr* w, const u32* __restrict__ err, PosDev D, Fr* ra, Fr* rb, Fr* rc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (err[0]) return;                       // the wave parked nothing (or the solve is lost anyway)
+    const u32* cd = P.calldata + P.arg[instr[blockIdx.y]];
+    const u32 n_in = cd[0], first = cd[1], row = cd[4];
+    const u32 full = n_in / 12u, rem = n_in % 12u;
+    const u32 n_sbox = full * (u32)(POS_RF * 13 + D.rp[13]) + (rem ? (u32)(POS_RF * (int)(rem + 1u) + D.rp[rem + 1u]) : 0u);
+    const bool rows = ra != nullptr && row != 0xffffffffu;
+    for (u32 sb = blockIdx.x * 128u + threadIdx.x; sb < n_sbox; sb += gridDim.x * 128u) {
+        Fr* o = w + first + 3u * sb;
+        const uint4 lo = *(const uint4*)o, hi = *((const uint4*)o + 1);
+        Fr29 u;
+        u.l[0] = lo.x; u.l[1] = lo.y; u.l[2] = lo.z; u.l[3] = lo.w; u.l[4] = hi.x; u.l[5] = hi.y; u.l[6] = hi.z; u.l[7] = hi.w; u.l[8] = ((const u32*)o)[8];
+        const Fr29 x2 = Fr29::sqr(u), x4 = Fr29::sqr(x2), x5 = Fr29::mul(x4, u);
+        const Fr X2 = Fr29::to32_div32(x2), X4 = Fr29::to32_div32(x4), X5 = Fr29::to32_div32(x5);
+        o[0] = X2; o[1] = X4; o[2] = X5;
+        if (rows) {
+            const Fr U = Fr29::to32_div32(u);
+            const size_t r0 = (size_t)row + 3u * sb;
+            ra[r0] = U; rb[r0] = U; rc[r0] = X2;
+            ra[r0 + 1] = X2; rb[r0 + 1] = X2; rc[r0 + 1] = X4;
+            ra[r0 + 2] = X4; rb[r0 + 2] = U; rc[r0 + 2] = X5;
+        }
+    }
 #endif
 }
 
@@ -1169,7 +1216,12 @@ int32_t gadget_poseidon_launch(zkpor_ctx* ctx, hipStream_t stream, const SolverP
     PosDev D;
     ZK_TRY(pos_dev(ctx, &D));
     if (ctx->solver_poseidon == 0) hipLaunchKernelGGL(k_gadget_poseidon, dim3((n + 63u) / 64u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off);
-    else hipLaunchKernelGGL(k_gadget_poseidon_coop, dim3((n + 3u) / 4u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off, d_a, d_b, d_c, n <= 64u ? 1 : 0);
+    else if ((int64_t)n <= ctx->poseidon_defer) {
+        // a launch this narrow is somebody's critical path (the challenge sponge: one call of 116 permutations; the CEX chains: two of 834; a Merkle level):
+        // the waves park their S-box inputs and a wide kernel behind them does the conversions ("poseidon_defer": calls per launch up to which)
+        hipLaunchKernelGGL(k_gadget_poseidon_coop<2>, dim3((n + 3u) / 4u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off, d_a, d_b, d_c, n <= 64u ? 1 : 0);
+        hipLaunchKernelGGL(k_sbox_expand, dim3(n <= 8u ? 256u : n <= 512u ? 16u : 1u, n), dim3(128), 0, stream, P, d_instr, w, (const u32*)d_err, D, d_a, d_b, d_c);
+    } else hipLaunchKernelGGL(k_gadget_poseidon_coop<1>, dim3((n + 3u) / 4u), dim3(64), 0, stream, P, d_instr, n, w, known, d_err, D, d_pre, d_pre_off, d_a, d_b, d_c, n <= 64u ? 1 : 0);
     ZK_KERNEL_CHECK(ctx);
     return ZKPOR_OK;
 }
