@@ -98,15 +98,17 @@ upper, lowest = fields[1:], fields[:1]
 def step_fn(s):                                                # the four steps of zkpor_compute_h_shard_dev, on the model
     if s == 0:
         for k in "abc": run(k, Ti, True, "low", upper)
-    elif s == 1:
-        for k in "abc": run(k, Ti, True, "high", lowest); run(k, Tf, False, "high", lowest, first=pre)
+    elif s == 1:                                               # "ntt_h" 1: c ends at its coefficients (times den / N), in D_high, and stays there
+        for k in "ab": run(k, Ti, True, "high", lowest); run(k, Tf, False, "high", lowest, first=pre)
+        run("c", Ti, True, "high", lowest, last=lambda p: den * ninv %% M.R)
     elif s == 2:
-        for k in "abc": run(k, Tf, False, "low", upper)
-        a, b, c = dec(ten["a"]), dec(ten["b"]), dec(ten["c"])
-        ten["a"].copy_(enc([(x * y - z) * den %% M.R for x, y, z in zip(a, b, c)]))
+        for k in "ab": run(k, Tf, False, "low", upper)
+        a, b = dec(ten["a"]), dec(ten["b"])
+        ten["a"].copy_(enc([x * y * den %% M.R for x, y in zip(a, b)]))
         run("a", Ti, True, "low", upper)
     else:
         run("a", Ti, True, "high", lowest, last=post)
+        ten["a"].copy_(enc([(x - z) %% M.R for x, z in zip(dec(ten["a"]), dec(ten["c"]))]))
 def transpose_fn(out, inp, interleave):                        # stand-in for zkpor_shard_transpose_dev
     Mch = (1 << nl) // world
     x = inp.view(world, Mch, 32) if interleave else inp.view(Mch, world, 32)

@@ -276,11 +276,14 @@ def _emulated_all_to_all(zk, bufs, tmp, n_local, wlog, to_high):
             zk.shard_transpose_dev(bufs[r].ptr, tmp[r].ptr, n_local, wlog, True)
 
 
+@pytest.mark.parametrize("six", [1, 0])
 @pytest.mark.parametrize("log2,wlog", [(20, 2), (20, 3), (17, 1), (22, 3)])
-def test_compute_h_sharded_equals_unsharded(zk, log2, wlog):
+def test_compute_h_sharded_equals_unsharded(zk, log2, wlog, six):
     """computeH spread over 2^wlog ranks (run one after the other here, the all-to-alls emulated by copies): the blocks of h that
-    the ranks end with, concatenated, are bit for bit the h of the unsharded computeH"""
+    the ranks end with, concatenated, are bit for bit the h of the unsharded computeH.  six = 1 ("ntt_h" 1, the default): c stops at its
+    coefficients in step 1, is not exchanged again and is subtracted by step 3; 0: gnark's seven transforms, c exchanged like a and b"""
     n = 1 << log2; W = 1 << wlog; nl = log2 - wlog
+    zk.set_param("ntt_h", six)
     full = {k: zk.alloc(32 * n) for k in "abc"}
     loc = {k: [zk.alloc(32 << nl) for _ in range(W)] for k in "abc"}
     tmp = [zk.alloc(32 << nl) for _ in range(W)]
@@ -303,16 +306,20 @@ def test_compute_h_sharded_equals_unsharded(zk, log2, wlog):
             _emulated_all_to_all(zk, loc[k], tmp, nl, wlog, True)
         for r in range(W):
             zk.compute_h_shard_dev(log2, wlog, r, *ptrs(r), 1)
-        for k in "abc":
+        for k in ("ab" if six else "abc"):
             _emulated_all_to_all(zk, loc[k], tmp, nl, wlog, False)
         for r in range(W):
-            zk.compute_h_shard_dev(log2, wlog, r, *ptrs(r), 2)
+            zk.compute_h_shard_dev(log2, wlog, r, loc["a"][r].ptr, loc["b"][r].ptr, None if six else loc["c"][r].ptr, 2)
         _emulated_all_to_all(zk, loc["a"], tmp, nl, wlog, True)
+        if six:
+            with pytest.raises(zkpor.ZkporError):
+                zk.compute_h_shard_dev(log2, wlog, 0, loc["a"][0].ptr, None, None, 3)      # step 3 subtracts c: it has to be there
         for r in range(W):
-            zk.compute_h_shard_dev(log2, wlog, r, loc["a"][r].ptr, None, None, 3)
+            zk.compute_h_shard_dev(log2, wlog, r, loc["a"][r].ptr, None, loc["c"][r].ptr if six else None, 3)
         got = np.concatenate([loc["a"][r].download(np.uint64, (1 << nl, 4)) for r in range(W)])
         assert np.array_equal(got, expect)
     finally:
+        zk.set_param("ntt_h", 1)
         for b in list(full.values()) + tmp + [x for v in loc.values() for x in v]:
             b.free()
 

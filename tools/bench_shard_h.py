@@ -29,11 +29,11 @@ for log2 in [int(x) for x in sys.argv[1:]] or [26, 28]:
             for x in (a, b, c):
                 ctx.shard_transpose_dev(x.ptr, tmp.ptr, nl, wlog, True)
             ctx.compute_h_shard_dev(log2, wlog, 0, a.ptr, b.ptr, c.ptr, 1)
-            for x in (a, b, c):
+            for x in (a, b):                    # "ntt_h" 1 (the default): c stays where step 1 left it, step 3 subtracts it
                 ctx.shard_transpose_dev(tmp.ptr, x.ptr, nl, wlog, False)
-            ctx.compute_h_shard_dev(log2, wlog, 0, a.ptr, b.ptr, c.ptr, 2)
+            ctx.compute_h_shard_dev(log2, wlog, 0, a.ptr, b.ptr, None, 2)
             ctx.shard_transpose_dev(a.ptr, tmp.ptr, nl, wlog, True)
-            ctx.compute_h_shard_dev(log2, wlog, 0, a.ptr, None, None, 3)
+            ctx.compute_h_shard_dev(log2, wlog, 0, a.ptr, None, c.ptr, 3)
 
         proof(); ctx.sync()                     # builds the 2^log2 domain tables
         ctx.phase_reset()

@@ -122,21 +122,21 @@ def run(log2, wlog, check_h="auto", reference_h=True, log=print):
                 zk.sync(); t0 = time.perf_counter()
                 if step < 3:
                     zk.compute_h_shard_dev(log2, wlog, r, *ptrs(r), step)
-                else:
-                    zk.compute_h_shard_dev(log2, wlog, r, loc["a"][r].ptr, None, None, 3)
+                else:                                                       # "ntt_h" 1: step 3 subtracts c, which step 1 left in place
+                    zk.compute_h_shard_dev(log2, wlog, r, loc["a"][r].ptr, None, loc["c"][r].ptr, 3)
                 zk.sync(); per_rank.append((time.perf_counter() - t0) * 1e3)
             step_ms.append(per_rank)
             if step == 0:
                 for k in "abc":
                     all_to_all(loc[k], True)
             elif step == 1:
-                for k in "abc":
+                for k in "ab":                                              # six all-to-alls of a vector, not seven: c is not exchanged again
                     all_to_all(loc[k], False)
             elif step == 2:
                 all_to_all(loc["a"], True)
         res["compute_h_sharded_ms_per_rank_by_step"] = [[round(x, 2) for x in s] for s in step_ms]
         res["compute_h_sharded_ms_per_rank"] = round(sum(max(s) for s in step_ms), 2)
-        res["all_to_all_bytes_per_rank"] = 7 * (32 << nl) * (W - 1) // W
+        res["all_to_all_bytes_per_rank"] = 6 * (32 << nl) * (W - 1) // W
         log(f"computeH sharded: {res['compute_h_sharded_ms_per_rank']} ms per rank (max over ranks, summed over the four steps)")
         # rank r's block of h = positions [r * 2^nl, (r + 1) * 2^nl) of h in the order of the key's Z: put them side by side
         h = stage

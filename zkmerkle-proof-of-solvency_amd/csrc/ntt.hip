@@ -424,11 +424,12 @@ __global__ void k_unpack29(const Fr* in, u32* out, u32 count) {
     for (int k = 0; k < 9; ++k) out[9u * i + k] = v.l[k];
 }
 
-// a = (a*b - c) * den
+// a = (a*b - c) * den (c may be null: a = a*b * den)
 __global__ __launch_bounds__(256) void k_h_pointwise(Fr* a, const Fr* b, const Fr* c, Fr den, size_t n) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    a[i] = Fr::mul(Fr::sub(Fr::mul(a[i], b[i]), c[i]), den);
+    const Fr ab = Fr::mul(a[i], b[i]);
+    a[i] = Fr::mul(c ? Fr::sub(ab, c[i]) : ab, den);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -760,8 +761,9 @@ static int32_t run_inverse_then_coset_forward(zkpor_ctx* ctx, NttDomain* d, Fr* 
 // wlog bits, local index p mod 2^(n-wlog)) for the lowest field.  stage 0 runs the passes before the exchange, stage 1 the ones
 // after it (DIF: upper fields under D_low, then the lowest under D_high; DIT: the reverse).  The passes are the unsharded kernels
 // on the local array; only the exponents of the inter-pass twiddles and of the scale use the global position.
+// last_packed: the transform's last pass leaves the packed 2^261 form instead of gnark's; last_sub: it subtracts last_sub[p] (that form) behind its scale
 static int32_t ntt_shard_stage(zkpor_ctx* ctx, NttDomain* d, Fr* x, int wlog, int rank, bool inverse, bool dif,
-                               const ScaleSpec& first_load, const ScaleSpec& last_store, int stage) {
+                               const ScaleSpec& first_load, const ScaleSpec& last_store, int stage, bool last_packed = false, const Fr* last_sub = nullptr) {
     Field f[8];
     const int nf = plan_fields(d->n, f);
     if (!d->have29 || ctx->ntt_variant != 1) { ctx->err = "ntt: the sharded transform needs the 29-bit kernels"; return ZKPOR_E_STATE; }
@@ -803,15 +805,8 @@ static int32_t ntt_shard_stage(zkpor_ctx* ctx, NttDomain* d, Fr* x, int wlog, in
             else { A.g_lo = table29(d, last_store.g_lo); A.g_hi = table29(d, last_store.g_hi); }
         }
         if ((A.scale_load > 1 || A.scale_store > 1) && (!A.g_lo || !A.g_hi)) { ctx->err = "ntt: no 2^261-form table for this scale"; return ZKPOR_E_ARG; }
-        u32 blocks = (u32)(((size_t)1 << nl) >> (fl.kb + A.clog));
-        size_t smem = ((size_t)36 << fl.kb) << A.clog;
-        if (smem > 64 * 1024) {
-            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass29<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
-        if (dif) hipLaunchKernelGGL(k_ntt_pass29<true>, dim3(blocks), dim3(256), smem, ctx->stream, A);
-        else hipLaunchKernelGGL(k_ntt_pass29<false>, dim3(blocks), dim3(256), smem, ctx->stream, A);
-        ZK_KERNEL_CHECK(ctx);
+        if (step == nf - 1) { if (last_packed) A.out_gnark = 0; A.sub = last_sub; }
+        ZK_TRY(launch_pass29(ctx, A, dif));
     }
     return ZKPOR_OK;
 }
@@ -830,6 +825,9 @@ __global__ void k_shard_transpose(const Fr* __restrict__ in, Fr* __restrict__ ou
 //   step 1  a, b, c (D_high): inverse DIF lowest field; forward coset DIT lowest field    -> exchange a, b, c to D_low
 //   step 2  a, b, c (D_low):  forward DIT upper fields; a = (a b - c) den; inverse coset DIF upper fields on a -> exchange a
 //   step 3  a (D_high):       inverse DIF lowest field with the g^-rev(p)/N scale: this rank's block of h, in the order of pk->Z
+// "ntt_h" 1 (the default, compute_h_dev): c stops at its coefficients — step 1 ends c's inverse transform with the constant den / N and leaves it, in
+// D_high, where h's last pass (step 3, D_high as well, the same local positions) subtracts it.  c is NOT exchanged after step 1 (six all-to-alls of a
+// vector instead of seven), step 2 does not touch it, step 3 takes it.
 int32_t compute_h_shard_step(zkpor_ctx* ctx, int n, int wlog, int rank, Fr* a, Fr* b, Fr* c, int step) {
     NttDomain* d;
     ZK_TRY(ntt_domain_get(ctx, n, &d));
@@ -838,30 +836,36 @@ int32_t compute_h_shard_step(zkpor_ctx* ctx, int n, int wlog, int rank, Fr* a, F
     post.mode = 3; post.g_lo = d->gi_lo; post.g_hi = d->gi_hi_ninv;
     Fr* v[3] = {a, b, c};
     const size_t NL = (size_t)1 << (n - wlog);
+    const bool six = ctx->ntt_h == 1;
     if (step == 0) {
         PhaseScope ps(ctx, "ntt");
         for (int i = 0; i < 3; ++i) ZK_TRY(ntt_shard_stage(ctx, d, v[i], wlog, rank, true, true, none, none, 0));
     } else if (step == 1) {
         PhaseScope ps(ctx, "ntt");
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < (six ? 2 : 3); ++i) {
             ZK_TRY(ntt_shard_stage(ctx, d, v[i], wlog, rank, true, true, none, none, 1));
             ZK_TRY(ntt_shard_stage(ctx, d, v[i], wlog, rank, false, false, pre, none, 0));
+        }
+        if (six) {
+            ScaleSpec kc; kc.mode = 1; kc.konst = Fr::mul(d->den, d->n_inv);
+            ZK_TRY(ntt_shard_stage(ctx, d, c, wlog, rank, true, true, none, kc, 1, true));
         }
     } else if (step == 2) {
         {
             PhaseScope ps(ctx, "ntt");
-            for (int i = 0; i < 3; ++i) ZK_TRY(ntt_shard_stage(ctx, d, v[i], wlog, rank, false, false, pre, none, 1));
+            for (int i = 0; i < (six ? 2 : 3); ++i) ZK_TRY(ntt_shard_stage(ctx, d, v[i], wlog, rank, false, false, pre, none, 1));
         }
         {
             PhaseScope ps(ctx, "pointwise");
-            hipLaunchKernelGGL(k_h_pointwise, dim3((unsigned)((NL + 255) / 256)), dim3(256), 0, ctx->stream, a, b, c, d->den, NL);
+            hipLaunchKernelGGL(k_h_pointwise, dim3((unsigned)((NL + 255) / 256)), dim3(256), 0, ctx->stream, a, b, six ? nullptr : c, d->den, NL);
             ZK_KERNEL_CHECK(ctx);
         }
         PhaseScope ps(ctx, "ntt");
         ZK_TRY(ntt_shard_stage(ctx, d, a, wlog, rank, true, true, none, post, 0));
     } else if (step == 3) {
         PhaseScope ps(ctx, "ntt");
-        ZK_TRY(ntt_shard_stage(ctx, d, a, wlog, rank, true, true, none, post, 1));
+        if (six && !c) { ctx->err = "computeH shard: step 3 takes c as step 1 left it (\"ntt_h\" 1: it is not exchanged after step 1)"; return ZKPOR_E_ARG; }
+        ZK_TRY(ntt_shard_stage(ctx, d, a, wlog, rank, true, true, none, post, 1, false, six ? c : nullptr));
     } else {
         ctx->err = "computeH shard: step must be 0..3"; return ZKPOR_E_ARG;
     }
@@ -987,7 +991,7 @@ int32_t zkpor_fft_dev(zkpor_ctx* ctx, void* d_a, int log2n, int inverse, int dec
 int32_t zkpor_compute_h_shard_dev(zkpor_ctx* ctx, int log2_domain, int world_log2, int rank, void* d_a, void* d_b, void* d_c, int step) try {
     ZK_ENTER(ctx ? ctx->device : -1);
     if (!ctx || !d_a || log2_domain < 1 || log2_domain > 28) return ZKPOR_E_ARG;
-    if (step < 3 && (!d_b || !d_c)) return ZKPOR_E_ARG;
+    if (step < 3 && (!d_b || (!d_c && !(step == 2 && ctx->ntt_h == 1)))) return ZKPOR_E_ARG;
     return compute_h_shard_step(ctx, log2_domain, world_log2, rank, (Fr*)d_a, (Fr*)d_b, (Fr*)d_c, step);
 } ZK_ABI_CATCH_IN(ctx)
 int32_t zkpor_shard_transpose_dev(zkpor_ctx* ctx, void* d_out, const void* d_in, int log2_local, int world_log2, int interleave) try {

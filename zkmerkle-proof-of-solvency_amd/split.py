@@ -12,8 +12,8 @@ Per proof:
   5. every rank adds the partials on the host (zkpor_g1/g2_jac_sum: RCCL has no reduction over curve points) and assembles the
      proof (zkpor_prove_assemble) — all ranks end with the same 256 bytes.
 With a power-of-two number of ranks computeH shards as well (SplitProver.prove_sharded_h / compute_h_sharded): every field pass of
-the transform is local under one of two distributions of the index bits, so steps 1-2 become seven all-to-alls of 1/world of a
-vector per rank and nobody waits for rank 0.
+the transform is local under one of two distributions of the index bits, so steps 1-2 become six all-to-alls of 1/world of a
+vector per rank (seven with gnark's seven-transform schedule, "ntt_h" 0) and nobody waits for rank 0.
 gnark has no counterpart: its MultiExp splits over CPU tasks inside one process.
 torch.distributed is plumbing here (backend "nccl" = RCCL on the GPUs, "gloo" in the CPU test of the exchange logic)."""
 import numpy as np
@@ -87,11 +87,13 @@ def exchange_and_assemble(dist, rank, world, h_full, h_mine, sums_fn, consts, r,
     return zkpor.prove_assemble(consts, add_partial_sums(parts), r, s)
 
 
-def compute_h_sharded(dist, world, step_fn, transpose_fn, a, b, c, tmp, device_sync=None):
+def compute_h_sharded(dist, world, step_fn, transpose_fn, a, b, c, tmp, device_sync=None, six=True):
     """computeH over all ranks (zkpor_compute_h_shard_dev, csrc/ntt.hip): a, b, c are this rank's D_low slices (elements at
     positions p = rank mod world) as 1-D uint8 tensors, tmp a scratch tensor of the same size; on return `a` holds this rank's
     contiguous block of h.  step_fn(k) runs step k on (a, b, c); transpose_fn(out, inp, interleave) is zkpor_shard_transpose_dev.
-    Seven all-to-alls of 1/world of a vector per rank — all seven xGMI links of a GPU busy at once — replace the NTT on one GPU."""
+    Six all-to-alls of 1/world of a vector per rank — all seven xGMI links of a GPU busy at once — replace the NTT on one GPU: with the library's
+    default schedule ("ntt_h" 1, six = True) c stops at its coefficients in step 1 and is NOT exchanged again — step 3 subtracts it where it lies;
+    six = False is gnark's seven-transform schedule ("ntt_h" 0: c goes to the coset as well, seven all-to-alls).  The caller keeps the two in step."""
     sync = device_sync if device_sync is not None else (lambda: None)
 
     def to_high(x):                      # D_low -> D_high: chunk d of the local array goes to rank d, the receiver interleaves
@@ -110,7 +112,7 @@ def compute_h_sharded(dist, world, step_fn, transpose_fn, a, b, c, tmp, device_s
     for x in (a, b, c):
         to_high(x)
     step_fn(1)
-    for x in (a, b, c):
+    for x in ((a, b) if six else (a, b, c)):
         to_low(x)
     step_fn(2)
     to_high(a)
@@ -122,8 +124,9 @@ class SplitProver:
     """rank-local half of the split: owns the shard of the key on this GPU.  `pk` must be fully loaded (every rank loads or
     synthesises the same key); it is cut down to this rank's ranges here."""
 
-    def __init__(self, ctx, pk, rank, world, dist):
+    def __init__(self, ctx, pk, rank, world, dist, six_transforms=True):
         self.ctx, self.pk, self.rank, self.world, self.dist = ctx, pk, rank, world, dist
+        self.six = bool(six_transforms)      # the sharded computeH's schedule: the library's parameter and the exchange pattern are set together
         _, self.n_wires = pk.g1_dev(zkpor.G1_A)
         _, nz = pk.g1_dev(zkpor.G1_Z)
         self.D = nz + 1
@@ -141,10 +144,11 @@ class SplitProver:
             raise ValueError("the sharded computeH needs a power-of-two number of ranks >= 2")
         log2 = self.D.bit_length() - 1
         nl = log2 - wlog
+        self.ctx.set_param("ntt_h", 1 if self.six else 0)
         compute_h_sharded(self.dist, self.world,
                           lambda k: self.ctx.compute_h_shard_dev(log2, wlog, self.rank, a.data_ptr(), b.data_ptr(), c.data_ptr(), k),
                           lambda out, inp, il: self.ctx.shard_transpose_dev(out.data_ptr(), inp.data_ptr(), nl, wlog, il),
-                          a, b, c, tmp, device_sync=torch.cuda.synchronize)
+                          a, b, c, tmp, device_sync=torch.cuda.synchronize, six=self.six)
         mine = self.ctx.prove_sums_dev(self.pk, d_w_full + 32 * self.w_lo, a.data_ptr())
         t = torch.from_numpy(np.ascontiguousarray(mine).copy()).to(a.device)
         allp = torch.empty(self.world * SUM_BYTES, dtype=torch.uint8, device=a.device)
