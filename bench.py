@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — Groth16 proofs/sec of the MI355X prove tail at the zkpor50_1380 shape (BASELINE.json metric).
 
-A "step" is ONE proof: computeH (7 NTTs of 2^log2) + the A/B1/K/Z G1 and B2 G2 multi-exponentiations + the two
+A "step" is ONE proof: computeH (gnark's 7 NTTs of 2^log2, run as 6: DESIGN.md 6d) + the A/B1/K/Z G1 and B2 G2 multi-exponentiations + the two
 Pedersen commitment MSMs (2^(log2-2) points), on synthetic inputs already resident in HBM (witness-like scalar
 mixture for w, uniform a,b with c = a.b).  One process per GPU; with N > 1 each rank proves its
 own independent batches (weak scaling, no data-path collective — witness batches are independent proofs).

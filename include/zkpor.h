@@ -360,6 +360,9 @@ int32_t zkpor_pk_consts(zkpor_pk* pk, void* alpha, void* beta, void* delta, void
  * bits, local index p mod local size) — so one all-to-all per transform replaces the NTT on a single GPU and the scatter of h:
  *   step 0 (a, b, c in D_low) | all-to-all to D_high | step 1 | all-to-all to D_low | step 2 (leaves the product in a) |
  *   all-to-all of a to D_high | step 3: a = this rank's contiguous block of h, in the order of the key's Z.
+ * With "ntt_h" 1 (the default) the all-to-all after step 1 moves a and b ONLY: step 1 has taken c to its coefficients (times 1 / (N (g^N - 1))),
+ * which stay in D_high; step 2 ignores d_c (may be NULL); step 3 needs d_c (ZKPOR_E_ARG without it) and subtracts it behind h's last pass —
+ * six all-to-alls of a vector per proof.  With "ntt_h" 0 c goes to the coset like a and b (seven), and step 3 takes no c.
  * An all-to-all to D_high is: all_to_all_single of the local array (chunk d = elements [d M, (d+1) M), M = local size / W), then
  * zkpor_shard_transpose_dev(interleave = 1); to D_low: zkpor_shard_transpose_dev(interleave = 0), then all_to_all_single. */
 int32_t zkpor_compute_h_shard_dev(zkpor_ctx* ctx, int log2_domain, int world_log2, int rank, void* d_a, void* d_b, void* d_c,
