@@ -191,7 +191,7 @@ def test_six_transforms_give_the_seven_transform_h_for_any_c(zk, log2d, valid):
     finally:
         zk.set_param("ntt_h", 1)
     assert np.array_equal(six, seven)
-    if log2d <= 17:
+    if log2d <= 10:      # (the plain oracle takes 10 s at 2^12, 15 s at 2^17; the seven-transform schedule is pinned to it at those sizes by the tests above)
         assert np.array_equal(six, O.compute_h(a, b, c, log2d))
     # in place on the device with preserved inputs is what the prove tail runs: tests/test_groth16_gpu.py (proofs bit-exact with the oracle under both schedules)
 
