@@ -918,6 +918,22 @@ def witness_gen_leg(ctx, users=1380, tier=50, n_wires=1 << 26):
                     "host executor's (host/solver_exec.hpp); gnark's wire map cannot be produced in this image (go/export_solver is source only)"}
 
 
+def go_toolchain_probe():
+    """the north-star acceptance (the UNMODIFIED verifier over emitted proofs, go/README.md) needs Go + the two pinned modules on the box: probed on every
+    run so that the line says whether it could have been run (profiles/r06_go_probe.txt: absent on this pool)"""
+    import shutil
+    import subprocess
+    go = shutil.which("go")
+    out = {"go": go, "version": None, "module_cache": os.path.isdir(os.path.expanduser("~/go/pkg/mod"))}
+    if go:
+        try:
+            out["version"] = subprocess.run([go, "version"], capture_output=True, text=True, timeout=20).stdout.strip()
+        except Exception as e:      # noqa: BLE001 — informational
+            out["version"] = f"failed: {e}"
+    out["note"] = ("present: run go/README.md's list" if go else "absent: gnark cannot run here; acceptance = the oracle's pairing verifier on a small real circuit (`acceptance`) + the trapdoor check of every timed proof (`checked`)")
+    return out
+
+
 def verifier_acceptance(ctx, n_proofs=4):
     """BASELINE.json's metric asks for 100 % verifier acceptance beside the rate.  The 2^26 key of the timed region is a
     random-point key (no R1CS behind it), so acceptance is measured on a real (small) circuit of the reference's SHAPE — one BSB22
@@ -2234,6 +2250,7 @@ def main():
                     out["acceptance"] = verifier_acceptance(ctx)
                 except Exception as e:
                     out["acceptance"] = {"proofs": 0, "accepted": 0, "verifier": f"failed: {e}"}
+            out["go_toolchain"] = go_toolchain_probe()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     for wk in workers[1:]:
         wk[0].close()
