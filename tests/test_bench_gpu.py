@@ -50,6 +50,7 @@ def test_bench_line_small_domain():
     g = d["witness_gen"]     # the device generators, measured (40 users at this size), spot-checked against the oracle
     assert g["checked_against_oracle"] is True and g["users_per_batch"] == 40 and g["accounts_per_s"] > 0 and g["wire_slots_generated"] > 40 * 20000 and g["lookup_results"] == 40 * 29 * 50 and g["integer_divisions"] == 40 * 150
     assert d["acceptance"]["accepted"] == d["acceptance"]["proofs"] == 4
+    assert set(d["go_toolchain"]) >= {"go", "version", "module_cache", "note"}      # the probe for the unmodified verifier's toolchain rides in every line
     assert d["solver_budget"]["gpu_ms_per_proof"] == d["ms_per_step"]
     he = d["solver_budget"]["host_executor_measured"]
     assert he["wire_vector_equals_builder"] is True and he["instructions_per_s"]["threads_1"] > 0 and he["hint_calls"] == 6000 * 5

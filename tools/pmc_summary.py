@@ -82,10 +82,12 @@ def main():
         corr = 2.0 if raw < 0.75 * arr else 1.0
         total += raw * corr + wmap.get(did, 0.0)
     if rows:
-        out["ntt_hbm_bytes_per_computeH"] = total
-        out["ntt_launches_per_computeH"] = len(rows)
+        proofs = max(1, sum(1 for _, name, _ in rows if "k_ntt_top29" in name))      # one fused top pass per computeH: the trace may hold several proofs
+        out["ntt_proofs_in_trace"] = proofs
+        out["ntt_hbm_bytes_per_computeH"] = total / proofs
+        out["ntt_launches_per_computeH"] = len(rows) / proofs
         out["ntt_note"] = ("per launch: FETCH_SIZE x 2 when the raw figure is below 3/4 of the array (contiguous tiles of the lowest field are "
-                           "read back at 1/2), x 1 otherwise (strided 64-128 B segments + tabulated twiddles), + WRITE_SIZE; one proof in the trace")
+                           "read back at 1/2), x 1 otherwise (strided 64-128 B segments + tabulated twiddles), + WRITE_SIZE; summed over the trace and divided by its proofs (k_ntt_top29 launches)")
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 
