@@ -131,7 +131,7 @@ int32_t zkpor_trim(zkpor_ctx* ctx);
  * "poseidon_defer" (64, the default: a launch of up to this many 16-lane calls — the challenge sponge, the CEX chains — parks the S-box inputs raw and a
  * wide kernel behind it converts them and writes wires and rows; same bits; 0 = the waves convert as they go),
  * "solver_batch_from" (2^21: levels from this many generic instructions on run four per thread), "solver_chain" (1, the default: runs of
- * one-instruction levels are decoded side by side and executed from registers; 0: the narrow-level kernel), "solver_tree_from" (1 024: levels from this many generic instructions on share one field inversion per workgroup), "solver_beside" (1, the default: a Poseidon call that carries a join level runs on a side stream beside the levels up to it; 0: in place), "solver_long" (256: those levels leave constraints of more terms than this to a wave each; 0 = never), "solver_defer_checks"
+ * one-instruction levels are decoded side by side and executed from registers; 0: the narrow-level kernel), "solver_tree_from" (1 024: levels from this many generic instructions on share one field inversion per workgroup), "solver_beside" (1, the default: a Poseidon call that carries a join level runs on a side stream beside the levels up to it; 0: in place), "solver_pre_join" (1, the default since round 6: the input expressions of such a call are evaluated side by side in front of it; 0: inside the serial kernel, one lane at a time), "solver_long" (256: those levels leave constraints of more terms than this to a wave each; 0 = never), "solver_defer_checks"
  * (1, the default: see zkpor_solver_set_abc_dev; 0: a run executes its CHECK instructions even when a, b, c buffers are set),
  * "poseidon_coop" (-1, the default: account leaves and CEX commitments run 16 lanes per hash chain when a launch has fewer than
  * 65 536 chains; 0 never, 1 always),

@@ -128,11 +128,13 @@ def test_the_long_call_beside_the_independent_levels_changes_no_wire(zk):
     finally:
         cir.close()
     try:
-        for beside in (1, 0):
-            zk.set_param("solver_beside", beside)
+        for beside, pre_join in ((1, 1), (0, 1), (1, 0), (0, 0)):      # "solver_pre_join" (round 6): the sponge's input expressions evaluated in front of it (1, the default) or inside it
+            zk.set_param("solver_beside", beside); zk.set_param("solver_pre_join", pre_join)
             prove_once(zk, (5, 20, 6), 1, reps=2)
+        zk.set_param("solver_pre_join", 1)
+        prove_once(zk, (5, 20, 6), 0)                                   # the one-thread-per-call kernel reads the pre-evaluated inputs too
     finally:
-        zk.set_param("solver_beside", 1)
+        zk.set_param("solver_beside", 1); zk.set_param("solver_pre_join", 1)
 
 
 def test_the_500_asset_tier_shape(zk):

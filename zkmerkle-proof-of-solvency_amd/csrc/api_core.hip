@@ -541,6 +541,7 @@ int32_t zkpor_set_param(zkpor_ctx* ctx, const char* name, int64_t value) try {
     else if (n == "r1cs_order") { if (value < 0 || value > 1) { ctx->err = "r1cs_order must be 0 (natural) or 1 (by row shape)"; return ZKPOR_E_ARG; } ctx->r1cs_order = (int)value; }
     else if (n == "solver_defer_checks") { if (value < 0 || value > 1) { ctx->err = "solver_defer_checks must be 0 or 1"; return ZKPOR_E_ARG; } ctx->solver_defer_checks = (int)value; }
     else if (n == "solver_tree_from") { if (value < 1) { ctx->err = "solver_tree_from must be positive"; return ZKPOR_E_ARG; } ctx->solver_tree_from = value; }
+    else if (n == "solver_pre_join") { if (value < 0 || value > 1) { ctx->err = "solver_pre_join must be 0 or 1"; return ZKPOR_E_ARG; } ctx->solver_pre_join = (int)value; }
     else if (n == "solver_beside") { if (value < 0 || value > 1) { ctx->err = "solver_beside must be 0 or 1"; return ZKPOR_E_ARG; } ctx->solver_beside = (int)value; }
     else if (n == "solver_long") { if (value < 0 || value > (1 << 30)) { ctx->err = "solver_long must be 0 (off) or a term count"; return ZKPOR_E_ARG; } ctx->solver_long = (int)value; }
     else if (n == "solver_chain") { if (value < 0 || value > 1) { ctx->err = "solver_chain must be 0 or 1"; return ZKPOR_E_ARG; } ctx->solver_chain = (int)value; }

@@ -76,6 +76,7 @@ struct zkpor_ctx {
     int solver_defer_checks = 1;     // with zkpor_solver_set_abc_dev: the run leaves its CHECK instructions (assertions) out and zkpor_solver_eval_abc_dev verifies a x b = c on EVERY row; 0 = the run executes them
     int64_t solver_tree_from = 1024; // levels from this many generic instructions on: the divisions of a workgroup share one inversion, long constraints go to k_solve_long
     int solver_beside = 1;           // Poseidon calls with a join level run on a side stream beside the levels up to it; 0 = in place, as ordinary calls
+    int solver_pre_join = 1;         // the inputs of a Poseidon call with a join level (the challenge sponge: 1 392 expressions) are evaluated side by side in front of the serial kernel (solver.hip k_hint_inputs), as the ASYNC calls' always were; 0 = inside it, one lane at a time
     int solver_long = 256;           // wide levels hand constraints of more terms than this to a wave each (k_solve_long); 0 = every instruction in its own thread
     int solver_chain = 1;            // runs of one-instruction levels in k_solve_chain (decoded side by side, values handed on in registers); 0 = the narrow kernel
     int64_t solver_batch_from = 1 << 21;  // levels from this many generic instructions on run 4 per thread with ONE inversion per thread (solver.hip)

@@ -37,6 +37,7 @@ struct LevelPlan {          // one level of the reordered instruction list: [gen
     uint32_t n_chk = 0;                          // CHECK instructions (assertions), listed right behind the generic ones: left out when the caller checks every row itself
     uint32_t n_gen = 0, n_pos = 0, n_posa = 0, n_cnt = 0, cnt_first = 0;   // the level's count hints are counts[cnt_first .. + n_cnt)
     uint32_t posa_first = 0;                                               // its ASYNC calls are asyncs[posa_first .. + n_posa), in list order
+    uint32_t posj_first = 0;                                               // its calls with a join level are joins[posj_first .. + n_posj)
     uint64_t cnt_rows = 0, cnt_queries = 0;                                // table rows / queries of all its count hints
     bool external = false;
 };
@@ -57,6 +58,8 @@ struct zkpor_solver {
     std::vector<BigHint> counts;                // in level order (the order the levels meet them)
     std::vector<BigHint> asyncs;                // the ASYNC Poseidon calls, in level order; nb_q = first element of the call's inputs in d_pre
     uint32_t* d_pre_off = nullptr;              // per ASYNC call (same order): that first element
+    std::vector<BigHint> joins;                 // the Poseidon calls with a join level (the challenge sponge), in level order: their inputs are pre-evaluated the same way ("solver_pre_join")
+    uint32_t* d_prej_off = nullptr;             // per such call: the first element of its inputs in d_pre
     zk::Fr* d_pre = nullptr;                    // their inputs, evaluated all at once in front of the (serial) sponge
     std::map<uint32_t, BigHint> externals;      // by instruction
     uint32_t *d_kind = nullptr, *d_arg = nullptr, *d_level_instr = nullptr, *d_calldata = nullptr, *d_gen_cnt = nullptr, *d_offs = nullptr;
@@ -520,7 +523,7 @@ static SolverProg prog_of(const zkpor_solver* s) {
     return P;
 }
 static void solver_free(zkpor_solver* s) {
-    void* ptrs[] = {s->d_rows, s->d_perr, s->d_ones, s->d_cmeta, s->d_pre_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_gen_cnt_all, s->d_long, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
+    void* ptrs[] = {s->d_rows, s->d_perr, s->d_ones, s->d_cmeta, s->d_pre_off, s->d_prej_off, s->d_pre, s->d_kind, s->d_arg, s->d_level_instr, s->d_calldata, s->d_gen_cnt, s->d_gen_cnt_all, s->d_long, s->d_offs, s->d_gen_lo, s->d_hint_kind, s->d_known, s->d_err, s->d_ext,
                     s->d_cnt, s->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     // side streams with hardware queues of their own go back to the pool (common.cuh stream_release_own_queue), ordinary ones to the runtime
@@ -642,12 +645,21 @@ static int32_t solver_advance(zkpor_solver* s, uint32_t* paused_instr) {
             }
             if (L.n_posj) {   // calls other levels run beside (the RLC challenge's 116-permutation sponge): on their own side stream, joined in front of their first consumer
                 const u32* lst = s->d_level_instr + L.lo + L.n_gen + L.n_chk + L.n_pos + L.n_posa;
-                if (ctx->solver_beside && !s->side2_busy) {
+                const bool beside = ctx->solver_beside && !s->side2_busy;
+                const hipStream_t js = beside ? s->side2 : ctx->stream;
+                if (beside) {
                     ZK_HIP(ctx, hipEventRecord(s->ev_fork2, ctx->stream));
                     ZK_HIP(ctx, hipStreamWaitEvent(s->side2, s->ev_fork2, 0));
-                    ZK_TRY(gadget_poseidon_launch(ctx, s->side2, P, lst, L.n_posj, w, s->known, s->d_err, nullptr, nullptr, nullptr, nullptr, nullptr));
-                    s->side2_busy = true; s->join2_level = L.join_level;
-                } else ZK_TRY(gadget_poseidon_launch(ctx, ctx->stream, P, lst, L.n_posj, w, s->known, s->d_err, nullptr, nullptr, nullptr, nullptr, nullptr));   // in place: an ordinary call
+                }
+                // "solver_pre_join" (round 6): the sponge's 1 392 input expressions (14 to 79 terms each) side by side first — inside the serial kernel the one lane
+                // that holds input i evaluates it while the other lanes wait: 12 expressions in a row per permutation, 0.14 of the 0.36 ms a permutation took
+                const bool pre = ctx->solver_pre_join != 0;
+                if (pre) for (u32 k = 0; k < L.n_posj; ++k) {
+                    const BigHint& a = s->joins[L.posj_first + k];
+                    hipLaunchKernelGGL(k_hint_inputs, dim3((a.n_in + 255u) / 256u), dim3(256), 0, js, P, a.ins, s->d_offs + a.offs_base, a.n_in, (const Fr*)w, s->known, s->d_pre + a.nb_q, s->d_err);
+                }
+                ZK_TRY(gadget_poseidon_launch(ctx, js, P, lst, L.n_posj, w, s->known, s->d_err, pre ? s->d_pre : nullptr, pre ? s->d_prej_off + L.posj_first : nullptr, nullptr, nullptr, nullptr));
+                if (beside) { s->side2_busy = true; s->join2_level = L.join_level; }
                 ++s->launches;
             }
             if ((int64_t)ng >= ctx->solver_tree_from) {
@@ -843,14 +855,14 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
                     }
                 }
             }
-            if (cls[i] == CL_POSA) {
+            if (cls[i] == CL_POSA || cls[i] == CL_POSJ) {     // long serial calls: their inputs are evaluated side by side in front of them (k_hint_inputs)
                 BigHint b;
                 b.ins = (uint32_t)i; b.n_in = v.calldata[arg]; b.offs_base = offs.size(); b.nb_q = pre_total;
                 uint64_t p = zkpor_host::POSEIDON_HDR;
                 for (uint32_t k = 0; k < b.n_in; ++k) {
                     offs.push_back((uint32_t)p);
                     const uint64_t nt = v.calldata[arg + p];
-                    for (uint64_t t = 0; t < nt; ++t) s->async_max_wire = std::max<uint64_t>(s->async_max_wire, v.calldata[arg + p + 2 + 2 * t]);   // a prefetch reads these from the bare assignment
+                    if (cls[i] == CL_POSA) for (uint64_t t = 0; t < nt; ++t) s->async_max_wire = std::max<uint64_t>(s->async_max_wire, v.calldata[arg + p + 2 + 2 * t]);   // a prefetch reads these from the bare assignment
                     p += 1 + 2 * nt;
                 }
                 pre_total += b.n_in;
@@ -892,7 +904,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     const uint64_t n_li = v.level_ptr[v.n_levels];
     std::vector<uint32_t> li(n_li), gen_cnt(v.n_levels), gen_cnt_all(v.n_levels);
     std::vector<uint64_t> gen_lo(v.n_levels);
-    std::vector<uint32_t> pre_off_host;
+    std::vector<uint32_t> pre_off_host, prej_off_host;
     std::vector<CountDev> cmeta;
     s->plan.resize(v.n_levels);
     for (uint64_t l = 0; l < v.n_levels; ++l) {
@@ -909,12 +921,13 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
                 if (c == CL_CNT) s->counts.push_back(big[ins]);
                 if (c == CL_POSA) { s->asyncs.push_back(big[ins]); pre_off_host.push_back((uint32_t)big[ins].nb_q); }
                 if (c == CL_POSJ) {
+                    s->joins.push_back(big[ins]); prej_off_host.push_back((uint32_t)big[ins].nb_q);
                     const uint64_t j = (uint64_t)(v.calldata[v.arg[ins] + 3] >> zkpor_host::POSEIDON_JOIN_SHIFT) - 1;
                     if (j <= l || j >= v.n_levels) return bad("Poseidon instruction " + std::to_string(ins) + " names a join level outside (its own level, the last level]");
                     L.join_level = L.n_posj_seen++ ? std::min(L.join_level, j) : j;
                 }
             }
-            if (c == CL_GEN) L.n_gen = n; else if (c == CL_CHK) L.n_chk = n; else if (c == CL_POS) L.n_pos = n; else if (c == CL_POSA) { L.n_posa = n; L.posa_first = (uint32_t)(s->asyncs.size() - n); } else if (c == CL_POSJ) L.n_posj = n; else { L.n_cnt = n; L.cnt_first = (uint32_t)(s->counts.size() - n); }
+            if (c == CL_GEN) L.n_gen = n; else if (c == CL_CHK) L.n_chk = n; else if (c == CL_POS) L.n_pos = n; else if (c == CL_POSA) { L.n_posa = n; L.posa_first = (uint32_t)(s->asyncs.size() - n); } else if (c == CL_POSJ) { L.n_posj = n; L.posj_first = (uint32_t)(s->joins.size() - n); } else { L.n_cnt = n; L.cnt_first = (uint32_t)(s->counts.size() - n); }
         }
         for (uint32_t k = 0; k < L.n_cnt; ++k) {
             const BigHint& c = s->counts[L.cnt_first + k];
@@ -938,7 +951,7 @@ int32_t zkpor_solver_create_on(zkpor_ctx* ctx, zkpor_r1cs* r1cs, const uint8_t* 
     bool ok = up((void**)&s->d_kind, kinds.data(), v.n_instructions * 4) && up((void**)&s->d_arg, v.arg, v.n_instructions * 4) &&
               up((void**)&s->d_level_instr, li.data(), n_li * 4) && up((void**)&s->d_calldata, v.calldata, v.n_calldata * 4) &&
               up((void**)&s->d_gen_lo, gen_lo.data(), v.n_levels * 8) && up((void**)&s->d_gen_cnt, gen_cnt.data(), v.n_levels * 4) && up((void**)&s->d_gen_cnt_all, gen_cnt_all.data(), v.n_levels * 4) &&
-              up((void**)&s->d_rows, row_bits.data(), row_bits.size() * 4) && up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up(&s->d_cmeta, cmeta.data(), cmeta.size() * sizeof(CountDev)) && up((void**)&s->d_pre_off, pre_off_host.data(), pre_off_host.size() * 4) &&
+              up((void**)&s->d_rows, row_bits.data(), row_bits.size() * 4) && up((void**)&s->d_offs, offs.data(), offs.size() * 4) && up(&s->d_cmeta, cmeta.data(), cmeta.size() * sizeof(CountDev)) && up((void**)&s->d_pre_off, pre_off_host.data(), pre_off_host.size() * 4) && up((void**)&s->d_prej_off, prej_off_host.data(), prej_off_host.size() * 4) &&
               hipMalloc((void**)&s->d_pre, (pre_total ? pre_total : 1) * sizeof(Fr)) == hipSuccess && up((void**)&s->d_hint_kind, s->hint_kind.data(), s->hint_kind.size()) &&
               hipMalloc((void**)&s->d_known, nw) == hipSuccess && hipMalloc((void**)&s->d_err, 32) == hipSuccess && hipMalloc((void**)&s->d_long, (size_t)(LONG_CAP + 1u) * 4) == hipSuccess &&
               hipMalloc((void**)&s->d_ext, (size_t)(s->ext_cap = (u32)std::max<size_t>(EXT_CAP, s->externals.size() + 1)) * sizeof(u32)) == hipSuccess && hipMalloc((void**)&s->d_cnt, max_table * sizeof(u32)) == hipSuccess &&
