@@ -90,6 +90,37 @@ def test_ntt_model_matches_naive_dft():
     assert M.fft(O.fr_to_ints(a), n, False, True, True) == O.fr_to_ints(O.fft(a, n, False, O.DIF, True))
 
 
+def test_six_transforms_are_gnarks_seven_in_python_integers():
+    """csrc/ntt.hip compute_h_dev ("ntt_h" 1, round 6): h = icFFT(den a_c b_c) - den c with c = the COEFFICIENTS of c, six transforms — against gnark's
+    computeH as written (seven: a, b, c to coefficients, the three to the coset, (a b - c) den there, back), on the index model with Python integers, for a c
+    that satisfies a b = c on the domain and for a random one (the rearrangement is linearity of the last transform, nothing else), and the oracle's
+    own computeH (oracle.compute_h, the restatement the device is compared with) agrees with both"""
+    import random
+    import ntt_model as M
+    random.seed(11)
+    for n, kl, km in [(5, 2, 2), (6, 2, 3)]:
+        N = 1 << n
+        den = pow((pow(M.G, N, M.R) - 1) % M.R, M.R - 2, M.R)
+        for valid in (True, False):
+            a = [random.randrange(M.R) for _ in range(N)]; b = [random.randrange(M.R) for _ in range(N)]
+            c = [x * y % M.R for x, y in zip(a, b)] if valid else [random.randrange(M.R) for _ in range(N)]
+            coef = {k: M.fft(v, n, True, True, False, kl, km) for k, v in (("a", a), ("b", b), ("c", c))}        # inverse DIF: bit-reversed coefficients
+            cos = {k: M.fft(v, n, False, False, True, kl, km) for k, v in coef.items()}                           # forward DIT on the coset: natural order
+            seven = M.fft([(x * y - z) * den % M.R for x, y, z in zip(cos["a"], cos["b"], cos["c"])], n, True, True, True, kl, km)
+            six = [(u - den * z) % M.R for u, z in zip(M.fft([x * y * den % M.R for x, y in zip(cos["a"], cos["b"])], n, True, True, True, kl, km), coef["c"])]
+            assert six == seven
+            if valid:       # the quotient is a polynomial of degree < N - 1: the top coefficient (index N - 1, position rev(N - 1) = N - 1) is zero
+                assert six[N - 1] == 0
+    n = 6
+    a = O.fr_random(21, 1 << n); b = O.fr_random(22, 1 << n); c = O.fr_random(23, 1 << n)
+    A, B, C = (O.fr_to_ints(v) for v in (a, b, c))
+    den = pow((pow(M.G, 1 << n, M.R) - 1) % M.R, M.R - 2, M.R)
+    coefc = M.fft(C, n, True, True, False)
+    ac = M.fft(M.fft(A, n, True, True, False), n, False, False, True); bc = M.fft(M.fft(B, n, True, True, False), n, False, False, True)
+    six = [(u - den * z) % M.R for u, z in zip(M.fft([x * y * den % M.R for x, y in zip(ac, bc)], n, True, True, True), coefc)]
+    assert six == O.fr_to_ints(O.compute_h(a, b, c, n))
+
+
 def test_sharded_ntt_model_matches_the_unsharded_passes():
     """tools/ntt_model.py fft_sharded: the index algebra of csrc/ntt.hip ntt_shard_stage (two distributions, one all-to-all per
     transform, global positions only in the twiddle / scale exponents) reproduces the unsharded transform exactly"""
