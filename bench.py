@@ -1902,7 +1902,9 @@ def main():
         last_w = E.wk[0]["last"]
         e2e["constraints_failing_on_device"] = dc.r1cs.check_dev(last_w.data_ptr())[0]
         if not args.timed_only:
-            sub = max(3, args.steps // 4) if args.e2e_steps < 0 else args.e2e_steps
+            # as many proofs as the headline region: with two workers a region pays one un-overlapped solve at its start, and over steps // 4 proofs (five, an odd
+            # number, in the driver's command) that alone read as +15 ms per proof — the figure is meant to show what the UPLOAD costs (round 6)
+            sub = args.steps if args.e2e_steps < 0 else args.e2e_steps
             if sub > 0:
                 # the same region with the assigned inputs coming from pageable HOST memory for every proof (129 MB for zkpor50_1380): what a prover
                 # holding a decoded witness row pays; `value` keeps the inputs resident (the bench contract), this is the PCIe-inclusive rate
