@@ -66,10 +66,11 @@ enum { ZKPOR_Z_ORDER_BITREV = 0, ZKPOR_Z_ORDER_NATURAL = 1 };
 
 /* ---- ABI version -------------------------------------------------------------------------------------- */
 /* Bumped whenever an existing entry point changes its signature or meaning (3: z_order joined the zkpor_pk_load_gnark* family in
- * the middle of their argument lists).  A binding compiled or written against another value must refuse to run: a stale ctypes /
+ * the middle of their argument lists; 4: zkpor_compute_h_shard_dev under the default "ntt_h" 1 — c is not exchanged after step 1 and
+ * step 3 takes it).  A binding compiled or written against another value must refuse to run: a stale ctypes /
  * cgo caller would otherwise pass arguments in the old positions and nothing would notice at load time.  zkpor.py and
  * go/zkporgpu check it when the library is loaded. */
-#define ZKPOR_ABI_VERSION 3u
+#define ZKPOR_ABI_VERSION 4u
 uint32_t zkpor_abi_version(void);
 
 /* ---- context ------------------------------------------------------------------------------------------- */

@@ -22,7 +22,7 @@ class ZkporError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 3   # include/zkpor.h ZKPOR_ABI_VERSION
+ABI_VERSION = 4   # include/zkpor.h ZKPOR_ABI_VERSION
 
 
 def load_library():
