@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — Groth16 proofs/sec of the MI355X prove tail at the zkpor50_1380 shape (BASELINE.json metric).
+"""bench.py — Groth16 proofs/sec at the zkpor50_1380 shape on MI355X (BASELINE.json metric).
 
-A "step" is ONE proof: computeH (gnark's 7 NTTs of 2^log2, run as 6: DESIGN.md 6d) + the A/B1/K/Z G1 and B2 G2 multi-exponentiations + the two
-Pedersen commitment MSMs (2^(log2-2) points), on synthetic inputs already resident in HBM (witness-like scalar
-mixture for w, uniform a,b with c = a.b).  One process per GPU; with N > 1 each rank proves its
-own independent batches (weak scaling, no data-path collective — witness batches are independent proofs).
+Default (circuit mode, since round 5): a "step" is ONE `groth16.Prove` END TO END on the compiled BatchCreateUserCircuit — assigned inputs (resident in HBM) ->
+solver program on the device -> BSB22 commitment -> a, b, c -> computeH (gnark's 7 NTTs of 2^26, run as 6: DESIGN.md 6d) + the A / B1 / K / Z G1 and B2 G2
+multi-exponentiations + blinding — two worker contexts per GPU (one proof's solve beside the other's prove tail), exactly --steps timed proofs after
+--warmup.  `--no-circuit` is the round-1..3 workload (prove tail only, D = n_wires = 2^log2, estimated scalar mixture).  One process per GPU; with N > 1 each
+rank proves its own independent batches (weak scaling, no data-path collective — witness batches are independent proofs).
 
 Output: ONE JSON line (rank 0) with value = proofs/s over all ranks, plus
   roofline     — the dominant kernel (G1 bucket accumulation k_acc_level1_fp29): algorithmic bytes per launch
-                 (n x (64 B point + 32 B scalar)) / its average launch time, vs the 8 TB/s HBM peak
-  cpu_baseline — the CPU oracle (a port of the reference's algorithm) timed on a bounded sample, scaled to proofs/s
-  checked      — every timed proof verified in the exponent from the synthetic key's trapdoor (untimed)
-  value_uniform — the same step with uniform witness scalars (the worst case), timed in a second region
+                 (n x (64 B point + 32 B scalar)) / its average launch time (HIP events, live), vs the 8 TB/s HBM peak; traffic, VALU issue
+                 and clock from the latest profile set under profiles/
+  cpu_baseline — the CPU oracle (a port of the reference's algorithm) timed on a bounded sample, scaled to proofs/s, + the full solver program on the host executor
+  checked      — every timed proof of every region verified in the exponent from the synthetic key's trapdoor, h from its definition (untimed)
+  end_to_end   — the headline region and its siblings: with_input_upload (the inputs from pageable host memory per proof), one_proof_at_a_time
+  prove_tail, value_uniform, two_in_flight, configs.zkpor500_200 — the tail alone, uniform witness scalars (worst case), two tails in flight, the other tier
   boundary     — the host-pointer ABI a cgo caller binds, from pageable host memory (untimed leg, N = 1)
   r1cs_resident — the same with the constraint matrices resident in HBM: only w crosses PCIe (zkpor_prove_r1cs; opt-in: --r1cs-terms 20)
+  go_toolchain — whether the box could have run the reference's own verifier (go/README.md)
 """
 import argparse
 import ctypes
